@@ -1,0 +1,148 @@
+"""Functional CPU restatement of the SW_Transformer backbone (test infrastructure; see oracle/__init__.py).
+
+State dict in (reference key names), tensors out.  Dropout / DropPath are identity here: the parity boundary is
+evaluated with every stochastic rate forced to 0 (train) or in eval mode; their statistics are
+tested separately on the HIP path.
+"""
+import torch
+import torch.nn.functional as F
+
+from .config import block_window_and_shift, swt_geometry
+
+
+def relative_position_index(wh, ww):
+    """[wh*ww, wh*ww] int64 index into the (2wh-1)(2ww-1) bias table.  models/SwinModules.py:101-111."""
+    ys, xs = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
+    pts = torch.stack([ys.reshape(-1), xs.reshape(-1)], 0)  # 2, N
+    rel = pts[:, :, None] - pts[:, None, :]  # 2, N, N
+    return (rel[0] + wh - 1) * (2 * ww - 1) + (rel[1] + ww - 1)
+
+
+def shifted_window_mask(H, W, wh, ww, sh, sw):
+    """[nW, N, N] additive mask, -100 between tokens of different wrap-around regions.  SwinModules.py:262-289."""
+    region = torch.zeros(H, W)
+    cnt = 0
+    for hs in (slice(0, -wh), slice(-wh, -sh), slice(-sh, None)):
+        for ws in (slice(0, -ww), slice(-ww, -sw), slice(-sw, None)):
+            region[hs, ws] = cnt
+            cnt += 1
+    win = region.view(H // wh, wh, W // ww, ww).permute(0, 2, 1, 3).reshape(-1, wh * ww)
+    diff = win[:, None, :] - win[:, :, None]
+    return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
+
+
+def _to_windows(x, wh, ww):
+    # [B, H, W, C] -> [B*nW, wh*ww, C]; SwinModules.py:37-52
+    B, H, W, C = x.shape
+    x = x.view(B, H // wh, wh, W // ww, ww, C).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(-1, wh * ww, C)
+
+
+def _from_windows(w, wh, ww, H, W):
+    # inverse of _to_windows; SwinModules.py:55-70
+    C = w.shape[-1]
+    B = w.shape[0] // ((H // wh) * (W // ww))
+    x = w.view(B, H // wh, W // ww, wh, ww, C).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(B, H, W, C)
+
+
+def window_attention(P, pre, xw, heads, wh, ww, mask):
+    """WindowAttention.forward, SwinModules.py:121-152 (dropouts are identity)."""
+    Bw, N, C = xw.shape
+    hd = C // heads
+    qkv = F.linear(xw, P[f"{pre}.qkv.weight"], P[f"{pre}.qkv.bias"]).view(Bw, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    table = P[f"{pre}.relative_position_bias_table"]
+    bias = table[relative_position_index(wh, ww).reshape(-1)].view(N, N, heads).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.view(Bw // nW, nW, heads, N, N) + mask.to(attn.dtype)[None, :, None]).view(-1, heads, N, N)
+    attn = attn.softmax(-1)
+    out = (attn @ v).transpose(1, 2).reshape(Bw, N, C)
+    return F.linear(out, P[f"{pre}.proj.weight"], P[f"{pre}.proj.bias"])
+
+
+def swin_block(P, pre, x, H, W, heads, window, block_idx, taps=None):
+    """SwinTransformerBlock.forward, SwinModules.py:294-343."""
+    B, L, C = x.shape
+    wh, ww, sh, sw, shifted = block_window_and_shift(H, W, window, block_idx)
+    y = F.layer_norm(x, (C,), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], 1e-5).view(B, H, W, C)
+    mask = None
+    if shifted:
+        y = torch.roll(y, shifts=(-sh, -sw), dims=(1, 2))
+        mask = shifted_window_mask(H, W, wh, ww, sh, sw)
+    aw = window_attention(P, f"{pre}.attn", _to_windows(y, wh, ww), heads, wh, ww, mask)
+    y = _from_windows(aw, wh, ww, H, W)
+    if shifted:
+        y = torch.roll(y, shifts=(sh, sw), dims=(1, 2))
+    x = x + y.reshape(B, L, C)
+    z = F.layer_norm(x, (C,), P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], 1e-5)
+    z = F.linear(z, P[f"{pre}.mlp.fc1.weight"], P[f"{pre}.mlp.fc1.bias"])
+    z = F.gelu(z)  # exact erf form, SwinModules.py:19
+    z = F.linear(z, P[f"{pre}.mlp.fc2.weight"], P[f"{pre}.mlp.fc2.bias"])
+    return x + z
+
+
+def patch_merging(P, pre, x, H, W):
+    """PatchMerging.forward, SwinModules.py:378-402: 2x2 gather (order x00,x10,x01,x11) -> LN(4C) -> Linear."""
+    B, L, C = x.shape
+    x = x.view(B, H, W, C)
+    x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).view(B, -1, 4 * C)
+    x = F.layer_norm(x, (4 * C,), P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-5)
+    return F.linear(x, P[f"{pre}.reduction.weight"])
+
+
+def pad_and_embed(P, cfg, x, loc, mod):
+    """SW_Transformer.pad_input (:184-208) + PatchEmbed.forward (SwinModules.py:547-558) -> [B, Hp*Wp, C0]."""
+    g = swt_geometry(cfg, loc, mod)
+    st = g["stride"]
+    b, c, i, s = x.shape
+    x = x.permute(0, 2, 3, 1).reshape(b, i, s // st, c * st).permute(0, 3, 1, 2)
+    x = F.pad(x, (0, g["pad_img"][1] - g["img"][1], 0, g["pad_img"][0] - g["img"][0]))
+    pre = f"patch_embed.{loc}.{mod}"
+    x = F.conv2d(x, P[f"{pre}.proj.weight"], P[f"{pre}.proj.bias"], stride=tuple(g["patch"]))
+    x = x.flatten(2).transpose(1, 2)
+    c0 = x.shape[-1]
+    return F.layer_norm(x, (c0,), P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-5)
+
+
+def swt_forward(P, cfg, freq_x, proj_head=True, taps=None):
+    """SW_Transformer.forward(freq_x, class_head=False, proj_head=...), SW_Transformer.py:210-304.
+
+    Returns {mod: [B, emb]} in `modality_names` order.  `taps`, if a dict, receives intermediate activations
+    keyed by "<loc>.<mod>.<stage point>" for layer-by-layer parity checks.
+    """
+    sw = cfg["SW_Transformer"]
+    assert len(cfg["location_names"]) == 1
+    loc = cfg["location_names"][0]
+    feats = {}
+    for mod in cfg["modality_names"]:
+        g = swt_geometry(cfg, loc, mod)
+        x = pad_and_embed(P, cfg, freq_x[loc][mod], loc, mod)
+        if taps is not None:
+            taps[f"{loc}.{mod}.embed"] = x
+        if sw["APE"]:
+            x = x + P[f"absolute_pos_embed.{loc}.{mod}"]
+        for si, st in enumerate(g["stages"]):
+            for bi in range(st["depth"]):
+                x = swin_block(P, f"freq_interval_layers.{loc}.{mod}.{si}.blocks.{bi}", x, st["H"], st["W"],
+                               g["heads"], g["window"], bi)
+                if taps is not None:
+                    taps[f"{loc}.{mod}.s{si}b{bi}"] = x
+            if st["downsample"]:
+                x = patch_merging(P, f"freq_interval_layers.{loc}.{mod}.{si}.downsample", x, st["H"], st["W"])
+                if taps is not None:
+                    taps[f"{loc}.{mod}.merge{si}"] = x
+        x = F.linear(x.reshape(x.shape[0], -1), P[f"mod_in_layers.{loc}.{mod}.weight"], P[f"mod_in_layers.{loc}.{mod}.bias"])
+        if taps is not None:
+            taps[f"{loc}.{mod}.feat"] = x
+        feats[mod] = x
+    if not proj_head:
+        return feats
+    out = {}
+    for mod in cfg["modality_names"]:
+        h = F.relu(F.linear(feats[mod], P[f"mod_projectors.{mod}.0.weight"], P[f"mod_projectors.{mod}.0.bias"]))
+        out[mod] = F.linear(h, P[f"mod_projectors.{mod}.2.weight"], P[f"mod_projectors.{mod}.2.bias"])
+    return out
