@@ -1,0 +1,110 @@
+"""ctypes binding of libfocal_hip.so (the C ABI declared in include/focal_hip.h).
+
+There is no CPU fallback: if the library is missing, `load()` raises, and every op in `focal_amd.ops` goes through
+`load()`.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C focal_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfocal_hip.so")
+
+FOCAL_F32, FOCAL_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU_OUT = 0, 1, 2
+EPI_NONE, EPI_RESIDUAL, EPI_RELU = 0, 1, 2
+ABI_VERSION = 1
+
+
+class DropDesc(C.Structure):
+    _fields_ = [("rng", C.c_void_p), ("stream_elem", C.c_uint32), ("p_elem", C.c_float),
+                ("stream_path", C.c_uint32), ("p_path", C.c_float), ("rows_per_sample", C.c_int)]
+
+
+class FFTDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "C", "I", "n", "n1", "n2")]
+
+
+class EmbedDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "cin", "I", "S", "Hp", "Wp", "pw", "C0")] + [("eps", C.c_float)]
+
+
+class LNDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("rows", C.c_int), ("C", C.c_int), ("eps", C.c_float), ("gather", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int)]
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("x_dtype", C.c_int),
+                ("y_dtype", C.c_int), ("act_in", C.c_int), ("epilogue", C.c_int), ("splits", C.c_int),
+                ("in_drop", DropDesc), ("out_drop", DropDesc)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("heads", C.c_int),
+                ("wh", C.c_int), ("ww", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("p_attn", C.c_float),
+                ("rng", C.c_void_p), ("stream", C.c_uint32)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("n_mod", C.c_int), ("B", C.c_int), ("dim", C.c_int), ("seq", C.c_int), ("temperature", C.c_float),
+                ("margin", C.c_float), ("w_shared", C.c_float), ("w_private", C.c_float), ("w_orth", C.c_float),
+                ("w_rank", C.c_float), ("no_private", C.c_int)]
+
+
+class AdamWDesc(C.Structure):
+    _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+
+
+P = C.c_void_p
+# name -> (restype, argtypes); every symbol include/focal_hip.h declares
+PROTOTYPES = {
+    "focal_abi_version": (C.c_int, []),
+    "focal_last_error": (C.c_char_p, []),
+    "focal_rng_advance": (C.c_int, [P, P]),
+    "focal_fft_realpack_fwd": (C.c_int, [C.POINTER(FFTDesc), P, P, P, P]),
+    "focal_pad_patch_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P]),
+    "focal_layernorm_fwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, P]),
+    "focal_layernorm_bwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, C.c_int, P, P, P]),
+    "focal_linear_fwd": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P]),
+    "focal_linear_bwd_data": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
+    "focal_linear_bwd_weight": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
+    "focal_window_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P]),
+    "focal_window_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P]),
+    "focal_loss_head_workspace": (C.c_size_t, [C.POINTER(LossDesc)]),
+    "focal_loss_head": (C.c_int, [C.POINTER(LossDesc), C.POINTER(P), P, C.POINTER(P), P, C.c_size_t, P]),
+    "focal_adamw_multi": (C.c_int, [C.POINTER(AdamWDesc), C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P),
+                                    C.POINTER(P), C.POINTER(P), C.POINTER(C.c_long), P, P, P]),
+    "focal_cast_bf16": (C.c_int, [P, P, C.c_long, P]),
+}
+
+_lib = None
+
+
+class FocalHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libfocal_hip.so once; raise (never fall back) if it is absent or its ABI does not match."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FocalHipError(
+            f"{LIB_PATH} not found: the FOCAL hot path has no CPU fallback. Build it with "
+            "`make -C focal_amd/csrc` (needs hipcc, cross-compiles without a GPU).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.focal_abi_version() != ABI_VERSION:
+        raise FocalHipError(f"libfocal_hip ABI {lib.focal_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().focal_last_error()
+        raise FocalHipError(f"libfocal_hip error {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,70 @@
+"""Shared plumbing of the two backbones: arena ownership, operand dtype, autograd glue."""
+import torch
+import torch.nn as nn
+
+from . import runtime
+from .arena import ParamArena
+
+DEAD_PREFIXES = ("patch_embed.", "class_layer.", "mod_fusion_layers.", "absolute_pos_embed.", "mod_extractors.",
+                 "loc_fusion_layers.", "loc_context_layers.", "loc_fusion_layer.")
+
+
+def is_hot(name):
+    """Parameters that receive a gradient in FOCAL pretraining."""
+    return not name.startswith(DEAD_PREFIXES)
+
+
+class HipBackbone(nn.Module):
+    def _init_hip(self, args):
+        self.compute_dtype = runtime.compute_dtype_from(args)
+        self._arena = None
+        self._named = None
+        self._fwd_calls = 0
+        self.register_load_state_dict_post_hook(lambda module, keys: module._after_load())
+
+    def _after_load(self):
+        if self._arena is not None and self._arena.intact():
+            self._arena.sync_shadow(force=True)
+
+    def arena(self):
+        if self._arena is None or not self._arena.intact():
+            self._arena = ParamArena(self, is_hot, self.compute_dtype)
+            self._named = None
+        self._arena.sync_shadow()
+        return self._arena
+
+    def param(self, name):
+        if self._named is None:
+            self._named = dict(self.named_parameters())
+        return self._named[name]
+
+    def rng_state(self):
+        return runtime.rng_state(next(self.parameters()).device)
+
+    def _anchor(self, device):
+        # torch.autograd only schedules a node whose inputs need grad; parameter gradients are written straight into
+        # the arena by the HIP kernels, so a dummy differentiable input keeps each encoder node alive.
+        return torch.zeros(1, device=device, requires_grad=True)
+
+
+class StageFn(torch.autograd.Function):
+    """One autograd node around an engine object exposing forward(x, ...)->(y, saved) / backward(saved, dy)->dx|None."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, engine, args):
+        y, saved = engine.forward(x, *args)
+        ctx.engine, ctx.saved = engine, saved
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = ctx.engine.backward(ctx.saved, dy.contiguous())
+        ctx.saved = None
+        return None, dx, None, None
+
+
+def run_stage(backbone, engine, x, *args):
+    if torch.is_grad_enabled():
+        return StageFn.apply(backbone._anchor(x.device), x, engine, args)
+    y, _ = engine.forward(x, *args)
+    return y

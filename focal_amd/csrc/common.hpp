@@ -1,0 +1,90 @@
+// Shared device/host helpers for libfocal_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/focal_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define FOCAL_WAVE 64
+
+// ----------------------------------------------------------------------------------------------- errors
+void focal_set_error(const char* fmt, ...);
+#define FOCAL_CHECK_ARG(cond, ...)                 \
+  do {                                             \
+    if (!(cond)) {                                 \
+      focal_set_error(__VA_ARGS__);                \
+      return FOCAL_EINVAL;                         \
+    }                                              \
+  } while (0)
+#define FOCAL_LAUNCH_CHECK()                                                       \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      focal_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return FOCAL_EHIP;                                                           \
+    }                                                                              \
+  } while (0)
+
+// ----------------------------------------------------------------------------------------------- scalar conversions
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// ----------------------------------------------------------------------------------------------- counter RNG
+// Dropout masks are a pure function of (seed word in device memory, stream id, element index) so that the
+// backward pass regenerates the forward mask without storing it, and so that a captured hipGraph gets fresh
+// masks on every replay (the seed word is bumped on the device by focal_rng_advance).
+__device__ __forceinline__ uint32_t focal_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct DropCtx {
+  uint32_t key;     // mixed (seed, stream)
+  uint32_t thresh;  // drop if (hash >> 8) < thresh  (24-bit resolution)
+  float scale;      // 1 / (1 - p)
+};
+__device__ __forceinline__ DropCtx make_drop(const uint32_t* seed_ptr, uint32_t stream, float p) {
+  DropCtx d;
+  uint32_t seed = seed_ptr ? seed_ptr[0] : 0u;
+  d.key = focal_mix32(seed * 0x9E3779B9U + stream * 0x85EBCA6BU + 0x1234567U);
+  d.thresh = (uint32_t)(p * 16777216.0f);
+  d.scale = 1.0f / (1.0f - p);
+  return d;
+}
+// multiplier (0 or 1/(1-p)) for element `idx`
+__device__ __forceinline__ float drop_mult(const DropCtx& d, uint32_t idx) {
+  uint32_t h = focal_mix32(idx ^ d.key);
+  return ((h >> 8) < d.thresh) ? 0.0f : d.scale;
+}
+
+// exact-erf GELU and its derivative (nn.GELU(approximate="none"))
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,97 @@
+// Zero-pad + PatchEmbed (Conv2d with kernel = stride = [1, pw]) + LayerNorm, fp32 end to end: this is the only
+// layer that sees the raw spectrum (dynamic range ~ sqrt(n) * input), so it is kept out of bf16.  HBM-bound: the
+// window is read exactly once, tokens are written once.  64 tokens per workgroup: patches and the transposed
+// filter bank are staged in LDS, each thread produces 16 channels of one token, LayerNorm over the 4 threads of a
+// token by wave shuffles.
+#include "common.hpp"
+
+#define EMB_TOK 64
+
+template <int C0>
+__global__ __launch_bounds__(256) void patch_embed_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ tokens,
+                                                             focal_embed_desc d, int K, int total_tokens) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int KP = K + 1;
+  float* wt = smem;                 // [K][C0]   transposed filters
+  float* patch = smem + K * C0;     // [EMB_TOK][KP]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < K * C0; i += 256) {
+    const int k = i / C0, n = i % C0;
+    wt[i] = w[n * K + k];  // conv weight [C0][cin][1][pw] flattened as [C0][K], K index = c*pw + t
+  }
+  constexpr int CPT = C0 / 4;  // channels per thread
+  const int tl = tid >> 2, q = tid & 3;
+  for (int t0 = blockIdx.x * EMB_TOK; t0 < total_tokens; t0 += gridDim.x * EMB_TOK) {
+    __syncthreads();
+    for (int i = tid; i < EMB_TOK * K; i += 256) {
+      const int t = i / K, k = i % K;
+      const int tok = t0 + t;
+      float v = 0.f;
+      if (tok < total_tokens) {
+        const int px = tok % d.Wp, r = tok / d.Wp, py = r % d.Hp, b = r / d.Hp;
+        const int c = k / d.pw, tt = k % d.pw;
+        const int col = px * d.pw + tt;
+        if (py < d.I && col < d.S) v = x[(((long)b * d.cin + c) * d.I + py) * d.S + col];  // else: zero padding
+      }
+      patch[t * KP + k] = v;
+    }
+    __syncthreads();
+    float acc[CPT];
+#pragma unroll
+    for (int n = 0; n < CPT; ++n) acc[n] = bias[q * CPT + n];
+    for (int k = 0; k < K; ++k) {
+      const float a = patch[tl * KP + k];
+      const float* wr = wt + k * C0 + q * CPT;
+#pragma unroll
+      for (int n = 0; n < CPT; n += 4) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr + n);
+        acc[n] += a * wv.x; acc[n + 1] += a * wv.y; acc[n + 2] += a * wv.z; acc[n + 3] += a * wv.w;
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int n = 0; n < CPT; ++n) s += acc[n];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const float mean = s / C0;
+    float v2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < CPT; ++n) v2 += (acc[n] - mean) * (acc[n] - mean);
+    v2 += __shfl_xor(v2, 1, 64);
+    v2 += __shfl_xor(v2, 2, 64);
+    const float rstd = rsqrtf(v2 / C0 + d.eps);
+    const int tok = t0 + tl;
+    if (tok < total_tokens) {
+      float* dst = tokens + (long)tok * C0 + q * CPT;
+#pragma unroll
+      for (int n = 0; n < CPT; n += 4) {
+        float4 o;
+        o.x = (acc[n] - mean) * rstd * gamma[q * CPT + n] + beta[q * CPT + n];
+        o.y = (acc[n + 1] - mean) * rstd * gamma[q * CPT + n + 1] + beta[q * CPT + n + 1];
+        o.z = (acc[n + 2] - mean) * rstd * gamma[q * CPT + n + 2] + beta[q * CPT + n + 2];
+        o.w = (acc[n + 3] - mean) * rstd * gamma[q * CPT + n + 3] + beta[q * CPT + n + 3];
+        *reinterpret_cast<float4*>(dst + n) = o;
+      }
+    }
+  }
+}
+
+extern "C" int focal_pad_patch_embed_ln_fwd(const focal_embed_desc* d, const float* x, const float* w, const float* b,
+                                            const float* gamma, const float* beta, float* tokens, void* stream) {
+  FOCAL_CHECK_ARG(d && x && w && b && gamma && beta && tokens, "pad_patch_embed_ln: null argument");
+  FOCAL_CHECK_ARG(d->C0 == 64 || d->C0 == 128, "pad_patch_embed_ln: embed dim %d not in {64, 128}", d->C0);
+  FOCAL_CHECK_ARG(d->Hp >= d->I && d->Wp * d->pw >= d->S && d->pw > 0, "pad_patch_embed_ln: padded grid smaller than the input");
+  const int K = d->cin * d->pw;
+  const size_t sm = ((size_t)K * d->C0 + (size_t)EMB_TOK * (K + 1)) * sizeof(float);
+  FOCAL_CHECK_ARG(sm <= 64 * 1024, "pad_patch_embed_ln: patch of %d values does not fit in LDS", K);
+  const int total = d->B * d->Hp * d->Wp;
+  int blocks = ceil_div(total, EMB_TOK);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->C0 == 64) hipLaunchKernelGGL((patch_embed_ln_kernel<64>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total);
+  else hipLaunchKernelGGL((patch_embed_ln_kernel<128>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}

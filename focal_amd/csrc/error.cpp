@@ -1,0 +1,16 @@
+// Thread-local error string + ABI version for libfocal_hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/focal_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void focal_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int focal_abi_version(void) { return FOCAL_ABI_VERSION; }
+extern "C" const char* focal_last_error(void) { return g_err; }

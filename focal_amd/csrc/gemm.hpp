@@ -1,0 +1,362 @@
+// MFMA GEMM family for the FOCAL hot path (gfx950).
+//
+//   C[m][n] (+)= epi( alpha * sum_r  proA(A)[m][r] * proB(B)[n][r] )
+//
+// Each operand is either "direct" (memory [i][r], r contiguous -> forward / dX's activation side) or
+// "transposed" (memory [r][i], i contiguous -> weights in dX, both operands in dW).  Transposed tiles are staged
+// as-is into LDS and read back as MFMA fragments with ds_read_b64_tr_b16 (bf16) or strided ds_read_b32 (f32), so
+// no transposed copy of any tensor ever exists in HBM.
+// Compute type CT is bf16 (v_mfma_f32_16x16x32_bf16) or f32 (v_mfma_f32_16x16x4_f32, exact fp32 -- the parity mode).
+// The MFMA is issued as D = Bfrag x Afrag so that a lane ends up with 4 consecutive n for one m: 8/16-byte stores.
+#pragma once
+#include "common.hpp"
+
+enum GemmPro { PRO_NONE = 0, PRO_GELU = 1, PRO_MASK = 2 };
+enum GemmEpi { EPI_STORE = 0, EPI_RESID = 1, EPI_GELU_BWD = 2, EPI_RELU = 3, EPI_RELU_BWD = 4, EPI_ATOMIC = 5 };
+
+struct MaskParams {
+  const uint32_t* seed;  // device word (null -> seed 0)
+  uint32_t stream_elem;  // element-wise dropout stream id
+  float p_elem;          // element-wise dropout probability (0 = off)
+  uint32_t stream_path;  // per-sample stochastic-depth stream id
+  float p_path;          // DropPath probability (0 = off)
+  int rows_per_sample;   // memory rows per sample (for DropPath)
+  int ncols;             // memory columns (linear element index = row * ncols + col)
+};
+
+struct GemmParams {
+  int M, N, K;
+  const void* A; long lda; long strideA;
+  const void* B; long ldb; long strideB;
+  void* C; long ldc; long strideC;
+  int batch, splits;
+  float alpha;
+  const float* bias;              // [N] f32 or null
+  const float* resid; long ldr;   // f32 [M][N] (EPI_RESID)
+  const void* aux; long ldaux;    // CT [M][N] (EPI_GELU_BWD: pre-activation u; EPI_RELU_BWD: relu output)
+  MaskParams proA, proB, epi;
+  float* colsumA;                 // f32 [M] (+=): sum_r proA(A)[m][r]; only with transposed A (bias gradient)
+};
+
+struct MaskEval {
+  DropCtx e, p;
+  bool on_e, on_p;
+  int rps, ncols;
+  __device__ __forceinline__ void init(const MaskParams& m) {
+    on_e = m.p_elem > 0.f;
+    on_p = m.p_path > 0.f;
+    e = make_drop(m.seed, m.stream_elem, m.p_elem);
+    p = make_drop(m.seed, m.stream_path, m.p_path);
+    rps = m.rows_per_sample > 0 ? m.rows_per_sample : 1;
+    ncols = m.ncols;
+  }
+  __device__ __forceinline__ float row_mult(int row) const { return on_p ? drop_mult(p, (uint32_t)(row / rps)) : 1.0f; }
+  __device__ __forceinline__ float elem_mult(int row, int col) const {
+    return on_e ? drop_mult(e, (uint32_t)row * (uint32_t)ncols + (uint32_t)col) : 1.0f;
+  }
+};
+
+template <typename CT> struct GemmCfg;
+template <> struct GemmCfg<bf16_t> {
+  static constexpr int BK = 64, EC = 8, KI = 32, PADK = 8, PADI = 8;
+};
+template <> struct GemmCfg<float> {
+  static constexpr int BK = 32, EC = 4, KI = 4, PADK = 4, PADI = 4;
+};
+
+// ---------------------------------------------------------------------------------------------- staging helpers
+template <typename T, int N> struct RawChunk {
+  static constexpr int R = (N * (int)sizeof(T)) / 16;
+  uint4 v[R];
+};
+template <typename T, int N>
+__device__ __forceinline__ void raw_load(RawChunk<T, N>& r, const T* p, bool pred) {
+#pragma unroll
+  for (int i = 0; i < RawChunk<T, N>::R; ++i) r.v[i] = pred ? reinterpret_cast<const uint4*>(p)[i] : make_uint4(0, 0, 0, 0);
+}
+template <int N> __device__ __forceinline__ void raw_to_f32(const RawChunk<float, N>& r, float* f) {
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) {
+    f[4 * i + 0] = __uint_as_float(r.v[i].x);
+    f[4 * i + 1] = __uint_as_float(r.v[i].y);
+    f[4 * i + 2] = __uint_as_float(r.v[i].z);
+    f[4 * i + 3] = __uint_as_float(r.v[i].w);
+  }
+}
+__device__ __forceinline__ void raw_to_f32(const RawChunk<bf16_t, 8>& r, float* f) {
+  const uint32_t w[4] = {r.v[0].x, r.v[0].y, r.v[0].z, r.v[0].w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void store_chunk(float* dst, const float* f) {
+  *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ void store_chunk(bf16_t* dst, const float* f) {
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
+  *reinterpret_cast<bf16x8*>(dst) = v;
+}
+
+template <int PRO>
+__device__ __forceinline__ void apply_prologue(float* f, int n, int row, int col0, const MaskEval& me) {
+  if (PRO == PRO_NONE) return;
+  if (PRO == PRO_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e < n) f[e] = gelu_f(f[e]) * me.elem_mult(row, col0 + e);
+  } else {  // PRO_MASK
+    const float rm = me.row_mult(row);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e < n) f[e] = f[e] * rm * me.elem_mult(row, col0 + e);
+  }
+}
+
+// One operand's staging state for one workgroup (256 threads).
+template <typename CT, typename TG, bool TRANS, int PRO, int BI> struct OperandStage {
+  using Cfg = GemmCfg<CT>;
+  static constexpr int BK = Cfg::BK, EC = Cfg::EC;
+  static constexpr int PITCH = TRANS ? (BI + Cfg::PADI) : (BK + Cfg::PADK);
+  static constexpr int LDS_ELEMS = TRANS ? BK * PITCH : BI * PITCH;
+  static constexpr int NCH = BI / 32;  // chunks per thread (8*BI chunks / 256 threads)
+  static constexpr int CPR = TRANS ? BI / EC : BK / EC;
+  RawChunk<TG, EC> raw[NCH];
+
+  // i_ext: extent of the non-reduced index, r_ext: extent of the reduced index (both in elements)
+  __device__ __forceinline__ void load(const TG* base, long ld, int i0, int r0, int i_ext, int r_end, int tid) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = tid + 256 * j;
+      const int a = c / CPR, b = (c % CPR) * EC;
+      if (TRANS) {  // memory [r][i]
+        const int r = r0 + a, i = i0 + b;
+        raw_load(raw[j], base + (long)r * ld + i, (r < r_end) && (i < i_ext));
+      } else {  // memory [i][r]
+        const int i = i0 + a, r = r0 + b;
+        raw_load(raw[j], base + (long)i * ld + r, (i < i_ext) && (r < r_end));
+      }
+    }
+  }
+  __device__ __forceinline__ void store(CT* lds, int i0, int r0, int tid, const MaskEval& me) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = tid + 256 * j;
+      const int a = c / CPR, b = (c % CPR) * EC;
+      float f[8];
+      raw_to_f32(raw[j], f);
+      if (TRANS) apply_prologue<PRO>(f, EC, r0 + a, i0 + b, me);
+      else apply_prologue<PRO>(f, EC, i0 + a, r0 + b, me);
+      store_chunk(lds + a * PITCH + b, f);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------- fragments
+template <typename CT, bool TRANS, int PITCH> struct FragLoad;
+template <int PITCH> struct FragLoad<bf16_t, false, PITCH> {
+  using Frag = bf16x8;
+  // tile [i][k]; 16 rows starting at ibase, k-step kk (32 wide)
+  static __device__ __forceinline__ Frag load(const bf16_t* lds, int ibase, int kk, int lane) {
+    return *reinterpret_cast<const bf16x8*>(lds + (ibase + (lane & 15)) * PITCH + kk * 32 + 8 * (lane >> 4));
+  }
+};
+template <int PITCH> struct FragLoad<bf16_t, true, PITCH> {
+  using Frag = bf16x8;
+  // tile [k][i]; hardware transpose read: two 4x16 blocks give this lane's 8 consecutive k for column ibase+(lane&15)
+  static __device__ __forceinline__ Frag load(const bf16_t* lds, int ibase, int kk, int lane) {
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const bf16_t* a0 = lds + (kk * 32 + 8 * (lane >> 4) + q) * PITCH + ibase + 4 * p;
+    typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(a0));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(a0 + 4 * PITCH));
+    Frag f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
+};
+template <int PITCH> struct FragLoad<float, false, PITCH> {
+  using Frag = float;
+  static __device__ __forceinline__ Frag load(const float* lds, int ibase, int kk, int lane) {
+    return lds[(ibase + (lane & 15)) * PITCH + kk * 4 + (lane >> 4)];
+  }
+};
+template <int PITCH> struct FragLoad<float, true, PITCH> {
+  using Frag = float;
+  static __device__ __forceinline__ Frag load(const float* lds, int ibase, int kk, int lane) {
+    return lds[(kk * 4 + (lane >> 4)) * PITCH + ibase + (lane & 15)];
+  }
+};
+__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// ---------------------------------------------------------------------------------------------- output helpers
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+  bf16x4 o;
+  o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+__device__ __forceinline__ f32x4 load4(const float* p) { float4 t = *reinterpret_cast<const float4*>(p); return f32x4{t.x, t.y, t.z, t.w}; }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+  bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+}
+
+// XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous run of logical
+// tiles; with n fastest, the column tiles that re-read the same activation rows hit that XCD's L2.  Bijective for
+// any block count.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+template <typename CT, typename TA, typename TB, typename TC, bool TRA, bool TRB, int PROA, int PROB, int EPI, int BM, int BN>
+__global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
+  using Cfg = GemmCfg<CT>;
+  constexpr int BK = Cfg::BK, KI = Cfg::KI;
+  using StA = OperandStage<CT, TA, TRA, PROA, BM>;
+  using StB = OperandStage<CT, TB, TRB, PROB, BN>;
+  using FA = FragLoad<CT, TRA, StA::PITCH>;
+  using FB = FragLoad<CT, TRB, StB::PITCH>;
+  constexpr int TM = BM / 32, TN = BN / 32;
+
+  __shared__ __attribute__((aligned(16))) CT lds[StA::LDS_ELEMS + StB::LDS_ELEMS];
+  CT* ldsA = lds;
+  CT* ldsB = lds + StA::LDS_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int z = blockIdx.y, bz = z / p.splits, sp = z % p.splits;
+
+  const TA* A = reinterpret_cast<const TA*>(p.A) + (long)bz * p.strideA;
+  const TB* B = reinterpret_cast<const TB*>(p.B) + (long)bz * p.strideB;
+  TC* C = reinterpret_cast<TC*>(p.C) + (long)bz * p.strideC;
+
+  const int KT = (p.K + BK - 1) / BK;
+  const int kt_per = (KT + p.splits - 1) / p.splits;
+  const int kt0 = sp * kt_per;
+  const int kt1 = min(KT, kt0 + kt_per);
+  const int k_end = min(p.K, kt1 * BK);
+
+  MaskEval meA, meB, meE;
+  if (PROA != PRO_NONE) meA.init(p.proA);
+  if (PROB != PRO_NONE) meB.init(p.proB);
+  if (EPI == EPI_RESID || EPI == EPI_GELU_BWD) meE.init(p.epi);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float csum = 0.f;
+  const bool do_colsum = TRA && (p.colsumA != nullptr) && (n0 == 0);
+
+  StA sa;
+  StB sb;
+  if (kt0 < kt1) {
+    sa.load(A, p.lda, m0, kt0 * BK, p.M, k_end, tid);
+    sb.load(B, p.ldb, n0, kt0 * BK, p.N, k_end, tid);
+  }
+  for (int kt = kt0; kt < kt1; ++kt) {
+    sa.store(ldsA, m0, kt * BK, tid, meA);
+    sb.store(ldsB, n0, kt * BK, tid, meB);
+    __syncthreads();
+    if (kt + 1 < kt1) {
+      sa.load(A, p.lda, m0, (kt + 1) * BK, p.M, k_end, tid);
+      sb.load(B, p.ldb, n0, (kt + 1) * BK, p.N, k_end, tid);
+    }
+    if (TRA) {
+      if (do_colsum && tid < BM) {
+#pragma unroll 8
+        for (int r = 0; r < BK; ++r) csum += to_f32(ldsA[r * StA::PITCH + tid]);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / KI; ++kk) {
+      typename FA::Frag xa[TM];
+      typename FB::Frag wb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xa[i] = FA::load(ldsA, wm * (BM / 2) + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wb[j] = FB::load(ldsB, wn * (BN / 2) + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mma16(wb[j], xa[i], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  if (TRA) {
+    if (do_colsum && tid < BM && (m0 + tid) < p.M) atomicAdd(p.colsumA + m0 + tid, csum);
+  }
+
+  // ---- epilogue: lane holds C[m][n..n+3] for m = ..+(lane&15), n = ..+(lane>>4)*4
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    float rowm = 1.f;
+    if (EPI == EPI_RESID) rowm = meE.row_mult(m);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j] * p.alpha;
+      if (EPI != EPI_ATOMIC) {
+        if (p.bias) v += load4(p.bias + n);
+      } else if (p.bias && sp == 0) {
+        v += load4(p.bias + n);
+      }
+      if (EPI == EPI_STORE) {
+        store4(C + (long)m * p.ldc + n, v);
+      } else if (EPI == EPI_RESID) {
+        f32x4 r = load4(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
+        store4(C + (long)m * p.ldc + n, v);
+      } else if (EPI == EPI_GELU_BWD) {
+        f32x4 u = load4(reinterpret_cast<const CT*>(p.aux) + (long)m * p.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * meE.elem_mult(m, n + e) * gelu_grad_f(u[e]);
+        store4(C + (long)m * p.ldc + n, v);
+      } else if (EPI == EPI_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        store4(C + (long)m * p.ldc + n, v);
+      } else if (EPI == EPI_RELU_BWD) {
+        f32x4 y = load4(reinterpret_cast<const TC*>(p.aux) + (long)m * p.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
+        store4(C + (long)m * p.ldc + n, v);
+      } else {  // EPI_ATOMIC (fp32 output only)
+        float* c = reinterpret_cast<float*>(C) + (long)m * p.ldc + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+      }
+    }
+  }
+}
+
+// Host-side dispatch (gemm_dispatch.inc, instantiated per compute type in gemm_bf16.hip / gemm_f32.hip).
+// dtype codes: FOCAL_F32 / FOCAL_BF16.  Returns a focal error code.
+struct GemmSpec {
+  int compute;  // compute type CT
+  int a_dtype, b_dtype, c_dtype;
+  bool tra, trb;
+  int proA, proB, epi;
+};
+int focal_launch_gemm_bf16(const GemmSpec& s, const GemmParams& p, hipStream_t stream);
+int focal_launch_gemm_f32(const GemmSpec& s, const GemmParams& p, hipStream_t stream);
+static inline int focal_launch_gemm(const GemmSpec& s, const GemmParams& p, hipStream_t stream) {
+  return s.compute == FOCAL_F32 ? focal_launch_gemm_f32(s, p, stream) : focal_launch_gemm_bf16(s, p, stream);
+}

@@ -1,0 +1,7 @@
+// fp32-compute instantiations of the MFMA GEMM family (v_mfma_f32_16x16x4_f32: exact fp32, the parity mode and
+// the loss head's similarity / distance products).
+#include <type_traits>
+#include "gemm.hpp"
+#define GEMM_CT float
+#define GEMM_FN focal_launch_gemm_f32
+#include "gemm_dispatch.inc"

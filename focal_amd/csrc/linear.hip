@@ -1,0 +1,129 @@
+// focal_linear_{fwd,bwd_data,bwd_weight}: the nn.Linear family of the SW_Transformer / projector stacks, mapped
+// onto the MFMA GEMM templates of gemm.hpp.
+#include "gemm.hpp"
+
+static MaskParams to_mask(const focal_drop_desc& d, int ncols) {
+  MaskParams m;
+  m.seed = d.rng;
+  m.stream_elem = d.stream_elem;
+  m.p_elem = d.p_elem;
+  m.stream_path = d.stream_path;
+  m.p_path = d.p_path;
+  m.rows_per_sample = d.rows_per_sample;
+  m.ncols = ncols;
+  return m;
+}
+static MaskParams no_mask() {
+  MaskParams m;
+  memset(&m, 0, sizeof(m));
+  return m;
+}
+
+static int check_desc(const focal_linear_desc* d) {
+  FOCAL_CHECK_ARG(d != nullptr, "linear: null descriptor");
+  FOCAL_CHECK_ARG(d->dtype == FOCAL_F32 || d->dtype == FOCAL_BF16, "linear: bad dtype %d", d->dtype);
+  FOCAL_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "linear: bad shape %d %d %d", d->M, d->N, d->K);
+  const int ec = d->dtype == FOCAL_BF16 ? 8 : 4;
+  FOCAL_CHECK_ARG(d->K % ec == 0 && d->N % ec == 0, "linear: N=%d and K=%d must be multiples of %d", d->N, d->K, ec);
+  FOCAL_CHECK_ARG(d->x_dtype == FOCAL_F32 || d->x_dtype == d->dtype, "linear: x_dtype must be f32 or dtype");
+  FOCAL_CHECK_ARG(d->y_dtype == FOCAL_F32 || d->y_dtype == d->dtype, "linear: y_dtype must be f32 or dtype");
+  return FOCAL_OK;
+}
+
+extern "C" int focal_linear_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias,
+                                const float* resid, void* y, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  FOCAL_CHECK_ARG(x && w && y, "linear_fwd: null tensor");
+  GemmSpec s;
+  s.compute = d->dtype;
+  s.a_dtype = d->x_dtype; s.b_dtype = d->dtype; s.c_dtype = d->y_dtype;
+  s.tra = false; s.trb = false;
+  s.proA = d->act_in == FOCAL_ACT_GELU ? PRO_GELU : PRO_NONE;
+  s.proB = PRO_NONE;
+  const int splits = d->splits > 1 ? d->splits : 1;
+  if (splits > 1) {
+    FOCAL_CHECK_ARG(d->epilogue == FOCAL_EPI_NONE && d->y_dtype == FOCAL_F32, "linear_fwd: split-K needs a plain fp32 output");
+    s.epi = EPI_ATOMIC;
+  } else {
+    s.epi = d->epilogue == FOCAL_EPI_RESIDUAL ? EPI_RESID : d->epilogue == FOCAL_EPI_RELU ? EPI_RELU : EPI_STORE;
+  }
+  if (s.epi == EPI_RESID) FOCAL_CHECK_ARG(resid != nullptr && d->y_dtype == FOCAL_F32, "linear_fwd: residual epilogue needs resid and fp32 y");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.A = x; p.lda = d->K;
+  p.B = w; p.ldb = d->K;
+  p.C = y; p.ldc = d->N;
+  p.batch = 1; p.splits = splits; p.alpha = 1.f;
+  p.bias = bias;
+  p.resid = resid; p.ldr = d->N;
+  p.proA = to_mask(d->in_drop, d->K);
+  p.proB = no_mask();
+  p.epi = to_mask(d->out_drop, d->N);
+  return focal_launch_gemm(s, p, (hipStream_t)stream);
+}
+
+extern "C" int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy, const void* w, const void* x, void* dx,
+                                     void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  FOCAL_CHECK_ARG(dy && w && dx, "linear_bwd_data: null tensor");
+  // dx[M, K] = (dy . out_mask)[M, N] . w[N, K]   (w read transposed: memory [r = n][i = k])
+  GemmSpec s;
+  s.compute = d->dtype;
+  s.a_dtype = d->y_dtype; s.b_dtype = d->dtype; s.c_dtype = d->x_dtype;
+  s.tra = false; s.trb = true;
+  // fp32 output gradients feeding `dtype` operands always go through the masking loader (identity when p = 0)
+  const bool masked = d->epilogue == FOCAL_EPI_RESIDUAL || (d->y_dtype == FOCAL_F32 && d->x_dtype != FOCAL_F32);
+  s.proA = masked ? PRO_MASK : PRO_NONE;
+  s.proB = PRO_NONE;
+  s.epi = d->act_in == FOCAL_ACT_GELU ? EPI_GELU_BWD : d->act_in == FOCAL_ACT_RELU_OUT ? EPI_RELU_BWD : EPI_STORE;
+  if (s.epi != EPI_STORE) FOCAL_CHECK_ARG(x != nullptr, "linear_bwd_data: forward input needed for the activation gradient");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->M; p.N = d->K; p.K = d->N;
+  p.A = dy; p.lda = d->N;
+  p.B = w; p.ldb = d->K;
+  p.C = dx; p.ldc = d->K;
+  p.batch = 1; p.splits = 1; p.alpha = 1.f;
+  p.aux = x; p.ldaux = d->K;
+  p.proA = masked ? to_mask(d->out_drop, d->N) : no_mask();
+  p.proB = no_mask();
+  p.epi = to_mask(d->in_drop, d->K);
+  return focal_launch_gemm(s, p, (hipStream_t)stream);
+}
+
+extern "C" int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const void* x, float* dw, float* dbias,
+                                       void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  FOCAL_CHECK_ARG(dy && x && dw, "linear_bwd_weight: null tensor");
+  // dw[N, K] += sum_m (dy . out_mask)[m][n] * act_in(x)[m][k]: both operands read transposed, reduction over M is
+  // split across workgroups and combined with fp32 atomics straight into the gradient arena.
+  GemmSpec s;
+  s.compute = d->dtype;
+  s.a_dtype = d->y_dtype; s.b_dtype = d->x_dtype; s.c_dtype = FOCAL_F32;
+  s.tra = true; s.trb = true;
+  // fp32 output gradients feeding `dtype` operands always go through the masking loader (identity when p = 0)
+  const bool masked = d->epilogue == FOCAL_EPI_RESIDUAL || (d->y_dtype == FOCAL_F32 && d->x_dtype != FOCAL_F32);
+  s.proA = masked ? PRO_MASK : PRO_NONE;
+  s.proB = d->act_in == FOCAL_ACT_GELU ? PRO_GELU : PRO_NONE;
+  s.epi = EPI_ATOMIC;
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->N; p.N = d->K; p.K = d->M;
+  p.A = dy; p.lda = d->N;
+  p.B = x; p.ldb = d->K;
+  p.C = dw; p.ldc = d->K;
+  p.batch = 1; p.alpha = 1.f;
+  // enough reduction chunks to fill the chip: ~1024 workgroups, at least 512 rows each
+  const long tiles = (long)ceil_div(d->N, 64) * ceil_div(d->K, 64);
+  long splits = (1024 + tiles - 1) / tiles;
+  const long max_splits = (d->M + 511) / 512;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.splits = (int)splits;
+  p.proA = masked ? to_mask(d->out_drop, d->N) : no_mask();
+  p.proB = to_mask(d->in_drop, d->K);
+  p.epi = no_mask();
+  p.colsumA = dbias;
+  return focal_launch_gemm(s, p, (hipStream_t)stream);
+}

@@ -1,0 +1,396 @@
+// FOCAL loss head (models/loss.py:139-218) forward + backward in one call.
+//
+// The reference materialises [seq, 2b, 2b, d] cosine broadcasts and index-masks them; here every cross-sample term
+// is a pair of batched exact-fp32 MFMA products (similarity / Gram matrix, then gradient = coefficient matrix x
+// embeddings) with small row-wise kernels in between (wave-shuffle log-sum-exp, block means, hinges):
+//   InfoNCE   S = Zn Zn^T / T          -> lse rows, loss   -> W = softmax + softmax^T - 2*pos   -> dZn = W Zn
+//   ranking   G = X X^T -> D = cdist   -> block means, hinge -> E = (A + A^T) / D              -> dX = rowsum(E) X - E X
+//   orthogonality is row-local (one wave per sample).
+// Everything is fp32: with T = 0.07 the logits amplify cosine errors 14x.
+#include "gemm.hpp"
+
+#define LOSS_MAXP 32   // InfoNCE problems  (2 views x mod pairs + mods)
+#define LOSS_MAXQ 8    // ranking problems  (2 views x mods)
+#define LOSS_MAXO 32   // orthogonality problems
+
+struct PairProb { const float* e1; const float* e2; float* d1; float* d2; int off1, off2, kind; };
+struct PairTable { PairProb p[LOSS_MAXP]; };
+struct RankTable { const float* x[LOSS_MAXQ]; float* d[LOSS_MAXQ]; };
+
+// ------------------------------------------------------------------------------------------------ InfoNCE
+// row r of problem (p, t): r < b -> e1[(r)*seq + t], else e2[(r-b)*seq + t]; transposition of loss.py:64-73.
+__global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int dim, int width,
+                                                       float* __restrict__ Zn, float* __restrict__ nrm) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long rows = (long)nprob * seq * 2 * b;
+  if (row >= rows) return;
+  const int r = row % (2 * b), t = (row / (2 * b)) % seq, p = row / (2L * b * seq);
+  const PairProb pr = tab.p[p0 + p];
+  const float* src = (r < b) ? pr.e1 + ((long)r * seq + t) * dim + pr.off1 : pr.e2 + ((long)(r - b) * seq + t) * dim + pr.off2;
+  float ss = 0.f;
+  for (int c = lane; c < width; c += 64) { const float v = src[c]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float n = fmaxf(sqrtf(ss), 1e-8f);  // nn.CosineSimilarity eps, loss.py:15
+  for (int c = lane; c < width; c += 64) Zn[row * width + c] = src[c] / n;
+  if (lane == 0) nrm[row] = n;
+}
+
+// one wave per row i of S[p,t]: lse over j != i, loss_i = lse_i - S[i][pos(i)]
+__global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, int nprob, int seq, int b, const float* __restrict__ S,
+                                                       float* __restrict__ lse, float* __restrict__ terms) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n2 = 2 * b;
+  const long rows = (long)nprob * seq * n2;
+  float contrib = 0.f;
+  int kind = 0;
+  if (row < rows) {
+    const int i = row % n2;
+    const int p = row / ((long)n2 * seq);
+    kind = tab.p[p0 + p].kind;
+    const float* s = S + row * n2;
+    float mx = -3.0e38f;
+    for (int j = lane; j < n2; j += 64) if (j != i) mx = fmaxf(mx, s[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < n2; j += 64) if (j != i) sum += __expf(s[j] - mx);
+    sum = wave_sum(sum);
+    const float l = mx + __logf(sum);
+    if (lane == 0) {
+      lse[row] = l;
+      contrib = (l - s[(i + b) % n2]) / (float)(seq * n2);
+    }
+  }
+  // all four rows of a block belong to problems of possibly different kinds: one atomic per wave
+  if (lane == 0 && row < rows) atomicAdd(terms + kind, contrib);
+}
+
+// in place S -> W (times the family weight): W_ij = [j != i](e^{S_ij - lse_i} + e^{S_ij - lse_j}) - 2 [j == pos(i)]
+__global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0, int nprob, int seq, int b, float* __restrict__ S,
+                                                          const float* __restrict__ lse, float w_shared, float w_private) {
+  const int n2 = 2 * b;
+  const long total = (long)nprob * seq * n2 * n2;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int j = e % n2;
+    const long row = e / n2;
+    const int i = row % n2;
+    const long base = row - i;  // first row of this (p, t)
+    const int p = row / ((long)n2 * seq);
+    const float wk = tab.p[p0 + p].kind == 0 ? w_shared : w_private;
+    float w = 0.f;
+    if (j != i) {
+      const float s = S[e];
+      w = __expf(s - lse[row]) + __expf(s - lse[base + j]);
+      if (j == (i + b) % n2) w -= 2.0f;
+    }
+    S[e] = w * wk;
+  }
+}
+
+// dz = (dzn - zn (zn . dzn)) / ||z||, scattered (+=) to the right sample / half of the source embeddings
+__global__ __launch_bounds__(256) void nce_unpack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int dim, int width,
+                                                         const float* __restrict__ Zn, const float* __restrict__ nrm,
+                                                         const float* __restrict__ dZn) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long rows = (long)nprob * seq * 2 * b;
+  if (row >= rows) return;
+  const int r = row % (2 * b), t = (row / (2 * b)) % seq, p = row / (2L * b * seq);
+  const PairProb pr = tab.p[p0 + p];
+  float* dst = (r < b) ? pr.d1 + ((long)r * seq + t) * dim + pr.off1 : pr.d2 + ((long)(r - b) * seq + t) * dim + pr.off2;
+  float dot = 0.f;
+  for (int c = lane; c < width; c += 64) dot += Zn[row * width + c] * dZn[row * width + c];
+  dot = wave_sum(dot);
+  const float inv = 1.0f / nrm[row];
+  for (int c = lane; c < width; c += 64) atomicAdd(dst + c, (dZn[row * width + c] - Zn[row * width + c] * dot) * inv);
+}
+
+// ------------------------------------------------------------------------------------------------ ranking
+__global__ __launch_bounds__(256) void rank_pack_kernel(RankTable tab, int nq, int B, int dim, float* __restrict__ X,
+                                                        float* __restrict__ sq) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)nq * B) return;
+  const int q = row / B, s = row % B;
+  const float* src = tab.x[q] + (long)s * dim;
+  float ss = 0.f;
+  for (int c = lane; c < dim; c += 64) { const float v = src[c]; X[row * dim + c] = v; ss += v * v; }
+  ss = wave_sum(ss);
+  if (lane == 0) sq[row] = ss;
+}
+
+// in place G -> D = sqrt(max(0, |x_p|^2 + |x_q|^2 - 2 G_pq)), D_pp = 0   (torch.cdist mm path, loss.py:117)
+__global__ __launch_bounds__(256) void rank_dist_kernel(int nq, int B, float* __restrict__ G, const float* __restrict__ sq) {
+  const long total = (long)nq * B * B;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = e % B;
+    const long row = e / B;
+    const int r = row % B;
+    const long qb = row - r;
+    const float d2 = sq[row] + sq[qb + c] - 2.0f * G[e];
+    G[e] = (r == c) ? 0.f : sqrtf(fmaxf(d2, 0.f));
+  }
+}
+
+// Dbar[q][I][J] = mean of the seq x seq block (self pairs excluded), loss.py:118-124
+__global__ __launch_bounds__(256) void rank_blockmean_kernel(int nq, int b, int seq, const float* __restrict__ D, float* __restrict__ Dbar) {
+  const long total = (long)nq * b * b;
+  const int B = b * seq;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int J = e % b, I = (e / b) % b, q = e / ((long)b * b);
+    const float* base = D + ((long)q * B + (long)I * seq) * B + (long)J * seq;
+    float s = 0.f;
+    for (int a = 0; a < seq; ++a)
+      for (int c = 0; c < seq; ++c) s += base[(long)a * B + c];  // the self pairs hold exact zeros
+    Dbar[e] = s / (float)(seq * seq - (I == J ? seq : 0));
+  }
+}
+
+// one wave per (q, I): hinge over J != I (MarginRankingLoss(margin, y = -1), loss.py:127-135) and dL/dDbar
+__global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float margin, const float* __restrict__ Dbar,
+                                                         float* __restrict__ dDbar, float* __restrict__ terms) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)nq * b) return;
+  const int I = row % b;
+  const float* d = Dbar + row * b;
+  const float dii = d[I];
+  const float inv = 1.0f / ((float)b * (float)(b - 1));
+  float loss = 0.f, cnt = 0.f;
+  for (int J = lane; J < b; J += 64) {
+    if (J == I) continue;
+    const float h = dii - d[J] + margin;
+    const bool on = h > 0.f;
+    loss += on ? h : 0.f;
+    cnt += on ? 1.f : 0.f;
+    dDbar[row * b + J] = on ? -inv : 0.f;
+  }
+  loss = wave_sum(loss);
+  cnt = wave_sum(cnt);
+  if (lane == 0) {
+    dDbar[row * b + I] = cnt * inv;
+    atomicAdd(terms + 3, loss * inv);
+  }
+}
+
+// in place D -> E = w_rank * (A_pq + A_qp) / D_pq, A_pq = dDbar[I(p)][J(q)] / count(I, J); rowsum[p] = sum_q E_pq
+__global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq, float w_rank, float* __restrict__ D,
+                                                         const float* __restrict__ dDbar, float* __restrict__ rowsum) {
+  const int lane = threadIdx.x & 63;
+  const int B = b * seq;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)nq * B) return;
+  const int p = row % B, q = row / B, I = p / seq;
+  const float* dd = dDbar + (long)q * b * b;
+  float* drow = D + row * B;
+  float rs = 0.f;
+  for (int c = lane; c < B; c += 64) {
+    const int J = c / seq;
+    const float cnt = (float)(seq * seq - (I == J ? seq : 0));
+    const float dist = drow[c];
+    float e = 0.f;
+    if (c != p && dist > 1e-12f) e = w_rank * (dd[(long)I * b + J] + dd[(long)J * b + I]) / (cnt * dist);
+    drow[c] = e;
+    rs += e;
+  }
+  rs = wave_sum(rs);
+  if (lane == 0) rowsum[row] = rs;
+}
+
+__global__ __launch_bounds__(256) void rank_grad_kernel(RankTable tab, int nq, int B, int dim, const float* __restrict__ X,
+                                                        const float* __restrict__ rowsum, const float* __restrict__ EX) {
+  const long total = (long)nq * B * dim;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long row = e / dim;
+    const int c = e % dim, q = row / B, s = row % B;
+    atomicAdd(tab.d[q] + (long)s * dim + c, rowsum[row] * X[e] - EX[e]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ orthogonality
+// CosineEmbeddingLoss(target = -1, margin 0, mean) = mean(max(0, cos)), loss.py:89-106; one wave per sample.
+__global__ __launch_bounds__(256) void orth_kernel(PairTable tab, int nprob, int B, int dim, int width, float w_orth,
+                                                   float* __restrict__ terms) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)nprob * B) return;
+  const int p = row / B, s = row % B;
+  const PairProb pr = tab.p[p];
+  const float* x1 = pr.e1 + (long)s * dim + pr.off1;
+  const float* x2 = pr.e2 + (long)s * dim + pr.off2;
+  float d = 0.f, n1 = 0.f, n2 = 0.f;
+  for (int c = lane; c < width; c += 64) { const float a = x1[c], b2 = x2[c]; d += a * b2; n1 += a * a; n2 += b2 * b2; }
+  d = wave_sum(d); n1 = wave_sum(n1) + 1e-12f; n2 = wave_sum(n2) + 1e-12f;
+  const float den = sqrtf(n1 * n2);
+  const float cs = d / den;
+  if (cs > 0.f) {
+    const float k = w_orth / (float)B;
+    float* g1 = pr.d1 + (long)s * dim + pr.off1;
+    float* g2 = pr.d2 + (long)s * dim + pr.off2;
+    for (int c = lane; c < width; c += 64) {
+      const float a = x1[c], b2 = x2[c];
+      atomicAdd(g1 + c, k * (b2 / den - cs * a / n1));
+      atomicAdd(g2 + c, k * (a / den - cs * b2 / n2));
+    }
+    if (lane == 0) atomicAdd(terms + 2, cs / (float)B);
+  }
+}
+
+__global__ void loss_total_kernel(float* terms, float ws, float wp, float wo, float wr) {
+  terms[4] = ws * terms[0] + wp * terms[1] + wo * terms[2] + wr * terms[3];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct LossPlan {
+  int b, n2, P_sh, P_pr, w_sh, w_pr, Q, O;
+  size_t off_zn, off_nrm, off_S, off_lse, off_dzn, off_X, off_sq, off_D, off_dbar, off_ddbar, off_rs, off_ex, total;
+};
+
+static int loss_plan(const focal_loss_desc* d, LossPlan* pl) {
+  FOCAL_CHECK_ARG(d != nullptr, "loss_head: null descriptor");
+  FOCAL_CHECK_ARG(d->n_mod >= 1 && d->n_mod <= 4, "loss_head: n_mod=%d out of [1, 4]", d->n_mod);
+  FOCAL_CHECK_ARG(d->seq >= 1 && d->B % d->seq == 0 && d->B / d->seq >= 2, "loss_head: batch %d must be >= 2 whole subsequences of %d", d->B, d->seq);
+  FOCAL_CHECK_ARG(d->dim % 8 == 0 && d->dim <= 1024, "loss_head: dim %d unsupported", d->dim);
+  const int M = d->n_mod;
+  pl->b = d->B / d->seq;
+  pl->n2 = 2 * pl->b;
+  FOCAL_CHECK_ARG(pl->n2 % 4 == 0 && d->B % 4 == 0, "loss_head: 2*batch/seq must be a multiple of 4");
+  pl->P_sh = 2 * (M * (M - 1) / 2);
+  pl->P_pr = M;
+  pl->w_sh = d->no_private ? d->dim : d->dim / 2;
+  pl->w_pr = d->dim / 2;
+  pl->Q = 2 * M;
+  pl->O = 2 * (M + M * (M - 1) / 2);
+  FOCAL_CHECK_ARG(pl->P_sh + pl->P_pr <= LOSS_MAXP && pl->O <= LOSS_MAXO && pl->Q <= LOSS_MAXQ, "loss_head: too many modality pairs");
+  const size_t rows_sh = (size_t)pl->P_sh * d->seq * pl->n2, rows_pr = (size_t)pl->P_pr * d->seq * pl->n2;
+  const size_t zn = rows_sh * pl->w_sh + rows_pr * pl->w_pr;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
+  pl->off_zn = take(zn);
+  pl->off_dzn = take(zn);
+  pl->off_nrm = take(rows_sh + rows_pr);
+  pl->off_lse = take(rows_sh + rows_pr);
+  pl->off_S = take((rows_sh + rows_pr) * pl->n2);
+  pl->off_X = take((size_t)pl->Q * d->B * d->dim);
+  pl->off_ex = take((size_t)pl->Q * d->B * d->dim);
+  pl->off_sq = take((size_t)pl->Q * d->B);
+  pl->off_rs = take((size_t)pl->Q * d->B);
+  pl->off_D = take((size_t)pl->Q * d->B * d->B);
+  pl->off_dbar = take((size_t)pl->Q * pl->b * pl->b);
+  pl->off_ddbar = take((size_t)pl->Q * pl->b * pl->b);
+  pl->total = o * sizeof(float);
+  return FOCAL_OK;
+}
+
+extern "C" size_t focal_loss_head_workspace(const focal_loss_desc* d) {
+  LossPlan pl;
+  if (loss_plan(d, &pl) != FOCAL_OK) return 0;
+  return pl.total;
+}
+
+static int f32_gemm(bool trb, int M, int N, int K, const float* A, long lda, long sA, const float* B, long ldb, long sB, float* C,
+                    long ldc, long sC, int batch, float alpha, hipStream_t st) {
+  GemmSpec s;
+  s.compute = FOCAL_F32; s.a_dtype = FOCAL_F32; s.b_dtype = FOCAL_F32; s.c_dtype = FOCAL_F32;
+  s.tra = false; s.trb = trb; s.proA = PRO_NONE; s.proB = PRO_NONE; s.epi = EPI_STORE;
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = M; p.N = N; p.K = K;
+  p.A = A; p.lda = lda; p.strideA = sA;
+  p.B = B; p.ldb = ldb; p.strideB = sB;
+  p.C = C; p.ldc = ldc; p.strideC = sC;
+  p.batch = batch; p.splits = 1; p.alpha = alpha;
+  return focal_launch_gemm(s, p, st);
+}
+
+extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* feats, float* terms, float* const* dfeats,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  LossPlan pl;
+  if (int rc = loss_plan(d, &pl)) return rc;
+  FOCAL_CHECK_ARG(feats && terms && dfeats && workspace, "loss_head: null argument");
+  if (workspace_bytes < pl.total) {
+    focal_set_error("loss_head: workspace %zu < required %zu bytes", workspace_bytes, pl.total);
+    return FOCAL_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int M = d->n_mod, B = d->B, dim = d->dim, seq = d->seq, b = pl.b, n2 = pl.n2, half = d->dim / 2;
+  float* ws = reinterpret_cast<float*>(workspace);
+  (void)hipMemsetAsync(terms, 0, 5 * sizeof(float), st);
+  for (int i = 0; i < 2 * M; ++i) (void)hipMemsetAsync(dfeats[i], 0, (size_t)B * dim * sizeof(float), st);
+
+  // ---- problem tables (view-major feature order: index v*M + m)
+  PairTable nce, orth;
+  memset(&nce, 0, sizeof(nce));
+  memset(&orth, 0, sizeof(orth));
+  int np = 0;
+  for (int v = 0; v < 2; ++v)  // shared family, loss.py:162-178
+    for (int m1 = 0; m1 < M; ++m1)
+      for (int m2 = m1 + 1; m2 < M; ++m2)
+        nce.p[np++] = PairProb{feats[v * M + m1], feats[v * M + m2], dfeats[v * M + m1], dfeats[v * M + m2], 0, 0, 0};
+  for (int m = 0; m < M; ++m)  // private family, loss.py:181-186
+    nce.p[np++] = PairProb{feats[m], feats[M + m], dfeats[m], dfeats[M + m], half, half, 1};
+  int no = 0;
+  for (int v = 0; v < 2; ++v)  // loss.py:195-209
+    for (int m = 0; m < M; ++m) {
+      orth.p[no++] = PairProb{feats[v * M + m], feats[v * M + m], dfeats[v * M + m], dfeats[v * M + m], 0, half, 2};
+      for (int m2 = m + 1; m2 < M; ++m2)
+        orth.p[no++] = PairProb{feats[v * M + m], feats[v * M + m2], dfeats[v * M + m], dfeats[v * M + m2], half, half, 2};
+    }
+  RankTable rk;
+  memset(&rk, 0, sizeof(rk));
+  for (int i = 0; i < 2 * M; ++i) { rk.x[i] = feats[i]; rk.d[i] = dfeats[i]; }
+
+  // ---- InfoNCE: the two families may have different widths (tag == "noPrivate"), so they run as two groups
+  size_t zoff = 0, roff = 0;
+  for (int grp = 0; grp < 2; ++grp) {
+    const int p0 = grp == 0 ? 0 : pl.P_sh, nprob = grp == 0 ? pl.P_sh : pl.P_pr, width = grp == 0 ? pl.w_sh : pl.w_pr;
+    if (nprob == 0) continue;
+    const long rows = (long)nprob * seq * n2;
+    float* Zn = ws + pl.off_zn + zoff;
+    float* dZn = ws + pl.off_dzn + zoff;
+    float* nrm = ws + pl.off_nrm + roff;
+    float* lse = ws + pl.off_lse + roff;
+    float* S = ws + pl.off_S + roff * n2;
+    const int rb = ceil_div(rows, 4);
+    hipLaunchKernelGGL(nce_pack_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, dim, width, Zn, nrm);
+    if (int rc = f32_gemm(false, n2, n2, width, Zn, width, (long)n2 * width, Zn, width, (long)n2 * width, S, n2, (long)n2 * n2,
+                          nprob * seq, 1.0f / d->temperature, st)) return rc;
+    hipLaunchKernelGGL(nce_rows_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, S, lse, terms);
+    int eb = ceil_div(rows * n2, 256);
+    if (eb > 8192) eb = 8192;
+    hipLaunchKernelGGL(nce_weights_kernel, dim3(eb), dim3(256), 0, st, nce, p0, nprob, seq, b, S, lse, d->w_shared, d->w_private);
+    if (int rc = f32_gemm(true, n2, width, n2, S, n2, (long)n2 * n2, Zn, width, (long)n2 * width, dZn, width, (long)n2 * width,
+                          nprob * seq, 1.0f / ((float)seq * n2 * d->temperature), st)) return rc;
+    hipLaunchKernelGGL(nce_unpack_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, dim, width, Zn, nrm, dZn);
+    zoff += (size_t)rows * width;
+    roff += rows;
+  }
+
+  // ---- temporal ranking, loss.py:189-192
+  {
+    const int Q = pl.Q;
+    float* X = ws + pl.off_X; float* EX = ws + pl.off_ex; float* sq = ws + pl.off_sq; float* rs = ws + pl.off_rs;
+    float* D = ws + pl.off_D; float* Dbar = ws + pl.off_dbar; float* dDbar = ws + pl.off_ddbar;
+    hipLaunchKernelGGL(rank_pack_kernel, dim3(ceil_div((long)Q * B, 4)), dim3(256), 0, st, rk, Q, B, dim, X, sq);
+    if (int rc = f32_gemm(false, B, B, dim, X, dim, (long)B * dim, X, dim, (long)B * dim, D, B, (long)B * B, Q, 1.0f, st)) return rc;
+    int eb = ceil_div((long)Q * B * B, 256);
+    if (eb > 8192) eb = 8192;
+    hipLaunchKernelGGL(rank_dist_kernel, dim3(eb), dim3(256), 0, st, Q, B, D, sq);
+    int bb = ceil_div((long)Q * b * b, 256);
+    if (bb > 4096) bb = 4096;
+    hipLaunchKernelGGL(rank_blockmean_kernel, dim3(bb), dim3(256), 0, st, Q, b, seq, D, Dbar);
+    hipLaunchKernelGGL(rank_hinge_kernel, dim3(ceil_div((long)Q * b, 4)), dim3(256), 0, st, Q, b, d->margin, Dbar, dDbar, terms);
+    hipLaunchKernelGGL(rank_coeff_kernel, dim3(ceil_div((long)Q * B, 4)), dim3(256), 0, st, Q, b, seq, d->w_rank, D, dDbar, rs);
+    if (int rc = f32_gemm(true, B, dim, B, D, B, (long)B * B, X, dim, (long)B * dim, EX, dim, (long)B * dim, Q, 1.0f, st)) return rc;
+    int gb = ceil_div((long)Q * B * dim, 256);
+    if (gb > 8192) gb = 8192;
+    hipLaunchKernelGGL(rank_grad_kernel, dim3(gb), dim3(256), 0, st, rk, Q, B, dim, X, rs, EX);
+  }
+
+  // ---- orthogonality
+  hipLaunchKernelGGL(orth_kernel, dim3(ceil_div((long)pl.O * B, 4)), dim3(256), 0, st, orth, pl.O, B, dim, half, d->w_orth, terms);
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, terms, d->w_shared, d->w_private, d->w_orth, d->w_rank);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}

@@ -1,0 +1,202 @@
+// LayerNorm forward / backward for the SW_Transformer residual stream (nn.LayerNorm, eps 1e-5, biased variance),
+// optionally fused with PatchMerging's 2x2 gather (models/SwinModules.py:388-399).  HBM-bound streaming kernels:
+// one float4 per lane, LPR = C/4 lanes per row (up to a full wave), wave-shuffle reductions, no LDS in forward.
+#include "common.hpp"
+
+// Row addressing.  Plain: row r -> x + r*C.  Gather: row r = (b, y2, x2) of the merged grid; segment s = c / Cin
+// comes from token (2*y2 + (s & 1), 2*x2 + (s >> 1)) of the [B, H, W, Cin] input (cat order x00, x10, x01, x11).
+struct RowMap {
+  int gather, H, W, Cin, C;
+  __device__ __forceinline__ long offset(int r, int c) const {
+    if (!gather) return (long)r * C + c;
+    const int W2 = W >> 1, H2 = H >> 1;
+    const int x2 = r % W2, t = r / W2, y2 = t % H2, b = t / H2;
+    const int s = c / Cin, cc = c - s * Cin;
+    const int y = 2 * y2 + (s & 1), x = 2 * x2 + (s >> 1);
+    return (((long)b * H + y) * W + x) * Cin + cc;
+  }
+};
+
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+  for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename TY, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, TY* __restrict__ y,
+                                                     float* __restrict__ stats, int rows, int C, int lpr, float eps,
+                                                     RowMap map) {
+  const int lane = threadIdx.x & 63;
+  const int rpw = 64 / lpr;                       // rows per wave
+  const int sub = lane / lpr, li = lane % lpr;    // row slot in the wave, lane within the row
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  for (int r0 = wave_global * rpw; r0 < rows; r0 += nwaves * rpw) {
+    const int r = r0 + sub;
+    const bool ok = r < rows;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * lpr + li) * 4;
+      v[k] = ok ? *reinterpret_cast<const float4*>(x + map.offset(r, c)) : make_float4(0, 0, 0, 0);
+      s += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+    const float mean = group_sum(s, lpr) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float a = v[k].x - mean, b = v[k].y - mean, c2 = v[k].z - mean, d = v[k].w - mean;
+      q += a * a + b * b + c2 * c2 + d * d;
+    }
+    const float rstd = rsqrtf(group_sum(q, lpr) / C + eps);
+    if (!ok) continue;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * lpr + li) * 4;
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c);
+      TY* dst = y + (long)r * C + c;
+      const float o0 = (v[k].x - mean) * rstd * g.x + b.x, o1 = (v[k].y - mean) * rstd * g.y + b.y;
+      const float o2 = (v[k].z - mean) * rstd * g.z + b.z, o3 = (v[k].w - mean) * rstd * g.w + b.w;
+      if (sizeof(TY) == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(o0, o1, o2, o3);
+      } else {
+        bf16x4 o;
+        o[0] = (bf16_t)o0; o[1] = (bf16_t)o1; o[2] = (bf16_t)o2; o[3] = (bf16_t)o3;
+        *reinterpret_cast<bf16x4*>(dst) = o;
+      }
+    }
+    if (li == 0) {
+      stats[2 * (long)r] = mean;
+      stats[2 * (long)r + 1] = rstd;
+    }
+  }
+}
+
+template <typename TY> __device__ __forceinline__ float4 load_dy4(const TY* p);
+template <> __device__ __forceinline__ float4 load_dy4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 load_dy4<bf16_t>(const bf16_t* p) {
+  bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+  return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+}
+
+// dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * gamma;  dgamma += sum_r dy * xhat; dbeta += sum_r dy.
+// Each lane keeps private column partials across its grid-stride rows; they are combined through LDS once per
+// workgroup and leave as one atomic per column per workgroup.
+template <typename TY, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TY* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     float* __restrict__ dx, int accumulate, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int rows, int C, int lpr, RowMap map) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int rpw = 64 / lpr;
+  const int sub = lane / lpr, li = lane % lpr;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  float4 pg[NV], pb[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) pg[k] = pb[k] = make_float4(0, 0, 0, 0);
+  for (int r0 = wave_global * rpw; r0 < rows; r0 += nwaves * rpw) {
+    const int r = r0 + sub;
+    const bool ok = r < rows;
+    const float mean = ok ? stats[2 * (long)r] : 0.f, rstd = ok ? stats[2 * (long)r + 1] : 0.f;
+    float4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * lpr + li) * 4;
+      float4 xv = ok ? *reinterpret_cast<const float4*>(x + map.offset(r, c)) : make_float4(0, 0, 0, 0);
+      float4 d = ok ? load_dy4<TY>(dy + (long)r * C + c) : make_float4(0, 0, 0, 0);
+      const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+      xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+      g[k] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+      s1 += g[k].x + g[k].y + g[k].z + g[k].w;
+      s2 += g[k].x * xh[k].x + g[k].y * xh[k].y + g[k].z * xh[k].z + g[k].w * xh[k].w;
+      pg[k].x += d.x * xh[k].x; pg[k].y += d.y * xh[k].y; pg[k].z += d.z * xh[k].z; pg[k].w += d.w * xh[k].w;
+      pb[k].x += d.x; pb[k].y += d.y; pb[k].z += d.z; pb[k].w += d.w;
+    }
+    const float m1 = group_sum(s1, lpr) / C, m2 = group_sum(s2, lpr) / C;
+    if (!ok) continue;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * lpr + li) * 4;
+      float* dst = dx + map.offset(r, c);
+      float4 o = make_float4(rstd * (g[k].x - m1 - xh[k].x * m2), rstd * (g[k].y - m1 - xh[k].y * m2),
+                             rstd * (g[k].z - m1 - xh[k].z * m2), rstd * (g[k].w - m1 - xh[k].w * m2));
+      if (accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(dst);
+        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+      }
+      *reinterpret_cast<float4*>(dst) = o;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (k * lpr + li) * 4;
+    atomicAdd(&red[c + 0], pg[k].x); atomicAdd(&red[c + 1], pg[k].y); atomicAdd(&red[c + 2], pg[k].z); atomicAdd(&red[c + 3], pg[k].w);
+    atomicAdd(&red[C + c + 0], pb[k].x); atomicAdd(&red[C + c + 1], pb[k].y); atomicAdd(&red[C + c + 2], pb[k].z); atomicAdd(&red[C + c + 3], pb[k].w);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    atomicAdd(dgamma + i, red[i]);
+    atomicAdd(dbeta + i, red[C + i]);
+  }
+}
+
+static int ln_geometry(const focal_ln_desc* d, int* lpr, int* nv, RowMap* map) {
+  FOCAL_CHECK_ARG(d != nullptr, "layernorm: null descriptor");
+  FOCAL_CHECK_ARG(d->dtype == FOCAL_F32 || d->dtype == FOCAL_BF16, "layernorm: bad dtype");
+  const int C = d->C;
+  FOCAL_CHECK_ARG(C >= 16 && C <= 1024 && (C & (C - 1)) == 0, "layernorm: C=%d must be a power of two in [16, 1024]", C);
+  *lpr = C / 4 < 64 ? C / 4 : 64;
+  *nv = C / (4 * *lpr);
+  map->gather = d->gather; map->H = d->H; map->W = d->W; map->Cin = d->Cin; map->C = C;
+  if (d->gather) {
+    FOCAL_CHECK_ARG(d->Cin * 4 == C && d->H % 2 == 0 && d->W % 2 == 0 && d->rows == d->B * (d->H / 2) * (d->W / 2) && d->Cin % 4 == 0,
+                    "layernorm: inconsistent gather geometry");
+  }
+  return FOCAL_OK;
+}
+
+extern "C" int focal_layernorm_fwd(const focal_ln_desc* d, const float* x, const float* gamma, const float* beta, void* y,
+                                   float* stats, void* stream) {
+  int lpr, nv;
+  RowMap map;
+  if (int rc = ln_geometry(d, &lpr, &nv, &map)) return rc;
+  FOCAL_CHECK_ARG(x && gamma && beta && y && stats, "layernorm_fwd: null tensor");
+  const int rpw = 64 / lpr;
+  int blocks = ceil_div(d->rows, rpw * 4);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+#define LN_FWD(TY, NV) hipLaunchKernelGGL((ln_fwd_kernel<TY, NV>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, (TY*)y, stats, d->rows, d->C, lpr, d->eps, map)
+  if (d->dtype == FOCAL_F32) { if (nv == 1) LN_FWD(float, 1); else if (nv == 2) LN_FWD(float, 2); else LN_FWD(float, 4); }
+  else { if (nv == 1) LN_FWD(bf16_t, 1); else if (nv == 2) LN_FWD(bf16_t, 2); else LN_FWD(bf16_t, 4); }
+#undef LN_FWD
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+extern "C" int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const float* x, const float* stats,
+                                   const float* gamma, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
+                                   void* stream) {
+  int lpr, nv;
+  RowMap map;
+  if (int rc = ln_geometry(d, &lpr, &nv, &map)) return rc;
+  FOCAL_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta, "layernorm_bwd: null tensor");
+  const int rpw = 64 / lpr;
+  int blocks = ceil_div(d->rows, rpw * 4);
+  if (blocks > 512) blocks = 512;  // bounds the per-column atomic fan-in of dgamma / dbeta
+  hipStream_t st = (hipStream_t)stream;
+  const size_t sm = 2 * d->C * sizeof(float);
+#define LN_BWD(TY, NV) hipLaunchKernelGGL((ln_bwd_kernel<TY, NV>), dim3(blocks), dim3(256), sm, st, (const TY*)dy, x, stats, gamma, dx, accumulate_dx, dgamma, dbeta, d->rows, d->C, lpr, map)
+  if (d->dtype == FOCAL_F32) { if (nv == 1) LN_BWD(float, 1); else if (nv == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
+  else { if (nv == 1) LN_BWD(bf16_t, 1); else if (nv == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
+#undef LN_BWD
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}

@@ -1,0 +1,221 @@
+"""Tensor-level wrappers over the libfocal_hip C ABI.
+
+PyTorch is plumbing here: it owns device memory (torch.empty), the current HIP stream and autograd bookkeeping; all
+arithmetic happens in the HIP kernels.  Every function enqueues on `torch.cuda.current_stream()` and returns
+immediately; none of them has a CPU implementation.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU_OUT, EPI_NONE, EPI_RELU, EPI_RESIDUAL, FOCAL_BF16, FOCAL_F32,
+                   AdamWDesc, AttnDesc, DropDesc, EmbedDesc, FFTDesc, LinearDesc, LNDesc, LossDesc, check)
+
+_TORCH2CODE = {torch.float32: FOCAL_F32, torch.bfloat16: FOCAL_BF16}
+_CODE2TORCH = {v: k for k, v in _TORCH2CODE.items()}
+
+
+def code(dtype):
+    return _TORCH2CODE[dtype]
+
+
+def torch_dtype(c):
+    return _CODE2TORCH[c]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.FocalHipError("libfocal_hip operates on device tensors only (no CPU fallback)")
+        if t is not None and not t.is_contiguous():
+            raise _lib.FocalHipError("libfocal_hip needs contiguous tensors")
+
+
+def drop_desc(rng=None, stream_elem=0, p_elem=0.0, stream_path=0, p_path=0.0, rows_per_sample=1):
+    return DropDesc(_p(rng), stream_elem, p_elem, stream_path, p_path, rows_per_sample)
+
+
+NO_DROP = drop_desc()
+
+
+# ------------------------------------------------------------------------------------------------ RNG / optimizer
+def new_rng_state(seed, device):
+    return torch.tensor([seed & 0xFFFFFFFF, 0, 0, 0], dtype=torch.int64, device=device).to(torch.int32)
+
+
+def rng_advance(state):
+    check(_lib.load().focal_rng_advance(_p(state), _stream()))
+
+
+def cast_bf16(src, dst):
+    _need_cuda(src, dst)
+    check(_lib.load().focal_cast_bf16(_p(src), _p(dst), src.numel(), _stream()))
+
+
+def adamw_multi(segments, lr_dev, rng_state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05):
+    """segments: list of (p, g, m, v, shadow_or_None) flat tensors (lengths multiples of 4)."""
+    n = len(segments)
+    arr = lambda i: (C.c_void_p * n)(*[_p(s[i]) for s in segments])
+    has_shadow = any(s[4] is not None for s in segments)
+    lens = (C.c_long * n)(*[s[0].numel() for s in segments])
+    d = AdamWDesc(beta1, beta2, eps, weight_decay)
+    check(_lib.load().focal_adamw_multi(C.byref(d), n, arr(0), arr(1), arr(2), arr(3), arr(4) if has_shadow else None,
+                                        lens, _p(lr_dev), _p(rng_state), _stream()))
+
+
+# ------------------------------------------------------------------------------------------------ row 3
+_TWIDDLES = {}
+
+
+def _factor(n):
+    """n = n1 * n2 with n1 as close to sqrt(n) as possible (n2 = 1 -> direct DFT for short rows)."""
+    if n <= 64:
+        return n, 1
+    best = 1
+    for a in range(1, int(math.isqrt(n)) + 1):
+        if n % a == 0:
+            best = a
+    return n // best, best
+
+
+def fft_realpack(x):
+    """[B, C, I, n] real fp32 -> [B, 2C, I, n] (Re/Im channel pairs of the full two-sided spectrum)."""
+    _need_cuda(x)
+    B, Cc, I, n = x.shape
+    key = (n, x.device)
+    if key not in _TWIDDLES:
+        k = torch.arange(n, dtype=torch.float64)
+        ang = 2.0 * math.pi * k / n
+        _TWIDDLES[key] = torch.stack([torch.cos(ang), -torch.sin(ang)], 1).to(torch.float32).contiguous().to(x.device)
+    n1, n2 = _factor(n)
+    out = torch.empty(B, 2 * Cc, I, n, dtype=torch.float32, device=x.device)
+    d = FFTDesc(B, Cc, I, n, n1, n2)
+    check(_lib.load().focal_fft_realpack_fwd(C.byref(d), _p(x), _p(_TWIDDLES[key]), _p(out), _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ row 8
+def pad_patch_embed_ln(x, w, b, gamma, beta, Hp, Wp, pw, eps=1e-5):
+    _need_cuda(x, w, b, gamma, beta)
+    B, cin, I, S = x.shape
+    C0 = w.shape[0]
+    out = torch.empty(B * Hp * Wp, C0, dtype=torch.float32, device=x.device)
+    d = EmbedDesc(B, cin, I, S, Hp, Wp, pw, C0, eps)
+    check(_lib.load().focal_pad_patch_embed_ln_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(out), _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def ln_desc(dtype_code, rows, Cc, eps=1e-5, gather=None):
+    if gather is None:
+        return LNDesc(dtype_code, rows, Cc, eps, 0, 0, 0, 0, 0)
+    B, H, W, Cin = gather
+    return LNDesc(dtype_code, rows, Cc, eps, 1, B, H, W, Cin)
+
+
+def layernorm_fwd(x, gamma, beta, out_dtype, gather=None, desc=None):
+    """x fp32 [rows, C] (or [B, H, W, Cin] with gather=(B, H, W, Cin)) -> (y [rows, C] out_dtype, stats [rows, 2])."""
+    _need_cuda(x, gamma, beta)
+    if gather is None:
+        rows, Cc = x.shape
+    else:
+        B, H, W, Cin = gather
+        rows, Cc = B * (H // 2) * (W // 2), 4 * Cin
+    d = desc or ln_desc(code(out_dtype), rows, Cc, gather=gather)
+    y = torch.empty(rows, Cc, dtype=out_dtype, device=x.device)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    check(_lib.load().focal_layernorm_fwd(C.byref(d), _p(x), _p(gamma), _p(beta), _p(y), _p(stats), _stream()))
+    return y, stats
+
+
+def layernorm_bwd(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None):
+    _need_cuda(dy, x, stats, gamma, dx, dgamma, dbeta)
+    rows, Cc = dy.shape
+    d = desc or ln_desc(code(dy.dtype), rows, Cc, gather=gather)
+    check(_lib.load().focal_layernorm_bwd(C.byref(d), _p(dy), _p(x), _p(stats), _p(gamma), _p(dx), int(accumulate),
+                                          _p(dgamma), _p(dbeta), _stream()))
+
+
+# ------------------------------------------------------------------------------------------------ Linear family
+def linear_desc(dtype_code, M, N, K, x_dtype, y_dtype, act_in=ACT_NONE, epilogue=EPI_NONE, splits=1, in_drop=None,
+                out_drop=None):
+    return LinearDesc(dtype_code, M, N, K, x_dtype, y_dtype, act_in, epilogue, splits, in_drop or NO_DROP,
+                      out_drop or NO_DROP)
+
+
+def linear_fwd(d, x, w, bias, resid, y):
+    check(_lib.load().focal_linear_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(resid), _p(y), _stream()))
+
+
+def linear_bwd_data(d, dy, w, x, dx):
+    check(_lib.load().focal_linear_bwd_data(C.byref(d), _p(dy), _p(w), _p(x), _p(dx), _stream()))
+
+
+def linear_bwd_weight(d, dy, x, dw, dbias):
+    check(_lib.load().focal_linear_bwd_weight(C.byref(d), _p(dy), _p(x), _p(dw), _p(dbias), _stream()))
+
+
+def linear(x, w, bias=None, *, compute, y_dtype=None, resid=None, act_in=ACT_NONE, epilogue=EPI_NONE, splits=1,
+           in_drop=None, out_drop=None):
+    """Convenience forward: allocates y.  `compute` is the matrix-core operand dtype (torch.float32 / bfloat16)."""
+    _need_cuda(x, w, bias, resid)
+    M, K = x.shape
+    N = w.shape[0]
+    y_dtype = y_dtype or compute
+    d = linear_desc(code(compute), M, N, K, code(x.dtype), code(y_dtype), act_in, epilogue, splits, in_drop, out_drop)
+    y = (torch.zeros if splits > 1 else torch.empty)(M, N, dtype=y_dtype, device=x.device)
+    linear_fwd(d, x, w, bias, resid, y)
+    return y, d
+
+
+# ------------------------------------------------------------------------------------------------ row 10
+def attn_desc(dtype_code, B, H, W, Cc, heads, wh, ww, sh, sw, p_attn=0.0, rng=None, stream=0):
+    return AttnDesc(dtype_code, B, H, W, Cc, heads, wh, ww, sh, sw, p_attn, _p(rng), stream)
+
+
+def window_attn_fwd(d, qkv, bias_table, out):
+    check(_lib.load().focal_window_attn_fwd(C.byref(d), _p(qkv), _p(bias_table), _p(out), _stream()))
+
+
+def window_attn_bwd(d, qkv, bias_table, dout, dqkv, dbias_table):
+    check(_lib.load().focal_window_attn_bwd(C.byref(d), _p(qkv), _p(bias_table), _p(dout), _p(dqkv), _p(dbias_table),
+                                            _stream()))
+
+
+# ------------------------------------------------------------------------------------------------ rows 11-13
+_LOSS_WS = {}
+
+
+def loss_head(feats1, feats2, temperature, margin, weights, seq=4, no_private=False):
+    """feats{1,2}: lists (modality order) of fp32 [B, dim].  Returns (terms[5] device tensor, grads1, grads2)."""
+    feats = list(feats1) + list(feats2)
+    _need_cuda(*feats)
+    M = len(feats1)
+    B, dim = feats[0].shape
+    dev = feats[0].device
+    d = LossDesc(M, B, dim, seq, temperature, margin, weights[0], weights[1], weights[2], weights[3], int(no_private))
+    lib = _lib.load()
+    need = lib.focal_loss_head_workspace(C.byref(d))
+    if need == 0:
+        raise _lib.FocalHipError(f"loss_head: {lib.focal_last_error().decode()}")
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    ws = _LOSS_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _LOSS_WS[key] = ws
+    terms = torch.empty(5, dtype=torch.float32, device=dev)
+    grads = [torch.empty_like(f) for f in feats]
+    fa = (C.c_void_p * (2 * M))(*[_p(f) for f in feats])
+    ga = (C.c_void_p * (2 * M))(*[_p(g) for g in grads])
+    check(lib.focal_loss_head(C.byref(d), fa, _p(terms), ga, _p(ws), ws.numel(), _stream()))
+    return terms, grads[:M], grads[M:]

@@ -1,0 +1,63 @@
+"""Fused AdamW over the parameter arena (reference: torch.optim.AdamW built in train_utils/optimizer.py:27-32).
+
+Keeps the torch.optim.Optimizer surface the reference loop and timm-style schedulers use (`param_groups[i]["lr"]`,
+`zero_grad()`, `step()`), but `step()` is one streaming HIP kernel over the arena's hot region; parameters whose
+`.grad` is None (frozen patch embedding, unused heads) are skipped entirely, exactly as torch does.
+"""
+import torch
+
+from . import ops, runtime
+
+
+class FocalAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._lr_dev = None
+        self._lr_host = None
+
+    def _arenas(self):
+        arenas, seen = [], set()
+        for group in self.param_groups:
+            for p in group["params"]:
+                ar = getattr(p, "_focal_arena", None)
+                if ar is None or not ar.owns(p):
+                    if p.grad is not None:
+                        raise ops._lib.FocalHipError("FocalAdamW: a parameter with a gradient lives outside the arena")
+                    continue
+                if id(ar) not in seen:
+                    seen.add(id(ar))
+                    arenas.append(ar)
+        return arenas
+
+    def zero_grad(self, set_to_none=True):
+        # gradients are views of the arena's grad buffer: zero the buffer, keep the views
+        for ar in self._arenas():
+            ar.zero_grad()
+
+    def sync_lr(self):
+        """Push param_groups[0]['lr'] to the device scalar the kernel reads (call outside graph capture)."""
+        lr = float(self.param_groups[0]["lr"])
+        if self._lr_dev is None:
+            dev = self._arenas()[0].device
+            self._lr_dev = torch.empty(1, dtype=torch.float32, device=dev)
+        if lr != self._lr_host:
+            self._lr_dev.fill_(lr)
+            self._lr_host = lr
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        arenas = self._arenas()
+        if not arenas:
+            raise ops._lib.FocalHipError("FocalAdamW: no arena-backed parameters (run the backbone on the GPU first)")
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        g0 = self.param_groups[0]
+        runtime.advance_step(arenas[0].device)  # step counter (bias correction) + fresh dropout seed
+        segs = []
+        for ar in arenas:
+            m, v = ar.moments()
+            segs.append((ar.flat, ar.grad, m, v, ar.shadow))
+        ops.adamw_multi(segs, self._lr_dev, runtime.rng_state(arenas[0].device), g0["betas"][0], g0["betas"][1], g0["eps"],
+                        g0["weight_decay"])
+        for ar in arenas:
+            ar.mark_shadow_fresh()

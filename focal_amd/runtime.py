@@ -1,0 +1,34 @@
+"""Process-wide runtime state of the HIP path: compute dtype selection and the device RNG state."""
+import os
+
+import torch
+
+from . import ops
+
+_RNG = {}
+
+
+def compute_dtype_from(args=None):
+    """bf16 operands unless `args.compute_dtype` / $FOCAL_COMPUTE_DTYPE says fp32 (the exact-fp32 parity mode)."""
+    name = getattr(args, "compute_dtype", None) or os.environ.get("FOCAL_COMPUTE_DTYPE", "bf16")
+    name = str(name).lower().replace("torch.", "")
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if name in ("fp32", "f32", "float32"):
+        return torch.float32
+    raise ValueError(f"unknown compute dtype {name!r} (use bf16 or fp32)")
+
+
+def rng_state(device, seed=None):
+    """Device-resident {seed, step} words shared by every dropout site and by AdamW's bias correction."""
+    key = torch.device(device)
+    if key.index is None and key.type == "cuda":
+        key = torch.device("cuda", torch.cuda.current_device())
+    if key not in _RNG or seed is not None:
+        s = int.from_bytes(os.urandom(4), "little") if seed is None else seed
+        _RNG[key] = ops.new_rng_state(s & 0x7FFFFFFF, key)
+    return _RNG[key]
+
+
+def advance_step(device):
+    ops.rng_advance(rng_state(device))

@@ -1,0 +1,121 @@
+"""SW_Transformer backbone -- same constructor contract, forward signature, module tree and state_dict as the
+reference (models/SW_Transformer.py), executed on the MI355X HIP kernels.
+
+`forward(freq_x, class_head=False, proj_head=...)` is the FOCAL pretraining path (reference :210-268, :294-304).
+The classifier path (`class_head=True`, attention fusion + class layer) is outside the hot path and raises.
+"""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from focal_amd.backbone import HipBackbone, run_stage  # noqa: E402
+from focal_amd.swin_engine import ProjectorHead, SwinModEncoder  # noqa: E402
+from input_utils.padding_utils import get_padded_size  # noqa: E402
+from models.FusionModules import TransformerFusionBlock  # noqa: E402
+from models.SwinModules import BasicLayer, PatchEmbed, PatchMerging  # noqa: E402
+
+
+class SW_Transformer(HipBackbone):
+    def __init__(self, args) -> None:
+        super().__init__()
+        self.args = args
+        self.config = args.dataset_config["SW_Transformer"]
+        self.modalities = args.dataset_config["modality_names"]
+        self.locations = args.dataset_config["location_names"]
+        self.num_segments = args.dataset_config["num_segments"]
+        self.drop_rate = self.config["dropout_ratio"]
+        self.attn_drop_rate = self.config["attn_drop_rate"]
+        self.norm_layer = nn.LayerNorm
+        self._init_hip(args)
+        self.init_encoder()
+
+    def init_encoder(self) -> None:
+        cfg, dcfg = self.config, self.args.dataset_config
+        if len(self.locations) != 1:
+            raise NotImplementedError("the MI355X hot path covers single-location datasets (MOD); see DESIGN.md")
+        self.freq_interval_layers = nn.ModuleDict()
+        self.patch_embed = nn.ModuleDict()
+        self.absolute_pos_embed = nn.ModuleDict()
+        self.mod_patch_embed = nn.ModuleDict()
+        self.mod_in_layers = nn.ModuleDict()
+        self.geometry, self.block_windows, self.drop_path_rates = {}, {}, {}
+        c0 = cfg["time_freq_out_channels"]
+        for loc in self.locations:
+            self.freq_interval_layers[loc] = nn.ModuleDict()
+            self.patch_embed[loc] = nn.ModuleDict()
+            self.absolute_pos_embed[loc] = nn.ParameterDict()
+            self.mod_in_layers[loc] = nn.ModuleDict()
+            self.geometry[loc] = {}
+            for mod in self.modalities:
+                stride = cfg["in_stride"][mod]
+                if stride != 1:
+                    raise NotImplementedError("in_stride != 1 is not used by any shipped config")
+                spectrum = dcfg["loc_mod_spectrum_len"][loc][mod]
+                window, patch = list(cfg["window_size"][mod]), list(cfg["patch_size"]["freq"][mod])
+                depths = list(cfg["time_freq_block_num"][mod])
+                padded = get_padded_size((self.num_segments, spectrum // stride), window, patch, len(depths))
+                pe = PatchEmbed(img_size=padded, patch_size=patch, in_chans=dcfg["loc_mod_in_freq_channels"][loc][mod] * stride,
+                                embed_dim=c0, norm_layer=self.norm_layer)
+                self.patch_embed[loc][mod] = pe
+                grid = pe.patches_resolution
+                self.absolute_pos_embed[loc][mod] = nn.Parameter(torch.zeros(1, pe.num_patches, c0))
+                nn.init.trunc_normal_(self.absolute_pos_embed[loc][mod], std=0.02)
+                dpr = [x.item() for x in torch.linspace(0, cfg["drop_path_rate"], sum(depths))]
+                self.drop_path_rates[mod] = dpr
+                layers, stages = nn.ModuleList(), []
+                for i, depth in enumerate(depths):
+                    res, dim = (grid[0] // 2 ** i, grid[1] // 2 ** i), c0 * 2 ** i
+                    layer = BasicLayer(dim=dim, input_resolution=res, num_heads=cfg["time_freq_head_num"],
+                                       window_size=list(window), depth=depth, drop=self.drop_rate,
+                                       attn_drop=self.attn_drop_rate, drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])],
+                                       norm_layer=self.norm_layer, downsample=PatchMerging if i < len(depths) - 1 else None)
+                    layers.append(layer)
+                    stages.append(dict(H=res[0], W=res[1], C=dim, depth=depth, downsample=i < len(depths) - 1))
+                    for bi, blk in enumerate(layer.blocks):
+                        self.block_windows[(loc, mod, i, bi)] = (*blk.window_size, *blk.shift_size)
+                self.freq_interval_layers[loc][mod] = layers
+                last = stages[-1]
+                self.mod_in_layers[loc][mod] = nn.Linear(last["H"] * last["W"] * last["C"], cfg["loc_out_channels"])
+                self.geometry[loc][mod] = dict(grid=grid, patch=patch, window=window, stages=stages,
+                                               heads=cfg["time_freq_head_num"], pad_img=padded)
+                if spectrum // patch[1] > grid[1] or self.num_segments > grid[0]:
+                    raise ValueError("padded patch grid smaller than the input")
+        out_dim = dcfg["FOCAL"]["emb_dim"]
+        self.mod_projectors = nn.ModuleDict()
+        for mod in self.modalities:
+            self.mod_projectors[mod] = nn.Sequential(nn.Linear(cfg["loc_out_channels"], out_dim), nn.ReLU(),
+                                                     nn.Linear(out_dim, out_dim))
+        self.mod_fusion_layers = TransformerFusionBlock(cfg["loc_out_channels"], cfg["loc_head_num"],
+                                                        cfg["dropout_ratio"], cfg["dropout_ratio"])
+        self.sample_dim = cfg["loc_out_channels"]
+        n_cls = dcfg[self.args.task]["num_classes"]
+        if self.args.train_mode == "supervised" or cfg["pretrained_head"] == "linear":
+            self.class_layer = nn.Sequential(nn.Linear(self.sample_dim, n_cls))
+        else:
+            self.class_layer = nn.Sequential(nn.Linear(self.sample_dim, cfg["fc_dim"]), nn.GELU(), nn.Linear(cfg["fc_dim"], n_cls))
+        self._encoders = {(loc, mod): SwinModEncoder(self, loc, mod, mi)
+                          for loc in self.locations for mi, mod in enumerate(self.modalities)}
+        self._heads = {mod: ProjectorHead(self, mod) for mod in self.modalities}
+
+    def forward_encoder(self, freq_x, class_head=True, proj_head=False):
+        if class_head:
+            raise NotImplementedError("class_head=True (supervised / finetune head) is outside the MI355X FOCAL pretraining "
+                                      "hot path; use class_head=False")
+        loc = self.locations[0]
+        view = self._fwd_calls
+        self._fwd_calls = (self._fwd_calls + 1) & 0xFFFF
+        feats = {}
+        for mod in self.modalities:
+            feats[mod] = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
+        if not proj_head:
+            return feats
+        return {mod: run_stage(self, self._heads[mod], feats[mod]) for mod in self.modalities}
+
+    def forward(self, freq_x, class_head=True, proj_head=False):
+        return self.forward_encoder(freq_x, class_head, proj_head)

@@ -1,0 +1,52 @@
+"""FOCALLoss (reference: models/loss.py:8-218) on the fused HIP loss head.
+
+Same constructor and call contract: `FOCALLoss(args)(mod_features1, mod_features2) -> 0-dim tensor`.  The four
+un-weighted terms of the last call are kept in `last_terms` (device tensor [shared, private, orth, rank, total]);
+the reference only returns their weighted sum.
+"""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from focal_amd import ops  # noqa: E402
+
+
+class _LossHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, n_mod, *feats):
+        feats = [f.contiguous().float() for f in feats]
+        terms, g1, g2 = ops.loss_head(feats[:n_mod], feats[n_mod:], owner.temperature, owner.config["inter_rank_margin"],
+                                      owner.weights, owner.seq_len, owner.args.tag == "noPrivate")
+        owner.last_terms = terms
+        ctx.grads = g1 + g2
+        return terms[4]
+
+    @staticmethod
+    def backward(ctx, gout):
+        grads = [g * gout for g in ctx.grads]
+        ctx.grads = None
+        return (None, None, *grads)
+
+
+class FOCALLoss(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.config = args.dataset_config["FOCAL"]
+        self.modalities = args.dataset_config["modality_names"]
+        self.seq_len = args.dataset_config["seq_len"]
+        t = self.config["temperature"]
+        self.temperature = t[args.model] if isinstance(t, dict) else t
+        self.weights = (self.config["shared_contrastive_loss_weight"], self.config["private_contrastive_loss_weight"],
+                        self.config["orthogonal_loss_weight"], self.config["rank_loss_weight"])
+        self.last_terms = None
+
+    def forward(self, mod_features1, mod_features2, index=None):
+        feats = [mod_features1[m] for m in self.modalities] + [mod_features2[m] for m in self.modalities]
+        return _LossHeadFn.apply(self, len(self.modalities), *feats)

@@ -1,0 +1,22 @@
+"""Command-line surface (reference: params/base_params.py:10-85): the same single-dash flags."""
+import argparse
+
+
+def parse_base_args(option="train"):
+    p = argparse.ArgumentParser()
+    p.add_argument("-dataset", type=str, default="MOD", help="Dataset to evaluate.")
+    p.add_argument("-task", type=str, default=None, help="The downstream task to evaluate.")
+    p.add_argument("-learn_framework", type=str, default="no", help="No/Contrastive/Predictive/Reconstruction learning framework to use")
+    p.add_argument("-stage", type=str, default="pretrain", help="The pretrain/finetune, used for foundation model only.")
+    p.add_argument("-model", type=str, default="DeepSense", help="The backbone classification model to use.")
+    p.add_argument("-model_weight", type=str, default=None, help="Specify the model weight path to evaluate.")
+    p.add_argument("-batch_size", type=int, default=None, help="Specify the batch size for training.")
+    p.add_argument("-label_ratio", type=float, default=1.0, help="Only used in supervised training or finetune stage.")
+    p.add_argument("-gpu", type=str, default="0", help="Specify which GPU to use ('cpu' is rejected: HIP path only).")
+    p.add_argument("-tag", type=str, default=None, help="The tag of execution, for record only.")
+    p.add_argument("-compute_dtype", type=str, default=None, help="[build extension] bf16 (default) or fp32 matrix-core operands.")
+    p.add_argument("-epochs", type=int, default=None, help="[build extension] override train_epochs.")
+    p.add_argument("-synthetic_batches", type=int, default=8, help="[build extension] batches per synthetic epoch.")
+    args = p.parse_args()
+    args.option = option
+    return args

@@ -1,0 +1,190 @@
+"""Execution of one (location, modality) SW_Transformer encoder on the HIP kernels, forward and backward.
+
+The reference runs ~35 ATen ops per Swin block through autograd (models/SwinModules.py:294-343).  Here a block is
+7 kernels forward / 13 backward, launched back to back on the current stream with explicitly managed saved
+activations; torch.autograd only sees one node per encoder (see `EncoderFn` in models/SW_Transformer.py).
+
+Per block (M = B*H*W tokens, C channels, CT = matrix-core operand dtype):
+  forward   a1,st1 = LN(x) . qkv = a1 Wqkv^T + b . o = W-MSA(qkv) . x_mid = x + drop(o Wp^T + b)
+            a2,st2 = LN(x_mid) . u = a2 W1^T + b . x_out = x_mid + drop(drop(gelu(u)) W2^T + b)
+  saved     x, st1, a1, qkv, o, x_mid, st2, a2, u   (x fp32; a*, qkv, o, u in CT; GELU / dropout masks recomputed)
+  backward  the residual-gradient stream g (fp32 [M, C]) is updated in place through the block.
+"""
+import torch
+
+from . import ops
+from ._lib import ACT_GELU, ACT_NONE, EPI_NONE, EPI_RESIDUAL
+
+
+class SwinModEncoder:
+    def __init__(self, backbone, loc, mod, mod_index):
+        self.bb = backbone
+        self.loc, self.mod, self.mod_index = loc, mod, mod_index
+        self.geo = backbone.geometry[loc][mod]
+        self.pre = f"freq_interval_layers.{loc}.{mod}"
+
+    # ------------------------------------------------------------------ helpers
+    def _drop(self, rng, view, uid, site, p_elem, p_path, rows_per_sample):
+        base = ((view * 8 + self.mod_index) * 64 + uid) * 8
+        return ops.drop_desc(rng, base + site, p_elem, base + site + 4, p_path, rows_per_sample)
+
+    def forward(self, x_freq, view, training):
+        """x_freq: [B, c, i, s] fp32 -> (feat [B, loc_out] fp32, saved state for backward)."""
+        bb, geo, ar = self.bb, self.geo, self.bb.arena()
+        ct = bb.compute_dtype
+        cc = ops.code(ct)
+        f32 = ops.code(torch.float32)
+        rng = bb.rng_state() if training else None
+        B = x_freq.shape[0]
+        if x_freq.dtype != torch.float32 or not x_freq.is_contiguous():
+            x_freq = x_freq.float().contiguous()
+        pe = f"patch_embed.{self.loc}.{self.mod}"
+        P = bb.param  # cold parameters (frozen patch embedding) are read where they live
+        x = ops.pad_patch_embed_ln(x_freq, P(f"{pe}.proj.weight"), P(f"{pe}.proj.bias"), P(f"{pe}.norm.weight"),
+                                   P(f"{pe}.norm.bias"), geo["grid"][0], geo["grid"][1], geo["patch"][1])
+        if bb.config["APE"]:
+            raise ops._lib.FocalHipError("absolute position embedding (APE: True) is outside the HIP hot path")
+        p_drop = bb.drop_rate if training else 0.0
+        p_attn = bb.attn_drop_rate if training else 0.0
+        saved = {"B": B, "view": view, "training": training, "blocks": [], "merges": []}
+        uid = 0
+        for si, st in enumerate(geo["stages"]):
+            H, W, Cc = st["H"], st["W"], st["C"]
+            L = H * W
+            M = B * L
+            for bi in range(st["depth"]):
+                pb = f"{self.pre}.{si}.blocks.{bi}"
+                wh, ww, sh, sw = bb.block_windows[(self.loc, self.mod, si, bi)]
+                p_path = bb.drop_path_rates[self.mod][uid] if training else 0.0
+                a1, st1 = ops.layernorm_fwd(x, ar.master(f"{pb}.norm1.weight"), ar.master(f"{pb}.norm1.bias"), ct)
+                d_qkv = ops.linear_desc(cc, M, 3 * Cc, Cc, cc, cc)
+                qkv = torch.empty(M, 3 * Cc, dtype=ct, device=x.device)
+                ops.linear_fwd(d_qkv, a1, ar.operand(f"{pb}.attn.qkv.weight"), ar.master(f"{pb}.attn.qkv.bias"), None, qkv)
+                d_att = ops.attn_desc(cc, B, H, W, Cc, geo["heads"], wh, ww, sh, sw, p_attn, rng,
+                                      ((view * 8 + self.mod_index) * 64 + uid) * 8 + 3)
+                o = torch.empty(M, Cc, dtype=ct, device=x.device)
+                ops.window_attn_fwd(d_att, qkv, ar.master(f"{pb}.attn.relative_position_bias_table"), o)
+                d_proj = ops.linear_desc(cc, M, Cc, Cc, cc, f32, ACT_NONE, EPI_RESIDUAL,
+                                         out_drop=self._drop(rng, view, uid, 0, p_drop, p_path, L))
+                x_mid = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
+                ops.linear_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"), x, x_mid)
+                a2, st2 = ops.layernorm_fwd(x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
+                d_fc1 = ops.linear_desc(cc, M, 4 * Cc, Cc, cc, cc)
+                u = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)
+                ops.linear_fwd(d_fc1, a2, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"), None, u)
+                d_fc2 = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, f32, ACT_GELU, EPI_RESIDUAL,
+                                        in_drop=self._drop(rng, view, uid, 1, p_drop, 0.0, L),
+                                        out_drop=self._drop(rng, view, uid, 2, p_drop, p_path, L))
+                x_out = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
+                ops.linear_fwd(d_fc2, u, ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_mid, x_out)
+                saved["blocks"].append(dict(pb=pb, x=x, st1=st1, a1=a1, qkv=qkv, o=o, x_mid=x_mid, st2=st2, a2=a2, u=u,
+                                            d_qkv=d_qkv, d_att=d_att, d_proj=d_proj, d_fc1=d_fc1, d_fc2=d_fc2,
+                                            M=M, C=Cc))
+                x = x_out
+                uid += 1
+            if st["downsample"]:
+                pm = f"{self.pre}.{si}.downsample"
+                gather = (B, H, W, Cc)
+                a4, st4 = ops.layernorm_fwd(x, ar.master(f"{pm}.norm.weight"), ar.master(f"{pm}.norm.bias"), ct, gather=gather)
+                M4 = M // 4
+                d_red = ops.linear_desc(cc, M4, 2 * Cc, 4 * Cc, cc, f32)
+                x_next = torch.empty(M4, 2 * Cc, dtype=torch.float32, device=x.device)
+                ops.linear_fwd(d_red, a4, ar.operand(f"{pm}.reduction.weight"), None, None, x_next)
+                saved["merges"].append(dict(pm=pm, x=x, st4=st4, a4=a4, d_red=d_red, gather=gather, after_block=len(saved["blocks"])))
+                x = x_next
+        last = geo["stages"][-1]
+        K = last["H"] * last["W"] * last["C"]
+        pin = f"mod_in_layers.{self.loc}.{self.mod}"
+        n_out = bb.config["loc_out_channels"]
+        splits = max(1, min(32, K // 512))
+        d_in = ops.linear_desc(cc, B, n_out, K, f32, f32, splits=splits)
+        feat = torch.zeros(B, n_out, dtype=torch.float32, device=x.device)
+        ops.linear_fwd(d_in, x, ar.operand(f"{pin}.weight"), ar.master(f"{pin}.bias"), None, feat)
+        saved.update(x_final=x, d_in=d_in, pin=pin)
+        return feat, saved
+
+    def backward(self, saved, dfeat):
+        """Accumulates every parameter gradient of this encoder into the arena; returns nothing (input is a leaf)."""
+        bb, ar = self.bb, self.bb.arena()
+        ct = bb.compute_dtype
+        dev = dfeat.device
+        if dfeat.dtype != torch.float32 or not dfeat.is_contiguous():
+            dfeat = dfeat.float().contiguous()
+        pin, d_in, xf = saved["pin"], saved["d_in"], saved["x_final"]
+        d_in_b = ops.linear_desc(d_in.dtype, d_in.M, d_in.N, d_in.K, d_in.x_dtype, d_in.y_dtype)  # no split on the way back
+        ops.linear_bwd_weight(d_in_b, dfeat, xf, ar.g(f"{pin}.weight"), ar.g(f"{pin}.bias"))
+        g = torch.empty_like(xf)
+        ops.linear_bwd_data(d_in_b, dfeat, ar.operand(f"{pin}.weight"), None, g)
+        merges = {m["after_block"]: m for m in saved["merges"]}
+        for k in range(len(saved["blocks"]) - 1, -1, -1):
+            if (k + 1) in merges:  # a PatchMerging sits between block k and block k+1
+                mg = merges[k + 1]
+                pm, d_red = mg["pm"], mg["d_red"]
+                ops.linear_bwd_weight(d_red, g, mg["a4"], ar.g(f"{pm}.reduction.weight"), None)
+                da4 = torch.empty_like(mg["a4"])
+                ops.linear_bwd_data(d_red, g, ar.operand(f"{pm}.reduction.weight"), None, da4)
+                g = torch.empty_like(mg["x"])
+                ops.layernorm_bwd(da4, mg["x"], mg["st4"], ar.master(f"{pm}.norm.weight"), g, False,
+                                  ar.g(f"{pm}.norm.weight"), ar.g(f"{pm}.norm.bias"), gather=mg["gather"])
+            s = saved["blocks"][k]
+            pb, M, Cc = s["pb"], s["M"], s["C"]
+            # ---- MLP branch: x_out = x_mid + mask * (drop(gelu(u)) W2^T + b2)
+            ops.linear_bwd_weight(s["d_fc2"], g, s["u"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
+            du = torch.empty_like(s["u"])
+            ops.linear_bwd_data(s["d_fc2"], g, ar.operand(f"{pb}.mlp.fc2.weight"), s["u"], du)
+            ops.linear_bwd_weight(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
+            dc = torch.empty_like(s["a2"])
+            ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
+            del du
+            ops.layernorm_bwd(dc, s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g, True,
+                              ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"))
+            # ---- attention branch: x_mid = x + mask * (o Wp^T + bp)
+            ops.linear_bwd_weight(s["d_proj"], g, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
+            do = dc  # reuse the [M, C] CT buffer
+            ops.linear_bwd_data(s["d_proj"], g, ar.operand(f"{pb}.attn.proj.weight"), None, do)
+            dqkv = torch.empty_like(s["qkv"])
+            ops.window_attn_bwd(s["d_att"], s["qkv"], ar.master(f"{pb}.attn.relative_position_bias_table"), do, dqkv,
+                                ar.g(f"{pb}.attn.relative_position_bias_table"))
+            ops.linear_bwd_weight(s["d_qkv"], dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias"))
+            da = do
+            ops.linear_bwd_data(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), None, da)
+            del dqkv
+            ops.layernorm_bwd(da, s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g, True,
+                              ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"))
+            saved["blocks"][k] = None  # free this block's activations as we go
+        # g now holds dL/d(patch-embed tokens); the embedding is frozen and its input is a leaf -> stop here.
+
+
+class ProjectorHead:
+    """mod_projectors[mod] = Linear -> ReLU -> Linear (models/SW_Transformer.py:157-161, models/DeepSense.py:84-91);
+    fp32 activations, `compute` operands."""
+
+    def __init__(self, backbone, mod):
+        self.bb, self.mod = backbone, mod
+        self.pre = f"mod_projectors.{mod}"
+
+    def forward(self, feat):
+        bb, ar = self.bb, self.bb.arena()
+        cc, f32 = ops.code(bb.compute_dtype), ops.code(torch.float32)
+        B, K = feat.shape
+        E = ar.index[f"{self.pre}.0.weight"][2][0]
+        from ._lib import ACT_RELU_OUT, EPI_RELU
+        d0 = ops.linear_desc(cc, B, E, K, f32, f32, ACT_NONE, EPI_RELU)
+        h = torch.empty(B, E, dtype=torch.float32, device=feat.device)
+        ops.linear_fwd(d0, feat, ar.operand(f"{self.pre}.0.weight"), ar.master(f"{self.pre}.0.bias"), None, h)
+        d2 = ops.linear_desc(cc, B, E, E, f32, f32, ACT_RELU_OUT, EPI_NONE)
+        z = torch.empty(B, E, dtype=torch.float32, device=feat.device)
+        ops.linear_fwd(d2, h, ar.operand(f"{self.pre}.2.weight"), ar.master(f"{self.pre}.2.bias"), None, z)
+        return z, dict(feat=feat, h=h, d0=d0, d2=d2)
+
+    def backward(self, saved, dz):
+        ar = self.bb.arena()
+        if dz.dtype != torch.float32 or not dz.is_contiguous():
+            dz = dz.float().contiguous()
+        ops.linear_bwd_weight(saved["d2"], dz, saved["h"], ar.g(f"{self.pre}.2.weight"), ar.g(f"{self.pre}.2.bias"))
+        dh = torch.empty_like(saved["h"])
+        ops.linear_bwd_data(saved["d2"], dz, ar.operand(f"{self.pre}.2.weight"), saved["h"], dh)  # masked by h > 0
+        ops.linear_bwd_weight(saved["d0"], dh, saved["feat"], ar.g(f"{self.pre}.0.weight"), ar.g(f"{self.pre}.0.bias"))
+        dfeat = torch.empty_like(saved["feat"])
+        ops.linear_bwd_data(saved["d0"], dh, ar.operand(f"{self.pre}.0.weight"), None, dfeat)
+        return dfeat

@@ -1,0 +1,156 @@
+/* libfocal_hip -- C ABI of the MI355X (gfx950) FOCAL pretraining hot path.
+ *
+ * The reference (tomoyoshki/focal) is pure PyTorch and has no FFI of its own; its boundary for this path is the
+ * Python plugin surface (`src/train_utils/model_selection.py:14-59`, the modules under `src/models/`).  This library sits
+ * *underneath* that surface: the modules under `focal_amd/src/models/` keep the reference's classes / state-dict names and calls
+ * the entry points below through ctypes, one per ATen operator group the reference step executes
+ * (the reference site each entry replaces is cited on the declaration).
+ *
+ * Conventions (all entry points):
+ *   - plain C: pointers + sizes, no torch / C++ types;
+ *   - every tensor pointer is a CALLER-OWNED DEVICE pointer, row-major contiguous unless a leading dimension is
+ *     given; descriptor structs and pointer *arrays* live on the host;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); nothing allocates, frees or
+ *     synchronises, so every call is hipGraph-capturable;
+ *   - returns FOCAL_OK (0) or a negative error code; `focal_last_error()` gives a thread-local message;
+ *   - "dtype" is the storage type of activations and of the weight operand handed to the matrix cores:
+ *     FOCAL_F32 (exact-fp32 MFMA, the 1e-3 parity mode) or FOCAL_BF16 (bf16 operands, fp32 accumulate).
+ *     Residual streams, statistics, loss values, master weights, gradients and optimizer state are always fp32.
+ */
+#ifndef FOCAL_HIP_H
+#define FOCAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOCAL_ABI_VERSION 1
+
+enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
+enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
+
+int focal_abi_version(void);
+const char* focal_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ RNG state
+ * Device-resident {seed, step} pair (uint32[4], two words used).  Dropout masks are pure functions of
+ * (seed, stream id, element index): backward regenerates the forward mask, and a captured graph gets new masks
+ * on every replay because `focal_rng_advance` bumps the words on the device.  Replaces torch's Philox stream
+ * for nn.Dropout / DropPath (models/SwinModules.py:26,115,257; models/ConvModules.py:96). */
+int focal_rng_advance(uint32_t* state, void* stream);
+
+typedef struct {
+  const uint32_t* rng;   /* device RNG state or NULL (seed 0) */
+  uint32_t stream_elem;  /* stream id of the element-wise dropout */
+  float p_elem;          /* element-wise drop probability, 0 = off */
+  uint32_t stream_path;  /* stream id of the per-sample stochastic depth (DropPath) */
+  float p_path;          /* DropPath probability, 0 = off */
+  int rows_per_sample;   /* rows of the [M, N] activation that belong to one sample */
+} focal_drop_desc;
+
+/* ------------------------------------------------------------------------------------------------ row 3: FFT
+ * Augmenter.fft_preprocess (data_augmenter/Augmenter.py:141-158): full two-sided complex DFT of a real
+ * [B, C, I, n] tensor along n, packed as [B, 2C, I, n] (channel 2c = Re, 2c+1 = Im).  n = n1 * n2 (four-step
+ * DFT; n2 = 1 gives a direct DFT); `twiddle` is a device table of n {cos, -sin}(2 pi k / n) pairs. */
+typedef struct { int B, C, I, n, n1, n2; } focal_fft_desc;
+int focal_fft_realpack_fwd(const focal_fft_desc* d, const float* x, const float* twiddle, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ row 8: embed
+ * SW_Transformer.pad_input + PatchEmbed (models/SW_Transformer.py:184-208, models/SwinModules.py:547-558):
+ * zero-pad [B, cin, I, S] to (Hp*1, Wp*pw), Conv2d(cin -> C0, kernel = stride = [1, pw]), flatten, LayerNorm.
+ * Output tokens fp32 [B, Hp*Wp, C0].  Frozen in pretraining (general_utils/weight_utils.py:85-94): no backward. */
+typedef struct { int B, cin, I, S, Hp, Wp, pw, C0; float eps; } focal_embed_desc;
+int focal_pad_patch_embed_ln_fwd(const focal_embed_desc* d, const float* x, const float* w, const float* b,
+                                 const float* gamma, const float* beta, float* tokens, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ LayerNorm
+ * nn.LayerNorm(eps 1e-5) of models/SwinModules.py:253,258,376.  x fp32 [rows, C]; y `dtype`; stats fp32
+ * [rows, 2] = {mean, rstd}.  gather = 1 is PatchMerging's 2x2 gather fused in front of its LayerNorm
+ * (SwinModules.py:388-399): x is [B, H, W, Cin], rows = B*(H/2)*(W/2), C = 4*Cin.
+ * Backward: dx (fp32) += or = the input gradient (scattered back to [B, H, W, Cin] when gather = 1);
+ * dgamma / dbeta (fp32 [C]) are accumulated (+=). */
+typedef struct { int dtype; int rows, C; float eps; int gather; int B, H, W, Cin; } focal_ln_desc;
+int focal_layernorm_fwd(const focal_ln_desc* d, const float* x, const float* gamma, const float* beta, void* y,
+                        float* stats, void* stream);
+int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const float* x, const float* stats,
+                        const float* gamma, float* dx, int accumulate_dx, float* dgamma, float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ Linear family
+ * y[M, N] = epilogue( act_in(x)[M, K] . w[N, K]^T + bias ), i.e. nn.Linear of models/SwinModules.py:22-34,113-116,
+ * 375 and models/SW_Transformer.py:121-124,157-161, with the element-wise neighbours of each call site fused:
+ *   act_in   FOCAL_ACT_GELU      x is the pre-activation; GELU(erf) + `in_drop` applied while loading (Mlp.act/drop)
+ *            FOCAL_ACT_RELU_OUT  x is already a ReLU output (only matters for bwd_data: dx is masked by x > 0)
+ *   epilogue FOCAL_EPI_RESIDUAL  y = resid + out_drop(DropPath(.)): proj_drop / Mlp.drop + drop_path + shortcut
+ *            FOCAL_EPI_RELU      y = relu(.)
+ * x_dtype / y_dtype are FOCAL_F32 or `dtype`; w is `dtype` (the bf16 shadow of the fp32 master in bf16 mode).
+ * splits > 1 = split-K with fp32 atomics (y must be zeroed, fp32, epilogue NONE).
+ * bwd_data  : dx = [(dy * out_mask) . w] (* in_mask * gelu'(x) | * (x > 0));  dy has y's dtype, dx has x's dtype.
+ * bwd_weight: dw[N, K] += (dy * out_mask)^T . act_in(x);  dbias[N] += column sums (either may be NULL). */
+enum { FOCAL_ACT_NONE = 0, FOCAL_ACT_GELU = 1, FOCAL_ACT_RELU_OUT = 2 };
+enum { FOCAL_EPI_NONE = 0, FOCAL_EPI_RESIDUAL = 1, FOCAL_EPI_RELU = 2 };
+typedef struct {
+  int dtype;
+  int M, N, K;
+  int x_dtype, y_dtype;
+  int act_in, epilogue;
+  int splits;
+  focal_drop_desc in_drop, out_drop;
+} focal_linear_desc;
+int focal_linear_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias, const float* resid,
+                     void* y, void* stream);
+int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy, const void* w, const void* x, void* dx,
+                          void* stream);
+int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const void* x, float* dw, float* dbias,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------ row 10: W-MSA
+ * WindowAttention between its qkv and proj Linears (models/SwinModules.py:121-152) with the cyclic shift, window
+ * partition / reverse of SwinTransformerBlock.forward (:294-334) folded into the addressing: qkv is the token-major
+ * [B*H*W, 3C] output of the qkv Linear in ORIGINAL token order, out is [B*H*W, C] in original order.
+ * (sh, sw) > 0 on both axes = rolled windows + the -100 region mask of :262-289.  Attention dropout via rng. */
+typedef struct {
+  int dtype;
+  int B, H, W, C, heads;
+  int wh, ww, sh, sw;
+  float p_attn;
+  const uint32_t* rng;
+  uint32_t stream;
+} focal_attn_desc;
+int focal_window_attn_fwd(const focal_attn_desc* d, const void* qkv, const float* bias_table, void* out, void* stream);
+int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, const float* bias_table, const void* dout,
+                          void* dqkv, float* dbias_table, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ rows 11-13: loss
+ * FOCALLoss.forward (models/loss.py:139-218): 2 InfoNCE families on the shared / private halves, orthogonality,
+ * temporal ranking.  feats / dfeats are HOST arrays of 2*n_mod device pointers, view-major
+ * ([view0 mod0, view0 mod1, .., view1 mod0, ..]), each fp32 [B, dim]; B = b*seq whole subsequences.
+ * terms (device fp32[5]) = {shared, private, orth, rank, weighted total}; dfeats receive d total / d feat. */
+typedef struct {
+  int n_mod, B, dim, seq;
+  float temperature, margin;
+  float w_shared, w_private, w_orth, w_rank;
+  int no_private;  /* args.tag == "noPrivate": shared InfoNCE on the full features (loss.py:163-170) */
+} focal_loss_desc;
+size_t focal_loss_head_workspace(const focal_loss_desc* d);
+int focal_loss_head(const focal_loss_desc* d, const float* const* feats, float* terms, float* const* dfeats,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ row 14: AdamW
+ * torch.optim.AdamW (train_utils/optimizer.py:27-32) over `nseg` contiguous fp32 segments (the parameter arena's
+ * trainable region; grad-less parameters are simply not listed, which is how torch skips them).  lr comes from a
+ * device scalar and the step count from rng_state[1] (1-based after focal_rng_advance) so a captured graph stays
+ * valid across epochs.  shadow (nullable) receives the bf16 copy of the updated weights for the matrix cores. */
+typedef struct { float beta1, beta2, eps, weight_decay; } focal_adamw_desc;
+int focal_adamw_multi(const focal_adamw_desc* d, int nseg, float* const* p, const float* const* g, float* const* m,
+                      float* const* v, void* const* shadow_bf16, const long* n, const float* lr_dev,
+                      const uint32_t* rng_state, void* stream);
+/* fp32 -> bf16 cast of a weight segment (refreshing the shadow after load_state_dict) */
+int focal_cast_bf16(const float* src, void* dst, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOCAL_HIP_H */

@@ -1,0 +1,281 @@
+"""Per-kernel parity of the HIP ops (through the C ABI) against plain PyTorch references of the same op.
+fp32 mode must agree to ~1e-4 relative (exact-fp32 MFMA); bf16 mode to bf16 operand rounding."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2.5e-2}
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from focal_amd import ops as o
+    return o
+
+
+# ---------------------------------------------------------------------------------------------- linear family
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(4608, 192, 64), (1000, 64, 256), (144, 768, 256), (4608, 128, 512), (36, 64, 64)])
+def test_linear_fwd_plain(ops, ct, M, N, K):
+    x, w, b = rnd(M, K, seed=1, dtype=ct), rnd(N, K, scale=K ** -0.5, seed=2, dtype=ct), rnd(N, seed=3)
+    y, _ = ops.linear(x, w, b, compute=ct)
+    ref = x.float() @ w.float().t() + b
+    assert rel_err(y.float(), ref) < (1e-5 if ct == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+def test_linear_residual_and_gelu_prologue(ops, ct):
+    from focal_amd._lib import ACT_GELU, EPI_RESIDUAL
+    M, N, K = 1152, 64, 256
+    u, w, b, r = rnd(M, K, seed=4, dtype=ct), rnd(N, K, scale=K ** -0.5, seed=5, dtype=ct), rnd(N, seed=6), rnd(M, N, seed=7)
+    y, _ = ops.linear(u, w, b, compute=ct, y_dtype=torch.float32, resid=r, act_in=ACT_GELU, epilogue=EPI_RESIDUAL)
+    h = F.gelu(u.float())
+    if ct == torch.bfloat16:
+        h = h.bfloat16().float()
+    ref = r + h @ w.float().t() + b
+    assert rel_err(y, ref) < (1e-5 if ct == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+def test_linear_split_k_and_relu(ops, ct):
+    from focal_amd._lib import EPI_RELU
+    B, N, K = 16, 256, 4608
+    x, w, b = rnd(B, K, seed=8), rnd(N, K, scale=K ** -0.5, seed=9, dtype=ct), rnd(N, seed=10)
+    y, _ = ops.linear(x, w, b, compute=ct, y_dtype=torch.float32, splits=9)
+    xr = x if ct == torch.float32 else x.bfloat16().float()
+    ref = xr @ w.float().t() + b
+    assert rel_err(y, ref) < (1e-5 if ct == torch.float32 else 4e-3)
+    y2, _ = ops.linear(x[:, :256].contiguous(), w[:, :256].contiguous(), b, compute=ct, y_dtype=torch.float32, epilogue=EPI_RELU)
+    ref2 = F.relu(xr[:, :256] @ w[:, :256].float().t() + b)
+    assert rel_err(y2, ref2) < (1e-5 if ct == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(4608, 192, 64), (1000, 64, 256), (144, 256, 1024), (2304, 512, 128)])
+def test_linear_bwd(ops, ct, M, N, K):
+    x = rnd(M, K, seed=11, dtype=ct)
+    w = rnd(N, K, scale=K ** -0.5, seed=12, dtype=ct)
+    dy = rnd(M, N, seed=13, dtype=ct)
+    c = ops.code(ct)
+    d = ops.linear_desc(c, M, N, K, c, c)
+    dx = torch.empty(M, K, dtype=ct, device=DEV)
+    ops.linear_bwd_data(d, dy, w, None, dx)
+    assert rel_err(dx.float(), dy.float() @ w.float()) < (1e-5 if ct == torch.float32 else 6e-3)
+    dw = torch.zeros(N, K, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    ops.linear_bwd_weight(d, dy, x, dw, db)
+    assert rel_err(dw, dy.float().t() @ x.float()) < (2e-5 if ct == torch.float32 else 1e-4)
+    assert rel_err(db, dy.float().sum(0)) < 2e-5
+    # accumulation semantics: a second call adds
+    ops.linear_bwd_weight(d, dy, x, dw, db)
+    assert rel_err(dw, 2 * (dy.float().t() @ x.float())) < (2e-5 if ct == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+def test_linear_bwd_fc2_chain(ops, ct):
+    """fc2 of the Swin MLP: y = r + gelu(u) W^T + b with fp32 dy -> du (through gelu') and dW (with gelu(u))."""
+    from focal_amd._lib import ACT_GELU, EPI_RESIDUAL
+    M, N, K = 1152, 64, 256
+    u = rnd(M, K, seed=14, dtype=ct)
+    w = rnd(N, K, scale=K ** -0.5, seed=15, dtype=ct)
+    g = rnd(M, N, seed=16)
+    c, f32 = ops.code(ct), ops.code(torch.float32)
+    d = ops.linear_desc(c, M, N, K, c, f32, ACT_GELU, EPI_RESIDUAL)
+    du = torch.empty(M, K, dtype=ct, device=DEV)
+    ops.linear_bwd_data(d, g, w, u, du)
+    uf = u.float().requires_grad_(True)
+    gq = g if ct == torch.float32 else g.bfloat16().float()
+    h = F.gelu(uf)
+    (h @ w.float().t() * gq).sum().backward()
+    assert rel_err(du.float(), uf.grad) < (1e-5 if ct == torch.float32 else 8e-3)
+    dw = torch.zeros(N, K, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    ops.linear_bwd_weight(d, g, u, dw, db)
+    hq = h.detach() if ct == torch.float32 else h.detach().bfloat16().float()
+    assert rel_err(dw, gq.t() @ hq) < (2e-5 if ct == torch.float32 else 2e-4)
+    assert rel_err(db, gq.sum(0)) < 1e-4
+
+
+def test_linear_relu_out_bwd(ops):
+    ct = torch.float32
+    B, E = 32, 256
+    h = F.relu(rnd(B, E, seed=17))
+    w, dz = rnd(E, E, scale=E ** -0.5, seed=18), rnd(B, E, seed=19)
+    from focal_amd._lib import ACT_RELU_OUT
+    f32 = ops.code(ct)
+    d = ops.linear_desc(f32, B, E, E, f32, f32, ACT_RELU_OUT)
+    dh = torch.empty(B, E, device=DEV)
+    ops.linear_bwd_data(d, dz, w, h, dh)
+    assert rel_err(dh, (dz @ w) * (h > 0)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- layer norm
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(4608, 64), (1153, 128), (300, 256), (77, 512)])
+def test_layernorm(ops, ct, rows, C):
+    x, g, b = rnd(rows, C, scale=2.0, seed=20) + 0.5, 1 + 0.1 * rnd(C, seed=21), 0.1 * rnd(C, seed=22)
+    y, stats = ops.layernorm_fwd(x, g, b, ct)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    assert rel_err(y.float(), ref) < (1e-5 if ct == torch.float32 else 4e-3)
+    assert rel_err(stats[:, 0], x.mean(1)) < 1e-5
+    dy = rnd(rows, C, seed=23, dtype=ct)
+    ref.backward(dy.float())
+    dx = rnd(rows, C, seed=24)
+    base = dx.clone()
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.layernorm_bwd(dy, x, stats, g, dx, True, dg, db)
+    assert rel_err(dx - base, xr.grad) < 2e-5
+    assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+def test_layernorm_patch_merge_gather(ops, ct):
+    B, H, W, Cin = 3, 6, 24, 64
+    x = rnd(B, H, W, Cin, seed=25)
+    g, b = 1 + 0.1 * rnd(4 * Cin, seed=26), 0.1 * rnd(4 * Cin, seed=27)
+    y, stats = ops.layernorm_fwd(x.view(-1, Cin), g, b, ct, gather=(B, H, W, Cin))
+    xr = x.clone().requires_grad_(True)
+    cat = torch.cat([xr[:, 0::2, 0::2], xr[:, 1::2, 0::2], xr[:, 0::2, 1::2], xr[:, 1::2, 1::2]], -1).view(-1, 4 * Cin)
+    ref = F.layer_norm(cat, (4 * Cin,), g, b, 1e-5)
+    assert rel_err(y.float(), ref) < (1e-5 if ct == torch.float32 else 4e-3)
+    dy = rnd(y.shape[0], 4 * Cin, seed=28, dtype=ct)
+    ref.backward(dy.float())
+    dx = torch.full_like(x, 7.0)
+    dg, db = torch.zeros(4 * Cin, device=DEV), torch.zeros(4 * Cin, device=DEV)
+    ops.layernorm_bwd(dy, x.view(-1, Cin), stats, g, dx, False, dg, db, gather=(B, H, W, Cin))
+    assert rel_err(dx, xr.grad) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------- window attention
+def _ref_window_attn(qkv, table, B, H, W, C, heads, wh, ww, sh, sw):
+    from oracle.swt import _from_windows, _to_windows, relative_position_index, shifted_window_mask
+    hd = C // heads
+    x = qkv.view(B, H, W, 3 * C)
+    shifted = sh > 0 and sw > 0
+    if shifted:
+        x = torch.roll(x, shifts=(-sh, -sw), dims=(1, 2))
+    xw = _to_windows(x, wh, ww)
+    Bw, N, _ = xw.shape
+    q, k, v = xw.view(Bw, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    idx = relative_position_index(wh, ww).to(qkv.device)
+    attn = attn + table[idx.reshape(-1)].view(N, N, heads).permute(2, 0, 1)[None]
+    if shifted:
+        mask = shifted_window_mask(H, W, wh, ww, sh, sw).to(qkv.device)
+        nW = mask.shape[0]
+        attn = (attn.view(Bw // nW, nW, heads, N, N) + mask[None, :, None]).view(-1, heads, N, N)
+    out = (attn.softmax(-1) @ v).transpose(1, 2).reshape(Bw, N, C)
+    y = _from_windows(out, wh, ww, H, W)
+    if shifted:
+        y = torch.roll(y, shifts=(sh, sw), dims=(1, 2))
+    return y.reshape(B * H * W, C)
+
+
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,W,C,sh,sw", [(12, 48, 64, 0, 0), (12, 48, 64, 1, 1), (6, 12, 128, 1, 1), (3, 6, 256, 0, 0), (3, 12, 256, 0, 1)])
+def test_window_attention(ops, ct, H, W, C, sh, sw):
+    B, heads, wh, ww = 5, 4, 3, 3
+    M = B * H * W
+    qkv = rnd(M, 3 * C, seed=30, dtype=ct)
+    table = rnd(25, heads, scale=0.5, seed=31)
+    c = ops.code(ct)
+    d = ops.attn_desc(c, B, H, W, C, heads, wh, ww, sh, sw)
+    out = torch.empty(M, C, dtype=ct, device=DEV)
+    ops.window_attn_fwd(d, qkv, table, out)
+    q32 = qkv.float().requires_grad_(True)
+    t32 = table.clone().requires_grad_(True)
+    ref = _ref_window_attn(q32, t32, B, H, W, C, heads, wh, ww, sh, sw)
+    assert rel_err(out.float(), ref) < (2e-5 if ct == torch.float32 else 5e-3)
+    do = rnd(M, C, seed=32, dtype=ct)
+    ref.backward(do.float())
+    dqkv = torch.empty_like(qkv)
+    dt = torch.zeros_like(table)
+    ops.window_attn_bwd(d, qkv, table, do, dqkv, dt)
+    assert rel_err(dqkv.float(), q32.grad) < (3e-5 if ct == torch.float32 else 8e-3)
+    assert rel_err(dt, t32.grad) < (1e-4 if ct == torch.float32 else 5e-3)
+
+
+# ---------------------------------------------------------------------------------------------- embed / fft
+@pytest.mark.parametrize("S,pw,Hp,Wp,cin", [(1600, 40, 12, 48, 2), (20, 1, 12, 24, 2)])
+def test_pad_patch_embed_ln(ops, S, pw, Hp, Wp, cin):
+    B, I, C0 = 3, 10, 64
+    x = rnd(B, cin, I, S, scale=20.0, seed=40)
+    w, b = rnd(C0, cin, 1, pw, scale=(cin * pw) ** -0.5, seed=41), rnd(C0, seed=42)
+    g, be = 1 + 0.1 * rnd(C0, seed=43), 0.1 * rnd(C0, seed=44)
+    out = ops.pad_patch_embed_ln(x, w, b, g, be, Hp, Wp, pw)
+    xp = F.pad(x, (0, Wp * pw - S, 0, Hp - I))
+    ref = F.conv2d(xp, w, b, stride=(1, pw)).flatten(2).transpose(1, 2)
+    ref = F.layer_norm(ref, (C0,), g, be, 1e-5).reshape(-1, C0)
+    assert (out - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("n", [1600, 20, 64, 360])
+def test_fft_realpack(ops, n):
+    x = rnd(3, 2, 10, n, seed=50)
+    out = ops.fft_realpack(x)
+    f = torch.view_as_real(torch.fft.fft(x.double(), dim=-1))
+    ref = f.permute(0, 1, 4, 2, 3).reshape(3, 4, 10, n)
+    assert (out.double() - ref).abs().max().item() < 2e-4 * math.sqrt(n)
+
+
+# ---------------------------------------------------------------------------------------------- optimizer / rng
+def test_adamw_matches_torch(ops):
+    n = 4096 + 8
+    p0, g = rnd(n, seed=60), rnd(n, seed=61)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-3, weight_decay=0.05)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    state = ops.new_rng_state(123, DEV)
+    lr = torch.full((1,), 1e-3, device=DEV)
+    for it in range(3):
+        pt.grad = g * (it + 1)
+        opt.step()
+        ops.rng_advance(state)
+        ops.adamw_multi([(p, g * (it + 1), m, v, shadow)], lr, state)
+    assert (p - pt.detach()).abs().max().item() < 1e-6
+    assert torch.equal(shadow, p.bfloat16())
+    assert int(state[1]) == 3
+
+
+def test_dropout_statistics_and_replay(ops):
+    """Dropout / DropPath masks: right keep-rate, 1/(1-p) scaling, identical between the forward epilogue and the
+    backward loader, and different after the seed advances."""
+    from focal_amd._lib import EPI_RESIDUAL
+    M, N, K, L = 4096, 64, 64, 64
+    state = ops.new_rng_state(7, DEV)
+    x = torch.ones(M, K, device=DEV)
+    w = torch.eye(N, K, device=DEV)
+    r = torch.zeros(M, N, device=DEV)
+    dd = ops.drop_desc(state, 11, 0.2, 12, 0.1, L)
+    y, d = ops.linear(x, w, None, compute=torch.float32, y_dtype=torch.float32, resid=r, epilogue=EPI_RESIDUAL, out_drop=dd)
+    vals = y.unique()
+    assert len(vals) == 2 and vals[0] == 0 and abs(vals[1].item() - 1 / (0.8 * 0.9)) < 1e-5
+    keep_rows = (y.view(M // L, L * N).abs().sum(1) > 0).float().mean().item()
+    assert abs(keep_rows - 0.9) < 0.12
+    kept = y.view(M // L, L * N)[y.view(M // L, L * N).abs().sum(1) > 0]
+    assert abs((kept > 0).float().mean().item() - 0.8) < 0.01
+    # backward sees the same mask: dx = (dy * mask) @ w with w = I
+    dx = torch.empty(M, K, device=DEV)
+    ops.linear_bwd_data(d, torch.ones(M, N, device=DEV), w, None, dx)
+    assert torch.equal(dx > 0, y > 0)
+    ops.rng_advance(state)
+    y2, _ = ops.linear(x, w, None, compute=torch.float32, y_dtype=torch.float32, resid=r, epilogue=EPI_RESIDUAL, out_drop=dd)
+    assert not torch.equal(y2 > 0, y > 0)
