@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""FOCAL pretraining throughput on MI355X: windows/sec of the full step (DFT of both views -> backbone x2 ->
+FOCAL loss head -> backward -> fused AdamW), BASELINE.json's metric.
+
+  python bench.py [--gpus N --steps K --warmup W] [--model SW_Transformer|DeepSense] [--batch 256] [--dtype bf16|fp32]
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+Workload (config.workload): BASELINE.json configs[2] at N=1 -- SW_Transformer + FOCAL, bf16 operands, 256 synthetic
+MOD-shaped 2-modality windows per GPU (audio [1,10,1600] @ 8 kHz, seismic [1,10,20] @ 100 Hz, N(0,1), 64
+subsequences of 4), train mode (dropout 0.2 / attention dropout 0.2 / drop-path 0.1 active), random-init weights.
+Views: view 1 = the window, view 2 = the window negated and scaled by 1.1 (two of the reference's FOCAL augmenters
+with fixed draws), each followed by the time->frequency DFT, which is inside the timed step.  N > 1 = configs[3]:
+embeddings all-gathered over RCCL so the loss sees the global batch, gradients all-reduced; weak scaling.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "focal_amd", "src")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_WINDOW = {"SW_Transformer": 4.376e9, "DeepSense": 0.809e9}  # SURVEY 8d (fwd+bwd, both views)
+HBM_PEAK_GBS = 8000.0
+MFMA_BF16_PEAK_TF = 2500.0
+MFMA_F32_PEAK_TF = 157.3
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--model", default="SW_Transformer")
+    p.add_argument("--batch", type=int, default=256, help="windows per GPU")
+    p.add_argument("--dtype", default="bf16")
+    p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=4)
+    return p.parse_args()
+
+
+def make_args(cfg, model, device, dtype):
+    return argparse.Namespace(model=model, dataset="MOD", device=device, train_mode="contrastive", learn_framework="FOCAL",
+                              stage="pretrain", task="vehicle_classification", tag=None, dataset_config=cfg,
+                              compute_dtype=dtype)
+
+
+class Step:
+    """One pretraining step on resident time-domain windows (the reference loop body, train_utils/pretrain.py:62-74)."""
+
+    def __init__(self, a, device):
+        from focal_amd import ops
+        from focal_amd.distributed import gather_features
+        from general_utils.weight_utils import freeze_patch_embedding
+        from oracle.config import load_config  # config loader only (YAML); no oracle arithmetic on this path
+        from train_utils.model_selection import init_backbone_model, init_loss_func, init_pretrain_framework
+        from train_utils.optimizer import define_optimizer
+        self.ops, self.gather = ops, gather_features
+        cfg = load_config()
+        self.cfg = cfg
+        args = make_args(cfg, a.model, device, a.dtype)
+        torch.manual_seed(1234)
+        self.backbone = init_backbone_model(args)
+        self.model = init_pretrain_framework(args, self.backbone)
+        self.loss_fn = init_loss_func(args)
+        self.opt = define_optimizer(args, self.model.parameters())
+        freeze_patch_embedding(args, self.model)
+        self.model.train()
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        g = torch.Generator().manual_seed(1234 + rank)
+        self.x = {}
+        for loc in cfg["location_names"]:
+            self.x[loc] = {}
+            for mod in cfg["modality_names"]:
+                shape = (a.batch, cfg["loc_mod_in_time_channels"][loc][mod], cfg["num_segments"], cfg["loc_mod_spectrum_len"][loc][mod])
+                self.x[loc][mod] = torch.randn(shape, generator=g).to(device)
+        self.loss = torch.zeros((), device=device)
+
+    def views(self):
+        v1 = {l: {m: self.ops.fft_realpack(x) for m, x in mm.items()} for l, mm in self.x.items()}
+        v2 = {l: {m: self.ops.fft_realpack(x * -1.1) for m, x in mm.items()} for l, mm in self.x.items()}
+        return v1, v2
+
+    def run(self):
+        self.opt.zero_grad()
+        v1, v2 = self.views()
+        f1, f2 = self.model(v1, v2, proj_head=True)
+        f1, f2 = self.gather([f1, f2])
+        loss = self.loss_fn(f1, f2)
+        loss.backward()
+        self.opt.step()
+        self.loss.copy_(loss.detach())
+
+
+def time_kernel(fn, iters=20):
+    """Average duration (ms) of one launch of `fn` on the current stream, HIP events on that stream."""
+    st = torch.cuda.current_stream()
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def roofline(a, step, device):
+    """Live measurement of the dominant kernel: the stage-0 audio MLP up-projection GEMM family
+    (focal_gemm_kernel, M = B*576 tokens, K = 64 -> N = 256).  At K = 64 the GEMM is HBM-bound: algorithmic bytes =
+    read A [M,K] + write C [M,N] (+ the 32 KB weight) in the operand dtype."""
+    ops = step.ops
+    ct = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    es = 2 if ct == torch.bfloat16 else 4
+    geo = step.backbone.geometry["shake"]["audio"]["stages"][0] if a.model == "SW_Transformer" else None
+    if geo is None:
+        return None
+    M, K, N = a.batch * geo["H"] * geo["W"], geo["C"], 4 * geo["C"]
+    x = torch.randn(M, K, device=device).to(ct)
+    w = (torch.randn(N, K, device=device) * K ** -0.5).to(ct)
+    b = torch.zeros(N, device=device)
+    y = torch.empty(M, N, dtype=ct, device=device)
+    d = ops.linear_desc(ops.code(ct), M, N, K, ops.code(ct), ops.code(ct))
+    ms = time_kernel(lambda: ops.linear_fwd(d, x, w, b, None, y))
+    bytes_alg = (M * K + M * N + N * K) * es + N * 4
+    flops = 2.0 * M * N * K
+    gbs = bytes_alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "focal_gemm_kernel<fwd, LN-out -> fc1> M=%d K=%d N=%d" % (M, K, N), "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "ms_per_launch": round(ms, 5), "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+
+
+def cpu_baseline(a, cfg):
+    """The oracle (CPU restatement of the reference step: "port") timed on this box's host cores, bounded sample."""
+    from oracle.step import OracleTrainer
+    from oracle.weights import seeded_values, swt_state_spec, deepsense_state_spec, synthetic_time_input
+    spec = swt_state_spec(cfg) if a.model == "SW_Transformer" else deepsense_state_spec(cfg)
+    state = {}
+    for k, shp in spec.items():
+        if k.endswith(("relative_position_index", "num_batches_tracked")):
+            state[k] = torch.zeros(shp, dtype=torch.long)
+        elif k.endswith("attn_mask"):
+            state[k] = torch.zeros(shp)
+        else:
+            state[k] = seeded_values(k, shp)
+    # torch's CPU kernels stop scaling (and collapse under oversubscription) long before a 256-thread host is full:
+    # use at most 32 threads and say so
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    B = 32
+    tr = OracleTrainer(a.model, cfg, state)
+    x = synthetic_time_input(cfg, B, 5)
+    t0 = time.time()
+    tr.step(time_x=x)  # warm-up
+    warm = time.time() - t0
+    t0 = time.time()
+    n = 0
+    while n < a.cpu_steps and (time.time() - t0) + warm < 25:
+        tr.step(time_x=x)
+        n += 1
+    dt = time.time() - t0
+    if n == 0:
+        n, dt = 1, warm
+    return {"value": round(B * n / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of batch {B} (fp32, FFT+fwd x2+loss+bwd+AdamW, dropout off) after 1 warm-up"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    rank = dist.get_rank() if world > 1 else 0
+    step = Step(a, device)
+
+    graphed = False
+    run = step.run
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step.run()  # builds the arena / moments / workspaces outside capture
+        torch.cuda.synchronize()
+        if not a.no_graph and world == 1:
+            try:
+                step.opt.sync_lr()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    step.run()
+                run, graphed = graph.replay, True
+            except Exception as e:  # noqa: BLE001
+                if rank == 0:
+                    print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                torch.cuda.synchronize()
+        for _ in range(a.warmup):
+            run()
+            step.loss.item()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run()
+            step.loss.item()  # the reference syncs on loss.item() every step (pretrain.py:74)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    last_loss = step.loss.item()
+    rl = roofline(a, step, device) if rank == 0 else None
+    cb = cpu_baseline(a, step.cfg) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
+    if rank == 0:
+        wps = a.batch * world * a.steps / dt
+        out = {"metric": "pretrain windows/sec (whole node), FOCAL " + a.model, "value": round(wps, 1), "unit": "windows/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": f"{a.model} + FOCAL pretrain step, {a.batch} MOD-shaped 2-modality windows/GPU "
+                                      f"(global batch {a.batch * world}), train mode, DFT + fwd x2 + loss + bwd + AdamW",
+                          "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graphed,
+                          "views": "identity / negate*1.1, then DFT", "last_loss": round(last_loss, 4)},
+               "model_flops_frac_of_bf16_mfma_peak": round(wps / world * FLOP_PER_WINDOW[a.model] / (MFMA_BF16_PEAK_TF * 1e12), 5),
+               "roofline": rl, "cpu_baseline": cb}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

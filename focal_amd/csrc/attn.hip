@@ -222,12 +222,9 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
       float dq[HD];
 #pragma unroll
       for (int d = 0; d < HD; ++d) dq[d] = 0.f;
-      const int iy = i / g.ww, ix = i % g.ww;
       _Pragma("unroll") for (int j = 0; j < NT; ++j) if (j < g.N) {
         const float ds = p[j] * (dp[j] - dot);  // softmax backward
         dS[((wl * g.heads + h) * g.N + i) * g.N + j] = ds;
-        const int rel = (iy - j / g.ww + g.wh - 1) * (2 * g.ww - 1) + (ix - j % g.ww + g.ww - 1);
-        atomicAdd(&dbacc[rel * g.heads + h], ds);
         const float* kj = lw + j * pitch + C + h * HD;
 #pragma unroll
         for (int d = 0; d < HD; d += 4) {
@@ -243,6 +240,14 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
       }
     }
     __syncthreads();
+    // relative-position-bias gradient: sum dS over this group's windows first, then ONE LDS add per (head, i, j)
+    for (int t = tid; t < g.heads * NN; t += blockDim.x) {
+      const int hh = t / NN, ij = t % NN, ii = ij / g.N, jj = ij % g.N;
+      float sacc = 0.f;
+      for (int w = 0; w < nwin; ++w) sacc += dS[(w * g.heads + hh) * NN + ij];
+      const int rel = (ii / g.ww - jj / g.ww + g.wh - 1) * (2 * g.ww - 1) + (ii % g.ww - jj % g.ww + g.ww - 1);
+      atomicAdd(&dbacc[rel * g.heads + hh], sacc);
+    }
     if (active) {
       // this thread now owns key/value row j = i:  dK_j = sum_i dS[i][j] q'_i,  dV_j = sum_i Pd[i][j] dO_i
       const int j = i;

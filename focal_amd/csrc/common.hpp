@@ -68,11 +68,25 @@ __device__ __forceinline__ float drop_mult(const DropCtx& d, uint32_t idx) {
   return ((h >> 8) < d.thresh) ? 0.0f : d.scale;
 }
 
-// exact-erf GELU and its derivative (nn.GELU(approximate="none"))
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-form GELU and its derivative (nn.GELU(approximate="none")).  erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7,
+// one v_exp + one v_rcp): libm erff costs ~3x more VALU and these sit in GEMM prologues / epilogues.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);  // = exp(-x^2 / 2)
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  pdf = 0.39894228040143268f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
   return cdf + x * pdf;
 }
 

@@ -225,7 +225,11 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   using FB = FragLoad<CT, TRB, StB::PITCH>;
   constexpr int TM = BM / 32, TN = BN / 32;
 
-  __shared__ __attribute__((aligned(16))) CT lds[StA::LDS_ELEMS + StB::LDS_ELEMS];
+  constexpr int OPER_BYTES = (StA::LDS_ELEMS + StB::LDS_ELEMS) * (int)sizeof(CT);
+  constexpr int STAGE_BYTES = (EPI == EPI_ATOMIC) ? 4 * 32 * (BN / 2 + 4) * 4 : 0;  // atomic epilogue staging
+  constexpr int LDS_BYTES = OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
+  CT* lds = reinterpret_cast<CT*>(lds_raw);
   CT* ldsA = lds;
   CT* ldsB = lds + StA::LDS_ELEMS;
 
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
 
   // ---- epilogue: lane holds C[m][n..n+3] for m = ..+(lane&15), n = ..+(lane>>4)*4
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < (EPI == EPI_ATOMIC ? 0 : TM); ++i) {
     const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
     if (m >= p.M) continue;
     float rowm = 1.f;
@@ -312,11 +316,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
       const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
       if (n >= p.N) continue;
       f32x4 v = acc[i][j] * p.alpha;
-      if (EPI != EPI_ATOMIC) {
-        if (p.bias) v += load4(p.bias + n);
-      } else if (p.bias && sp == 0) {
-        v += load4(p.bias + n);
-      }
+      if (p.bias) v += load4(p.bias + n);
       if (EPI == EPI_STORE) {
         store4(C + (long)m * p.ldc + n, v);
       } else if (EPI == EPI_RESID) {
@@ -338,10 +338,40 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
         store4(C + (long)m * p.ldc + n, v);
-      } else {  // EPI_ATOMIC (fp32 output only)
-        float* c = reinterpret_cast<float*>(C) + (long)m * p.ldc + n;
+      }
+    }
+  }
+  if (EPI == EPI_ATOMIC) {
+    // fp32 atomics run at full rate only when one wave-instruction covers 256 contiguous bytes (or two 128-B row
+    // segments); the MFMA register layout would instead scatter each instruction over 16 rows x 4 dwords (~17x
+    // slower).  So each wave transposes its sub-tile through a private LDS region, 32 rows per pass, and issues
+    // the adds row by row with lane = consecutive column.
+    constexpr int WN = BN / 2, WPITCH = WN + 4;
+    float* stage = reinterpret_cast<float*>(lds) + wave * 32 * WPITCH;
+    float* Cf = reinterpret_cast<float*>(C);
+    const bool add_bias = p.bias && sp == 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+    for (int pass = 0; pass < TM / 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const f32x4 v = acc[pass * 2 + ii][j] * p.alpha;
+          *reinterpret_cast<float4*>(stage + (ii * 16 + (lane & 15)) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      __syncthreads();
+      constexpr int RPI = 64 / WN;  // rows per wave-instruction (1 or 2)
+#pragma unroll 4
+      for (int rr = 0; rr < 32; rr += RPI) {
+        const int row = rr + lane / WN, col = lane % WN;
+        const int m = m0 + wm * (BM / 2) + pass * 32 + row, n = n0 + wn * WN + col;
+        if (m < p.M && n < p.N) {
+          float v = stage[row * WPITCH + col];
+          if (add_bias) v += p.bias[n];
+          atomicAdd(Cf + (long)m * p.ldc + n, v);
+        }
       }
     }
   }

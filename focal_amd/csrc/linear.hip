@@ -114,10 +114,11 @@ extern "C" int focal_linear_bwd_weight(const focal_linear_desc* d, const void* d
   p.B = x; p.ldb = d->K;
   p.C = dw; p.ldc = d->K;
   p.batch = 1; p.alpha = 1.f;
-  // enough reduction chunks to fill the chip: ~1024 workgroups, at least 512 rows each
+  // reduction chunks: ~512 workgroups of one 64x64 tile each (2 per CU), at least 256 rows per chunk; the atomic
+  // volume is then ~512 x 16 KB = 8 MB per call whatever the weight shape
   const long tiles = (long)ceil_div(d->N, 64) * ceil_div(d->K, 64);
-  long splits = (1024 + tiles - 1) / tiles;
-  const long max_splits = (d->M + 511) / 512;
+  long splits = (512 + tiles - 1) / tiles;
+  const long max_splits = (d->M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   p.splits = (int)splits;

@@ -6,7 +6,7 @@ Keeps the torch.optim.Optimizer surface the reference loop and timm-style schedu
 """
 import torch
 
-from . import ops, runtime
+from . import distributed, ops, runtime
 
 
 class FocalAdamW(torch.optim.Optimizer):
@@ -51,6 +51,8 @@ class FocalAdamW(torch.optim.Optimizer):
             raise ops._lib.FocalHipError("FocalAdamW: no arena-backed parameters (run the backbone on the GPU first)")
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
+        for ar in arenas:
+            distributed.all_reduce_gradients(ar)  # data parallel: exact global-batch gradient = sum over ranks
         g0 = self.param_groups[0]
         runtime.advance_step(arenas[0].device)  # step counter (bias correction) + fresh dropout seed
         segs = []

@@ -1,0 +1,84 @@
+"""Loss head (rows 11-13) through the C ABI vs the oracle restatement and the committed reference fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _views(B, mods, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    f1 = {m: torch.randn(B, 256, generator=g) * scale for m in mods}
+    f2 = {m: torch.randn(B, 256, generator=g) * scale for m in mods}
+    for m in mods:
+        f2[m] = 0.5 * f2[m] + 0.5 * f1[m]
+    return f1, f2
+
+
+@pytest.mark.parametrize("name,model", [("swt_b32", "SW_Transformer"), ("ds_b32", "DeepSense"), ("swt_b256", "SW_Transformer")])
+def test_loss_head_matches_reference_fixture(cfg, name, model):
+    from focal_amd import ops
+    fx = np.load(os.path.join(GOLD, f"loss_{name}.npz"))
+    B, seed, scale = int(fx["B"]), int(fx["seed"]), float(fx["scale"])
+    mods = [str(m) for m in fx["mods"]]
+    f1, f2 = _views(B, mods, seed, scale)
+    fc = cfg["FOCAL"]
+    T = fc["temperature"][model]
+    w = (fc["shared_contrastive_loss_weight"], fc["private_contrastive_loss_weight"], fc["orthogonal_loss_weight"], fc["rank_loss_weight"])
+    terms, g1, g2 = ops.loss_head([f1[m].cuda() for m in mods], [f2[m].cuda() for m in mods], T, fc["inter_rank_margin"], w, cfg["seq_len"])
+    terms = terms.cpu().numpy()
+    for i, k in enumerate(("shared", "private", "orth", "rank", "total")):
+        ref = float(fx[f"loss.{k}"])
+        assert abs(terms[i] - ref) < 1e-3 * max(1.0, abs(ref)), (k, terms[i], ref)  # north_star fp32 tolerance
+    assert abs(terms[4] - float(fx["loss.reference_total"])) < 1e-3 * abs(float(fx["loss.reference_total"]))
+    for i, m in enumerate(mods):
+        for got, key in ((g1[i], f"demb1.{m}"), (g2[i], f"demb2.{m}")):
+            ref = torch.from_numpy(fx[key])
+            err = (got.cpu() - ref).norm() / ref.norm()
+            assert err < 1e-3, (key, err.item())
+
+
+@pytest.mark.parametrize("M,B,no_private", [(2, 16, False), (4, 32, False), (2, 32, True), (3, 2048, False)])
+def test_loss_head_matches_oracle(cfg, M, B, no_private):
+    """Other modality counts / the global batch of config 4 (b = 512) / the noPrivate tag, against the oracle."""
+    import copy
+
+    from focal_amd import ops
+    from oracle.loss import focal_loss_terms
+    c = copy.deepcopy(cfg)
+    mods = [f"m{i}" for i in range(M)]
+    c["modality_names"] = mods
+    f1, f2 = _views(B, mods, 100 + M, 1.2)
+    fc = c["FOCAL"]
+    T = 0.07
+    w = (1.0, 1.0, 3.0, 5.0)
+    a1 = {m: f1[m].double().requires_grad_(True) for m in mods}
+    a2 = {m: f2[m].double().requires_grad_(True) for m in mods}
+    if B <= 256:
+        ref = focal_loss_terms(a1, a2, c, "SW_Transformer", tag="noPrivate" if no_private else None)
+        ref["total"].backward()
+    terms, g1, g2 = ops.loss_head([f1[m].cuda() for m in mods], [f2[m].cuda() for m in mods], T, fc["inter_rank_margin"], w,
+                                  c["seq_len"], no_private)
+    terms = terms.cpu()
+    assert torch.isfinite(terms).all()
+    if B <= 256:
+        for i, k in enumerate(("shared", "private", "orth", "rank", "total")):
+            assert abs(terms[i].item() - float(ref[k])) < 1e-3 * max(1.0, abs(float(ref[k]))), (k, terms[i].item(), float(ref[k]))
+        for i, m in enumerate(mods):
+            assert ((g1[i].cpu().double() - a1[m].grad).norm() / a1[m].grad.norm()).item() < 1e-3
+            assert ((g2[i].cpu().double() - a2[m].grad).norm() / a2[m].grad.norm()).item() < 1e-3
+    else:
+        # size-independent property at the full global batch: total = weighted sum, and the gradient is a descent
+        # direction whose first-order prediction matches a finite step
+        assert abs(terms[4] - (terms[0] + terms[1] + 3 * terms[2] + 5 * terms[3])) < 1e-3 * terms[4].abs()
+        eps = 0.05
+        gn = sum((g ** 2).sum() for g in g1 + g2).sqrt()
+        s1 = [f1[m].cuda() - eps * g1[i] / gn for i, m in enumerate(mods)]
+        s2 = [f2[m].cuda() - eps * g2[i] / gn for i, m in enumerate(mods)]
+        t2, _, _ = ops.loss_head(s1, s2, T, fc["inter_rank_margin"], w, c["seq_len"], no_private)
+        pred = -eps * gn
+        got = (t2[4] - terms[4].cuda())
+        assert abs(got.item() - pred.item()) < 0.1 * abs(pred.item()), (got.item(), pred.item())
