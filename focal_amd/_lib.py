@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libfocal_hip.so")
 
 FOCAL_F32, FOCAL_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU_OUT = 0, 1, 2
-EPI_NONE, EPI_RESIDUAL, EPI_RELU = 0, 1, 2
+EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 ABI_VERSION = 1
 
 
@@ -36,7 +36,7 @@ class LNDesc(C.Structure):
 class LinearDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("x_dtype", C.c_int),
                 ("y_dtype", C.c_int), ("act_in", C.c_int), ("epilogue", C.c_int), ("splits", C.c_int),
-                ("in_drop", DropDesc), ("out_drop", DropDesc)]
+                ("out_drop", DropDesc)]
 
 
 class AttnDesc(C.Structure):
@@ -65,7 +65,7 @@ PROTOTYPES = {
     "focal_pad_patch_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P]),
     "focal_layernorm_fwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, P]),
     "focal_layernorm_bwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, C.c_int, P, P, P]),
-    "focal_linear_fwd": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P]),
+    "focal_linear_fwd": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P, P]),
     "focal_linear_bwd_data": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_window_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P]),

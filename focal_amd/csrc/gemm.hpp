@@ -12,7 +12,7 @@
 #include "common.hpp"
 
 enum GemmPro { PRO_NONE = 0, PRO_GELU = 1, PRO_MASK = 2 };
-enum GemmEpi { EPI_STORE = 0, EPI_RESID = 1, EPI_GELU_BWD = 2, EPI_RELU = 3, EPI_RELU_BWD = 4, EPI_ATOMIC = 5 };
+enum GemmEpi { EPI_STORE = 0, EPI_RESID = 1, EPI_MUL_AUX = 2, EPI_RELU = 3, EPI_RELU_BWD = 4, EPI_ATOMIC = 5, EPI_GELU_FWD = 6 };
 
 struct MaskParams {
   const uint32_t* seed;  // device word (null -> seed 0)
@@ -33,7 +33,8 @@ struct GemmParams {
   float alpha;
   const float* bias;              // [N] f32 or null
   const float* resid; long ldr;   // f32 [M][N] (EPI_RESID)
-  const void* aux; long ldaux;    // CT [M][N] (EPI_GELU_BWD: pre-activation u; EPI_RELU_BWD: relu output)
+  const void* aux; long ldaux;    // [M][N]: EPI_MUL_AUX: CT multiplier (saved activation derivative); EPI_RELU_BWD: relu output (TC)
+  void* aux_out;                  // TC [M][N], ldc: EPI_GELU_FWD writes d gelu/dx * dropout mask here
   MaskParams proA, proB, epi;
   float* colsumA;                 // f32 [M] (+=): sum_r proA(A)[m][r]; only with transposed A (bias gradient)
 };
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   constexpr int TM = BM / 32, TN = BN / 32;
 
   constexpr int OPER_BYTES = (StA::LDS_ELEMS + StB::LDS_ELEMS) * (int)sizeof(CT);
-  constexpr int STAGE_BYTES = (EPI == EPI_ATOMIC) ? 4 * 32 * (BN / 2 + 4) * 4 : 0;  // atomic epilogue staging
+  constexpr int STAGE_BYTES = 4 * 32 * (BN / 2 + 4) * 4;  // epilogue staging: 4 waves x 32 rows x (BN/2 + 4) floats
   constexpr int LDS_BYTES = OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES;
   __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
   CT* lds = reinterpret_cast<CT*>(lds_raw);
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   MaskEval meA, meB, meE;
   if (PROA != PRO_NONE) meA.init(p.proA);
   if (PROB != PRO_NONE) meB.init(p.proB);
-  if (EPI == EPI_RESID || EPI == EPI_GELU_BWD) meE.init(p.epi);
+  if (EPI == EPI_RESID || EPI == EPI_GELU_FWD) meE.init(p.epi);
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -304,73 +305,84 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
     if (do_colsum && tid < BM && (m0 + tid) < p.M) atomicAdd(p.colsumA + m0 + tid, csum);
   }
 
-  // ---- epilogue: lane holds C[m][n..n+3] for m = ..+(lane&15), n = ..+(lane>>4)*4
+  // ---- epilogue.  The MFMA register layout gives a lane 4 consecutive n of ONE row per accumulator, i.e. a wave
+  // store would touch 16 rows x 32-64 B.  Each wave instead transposes its sub-tile through a private LDS region (32
+  // rows per pass) and walks it row-major: 128-256 B contiguous per row for stores, residual / aux loads and, for
+  // the atomic form, 256 contiguous bytes per wave-instruction (the only shape fp32 atomics run at full rate in).
+  constexpr int WN = BN / 2, WPITCH = WN + 4;
+  float* stage = reinterpret_cast<float*>(lds_raw) + wave * 32 * WPITCH;
 #pragma unroll
-  for (int i = 0; i < (EPI == EPI_ATOMIC ? 0 : TM); ++i) {
-    const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-    if (m >= p.M) continue;
-    float rowm = 1.f;
-    if (EPI == EPI_RESID) rowm = meE.row_mult(m);
+  for (int pass = 0; pass < TM / 2; ++pass) {
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j] * p.alpha;
-      if (p.bias) v += load4(p.bias + n);
-      if (EPI == EPI_STORE) {
-        store4(C + (long)m * p.ldc + n, v);
-      } else if (EPI == EPI_RESID) {
-        f32x4 r = load4(p.resid + (long)m * p.ldr + n);
+    for (int ii = 0; ii < 2; ++ii) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
-        store4(C + (long)m * p.ldc + n, v);
-      } else if (EPI == EPI_GELU_BWD) {
-        f32x4 u = load4(reinterpret_cast<const CT*>(p.aux) + (long)m * p.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] * meE.elem_mult(m, n + e) * gelu_grad_f(u[e]);
-        store4(C + (long)m * p.ldc + n, v);
-      } else if (EPI == EPI_RELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        store4(C + (long)m * p.ldc + n, v);
-      } else if (EPI == EPI_RELU_BWD) {
-        f32x4 y = load4(reinterpret_cast<const TC*>(p.aux) + (long)m * p.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
-        store4(C + (long)m * p.ldc + n, v);
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 v = acc[pass * 2 + ii][j] * p.alpha;
+        *reinterpret_cast<float4*>(stage + (ii * 16 + (lane & 15)) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-  }
-  if (EPI == EPI_ATOMIC) {
-    // fp32 atomics run at full rate only when one wave-instruction covers 256 contiguous bytes (or two 128-B row
-    // segments); the MFMA register layout would instead scatter each instruction over 16 rows x 4 dwords (~17x
-    // slower).  So each wave transposes its sub-tile through a private LDS region, 32 rows per pass, and issues
-    // the adds row by row with lane = consecutive column.
-    constexpr int WN = BN / 2, WPITCH = WN + 4;
-    float* stage = reinterpret_cast<float*>(lds) + wave * 32 * WPITCH;
-    float* Cf = reinterpret_cast<float*>(C);
-    const bool add_bias = p.bias && sp == 0;
-#pragma unroll
-    for (int pass = 0; pass < TM / 2; ++pass) {
-      __syncthreads();
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const f32x4 v = acc[pass * 2 + ii][j] * p.alpha;
-          *reinterpret_cast<float4*>(stage + (ii * 16 + (lane & 15)) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-      __syncthreads();
+    __syncthreads();
+    const int mbase = m0 + wm * (BM / 2) + pass * 32, nbase = n0 + wn * WN;
+    if (EPI == EPI_ATOMIC) {
+      float* Cf = reinterpret_cast<float*>(C);
+      const bool add_bias = p.bias && sp == 0;
       constexpr int RPI = 64 / WN;  // rows per wave-instruction (1 or 2)
 #pragma unroll 4
       for (int rr = 0; rr < 32; rr += RPI) {
         const int row = rr + lane / WN, col = lane % WN;
-        const int m = m0 + wm * (BM / 2) + pass * 32 + row, n = n0 + wn * WN + col;
+        const int m = mbase + row, n = nbase + col;
         if (m < p.M && n < p.N) {
           float v = stage[row * WPITCH + col];
           if (add_bias) v += p.bias[n];
           atomicAdd(Cf + (long)m * p.ldc + n, v);
+        }
+      }
+    } else {
+      constexpr int LPR = WN / 4, RPI = 64 / LPR;  // lanes per row (float4 each), rows per wave-instruction
+      const int c = (lane % LPR) * 4, n = nbase + c;
+      f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.N) bias4 = load4(p.bias + n);
+#pragma unroll
+      for (int rr = 0; rr < 32; rr += RPI) {
+        const int row = rr + lane / LPR;
+        const int m = mbase + row;
+        if (m >= p.M || n >= p.N) continue;
+        const float4 t = *reinterpret_cast<const float4*>(stage + row * WPITCH + c);
+        f32x4 v = f32x4{t.x, t.y, t.z, t.w} + bias4;
+        TC* dst = C + (long)m * p.ldc + n;
+        if (EPI == EPI_STORE) {
+          store4(dst, v);
+        } else if (EPI == EPI_RESID) {
+          const f32x4 r = load4(p.resid + (long)m * p.ldr + n);
+          const float rowm = meE.row_mult(m);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
+          store4(dst, v);
+        } else if (EPI == EPI_MUL_AUX) {
+          const f32x4 a = load4(reinterpret_cast<const CT*>(p.aux) + (long)m * p.ldaux + n);
+          store4(dst, v * a);
+        } else if (EPI == EPI_GELU_FWD) {
+          f32x4 g;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float cdf, pdf;
+            gelu_parts(v[e], cdf, pdf);
+            const float mult = meE.elem_mult(m, n + e);
+            g[e] = (cdf + v[e] * pdf) * mult;
+            v[e] = v[e] * cdf * mult;
+          }
+          store4(dst, v);
+          store4(reinterpret_cast<TC*>(p.aux_out) + (long)m * p.ldc + n, g);
+        } else if (EPI == EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          store4(dst, v);
+        } else if (EPI == EPI_RELU_BWD) {
+          const f32x4 y = load4(reinterpret_cast<const TC*>(p.aux) + (long)m * p.ldaux + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
+          store4(dst, v);
         }
       }
     }

@@ -31,23 +31,25 @@ static int check_desc(const focal_linear_desc* d) {
 }
 
 extern "C" int focal_linear_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias,
-                                const float* resid, void* y, void* stream) {
+                                const float* resid, void* y, void* act_grad, void* stream) {
   if (int rc = check_desc(d)) return rc;
   FOCAL_CHECK_ARG(x && w && y, "linear_fwd: null tensor");
   GemmSpec s;
   s.compute = d->dtype;
   s.a_dtype = d->x_dtype; s.b_dtype = d->dtype; s.c_dtype = d->y_dtype;
   s.tra = false; s.trb = false;
-  s.proA = d->act_in == FOCAL_ACT_GELU ? PRO_GELU : PRO_NONE;
+  s.proA = PRO_NONE;
   s.proB = PRO_NONE;
   const int splits = d->splits > 1 ? d->splits : 1;
   if (splits > 1) {
     FOCAL_CHECK_ARG(d->epilogue == FOCAL_EPI_NONE && d->y_dtype == FOCAL_F32, "linear_fwd: split-K needs a plain fp32 output");
     s.epi = EPI_ATOMIC;
   } else {
-    s.epi = d->epilogue == FOCAL_EPI_RESIDUAL ? EPI_RESID : d->epilogue == FOCAL_EPI_RELU ? EPI_RELU : EPI_STORE;
+    s.epi = d->epilogue == FOCAL_EPI_RESIDUAL ? EPI_RESID : d->epilogue == FOCAL_EPI_RELU ? EPI_RELU
+          : d->epilogue == FOCAL_EPI_GELU ? EPI_GELU_FWD : EPI_STORE;
   }
   if (s.epi == EPI_RESID) FOCAL_CHECK_ARG(resid != nullptr && d->y_dtype == FOCAL_F32, "linear_fwd: residual epilogue needs resid and fp32 y");
+  if (s.epi == EPI_GELU_FWD) FOCAL_CHECK_ARG(act_grad != nullptr && d->y_dtype == d->dtype && d->x_dtype == d->dtype, "linear_fwd: GELU epilogue needs act_grad and dtype-typed x / y");
   GemmParams p;
   memset(&p, 0, sizeof(p));
   p.M = d->M; p.N = d->N; p.K = d->K;
@@ -57,7 +59,8 @@ extern "C" int focal_linear_fwd(const focal_linear_desc* d, const void* x, const
   p.batch = 1; p.splits = splits; p.alpha = 1.f;
   p.bias = bias;
   p.resid = resid; p.ldr = d->N;
-  p.proA = to_mask(d->in_drop, d->K);
+  p.aux_out = act_grad;
+  p.proA = no_mask();
   p.proB = no_mask();
   p.epi = to_mask(d->out_drop, d->N);
   return focal_launch_gemm(s, p, (hipStream_t)stream);
@@ -76,8 +79,8 @@ extern "C" int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy,
   const bool masked = d->epilogue == FOCAL_EPI_RESIDUAL || (d->y_dtype == FOCAL_F32 && d->x_dtype != FOCAL_F32);
   s.proA = masked ? PRO_MASK : PRO_NONE;
   s.proB = PRO_NONE;
-  s.epi = d->act_in == FOCAL_ACT_GELU ? EPI_GELU_BWD : d->act_in == FOCAL_ACT_RELU_OUT ? EPI_RELU_BWD : EPI_STORE;
-  if (s.epi != EPI_STORE) FOCAL_CHECK_ARG(x != nullptr, "linear_bwd_data: forward input needed for the activation gradient");
+  s.epi = d->act_in == FOCAL_ACT_GELU ? EPI_MUL_AUX : d->act_in == FOCAL_ACT_RELU_OUT ? EPI_RELU_BWD : EPI_STORE;
+  if (s.epi != EPI_STORE) FOCAL_CHECK_ARG(x != nullptr, "linear_bwd_data: activation derivative / relu output needed");
   GemmParams p;
   memset(&p, 0, sizeof(p));
   p.M = d->M; p.N = d->K; p.K = d->N;
@@ -88,7 +91,7 @@ extern "C" int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy,
   p.aux = x; p.ldaux = d->K;
   p.proA = masked ? to_mask(d->out_drop, d->N) : no_mask();
   p.proB = no_mask();
-  p.epi = to_mask(d->in_drop, d->K);
+  p.epi = no_mask();
   return focal_launch_gemm(s, p, (hipStream_t)stream);
 }
 
@@ -105,7 +108,7 @@ extern "C" int focal_linear_bwd_weight(const focal_linear_desc* d, const void* d
   // fp32 output gradients feeding `dtype` operands always go through the masking loader (identity when p = 0)
   const bool masked = d->epilogue == FOCAL_EPI_RESIDUAL || (d->y_dtype == FOCAL_F32 && d->x_dtype != FOCAL_F32);
   s.proA = masked ? PRO_MASK : PRO_NONE;
-  s.proB = d->act_in == FOCAL_ACT_GELU ? PRO_GELU : PRO_NONE;
+  s.proB = PRO_NONE;
   s.epi = EPI_ATOMIC;
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -123,7 +126,7 @@ extern "C" int focal_linear_bwd_weight(const focal_linear_desc* d, const void* d
   if (splits < 1) splits = 1;
   p.splits = (int)splits;
   p.proA = masked ? to_mask(d->out_drop, d->N) : no_mask();
-  p.proB = to_mask(d->in_drop, d->K);
+  p.proB = no_mask();
   p.epi = no_mask();
   p.colsumA = dbias;
   return focal_launch_gemm(s, p, (hipStream_t)stream);

@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU_OUT, EPI_NONE, EPI_RELU, EPI_RESIDUAL, FOCAL_BF16, FOCAL_F32,
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU_OUT, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RESIDUAL, FOCAL_BF16, FOCAL_F32,
                    AdamWDesc, AttnDesc, DropDesc, EmbedDesc, FFTDesc, LinearDesc, LNDesc, LossDesc, check)
 
 _TORCH2CODE = {torch.float32: FOCAL_F32, torch.bfloat16: FOCAL_BF16}
@@ -147,14 +147,12 @@ def layernorm_bwd(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=Non
 
 
 # ------------------------------------------------------------------------------------------------ Linear family
-def linear_desc(dtype_code, M, N, K, x_dtype, y_dtype, act_in=ACT_NONE, epilogue=EPI_NONE, splits=1, in_drop=None,
-                out_drop=None):
-    return LinearDesc(dtype_code, M, N, K, x_dtype, y_dtype, act_in, epilogue, splits, in_drop or NO_DROP,
-                      out_drop or NO_DROP)
+def linear_desc(dtype_code, M, N, K, x_dtype, y_dtype, act_in=ACT_NONE, epilogue=EPI_NONE, splits=1, out_drop=None):
+    return LinearDesc(dtype_code, M, N, K, x_dtype, y_dtype, act_in, epilogue, splits, out_drop or NO_DROP)
 
 
-def linear_fwd(d, x, w, bias, resid, y):
-    check(_lib.load().focal_linear_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(resid), _p(y), _stream()))
+def linear_fwd(d, x, w, bias, resid, y, act_grad=None):
+    check(_lib.load().focal_linear_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(resid), _p(y), _p(act_grad), _stream()))
 
 
 def linear_bwd_data(d, dy, w, x, dx):
@@ -166,15 +164,15 @@ def linear_bwd_weight(d, dy, x, dw, dbias):
 
 
 def linear(x, w, bias=None, *, compute, y_dtype=None, resid=None, act_in=ACT_NONE, epilogue=EPI_NONE, splits=1,
-           in_drop=None, out_drop=None):
+           out_drop=None, act_grad=None):
     """Convenience forward: allocates y.  `compute` is the matrix-core operand dtype (torch.float32 / bfloat16)."""
     _need_cuda(x, w, bias, resid)
     M, K = x.shape
     N = w.shape[0]
     y_dtype = y_dtype or compute
-    d = linear_desc(code(compute), M, N, K, code(x.dtype), code(y_dtype), act_in, epilogue, splits, in_drop, out_drop)
+    d = linear_desc(code(compute), M, N, K, code(x.dtype), code(y_dtype), act_in, epilogue, splits, out_drop)
     y = (torch.zeros if splits > 1 else torch.empty)(M, N, dtype=y_dtype, device=x.device)
-    linear_fwd(d, x, w, bias, resid, y)
+    linear_fwd(d, x, w, bias, resid, y, act_grad)
     return y, d
 
 

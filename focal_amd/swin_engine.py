@@ -6,14 +6,14 @@ activations; torch.autograd only sees one node per encoder (see `EncoderFn` in m
 
 Per block (M = B*H*W tokens, C channels, CT = matrix-core operand dtype):
   forward   a1,st1 = LN(x) . qkv = a1 Wqkv^T + b . o = W-MSA(qkv) . x_mid = x + drop(o Wp^T + b)
-            a2,st2 = LN(x_mid) . u = a2 W1^T + b . x_out = x_mid + drop(drop(gelu(u)) W2^T + b)
-  saved     x, st1, a1, qkv, o, x_mid, st2, a2, u   (x fp32; a*, qkv, o, u in CT; GELU / dropout masks recomputed)
+            a2,st2 = LN(x_mid) . (h, h') = drop(gelu(a2 W1^T + b)) and its derivative . x_out = x_mid + drop(h W2^T + b)
+  saved     x, st1, a1, qkv, o, x_mid, st2, a2, h, h'   (x fp32; the rest in CT; dropout masks are regenerated)
   backward  the residual-gradient stream g (fp32 [M, C]) is updated in place through the block.
 """
 import torch
 
 from . import ops
-from ._lib import ACT_GELU, ACT_NONE, EPI_NONE, EPI_RESIDUAL
+from ._lib import ACT_GELU, ACT_NONE, EPI_GELU, EPI_NONE, EPI_RESIDUAL
 
 
 class SwinModEncoder:
@@ -69,15 +69,16 @@ class SwinModEncoder:
                 x_mid = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
                 ops.linear_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"), x, x_mid)
                 a2, st2 = ops.layernorm_fwd(x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
-                d_fc1 = ops.linear_desc(cc, M, 4 * Cc, Cc, cc, cc)
-                u = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)
-                ops.linear_fwd(d_fc1, a2, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"), None, u)
+                d_fc1 = ops.linear_desc(cc, M, 4 * Cc, Cc, cc, cc, ACT_NONE, EPI_GELU,
+                                        out_drop=self._drop(rng, view, uid, 1, p_drop, 0.0, L))
+                h = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)
+                hg = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)  # d h / d(pre-activation), dropout included
+                ops.linear_fwd(d_fc1, a2, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"), None, h, hg)
                 d_fc2 = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, f32, ACT_GELU, EPI_RESIDUAL,
-                                        in_drop=self._drop(rng, view, uid, 1, p_drop, 0.0, L),
                                         out_drop=self._drop(rng, view, uid, 2, p_drop, p_path, L))
                 x_out = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
-                ops.linear_fwd(d_fc2, u, ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_mid, x_out)
-                saved["blocks"].append(dict(pb=pb, x=x, st1=st1, a1=a1, qkv=qkv, o=o, x_mid=x_mid, st2=st2, a2=a2, u=u,
+                ops.linear_fwd(d_fc2, h, ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_mid, x_out)
+                saved["blocks"].append(dict(pb=pb, x=x, st1=st1, a1=a1, qkv=qkv, o=o, x_mid=x_mid, st2=st2, a2=a2, h=h, hg=hg,
                                             d_qkv=d_qkv, d_att=d_att, d_proj=d_proj, d_fc1=d_fc1, d_fc2=d_fc2,
                                             M=M, C=Cc))
                 x = x_out
@@ -128,10 +129,10 @@ class SwinModEncoder:
                                   ar.g(f"{pm}.norm.weight"), ar.g(f"{pm}.norm.bias"), gather=mg["gather"])
             s = saved["blocks"][k]
             pb, M, Cc = s["pb"], s["M"], s["C"]
-            # ---- MLP branch: x_out = x_mid + mask * (drop(gelu(u)) W2^T + b2)
-            ops.linear_bwd_weight(s["d_fc2"], g, s["u"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
-            du = torch.empty_like(s["u"])
-            ops.linear_bwd_data(s["d_fc2"], g, ar.operand(f"{pb}.mlp.fc2.weight"), s["u"], du)
+            # ---- MLP branch: x_out = x_mid + mask * (h W2^T + b2), h = drop(gelu(a2 W1^T + b1))
+            ops.linear_bwd_weight(s["d_fc2"], g, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
+            du = torch.empty_like(s["h"])
+            ops.linear_bwd_data(s["d_fc2"], g, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
             ops.linear_bwd_weight(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
             dc = torch.empty_like(s["a2"])
             ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)

@@ -79,28 +79,31 @@ int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const float* x, 
                         const float* gamma, float* dx, int accumulate_dx, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ Linear family
- * y[M, N] = epilogue( act_in(x)[M, K] . w[N, K]^T + bias ), i.e. nn.Linear of models/SwinModules.py:22-34,113-116,
- * 375 and models/SW_Transformer.py:121-124,157-161, with the element-wise neighbours of each call site fused:
- *   act_in   FOCAL_ACT_GELU      x is the pre-activation; GELU(erf) + `in_drop` applied while loading (Mlp.act/drop)
- *            FOCAL_ACT_RELU_OUT  x is already a ReLU output (only matters for bwd_data: dx is masked by x > 0)
+ * y[M, N] = epilogue( x[M, K] . w[N, K]^T + bias ), i.e. nn.Linear of models/SwinModules.py:22-34,113-116,375 and
+ * models/SW_Transformer.py:121-124,157-161, with the element-wise neighbours of each call site fused:
  *   epilogue FOCAL_EPI_RESIDUAL  y = resid + out_drop(DropPath(.)): proj_drop / Mlp.drop + drop_path + shortcut
+ *            FOCAL_EPI_GELU      y = out_drop(gelu_erf(.)) AND act_grad = d y / d(.)  (Mlp.act + Mlp.drop; the
+ *                                derivative is emitted once here so that no pass ever re-evaluates erf)
  *            FOCAL_EPI_RELU      y = relu(.)
+ *   act_in   FOCAL_ACT_GELU      x came out of an upstream FOCAL_EPI_GELU linear: bwd_data multiplies dx by that
+ *                                linear's act_grad, which is passed in the `x` slot
+ *            FOCAL_ACT_RELU_OUT  x is a ReLU output: bwd_data masks dx by x > 0
  * x_dtype / y_dtype are FOCAL_F32 or `dtype`; w is `dtype` (the bf16 shadow of the fp32 master in bf16 mode).
  * splits > 1 = split-K with fp32 atomics (y must be zeroed, fp32, epilogue NONE).
- * bwd_data  : dx = [(dy * out_mask) . w] (* in_mask * gelu'(x) | * (x > 0));  dy has y's dtype, dx has x's dtype.
- * bwd_weight: dw[N, K] += (dy * out_mask)^T . act_in(x);  dbias[N] += column sums (either may be NULL). */
+ * bwd_data  : dx = [(dy * out_mask) . w] (* act_grad | * (x > 0));  dy has y's dtype, dx has x's dtype.
+ * bwd_weight: dw[N, K] += (dy * out_mask)^T . x;  dbias[N] += column sums (either may be NULL). */
 enum { FOCAL_ACT_NONE = 0, FOCAL_ACT_GELU = 1, FOCAL_ACT_RELU_OUT = 2 };
-enum { FOCAL_EPI_NONE = 0, FOCAL_EPI_RESIDUAL = 1, FOCAL_EPI_RELU = 2 };
+enum { FOCAL_EPI_NONE = 0, FOCAL_EPI_RESIDUAL = 1, FOCAL_EPI_RELU = 2, FOCAL_EPI_GELU = 3 };
 typedef struct {
   int dtype;
   int M, N, K;
   int x_dtype, y_dtype;
   int act_in, epilogue;
   int splits;
-  focal_drop_desc in_drop, out_drop;
+  focal_drop_desc out_drop;
 } focal_linear_desc;
 int focal_linear_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias, const float* resid,
-                     void* y, void* stream);
+                     void* y, void* act_grad, void* stream);
 int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy, const void* w, const void* x, void* dx,
                           void* stream);
 int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const void* x, float* dw, float* dbias,

@@ -39,15 +39,23 @@ def test_linear_fwd_plain(ops, ct, M, N, K):
 
 
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
-def test_linear_residual_and_gelu_prologue(ops, ct):
-    from focal_amd._lib import ACT_GELU, EPI_RESIDUAL
-    M, N, K = 1152, 64, 256
-    u, w, b, r = rnd(M, K, seed=4, dtype=ct), rnd(N, K, scale=K ** -0.5, seed=5, dtype=ct), rnd(N, seed=6), rnd(M, N, seed=7)
-    y, _ = ops.linear(u, w, b, compute=ct, y_dtype=torch.float32, resid=r, act_in=ACT_GELU, epilogue=EPI_RESIDUAL)
-    h = F.gelu(u.float())
-    if ct == torch.bfloat16:
-        h = h.bfloat16().float()
-    ref = r + h @ w.float().t() + b
+def test_linear_gelu_epilogue_and_residual(ops, ct):
+    """Swin MLP forward: (h, h') = gelu(a W1^T + b1) and its derivative from ONE kernel; y = r + h W2^T + b2."""
+    from focal_amd._lib import ACT_GELU, EPI_GELU, EPI_RESIDUAL
+    M, C = 1152, 64
+    a, w1, b1 = rnd(M, C, seed=4, dtype=ct), rnd(4 * C, C, scale=C ** -0.5, seed=5, dtype=ct), rnd(4 * C, seed=6)
+    hg = torch.empty(M, 4 * C, dtype=ct, device=DEV)
+    h, _ = ops.linear(a, w1, b1, compute=ct, epilogue=EPI_GELU, act_grad=hg)
+    u = (a.float() @ w1.float().t() + b1).requires_grad_(True)
+    href = F.gelu(u)
+    href.sum().backward()
+    tol = 2e-6 if ct == torch.float32 else 5e-3
+    assert rel_err(h.float(), href) < tol and rel_err(hg.float(), u.grad) < tol
+    if ct == torch.float32:  # the erf approximation itself: absolute error << 1e-6
+        assert (h - href).abs().max().item() < 2e-6 and (hg - u.grad).abs().max().item() < 2e-6
+    w2, b2, r = rnd(C, 4 * C, scale=(4 * C) ** -0.5, seed=7, dtype=ct), rnd(C, seed=8), rnd(M, C, seed=9)
+    y, _ = ops.linear(h, w2, b2, compute=ct, y_dtype=torch.float32, resid=r, act_in=ACT_GELU, epilogue=EPI_RESIDUAL)
+    ref = r + h.float() @ w2.float().t() + b2
     assert rel_err(y, ref) < (1e-5 if ct == torch.float32 else 4e-3)
 
 
@@ -88,26 +96,22 @@ def test_linear_bwd(ops, ct, M, N, K):
 
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
 def test_linear_bwd_fc2_chain(ops, ct):
-    """fc2 of the Swin MLP: y = r + gelu(u) W^T + b with fp32 dy -> du (through gelu') and dW (with gelu(u))."""
+    """fc2 of the Swin MLP: y = r + h W^T + b with fp32 dy -> du = (dy W) * h' and dW = dy^T h."""
     from focal_amd._lib import ACT_GELU, EPI_RESIDUAL
     M, N, K = 1152, 64, 256
-    u = rnd(M, K, seed=14, dtype=ct)
+    h, hg = rnd(M, K, seed=14, dtype=ct), rnd(M, K, seed=141, dtype=ct)
     w = rnd(N, K, scale=K ** -0.5, seed=15, dtype=ct)
     g = rnd(M, N, seed=16)
     c, f32 = ops.code(ct), ops.code(torch.float32)
     d = ops.linear_desc(c, M, N, K, c, f32, ACT_GELU, EPI_RESIDUAL)
     du = torch.empty(M, K, dtype=ct, device=DEV)
-    ops.linear_bwd_data(d, g, w, u, du)
-    uf = u.float().requires_grad_(True)
+    ops.linear_bwd_data(d, g, w, hg, du)
     gq = g if ct == torch.float32 else g.bfloat16().float()
-    h = F.gelu(uf)
-    (h @ w.float().t() * gq).sum().backward()
-    assert rel_err(du.float(), uf.grad) < (1e-5 if ct == torch.float32 else 8e-3)
+    assert rel_err(du.float(), (gq @ w.float()) * hg.float()) < (1e-5 if ct == torch.float32 else 8e-3)
     dw = torch.zeros(N, K, device=DEV)
     db = torch.zeros(N, device=DEV)
-    ops.linear_bwd_weight(d, g, u, dw, db)
-    hq = h.detach() if ct == torch.float32 else h.detach().bfloat16().float()
-    assert rel_err(dw, gq.t() @ hq) < (2e-5 if ct == torch.float32 else 2e-4)
+    ops.linear_bwd_weight(d, g, h, dw, db)
+    assert rel_err(dw, gq.t() @ h.float()) < (2e-5 if ct == torch.float32 else 2e-4)
     assert rel_err(db, gq.sum(0)) < 1e-4
 
 
