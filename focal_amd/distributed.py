@@ -20,8 +20,10 @@ class _AllGatherFeatures(torch.autograd.Function):
     def forward(ctx, *feats):
         W, r = dist.get_world_size(), dist.get_rank()
         packed = torch.stack([f.contiguous() for f in feats], 0)  # [n, B_local, D]
-        out = torch.empty((W,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-        dist.all_gather_into_tensor(out, packed)
+        n = packed.shape[0]
+        flat = torch.empty((W * n,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(flat, packed)  # concatenation along dim 0: [rank0 feats.., rank1 feats.., ...]
+        out = flat.view((W, n) + tuple(packed.shape[1:]))
         ctx.rank, ctx.b = r, packed.shape[1]
         # rank-major concat keeps subsequences contiguous (models/loss.py:152-155 reshapes [B] -> [b, seq])
         return tuple(out[:, i].reshape(-1, packed.shape[2]) for i in range(len(feats)))

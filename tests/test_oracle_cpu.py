@@ -1,0 +1,199 @@
+"""CPU suite (no GPU): the oracle against the committed reference fixtures, host-side logic, and the C ABI surface
+(library loads, exports every symbol include/focal_hip.h declares; no compute calls)."""
+import json
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_args, no_dropout
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _state(model, cfg):
+    from oracle import weights as ow
+    spec = ow.swt_state_spec(cfg) if model == "SW_Transformer" else ow.deepsense_state_spec(cfg)
+    st = {}
+    for k, shp in spec.items():
+        if k.endswith(("relative_position_index", "num_batches_tracked")):
+            st[k] = torch.zeros(shp, dtype=torch.long)
+        elif k.endswith("attn_mask"):
+            st[k] = torch.zeros(shp)
+        else:
+            st[k] = ow.seeded_values(k, shp)
+    return st
+
+
+@pytest.mark.parametrize("model", ["SW_Transformer", "DeepSense"])
+def test_oracle_state_spec_matches_reference_manifest(cfg, model):
+    from oracle import weights as ow
+    man = json.load(open(os.path.join(GOLD, f"manifest_{model}.json")))
+    spec = ow.swt_state_spec(cfg) if model == "SW_Transformer" else ow.deepsense_state_spec(cfg)
+    assert [m[0] for m in man] == list(spec.keys())
+    for k, shp, _ in man:
+        assert tuple(shp) == tuple(spec[k]), k
+
+
+@pytest.mark.parametrize("model", ["SW_Transformer", "DeepSense"])
+def test_oracle_eval_embeddings_match_reference(cfg, model):
+    from oracle import weights as ow
+    from oracle.deepsense import deepsense_forward
+    from oracle.swt import swt_forward
+    fx = np.load(os.path.join(GOLD, f"{model}_b8.npz"))
+    st = _state(model, cfg)
+    x1 = ow.synthetic_freq_input(cfg, 8, seed=101)
+    taps = {}
+    with torch.no_grad():
+        if model == "SW_Transformer":
+            emb = swt_forward(st, cfg, x1, proj_head=True, taps=taps)
+        else:
+            emb = deepsense_forward(st, cfg, x1, proj_head=True, train=False, taps=taps)
+    for m in emb:
+        ref = torch.from_numpy(fx[f"eval.emb.{m}"])
+        assert (emb[m] - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), m
+    for k, v in taps.items():
+        n = fx[f"eval.tapnorm.{k}"]
+        assert abs(v.double().norm().item() - n[0]) < 1e-4 * max(n[0], 1e-6), k
+
+
+@pytest.mark.parametrize("model", ["SW_Transformer", "DeepSense"])
+def test_oracle_train_step_matches_reference(cfg, model):
+    """Loss terms, per-parameter gradient norms and (DeepSense) BatchNorm running statistics of one FOCAL step."""
+    from oracle import weights as ow
+    from oracle.step import OracleTrainer
+    fx = np.load(os.path.join(GOLD, f"{model}_b8.npz"))
+    tr = OracleTrainer(model, cfg, _state(model, cfg))
+    x1, x2 = ow.synthetic_freq_input(cfg, 8, seed=101), ow.synthetic_freq_input(cfg, 8, seed=202)
+    terms, f1, f2, grads = tr.loss_and_grads(x1, x2)
+    assert abs(float(terms["total"]) - float(fx["train.loss.reference_total"])) < 1e-4 * abs(float(fx["train.loss.reference_total"]))
+    for k in ("shared", "private", "orth", "rank"):
+        assert abs(float(terms[k]) - float(fx[f"train.loss.{k}"])) < 1e-5 * max(1.0, abs(float(fx[f"train.loss.{k}"])))
+    for n, ref in zip(fx["train.grad_names"], fx["train.grad_norms"]):
+        got = grads[str(n)].double().norm().item()
+        assert abs(got - ref) < 5e-4 * ref + 1e-5, (n, got, ref)
+    for k in fx.files:
+        if k.startswith("train.buf."):
+            name = k[len("train.buf."):]
+            assert (tr.P[name] - torch.from_numpy(fx[k])).abs().max().item() < 1e-5 * max(1.0, float(np.abs(fx[k]).max()))
+
+
+@pytest.mark.parametrize("model", ["SW_Transformer"])
+def test_oracle_adamw_trajectory_matches_reference(cfg, model):
+    from oracle import weights as ow
+    from oracle.step import OracleTrainer
+    fx = np.load(os.path.join(GOLD, f"{model}_b8.npz"))
+    tr = OracleTrainer(model, cfg, _state(model, cfg))
+    x1, x2 = ow.synthetic_freq_input(cfg, 8, seed=101), ow.synthetic_freq_input(cfg, 8, seed=202)
+    for ref in fx["adamw.loss_traj"]:
+        t = tr.step(freq_pair=(x1, x2))
+        assert abs(t["total"] - ref) < 2e-3 * abs(ref)
+
+
+@pytest.mark.parametrize("name,model", [("swt_b32", "SW_Transformer"), ("ds_b32", "DeepSense"), ("swt_b256", "SW_Transformer")])
+def test_oracle_loss_matches_reference(cfg, name, model):
+    from oracle.loss import focal_loss_terms
+    fx = np.load(os.path.join(GOLD, f"loss_{name}.npz"))
+    B, seed, scale = int(fx["B"]), int(fx["seed"]), float(fx["scale"])
+    mods = [str(m) for m in fx["mods"]]
+    g = torch.Generator().manual_seed(seed)
+    f1 = {m: (torch.randn(B, 256, generator=g) * scale).requires_grad_(True) for m in mods}
+    f2 = {m: torch.randn(B, 256, generator=g) * scale for m in mods}
+    f2 = {m: (0.5 * f2[m] + 0.5 * f1[m].detach()).requires_grad_(True) for m in mods}
+    terms = focal_loss_terms(f1, f2, cfg, model)
+    assert abs(float(terms["total"]) - float(fx["loss.reference_total"])) < 2e-5 * abs(float(fx["loss.reference_total"]))
+    terms["total"].backward()
+    for m in mods:
+        ref = torch.from_numpy(fx[f"demb1.{m}"])
+        assert ((f1[m].grad - ref).norm() / ref.norm()).item() < 1e-4
+
+
+def test_fft_realpack_matches_reference(cfg):
+    from oracle import weights as ow
+    from oracle.step import fft_realpack
+    fx = np.load(os.path.join(GOLD, "fft_b4_seed11.npz"))
+    out = fft_realpack(ow.synthetic_time_input(cfg, 4, seed=11))
+    for loc in out:
+        for mod in out[loc]:
+            assert torch.equal(out[loc][mod], torch.from_numpy(fx[f"{loc}.{mod}"]))
+
+
+# ---------------------------------------------------------------------------------------------- host logic
+def test_product_state_dict_matches_reference_manifest(cfg):
+    from models.SW_Transformer import SW_Transformer
+    net = SW_Transformer(make_args(cfg, "SW_Transformer", torch.device("cpu")))
+    man = json.load(open(os.path.join(GOLD, "manifest_SW_Transformer.json")))
+    sd = net.state_dict()
+    assert [m[0] for m in man] == list(sd.keys())
+    for k, shp, dt in man:
+        assert list(sd[k].shape) == shp and str(sd[k].dtype).replace("torch.", "") == dt, k
+    # buffers derived from geometry agree with the oracle's restatement of the reference formulas
+    from oracle.swt import relative_position_index, shifted_window_mask
+    assert torch.equal(sd["freq_interval_layers.shake.audio.0.blocks.1.attn.relative_position_index"], relative_position_index(3, 3))
+    assert torch.equal(sd["freq_interval_layers.shake.audio.0.blocks.1.attn_mask"], shifted_window_mask(12, 48, 3, 3, 1, 1))
+    assert "freq_interval_layers.shake.audio.2.blocks.1.attn_mask" not in sd  # H = 3 <= window: no shift (the quirk)
+
+
+def test_product_fails_loudly_without_gpu(cfg):
+    """No CPU fallback anywhere on the product path."""
+    from focal_amd import _lib
+    from models.SW_Transformer import SW_Transformer
+    net = SW_Transformer(make_args(cfg, "SW_Transformer", torch.device("cpu")))
+    x = {"shake": {"audio": torch.zeros(4, 2, 10, 1600), "seismic": torch.zeros(4, 2, 10, 20)}}
+    with pytest.raises(_lib.FocalHipError):
+        net(x, class_head=False, proj_head=True)
+    with pytest.raises(NotImplementedError):
+        net(x, class_head=True)
+
+
+def test_padded_size_and_schedules(cfg):
+    from input_utils.padding_utils import get_padded_size
+    from train_utils.lr_scheduler import CosineLRScheduler, StepLRScheduler
+    assert get_padded_size((10, 1600), [3, 3], [1, 40], 3) == [12, 1920]
+    assert get_padded_size((10, 20), [3, 3], [1, 1], 3) == [12, 24]
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1e-3)
+    s = CosineLRScheduler(opt, t_initial=6000, lr_min=1e-7)
+    s.step(0)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-3)
+    s.step(3000)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-7 + 0.5 * (1e-3 - 1e-7) * (1 + math.cos(math.pi / 2)))
+    s.step(7000)
+    assert opt.param_groups[0]["lr"] == pytest.approx(1e-7)
+    from oracle.step import cosine_lr
+    assert cosine_lr(1234, 1e-3, 1e-7, 6000) == pytest.approx(s.value(1e-3, 1234))
+    st = StepLRScheduler(opt, decay_t=300, decay_rate=0.2)
+    assert st.value(1e-4, 650) == pytest.approx(1e-4 * 0.2 ** 2)
+
+
+def test_registry_and_errors(cfg):
+    from train_utils.model_selection import init_backbone_model
+    a = make_args(cfg, "NoSuchModel", torch.device("cpu"))
+    with pytest.raises(Exception, match="Invalid model provided"):
+        init_backbone_model(a)
+    from input_utils.multi_modal_dataloader import SyntheticSequenceLoader
+    with pytest.raises(ValueError):
+        SyntheticSequenceLoader(make_args(cfg, "SW_Transformer", torch.device("cpu")), batch_size=30)
+    dl = SyntheticSequenceLoader(make_args(cfg, "SW_Transformer", torch.device("cpu")), batch_size=8, num_batches=2)
+    batches = list(dl)
+    assert len(batches) == 2 and batches[0][0]["shake"]["audio"].shape == (8, 1, 10, 1600)
+
+
+# ---------------------------------------------------------------------------------------------- C ABI surface
+def test_library_exports_every_declared_symbol():
+    from focal_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "focal_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(focal_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    lib = _lib.load()  # raises if the .so is missing or a symbol does not resolve
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.focal_abi_version() == _lib.ABI_VERSION
+    import ctypes as C
+    assert C.sizeof(_lib.DropDesc) == 32 and C.sizeof(_lib.LinearDesc) == 9 * 4 + 4 + 32

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Per-kernel microbenchmark at the shapes of the B=256 SW_Transformer step (HIP-event timed, GPU box only).
+Prints one line per (op, shape): microseconds per launch, algorithmic GB/s and TFLOP/s."""
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from focal_amd import ops  # noqa: E402
+from focal_amd._lib import ACT_GELU, ACT_NONE, EPI_GELU, EPI_NONE, EPI_RESIDUAL  # noqa: E402
+
+DEV = "cuda"
+CT = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
+ES = 2 if CT == torch.bfloat16 else 4
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
+
+
+def timeit(fn, iters=30):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def report(name, us, nbytes, flops=0):
+    print(f"{name:58s} {us:8.1f} us  {nbytes / us / 1e3:8.1f} GB/s  {flops / us / 1e6:8.1f} TF/s", flush=True)
+
+
+def rnd(*s, dtype=torch.float32):
+    return torch.randn(*s, device=DEV).to(dtype)
+
+
+# (tag, tokens M, channels C) of the six (stage, modality) encoders at B=256
+STAGES = [("s0a", 147456, 64), ("s0s", 73728, 64), ("s1a", 36864, 128), ("s1s", 18432, 128), ("s2a", 9216, 256), ("s2s", 4608, 256)]
+c, f32 = ops.code(CT), ops.code(torch.float32)
+
+for tag, M, C in STAGES:
+    if ONLY and ONLY not in ("gemm", tag):
+        continue
+    a = rnd(M, C, dtype=CT)
+    x32 = rnd(M, C)
+    g32 = rnd(M, C)
+    for nm, N in (("qkv", 3 * C), ("fc1", 4 * C)):
+        w, b = rnd(N, C, dtype=CT), rnd(N)
+        y = torch.empty(M, N, dtype=CT, device=DEV)
+        if nm == "qkv":
+            d = ops.linear_desc(c, M, N, C, c, c)
+            report(f"{tag} fwd {nm} [{M}x{C}]->{N}", timeit(lambda: ops.linear_fwd(d, a, w, b, None, y)), (M * C + M * N) * ES, 2.0 * M * N * C)
+        else:
+            y2 = torch.empty_like(y)
+            d = ops.linear_desc(c, M, N, C, c, c, ACT_NONE, EPI_GELU)
+            report(f"{tag} fwd {nm}+gelu [{M}x{C}]->{N} (2 outputs)", timeit(lambda: ops.linear_fwd(d, a, w, b, None, y, y2)), (M * C + 2 * M * N) * ES, 2.0 * M * N * C)
+        dx = torch.empty(M, C, dtype=CT, device=DEV)
+        dpl = ops.linear_desc(c, M, N, C, c, c)
+        report(f"{tag} dX  {nm} dy[{M}x{N}]->{C}", timeit(lambda: ops.linear_bwd_data(dpl, y, w, None, dx)), (M * C + M * N) * ES, 2.0 * M * N * C)
+        dw, db = torch.zeros(N, C, device=DEV), torch.zeros(N, device=DEV)
+        report(f"{tag} dW  {nm} dy[{M}x{N}]^T x[{M}x{C}]", timeit(lambda: ops.linear_bwd_weight(dpl, y, a, dw, db)), (M * C + M * N) * ES, 2.0 * M * N * C)
+    # proj / fc2 with residual epilogue
+    for nm, K in (("proj", C), ("fc2", 4 * C)):
+        xin = rnd(M, K, dtype=CT)
+        w, b = rnd(C, K, dtype=CT), rnd(C)
+        out = torch.empty(M, C, device=DEV)
+        d = ops.linear_desc(c, M, C, K, c, f32, ACT_GELU if nm == "fc2" else ACT_NONE, EPI_RESIDUAL)
+        report(f"{tag} fwd {nm}+res [{M}x{K}]->{C}", timeit(lambda: ops.linear_fwd(d, xin, w, b, x32, out)), M * K * ES + 2 * M * C * 4, 2.0 * M * C * K)
+        dxin = torch.empty(M, K, dtype=CT, device=DEV)
+        aux = rnd(M, K, dtype=CT) if nm == "fc2" else None
+        report(f"{tag} dX  {nm} g[{M}x{C}]f32->{K}", timeit(lambda: ops.linear_bwd_data(d, g32, w, aux, dxin)), M * C * 4 + M * K * ES * (2 if aux is not None else 1), 2.0 * M * C * K)
+        dw, db = torch.zeros(C, K, device=DEV), torch.zeros(C, device=DEV)
+        report(f"{tag} dW  {nm} g[{M}x{C}]^T x[{M}x{K}]", timeit(lambda: ops.linear_bwd_weight(d, g32, xin, dw, db)), M * C * 4 + M * K * ES, 2.0 * M * C * K)
+
+for tag, M, C in STAGES:
+    if ONLY and ONLY not in ("ln", tag):
+        continue
+    x, gam, bet = rnd(M, C), rnd(C), rnd(C)
+    y, st = ops.layernorm_fwd(x, gam, bet, CT)
+    report(f"{tag} ln_fwd [{M}x{C}]", timeit(lambda: ops.layernorm_fwd(x, gam, bet, CT)), M * C * (4 + ES))
+    dy, dx = rnd(M, C, dtype=CT), rnd(M, C)
+    dg, dbt = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    report(f"{tag} ln_bwd [{M}x{C}]", timeit(lambda: ops.layernorm_bwd(dy, x, st, gam, dx, True, dg, dbt)), M * C * (ES + 4 + 8))
+
+GEO = [("s0a", 12, 48, 64), ("s0s", 12, 24, 64), ("s1a", 6, 24, 128), ("s1s", 6, 12, 128), ("s2a", 3, 12, 256), ("s2s", 3, 6, 256)]
+for tag, H, W, C in GEO:
+    if ONLY and ONLY not in ("attn", tag):
+        continue
+    B = 256
+    M = B * H * W
+    qkv, table = rnd(M, 3 * C, dtype=CT), rnd(25, 4)
+    o = torch.empty(M, C, dtype=CT, device=DEV)
+    for sh in (0, 1):
+        d = ops.attn_desc(c, B, H, W, C, 4, 3, 3, sh, sh)
+        report(f"{tag} attn_fwd shift={sh} [{M}x{3 * C}]", timeit(lambda: ops.window_attn_fwd(d, qkv, table, o)), M * 4 * C * ES, 4.0 * M * 9 * C)
+        do, dqkv, dt = rnd(M, C, dtype=CT), torch.empty_like(qkv), torch.zeros_like(table)
+        report(f"{tag} attn_bwd shift={sh}", timeit(lambda: ops.window_attn_bwd(d, qkv, table, do, dqkv, dt)), M * 8 * C * ES, 10.0 * M * 9 * C)
