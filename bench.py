@@ -122,9 +122,9 @@ def roofline(a, step, device):
     ops = step.ops
     ct = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     es = 2 if ct == torch.bfloat16 else 4
-    geo = step.backbone.geometry["shake"]["audio"]["stages"][0] if a.model == "SW_Transformer" else None
-    if geo is None:
-        return None
+    if a.model != "SW_Transformer":
+        return roofline_deepsense(a, step, device)
+    geo = step.backbone.geometry["shake"]["audio"]["stages"][0]
     M, K, N = a.batch * geo["H"] * geo["W"], geo["C"], 4 * geo["C"]
     x = torch.randn(M, K, device=device).to(ct)
     w = (torch.randn(N, K, device=device) * K ** -0.5).to(ct)
@@ -138,6 +138,26 @@ def roofline(a, step, device):
     return {"bound": "hbm", "kernel": "focal_gemm_kernel<fwd, LN-out -> fc1> M=%d K=%d N=%d" % (M, K, N), "achieved": round(gbs, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
             "ms_per_launch": round(ms, 5), "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+
+
+def roofline_deepsense(a, step, device):
+    """DeepSense's dominant kernel family: the [1,5] inter-conv as a sliding-window MFMA GEMM
+    (M = B*10*20 tokens, K = 5*64, N = 64): reads the bf16 activation once, writes the fp32 pre-BN output."""
+    ops = step.ops
+    ct = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    es = 2 if ct == torch.bfloat16 else 4
+    C, S, k = 64, 20, 5
+    rows = a.batch * 10 * S
+    x = torch.randn(rows, C, device=device).to(ct)
+    w = (torch.randn(C, k * C, device=device) * (k * C) ** -0.5).to(ct)
+    b = torch.zeros(C, device=device)
+    d = ops.conv_desc(ops.code(ct), rows, S, C, C, k)
+    ms = time_kernel(lambda: ops.conv_fwd(d, x, w, b))
+    bytes_alg = rows * C * es + rows * C * 4 + C * k * C * es
+    gbs = bytes_alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "focal_gemm_kernel<conv window> rows=%d K=%d N=%d" % (rows, k * C, C), "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "ms_per_launch": round(ms, 5), "tflops": round(2.0 * rows * C * k * C / (ms * 1e-3) / 1e12, 1)}
 
 
 def cpu_baseline(a, cfg):

@@ -51,6 +51,23 @@ class LossDesc(C.Structure):
                 ("w_rank", C.c_float), ("no_private", C.c_int)]
 
 
+class ConvInDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "cin", "I", "S_in", "S_out", "k", "stride", "pad_left", "C")]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("dtype", "rows", "S", "C_in", "C_out", "k")]
+
+
+class BNDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("rows", C.c_int), ("C", C.c_int), ("rows_per_sample", C.c_int), ("eps", C.c_float),
+                ("momentum", C.c_float), ("p_drop", C.c_float), ("rng", C.c_void_p), ("stream", C.c_uint32)]
+
+
+class GRUDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("H", C.c_int)]
+
+
 class AdamWDesc(C.Structure):
     _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
 
@@ -75,6 +92,22 @@ PROTOTYPES = {
     "focal_adamw_multi": (C.c_int, [C.POINTER(AdamWDesc), C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P),
                                     C.POINTER(P), C.POINTER(P), C.POINTER(C.c_long), P, P, P]),
     "focal_cast_bf16": (C.c_int, [P, P, C.c_long, P]),
+    "focal_conv_in_fwd": (C.c_int, [C.POINTER(ConvInDesc), P, P, P, P, P]),
+    "focal_conv_in_bwd_weight": (C.c_int, [C.POINTER(ConvInDesc), P, P, C.c_int, P, P, P]),
+    "focal_permute_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, C.c_int, P]),
+    "focal_permute_unpack_add": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, P]),
+    "focal_conv_pack_bwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P]),
+    "focal_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
+    "focal_conv_bwd_data": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
+    "focal_conv_bwd_weight": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
+    "focal_bn_stats": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, C.c_int, P]),
+    "focal_bn_act_fwd": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P]),
+    "focal_bn_act_bwd": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P, P, P]),
+    "focal_gru_gate_fwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, C.c_int, P, P, P, P, P, P, P]),
+    "focal_gru_gate_bwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, C.c_int, P, C.c_long, C.c_long, C.c_float, P, P, P, P, P, P, P, P]),
+    "focal_mean_time": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, P]),
+    "focal_dropout": (C.c_int, [C.c_long, P, P, P, C.c_uint32, C.c_float, P]),
+    "focal_axpy": (C.c_int, [C.c_long, C.c_float, P, P, P]),
 }
 
 _lib = None

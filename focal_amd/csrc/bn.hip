@@ -1,0 +1,232 @@
+// BatchNorm2d (train: batch statistics, eval: running statistics) + GELU + Dropout2d + residual for the DeepSense
+// ConvLayer2D stack (models/ConvModules.py:98-112, 203-204), on channel-last tokens z[rows][C] (C = 64):
+//   forward   stats(z) -> y = resid + mask * gelu(gamma * (z - mean) * rstd + beta)       (+ a dtype copy for the next GEMM)
+//   backward  da = g * mask * gelu'(.)  ->  s1 = sum da, s2 = sum da * zhat  (= dbeta, dgamma)
+//             dz = gamma * rstd * (da - s1/n - zhat * s2/n)
+// All streaming, HBM-bound; per-channel reductions: registers -> LDS -> one atomic per channel per workgroup.
+#include "common.hpp"
+
+// sums[0..C) = sum z, sums[C..2C) = sum z^2   (sums must be zeroed by the caller-side launcher)
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ z, float* __restrict__ sums, long rows, int C) {
+  extern __shared__ float red[];  // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int lpr = C / 4;                 // lanes per row
+  const int rpb = 256 / lpr;             // rows per block-iteration
+  const int li = threadIdx.x % lpr, sub = threadIdx.x / lpr;
+  float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+  for (long r = (long)blockIdx.x * rpb + sub; r < rows; r += (long)gridDim.x * rpb) {
+    const float4 v = *reinterpret_cast<const float4*>(z + r * C + li * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+  }
+  atomicAdd(&red[li * 4 + 0], s.x); atomicAdd(&red[li * 4 + 1], s.y); atomicAdd(&red[li * 4 + 2], s.z); atomicAdd(&red[li * 4 + 3], s.w);
+  atomicAdd(&red[C + li * 4 + 0], q.x); atomicAdd(&red[C + li * 4 + 1], q.y); atomicAdd(&red[C + li * 4 + 2], q.z); atomicAdd(&red[C + li * 4 + 3], q.w);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(sums + i, red[i]);
+}
+
+// mean_rstd[0..C) = mean, [C..2C) = rstd; running stats: momentum update with the UNBIASED variance (torch semantics)
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float* __restrict__ mean_rstd, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var, long rows, int C, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float n = (float)rows;
+  const float mean = sums[c] / n;
+  float var = sums[C + c] / n - mean * mean;
+  var = fmaxf(var, 0.f);
+  mean_rstd[c] = mean;
+  mean_rstd[C + c] = rsqrtf(var + eps);
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+  }
+}
+__global__ void bn_eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                     float* __restrict__ mean_rstd, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean_rstd[c] = run_mean[c];
+  mean_rstd[C + c] = rsqrtf(run_var[c] + eps);
+}
+
+template <typename TY>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean_rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ resid, float* __restrict__ y, TY* __restrict__ ya,
+                                                         long rows, int C, int rows_per_sample, const uint32_t* rng,
+                                                         uint32_t stream, float p) {
+  const DropCtx dc = make_drop(rng, stream, p);
+  const bool drop_on = p > 0.f;
+  const long n4 = rows * C / 4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+    const long r = (e * 4) / C;
+    const int c = (int)((e * 4) % C);
+    const float4 v = reinterpret_cast<const float4*>(z)[e];
+    const float4 mu = *reinterpret_cast<const float4*>(mean_rstd + c), rs = *reinterpret_cast<const float4*>(mean_rstd + C + c);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+    float o[4] = {(v.x - mu.x) * rs.x * ga.x + be.x, (v.y - mu.y) * rs.y * ga.y + be.y, (v.z - mu.z) * rs.z * ga.z + be.z,
+                  (v.w - mu.w) * rs.w * ga.w + be.w};
+    const uint32_t sample = (uint32_t)(r / rows_per_sample);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k] = gelu_f(o[k]);
+      if (drop_on) o[k] *= drop_mult(dc, sample * (uint32_t)C + (uint32_t)(c + k));  // Dropout2d: one draw per (sample, channel)
+    }
+    if (resid) {
+      const float4 rr = reinterpret_cast<const float4*>(resid)[e];
+      o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
+    }
+    reinterpret_cast<float4*>(y)[e] = make_float4(o[0], o[1], o[2], o[3]);
+    if (ya) {
+      if (sizeof(TY) == 4) reinterpret_cast<float4*>(ya)[e] = make_float4(o[0], o[1], o[2], o[3]);
+      else {
+        bf16x4 t;
+        t[0] = (bf16_t)o[0]; t[1] = (bf16_t)o[1]; t[2] = (bf16_t)o[2]; t[3] = (bf16_t)o[3];
+        reinterpret_cast<bf16x4*>(ya)[e] = t;
+      }
+    }
+  }
+}
+
+// da (recomputed, never stored) and its two per-channel sums: sums[0..C) += sum da (= dbeta), sums[C..2C) += sum da*zhat (= dgamma)
+__device__ __forceinline__ void bn_da4(const float4 v, const float4 g, const float* mean_rstd, const float* gamma, const float* beta,
+                                       int c, int C, const DropCtx& dc, bool drop_on, uint32_t sample, float* da, float* zh) {
+  const float vv[4] = {v.x, v.y, v.z, v.w}, gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    zh[k] = (vv[k] - mean_rstd[c + k]) * mean_rstd[C + c + k];
+    const float pre = zh[k] * gamma[c + k] + beta[c + k];
+    float m = 1.f;
+    if (drop_on) m = drop_mult(dc, sample * (uint32_t)C + (uint32_t)(c + k));
+    da[k] = gg[k] * m * gelu_grad_f(pre);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ g,
+                                                            const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ sums, long rows, int C,
+                                                            int rows_per_sample, const uint32_t* rng, uint32_t stream, float p) {
+  extern __shared__ float red[];
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const DropCtx dc = make_drop(rng, stream, p);
+  const bool drop_on = p > 0.f;
+  const int lpr = C / 4, rpb = 256 / lpr;
+  const int li = threadIdx.x % lpr, sub = threadIdx.x / lpr, c = li * 4;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (long r = (long)blockIdx.x * rpb + sub; r < rows; r += (long)gridDim.x * rpb) {
+    float da[4], zh[4];
+    bn_da4(*reinterpret_cast<const float4*>(z + r * C + c), *reinterpret_cast<const float4*>(g + r * C + c), mean_rstd, gamma, beta, c, C,
+           dc, drop_on, (uint32_t)(r / rows_per_sample), da, zh);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s1[k] += da[k]; s2[k] += da[k] * zh[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { atomicAdd(&red[c + k], s1[k]); atomicAdd(&red[C + c + k], s2[k]); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(sums + i, red[i]);
+}
+
+template <typename TD>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ g,
+                                                           const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ sums,
+                                                           TD* __restrict__ dz, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           long rows, int C, int rows_per_sample, const uint32_t* rng, uint32_t stream,
+                                                           float p) {
+  const DropCtx dc = make_drop(rng, stream, p);
+  const bool drop_on = p > 0.f;
+  const float inv_n = 1.0f / (float)rows;
+  if (blockIdx.x == 0 && dgamma) {
+    for (int i = threadIdx.x; i < C; i += 256) { dbeta[i] += sums[i]; dgamma[i] += sums[C + i]; }
+  }
+  const long n4 = rows * C / 4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+    const long r = (e * 4) / C;
+    const int c = (int)((e * 4) % C);
+    float da[4], zh[4], o[4];
+    bn_da4(reinterpret_cast<const float4*>(z)[e], reinterpret_cast<const float4*>(g)[e], mean_rstd, gamma, beta, c, C, dc, drop_on,
+           (uint32_t)(r / rows_per_sample), da, zh);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o[k] = gamma[c + k] * mean_rstd[C + c + k] * (da[k] - sums[c + k] * inv_n - zh[k] * sums[C + c + k] * inv_n);
+    if (sizeof(TD) == 4) reinterpret_cast<float4*>(dz)[e] = make_float4(o[0], o[1], o[2], o[3]);
+    else {
+      bf16x4 t;
+      t[0] = (bf16_t)o[0]; t[1] = (bf16_t)o[1]; t[2] = (bf16_t)o[2]; t[3] = (bf16_t)o[3];
+      reinterpret_cast<bf16x4*>(dz)[e] = t;
+    }
+  }
+}
+
+static int bn_check(const focal_bn_desc* d) {
+  FOCAL_CHECK_ARG(d != nullptr, "bn: null descriptor");
+  FOCAL_CHECK_ARG(d->dtype == FOCAL_F32 || d->dtype == FOCAL_BF16, "bn: bad dtype");
+  FOCAL_CHECK_ARG(d->C >= 4 && d->C <= 1024 && d->C % 4 == 0 && 256 % (d->C / 4) == 0, "bn: unsupported channel count %d", d->C);
+  FOCAL_CHECK_ARG(d->rows > 0 && d->rows_per_sample > 0 && d->rows % d->rows_per_sample == 0, "bn: rows %% rows_per_sample != 0");
+  return FOCAL_OK;
+}
+static int stream_blocks(long rows, int C) {
+  long b = (rows * C / 4 + 255) / 256;
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scratch, float* mean_rstd, float* running_mean,
+                              float* running_var, int training, void* stream) {
+  if (int rc = bn_check(d)) return rc;
+  FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
+  hipStream_t st = (hipStream_t)stream;
+  const int C = d->C;
+  if (!training) {
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, running_mean, running_var, mean_rstd, C, d->eps);
+  } else {
+    FOCAL_CHECK_ARG(z && scratch, "bn_stats: null tensor");
+    (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
+    int blocks = stream_blocks(d->rows, C);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), st, z, scratch, (long)d->rows, C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, mean_rstd, running_mean, running_var,
+                       (long)d->rows, C, d->eps, d->momentum);
+  }
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+extern "C" int focal_bn_act_fwd(const focal_bn_desc* d, const float* z, const float* mean_rstd, const float* gamma, const float* beta,
+                                const float* resid, float* y, void* y_cast, void* stream) {
+  if (int rc = bn_check(d)) return rc;
+  FOCAL_CHECK_ARG(z && mean_rstd && gamma && beta && y, "bn_act_fwd: null tensor");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = stream_blocks(d->rows, d->C);
+  if (d->dtype == FOCAL_F32)
+    hipLaunchKernelGGL((bn_act_fwd_kernel<float>), dim3(blocks), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (float*)y_cast,
+                       (long)d->rows, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+  else
+    hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (bf16_t*)y_cast,
+                       (long)d->rows, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+extern "C" int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const float* g, const float* mean_rstd, const float* gamma,
+                                const float* beta, float* scratch, void* dz, float* dgamma, float* dbeta, void* stream) {
+  if (int rc = bn_check(d)) return rc;
+  FOCAL_CHECK_ARG(z && g && mean_rstd && gamma && beta && scratch && dz && dgamma && dbeta, "bn_act_bwd: null tensor");
+  hipStream_t st = (hipStream_t)stream;
+  const int C = d->C;
+  (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
+  int rb = stream_blocks(d->rows, C);
+  if (rb > 512) rb = 512;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(256), 2 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
+                     (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+  const int blocks = stream_blocks(d->rows, C);
+  if (d->dtype == FOCAL_F32)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (float*)dz,
+                       dgamma, dbeta, (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (bf16_t*)dz,
+                       dgamma, dbeta, (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}

@@ -1,0 +1,278 @@
+// DeepSense ConvBlock convolutions (models/ConvModules.py:115-216) in channel-last token layout [B*I*S, C]:
+//   * in-conv   Conv2d(cin -> C, [1,k], stride [1,s]) straight from the reference's NCHW fp32 spectrum: fp32 FMA
+//               kernel (HBM-bound: the audio layer reads the 128 KB window once; AI ~ 32 flop/B), + its weight gradient;
+//   * inter-convs / flatten+1x1: MFMA GEMMs whose A (or, for dW, B) operand is a sliding window over tokens
+//               (PRO_CONV in gemm.hpp) -- a [1,k] "same" conv over channel-last rows is a GEMM with lda = C_in < K;
+//   * the small weight re-layouts between the reference's [Cout][Cin][1][k] storage and the GEMM operand orders.
+#include "gemm.hpp"
+
+#define CIN_TOK 64
+
+// ------------------------------------------------------------------------------------------------ in-conv forward
+template <int C0>
+__global__ __launch_bounds__(256) void conv_in_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ z,
+                                                          focal_conv_in_desc d, int K, int total) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int KP = K + 1;
+  float* wt = smem;              // [K][C0]
+  float* patch = smem + K * C0;  // [CIN_TOK][KP]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < K * C0; i += 256) wt[i] = w[(i % C0) * K + i / C0];  // w: [C0][cin][1][k] = [C0][K]
+  constexpr int CPT = C0 / 4;
+  const int tl = tid >> 2, q = tid & 3;
+  for (int t0 = blockIdx.x * CIN_TOK; t0 < total; t0 += gridDim.x * CIN_TOK) {
+    __syncthreads();
+    for (int i = tid; i < CIN_TOK * K; i += 256) {
+      const int t = i / K, kk = i % K, tok = t0 + t;
+      float v = 0.f;
+      if (tok < total) {
+        const int so = tok % d.S_out, r = tok / d.S_out, ii = r % d.I, b = r / d.I;
+        const int c = kk / d.k, tt = kk % d.k;
+        const int col = so * d.stride + tt - d.pad_left;
+        if (col >= 0 && col < d.S_in) v = x[(((long)b * d.cin + c) * d.I + ii) * d.S_in + col];
+      }
+      patch[t * KP + kk] = v;
+    }
+    __syncthreads();
+    float acc[CPT];
+#pragma unroll
+    for (int n = 0; n < CPT; ++n) acc[n] = bias[q * CPT + n];
+    for (int kk = 0; kk < K; ++kk) {
+      const float a = patch[tl * KP + kk];
+      const float* wr = wt + kk * C0 + q * CPT;
+#pragma unroll
+      for (int n = 0; n < CPT; n += 4) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr + n);
+        acc[n] += a * wv.x; acc[n + 1] += a * wv.y; acc[n + 2] += a * wv.z; acc[n + 3] += a * wv.w;
+      }
+    }
+    const int tok = t0 + tl;
+    if (tok < total) {
+      float* dst = z + (long)tok * C0 + q * CPT;
+#pragma unroll
+      for (int n = 0; n < CPT; n += 4) *reinterpret_cast<float4*>(dst + n) = make_float4(acc[n], acc[n + 1], acc[n + 2], acc[n + 3]);
+    }
+  }
+}
+
+// dw[n][kk] += sum_tok dz[tok][n] * patch[tok][kk];  dbias[n] += sum_tok dz[tok][n].
+// Thread kk owns column kk of dw for all C0 rows (accumulators in registers) across several 64-token chunks, so the
+// final fp32 atomics of a wave hit CONSECUTIVE addresses of one dw row (the only shape atomics run fast in).
+template <typename TZ, int C0>
+__global__ __launch_bounds__(256) void conv_in_bwd_weight_kernel(const float* __restrict__ x, const TZ* __restrict__ dz,
+                                                                 float* __restrict__ dw, float* __restrict__ dbias,
+                                                                 focal_conv_in_desc d, int K, int total, int chunks_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int KP = K + 1, GP = C0 + 4;
+  float* patch = smem;              // [CIN_TOK][KP]
+  float* g = smem + CIN_TOK * KP;   // [CIN_TOK][GP]
+  const int tid = threadIdx.x;
+  float acc[C0];
+#pragma unroll
+  for (int n = 0; n < C0; ++n) acc[n] = 0.f;
+  float bsum = 0.f;  // threads K..K+C0-1 double as bias-gradient accumulators when they exist
+  const int bn = tid - (256 - C0);  // last C0 threads: bias column
+  for (int ch = 0; ch < chunks_per_wg; ++ch) {
+    const int t0 = (blockIdx.x * chunks_per_wg + ch) * CIN_TOK;
+    if (t0 >= total) break;
+    __syncthreads();
+    for (int i = tid; i < CIN_TOK * K; i += 256) {
+      const int t = i / K, kk = i - t * K, tok = t0 + t;
+      float v = 0.f;
+      if (tok < total) {
+        const int so = tok % d.S_out, r = tok / d.S_out, ii = r % d.I, b = r / d.I;
+        const int c = kk / d.k, tt = kk - c * d.k;
+        const int col = so * d.stride + tt - d.pad_left;
+        if (col >= 0 && col < d.S_in) v = x[(((long)b * d.cin + c) * d.I + ii) * d.S_in + col];
+      }
+      patch[t * KP + kk] = v;
+    }
+    for (int i = tid; i < CIN_TOK * C0; i += 256) {
+      const int t = i / C0, c = i % C0, tok = t0 + t;
+      g[t * GP + c] = tok < total ? to_f32(dz[(long)tok * C0 + c]) : 0.f;
+    }
+    __syncthreads();
+    if (tid < K) {
+      for (int t = 0; t < CIN_TOK; ++t) {
+        const float pv = patch[t * KP + tid];
+        const float* gr = g + t * GP;
+#pragma unroll
+        for (int n = 0; n < C0; n += 4) {
+          const float4 gv = *reinterpret_cast<const float4*>(gr + n);
+          acc[n] += pv * gv.x; acc[n + 1] += pv * gv.y; acc[n + 2] += pv * gv.z; acc[n + 3] += pv * gv.w;
+        }
+      }
+    } else if (bn >= 0) {
+      for (int t = 0; t < CIN_TOK; ++t) bsum += g[t * GP + bn];
+    }
+  }
+  if (tid < K) {
+#pragma unroll
+    for (int n = 0; n < C0; ++n) atomicAdd(dw + (long)n * K + tid, acc[n]);
+  } else if (bn >= 0 && dbias) {
+    atomicAdd(dbias + bn, bsum);
+  }
+}
+
+static int conv_in_check(const focal_conv_in_desc* d) {
+  FOCAL_CHECK_ARG(d != nullptr, "conv_in: null descriptor");
+  FOCAL_CHECK_ARG(d->C == 64, "conv_in: %d output channels unsupported (64 only)", d->C);
+  FOCAL_CHECK_ARG(d->cin * d->k <= 192 && d->k >= 1 && d->stride >= 1, "conv_in: kernel too large for the LDS patch buffer");
+  return FOCAL_OK;
+}
+
+extern "C" int focal_conv_in_fwd(const focal_conv_in_desc* d, const float* x, const float* w, const float* bias, float* z,
+                                 void* stream) {
+  if (int rc = conv_in_check(d)) return rc;
+  FOCAL_CHECK_ARG(x && w && bias && z, "conv_in_fwd: null tensor");
+  const int K = d->cin * d->k, total = d->B * d->I * d->S_out;
+  const size_t sm = ((size_t)K * d->C + (size_t)CIN_TOK * (K + 1)) * sizeof(float);
+  int blocks = ceil_div(total, CIN_TOK);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((conv_in_fwd_kernel<64>), dim3(blocks), dim3(256), sm, (hipStream_t)stream, x, w, bias, z, *d, K, total);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float* x, const void* dz, int dz_dtype, float* dw,
+                                        float* dbias, void* stream) {
+  if (int rc = conv_in_check(d)) return rc;
+  FOCAL_CHECK_ARG(x && dz && dw, "conv_in_bwd_weight: null tensor");
+  const int K = d->cin * d->k, total = d->B * d->I * d->S_out;
+  FOCAL_CHECK_ARG(K + d->C <= 256, "conv_in_bwd_weight: cin*k + C must be <= 256");
+  const size_t sm = ((size_t)CIN_TOK * (K + 1) + (size_t)CIN_TOK * (d->C + 4)) * sizeof(float);
+  const int chunks = ceil_div(total, CIN_TOK);
+  int cpw = ceil_div(chunks, 256);
+  if (cpw < 1) cpw = 1;
+  const int blocks = ceil_div(chunks, cpw);
+  hipStream_t st = (hipStream_t)stream;
+  if (dz_dtype == FOCAL_F32)
+    hipLaunchKernelGGL((conv_in_bwd_weight_kernel<float, 64>), dim3(blocks), dim3(256), sm, st, x, (const float*)dz, dw, dbias, *d, K, total, cpw);
+  else
+    hipLaunchKernelGGL((conv_in_bwd_weight_kernel<bf16_t, 64>), dim3(blocks), dim3(256), sm, st, x, (const bf16_t*)dz, dw, dbias, *d, K, total, cpw);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight re-layouts
+template <typename TD> __global__ void permute_pack_kernel(const float* __restrict__ src, TD* __restrict__ dst, int A, int Bd, int Cd) {
+  const long n = (long)A * Bd * Cd;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int b = e % Bd, c = (e / Bd) % Cd, a = e / ((long)Bd * Cd);  // dst index [a][c][b]
+    dst[e] = from_f32<TD>(src[((long)a * Bd + b) * Cd + c]);
+  }
+}
+__global__ void permute_unpack_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int A, int Bd, int Cd) {
+  const long n = (long)A * Bd * Cd;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int c = e % Cd, b = (e / Cd) % Bd, a = e / ((long)Bd * Cd);  // dst index [a][b][c]
+    dst[e] += src[((long)a * Cd + c) * Bd + b];
+  }
+}
+// w_bwd[ci][t'][co] = w[co][ci][k-1-t']: the data gradient of a "same" conv is the conv with flipped taps
+template <typename TD> __global__ void conv_pack_bwd_kernel(const float* __restrict__ w, TD* __restrict__ dst, int Co, int Ci, int k) {
+  const long n = (long)Co * Ci * k;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int co = e % Co, t = (e / Co) % k, ci = e / ((long)Co * k);
+    dst[e] = from_f32<TD>(w[((long)co * Ci + ci) * k + (k - 1 - t)]);
+  }
+}
+
+extern "C" int focal_permute_pack(int A, int Bd, int Cd, const float* src, void* dst, int dtype, void* stream) {
+  FOCAL_CHECK_ARG(src && dst && A > 0 && Bd > 0 && Cd > 0, "permute_pack: bad argument");
+  const int blocks = min(1024, ceil_div((long)A * Bd * Cd, 256));
+  if (dtype == FOCAL_F32) hipLaunchKernelGGL((permute_pack_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, A, Bd, Cd);
+  else hipLaunchKernelGGL((permute_pack_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, A, Bd, Cd);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+extern "C" int focal_permute_unpack_add(int A, int Bd, int Cd, const float* src, float* dst, void* stream) {
+  FOCAL_CHECK_ARG(src && dst && A > 0 && Bd > 0 && Cd > 0, "permute_unpack_add: bad argument");
+  const int blocks = min(1024, ceil_div((long)A * Bd * Cd, 256));
+  hipLaunchKernelGGL(permute_unpack_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, A, Bd, Cd);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+extern "C" int focal_conv_pack_bwd(const focal_conv_desc* d, const float* w, void* w_bwd, void* stream) {
+  FOCAL_CHECK_ARG(d && w && w_bwd, "conv_pack_bwd: null argument");
+  const int blocks = min(1024, ceil_div((long)d->C_out * d->C_in * d->k, 256));
+  if (d->dtype == FOCAL_F32) hipLaunchKernelGGL((conv_pack_bwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)w_bwd, d->C_out, d->C_in, d->k);
+  else hipLaunchKernelGGL((conv_pack_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)w_bwd, d->C_out, d->C_in, d->k);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ [1,k] convs as GEMMs
+static int conv_check(const focal_conv_desc* d) {
+  FOCAL_CHECK_ARG(d != nullptr, "conv: null descriptor");
+  FOCAL_CHECK_ARG(d->dtype == FOCAL_F32 || d->dtype == FOCAL_BF16, "conv: bad dtype");
+  FOCAL_CHECK_ARG(d->k % 2 == 1 && d->k >= 1, "conv: kernel length %d must be odd ('same' padding)", d->k);
+  FOCAL_CHECK_ARG(d->rows % d->S == 0 && d->C_in % 8 == 0 && d->C_out % 8 == 0, "conv: rows %% S != 0 or channels not multiples of 8");
+  return FOCAL_OK;
+}
+static MaskParams conv_window(int S, int C, int pad) {
+  MaskParams m;
+  memset(&m, 0, sizeof(m));
+  m.rows_per_sample = S; m.ncols = C; m.stream_elem = (uint32_t)pad;
+  return m;
+}
+static size_t esize(int dtype) { return dtype == FOCAL_F32 ? 4 : 2; }
+
+extern "C" int focal_conv_fwd(const focal_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* z, void* stream) {
+  if (int rc = conv_check(d)) return rc;
+  FOCAL_CHECK_ARG(x && w_fwd && z, "conv_fwd: null tensor");
+  const int pad = d->k / 2, K = d->k * d->C_in;
+  GemmSpec s{d->dtype, d->dtype, d->dtype, FOCAL_F32, false, false, PRO_CONV, PRO_NONE, EPI_STORE};
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->rows; p.N = d->C_out; p.K = K;
+  p.A = (const char*)x - (size_t)pad * d->C_in * esize(d->dtype); p.lda = d->C_in;   // A[m][kk] = tokens[(m - pad) * C_in + kk]
+  p.B = w_fwd; p.ldb = K;
+  p.C = z; p.ldc = d->C_out;
+  p.batch = 1; p.splits = 1; p.alpha = 1.f; p.bias = bias;
+  p.proA = conv_window(d->S, d->C_in, pad);
+  return focal_launch_gemm(s, p, (hipStream_t)stream);
+}
+
+extern "C" int focal_conv_bwd_data(const focal_conv_desc* d, const void* dz, const void* w_bwd, const float* g_in, float* g_out,
+                                   void* stream) {
+  if (int rc = conv_check(d)) return rc;
+  FOCAL_CHECK_ARG(dz && w_bwd && g_in && g_out, "conv_bwd_data: null tensor");
+  const int pad = d->k / 2, K = d->k * d->C_out;
+  GemmSpec s{d->dtype, d->dtype, d->dtype, FOCAL_F32, false, false, PRO_CONV, PRO_NONE, EPI_RESID};
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->rows; p.N = d->C_in; p.K = K;
+  p.A = (const char*)dz - (size_t)pad * d->C_out * esize(d->dtype); p.lda = d->C_out;
+  p.B = w_bwd; p.ldb = K;
+  p.C = g_out; p.ldc = d->C_in;
+  p.resid = g_in; p.ldr = d->C_in;
+  p.batch = 1; p.splits = 1; p.alpha = 1.f;
+  p.proA = conv_window(d->S, d->C_out, pad);
+  return focal_launch_gemm(s, p, (hipStream_t)stream);
+}
+
+extern "C" int focal_conv_bwd_weight(const focal_conv_desc* d, const void* dz, const void* x, float* dw_packed, float* dbias,
+                                     void* stream) {
+  if (int rc = conv_check(d)) return rc;
+  FOCAL_CHECK_ARG(dz && x && dw_packed, "conv_bwd_weight: null tensor");
+  const int pad = d->k / 2, K = d->k * d->C_in;
+  GemmSpec s{d->dtype, d->dtype, d->dtype, FOCAL_F32, true, true, PRO_NONE, PRO_CONV, EPI_ATOMIC};
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->C_out; p.N = K; p.K = d->rows;
+  p.A = dz; p.lda = d->C_out;
+  p.B = (const char*)x - (size_t)pad * d->C_in * esize(d->dtype); p.ldb = d->C_in;
+  p.C = dw_packed; p.ldc = K;
+  p.batch = 1; p.alpha = 1.f;
+  const long tiles = (long)ceil_div(d->C_out, 64) * ceil_div(K, 64);
+  long splits = (512 + tiles - 1) / tiles;
+  const long max_splits = (d->rows + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.splits = (int)splits;
+  p.proB = conv_window(d->S, d->C_in, pad);
+  p.colsumA = dbias;
+  return focal_launch_gemm(s, p, (hipStream_t)stream);
+}

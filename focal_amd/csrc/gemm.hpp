@@ -11,7 +11,7 @@
 #pragma once
 #include "common.hpp"
 
-enum GemmPro { PRO_NONE = 0, PRO_GELU = 1, PRO_MASK = 2 };
+enum GemmPro { PRO_NONE = 0, PRO_GELU = 1, PRO_MASK = 2, PRO_CONV = 3 };
 enum GemmEpi { EPI_STORE = 0, EPI_RESID = 1, EPI_MUL_AUX = 2, EPI_RELU = 3, EPI_RELU_BWD = 4, EPI_ATOMIC = 5, EPI_GELU_FWD = 6 };
 
 struct MaskParams {
@@ -43,13 +43,23 @@ struct MaskEval {
   DropCtx e, p;
   bool on_e, on_p;
   int rps, ncols;
+  uint32_t pad;
   __device__ __forceinline__ void init(const MaskParams& m) {
+    pad = m.stream_elem;
     on_e = m.p_elem > 0.f;
     on_p = m.p_path > 0.f;
     e = make_drop(m.seed, m.stream_elem, m.p_elem);
     p = make_drop(m.seed, m.stream_path, m.p_path);
     rps = m.rows_per_sample > 0 ? m.rows_per_sample : 1;
     ncols = m.ncols;
+  }
+  // PRO_CONV: the operand is a [1, k] "same" convolution window over channel-last tokens: memory row m, column
+  // kk = tap * Cin + ci reads token m + tap - pad, valid only while it stays inside the same interval of S tokens
+  // (rows_per_sample = S, ncols = Cin, stream_elem = pad).
+  __device__ __forceinline__ bool conv_valid(int row, int col, uint32_t pad) const {
+    const int s = row % rps, t = col / ncols;
+    const int q = s + t - (int)pad;
+    return q >= 0 && q < rps;
   }
   __device__ __forceinline__ float row_mult(int row) const { return on_p ? drop_mult(p, (uint32_t)(row / rps)) : 1.0f; }
   __device__ __forceinline__ float elem_mult(int row, int col) const {
@@ -109,6 +119,8 @@ __device__ __forceinline__ void apply_prologue(float* f, int n, int row, int col
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       if (e < n) f[e] = gelu_f(f[e]) * me.elem_mult(row, col0 + e);
+  } else if (PRO == PRO_CONV) {
+    // nothing to do: invalid taps were predicated off at load time and arrive as zeros
   } else {  // PRO_MASK
     const float rm = me.row_mult(row);
 #pragma unroll
@@ -128,17 +140,22 @@ template <typename CT, typename TG, bool TRANS, int PRO, int BI> struct OperandS
   RawChunk<TG, EC> raw[NCH];
 
   // i_ext: extent of the non-reduced index, r_ext: extent of the reduced index (both in elements)
-  __device__ __forceinline__ void load(const TG* base, long ld, int i0, int r0, int i_ext, int r_end, int tid) {
+  __device__ __forceinline__ void load(const TG* base, long ld, int i0, int r0, int i_ext, int r_end, int tid,
+                                       const MaskEval& me) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = tid + 256 * j;
       const int a = c / CPR, b = (c % CPR) * EC;
       if (TRANS) {  // memory [r][i]
         const int r = r0 + a, i = i0 + b;
-        raw_load(raw[j], base + (long)r * ld + i, (r < r_end) && (i < i_ext));
+        bool ok = (r < r_end) && (i < i_ext);
+        if (PRO == PRO_CONV) ok = ok && me.conv_valid(r, i, me.pad);  // out-of-window taps are never dereferenced
+        raw_load(raw[j], base + (long)r * ld + i, ok);
       } else {  // memory [i][r]
         const int i = i0 + a, r = r0 + b;
-        raw_load(raw[j], base + (long)i * ld + r, (i < i_ext) && (r < r_end));
+        bool ok = (i < i_ext) && (r < r_end);
+        if (PRO == PRO_CONV) ok = ok && me.conv_valid(i, r, me.pad);
+        raw_load(raw[j], base + (long)i * ld + r, ok);
       }
     }
   }
@@ -268,16 +285,16 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   StA sa;
   StB sb;
   if (kt0 < kt1) {
-    sa.load(A, p.lda, m0, kt0 * BK, p.M, k_end, tid);
-    sb.load(B, p.ldb, n0, kt0 * BK, p.N, k_end, tid);
+    sa.load(A, p.lda, m0, kt0 * BK, p.M, k_end, tid, meA);
+    sb.load(B, p.ldb, n0, kt0 * BK, p.N, k_end, tid, meB);
   }
   for (int kt = kt0; kt < kt1; ++kt) {
     sa.store(ldsA, m0, kt * BK, tid, meA);
     sb.store(ldsB, n0, kt * BK, tid, meB);
     __syncthreads();
     if (kt + 1 < kt1) {
-      sa.load(A, p.lda, m0, (kt + 1) * BK, p.M, k_end, tid);
-      sb.load(B, p.ldb, n0, (kt + 1) * BK, p.N, k_end, tid);
+      sa.load(A, p.lda, m0, (kt + 1) * BK, p.M, k_end, tid, meA);
+      sb.load(B, p.ldb, n0, (kt + 1) * BK, p.N, k_end, tid, meB);
     }
     if (TRA) {
       if (do_colsum && tid < BM) {

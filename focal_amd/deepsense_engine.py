@@ -1,0 +1,185 @@
+"""Execution of one (location, modality) DeepSense encoder on the HIP kernels, forward and backward
+(reference: models/DeepSense.py:108-157 -> ConvBlock (ConvModules.py:187-216) -> RecurrentBlock (RecurrentModule.py:14-31)).
+
+Layout: activations are channel-last tokens [B*I*S, C] (row = (sample, interval, spectrum bin)), so
+  * every [1,k] conv is an MFMA GEMM over a sliding row window, BatchNorm statistics are column sums,
+  * the reference's permute + reshape to [B, C*S, I] before the 1x1 Conv1d is a plain row-major view [B*I, S*C]
+    (the 1x1 weight is re-ordered from (c*S + s) to (s*C + c) on the fly), and its output [B*I, 128] is already
+    the batch-first GRU input.
+GRU: input projections for all 10 steps in one GEMM per direction; per step one [B,H]x[H,3H] GEMM + one gate
+kernel; backward mirrors it and ends with ONE weight-gradient GEMM per matrix over all steps.
+"""
+import torch
+
+from . import ops
+from ._lib import ACT_NONE, EPI_NONE
+
+
+class DeepSenseModEncoder:
+    def __init__(self, backbone, loc, mod, mod_index):
+        self.bb, self.loc, self.mod, self.mod_index = backbone, loc, mod, mod_index
+        self.pre = f"loc_mod_extractors.{loc}.{mod}"
+        self.rnn = f"recurrent_layers.{mod}.gru"
+        self.geo = backbone.geometry[loc][mod]
+
+    def _stream(self, view, uid):
+        return ((view * 8 + self.mod_index) * 64 + uid) * 8
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x_freq, view, training):
+        bb, ar, geo = self.bb, self.bb.arena(), self.geo
+        ct = bb.compute_dtype
+        cc, f32 = ops.code(ct), ops.code(torch.float32)
+        rng = bb.rng_state() if training else None
+        p_drop = bb.drop_rate if training else 0.0
+        if x_freq.dtype != torch.float32 or not x_freq.is_contiguous():
+            x_freq = x_freq.float().contiguous()
+        B, cin, I, S_in = x_freq.shape
+        S, C = geo["S"], geo["C"]
+        rows = B * I * S
+        buf = bb.buffer
+        sv = dict(B=B, view=view, x=x_freq, layers=[])
+        # ---- conv stack
+        pin = f"{self.pre}.conv_layer_in"
+        d_in = ops.conv_in_desc(B, cin, I, S_in, S, geo["k_in"], geo["stride"], geo["pad_in"], C)
+        z = ops.conv_in_fwd(d_in, x_freq, ar.master(f"{pin}.conv.weight"), ar.master(f"{pin}.conv.bias"))
+        d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 0))
+        mr = ops.bn_stats(d_bn, z, buf(f"{pin}.batch_norm.running_mean"), buf(f"{pin}.batch_norm.running_var"), training)
+        y, ya = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pin}.batch_norm.weight"), ar.master(f"{pin}.batch_norm.bias"), None, ct)
+        sv["in"] = dict(d=d_in, z=z, mr=mr, d_bn=d_bn, p=pin)
+        if training:
+            buf(f"{pin}.batch_norm.num_batches_tracked").add_(1)
+        k = geo["k"]
+        d_cv = ops.conv_desc(cc, rows, S, C, C, k)
+        for li in range(geo["n_inter"]):
+            pl = f"{self.pre}.conv_layers_inter.{li}"
+            w = ar.master(f"{pl}.conv.weight")  # [C, C, 1, k]
+            w_fwd = ops.permute_pack(w, C, C, k, ct)
+            z = ops.conv_fwd(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"))
+            d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 1 + li))
+            mr = ops.bn_stats(d_bn, z, buf(f"{pl}.batch_norm.running_mean"), buf(f"{pl}.batch_norm.running_var"), training)
+            y_next, ya_next = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pl}.batch_norm.weight"), ar.master(f"{pl}.batch_norm.bias"), y, ct)
+            sv["layers"].append(dict(p=pl, z=z, mr=mr, d_bn=d_bn, xa=ya))
+            y, ya = y_next, ya_next
+            if training:
+                buf(f"{pl}.batch_norm.num_batches_tracked").add_(1)
+        sv["d_cv"] = d_cv
+        pout = f"{self.pre}.conv_layer_out"
+        n_out = geo["C_out"]
+        w_out = ops.permute_pack(ar.master(f"{pout}.weight"), n_out, C, S, ct)  # [n][c*S + s] -> [n][s*C + c]
+        d_out = ops.linear_desc(cc, B * I, n_out, S * C, cc, f32)
+        c_out = torch.empty(B * I, n_out, dtype=torch.float32, device=y.device)
+        ops.linear_fwd(d_out, ya, w_out, ar.master(f"{pout}.bias"), None, c_out)
+        sv.update(ya_last=ya, w_out=w_out, d_out=d_out, pout=pout)
+        # ---- bidirectional GRU
+        T, H = I, geo["H"]
+        gd = ops.GRUDesc(B, T, H)
+        x_l = c_out
+        sv["gru"] = []
+        for layer in range(geo["n_rnn"]):
+            F = x_l.shape[1]
+            out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=y.device)
+            lsv = dict(x=x_l, dirs=[])
+            for di, suf in enumerate(("", "_reverse")):
+                wih, whh = f"{self.rnn}.weight_ih_l{layer}{suf}", f"{self.rnn}.weight_hh_l{layer}{suf}"
+                bih, bhh = f"{self.rnn}.bias_ih_l{layer}{suf}", f"{self.rnn}.bias_hh_l{layer}{suf}"
+                d_ih = ops.linear_desc(cc, B * T, 3 * H, F, f32, f32)
+                gi = torch.empty(B * T, 3 * H, dtype=torch.float32, device=y.device)
+                ops.linear_fwd(d_ih, x_l, ar.operand(wih), ar.master(bih), None, gi)
+                d_hh = ops.linear_desc(cc, B, 3 * H, H, f32, f32)
+                hs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=y.device)  # hs[0] = h0 = 0
+                save = torch.empty(T, 4, B, H, dtype=torch.float32, device=y.device)
+                gh = torch.empty(B, 3 * H, dtype=torch.float32, device=y.device)
+                for s in range(T):
+                    t = s if di == 0 else T - 1 - s
+                    ops.linear_fwd(d_hh, hs[s], ar.operand(whh), ar.master(bhh), None, gh)
+                    ops.gru_gate_fwd(gd, t, di * H, gi, gh, hs[s], hs[s + 1], out, save[s])
+                lsv["dirs"].append(dict(names=(wih, whh, bih, bhh), d_ih=d_ih, d_hh=d_hh, hs=hs, save=save))
+            sv["gru"].append(lsv)
+            if layer + 1 < geo["n_rnn"]:
+                if p_drop > 0:  # nn.GRU applies dropout to the outputs of every layer but the last
+                    sid = self._stream(view, 16 + layer)
+                    x_l = ops.dropout(out.view(B * T, 2 * H), rng, sid, p_drop)
+                    lsv["drop"] = (rng, sid, p_drop)
+                else:
+                    x_l = out.view(B * T, 2 * H)
+        feat = ops.mean_time(out, B, T, 2 * H)
+        sv.update(gd=gd, T=T, H=H)
+        return feat, sv
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, sv, dfeat):
+        bb, ar, geo = self.bb, self.bb.arena(), self.geo
+        ct = bb.compute_dtype
+        cc, f32 = ops.code(ct), ops.code(torch.float32)
+        dev = dfeat.device
+        if dfeat.dtype != torch.float32 or not dfeat.is_contiguous():
+            dfeat = dfeat.float().contiguous()
+        B, T, H, gd = sv["B"], sv["T"], sv["H"], sv["gd"]
+        # ---- GRU, last layer first
+        dout, ld_b, ld_t, scale = dfeat, 2 * H, 0, 1.0 / T  # d(mean over time): every step gets dfeat / T
+        for layer in range(geo["n_rnn"] - 1, -1, -1):
+            lsv = sv["gru"][layer]
+            x_l = lsv["x"]
+            F = x_l.shape[1]
+            dx = None
+            for di, dsv in enumerate(lsv["dirs"]):
+                wih, whh, bih, bhh = dsv["names"]
+                hs, save = dsv["hs"], dsv["save"]
+                dgi = torch.empty(B * T, 3 * H, dtype=torch.float32, device=dev)
+                dgh = torch.empty(T, B, 3 * H, dtype=torch.float32, device=dev)
+                dhz = torch.empty(2, B, H, dtype=torch.float32, device=dev)
+                dh_rec = torch.empty(B, H, dtype=torch.float32, device=dev)
+                have = False
+                for s in range(T - 1, -1, -1):
+                    t = s if di == 0 else T - 1 - s
+                    ops.gru_gate_bwd(gd, t, di * H, dout, ld_b, ld_t, scale, dh_rec if have else None, dhz[(s + 1) & 1] if have else None,
+                                     save[s], hs[s], dgi, dgh[s], dhz[s & 1])
+                    if s > 0:
+                        ops.linear_bwd_data(dsv["d_hh"], dgh[s], ar.operand(whh), None, dh_rec)
+                        have = True
+                d_hh_all = ops.linear_desc(cc, T * B, 3 * H, H, f32, f32)
+                ops.linear_bwd_weight(d_hh_all, dgh, hs[:T], ar.g(whh), ar.g(bhh))
+                ops.linear_bwd_weight(dsv["d_ih"], dgi, x_l, ar.g(wih), ar.g(bih))
+                dxi = torch.empty(B * T, F, dtype=torch.float32, device=dev)
+                ops.linear_bwd_data(dsv["d_ih"], dgi, ar.operand(wih), None, dxi)
+                if dx is None:
+                    dx = dxi
+                else:
+                    ops.axpy(1.0, dxi, dx)
+            if layer > 0:
+                prev = sv["gru"][layer - 1]
+                if "drop" in prev:
+                    rng, sid, p = prev["drop"]
+                    dx = ops.dropout(dx, rng, sid, p)
+                dout, ld_b, ld_t, scale = dx, T * 2 * H, 2 * H, 1.0
+        # ---- flatten + 1x1 output conv
+        C, S, I = geo["C"], geo["S"], T
+        rows = B * I * S
+        pout, d_out = sv["pout"], sv["d_out"]
+        n_out = geo["C_out"]
+        dwp = torch.zeros(n_out, S * C, dtype=torch.float32, device=dev)
+        ops.linear_bwd_weight(d_out, dx, sv["ya_last"], dwp, ar.g(f"{pout}.bias"))
+        ops.permute_unpack_add(dwp, ar.g(f"{pout}.weight"), n_out, C, S)
+        d_out_data = ops.linear_desc(cc, B * I, n_out, S * C, f32, f32)  # gradient w.r.t. the fp32 residual stream
+        g = torch.empty(rows, C, dtype=torch.float32, device=dev)
+        ops.linear_bwd_data(d_out_data, dx, sv["w_out"], None, g)
+        # ---- residual conv layers
+        d_cv, k = sv["d_cv"], geo["k"]
+        for li in range(geo["n_inter"] - 1, -1, -1):
+            L = sv["layers"][li]
+            pl = L["p"]
+            dz = ops.bn_act_bwd(L["d_bn"], L["z"], g, L["mr"], ar.master(f"{pl}.batch_norm.weight"), ar.master(f"{pl}.batch_norm.bias"),
+                                ar.g(f"{pl}.batch_norm.weight"), ar.g(f"{pl}.batch_norm.bias"), ct)
+            dwp = torch.zeros(C, k * C, dtype=torch.float32, device=dev)
+            ops.conv_bwd_weight(d_cv, dz, L["xa"], dwp, ar.g(f"{pl}.conv.bias"))
+            ops.permute_unpack_add(dwp, ar.g(f"{pl}.conv.weight"), C, C, k)
+            w_bwd = ops.conv_pack_bwd(d_cv, ar.master(f"{pl}.conv.weight"), ct)  # flipped taps, [C_in][k][C_out]
+            ops.conv_bwd_data(d_cv, dz, w_bwd, g, g)  # g <- g + conv^T(dz), in place
+            sv["layers"][li] = None
+        Lin = sv["in"]
+        pin = Lin["p"]
+        dz = ops.bn_act_bwd(Lin["d_bn"], Lin["z"], g, Lin["mr"], ar.master(f"{pin}.batch_norm.weight"), ar.master(f"{pin}.batch_norm.bias"),
+                            ar.g(f"{pin}.batch_norm.weight"), ar.g(f"{pin}.batch_norm.bias"), ct)
+        ops.conv_in_bwd_weight(Lin["d"], sv["x"], dz, ar.g(f"{pin}.conv.weight"), ar.g(f"{pin}.conv.bias"))
+        # the spectrum is a leaf: nothing flows further

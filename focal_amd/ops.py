@@ -11,7 +11,8 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU_OUT, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RESIDUAL, FOCAL_BF16, FOCAL_F32,
-                   AdamWDesc, AttnDesc, DropDesc, EmbedDesc, FFTDesc, LinearDesc, LNDesc, LossDesc, check)
+                   AdamWDesc, AttnDesc, BNDesc, ConvDesc, ConvInDesc, DropDesc, EmbedDesc, FFTDesc, GRUDesc, LinearDesc,
+                   LNDesc, LossDesc, check)
 
 _TORCH2CODE = {torch.float32: FOCAL_F32, torch.bfloat16: FOCAL_BF16}
 _CODE2TORCH = {v: k for k, v in _TORCH2CODE.items()}
@@ -217,3 +218,107 @@ def loss_head(feats1, feats2, temperature, margin, weights, seq=4, no_private=Fa
     ga = (C.c_void_p * (2 * M))(*[_p(g) for g in grads])
     check(lib.focal_loss_head(C.byref(d), fa, _p(terms), ga, _p(ws), ws.numel(), _stream()))
     return terms, grads[:M], grads[M:]
+
+
+# ------------------------------------------------------------------------------------------------ rows 5-6 (DeepSense)
+def conv_in_desc(B, cin, I, S_in, S_out, k, stride, pad_left, Cc):
+    return ConvInDesc(B, cin, I, S_in, S_out, k, stride, pad_left, Cc)
+
+
+def conv_in_fwd(d, x, w, bias):
+    z = torch.empty(d.B * d.I * d.S_out, d.C, dtype=torch.float32, device=x.device)
+    check(_lib.load().focal_conv_in_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(z), _stream()))
+    return z
+
+
+def conv_in_bwd_weight(d, x, dz, dw, dbias):
+    check(_lib.load().focal_conv_in_bwd_weight(C.byref(d), _p(x), _p(dz), code(dz.dtype), _p(dw), _p(dbias), _stream()))
+
+
+def permute_pack(src, A, Bd, Cd, dtype):
+    """dst[a][c][b] = src[a][b][c], cast to `dtype`."""
+    dst = torch.empty(A, Cd, Bd, dtype=dtype, device=src.device)
+    check(_lib.load().focal_permute_pack(A, Bd, Cd, _p(src), _p(dst), code(dtype), _stream()))
+    return dst
+
+
+def permute_unpack_add(src, dst, A, Bd, Cd):
+    """dst[a][b][c] += src[a][c][b] (fp32)."""
+    check(_lib.load().focal_permute_unpack_add(A, Bd, Cd, _p(src), _p(dst), _stream()))
+
+
+def conv_desc(dtype_code, rows, S, C_in, C_out, k):
+    return ConvDesc(dtype_code, rows, S, C_in, C_out, k)
+
+
+def conv_pack_bwd(d, w, dtype):
+    dst = torch.empty(d.C_in, d.k, d.C_out, dtype=dtype, device=w.device)
+    check(_lib.load().focal_conv_pack_bwd(C.byref(d), _p(w), _p(dst), _stream()))
+    return dst
+
+
+def conv_fwd(d, x, w_fwd, bias):
+    z = torch.empty(d.rows, d.C_out, dtype=torch.float32, device=x.device)
+    check(_lib.load().focal_conv_fwd(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(z), _stream()))
+    return z
+
+
+def conv_bwd_data(d, dz, w_bwd, g_in, g_out):
+    check(_lib.load().focal_conv_bwd_data(C.byref(d), _p(dz), _p(w_bwd), _p(g_in), _p(g_out), _stream()))
+
+
+def conv_bwd_weight(d, dz, x, dw_packed, dbias):
+    check(_lib.load().focal_conv_bwd_weight(C.byref(d), _p(dz), _p(x), _p(dw_packed), _p(dbias), _stream()))
+
+
+def bn_desc(dtype_code, rows, Cc, rows_per_sample, p_drop=0.0, rng=None, stream=0, eps=1e-5, momentum=0.1):
+    return BNDesc(dtype_code, rows, Cc, rows_per_sample, eps, momentum, p_drop, _p(rng), stream)
+
+
+def bn_stats(d, z, running_mean, running_var, training):
+    dev = running_mean.device
+    scratch = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
+    mean_rstd = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
+    check(_lib.load().focal_bn_stats(C.byref(d), _p(z), _p(scratch), _p(mean_rstd), _p(running_mean), _p(running_var),
+                                     int(training), _stream()))
+    return mean_rstd
+
+
+def bn_act_fwd(d, z, mean_rstd, gamma, beta, resid, cast_dtype=None):
+    y = torch.empty_like(z)
+    ya = torch.empty(z.shape, dtype=cast_dtype, device=z.device) if cast_dtype not in (None, torch.float32) else None
+    check(_lib.load().focal_bn_act_fwd(C.byref(d), _p(z), _p(mean_rstd), _p(gamma), _p(beta), _p(resid), _p(y), _p(ya), _stream()))
+    return y, (ya if ya is not None else y)
+
+
+def bn_act_bwd(d, z, g, mean_rstd, gamma, beta, dgamma, dbeta, out_dtype):
+    scratch = torch.empty(2 * d.C, dtype=torch.float32, device=z.device)
+    dz = torch.empty(z.shape, dtype=out_dtype, device=z.device)
+    check(_lib.load().focal_bn_act_bwd(C.byref(d), _p(z), _p(g), _p(mean_rstd), _p(gamma), _p(beta), _p(scratch), _p(dz),
+                                       _p(dgamma), _p(dbeta), _stream()))
+    return dz
+
+
+def gru_gate_fwd(d, t, dir_off, gi, gh, h_prev, h_new, out, save):
+    check(_lib.load().focal_gru_gate_fwd(C.byref(d), t, dir_off, _p(gi), _p(gh), _p(h_prev), _p(h_new), _p(out), _p(save), _stream()))
+
+
+def gru_gate_bwd(d, t, dir_off, dout, ld_b, ld_t, scale, dh_rec, dhz_in, save, h_prev, dgi, dgh, dhz_out):
+    check(_lib.load().focal_gru_gate_bwd(C.byref(d), t, dir_off, _p(dout), ld_b, ld_t, scale, _p(dh_rec), _p(dhz_in), _p(save),
+                                         _p(h_prev), _p(dgi), _p(dgh), _p(dhz_out), _stream()))
+
+
+def mean_time(x, B, T, D):
+    y = torch.empty(B, D, dtype=torch.float32, device=x.device)
+    check(_lib.load().focal_mean_time(B, T, D, _p(x), _p(y), _stream()))
+    return y
+
+
+def dropout(x, rng, stream_id, p):
+    y = torch.empty_like(x)
+    check(_lib.load().focal_dropout(x.numel(), _p(x), _p(y), _p(rng), stream_id, p, _stream()))
+    return y
+
+
+def axpy(a, x, y):
+    check(_lib.load().focal_axpy(x.numel(), a, _p(x), _p(y), _stream()))

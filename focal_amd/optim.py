@@ -14,6 +14,7 @@ class FocalAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._lr_dev = None
         self._lr_host = None
+        self._step_state = None  # device {., step}: this optimizer's own step counter (AdamW bias correction)
 
     def _arenas(self):
         arenas, seen = [], set()
@@ -32,6 +33,7 @@ class FocalAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         # gradients are views of the arena's grad buffer: zero the buffer, keep the views
         for ar in self._arenas():
+            runtime.join_all(ar.device)  # encoder backward kernels run on side streams and write the arena directly
             ar.zero_grad()
 
     def sync_lr(self):
@@ -51,15 +53,20 @@ class FocalAdamW(torch.optim.Optimizer):
             raise ops._lib.FocalHipError("FocalAdamW: no arena-backed parameters (run the backbone on the GPU first)")
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
+        runtime.join_all(arenas[0].device)
         for ar in arenas:
             distributed.all_reduce_gradients(ar)  # data parallel: exact global-batch gradient = sum over ranks
         g0 = self.param_groups[0]
-        runtime.advance_step(arenas[0].device)  # step counter (bias correction) + fresh dropout seed
+        dev = arenas[0].device
+        if self._step_state is None:
+            self._step_state = ops.new_rng_state(0, dev)
+        ops.rng_advance(self._step_state)  # this optimizer's step count, on the device (graph-replay safe)
+        runtime.advance_step(dev)          # fresh dropout seed for the next forward
         segs = []
         for ar in arenas:
             m, v = ar.moments()
             segs.append((ar.flat, ar.grad, m, v, ar.shadow))
-        ops.adamw_multi(segs, self._lr_dev, runtime.rng_state(arenas[0].device), g0["betas"][0], g0["betas"][1], g0["eps"],
+        ops.adamw_multi(segs, self._lr_dev, self._step_state, g0["betas"][0], g0["betas"][1], g0["eps"],
                         g0["weight_decay"])
         for ar in arenas:
             ar.mark_shadow_fresh()

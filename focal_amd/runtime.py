@@ -32,3 +32,35 @@ def rng_state(device, seed=None):
 
 def advance_step(device):
     ops.rng_advance(rng_state(device))
+
+
+# ---------------------------------------------------------------------------------------------- side streams
+# The per-(view, modality) encoders are independent until the loss head, and their late stages launch far fewer
+# workgroups than the chip has CUs (72-288 on 256 CUs), so they run on separate HIP streams and overlap; everything
+# is joined back to the caller's stream before the loss head, the optimizer and graph-capture end.
+_SIDE = {}
+
+
+def side_stream(device, index):
+    """index 0 = the caller's current stream; index >= 1 = a dedicated side stream of this device."""
+    if index == 0:
+        return torch.cuda.current_stream(device)
+    key = (torch.device(device), index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def fork(device, index):
+    st = side_stream(device, index)
+    cur = torch.cuda.current_stream(device)
+    if st != cur:
+        st.wait_stream(cur)
+    return st
+
+
+def join_all(device):
+    cur = torch.cuda.current_stream(device)
+    for (dev, _), st in _SIDE.items():
+        if dev == torch.device(device) and st != cur:
+            cur.wait_stream(st)

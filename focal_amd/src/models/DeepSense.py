@@ -1,0 +1,106 @@
+"""DeepSense backbone -- same constructor contract, forward signature, module tree and state_dict as the reference
+(models/DeepSense.py), executed on the MI355X HIP kernels.  FOCAL pretraining path only (`class_head=False`)."""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from focal_amd import runtime  # noqa: E402
+from focal_amd.backbone import HipBackbone, run_stage  # noqa: E402
+from focal_amd.deepsense_engine import DeepSenseModEncoder  # noqa: E402
+from focal_amd.swin_engine import ProjectorHead  # noqa: E402
+from models.ConvModules import ConvBlock  # noqa: E402
+from models.FusionModules import MeanFusionBlock  # noqa: E402
+from models.RecurrentModule import RecurrentBlock  # noqa: E402
+
+
+class DeepSense(HipBackbone):
+    def __init__(self, args) -> None:
+        super().__init__()
+        self.args = args
+        self.config = args.dataset_config["DeepSense"]
+        self.device = args.device
+        self.modalities = args.dataset_config["modality_names"]
+        self.locations = args.dataset_config["location_names"]
+        self.multi_location_flag = len(self.locations) > 1
+        self.drop_rate = self.config["dropout_ratio"]
+        self._init_hip(args)
+        self.init_encoder(args)
+
+    def init_encoder(self, args):
+        cfg, dcfg = self.config, args.dataset_config
+        if self.multi_location_flag:
+            raise NotImplementedError("the MI355X hot path covers single-location datasets (MOD); see DESIGN.md")
+        self.loc_mod_extractors = nn.ModuleDict()
+        self.geometry = {}
+        for loc in self.locations:
+            self.loc_mod_extractors[loc] = nn.ModuleDict()
+            self.geometry[loc] = {}
+            for mod in self.modalities:
+                if type(cfg["loc_mod_conv_lens"]) is dict:
+                    conv_lens, in_stride = cfg["loc_mod_conv_lens"][mod], cfg["loc_mod_in_conv_stride"][mod]
+                else:
+                    conv_lens, in_stride = cfg["loc_mod_conv_lens"], 1
+                blk = ConvBlock(in_channels=dcfg["loc_mod_in_freq_channels"][loc][mod], out_channels=cfg["loc_mod_out_channels"],
+                                in_spectrum_len=dcfg["loc_mod_spectrum_len"][loc][mod], conv_lens=conv_lens,
+                                dropout_ratio=cfg["dropout_ratio"], num_inter_layers=cfg["loc_mod_conv_inter_layers"], in_stride=in_stride)
+                self.loc_mod_extractors[loc][mod] = blk
+                self.geometry[loc][mod] = dict(blk.geometry, H=cfg["recurrent_dim"], n_rnn=cfg["recurrent_layers"])
+        self.loc_fusion_layers = nn.ModuleDict()
+        self.mod_extractors = nn.ModuleDict()
+        for mod in self.modalities:
+            self.loc_fusion_layers[mod] = MeanFusionBlock()
+            self.mod_extractors[mod] = ConvBlock(in_channels=1, out_channels=cfg["loc_out_channels"], in_spectrum_len=cfg["loc_mod_out_channels"],
+                                                 conv_lens=cfg["loc_conv_lens"], dropout_ratio=cfg["dropout_ratio"],
+                                                 num_inter_layers=cfg["loc_conv_inter_layers"])
+        self.recurrent_layers = nn.ModuleDict()
+        for mod in self.modalities:
+            self.recurrent_layers[mod] = RecurrentBlock(in_channel=cfg["loc_out_channels"], out_channel=cfg["recurrent_dim"],
+                                                        num_layers=cfg["recurrent_layers"], dropout_ratio=cfg["dropout_ratio"])
+        out_dim = dcfg["FOCAL"]["emb_dim"]
+        self.mod_projectors = nn.ModuleDict()
+        for mod in self.modalities:
+            self.mod_projectors[mod] = nn.Sequential(nn.Linear(cfg["recurrent_dim"] * 2, out_dim), nn.ReLU(), nn.Linear(out_dim, out_dim))
+        self.sample_dim = cfg["recurrent_dim"] * 2 * len(self.modalities)
+        n_cls = dcfg[args.task]["num_classes"]
+        if args.train_mode == "supervised" or cfg["pretrained_head"] == "linear":
+            self.class_layer = nn.Sequential(nn.Linear(self.sample_dim, n_cls))
+        else:
+            self.class_layer = nn.Sequential(nn.Linear(self.sample_dim, cfg["fc_dim"]), nn.GELU(), nn.Linear(cfg["fc_dim"], n_cls))
+        self._encoders = {(loc, mod): DeepSenseModEncoder(self, loc, mod, mi)
+                          for loc in self.locations for mi, mod in enumerate(self.modalities)}
+        self._heads = {mod: ProjectorHead(self, mod) for mod in self.modalities}
+        self._buffers_by_name = None
+
+    def buffer(self, name):
+        if self._buffers_by_name is None or self._buffers_by_name.get("__dev") != next(self.parameters()).device:
+            self._buffers_by_name = dict(self.named_buffers())
+            self._buffers_by_name["__dev"] = next(self.parameters()).device
+        return self._buffers_by_name[name]
+
+    def forward_encoder(self, freq_x, class_head=True, proj_head=False):
+        if class_head:
+            raise NotImplementedError("class_head=True (supervised / finetune head) is outside the MI355X FOCAL pretraining hot path")
+        loc = self.locations[0]
+        view = self._fwd_calls
+        self._fwd_calls = (self._fwd_calls + 1) & 0xFFFF
+        # one HIP stream per modality encoder (see focal_amd/runtime.py: side streams); joined before returning
+        dev = next(self.parameters()).device
+        cur = torch.cuda.current_stream(dev)
+        out = {}
+        for mi, mod in enumerate(self.modalities):
+            st = runtime.fork(dev, mi)
+            with torch.cuda.stream(st):
+                f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
+                out[mod] = run_stage(self, self._heads[mod], f) if proj_head else f
+                out[mod].record_stream(cur)
+        runtime.join_all(dev)
+        return out
+
+    def forward(self, freq_x, class_head=True, proj_head=False):
+        return self.forward_encoder(freq_x, class_head, proj_head)

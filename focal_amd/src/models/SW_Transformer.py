@@ -14,6 +14,7 @@ _ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
+from focal_amd import runtime  # noqa: E402
 from focal_amd.backbone import HipBackbone, run_stage  # noqa: E402
 from focal_amd.swin_engine import ProjectorHead, SwinModEncoder  # noqa: E402
 from input_utils.padding_utils import get_padded_size  # noqa: E402
@@ -110,12 +111,18 @@ class SW_Transformer(HipBackbone):
         loc = self.locations[0]
         view = self._fwd_calls
         self._fwd_calls = (self._fwd_calls + 1) & 0xFFFF
-        feats = {}
-        for mod in self.modalities:
-            feats[mod] = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
-        if not proj_head:
-            return feats
-        return {mod: run_stage(self, self._heads[mod], feats[mod]) for mod in self.modalities}
+        # one HIP stream per modality encoder (see focal_amd/runtime.py: side streams); joined before returning
+        dev = next(self.parameters()).device
+        cur = torch.cuda.current_stream(dev)
+        out = {}
+        for mi, mod in enumerate(self.modalities):
+            st = runtime.fork(dev, (view % 2) * len(self.modalities) + mi)
+            with torch.cuda.stream(st):
+                f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
+                out[mod] = run_stage(self, self._heads[mod], f) if proj_head else f
+                out[mod].record_stream(cur)
+        runtime.join_all(dev)
+        return out
 
     def forward(self, freq_x, class_head=True, proj_head=False):
         return self.forward_encoder(freq_x, class_head, proj_head)

@@ -126,6 +126,57 @@ int focal_window_attn_fwd(const focal_attn_desc* d, const void* qkv, const float
 int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, const float* bias_table, const void* dout,
                           void* dqkv, float* dbias_table, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ row 5: DeepSense convs
+ * ConvBlock (models/ConvModules.py:115-216) on CHANNEL-LAST tokens: activation [B*I*S, C] (row = (b, interval, s)).
+ * in-conv: Conv2d(cin -> C, [1,k], stride [1,stride], zero pad `pad_left`) read straight from the reference's NCHW fp32
+ * spectrum [B, cin, I, S_in]; fp32; its input is a leaf, so only the weight gradient exists.  w: [C, cin, 1, k]. */
+typedef struct { int B, cin, I, S_in, S_out, k, stride, pad_left, C; } focal_conv_in_desc;
+int focal_conv_in_fwd(const focal_conv_in_desc* d, const float* x, const float* w, const float* bias, float* z, void* stream);
+int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float* x, const void* dz, int dz_dtype, float* dw, float* dbias,
+                             void* stream);
+/* [1,k] "same" convs (k odd) = MFMA GEMMs over a sliding token window.  Operand orders: w_fwd [C_out][k][C_in],
+ * w_bwd [C_in][k][C_out] with taps flipped, both `dtype`, produced from the reference layout [C_out][C_in][1][k] by
+ * focal_permute_pack / focal_conv_pack_bwd (the flatten + Conv1d(1x1) output layer, ConvModules.py:207-216, is
+ * focal_linear_* on weights re-ordered from (c*S + s) to (s*C + c) by focal_permute_pack).
+ * fwd: z (fp32) = conv(x) + bias.  bwd_data: g_out = g_in + conv^T(dz) (fp32; the residual-gradient stream).
+ * bwd_weight: dw_packed [C_out][k][C_in] += dz^T window(x); dbias += column sums; focal_permute_unpack_add folds
+ * dw_packed back into the [C_out][C_in][1][k] gradient. */
+typedef struct { int dtype; int rows, S, C_in, C_out, k; } focal_conv_desc;
+int focal_permute_pack(int A, int Bd, int Cd, const float* src, void* dst, int dtype, void* stream);      /* dst[a][c][b] = src[a][b][c] */
+int focal_permute_unpack_add(int A, int Bd, int Cd, const float* src, float* dst, void* stream);          /* dst[a][b][c] += src[a][c][b] */
+int focal_conv_pack_bwd(const focal_conv_desc* d, const float* w, void* w_bwd, void* stream);
+int focal_conv_fwd(const focal_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* z, void* stream);
+int focal_conv_bwd_data(const focal_conv_desc* d, const void* dz, const void* w_bwd, const float* g_in, float* g_out, void* stream);
+int focal_conv_bwd_weight(const focal_conv_desc* d, const void* dz, const void* x, float* dw_packed, float* dbias, void* stream);
+
+/* BatchNorm2d(eps 1e-5, momentum 0.1) + GELU + Dropout2d + residual of ConvLayer2D (ConvModules.py:98-112,203-204).
+ * focal_bn_stats: training -> batch mean / biased variance of z [rows, C] into mean_rstd [2C] and the momentum update of the
+ * running buffers (unbiased variance); eval -> mean_rstd from the running buffers.  scratch: 2C floats.
+ * focal_bn_act_fwd: y = resid + drop2d(gelu(gamma * zhat + beta)) (fp32), optional `dtype` copy y_cast for the next GEMM.
+ * focal_bn_act_bwd: dz (`dtype`) from g = dL/dy (fp32); dgamma / dbeta accumulated (+=). */
+typedef struct { int dtype; int rows, C, rows_per_sample; float eps, momentum, p_drop; const uint32_t* rng; uint32_t stream; } focal_bn_desc;
+int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scratch, float* mean_rstd, float* running_mean, float* running_var,
+                   int training, void* stream);
+int focal_bn_act_fwd(const focal_bn_desc* d, const float* z, const float* mean_rstd, const float* gamma, const float* beta,
+                     const float* resid, float* y, void* y_cast, void* stream);
+int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const float* g, const float* mean_rstd, const float* gamma,
+                     const float* beta, float* scratch, void* dz, float* dgamma, float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ row 6: bi-GRU
+ * nn.GRU(2 layers, bidirectional) + time mean (models/RecurrentModule.py:5-31).  Matrix products go through
+ * focal_linear_*; these are the per-step gate kernels.  gi: [B*T, 3H] (rows (b, t), b_ih included), gh: [B, 3H] (b_hh
+ * included), out: [B, T, 2H], save: [4][B][H] per step (r, z, n, W_hn h + b_hn).
+ * bwd: dh = scale * dout[b*ld_b + t*ld_t + dir_offset + j] + dh_rec + dhz_in; writes dgi rows (b, t), dgh [B, 3H], dhz_out. */
+typedef struct { int B, T, H; } focal_gru_desc;
+int focal_gru_gate_fwd(const focal_gru_desc* d, int t, int dir_offset, const float* gi, const float* gh, const float* h_prev,
+                       float* h_new, float* out, float* save, void* stream);
+int focal_gru_gate_bwd(const focal_gru_desc* d, int t, int dir_offset, const float* dout, long ld_b, long ld_t, float scale,
+                       const float* dh_rec, const float* dhz_in, const float* save, const float* h_prev, float* dgi, float* dgh,
+                       float* dhz_out, void* stream);
+int focal_mean_time(int B, int T, int D, const float* x, float* y, void* stream);                       /* y[b] = mean_t x[b][t] */
+int focal_dropout(long n, const float* x, float* y, const uint32_t* rng, uint32_t stream_id, float p, void* stream); /* y = x * mask */
+int focal_axpy(long n, float a, const float* x, float* y, void* stream);                                   /* y += a * x */
+
 /* ------------------------------------------------------------------------------------------------ rows 11-13: loss
  * FOCALLoss.forward (models/loss.py:139-218): 2 InfoNCE families on the shared / private halves, orthogonality,
  * temporal ranking.  feats / dfeats are HOST arrays of 2*n_mod device pointers, view-major

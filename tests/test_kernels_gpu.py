@@ -283,3 +283,89 @@ def test_dropout_statistics_and_replay(ops):
     ops.rng_advance(state)
     y2, _ = ops.linear(x, w, None, compute=torch.float32, y_dtype=torch.float32, resid=r, epilogue=EPI_RESIDUAL, out_drop=dd)
     assert not torch.equal(y2 > 0, y > 0)
+
+
+# ---------------------------------------------------------------------------------------------- DeepSense pieces
+@pytest.mark.parametrize("S_in,k,stride,pad", [(1600, 80, 80, 0), (20, 3, 1, 1)])
+def test_conv_in(ops, S_in, k, stride, pad):
+    B, cin, I, C = 3, 2, 10, 64
+    S_out = (S_in + 2 * pad - k) // stride + 1
+    x = rnd(B, cin, I, S_in, scale=10.0, seed=70)
+    w, b = rnd(C, cin, 1, k, scale=(cin * k) ** -0.5, seed=71), rnd(C, seed=72)
+    d = ops.conv_in_desc(B, cin, I, S_in, S_out, k, stride, pad, C)
+    z = ops.conv_in_fwd(d, x, w, b)
+    ref = F.conv2d(x, w, b, stride=(1, stride), padding=(0, pad))  # [B, C, I, S_out]
+    ref_tok = ref.permute(0, 2, 3, 1).reshape(-1, C)
+    assert rel_err(z, ref_tok) < 1e-5
+    dz = rnd(B * I * S_out, C, seed=73)
+    dw, db = torch.zeros_like(w), torch.zeros(C, device=DEV)
+    ops.conv_in_bwd_weight(d, x, dz, dw, db)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    out = F.conv2d(x, wr, br, stride=(1, stride), padding=(0, pad)).permute(0, 2, 3, 1).reshape(-1, C)
+    (out * dz).sum().backward()
+    assert rel_err(dw, wr.grad) < 2e-5 and rel_err(db, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k", [3, 5])
+def test_conv1xk_same_as_sliding_window_gemm(ops, ct, k):
+    B, I, S, C = 3, 10, 20, 64
+    rows = B * I * S
+    x = rnd(rows, C, seed=74, dtype=ct)
+    w, b = rnd(C, C, 1, k, scale=(C * k) ** -0.5, seed=75), rnd(C, seed=76)
+    d = ops.conv_desc(ops.code(ct), rows, S, C, C, k)
+    w_fwd = ops.permute_pack(w, C, C, k, ct)
+    w_bwd = ops.conv_pack_bwd(d, w, ct)
+    z = ops.conv_fwd(d, x, w_fwd, b)
+    wq = w if ct == torch.float32 else w.bfloat16().float()
+    xi = x.float().view(B * I, S, C).permute(0, 2, 1).unsqueeze(2).requires_grad_(True)  # [B*I, C, 1, S]
+    wr = wq.clone().requires_grad_(True)
+    ref4 = F.conv2d(xi, wr, b, padding=(0, k // 2))
+    ref = ref4.squeeze(2).permute(0, 2, 1).reshape(rows, C)
+    assert rel_err(z, ref) < (1e-5 if ct == torch.float32 else 5e-3)
+    dz = rnd(rows, C, seed=77, dtype=ct)
+    ref.backward(dz.float())
+    g_in = rnd(rows, C, seed=78)
+    g = g_in.clone()
+    ops.conv_bwd_data(d, dz, w_bwd, g, g)
+    dx_ref = xi.grad.squeeze(2).permute(0, 2, 1).reshape(rows, C)
+    assert rel_err(g - g_in, dx_ref) < (1e-5 if ct == torch.float32 else 6e-3)
+    dwp = torch.zeros(C, k * C, device=DEV)
+    db = torch.zeros(C, device=DEV)
+    ops.conv_bwd_weight(d, dz, x, dwp, db)
+    dw = torch.zeros_like(w)
+    ops.permute_unpack_add(dwp, dw, C, C, k)
+    assert rel_err(dw, wr.grad) < (2e-5 if ct == torch.float32 else 2e-4)
+    assert rel_err(db, dz.float().sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+def test_batchnorm_gelu_residual(ops, ct):
+    B, I, S, C = 4, 10, 20, 64
+    rows = B * I * S
+    z = rnd(rows, C, scale=3.0, seed=80) + 0.7
+    gam, bet, res = 1 + 0.1 * rnd(C, seed=81), 0.1 * rnd(C, seed=82), rnd(rows, C, seed=83)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    d = ops.bn_desc(ops.code(ct), rows, C, I * S)
+    mr = ops.bn_stats(d, z, rm, rv, True)
+    y, ya = ops.bn_act_fwd(d, z, mr, gam, bet, res, ct)
+    zr = z.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C, eps=1e-5, momentum=0.1).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.copy_(gam); bn.bias.copy_(bet)
+    ref = res + F.gelu(F.batch_norm(zr, None, None, gr, br, True, 0.1, 1e-5))
+    bn(z)
+    assert rel_err(y, ref) < 2e-5
+    assert rel_err(rm, bn.running_mean) < 1e-4 and rel_err(rv, bn.running_var) < 1e-4
+    assert rel_err(ya.float(), ref) < (2e-5 if ct == torch.float32 else 4e-3)
+    g = rnd(rows, C, seed=84)
+    ref.backward(g)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dz = ops.bn_act_bwd(d, z, g, mr, gam, bet, dg, db, ct)
+    assert rel_err(dz.float(), zr.grad) < (5e-5 if ct == torch.float32 else 5e-3)
+    assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+    # eval mode: statistics come from the running buffers
+    mr_e = ops.bn_stats(d, z, rm, rv, False)
+    assert rel_err(mr_e[:C], rm) < 1e-6 and rel_err(mr_e[C:], torch.rsqrt(rv + 1e-5)) < 1e-5
