@@ -52,13 +52,17 @@ class StageFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, x, engine, args):
+        # x may have been produced on another stream (encoders run on side streams): keep its block alive for us
+        x.record_stream(torch.cuda.current_stream(x.device))
         y, saved = engine.forward(x, *args)
         ctx.engine, ctx.saved = engine, saved
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        dx = ctx.engine.backward(ctx.saved, dy.contiguous())
+        dy = dy.contiguous()
+        dy.record_stream(torch.cuda.current_stream(dy.device))  # produced by the loss head on the caller's stream
+        dx = ctx.engine.backward(ctx.saved, dy)
         ctx.saved = None
         return None, dx, None, None
 
@@ -66,5 +70,6 @@ class StageFn(torch.autograd.Function):
 def run_stage(backbone, engine, x, *args):
     if torch.is_grad_enabled():
         return StageFn.apply(backbone._anchor(x.device), x, engine, args)
+    x.record_stream(torch.cuda.current_stream(x.device))
     y, _ = engine.forward(x, *args)
     return y

@@ -295,7 +295,14 @@ static int attn_geometry(const focal_attn_desc* d, AttnGeom* g) {
   return FOCAL_OK;
 }
 
-static const size_t ATT_LDS_BUDGET = 60 * 1024;
+#include <stdlib.h>
+// LDS budget per workgroup: small enough that several workgroups share a CU and overlap their gather / compute /
+// scatter phases (tunable for experiments with FOCAL_ATTN_LDS_KB).
+static size_t att_lds_budget(bool bwd) {
+  const char* e = getenv(bwd ? "FOCAL_ATTN_BWD_LDS_KB" : "FOCAL_ATTN_LDS_KB");
+  const long kb = e ? atol(e) : (bwd ? 40 : 32);
+  return (size_t)(kb < 8 ? 8 : (kb > 60 ? 60 : kb)) * 1024;
+}
 
 extern "C" int focal_window_attn_fwd(const focal_attn_desc* d, const void* qkv, const float* bias_table, void* out,
                                      void* stream) {
@@ -304,7 +311,8 @@ extern "C" int focal_window_attn_fwd(const focal_attn_desc* d, const void* qkv, 
   FOCAL_CHECK_ARG(qkv && bias_table && out, "window_attn_fwd: null tensor");
   const size_t per_win = (size_t)g.N * (3 * g.C + 4) * 4 + 2 * g.N * 4;
   int wpb = 256 / (g.heads * g.N);
-  if ((size_t)wpb * per_win > ATT_LDS_BUDGET) wpb = (int)(ATT_LDS_BUDGET / per_win);
+  const size_t budget = att_lds_budget(false) > per_win ? att_lds_budget(false) : (per_win <= 60 * 1024 ? per_win : 0);
+  if ((size_t)wpb * per_win > budget) wpb = (int)(budget / per_win);
   FOCAL_CHECK_ARG(wpb >= 1, "window_attn_fwd: one window does not fit in LDS");
   const int total = g.B * g.nW;
   int threads = ((wpb * g.heads * g.N + 63) / 64) * 64;
@@ -331,7 +339,8 @@ extern "C" int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, 
   const size_t per_win = (size_t)g.N * (4 * g.C + 4) * 4 + 2 * (size_t)g.heads * g.N * g.N * 4 + 2 * g.N * 4;
   const size_t fixed = (size_t)table * 4;
   int wpb = 256 / (g.heads * g.N);
-  if ((size_t)wpb * per_win + fixed > ATT_LDS_BUDGET) wpb = (int)((ATT_LDS_BUDGET - fixed) / per_win);
+  const size_t budget = att_lds_budget(true) > per_win + fixed ? att_lds_budget(true) : (per_win + fixed <= 60 * 1024 ? per_win + fixed : 0);
+  if ((size_t)wpb * per_win + fixed > budget) wpb = (int)((budget - fixed) / per_win);
   FOCAL_CHECK_ARG(wpb >= 1, "window_attn_bwd: one window does not fit in LDS");
   const int total = g.B * g.nW;
   int threads = ((wpb * g.heads * g.N + 63) / 64) * 64;

@@ -1,4 +1,5 @@
 // bf16-compute instantiations of the MFMA GEMM family (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+#include <stdlib.h>
 #include <type_traits>
 #include "gemm.hpp"
 #define GEMM_CT bf16_t

@@ -1,5 +1,6 @@
 // fp32-compute instantiations of the MFMA GEMM family (v_mfma_f32_16x16x4_f32: exact fp32, the parity mode and
 // the loss head's similarity / distance products).
+#include <stdlib.h>
 #include <type_traits>
 #include "gemm.hpp"
 #define GEMM_CT float

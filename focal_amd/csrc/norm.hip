@@ -88,8 +88,8 @@ template <> __device__ __forceinline__ float4 load_dy4<bf16_t>(const bf16_t* p) 
 template <typename TY, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TY* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     float* __restrict__ dx, int accumulate, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows, int C, int lpr, RowMap map) {
+                                                     float* __restrict__ dx, int accumulate, float* __restrict__ partials,
+                                                     int rows, int C, int lpr, RowMap map) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C]
   for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
   __syncthreads();
@@ -142,9 +142,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TY* __restrict__ dy, 
     atomicAdd(&red[C + c + 0], pb[k].x); atomicAdd(&red[C + c + 1], pb[k].y); atomicAdd(&red[C + c + 2], pb[k].z); atomicAdd(&red[C + c + 3], pb[k].w);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) {
-    atomicAdd(dgamma + i, red[i]);
-    atomicAdd(dbeta + i, red[C + i]);
+  // per-workgroup partial sums; ln_bwd_finalize_kernel folds them into dgamma / dbeta (global atomics from hundreds
+  // of workgroups onto the same 2C addresses run at the contended rate, ~20 G adds/s)
+  for (int i = threadIdx.x; i < 2 * C; i += 256) partials[(long)blockIdx.x * 2 * C + i] = red[i];
+}
+
+// grid (2C / 64, ceil(nblocks / 256)), 1024 threads: thread (r, c) sums 16 of its slice's 256 partial rows, LDS combines
+// the 16 row groups, one atomic per column per slice (<= 8 adds per address).
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ partials, int nblocks, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[16][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int b0 = blockIdx.y * 256, b1 = min(nblocks, b0 + 256);
+  float s = 0.f;
+  if (col < 2 * C)
+    for (int b = b0 + r; b < b1; b += 16) s += partials[(long)b * 2 * C + col];
+  red[r][c] = s;
+  __syncthreads();
+  if (r == 0 && col < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][c];
+    if (col < C) atomicAdd(dgamma + col, t);
+    else atomicAdd(dbeta + col - C, t);
   }
 }
 
@@ -181,22 +202,34 @@ extern "C" int focal_layernorm_fwd(const focal_ln_desc* d, const float* x, const
   return FOCAL_OK;
 }
 
+#define LN_BWD_MAX_BLOCKS 2048
+extern "C" size_t focal_layernorm_bwd_workspace(const focal_ln_desc* d) {
+  return d ? (size_t)LN_BWD_MAX_BLOCKS * 2 * d->C * sizeof(float) : 0;
+}
+
 extern "C" int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const float* x, const float* stats,
                                    const float* gamma, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
-                                   void* stream) {
+                                   void* workspace, size_t workspace_bytes, void* stream) {
   int lpr, nv;
   RowMap map;
   if (int rc = ln_geometry(d, &lpr, &nv, &map)) return rc;
-  FOCAL_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta, "layernorm_bwd: null tensor");
+  FOCAL_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta && workspace, "layernorm_bwd: null tensor");
+  if (workspace_bytes < focal_layernorm_bwd_workspace(d)) {
+    focal_set_error("layernorm_bwd: workspace %zu < %zu bytes", workspace_bytes, focal_layernorm_bwd_workspace(d));
+    return FOCAL_EWORKSPACE;
+  }
   const int rpw = 64 / lpr;
-  int blocks = ceil_div(d->rows, rpw * 4);
-  if (blocks > 512) blocks = 512;  // bounds the per-column atomic fan-in of dgamma / dbeta
+  // ~2 rows per wave: short dependent-load chains and thousands of waves in flight to cover HBM latency
+  int blocks = ceil_div(d->rows, rpw * 4 * 2);
+  if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
   hipStream_t st = (hipStream_t)stream;
   const size_t sm = 2 * d->C * sizeof(float);
-#define LN_BWD(TY, NV) hipLaunchKernelGGL((ln_bwd_kernel<TY, NV>), dim3(blocks), dim3(256), sm, st, (const TY*)dy, x, stats, gamma, dx, accumulate_dx, dgamma, dbeta, d->rows, d->C, lpr, map)
+  float* partials = reinterpret_cast<float*>(workspace);
+#define LN_BWD(TY, NV) hipLaunchKernelGGL((ln_bwd_kernel<TY, NV>), dim3(blocks), dim3(256), sm, st, (const TY*)dy, x, stats, gamma, dx, accumulate_dx, partials, d->rows, d->C, lpr, map)
   if (d->dtype == FOCAL_F32) { if (nv == 1) LN_BWD(float, 1); else if (nv == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
   else { if (nv == 1) LN_BWD(bf16_t, 1); else if (nv == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
 #undef LN_BWD
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(ceil_div(2 * d->C, 64), ceil_div(blocks, 256)), dim3(1024), 0, st, partials, blocks, d->C, dgamma, dbeta);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -17,16 +17,26 @@ ES = 2 if CT == torch.bfloat16 else 4
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
 
 
-def timeit(fn, iters=30):
-    for _ in range(5):
-        fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3  # us
+def timeit(fn, iters=20):
+    """Time `fn` by replaying a captured hipGraph of `iters` launches (no host launch overhead in the number)."""
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(3):
+            g.replay()
+        e1.record(st)
+        e1.synchronize()
+    return e0.elapsed_time(e1) / (3 * iters) * 1e3  # us
 
 
 def report(name, us, nbytes, flops=0):
