@@ -4,31 +4,7 @@
 // (window, head, query row), and results are scattered straight back to original positions.
 // Tiles are 9x9xhead_dim: far too small for MFMA (1.1 % of the model's FLOPs), so this is an LDS + VALU kernel
 // whose job is to move qkv once through HBM.
-#include "common.hpp"
-
-#define ATT_NMAX 16  // max tokens per window
-
-struct AttnGeom {
-  int B, H, W, C, heads, hd, wh, ww, sh, sw, N, nWx, nW, shifted;
-  float scale;
-};
-
-__device__ __forceinline__ int att_token(const AttnGeom& g, int win, int i, int* region) {
-  const int b = win / g.nW, wl = win % g.nW;
-  const int wy = wl / g.nWx, wx = wl % g.nWx;
-  const int Y = wy * g.wh + i / g.ww, X = wx * g.ww + i % g.ww;  // coordinates in the rolled frame
-  if (region) {
-    const int rh = Y < g.H - g.wh ? 0 : (Y < g.H - g.sh ? 1 : 2);
-    const int rw = X < g.W - g.ww ? 0 : (X < g.W - g.sw ? 1 : 2);
-    *region = rh * 3 + rw;
-  }
-  int y = Y, x = X;
-  if (g.shifted) {  // rolled[Y] = original[(Y + sh) mod H]   (torch.roll by -shift, SwinModules.py:307)
-    y = (Y + g.sh) % g.H;
-    x = (X + g.sw) % g.W;
-  }
-  return (b * g.H + y) * g.W + x;
-}
+#include "attn_geom.hpp"
 
 template <typename T> __device__ __forceinline__ void load_vec_f32(const T* p, float* f);
 template <> __device__ __forceinline__ void load_vec_f32<float>(const float* p, float* f) {
@@ -309,6 +285,8 @@ extern "C" int focal_window_attn_fwd(const focal_attn_desc* d, const void* qkv, 
   AttnGeom g;
   if (int rc = attn_geometry(d, &g)) return rc;
   FOCAL_CHECK_ARG(qkv && bias_table && out, "window_attn_fwd: null tensor");
+  if (d->dtype == FOCAL_BF16 && !getenv("FOCAL_ATTN_VALU"))  // matrix-core path (attn_mfma.hip); fp32 stays on the exact VALU kernel
+    return focal_attn_mfma_fwd(g, (const bf16_t*)qkv, bias_table, (bf16_t*)out, d->rng, d->stream, d->p_attn, (hipStream_t)stream);
   const size_t per_win = (size_t)g.N * (3 * g.C + 4) * 4 + 2 * g.N * 4;
   int wpb = 256 / (g.heads * g.N);
   const size_t budget = att_lds_budget(false) > per_win ? att_lds_budget(false) : (per_win <= 60 * 1024 ? per_win : 0);
@@ -335,6 +313,11 @@ extern "C" int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, 
   AttnGeom g;
   if (int rc = attn_geometry(d, &g)) return rc;
   FOCAL_CHECK_ARG(qkv && bias_table && dout && dqkv && dbias_table, "window_attn_bwd: null tensor");
+  if (d->dtype == FOCAL_BF16 && !getenv("FOCAL_ATTN_VALU")) {
+    FOCAL_CHECK_ARG((2 * g.wh - 1) * (2 * g.ww - 1) * g.heads <= 256, "window_attn_bwd: bias table too large");
+    return focal_attn_mfma_bwd(g, (const bf16_t*)qkv, bias_table, (const bf16_t*)dout, (bf16_t*)dqkv, dbias_table, d->rng, d->stream,
+                               d->p_attn, (hipStream_t)stream);
+  }
   const int table = (2 * g.wh - 1) * (2 * g.ww - 1) * g.heads;
   const size_t per_win = (size_t)g.N * (4 * g.C + 4) * 4 + 2 * (size_t)g.heads * g.N * g.N * 4 + 2 * g.N * 4;
   const size_t fixed = (size_t)table * 4;

@@ -1,0 +1,33 @@
+// Window geometry shared by the VALU (attn.hip) and MFMA (attn_mfma.hip) attention kernels.
+#pragma once
+#include "common.hpp"
+
+#define ATT_NMAX 16  // max tokens per window
+
+struct AttnGeom {
+  int B, H, W, C, heads, hd, wh, ww, sh, sw, N, nWx, nW, shifted;
+  float scale;
+};
+
+__device__ __forceinline__ int att_token(const AttnGeom& g, int win, int i, int* region) {
+  const int b = win / g.nW, wl = win % g.nW;
+  const int wy = wl / g.nWx, wx = wl % g.nWx;
+  const int Y = wy * g.wh + i / g.ww, X = wx * g.ww + i % g.ww;  // coordinates in the rolled frame
+  if (region) {
+    const int rh = Y < g.H - g.wh ? 0 : (Y < g.H - g.sh ? 1 : 2);
+    const int rw = X < g.W - g.ww ? 0 : (X < g.W - g.sw ? 1 : 2);
+    *region = rh * 3 + rw;
+  }
+  int y = Y, x = X;
+  if (g.shifted) {  // rolled[Y] = original[(Y + sh) mod H]   (torch.roll by -shift, SwinModules.py:307)
+    y = (Y + g.sh) % g.H;
+    x = (X + g.sw) % g.W;
+  }
+  return (b * g.H + y) * g.W + x;
+}
+
+
+int focal_attn_mfma_fwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, bf16_t* out, const uint32_t* rng, uint32_t stream_id,
+                        float p_attn, hipStream_t st);
+int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, const bf16_t* dout, bf16_t* dqkv, float* dbias_table,
+                        const uint32_t* rng, uint32_t stream_id, float p_attn, hipStream_t st);

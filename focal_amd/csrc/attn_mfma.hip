@@ -1,0 +1,311 @@
+// bf16 window attention on the matrix cores: one wave per (window, head), 16x16x16 MFMA tiles (9 tokens padded to 16).
+// Every contraction is arranged so that a product's accumulator (lane = column, 4 consecutive rows per lane) is
+// DIRECTLY the B operand of the next product (v_mfma_f32_16x16x16_bf16 takes k = 4*(lane>>4)+e, the same map), and the
+// operands contracted over the token index come out of the [token][d] LDS tiles with the hardware transpose read
+// (ds_read_b64_tr_b16).  Both orientations of the 16x16 score tile are computed (2 tiny MFMAs) so that no tile is ever
+// transposed through LDS:
+//   S   = Q K^T  (lane col j, rows i)  -> feeds dK^T = Q^T dS and dV^T = dO^T P
+//   S^T = K Q^T  (lane col i, rows j)  -> feeds O^T = V^T P^T and dQ^T = K^T dS^T
+// The gather (roll + window partition) and scatter are index arithmetic on the original token order, as in attn.hip.
+#include "attn_geom.hpp"
+
+typedef __attribute__((address_space(3))) bf16x4* lds_b4;
+
+__device__ __forceinline__ f32x4 mma16x16(bf16x4 a, bf16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x4 pack4(const float* v) {
+  bf16x4 o;
+  o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+  return o;
+}
+// direct fragment: rows = tokens; lane (row = l&15) holds d = kk*16 + 4*(l>>4) .. +3
+__device__ __forceinline__ bf16x4 frag_rows(const bf16_t* tile, int P, int kk, int lane) {
+  return *reinterpret_cast<const bf16x4*>(tile + (lane & 15) * P + kk * 16 + 4 * (lane >> 4));
+}
+// transposed fragment: lane (row = d = db*16 + (l&15)) holds tokens 4*(l>>4) .. +3
+__device__ __forceinline__ bf16x4 frag_cols(const bf16_t* tile, int P, int db, int lane) {
+  const int q = (lane & 15) >> 2, p = lane & 3;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(tile + (4 * (lane >> 4) + q) * P + db * 16 + 4 * p));
+}
+
+// tok_own: this lane's token index for window slot (lane & 15); other slots come by wave shuffle
+template <int HD>
+__device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* base, long row_stride, int tok_own, int N, int lane) {
+  constexpr int P = HD + 4, CPR = HD / 4;
+#pragma unroll
+  for (int c = lane; c < 16 * CPR; c += 64) {
+    const int t = c / CPR, dc = c % CPR;
+    const int tok = __shfl(tok_own, t, 64);
+    bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (t < N) v = *reinterpret_cast<const bf16x4*>(base + (long)tok * row_stride + dc * 4);
+    *reinterpret_cast<bf16x4*>(tile + t * P + dc * 4) = v;
+  }
+}
+
+// The LDS tiles are private to one wave and DS operations of a wave execute in issue order, so no workgroup barrier
+// is needed between filling a tile and reading fragments from it; this only stops the compiler from reordering.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Per-lane constants of a 16x16 score tile: for each of the lane's 4 accumulator rows, the relative-position index
+// and validity of its (query i, key j).  They depend only on the lane, so they are computed ONCE per kernel: the
+// item loop then contains no integer division (a runtime div/mod costs ~40 VALU instructions on CDNA).
+struct TileIdx {
+  int rel[4];   // relative_position_index(i, j) * heads
+  int qi[4], kj[4];
+  bool ok[4];   // i < N && j < N
+  bool qpad[4]; // i >= N && j < N (padded query row: keep finite)
+};
+template <bool ROWS_ARE_KEYS> __device__ __forceinline__ TileIdx make_tile_idx(const AttnGeom& g, int lane) {
+  TileIdx t;
+  const int grp = lane >> 4, col = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * grp + r;
+    const int i = ROWS_ARE_KEYS ? col : row, j = ROWS_ARE_KEYS ? row : col;
+    t.qi[r] = i; t.kj[r] = j;
+    t.ok[r] = i < g.N && j < g.N;
+    t.qpad[r] = i >= g.N && j < g.N;
+    t.rel[r] = ((i / g.ww - j / g.ww + g.wh - 1) * (2 * g.ww - 1) + (i % g.ww - j % g.ww + g.ww - 1)) * g.heads;
+  }
+  return t;
+}
+
+// softmax of a score tile.  ROWS_ARE_KEYS: lane holds keys j = 4g + r of query i = l & 15 (S^T layout), otherwise
+// lane holds queries i = 4g + r and key j = l & 15 (S layout).  Returns probabilities in s[].
+template <bool ROWS_ARE_KEYS>
+__device__ __forceinline__ void tile_softmax(const AttnGeom& g, const TileIdx& t, float* s, int h, const float* bias_table, int reg_own) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool cross = __shfl(reg_own, t.qi[r], 64) != __shfl(reg_own, t.kj[r], 64);  // shuffles outside divergent code
+    float v = -1.0e30f;
+    if (t.ok[r]) {
+      v = s[r] * g.scale + bias_table[t.rel[r] + h];
+      if (g.shifted && cross) v += -100.0f;  // SwinModules.py:287
+    } else if (t.qpad[r]) {
+      v = 0.f;
+    }
+    s[r] = v;
+  }
+  if (ROWS_ARE_KEYS) {
+    float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - m); sum += s[r]; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] *= inv;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float m = s[r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float e = __expf(s[r] - m), sum = e;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+      s[r] = e / sum;
+    }
+  }
+}
+
+// token index of this lane's window slot; slot coordinates (sy, sx) are loop-invariant, only the window decomposes
+__device__ __forceinline__ int slot_token(const AttnGeom& g, int win, int sy, int sx, int* region) {
+  const int b = win / g.nW, wl = win - b * g.nW;
+  const int wy = wl / g.nWx, wx = wl - wy * g.nWx;
+  const int Y = wy * g.wh + sy, X = wx * g.ww + sx;
+  const int rh = Y < g.H - g.wh ? 0 : (Y < g.H - g.sh ? 1 : 2);
+  const int rw = X < g.W - g.ww ? 0 : (X < g.W - g.sw ? 1 : 2);
+  *region = rh * 3 + rw;
+  int y = Y, x = X;
+  if (g.shifted) {
+    y = Y + g.sh; if (y >= g.H) y -= g.H;
+    x = X + g.sw; if (x >= g.W) x -= g.W;
+  }
+  return (b * g.H + y) * g.W + x;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_table,
+                                                                   bf16_t* __restrict__ out, AttnGeom g, int total_items, int iters,
+                                                                   const uint32_t* rng, uint32_t stream, float p_attn) {
+  constexpr int P = HD + 4, TILE = 16 * P;
+  __shared__ __attribute__((aligned(16))) bf16_t tiles[4][3][TILE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bf16_t* Qt = tiles[wave][0];
+  bf16_t* Kt = tiles[wave][1];
+  bf16_t* Vt = tiles[wave][2];
+  const DropCtx dc = make_drop(rng, stream, p_attn);
+  const bool drop_on = p_attn > 0.f;
+  const int C = g.C;
+  const TileIdx tA = make_tile_idx<true>(g, lane);
+  const int slot = lane & 15, sy = slot / g.ww, sx = slot - sy * g.ww;
+  for (int it = 0; it < iters; ++it) {
+    const int item = (it * gridDim.x + blockIdx.x) * 4 + wave;
+    const bool live = item < total_items;
+    const int win = live ? item / g.heads : 0, h = live ? item % g.heads : 0;
+    int reg_own = 0;
+    const int tok_own = slot < g.N ? slot_token(g, win, sy, sx, &reg_own) : 0;
+    wave_lds_fence();  // previous iteration's fragment reads are issued before these tile writes
+    load_tile<HD>(Qt, qkv + h * HD, 3 * C, tok_own, g.N, lane);
+    load_tile<HD>(Kt, qkv + C + h * HD, 3 * C, tok_own, g.N, lane);
+    load_tile<HD>(Vt, qkv + 2 * C + h * HD, 3 * C, tok_own, g.N, lane);
+    wave_lds_fence();
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};  // S^T: rows j (keys), col i (query)
+#pragma unroll
+    for (int kk = 0; kk < HD / 16; ++kk) st = mma16x16(frag_rows(Kt, P, kk, lane), frag_rows(Qt, P, kk, lane), st);
+    float p[4] = {st[0], st[1], st[2], st[3]};
+    tile_softmax<true>(g, tA, p, h, bias_table, reg_own);
+    const int i = lane & 15;
+    if (drop_on) {
+      const uint32_t base = (((uint32_t)win * g.heads + h) * g.N + i) * g.N;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] *= drop_mult(dc, base + 4 * (lane >> 4) + r);
+    }
+    const bf16x4 pb = pack4(p);
+#pragma unroll
+    for (int db = 0; db < HD / 16; ++db) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      o = mma16x16(frag_cols(Vt, P, db, lane), pb, o);  // O^T[d][i] = sum_j V[j][d] P[i][j]
+      if (live && i < g.N) {
+        const float ov[4] = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<bf16x4*>(out + (long)tok_own * C + h * HD + db * 16 + 4 * (lane >> 4)) = pack4(ov);
+      }
+    }
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_table,
+                                                                   const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+                                                                   float* __restrict__ dbias_table, AttnGeom g, int total_items,
+                                                                   int iters, const uint32_t* rng, uint32_t stream, float p_attn) {
+  constexpr int P = HD + 4, TILE = 16 * P;
+  __shared__ __attribute__((aligned(16))) bf16_t tiles[4][4][TILE];
+  __shared__ float dbacc[256];  // (2wh-1)(2ww-1) x heads <= 256 entries
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bf16_t* Qt = tiles[wave][0];
+  bf16_t* Kt = tiles[wave][1];
+  bf16_t* Vt = tiles[wave][2];
+  bf16_t* Gt = tiles[wave][3];  // dO
+  const int table = (2 * g.wh - 1) * (2 * g.ww - 1) * g.heads;
+  for (int t = threadIdx.x; t < 256; t += 256) dbacc[t] = 0.f;
+  __syncthreads();
+  const DropCtx dc = make_drop(rng, stream, p_attn);
+  const bool drop_on = p_attn > 0.f;
+  const int C = g.C, grp = lane >> 4, col = lane & 15;
+  const TileIdx tA = make_tile_idx<true>(g, lane), tB = make_tile_idx<false>(g, lane);
+  const int slot = lane & 15, sy = slot / g.ww, sx = slot - sy * g.ww;
+  for (int it = 0; it < iters; ++it) {
+    const int item = (it * gridDim.x + blockIdx.x) * 4 + wave;
+    const bool live = item < total_items;
+    const int win = live ? item / g.heads : 0, h = live ? item % g.heads : 0;
+    int reg_own = 0;
+    const int tok_own = slot < g.N ? slot_token(g, win, sy, sx, &reg_own) : 0;
+    wave_lds_fence();
+    load_tile<HD>(Qt, qkv + h * HD, 3 * C, tok_own, g.N, lane);
+    load_tile<HD>(Kt, qkv + C + h * HD, 3 * C, tok_own, g.N, lane);
+    load_tile<HD>(Vt, qkv + 2 * C + h * HD, 3 * C, tok_own, g.N, lane);
+    load_tile<HD>(Gt, dout + h * HD, C, tok_own, g.N, lane);
+    wave_lds_fence();
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, d1 = s1, d2 = s1;
+#pragma unroll
+    for (int kk = 0; kk < HD / 16; ++kk) {
+      const bf16x4 fq = frag_rows(Qt, P, kk, lane), fk = frag_rows(Kt, P, kk, lane);
+      const bf16x4 fv = frag_rows(Vt, P, kk, lane), fg = frag_rows(Gt, P, kk, lane);
+      s1 = mma16x16(fq, fk, s1);  // S   : rows i, col j
+      s2 = mma16x16(fk, fq, s2);  // S^T : rows j, col i
+      d1 = mma16x16(fg, fv, d1);  // dPd : rows i, col j
+      d2 = mma16x16(fv, fg, d2);  // dPd^T
+    }
+    float p1[4] = {s1[0], s1[1], s1[2], s1[3]}, p2[4] = {s2[0], s2[1], s2[2], s2[3]};
+    tile_softmax<false>(g, tB, p1, h, bias_table, reg_own);
+    tile_softmax<true>(g, tA, p2, h, bias_table, reg_own);
+    const uint32_t wbase = ((uint32_t)win * g.heads + h) * g.N;
+    // ---- layout 1: rows i = 4*grp + r, col j
+    float ds1[4], pd1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * grp + r, j = col;
+      const bool ok = i < g.N && j < g.N;
+      const float m = (drop_on && ok) ? drop_mult(dc, (wbase + i) * g.N + j) : 1.f;
+      const float dp = d1[r] * m;
+      float dot = ok ? p1[r] * dp : 0.f;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
+      ds1[r] = ok ? p1[r] * (dp - dot) : 0.f;
+      pd1[r] = ok ? p1[r] * m : 0.f;
+      if (ok && live) atomicAdd(&dbacc[tB.rel[r] + h], ds1[r]);
+    }
+    // ---- layout 2: rows j = 4*grp + r, col i
+    float ds2[4], dpv[4];
+    float dot2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 4 * grp + r, i = col;
+      const bool ok = i < g.N && j < g.N;
+      const float m = (drop_on && ok) ? drop_mult(dc, (wbase + i) * g.N + j) : 1.f;
+      dpv[r] = d2[r] * m;
+      dot2 += ok ? p2[r] * dpv[r] : 0.f;
+    }
+    dot2 += __shfl_xor(dot2, 16, 64);
+    dot2 += __shfl_xor(dot2, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = col < g.N && (4 * grp + r) < g.N;
+      ds2[r] = ok ? p2[r] * (dpv[r] - dot2) : 0.f;
+    }
+    const bf16x4 bds1 = pack4(ds1), bpd1 = pack4(pd1), bds2 = pack4(ds2);
+    const bool st_ok = live && col < g.N;
+    bf16_t* dst = dqkv + (long)tok_own * 3 * C + h * HD + 4 * grp;
+#pragma unroll
+    for (int db = 0; db < HD / 16; ++db) {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 dq = mma16x16(frag_cols(Kt, P, db, lane), bds2, z);  // dQ^T[d][i] = sum_j K[j][d] dS[i][j]
+      const f32x4 dk = mma16x16(frag_cols(Qt, P, db, lane), bds1, z);  // dK^T[d][j] = sum_i Q[i][d] dS[i][j]
+      const f32x4 dv = mma16x16(frag_cols(Gt, P, db, lane), bpd1, z);  // dV^T[d][j] = sum_i dO[i][d] Pd[i][j]
+      if (st_ok) {
+        const float a[4] = {dq[0] * g.scale, dq[1] * g.scale, dq[2] * g.scale, dq[3] * g.scale};
+        const float b[4] = {dk[0] * g.scale, dk[1] * g.scale, dk[2] * g.scale, dk[3] * g.scale};
+        const float c[4] = {dv[0], dv[1], dv[2], dv[3]};
+        *reinterpret_cast<bf16x4*>(dst + db * 16) = pack4(a);
+        *reinterpret_cast<bf16x4*>(dst + C + db * 16) = pack4(b);
+        *reinterpret_cast<bf16x4*>(dst + 2 * C + db * 16) = pack4(c);
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < table; t += 256) atomicAdd(dbias_table + t, dbacc[t]);
+}
+
+int focal_attn_mfma_fwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, bf16_t* out, const uint32_t* rng, uint32_t stream_id,
+                        float p_attn, hipStream_t st) {
+  const int items = g.B * g.nW * g.heads;
+  int blocks = ceil_div(items, 4);
+  if (blocks > 4096) blocks = 4096;
+  const int iters = ceil_div(items, blocks * 4);
+#define LAUNCH(HD) hipLaunchKernelGGL((window_attn_fwd_mfma_kernel<HD>), dim3(blocks), dim3(256), 0, st, qkv, bias_table, out, g, items, iters, rng, stream_id, p_attn)
+  if (g.hd == 16) LAUNCH(16); else if (g.hd == 32) LAUNCH(32); else LAUNCH(64);
+#undef LAUNCH
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, const bf16_t* dout, bf16_t* dqkv, float* dbias_table,
+                        const uint32_t* rng, uint32_t stream_id, float p_attn, hipStream_t st) {
+  const int items = g.B * g.nW * g.heads;
+  int blocks = ceil_div(items, 4);
+  if (blocks > 2048) blocks = 2048;  // 8 workgroups per CU; also bounds the atomic fan-in on the bias-table gradient
+  const int iters = ceil_div(items, blocks * 4);
+#define LAUNCH(HD) hipLaunchKernelGGL((window_attn_bwd_mfma_kernel<HD>), dim3(blocks), dim3(256), 0, st, qkv, bias_table, dout, dqkv, dbias_table, g, items, iters, rng, stream_id, p_attn)
+  if (g.hd == 16) LAUNCH(16); else if (g.hd == 32) LAUNCH(32); else LAUNCH(64);
+#undef LAUNCH
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}

@@ -253,10 +253,15 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  // 1-D grid over (batch x split) x tiles, re-ordered so that each XCD (private L2) owns a contiguous run of
+  // logical ids with the tile index fastest: the column tiles that re-read the same activation rows -- and, in the
+  // weight-gradient GEMMs, all output tiles of one reduction chunk -- then share an L2 instead of re-fetching.
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int ntiles = tiles_m * tiles_n;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = logical % ntiles, z = logical / ntiles;
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int z = blockIdx.y, bz = z / p.splits, sp = z % p.splits;
+  const int bz = z / p.splits, sp = z % p.splits;
 
   const TA* A = reinterpret_cast<const TA*>(p.A) + (long)bz * p.strideA;
   const TB* B = reinterpret_cast<const TB*>(p.B) + (long)bz * p.strideB;

@@ -1,5 +1,13 @@
 """FOCAL framework wrapper (reference: models/FOCALModules.py): the backbone is run on both augmented views."""
+import inspect
+import os
+import sys
+
 import torch.nn as nn
+
+_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
 
 
 class FOCAL(nn.Module):
@@ -12,9 +20,17 @@ class FOCAL(nn.Module):
         self.backbone = backbone
 
     def forward(self, aug_freq_input1, aug_freq_input2, proj_head=False):
-        # two sequential calls, as in the reference (:21-34): BatchNorm statistics are per view
-        mod_features1 = self.backbone(aug_freq_input1, class_head=False, proj_head=proj_head)
-        mod_features2 = self.backbone(aug_freq_input2, class_head=False, proj_head=proj_head)
+        # two backbone calls in program order, as in the reference (:21-34): BatchNorm statistics are per view and the
+        # running buffers see view 1 before view 2.  HIP backbones run each modality encoder on its own stream; the
+        # streams are joined once here, after both views, so late (small) stages of the two views overlap.
+        kw = {}
+        if "defer_join" in inspect.signature(self.backbone.forward).parameters:
+            kw["defer_join"] = True
+        mod_features1 = self.backbone(aug_freq_input1, class_head=False, proj_head=proj_head, **kw)
+        mod_features2 = self.backbone(aug_freq_input2, class_head=False, proj_head=proj_head, **kw)
+        if kw:
+            from focal_amd import runtime
+            runtime.join_all(next(self.backbone.parameters()).device)
         return mod_features1, mod_features2
 
 

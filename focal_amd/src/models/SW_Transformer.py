@@ -104,7 +104,7 @@ class SW_Transformer(HipBackbone):
                           for loc in self.locations for mi, mod in enumerate(self.modalities)}
         self._heads = {mod: ProjectorHead(self, mod) for mod in self.modalities}
 
-    def forward_encoder(self, freq_x, class_head=True, proj_head=False):
+    def forward_encoder(self, freq_x, class_head=True, proj_head=False, defer_join=False):
         if class_head:
             raise NotImplementedError("class_head=True (supervised / finetune head) is outside the MI355X FOCAL pretraining "
                                       "hot path; use class_head=False")
@@ -121,8 +121,9 @@ class SW_Transformer(HipBackbone):
                 f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
                 out[mod] = run_stage(self, self._heads[mod], f) if proj_head else f
                 out[mod].record_stream(cur)
-        runtime.join_all(dev)
+        if not defer_join:  # FOCAL.forward joins once after both views so that their encoders overlap
+            runtime.join_all(dev)
         return out
 
-    def forward(self, freq_x, class_head=True, proj_head=False):
-        return self.forward_encoder(freq_x, class_head, proj_head)
+    def forward(self, freq_x, class_head=True, proj_head=False, defer_join=False):
+        return self.forward_encoder(freq_x, class_head, proj_head, defer_join)

@@ -369,3 +369,45 @@ def test_batchnorm_gelu_residual(ops, ct):
     # eval mode: statistics come from the running buffers
     mr_e = ops.bn_stats(d, z, rm, rv, False)
     assert rel_err(mr_e[:C], rm) < 1e-6 and rel_err(mr_e[C:], torch.rsqrt(rv + 1e-5)) < 1e-5
+
+
+def test_window_attention_dropout_fwd_bwd_consistent(ops):
+    """Attention dropout: forward and backward regenerate the same mask (directional derivative check, exact fp32
+    kernel), and the bf16 matrix-core kernel draws the same mask as the fp32 VALU kernel."""
+    import os
+    B, H, W, C, heads = 3, 6, 12, 64, 4
+    M = B * H * W
+    state = ops.new_rng_state(5, DEV)
+    table = rnd(25, heads, scale=0.5, seed=91)
+    qkv = rnd(M, 3 * C, seed=90)
+    do = rnd(M, C, seed=92)
+    d = ops.attn_desc(ops.code(torch.float32), B, H, W, C, heads, 3, 3, 1, 1, 0.2, state, 77)
+
+    def f(x):
+        o = torch.empty(M, C, device=DEV)
+        ops.window_attn_fwd(d, x, table, o)
+        return o
+    dqkv, dt = torch.empty_like(qkv), torch.zeros_like(table)
+    ops.window_attn_bwd(d, qkv, table, do, dqkv, dt)
+    v = rnd(M, 3 * C, seed=93)
+    eps = 1e-2
+    num = ((f(qkv + eps * v) - f(qkv - eps * v)) * do).sum().item() / (2 * eps)
+    ana = (dqkv * v).sum().item()
+    assert abs(num - ana) < 2e-2 * max(1.0, abs(ana)), (num, ana)
+    # same mask in the bf16 MFMA kernel: outputs agree to bf16 rounding, which a different mask would not
+    d16 = ops.attn_desc(ops.code(torch.bfloat16), B, H, W, C, heads, 3, 3, 1, 1, 0.2, state, 77)
+    o16 = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    ops.window_attn_fwd(d16, qkv.bfloat16(), table, o16)
+    assert rel_err(o16.float(), f(qkv.bfloat16().float())) < 1e-2
+    os.environ["FOCAL_ATTN_VALU"] = "1"
+    try:
+        o16v = torch.empty_like(o16)
+        ops.window_attn_fwd(d16, qkv.bfloat16(), table, o16v)
+        g1, g2 = torch.empty(M, 3 * C, dtype=torch.bfloat16, device=DEV), torch.zeros_like(table)
+        ops.window_attn_bwd(d16, qkv.bfloat16(), table, do.bfloat16(), g1, g2)
+    finally:
+        del os.environ["FOCAL_ATTN_VALU"]
+    assert rel_err(o16.float(), o16v.float()) < 1e-2
+    h1, h2 = torch.empty_like(g1), torch.zeros_like(table)
+    ops.window_attn_bwd(d16, qkv.bfloat16(), table, do.bfloat16(), h1, h2)
+    assert rel_err(h1.float(), g1.float()) < 2e-2 and rel_err(h2, g2) < 2e-2
