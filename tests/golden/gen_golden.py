@@ -280,6 +280,46 @@ def main():
     except FileNotFoundError:
         print("HAR4.yaml not authored yet; skipping 4-modality loss fixture")
 
+    # ---------------------------------------------------------------- 4-modality SW_Transformer (BASELINE configs[4])
+    c4_ref = four_mod_cfg(cfg)
+    c4 = no_dropout(c4_ref)
+    args4 = ref_args("SW_Transformer", c4)
+    args4.dataset, args4.task = "HAR4", "activity_classification"
+    net4 = SW_Transformer(args4)
+    ow.fill_state_dict_(net4.state_dict())
+    st4 = {k: v.clone() for k, v in net4.state_dict().items()}
+    spec4 = ow.swt_state_spec(c4, task="activity_classification")
+    assert list(spec4.keys()) == list(st4.keys())
+    y1, y2 = ow.synthetic_freq_input(c4, 8, seed=303), ow.synthetic_freq_input(c4, 8, seed=404)
+    net4.train()
+    focal4 = freeze_patch_embedding(args4, FOCAL(args4, net4))
+    g1, g2 = focal4(y1, y2, proj_head=True)
+    loss4 = FOCALLoss(args4)(g1, g2)
+    loss4.backward()
+    tr4 = OracleTrainer("SW_Transformer", c4, st4)
+    t4, o1, o2, gr4 = tr4.loss_and_grads(y1, y2)
+    assert abs(float(t4["total"]) - float(loss4)) < 1e-4 * abs(float(loss4)), (float(t4["total"]), float(loss4))
+    fix4 = {"train.loss.reference_total": np.array(float(loss4))}
+    for k in ("shared", "private", "orth", "rank", "total"):
+        fix4[f"train.loss.{k}"] = np.array(float(t4[k]))
+    for m in g1:
+        assert (g1[m] - o1[m]).abs().max().item() < 1e-4
+        fix4[f"train.emb1.{m}"] = g1[m].detach().numpy()
+        fix4[f"train.emb2.{m}"] = g2[m].detach().numpy()
+    names4, norms4 = [], []
+    for k, p_ in net4.named_parameters():
+        if p_.grad is None:
+            continue
+        gerr = (p_.grad - gr4[k]).norm().item()
+        assert gerr < 5e-4 * p_.grad.norm().item() + 1e-5, (k, gerr)
+        names4.append(k)
+        norms4.append(p_.grad.double().norm().item())
+    fix4["train.grad_names"] = np.array(names4)
+    fix4["train.grad_norms"] = np.array(norms4)
+    np.savez_compressed(os.path.join(OUT, "SW_Transformer_4mod_b8.npz"), **fix4)
+    summary["SW_Transformer_4mod_loss"] = float(loss4)
+    summary["SW_Transformer_4mod_params"] = int(sum(p_.numel() for p_ in net4.parameters()))
+
     with open(os.path.join(OUT, "SUMMARY.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))

@@ -18,7 +18,8 @@ def _views(B, mods, seed, scale):
     return f1, f2
 
 
-@pytest.mark.parametrize("name,model", [("swt_b32", "SW_Transformer"), ("ds_b32", "DeepSense"), ("swt_b256", "SW_Transformer")])
+@pytest.mark.parametrize("name,model", [("swt_b32", "SW_Transformer"), ("ds_b32", "DeepSense"), ("swt_b256", "SW_Transformer"),
+                                        ("swt_4mod_b32", "SW_Transformer")])
 def test_loss_head_matches_reference_fixture(cfg, name, model):
     from focal_amd import ops
     fx = np.load(os.path.join(GOLD, f"loss_{name}.npz"))

@@ -94,7 +94,8 @@ def test_oracle_adamw_trajectory_matches_reference(cfg, model):
         assert abs(t["total"] - ref) < 2e-3 * abs(ref)
 
 
-@pytest.mark.parametrize("name,model", [("swt_b32", "SW_Transformer"), ("ds_b32", "DeepSense"), ("swt_b256", "SW_Transformer")])
+@pytest.mark.parametrize("name,model", [("swt_b32", "SW_Transformer"), ("ds_b32", "DeepSense"), ("swt_b256", "SW_Transformer"),
+                                        ("swt_4mod_b32", "SW_Transformer")])
 def test_oracle_loss_matches_reference(cfg, name, model):
     from oracle.loss import focal_loss_terms
     fx = np.load(os.path.join(GOLD, f"loss_{name}.npz"))
@@ -104,7 +105,10 @@ def test_oracle_loss_matches_reference(cfg, name, model):
     f1 = {m: (torch.randn(B, 256, generator=g) * scale).requires_grad_(True) for m in mods}
     f2 = {m: torch.randn(B, 256, generator=g) * scale for m in mods}
     f2 = {m: (0.5 * f2[m] + 0.5 * f1[m].detach()).requires_grad_(True) for m in mods}
-    terms = focal_loss_terms(f1, f2, cfg, model)
+    import copy
+    lcfg = copy.deepcopy(cfg)
+    lcfg["modality_names"] = mods
+    terms = focal_loss_terms(f1, f2, lcfg, model)
     assert abs(float(terms["total"]) - float(fx["loss.reference_total"])) < 2e-5 * abs(float(fx["loss.reference_total"]))
     terms["total"].backward()
     for m in mods:
