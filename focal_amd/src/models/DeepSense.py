@@ -91,6 +91,9 @@ class DeepSense(HipBackbone):
         self._fwd_calls = (self._fwd_calls + 1) & 0xFFFF
         # one HIP stream per modality encoder (see focal_amd/runtime.py: side streams); joined before returning
         dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            from focal_amd._lib import FocalHipError
+            raise FocalHipError("the FOCAL HIP path needs the model on a ROCm device (no CPU fallback)")
         cur = torch.cuda.current_stream(dev)
         out = {}
         for mi, mod in enumerate(self.modalities):
