@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=4)
+    p.add_argument("--roofline-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
+    p.add_argument("--roofline-iters", type=int, default=20)
     return p.parse_args()
 
 
@@ -116,28 +118,36 @@ def time_kernel(fn, iters=20):
 
 
 def roofline(a, step, device):
-    """Live measurement of the dominant kernel: the stage-0 audio MLP up-projection GEMM family
-    (focal_gemm_kernel, M = B*576 tokens, K = 64 -> N = 256).  At K = 64 the GEMM is HBM-bound: algorithmic bytes =
-    read A [M,K] + write C [M,N] (+ the 32 KB weight) in the operand dtype."""
+    """Live measurement of the dominant kernel (largest total time in profiles/r1_h_kernel_stats.csv): the weight-gradient
+    GEMM template focal_gemm_kernel<bf16, A=f32 grad (transposed), B=bf16 act (transposed), fp32 atomic out, 64x64>, timed on
+    its largest instance: dW of the stage-0 audio MLP down-projection, dW[64,256] += g[M,64]^T h[M,256], M = B*576 tokens.
+    HBM-bound (AI = 2*64*256 / (64*4 + 256*2) = 43 flop/B): algorithmic bytes = read g (fp32) + read h + write dW once."""
     ops = step.ops
-    ct = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    es = 2 if ct == torch.bfloat16 else 4
     if a.model != "SW_Transformer":
         return roofline_deepsense(a, step, device)
+    ct = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    es = 2 if ct == torch.bfloat16 else 4
     geo = step.backbone.geometry["shake"]["audio"]["stages"][0]
-    M, K, N = a.batch * geo["H"] * geo["W"], geo["C"], 4 * geo["C"]
-    x = torch.randn(M, K, device=device).to(ct)
-    w = (torch.randn(N, K, device=device) * K ** -0.5).to(ct)
-    b = torch.zeros(N, device=device)
-    y = torch.empty(M, N, dtype=ct, device=device)
-    d = ops.linear_desc(ops.code(ct), M, N, K, ops.code(ct), ops.code(ct))
-    ms = time_kernel(lambda: ops.linear_fwd(d, x, w, b, None, y))
-    bytes_alg = (M * K + M * N + N * K) * es + N * 4
+    M, C = a.batch * geo["H"] * geo["W"], geo["C"]
+    N, K = C, 4 * C  # the forward linear is [M, K=4C] -> [M, N=C]
+    from focal_amd._lib import ACT_GELU, EPI_RESIDUAL
+    g = torch.randn(M, N, device=device)
+    h = torch.randn(M, K, device=device).to(ct)
+    dw = torch.zeros(N, K, device=device)
+    db = torch.zeros(N, device=device)
+    d = ops.linear_desc(ops.code(ct), M, N, K, ops.code(ct), ops.code(torch.float32), ACT_GELU, EPI_RESIDUAL)
+    ms = time_kernel(lambda: ops.linear_bwd_weight(d, g, h, dw, db), iters=a.roofline_iters)
+    bytes_alg = M * N * 4 + M * K * es + N * K * 4
     flops = 2.0 * M * N * K
     gbs = bytes_alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "focal_gemm_kernel<fwd, LN-out -> fc1> M=%d K=%d N=%d" % (M, K, N), "achieved": round(gbs, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "ms_per_launch": round(ms, 5), "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "r1_pmc_roofline_kernel.json")
+    if os.path.exists(tf):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --roofline-only` (see the file's note)
+        traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+    return {"bound": "hbm", "kernel": "focal_gemm_kernel<dW: g[%d,%d]f32^T x h[%d,%d]%s -> fp32 atomics, 64x64 tiles>" % (M, N, M, K, a.dtype),
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "algorithmic_bytes": bytes_alg, "ms_per_launch": round(ms, 5),
+            "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
 
 
 def roofline_deepsense(a, step, device):
@@ -205,6 +215,9 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     rank = dist.get_rank() if world > 1 else 0
     step = Step(a, device)
+    if a.roofline_only:
+        print(json.dumps(roofline(a, step, device)))
+        return
 
     graphed = False
     run = step.run

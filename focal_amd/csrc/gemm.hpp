@@ -130,12 +130,12 @@ __device__ __forceinline__ void apply_prologue(float* f, int n, int row, int col
 }
 
 // One operand's staging state for one workgroup (256 threads).
-template <typename CT, typename TG, bool TRANS, int PRO, int BI> struct OperandStage {
+template <typename CT, typename TG, bool TRANS, int PRO, int BI, int BKM> struct OperandStage {
   using Cfg = GemmCfg<CT>;
-  static constexpr int BK = Cfg::BK, EC = Cfg::EC;
+  static constexpr int BK = Cfg::BK * BKM, EC = Cfg::EC;
   static constexpr int PITCH = TRANS ? (BI + Cfg::PADI) : (BK + Cfg::PADK);
   static constexpr int LDS_ELEMS = TRANS ? BK * PITCH : BI * PITCH;
-  static constexpr int NCH = BI / 32;  // chunks per thread (8*BI chunks / 256 threads)
+  static constexpr int NCH = (BK / EC) * BI / 256;  // 16-byte chunks per thread
   static constexpr int CPR = TRANS ? BI / EC : BK / EC;
   RawChunk<TG, EC> raw[NCH];
 
@@ -159,7 +159,11 @@ template <typename CT, typename TG, bool TRANS, int PRO, int BI> struct OperandS
       }
     }
   }
-  __device__ __forceinline__ void store(CT* lds, int i0, int r0, int tid, const MaskEval& me) {
+  // csum (transposed operands only): running column sums of the prologue'd values.  A thread's chunks always cover
+  // the same EC columns ((tid % CPR) * EC, since 256 % CPR == 0), so the bias gradient accumulates in registers
+  // during staging -- no extra LDS or HBM traffic.
+  template <bool CSUM>
+  __device__ __forceinline__ void store(CT* lds, int i0, int r0, int tid, const MaskEval& me, float* csum) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = tid + 256 * j;
@@ -168,6 +172,10 @@ template <typename CT, typename TG, bool TRANS, int PRO, int BI> struct OperandS
       raw_to_f32(raw[j], f);
       if (TRANS) apply_prologue<PRO>(f, EC, r0 + a, i0 + b, me);
       else apply_prologue<PRO>(f, EC, i0 + a, r0 + b, me);
+      if (CSUM) {
+#pragma unroll
+        for (int e = 0; e < EC; ++e) csum[e] += f[e];
+      }
       store_chunk(lds + a * PITCH + b, f);
     }
   }
@@ -233,12 +241,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <typename CT, typename TA, typename TB, typename TC, bool TRA, bool TRB, int PROA, int PROB, int EPI, int BM, int BN>
+// BKM: reduction-tile multiplier.  The weight-gradient GEMMs (reduction over 1e4-1e5 tokens, tiny output) use 2: twice
+// the bytes in flight per workgroup and half the barriers in a loop that is bound by memory latency.
+template <typename CT, typename TA, typename TB, typename TC, bool TRA, bool TRB, int PROA, int PROB, int EPI, int BM, int BN, int BKM = 1>
 __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   using Cfg = GemmCfg<CT>;
-  constexpr int BK = Cfg::BK, KI = Cfg::KI;
-  using StA = OperandStage<CT, TA, TRA, PROA, BM>;
-  using StB = OperandStage<CT, TB, TRB, PROB, BN>;
+  constexpr int BK = Cfg::BK * BKM, KI = Cfg::KI;
+  using StA = OperandStage<CT, TA, TRA, PROA, BM, BKM>;
+  using StB = OperandStage<CT, TB, TRB, PROB, BN, BKM>;
   using FA = FragLoad<CT, TRA, StA::PITCH>;
   using FB = FragLoad<CT, TRB, StB::PITCH>;
   constexpr int TM = BM / 32, TN = BN / 32;
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float csum = 0.f;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool do_colsum = TRA && (p.colsumA != nullptr) && (n0 == 0);
 
   StA sa;
@@ -294,18 +304,13 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
     sb.load(B, p.ldb, n0, kt0 * BK, p.N, k_end, tid, meB);
   }
   for (int kt = kt0; kt < kt1; ++kt) {
-    sa.store(ldsA, m0, kt * BK, tid, meA);
-    sb.store(ldsB, n0, kt * BK, tid, meB);
+    if (TRA && do_colsum) sa.template store<true>(ldsA, m0, kt * BK, tid, meA, csum);
+    else sa.template store<false>(ldsA, m0, kt * BK, tid, meA, csum);
+    sb.template store<false>(ldsB, n0, kt * BK, tid, meB, csum);
     __syncthreads();
     if (kt + 1 < kt1) {
       sa.load(A, p.lda, m0, (kt + 1) * BK, p.M, k_end, tid, meA);
       sb.load(B, p.ldb, n0, (kt + 1) * BK, p.N, k_end, tid, meB);
-    }
-    if (TRA) {
-      if (do_colsum && tid < BM) {
-#pragma unroll 8
-        for (int r = 0; r < BK; ++r) csum += to_f32(ldsA[r * StA::PITCH + tid]);
-      }
     }
 #pragma unroll
     for (int kk = 0; kk < BK / KI; ++kk) {
@@ -324,7 +329,18 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   }
 
   if (TRA) {
-    if (do_colsum && tid < BM && (m0 + tid) < p.M) atomicAdd(p.colsumA + m0 + tid, csum);
+    if (do_colsum) {  // combine the 256 / CPR threads that share a column group through LDS, then one atomic per column
+      float* red = reinterpret_cast<float*>(lds_raw);
+      __syncthreads();
+      if (tid < BM) red[tid] = 0.f;
+      __syncthreads();
+      constexpr int EC = Cfg::EC;
+      const int cb = (tid % StA::CPR) * EC;
+#pragma unroll
+      for (int e = 0; e < EC; ++e) atomicAdd(&red[cb + e], csum[e]);
+      __syncthreads();
+      if (tid < BM && (m0 + tid) < p.M) atomicAdd(p.colsumA + m0 + tid, red[tid]);
+    }
   }
 
   // ---- epilogue.  The MFMA register layout gives a lane 4 consecutive n of ONE row per accumulator, i.e. a wave

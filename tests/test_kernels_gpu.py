@@ -112,7 +112,7 @@ def test_linear_bwd_fc2_chain(ops, ct):
     db = torch.zeros(N, device=DEV)
     ops.linear_bwd_weight(d, g, h, dw, db)
     assert rel_err(dw, gq.t() @ h.float()) < (2e-5 if ct == torch.float32 else 2e-4)
-    assert rel_err(db, gq.sum(0)) < 1e-4
+    assert rel_err(db, g.sum(0)) < 2e-5  # the bias gradient is summed in fp32 BEFORE the operand is rounded to bf16
 
 
 def test_linear_relu_out_bwd(ops):
