@@ -266,12 +266,7 @@ extern "C" int focal_conv_bwd_weight(const focal_conv_desc* d, const void* dz, c
   p.B = (const char*)x - (size_t)pad * d->C_in * esize(d->dtype); p.ldb = d->C_in;
   p.C = dw_packed; p.ldc = K;
   p.batch = 1; p.alpha = 1.f;
-  const long tiles = (long)ceil_div(d->C_out, 64) * ceil_div(K, 64);
-  long splits = (512 + tiles - 1) / tiles;
-  const long max_splits = (d->rows + 255) / 256;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  p.splits = (int)splits;
+  p.splits = 1;  // chosen with the tile shape in gemm_dispatch.inc (launch_dw)
   p.proB = conv_window(d->S, d->C_in, pad);
   p.colsumA = dbias;
   return focal_launch_gemm(s, p, (hipStream_t)stream);

@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   constexpr int TM = BM / 32, TN = BN / 32;
 
   constexpr int OPER_BYTES = (StA::LDS_ELEMS + StB::LDS_ELEMS) * (int)sizeof(CT);
-  constexpr int STAGE_BYTES = 4 * 32 * (BN / 2 + 4) * 4;  // epilogue staging: 4 waves x 32 rows x (BN/2 + 4) floats
+  constexpr int EPI_RP = (BN / 2 > 64) ? 16 : 32;          // rows per epilogue pass (wide tiles: 16, to fit LDS)
+  constexpr int STAGE_BYTES = 4 * EPI_RP * (BN / 2 + 4) * 4;  // epilogue staging: 4 waves x RP rows x (BN/2 + 4) floats
   constexpr int LDS_BYTES = OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES;
   __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
   CT* lds = reinterpret_cast<CT*>(lds_raw);
@@ -347,33 +348,37 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   // store would touch 16 rows x 32-64 B.  Each wave instead transposes its sub-tile through a private LDS region (32
   // rows per pass) and walks it row-major: 128-256 B contiguous per row for stores, residual / aux loads and, for
   // the atomic form, 256 contiguous bytes per wave-instruction (the only shape fp32 atomics run at full rate in).
-  constexpr int WN = BN / 2, WPITCH = WN + 4;
-  float* stage = reinterpret_cast<float*>(lds_raw) + wave * 32 * WPITCH;
+  constexpr int WN = BN / 2, WPITCH = WN + 4, RP = EPI_RP, TPP = RP / 16;  // MFMA row-tiles per pass
+  float* stage = reinterpret_cast<float*>(lds_raw) + wave * RP * WPITCH;
 #pragma unroll
-  for (int pass = 0; pass < TM / 2; ++pass) {
+  for (int pass = 0; pass < TM / TPP; ++pass) {
     __syncthreads();
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
+    for (int ii = 0; ii < TPP; ++ii) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const f32x4 v = acc[pass * 2 + ii][j] * p.alpha;
+        const f32x4 v = acc[pass * TPP + ii][j] * p.alpha;
         *reinterpret_cast<float4*>(stage + (ii * 16 + (lane & 15)) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
     __syncthreads();
-    const int mbase = m0 + wm * (BM / 2) + pass * 32, nbase = n0 + wn * WN;
+    const int mbase = m0 + wm * (BM / 2) + pass * RP, nbase = n0 + wn * WN;
     if (EPI == EPI_ATOMIC) {
       float* Cf = reinterpret_cast<float*>(C);
       const bool add_bias = p.bias && sp == 0;
-      constexpr int RPI = 64 / WN;  // rows per wave-instruction (1 or 2)
+      constexpr int RPI = WN >= 64 ? 1 : 64 / WN;  // rows per wave-instruction
+      constexpr int CPI = WN >= 64 ? WN / 64 : 1;  // 64-column pieces per row
 #pragma unroll 4
-      for (int rr = 0; rr < 32; rr += RPI) {
-        const int row = rr + lane / WN, col = lane % WN;
-        const int m = mbase + row, n = nbase + col;
-        if (m < p.M && n < p.N) {
-          float v = stage[row * WPITCH + col];
-          if (add_bias) v += p.bias[n];
-          atomicAdd(Cf + (long)m * p.ldc + n, v);
+      for (int rr = 0; rr < RP; rr += RPI) {
+#pragma unroll
+        for (int cp = 0; cp < CPI; ++cp) {
+          const int row = rr + (WN >= 64 ? 0 : lane / WN), col = (WN >= 64 ? cp * 64 + lane : lane % WN);
+          const int m = mbase + row, n = nbase + col;
+          if (m < p.M && n < p.N) {
+            float v = stage[row * WPITCH + col];
+            if (add_bias) v += p.bias[n];
+            atomicAdd(Cf + (long)m * p.ldc + n, v);
+          }
         }
       }
     } else {
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
       f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
       if (p.bias && n < p.N) bias4 = load4(p.bias + n);
 #pragma unroll
-      for (int rr = 0; rr < 32; rr += RPI) {
+      for (int rr = 0; rr < RP; rr += RPI) {
         const int row = rr + lane / LPR;
         const int m = mbase + row;
         if (m >= p.M || n >= p.N) continue;

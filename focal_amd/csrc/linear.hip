@@ -1,5 +1,6 @@
 // focal_linear_{fwd,bwd_data,bwd_weight}: the nn.Linear family of the SW_Transformer / projector stacks, mapped
 // onto the MFMA GEMM templates of gemm.hpp.
+#include <stdlib.h>
 #include "gemm.hpp"
 
 static MaskParams to_mask(const focal_drop_desc& d, int ncols) {
@@ -117,14 +118,7 @@ extern "C" int focal_linear_bwd_weight(const focal_linear_desc* d, const void* d
   p.B = x; p.ldb = d->K;
   p.C = dw; p.ldc = d->K;
   p.batch = 1; p.alpha = 1.f;
-  // reduction chunks: ~512 workgroups of one 64x64 tile each (2 per CU), at least 256 rows per chunk; the atomic
-  // volume is then ~512 x 16 KB = 8 MB per call whatever the weight shape
-  const long tiles = (long)ceil_div(d->N, 64) * ceil_div(d->K, 64);
-  long splits = (512 + tiles - 1) / tiles;
-  const long max_splits = (d->M + 255) / 256;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  p.splits = (int)splits;
+  p.splits = 1;  // chosen with the tile shape in gemm_dispatch.inc (launch_dw)
   p.proA = masked ? to_mask(d->out_drop, d->N) : no_mask();
   p.proB = no_mask();
   p.epi = no_mask();
