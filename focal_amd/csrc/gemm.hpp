@@ -298,20 +298,20 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool do_colsum = TRA && (p.colsumA != nullptr) && (n0 == 0);
 
-  StA sa;
-  StB sb;
-  if (kt0 < kt1) {
-    sa.load(A, p.lda, m0, kt0 * BK, p.M, k_end, tid, meA);
-    sb.load(B, p.ldb, n0, kt0 * BK, p.N, k_end, tid, meB);
-  }
-  for (int kt = kt0; kt < kt1; ++kt) {
+  // Main loop: single LDS buffer; the global loads of the NEXT tile sit in registers while the current tile is
+  // multiplied.  Keeping TWO tiles in flight (PF2) was measured and rejected: +40 VGPRs drop the 64x64 kernels from
+  // 5-6 to 3-4 waves/SIMD and the step got 8 % slower -- occupancy, not prefetch depth, hides the latency here.
+  constexpr bool PF2 = false;
+  StA sa0, sa1;
+  StB sb0, sb1;
+  auto step = [&](StA& sa, StB& sb, int kt, int kt_next) {
     if (TRA && do_colsum) sa.template store<true>(ldsA, m0, kt * BK, tid, meA, csum);
     else sa.template store<false>(ldsA, m0, kt * BK, tid, meA, csum);
     sb.template store<false>(ldsB, n0, kt * BK, tid, meB, csum);
     __syncthreads();
-    if (kt + 1 < kt1) {
-      sa.load(A, p.lda, m0, (kt + 1) * BK, p.M, k_end, tid, meA);
-      sb.load(B, p.ldb, n0, (kt + 1) * BK, p.N, k_end, tid, meB);
+    if (kt_next < kt1) {
+      sa.load(A, p.lda, m0, kt_next * BK, p.M, k_end, tid, meA);
+      sb.load(B, p.ldb, n0, kt_next * BK, p.N, k_end, tid, meB);
     }
 #pragma unroll
     for (int kk = 0; kk < BK / KI; ++kk) {
@@ -327,6 +327,22 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = mma16(wb[j], xa[i], acc[i][j]);
     }
     __syncthreads();
+  };
+  if (kt0 < kt1) {
+    sa0.load(A, p.lda, m0, kt0 * BK, p.M, k_end, tid, meA);
+    sb0.load(B, p.ldb, n0, kt0 * BK, p.N, k_end, tid, meB);
+  }
+  if (PF2) {
+    if (kt0 + 1 < kt1) {
+      sa1.load(A, p.lda, m0, (kt0 + 1) * BK, p.M, k_end, tid, meA);
+      sb1.load(B, p.ldb, n0, (kt0 + 1) * BK, p.N, k_end, tid, meB);
+    }
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      step(sa0, sb0, kt, kt + 2);
+      if (kt + 1 < kt1) step(sa1, sb1, kt + 1, kt + 3);
+    }
+  } else {
+    for (int kt = kt0; kt < kt1; ++kt) step(sa0, sb0, kt, kt + 1);
   }
 
   if (TRA) {
