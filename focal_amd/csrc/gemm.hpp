@@ -233,6 +233,43 @@ __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
   return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
 }
 
+// N-element (16-byte for bf16 x 8 / fp32 x 4, 32-byte for fp32 x 8) vector load / store helpers, fp32 in registers
+template <int N> __device__ __forceinline__ void loadN(const float* p, float* f) {
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) {
+    const float4 t = reinterpret_cast<const float4*>(p)[i];
+    f[4 * i] = t.x; f[4 * i + 1] = t.y; f[4 * i + 2] = t.z; f[4 * i + 3] = t.w;
+  }
+}
+template <int N> __device__ __forceinline__ void loadN(const bf16_t* p, float* f) {
+  if (N == 8) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)t[i];
+  } else {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = (float)t[i];
+  }
+}
+template <int N> __device__ __forceinline__ void storeN(float* p, const float* f) {
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) reinterpret_cast<float4*>(p)[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+}
+template <int N> __device__ __forceinline__ void storeN(bf16_t* p, const float* f) {
+  if (N == 8) {
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)f[i];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  } else {
+    bf16x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = (bf16_t)f[i];
+    *reinterpret_cast<bf16x4*>(p) = t;
+  }
+}
+
 // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous run of logical
 // tiles; with n fastest, the column tiles that re-read the same activation rows hit that XCD's L2.  Bijective for
 // any block count.
@@ -251,11 +288,15 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   using StB = OperandStage<CT, TB, TRB, PROB, BN, BKM>;
   using FA = FragLoad<CT, TRA, StA::PITCH>;
   using FB = FragLoad<CT, TRB, StB::PITCH>;
-  constexpr int TM = BM / 32, TN = BN / 32;
+  // wave grid: 64-column tiles put the 4 waves 4 x 1 so that one wave spans the full tile width -- its epilogue then
+  // writes whole 128-B (bf16) / 256-B (fp32) row segments instead of half lines; wider tiles use 2 x 2
+  constexpr int WGN = (BN <= 64) ? 1 : 2, WGM = 4 / WGN;
+  constexpr int WR = BM / WGM, WC = BN / WGN;  // rows / columns of the output tile owned by one wave
+  constexpr int TM = WR / 16, TN = WC / 16;
 
   constexpr int OPER_BYTES = (StA::LDS_ELEMS + StB::LDS_ELEMS) * (int)sizeof(CT);
-  constexpr int EPI_RP = (BN / 2 > 64) ? 16 : 32;          // rows per epilogue pass (wide tiles: 16, to fit LDS)
-  constexpr int STAGE_BYTES = 4 * EPI_RP * (BN / 2 + 4) * 4;  // epilogue staging: 4 waves x RP rows x (BN/2 + 4) floats
+  constexpr int EPI_RP = (WC > 64 || WR < 32) ? 16 : 32;  // rows per epilogue pass
+  constexpr int STAGE_BYTES = 4 * EPI_RP * (WC + 4) * 4;  // epilogue staging: 4 waves x RP rows x (WC + 4) floats
   constexpr int LDS_BYTES = OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES;
   __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
   CT* lds = reinterpret_cast<CT*>(lds_raw);
@@ -263,7 +304,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   CT* ldsB = lds + StA::LDS_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   // 1-D grid over (batch x split) x tiles, re-ordered so that each XCD (private L2) owns a contiguous run of
   // logical ids with the tile index fastest: the column tiles that re-read the same activation rows -- and, in the
   // weight-gradient GEMMs, all output tiles of one reduction chunk -- then share an L2 instead of re-fetching.
@@ -318,9 +359,9 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
       typename FA::Frag xa[TM];
       typename FB::Frag wb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) xa[i] = FA::load(ldsA, wm * (BM / 2) + i * 16, kk, lane);
+      for (int i = 0; i < TM; ++i) xa[i] = FA::load(ldsA, wm * WR + i * 16, kk, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) wb[j] = FB::load(ldsB, wn * (BN / 2) + j * 16, kk, lane);
+      for (int j = 0; j < TN; ++j) wb[j] = FB::load(ldsB, wn * WC + j * 16, kk, lane);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -364,7 +405,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   // store would touch 16 rows x 32-64 B.  Each wave instead transposes its sub-tile through a private LDS region (32
   // rows per pass) and walks it row-major: 128-256 B contiguous per row for stores, residual / aux loads and, for
   // the atomic form, 256 contiguous bytes per wave-instruction (the only shape fp32 atomics run at full rate in).
-  constexpr int WN = BN / 2, WPITCH = WN + 4, RP = EPI_RP, TPP = RP / 16;  // MFMA row-tiles per pass
+  constexpr int WN = WC, WPITCH = WN + 4, RP = EPI_RP, TPP = RP / 16;  // MFMA row-tiles per pass
   float* stage = reinterpret_cast<float*>(lds_raw) + wave * RP * WPITCH;
 #pragma unroll
   for (int pass = 0; pass < TM / TPP; ++pass) {
@@ -378,7 +419,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
       }
     }
     __syncthreads();
-    const int mbase = m0 + wm * (BM / 2) + pass * RP, nbase = n0 + wn * WN;
+    const int mbase = m0 + wm * WR + pass * RP, nbase = n0 + wn * WN;
     if (EPI == EPI_ATOMIC) {
       float* Cf = reinterpret_cast<float*>(C);
       const bool add_bias = p.bias && sp == 0;
@@ -398,50 +439,62 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
         }
       }
     } else {
-      constexpr int LPR = WN / 4, RPI = 64 / LPR;  // lanes per row (float4 each), rows per wave-instruction
-      const int c = (lane % LPR) * 4, n = nbase + c;
-      f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias && n < p.N) bias4 = load4(p.bias + n);
+      // 16 bytes per lane on the way out: 8 columns for bf16 outputs, 4 for fp32 (the store tail is issue-bound:
+      // half the store instructions at equal bytes)
+      constexpr int CPL = (sizeof(TC) == 2) ? 8 : 4;
+      constexpr int LPR = WN / CPL, RPI = 64 / LPR;  // lanes per row, rows per wave-instruction
+      const int c = (lane % LPR) * CPL, n = nbase + c;
+      float bias[CPL];
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) bias[e] = 0.f;
+      if (p.bias && n < p.N) loadN<CPL>(p.bias + n, bias);
 #pragma unroll
       for (int rr = 0; rr < RP; rr += RPI) {
         const int row = rr + lane / LPR;
         const int m = mbase + row;
         if (m >= p.M || n >= p.N) continue;
-        const float4 t = *reinterpret_cast<const float4*>(stage + row * WPITCH + c);
-        f32x4 v = f32x4{t.x, t.y, t.z, t.w} + bias4;
+        float v[CPL];
+        loadN<CPL>(stage + row * WPITCH + c, v);
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) v[e] += bias[e];
         TC* dst = C + (long)m * p.ldc + n;
         if (EPI == EPI_STORE) {
-          store4(dst, v);
+          storeN<CPL>(dst, v);
         } else if (EPI == EPI_RESID) {
-          const f32x4 r = load4(p.resid + (long)m * p.ldr + n);
+          float r[CPL];
+          loadN<CPL>(p.resid + (long)m * p.ldr + n, r);
           const float rowm = meE.row_mult(m);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
-          store4(dst, v);
+          for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
+          storeN<CPL>(dst, v);
         } else if (EPI == EPI_MUL_AUX) {
-          const f32x4 a = load4(reinterpret_cast<const CT*>(p.aux) + (long)m * p.ldaux + n);
-          store4(dst, v * a);
-        } else if (EPI == EPI_GELU_FWD) {
-          f32x4 g;
+          float a[CPL];
+          loadN<CPL>(reinterpret_cast<const CT*>(p.aux) + (long)m * p.ldaux + n, a);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < CPL; ++e) v[e] *= a[e];
+          storeN<CPL>(dst, v);
+        } else if (EPI == EPI_GELU_FWD) {
+          float g[CPL];
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) {
             float cdf, pdf;
             gelu_parts(v[e], cdf, pdf);
             const float mult = meE.elem_mult(m, n + e);
             g[e] = (cdf + v[e] * pdf) * mult;
             v[e] = v[e] * cdf * mult;
           }
-          store4(dst, v);
-          store4(reinterpret_cast<TC*>(p.aux_out) + (long)m * p.ldc + n, g);
+          storeN<CPL>(dst, v);
+          storeN<CPL>(reinterpret_cast<TC*>(p.aux_out) + (long)m * p.ldc + n, g);
         } else if (EPI == EPI_RELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          store4(dst, v);
+          for (int e = 0; e < CPL; ++e) v[e] = fmaxf(v[e], 0.f);
+          storeN<CPL>(dst, v);
         } else if (EPI == EPI_RELU_BWD) {
-          const f32x4 y = load4(reinterpret_cast<const TC*>(p.aux) + (long)m * p.ldaux + n);
+          float y[CPL];
+          loadN<CPL>(reinterpret_cast<const TC*>(p.aux) + (long)m * p.ldaux + n, y);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
-          store4(dst, v);
+          for (int e = 0; e < CPL; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
+          storeN<CPL>(dst, v);
         }
       }
     }
