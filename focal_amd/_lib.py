@@ -81,8 +81,7 @@ PROTOTYPES = {
     "focal_fft_realpack_fwd": (C.c_int, [C.POINTER(FFTDesc), P, P, P, P]),
     "focal_pad_patch_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P]),
     "focal_layernorm_fwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, P]),
-    "focal_layernorm_bwd_workspace": (C.c_size_t, [C.POINTER(LNDesc)]),
-    "focal_layernorm_bwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, C.c_int, P, P, P, C.c_size_t, P]),
+    "focal_layernorm_bwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, C.c_int, P, P, P]),
     "focal_linear_fwd": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P, P]),
     "focal_linear_bwd_data": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),

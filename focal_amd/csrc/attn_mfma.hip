@@ -181,13 +181,13 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
   }
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_table,
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_table,
                                                                    const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                                    float* __restrict__ dbias_table, AttnGeom g, int total_items,
                                                                    int iters, const uint32_t* rng, uint32_t stream, float p_attn) {
   constexpr int P = HD + 4, TILE = 16 * P;
-  __shared__ __attribute__((aligned(16))) bf16_t tiles[4][4][TILE];
+  __shared__ __attribute__((aligned(16))) bf16_t tiles[NW][4][TILE];
   __shared__ float dbacc[256];  // (2wh-1)(2ww-1) x heads <= 256 entries
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   bf16_t* Qt = tiles[wave][0];
@@ -195,17 +195,34 @@ __global__ __launch_bounds__(256) void window_attn_bwd_mfma_kernel(const bf16_t*
   bf16_t* Vt = tiles[wave][2];
   bf16_t* Gt = tiles[wave][3];  // dO
   const int table = (2 * g.wh - 1) * (2 * g.ww - 1) * g.heads;
-  for (int t = threadIdx.x; t < 256; t += 256) dbacc[t] = 0.f;
+  for (int t = threadIdx.x; t < 256; t += NW * 64) dbacc[t] = 0.f;
   __syncthreads();
   const DropCtx dc = make_drop(rng, stream, p_attn);
   const bool drop_on = p_attn > 0.f;
   const int C = g.C, grp = lane >> 4, col = lane & 15;
   const TileIdx tA = make_tile_idx<true>(g, lane), tB = make_tile_idx<false>(g, lane);
   const int slot = lane & 15, sy = slot / g.ww, sx = slot - sy * g.ww;
+  // Relative-position-bias gradient: a lane owns the same (i, j) -- hence the same table row -- in every window, so it
+  // accumulates in registers and touches LDS only when the head it works on changes (never, when 4 * gridDim is a
+  // multiple of heads).  LDS float atomics serialise per lane; issuing 4 per (window, head) was ~half of this kernel.
+  float dbreg[4] = {0.f, 0.f, 0.f, 0.f};
+  int h_acc = -1;
+  auto flush_dbias = [&]() {
+    if (h_acc < 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if ((4 * grp + r) < g.N && col < g.N) atomicAdd(&dbacc[tB.rel[r] + h_acc], dbreg[r]);
+      dbreg[r] = 0.f;
+    }
+  };
   for (int it = 0; it < iters; ++it) {
-    const int item = (it * gridDim.x + blockIdx.x) * 4 + wave;
+    const int item = (it * gridDim.x + blockIdx.x) * NW + wave;
     const bool live = item < total_items;
     const int win = live ? item / g.heads : 0, h = live ? item % g.heads : 0;
+    if (live && h != h_acc) {
+      flush_dbias();
+      h_acc = h;
+    }
     int reg_own = 0;
     const int tok_own = slot < g.N ? slot_token(g, win, sy, sx, &reg_own) : 0;
     wave_lds_fence();
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_mfma_kernel(const bf16_t*
       for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
       ds1[r] = ok ? p1[r] * (dp - dot) : 0.f;
       pd1[r] = ok ? p1[r] * m : 0.f;
-      if (ok && live) atomicAdd(&dbacc[tB.rel[r] + h], ds1[r]);
+      if (live) dbreg[r] += ds1[r];  // ds1 is 0 outside the window
     }
     // ---- layout 2: rows j = 4*grp + r, col i
     float ds2[4], dpv[4];
@@ -280,8 +297,9 @@ __global__ __launch_bounds__(256) void window_attn_bwd_mfma_kernel(const bf16_t*
       }
     }
   }
+  flush_dbias();
   __syncthreads();
-  for (int t = threadIdx.x; t < table; t += 256) atomicAdd(dbias_table + t, dbacc[t]);
+  for (int t = threadIdx.x; t < table; t += NW * 64) atomicAdd(dbias_table + t, dbacc[t]);
 }
 
 int focal_attn_mfma_fwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, bf16_t* out, const uint32_t* rng, uint32_t stream_id,
@@ -300,11 +318,20 @@ int focal_attn_mfma_fwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
 int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, const bf16_t* dout, bf16_t* dqkv, float* dbias_table,
                         const uint32_t* rng, uint32_t stream_id, float p_attn, hipStream_t st) {
   const int items = g.B * g.nW * g.heads;
-  int blocks = ceil_div(items, 4);
-  if (blocks > 2048) blocks = 2048;  // 8 workgroups per CU; also bounds the atomic fan-in on the bias-table gradient
-  const int iters = ceil_div(items, blocks * 4);
-#define LAUNCH(HD) hipLaunchKernelGGL((window_attn_bwd_mfma_kernel<HD>), dim3(blocks), dim3(256), 0, st, qkv, bias_table, dout, dqkv, dbias_table, g, items, iters, rng, stream_id, p_attn)
+  // Every workgroup ends with one atomic per bias-table entry, and atomics onto one address are a serial chain
+  // (~10 ns a link): the grid is kept small (workgroups loop over items) so the chain, not the math, does not set the
+  // kernel's duration.
+  // Measured (r1, B=256): 4-wave x 4096 blocks 125/83/69/59/36/21 us for the six stage geometries, 16-wave x 256
+  // blocks 99/54/39/24/20/16 us.
+  static const int nw = getenv("FOCAL_ATTN_BWD_NW") ? atoi(getenv("FOCAL_ATTN_BWD_NW")) : 16;
+  static const int maxb = getenv("FOCAL_ATTN_BWD_BLOCKS") ? atoi(getenv("FOCAL_ATTN_BWD_BLOCKS")) : 256;
+  int blocks = ceil_div(items, nw);
+  if (blocks > maxb) blocks = maxb;
+  const int iters = ceil_div(items, blocks * nw);
+#define LAUNCH2(HD, NW) hipLaunchKernelGGL((window_attn_bwd_mfma_kernel<HD, NW>), dim3(blocks), dim3(NW * 64), 0, st, qkv, bias_table, dout, dqkv, dbias_table, g, items, iters, rng, stream_id, p_attn)
+#define LAUNCH(HD) do { if (nw == 16) LAUNCH2(HD, 16); else if (nw == 8) LAUNCH2(HD, 8); else LAUNCH2(HD, 4); } while (0)
   if (g.hd == 16) LAUNCH(16); else if (g.hd == 32) LAUNCH(32); else LAUNCH(64);
+#undef LAUNCH2
 #undef LAUNCH
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;

@@ -3,14 +3,33 @@
 //   forward   stats(z) -> y = resid + mask * gelu(gamma * (z - mean) * rstd + beta)       (+ a dtype copy for the next GEMM)
 //   backward  da = g * mask * gelu'(.)  ->  s1 = sum da, s2 = sum da * zhat  (= dbeta, dgamma)
 //             dz = gamma * rstd * (da - s1/n - zhat * s2/n)
-// All streaming, HBM-bound; per-channel reductions: registers -> LDS -> one atomic per channel per workgroup.
+// All streaming, HBM-bound; per-channel reductions: registers -> wave shuffles -> LDS rows -> one atomic per channel per workgroup.
 #include "common.hpp"
+
+// Per-channel partial sums -> global: lanes that hold the same channels are folded with xor-shuffles, each wave parks one
+// [2][C] row in LDS (plain stores: LDS float atomics serialise per lane), the 4 waves are summed and every channel leaves
+// as one atomic per workgroup.  `red` is [4][2][C] floats; a[k] belongs to channel c + k of the first half, b[k] of the second.
+__device__ __forceinline__ void bn_commit_sums(float* red, float* __restrict__ sums, float (&a)[4], float (&b)[4], int C, int c) {
+  const int lpr = C / 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 8 * C; i += 256) red[i] = 0.f;
+  for (int o = lpr; o < 64; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] += __shfl_xor(a[k], o, 64); b[k] += __shfl_xor(b[k], o, 64); }
+  }
+  __syncthreads();
+  if (lpr >= 64 || lane < lpr) {
+    float* row = red + wave * 2 * C;
+    *reinterpret_cast<float4*>(row + c) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(row + C + c) = make_float4(b[0], b[1], b[2], b[3]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256)
+    atomicAdd(sums + i, red[i] + red[2 * C + i] + red[4 * C + i] + red[6 * C + i]);
+}
 
 // sums[0..C) = sum z, sums[C..2C) = sum z^2   (sums must be zeroed by the caller-side launcher)
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ z, float* __restrict__ sums, long rows, int C) {
-  extern __shared__ float red[];  // [2][C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-  __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][C]
   const int lpr = C / 4;                 // lanes per row
   const int rpb = 256 / lpr;             // rows per block-iteration
   const int li = threadIdx.x % lpr, sub = threadIdx.x / lpr;
@@ -20,10 +39,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
   }
-  atomicAdd(&red[li * 4 + 0], s.x); atomicAdd(&red[li * 4 + 1], s.y); atomicAdd(&red[li * 4 + 2], s.z); atomicAdd(&red[li * 4 + 3], s.w);
-  atomicAdd(&red[C + li * 4 + 0], q.x); atomicAdd(&red[C + li * 4 + 1], q.y); atomicAdd(&red[C + li * 4 + 2], q.z); atomicAdd(&red[C + li * 4 + 3], q.w);
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(sums + i, red[i]);
+  float a[4] = {s.x, s.y, s.z, s.w}, b[4] = {q.x, q.y, q.z, q.w};
+  bn_commit_sums(red, sums, a, b, C, li * 4);
 }
 
 // mean_rstd[0..C) = mean, [C..2C) = rstd; running stats: momentum update with the UNBIASED variance (torch semantics)
@@ -107,9 +124,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ sums, long rows, int C,
                                                             int rows_per_sample, const uint32_t* rng, uint32_t stream, float p) {
-  extern __shared__ float red[];
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-  __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][C]
   const DropCtx dc = make_drop(rng, stream, p);
   const bool drop_on = p > 0.f;
   const int lpr = C / 4, rpb = 256 / lpr;
@@ -122,10 +137,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s1[k] += da[k]; s2[k] += da[k] * zh[k]; }
   }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { atomicAdd(&red[c + k], s1[k]); atomicAdd(&red[C + c + k], s2[k]); }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(sums + i, red[i]);
+  bn_commit_sums(red, sums, s1, s2, C, c);
 }
 
 template <typename TD>
@@ -185,7 +197,7 @@ extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scr
     (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
     int blocks = stream_blocks(d->rows, C);
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), st, z, scratch, (long)d->rows, C);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(256), 8 * C * sizeof(float), st, z, scratch, (long)d->rows, C);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, mean_rstd, running_mean, running_var,
                        (long)d->rows, C, d->eps, d->momentum);
   }
@@ -218,7 +230,7 @@ extern "C" int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const fl
   (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
   int rb = stream_blocks(d->rows, C);
   if (rb > 512) rb = 512;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(256), 2 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(256), 8 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
                      (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
   const int blocks = stream_blocks(d->rows, C);
   if (d->dtype == FOCAL_F32)

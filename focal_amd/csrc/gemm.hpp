@@ -387,17 +387,24 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   }
 
   if (TRA) {
-    if (do_colsum) {  // combine the 256 / CPR threads that share a column group through LDS, then one atomic per column
+    if (do_colsum) {
+      // Combine the 256 / CPR threads that share a column group: xor-shuffles inside the wave, one LDS row per wave
+      // (LDS float atomics serialise per lane and cost microseconds here), then one global atomic per column.
       float* red = reinterpret_cast<float*>(lds_raw);
-      __syncthreads();
-      if (tid < BM) red[tid] = 0.f;
-      __syncthreads();
-      constexpr int EC = Cfg::EC;
-      const int cb = (tid % StA::CPR) * EC;
+      constexpr int EC = Cfg::EC, CPR = StA::CPR;
+      static_assert((CPR & (CPR - 1)) == 0 && CPR <= 64, "column groups per row must be a power of two");
 #pragma unroll
-      for (int e = 0; e < EC; ++e) atomicAdd(&red[cb + e], csum[e]);
+      for (int e = 0; e < EC; ++e)
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) csum[e] += __shfl_xor(csum[e], o, 64);
       __syncthreads();
-      if (tid < BM && (m0 + tid) < p.M) atomicAdd(p.colsumA + m0 + tid, red[tid]);
+      if (lane < CPR) {
+#pragma unroll
+        for (int e = 0; e < EC; ++e) red[wave * BM + lane * EC + e] = csum[e];
+      }
+      __syncthreads();
+      if (tid < BM && (m0 + tid) < p.M)
+        atomicAdd(p.colsumA + m0 + tid, red[tid] + red[BM + tid] + red[2 * BM + tid] + red[3 * BM + tid]);
     }
   }
 

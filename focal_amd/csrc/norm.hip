@@ -86,18 +86,17 @@ template <> __device__ __forceinline__ float4 load_dy4<bf16_t>(const bf16_t* p) 
 // Each lane keeps private column partials across its grid-stride rows; they are combined through LDS once per
 // workgroup and leave as one atomic per column per workgroup.
 template <typename TY, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const TY* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(1024) void ln_bwd_kernel(const TY* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     float* __restrict__ dx, int accumulate, float* __restrict__ partials,
-                                                     int rows, int C, int lpr, RowMap map) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-  __syncthreads();
+                                                     float* __restrict__ dx, int accumulate, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int rows, int C, int lpr, RowMap map) {
+  extern __shared__ __attribute__((aligned(16))) float part[];  // [waves per block][2][C]
   const int lane = threadIdx.x & 63;
   const int rpw = 64 / lpr;
   const int sub = lane / lpr, li = lane % lpr;
-  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * 4;
+  const int wpb = blockDim.x >> 6;
+  const int wave_global = blockIdx.x * wpb + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * wpb;
   float4 pg[NV], pb[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) pg[k] = pb[k] = make_float4(0, 0, 0, 0);
@@ -135,37 +134,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TY* __restrict__ dy, 
       *reinterpret_cast<float4*>(dst) = o;
     }
   }
+  // Column partials: fold the rows that share a wave with xor-shuffles, park one [2][C] row per wave in LDS (plain
+  // stores -- LDS float atomics from 16 waves onto 2C addresses cost ~10 us here), sum the waves, then one global atomic
+  // per column per workgroup.  16 waves per workgroup and at most one workgroup per CU keeps the number of contended
+  // global atomics at gridDim x 2C.
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int c = (k * lpr + li) * 4;
-    atomicAdd(&red[c + 0], pg[k].x); atomicAdd(&red[c + 1], pg[k].y); atomicAdd(&red[c + 2], pg[k].z); atomicAdd(&red[c + 3], pg[k].w);
-    atomicAdd(&red[C + c + 0], pb[k].x); atomicAdd(&red[C + c + 1], pb[k].y); atomicAdd(&red[C + c + 2], pb[k].z); atomicAdd(&red[C + c + 3], pb[k].w);
+    for (int o = lpr; o < 64; o <<= 1) {
+      pg[k].x += __shfl_xor(pg[k].x, o, 64); pg[k].y += __shfl_xor(pg[k].y, o, 64);
+      pg[k].z += __shfl_xor(pg[k].z, o, 64); pg[k].w += __shfl_xor(pg[k].w, o, 64);
+      pb[k].x += __shfl_xor(pb[k].x, o, 64); pb[k].y += __shfl_xor(pb[k].y, o, 64);
+      pb[k].z += __shfl_xor(pb[k].z, o, 64); pb[k].w += __shfl_xor(pb[k].w, o, 64);
+    }
+    if (sub == 0) {
+      float* row = part + (threadIdx.x >> 6) * 2 * C;
+      const int c = (k * lpr + li) * 4;
+      *reinterpret_cast<float4*>(row + c) = pg[k];
+      *reinterpret_cast<float4*>(row + C + c) = pb[k];
+    }
   }
   __syncthreads();
-  // per-workgroup partial sums; ln_bwd_finalize_kernel folds them into dgamma / dbeta (global atomics from hundreds
-  // of workgroups onto the same 2C addresses run at the contended rate, ~20 G adds/s)
-  for (int i = threadIdx.x; i < 2 * C; i += 256) partials[(long)blockIdx.x * 2 * C + i] = red[i];
-}
-
-// grid (2C / 64, ceil(nblocks / 256)), 1024 threads: thread (r, c) sums 16 of its slice's 256 partial rows, LDS combines
-// the 16 row groups, one atomic per column per slice (<= 8 adds per address).
-__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* __restrict__ partials, int nblocks, int C,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float red[16][64];
-  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + c;
-  const int b0 = blockIdx.y * 256, b1 = min(nblocks, b0 + 256);
-  float s = 0.f;
-  if (col < 2 * C)
-    for (int b = b0 + r; b < b1; b += 16) s += partials[(long)b * 2 * C + col];
-  red[r][c] = s;
-  __syncthreads();
-  if (r == 0 && col < 2 * C) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][c];
-    if (col < C) atomicAdd(dgamma + col, t);
-    else atomicAdd(dbeta + col - C, t);
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float acc = 0.f;
+    for (int w = 0; w < wpb; ++w) acc += part[w * 2 * C + i];
+    atomicAdd(i < C ? dgamma + i : dbeta + (i - C), acc);
   }
 }
 
@@ -202,34 +194,23 @@ extern "C" int focal_layernorm_fwd(const focal_ln_desc* d, const float* x, const
   return FOCAL_OK;
 }
 
-#define LN_BWD_MAX_BLOCKS 2048
-extern "C" size_t focal_layernorm_bwd_workspace(const focal_ln_desc* d) {
-  return d ? (size_t)LN_BWD_MAX_BLOCKS * 2 * d->C * sizeof(float) : 0;
-}
-
 extern "C" int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const float* x, const float* stats,
                                    const float* gamma, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
+                                   void* stream) {
   int lpr, nv;
   RowMap map;
   if (int rc = ln_geometry(d, &lpr, &nv, &map)) return rc;
-  FOCAL_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta && workspace, "layernorm_bwd: null tensor");
-  if (workspace_bytes < focal_layernorm_bwd_workspace(d)) {
-    focal_set_error("layernorm_bwd: workspace %zu < %zu bytes", workspace_bytes, focal_layernorm_bwd_workspace(d));
-    return FOCAL_EWORKSPACE;
-  }
+  FOCAL_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta, "layernorm_bwd: null tensor");
   const int rpw = 64 / lpr;
-  // ~2 rows per wave: short dependent-load chains and thousands of waves in flight to cover HBM latency
-  int blocks = ceil_div(d->rows, rpw * 4 * 2);
-  if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
+  const int tpb = d->C >= 512 ? 256 : 1024, maxb = 256;
+  int blocks = ceil_div(d->rows, rpw * (tpb / 64) * 2);  // ~2 rows per wave
+  if (blocks > maxb) blocks = maxb;
   hipStream_t st = (hipStream_t)stream;
-  const size_t sm = 2 * d->C * sizeof(float);
-  float* partials = reinterpret_cast<float*>(workspace);
-#define LN_BWD(TY, NV) hipLaunchKernelGGL((ln_bwd_kernel<TY, NV>), dim3(blocks), dim3(256), sm, st, (const TY*)dy, x, stats, gamma, dx, accumulate_dx, partials, d->rows, d->C, lpr, map)
+  const size_t sm = (size_t)(tpb / 64) * 2 * d->C * sizeof(float);
+#define LN_BWD(TY, NV) hipLaunchKernelGGL((ln_bwd_kernel<TY, NV>), dim3(blocks), dim3(tpb), sm, st, (const TY*)dy, x, stats, gamma, dx, accumulate_dx, dgamma, dbeta, d->rows, d->C, lpr, map)
   if (d->dtype == FOCAL_F32) { if (nv == 1) LN_BWD(float, 1); else if (nv == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
   else { if (nv == 1) LN_BWD(bf16_t, 1); else if (nv == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
 #undef LN_BWD
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(ceil_div(2 * d->C, 64), ceil_div(blocks, 256)), dim3(1024), 0, st, partials, blocks, d->C, dgamma, dbeta);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

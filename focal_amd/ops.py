@@ -143,9 +143,8 @@ def layernorm_bwd(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=Non
     _need_cuda(dy, x, stats, gamma, dx, dgamma, dbeta)
     rows, Cc = dy.shape
     d = desc or ln_desc(code(dy.dtype), rows, Cc, gather=gather)
-    ws = torch.empty(2048 * 2 * Cc, dtype=torch.float32, device=dy.device)  # per-workgroup column partials
     check(_lib.load().focal_layernorm_bwd(C.byref(d), _p(dy), _p(x), _p(stats), _p(gamma), _p(dx), int(accumulate),
-                                          _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _stream()))
+                                          _p(dgamma), _p(dbeta), _stream()))
 
 
 # ------------------------------------------------------------------------------------------------ Linear family
