@@ -33,6 +33,10 @@ class SW_Transformer(HipBackbone):
         self.drop_rate = self.config["dropout_ratio"]
         self.attn_drop_rate = self.config["attn_drop_rate"]
         self.norm_layer = nn.LayerNorm
+        # No batch statistics anywhere in this backbone: FOCAL may run both views as one batch of 2B
+        # (FOCALModules.FOCAL.forward).  Measured r1: 9.48 ms (two passes on 4 streams) -> 9.12 ms (one pass, 2 streams);
+        # cutting the heavier modality back into batch chunks to balance the streams was slower again (9.34 ms).
+        self.views_share_pass = os.environ.get("FOCAL_SPLIT_VIEWS", "0") != "1"
         self._init_hip(args)
         self.init_encoder()
 
