@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--dtype", default="bf16")
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-dropout", action="store_true", help="diagnostic: all dropout rates 0 (flagged in the JSON line)")
     p.add_argument("--cpu-steps", type=int, default=4)
     p.add_argument("--roofline-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
     p.add_argument("--roofline-iters", type=int, default=20)
@@ -63,11 +64,15 @@ class Step:
         from focal_amd import ops
         from focal_amd.distributed import gather_features
         from general_utils.weight_utils import freeze_patch_embedding
-        from oracle.config import load_config  # config loader only (YAML); no oracle arithmetic on this path
+        from input_utils.yaml_utils import load_yaml
         from train_utils.model_selection import init_backbone_model, init_loss_func, init_pretrain_framework
         from train_utils.optimizer import define_optimizer
         self.ops, self.gather = ops, gather_features
-        cfg = load_config()
+        cfg = load_yaml(os.path.join(ROOT, "focal_amd", "src", "data", "MOD.yaml"))
+        if a.no_dropout:  # diagnostic only (measures what the mask generation costs); never the reported configuration
+            for k in ("dropout_ratio", "drop_path_rate", "attn_drop_rate"):
+                cfg["SW_Transformer"][k] = 0.0
+            cfg["DeepSense"]["dropout_ratio"] = 0.0
         self.cfg = cfg
         args = make_args(cfg, a.model, device, a.dtype)
         torch.manual_seed(1234)
@@ -209,10 +214,18 @@ def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/ and single-GPU boxes only): FOCAL_BENCH_TEST_BACKEND=gloo runs every rank on cuda:0 over gloo so
+    # that the N>1 control flow can be exercised on a 1-GPU box; the driver's multi-GPU runs use RCCL, one GPU per rank.
+    test_backend = os.environ.get("FOCAL_BENCH_TEST_BACKEND")
+    if test_backend:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if test_backend:
+            dist.init_process_group(test_backend)
+        else:
+            dist.init_process_group("nccl", device_id=device)
     rank = dist.get_rank() if world > 1 else 0
     step = Step(a, device)
     if a.roofline_only:
@@ -267,7 +280,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": f"{a.model} + FOCAL pretrain step, {a.batch} MOD-shaped 2-modality windows/GPU "
                                       f"(global batch {a.batch * world}), train mode, DFT + fwd x2 + loss + bwd + AdamW",
-                          "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graphed,
+                          "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graphed, **({"DIAGNOSTIC_no_dropout": True} if a.no_dropout else {}),
                           "views": "identity / negate*1.1, then DFT", "last_loss": round(last_loss, 4)},
                "model_flops_frac_of_bf16_mfma_peak": round(wps / world * FLOP_PER_WINDOW[a.model] / (MFMA_BF16_PEAK_TF * 1e12), 5),
                "roofline": rl, "cpu_baseline": cb}

@@ -72,7 +72,7 @@ __device__ __forceinline__ float drop_mult(const DropCtx& d, uint32_t idx) {
 // one v_exp + one v_rcp): libm erff costs ~3x more VALU and these sit in GEMM prologues / epilogues.
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);  // raw v_rcp_f32 (1 ulp); __frcp_rn expands to the ~10-instruction IEEE divide
   const float e = __expf(-z * z);  // = exp(-x^2 / 2)
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * e;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel microbenchmark at the shapes of the B=256 SW_Transformer step (HIP-event timed, GPU box only).
+"""Per-kernel microbenchmark at the shapes of the SW_Transformer step (B=256 windows, two views in one pass) (HIP-event timed, GPU box only).
 Prints one line per (op, shape): microseconds per launch, algorithmic GB/s and TFLOP/s."""
 import os
 import sys
@@ -47,8 +47,9 @@ def rnd(*s, dtype=torch.float32):
     return torch.randn(*s, device=DEV).to(dtype)
 
 
-# (tag, tokens M, channels C) of the six (stage, modality) encoders at B=256
-STAGES = [("s0a", 147456, 64), ("s0s", 73728, 64), ("s1a", 36864, 128), ("s1s", 18432, 128), ("s2a", 9216, 256), ("s2s", 4608, 256)]
+# (tag, tokens M, channels C) of the six (stage, modality) encoders; B = samples per backbone pass (both views = 512)
+B = int(os.environ.get("FOCAL_MB_B", "512"))
+STAGES = [("s0a", B * 576, 64), ("s0s", B * 288, 64), ("s1a", B * 144, 128), ("s1s", B * 72, 128), ("s2a", B * 36, 256), ("s2s", B * 18, 256)]
 c, f32 = ops.code(CT), ops.code(torch.float32)
 
 for tag, M, C in STAGES:
@@ -99,7 +100,6 @@ GEO = [("s0a", 12, 48, 64), ("s0s", 12, 24, 64), ("s1a", 6, 24, 128), ("s1s", 6,
 for tag, H, W, C in GEO:
     if ONLY and ONLY not in ("attn", tag):
         continue
-    B = 256
     M = B * H * W
     qkv, table = rnd(M, 3 * C, dtype=CT), rnd(25, 4)
     o = torch.empty(M, C, dtype=CT, device=DEV)
