@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--dtype", default="bf16")
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--sync-bn", action="store_true", help="DeepSense under DP: cross-rank BatchNorm statistics (exact global-batch parity)")
     p.add_argument("--no-dropout", action="store_true", help="diagnostic: all dropout rates 0 (flagged in the JSON line)")
     p.add_argument("--cpu-steps", type=int, default=4)
     p.add_argument("--roofline-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
@@ -75,6 +76,7 @@ class Step:
             cfg["DeepSense"]["dropout_ratio"] = 0.0
         self.cfg = cfg
         args = make_args(cfg, a.model, device, a.dtype)
+        args.sync_bn = a.sync_bn
         torch.manual_seed(1234)
         self.backbone = init_backbone_model(args)
         self.model = init_pretrain_framework(args, self.backbone)

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libfocal_hip.so")
 FOCAL_F32, FOCAL_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU_OUT = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
+BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 ABI_VERSION = 1
 
 
@@ -61,7 +62,8 @@ class ConvDesc(C.Structure):
 
 class BNDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("rows", C.c_int), ("C", C.c_int), ("rows_per_sample", C.c_int), ("eps", C.c_float),
-                ("momentum", C.c_float), ("p_drop", C.c_float), ("rng", C.c_void_p), ("stream", C.c_uint32)]
+                ("momentum", C.c_float), ("p_drop", C.c_float), ("rng", C.c_void_p), ("stream", C.c_uint32),
+                ("stat_rows", C.c_int)]
 
 
 class GRUDesc(C.Structure):
@@ -102,7 +104,7 @@ PROTOTYPES = {
     "focal_conv_bwd_weight": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
     "focal_bn_stats": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, C.c_int, P]),
     "focal_bn_act_fwd": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P]),
-    "focal_bn_act_bwd": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P, P, P]),
+    "focal_bn_act_bwd": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P, P, C.c_int, P]),
     "focal_gru_gate_fwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, C.c_int, P, P, P, P, P, P, P]),
     "focal_gru_gate_bwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, C.c_int, P, C.c_long, C.c_long, C.c_float, P, P, P, P, P, P, P, P]),
     "focal_mean_time": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, P]),

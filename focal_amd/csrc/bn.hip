@@ -140,16 +140,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   bn_commit_sums(red, sums, s1, s2, C, c);
 }
 
+__global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C) { dbeta[i] += sums[i]; dgamma[i] += sums[C + i]; }
+}
+
 template <typename TD>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ g,
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ sums,
                                                            TD* __restrict__ dz, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           long rows, int C, int rows_per_sample, const uint32_t* rng, uint32_t stream,
-                                                           float p) {
+                                                           long rows, long stat_rows, int C, int rows_per_sample, const uint32_t* rng,
+                                                           uint32_t stream, float p) {
   const DropCtx dc = make_drop(rng, stream, p);
   const bool drop_on = p > 0.f;
-  const float inv_n = 1.0f / (float)rows;
+  const float inv_n = 1.0f / (float)stat_rows;
   if (blockIdx.x == 0 && dgamma) {
     for (int i = threadIdx.x; i < C; i += 256) { dbeta[i] += sums[i]; dgamma[i] += sums[C + i]; }
   }
@@ -187,19 +192,28 @@ static int stream_blocks(long rows, int C) {
 extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scratch, float* mean_rstd, float* running_mean,
                               float* running_var, int training, void* stream) {
   if (int rc = bn_check(d)) return rc;
-  FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
+  FOCAL_CHECK_ARG(training >= FOCAL_BN_EVAL && training <= FOCAL_BN_FINALIZE, "bn_stats: bad mode %d", training);
   hipStream_t st = (hipStream_t)stream;
   const int C = d->C;
-  if (!training) {
+  if (training == FOCAL_BN_EVAL) {
+    FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, running_mean, running_var, mean_rstd, C, d->eps);
-  } else {
-    FOCAL_CHECK_ARG(z && scratch, "bn_stats: null tensor");
+    FOCAL_LAUNCH_CHECK();
+    return FOCAL_OK;
+  }
+  FOCAL_CHECK_ARG(scratch, "bn_stats: null scratch");
+  if (training != FOCAL_BN_FINALIZE) {
+    FOCAL_CHECK_ARG(z, "bn_stats: null tensor");
     (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
     int blocks = stream_blocks(d->rows, C);
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(256), 8 * C * sizeof(float), st, z, scratch, (long)d->rows, C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, mean_rstd, running_mean, running_var,
-                       (long)d->rows, C, d->eps, d->momentum);
+  }
+  if (training != FOCAL_BN_PARTIAL) {
+    FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
+    const long n = d->stat_rows > 0 ? d->stat_rows : d->rows;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, mean_rstd, running_mean, running_var, n, C,
+                       d->eps, d->momentum);
   }
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
@@ -222,23 +236,34 @@ extern "C" int focal_bn_act_fwd(const focal_bn_desc* d, const float* z, const fl
 }
 
 extern "C" int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const float* g, const float* mean_rstd, const float* gamma,
-                                const float* beta, float* scratch, void* dz, float* dgamma, float* dbeta, void* stream) {
+                                const float* beta, float* scratch, void* dz, float* dgamma, float* dbeta, int phase, void* stream) {
   if (int rc = bn_check(d)) return rc;
-  FOCAL_CHECK_ARG(z && g && mean_rstd && gamma && beta && scratch && dz && dgamma && dbeta, "bn_act_bwd: null tensor");
+  FOCAL_CHECK_ARG(phase == FOCAL_BN_TRAIN || phase == FOCAL_BN_PARTIAL || phase == FOCAL_BN_FINALIZE, "bn_act_bwd: bad phase %d", phase);
+  FOCAL_CHECK_ARG(z && g && mean_rstd && gamma && beta && scratch, "bn_act_bwd: null tensor");
   hipStream_t st = (hipStream_t)stream;
   const int C = d->C;
-  (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
-  int rb = stream_blocks(d->rows, C);
-  if (rb > 512) rb = 512;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(256), 8 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
-                     (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
-  const int blocks = stream_blocks(d->rows, C);
-  if (d->dtype == FOCAL_F32)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (float*)dz,
-                       dgamma, dbeta, (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
-  else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (bf16_t*)dz,
-                       dgamma, dbeta, (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+  if (phase != FOCAL_BN_FINALIZE) {
+    (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
+    int rb = stream_blocks(d->rows, C);
+    if (rb > 512) rb = 512;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(256), 8 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
+                       (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+  }
+  if (phase == FOCAL_BN_PARTIAL) {  // the parameter gradients are the LOCAL sums (the gradient all-reduce adds the other ranks')
+    FOCAL_CHECK_ARG(dgamma && dbeta, "bn_act_bwd: null tensor");
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, dgamma, dbeta, C);
+  } else {
+    FOCAL_CHECK_ARG(dz && (phase == FOCAL_BN_FINALIZE || (dgamma && dbeta)), "bn_act_bwd: null tensor");
+    float* dgm = phase == FOCAL_BN_FINALIZE ? nullptr : dgamma;
+    const long stat_rows = (phase == FOCAL_BN_FINALIZE && d->stat_rows > 0) ? d->stat_rows : d->rows;
+    const int blocks = stream_blocks(d->rows, C);
+    if (d->dtype == FOCAL_F32)
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (float*)dz,
+                         dgm, dbeta, (long)d->rows, stat_rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (bf16_t*)dz,
+                         dgm, dbeta, (long)d->rows, stat_rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+  }
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -44,7 +44,7 @@ class DeepSenseModEncoder:
         d_in = ops.conv_in_desc(B, cin, I, S_in, S, geo["k_in"], geo["stride"], geo["pad_in"], C)
         z = ops.conv_in_fwd(d_in, x_freq, ar.master(f"{pin}.conv.weight"), ar.master(f"{pin}.conv.bias"))
         d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 0))
-        mr = ops.bn_stats(d_bn, z, buf(f"{pin}.batch_norm.running_mean"), buf(f"{pin}.batch_norm.running_var"), training)
+        mr = ops.bn_stats(d_bn, z, buf(f"{pin}.batch_norm.running_mean"), buf(f"{pin}.batch_norm.running_var"), training, bb.sync_bn)
         y, ya = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pin}.batch_norm.weight"), ar.master(f"{pin}.batch_norm.bias"), None, ct)
         sv["in"] = dict(d=d_in, z=z, mr=mr, d_bn=d_bn, p=pin)
         if training:
@@ -57,7 +57,7 @@ class DeepSenseModEncoder:
             w_fwd = ops.permute_pack(w, C, C, k, ct)
             z = ops.conv_fwd(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"))
             d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 1 + li))
-            mr = ops.bn_stats(d_bn, z, buf(f"{pl}.batch_norm.running_mean"), buf(f"{pl}.batch_norm.running_var"), training)
+            mr = ops.bn_stats(d_bn, z, buf(f"{pl}.batch_norm.running_mean"), buf(f"{pl}.batch_norm.running_var"), training, bb.sync_bn)
             y_next, ya_next = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pl}.batch_norm.weight"), ar.master(f"{pl}.batch_norm.bias"), y, ct)
             sv["layers"].append(dict(p=pl, z=z, mr=mr, d_bn=d_bn, xa=ya))
             y, ya = y_next, ya_next
@@ -170,7 +170,7 @@ class DeepSenseModEncoder:
             L = sv["layers"][li]
             pl = L["p"]
             dz = ops.bn_act_bwd(L["d_bn"], L["z"], g, L["mr"], ar.master(f"{pl}.batch_norm.weight"), ar.master(f"{pl}.batch_norm.bias"),
-                                ar.g(f"{pl}.batch_norm.weight"), ar.g(f"{pl}.batch_norm.bias"), ct)
+                                ar.g(f"{pl}.batch_norm.weight"), ar.g(f"{pl}.batch_norm.bias"), ct, bb.sync_bn)
             dwp = torch.zeros(C, k * C, dtype=torch.float32, device=dev)
             ops.conv_bwd_weight(d_cv, dz, L["xa"], dwp, ar.g(f"{pl}.conv.bias"))
             ops.permute_unpack_add(dwp, ar.g(f"{pl}.conv.weight"), C, C, k)
@@ -180,6 +180,6 @@ class DeepSenseModEncoder:
         Lin = sv["in"]
         pin = Lin["p"]
         dz = ops.bn_act_bwd(Lin["d_bn"], Lin["z"], g, Lin["mr"], ar.master(f"{pin}.batch_norm.weight"), ar.master(f"{pin}.batch_norm.bias"),
-                            ar.g(f"{pin}.batch_norm.weight"), ar.g(f"{pin}.batch_norm.bias"), ct)
+                            ar.g(f"{pin}.batch_norm.weight"), ar.g(f"{pin}.batch_norm.bias"), ct, bb.sync_bn)
         ops.conv_in_bwd_weight(Lin["d"], sv["x"], dz, ar.g(f"{pin}.conv.weight"), ar.g(f"{pin}.conv.bias"))
         # the spectrum is a leaf: nothing flows further

@@ -271,16 +271,32 @@ def conv_bwd_weight(d, dz, x, dw_packed, dbias):
     check(_lib.load().focal_conv_bwd_weight(C.byref(d), _p(dz), _p(x), _p(dw_packed), _p(dbias), _stream()))
 
 
-def bn_desc(dtype_code, rows, Cc, rows_per_sample, p_drop=0.0, rng=None, stream=0, eps=1e-5, momentum=0.1):
-    return BNDesc(dtype_code, rows, Cc, rows_per_sample, eps, momentum, p_drop, _p(rng), stream)
+def bn_desc(dtype_code, rows, Cc, rows_per_sample, p_drop=0.0, rng=None, stream=0, eps=1e-5, momentum=0.1, stat_rows=0):
+    return BNDesc(dtype_code, rows, Cc, rows_per_sample, eps, momentum, p_drop, _p(rng), stream, stat_rows)
 
 
-def bn_stats(d, z, running_mean, running_var, training):
+def _sync_world():
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def bn_stats(d, z, running_mean, running_var, training, sync=False):
+    """mean / rstd of z [rows, C].  sync=True under torch.distributed: the 2C per-channel sums are all-reduced between the
+    partial and the finalize kernels, so every rank normalises with the statistics of the GLOBAL batch (equal shards)."""
     dev = running_mean.device
     scratch = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
     mean_rstd = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
-    check(_lib.load().focal_bn_stats(C.byref(d), _p(z), _p(scratch), _p(mean_rstd), _p(running_mean), _p(running_var),
-                                     int(training), _stream()))
+    lib = _lib.load()
+    args = (_p(z), _p(scratch), _p(mean_rstd), _p(running_mean), _p(running_var))
+    world = _sync_world() if (sync and training) else 1
+    if world > 1:
+        import torch.distributed as dist
+        check(lib.focal_bn_stats(C.byref(d), *args, _lib.BN_PARTIAL, _stream()))
+        dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
+        d.stat_rows = d.rows * world
+        check(lib.focal_bn_stats(C.byref(d), *args, _lib.BN_FINALIZE, _stream()))
+    else:
+        check(lib.focal_bn_stats(C.byref(d), *args, _lib.BN_TRAIN if training else _lib.BN_EVAL, _stream()))
     return mean_rstd
 
 
@@ -291,11 +307,20 @@ def bn_act_fwd(d, z, mean_rstd, gamma, beta, resid, cast_dtype=None):
     return y, (ya if ya is not None else y)
 
 
-def bn_act_bwd(d, z, g, mean_rstd, gamma, beta, dgamma, dbeta, out_dtype):
+def bn_act_bwd(d, z, g, mean_rstd, gamma, beta, dgamma, dbeta, out_dtype, sync=False):
     scratch = torch.empty(2 * d.C, dtype=torch.float32, device=z.device)
     dz = torch.empty(z.shape, dtype=out_dtype, device=z.device)
-    check(_lib.load().focal_bn_act_bwd(C.byref(d), _p(z), _p(g), _p(mean_rstd), _p(gamma), _p(beta), _p(scratch), _p(dz),
-                                       _p(dgamma), _p(dbeta), _stream()))
+    lib = _lib.load()
+    args = (_p(z), _p(g), _p(mean_rstd), _p(gamma), _p(beta), _p(scratch), _p(dz), _p(dgamma), _p(dbeta))
+    world = _sync_world() if sync else 1
+    if world > 1:
+        import torch.distributed as dist
+        check(lib.focal_bn_act_bwd(C.byref(d), *args, _lib.BN_PARTIAL, _stream()))
+        dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
+        d.stat_rows = d.rows * world
+        check(lib.focal_bn_act_bwd(C.byref(d), *args, _lib.BN_FINALIZE, _stream()))
+    else:
+        check(lib.focal_bn_act_bwd(C.byref(d), *args, _lib.BN_TRAIN, _stream()))
     return dz
 
 

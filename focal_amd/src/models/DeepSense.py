@@ -29,6 +29,10 @@ class DeepSense(HipBackbone):
         self.locations = args.dataset_config["location_names"]
         self.multi_location_flag = len(self.locations) > 1
         self.drop_rate = self.config["dropout_ratio"]
+        # Data parallel: BatchNorm2d batch statistics are per call (ConvModules.py:86), so the single-device reference at
+        # the global batch normalises over ALL windows.  sync_bn=True all-reduces the per-channel sums (2C floats, twice
+        # per BN layer per step) and reproduces that exactly; False = per-rank statistics (throughput mode).
+        self.sync_bn = bool(getattr(args, "sync_bn", False)) or os.environ.get("FOCAL_SYNC_BN", "0") == "1"
         self._init_hip(args)
         self.init_encoder(args)
 

@@ -153,14 +153,22 @@ int focal_conv_bwd_weight(const focal_conv_desc* d, const void* dz, const void* 
  * focal_bn_stats: training -> batch mean / biased variance of z [rows, C] into mean_rstd [2C] and the momentum update of the
  * running buffers (unbiased variance); eval -> mean_rstd from the running buffers.  scratch: 2C floats.
  * focal_bn_act_fwd: y = resid + drop2d(gelu(gamma * zhat + beta)) (fp32), optional `dtype` copy y_cast for the next GEMM.
- * focal_bn_act_bwd: dz (`dtype`) from g = dL/dy (fp32); dgamma / dbeta accumulated (+=). */
-typedef struct { int dtype; int rows, C, rows_per_sample; float eps, momentum, p_drop; const uint32_t* rng; uint32_t stream; } focal_bn_desc;
+ * focal_bn_act_bwd: dz (`dtype`) from g = dL/dy (fp32); dgamma / dbeta accumulated (+=).
+ * Data-parallel exact ("sync") statistics: the per-channel sums are exposed so that the caller can all-reduce the 2C
+ * floats of `scratch` between the two halves of each call --
+ *   focal_bn_stats   training = FOCAL_BN_PARTIAL: scratch <- local {sum z, sum z^2};   FOCAL_BN_FINALIZE: mean_rstd and
+ *                    running buffers from scratch, normalising by d->stat_rows (the GLOBAL row count);
+ *   focal_bn_act_bwd phase = FOCAL_BN_PARTIAL: scratch <- local {sum da, sum da*zhat}, dgamma / dbeta += the LOCAL sums;
+ *                    FOCAL_BN_FINALIZE: dz from the (all-reduced) scratch and d->stat_rows.
+ * stat_rows = 0 means rows. */
+typedef struct { int dtype; int rows, C, rows_per_sample; float eps, momentum, p_drop; const uint32_t* rng; uint32_t stream; int stat_rows; } focal_bn_desc;
+enum { FOCAL_BN_EVAL = 0, FOCAL_BN_TRAIN = 1, FOCAL_BN_PARTIAL = 2, FOCAL_BN_FINALIZE = 3 };
 int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scratch, float* mean_rstd, float* running_mean, float* running_var,
                    int training, void* stream);
 int focal_bn_act_fwd(const focal_bn_desc* d, const float* z, const float* mean_rstd, const float* gamma, const float* beta,
                      const float* resid, float* y, void* y_cast, void* stream);
 int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const float* g, const float* mean_rstd, const float* gamma,
-                     const float* beta, float* scratch, void* dz, float* dgamma, float* dbeta, void* stream);
+                     const float* beta, float* scratch, void* dz, float* dgamma, float* dbeta, int phase, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 6: bi-GRU
  * nn.GRU(2 layers, bidirectional) + time mean (models/RecurrentModule.py:5-31).  Matrix products go through
