@@ -63,12 +63,12 @@ class Step:
 
     def __init__(self, a, device):
         from focal_amd import ops
-        from focal_amd.distributed import gather_features
+        from focal_amd import distributed
         from general_utils.weight_utils import freeze_patch_embedding
         from input_utils.yaml_utils import load_yaml
         from train_utils.model_selection import init_backbone_model, init_loss_func, init_pretrain_framework
         from train_utils.optimizer import define_optimizer
-        self.ops, self.gather = ops, gather_features
+        self.ops, self.dist = ops, distributed
         cfg = load_yaml(os.path.join(ROOT, "focal_amd", "src", "data", "MOD.yaml"))
         if a.no_dropout:  # diagnostic only (measures what the mask generation costs); never the reported configuration
             for k in ("dropout_ratio", "drop_path_rate", "attn_drop_rate"):
@@ -99,15 +99,67 @@ class Step:
         v2 = {l: {m: self.ops.fft_realpack(x * -1.1) for m, x in mm.items()} for l, mm in self.x.items()}
         return v1, v2
 
-    def run(self):
+    # The step in three capturable segments with the two data-parallel collectives between them:
+    #   A: zero_grad, views (DFT), both backbone passes, pack the embeddings     -> [all-gather embeddings]
+    #   B: loss head on the global batch, backward                                -> [all-reduce gradient arena]
+    #   C: AdamW, loss value
+    def seg_a(self):
         self.opt.zero_grad()
         v1, v2 = self.views()
-        f1, f2 = self.model(v1, v2, proj_head=True)
-        f1, f2 = self.gather([f1, f2])
-        loss = self.loss_fn(f1, f2)
+        self.feats = self.model(v1, v2, proj_head=True)
+        if self.dist.is_dist():
+            self.packed, self.keys = self.dist.pack_features(list(self.feats))
+
+    def exchange(self):
+        if self.dist.is_dist():
+            self.gathered = self.dist.exchange_packed(self.packed)  # the collective only: nothing else runs between segments
+
+    def seg_b(self):
+        if self.dist.is_dist():
+            self.feats = self.dist.unpack_gathered(self.gathered, self.keys, 2)
+        loss = self.loss_fn(*self.feats)
         loss.backward()
-        self.opt.step()
         self.loss.copy_(loss.detach())
+        self.feats = None
+
+    def reduce(self):
+        self.opt.reduce_gradients()
+
+    def seg_c(self):
+        self.opt.step(reduce=False)
+
+    def run(self):
+        self.seg_a()
+        self.exchange()
+        self.seg_b()
+        self.reduce()
+        self.seg_c()
+
+    def capture(self, stream):
+        """hipGraphs of the three segments (one shared memory pool); returns the replay callable.  On one rank the
+        collectives are no-ops and the three graphs replay back to back."""
+        self.opt.sync_lr()
+        ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, stream=stream):
+            self.seg_a()
+        self.exchange()  # eager, autograd-aware: links segment B's backward to segment A's forward
+        with torch.cuda.graph(gb, pool=ga.pool(), stream=stream):
+            self.seg_b()
+        self.reduce()
+        with torch.cuda.graph(gc, pool=ga.pool(), stream=stream):
+            self.seg_c()
+        multi = self.dist.is_dist()
+        packed = self.packed if multi else None
+
+        def replay():
+            ga.replay()
+            if multi:
+                self.dist.replay_exchange(packed)
+            gb.replay()
+            if multi:
+                self.opt.reduce_gradients()
+            gc.replay()
+        return replay
 
 
 def time_kernel(fn, iters=20):
@@ -241,17 +293,22 @@ def main():
         for _ in range(2):
             step.run()  # builds the arena / moments / workspaces outside capture
         torch.cuda.synchronize()
-        if not a.no_graph and world == 1:
+        if not a.no_graph:
+            # capture failures must not be rank-dependent (a rank falling back to eager while another replays would
+            # desynchronise the collectives): agree on the outcome before using the graphs
+            ok = 1
             try:
-                step.opt.sync_lr()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
-                    step.run()
-                run, graphed = graph.replay, True
+                replay = step.capture(side)
             except Exception as e:  # noqa: BLE001
-                if rank == 0:
-                    print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                ok = 0
+                print(f"[bench] rank {rank}: hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 torch.cuda.synchronize()
+            if world > 1:
+                flag = torch.tensor([ok], device=device, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok:
+                run, graphed = replay, True
         for _ in range(a.warmup):
             run()
             step.loss.item()

@@ -15,35 +15,79 @@ def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-class _AllGatherFeatures(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, *feats):
-        W, r = dist.get_world_size(), dist.get_rank()
-        packed = torch.stack([f.contiguous() for f in feats], 0)  # [n, B_local, D]
-        n = packed.shape[0]
-        flat = torch.empty((W * n,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
-        dist.all_gather_into_tensor(flat, packed)  # concatenation along dim 0: [rank0 feats.., rank1 feats.., ...]
-        out = flat.view((W, n) + tuple(packed.shape[1:]))
-        ctx.rank, ctx.b = r, packed.shape[1]
-        # rank-major concat keeps subsequences contiguous (models/loss.py:152-155 reshapes [B] -> [b, seq])
-        return tuple(out[:, i].reshape(-1, packed.shape[2]) for i in range(len(feats)))
+_STATIC = {}
+
+
+def _static(tag, shape, dtype, device):
+    """Persistent exchange buffers: stable addresses, so that a captured hipGraph can fill / read them while the collective
+    itself stays an eager RCCL call between graph segments (bench.py)."""
+    key = (tag, tuple(shape), dtype, torch.device(device))
+    if key not in _STATIC:
+        _STATIC[key] = torch.empty(shape, dtype=dtype, device=device)
+    return _STATIC[key]
+
+
+class _PackFeatures(torch.autograd.Function):
+    """[B_local, D] x n  ->  one [n, B_local, D] send buffer (ONE collective for all views and modalities)."""
 
     @staticmethod
-    def backward(ctx, *grads):
-        lo = ctx.rank * ctx.b
-        return tuple(g[lo:lo + ctx.b].contiguous() for g in grads)
+    def forward(ctx, *feats):
+        buf = _static("send", (len(feats),) + tuple(feats[0].shape), feats[0].dtype, feats[0].device)
+        torch.stack([f.contiguous() for f in feats], 0, out=buf)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.unbind(0))
+
+
+class _GatherPacked(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, packed):
+        W = dist.get_world_size()
+        flat = _static("recv", (W * packed.shape[0],) + tuple(packed.shape[1:]), packed.dtype, packed.device)
+        dist.all_gather_into_tensor(flat, packed)  # concatenation along dim 0: [rank0 feats.., rank1 feats.., ...]
+        ctx.rank = dist.get_rank()
+        return flat.view((W,) + tuple(packed.shape))
+
+    @staticmethod
+    def backward(ctx, g):
+        # every rank evaluates the same global loss: the gradient of ITS samples is its own slice (the sum over ranks is
+        # taken by the gradient all-reduce)
+        return g[ctx.rank]
+
+
+def pack_features(feature_dicts):
+    keys = [(i, m) for i, d in enumerate(feature_dicts) for m in d]
+    return _PackFeatures.apply(*[feature_dicts[i][m] for i, m in keys]), keys
+
+
+def exchange_packed(packed):
+    """The one exchange step of the data path: [n, B_local, D] -> [W, n, B_local, D]."""
+    return _GatherPacked.apply(packed)
+
+
+@torch.no_grad()
+def replay_exchange(packed):
+    """Same collective on the same persistent buffers without autograd (between replays of captured graph segments)."""
+    flat = _static("recv", (dist.get_world_size() * packed.shape[0],) + tuple(packed.shape[1:]), packed.dtype, packed.device)
+    dist.all_gather_into_tensor(flat, packed)
+
+
+def unpack_gathered(gathered, keys, n_dicts):
+    # rank-major concat keeps subsequences contiguous (models/loss.py:152-155 reshapes [B] -> [b, seq])
+    out = [dict() for _ in range(n_dicts)]
+    for j, (i, m) in enumerate(keys):
+        out[i][m] = gathered[:, j].reshape(-1, gathered.shape[-1])
+    return out
 
 
 def gather_features(feature_dicts):
     """[{mod: [B_local, D]}, ...] -> same structure with [B_global, D] tensors (identity when not distributed)."""
     if not is_dist():
         return feature_dicts
-    keys = [(i, m) for i, d in enumerate(feature_dicts) for m in d]
-    flat = _AllGatherFeatures.apply(*[feature_dicts[i][m] for i, m in keys])
-    out = [dict() for _ in feature_dicts]
-    for (i, m), t in zip(keys, flat):
-        out[i][m] = t
-    return out
+    packed, keys = pack_features(feature_dicts)
+    return unpack_gathered(exchange_packed(packed), keys, len(feature_dicts))
 
 
 def all_reduce_gradients(arena, bucket_bytes=64 << 20):

@@ -47,15 +47,25 @@ class FocalAdamW(torch.optim.Optimizer):
             self._lr_host = lr
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def reduce_gradients(self):
+        """Data parallel: exact global-batch gradient = SUM over ranks of the flat gradient arena (no-op on one rank)."""
+        arenas = self._arenas()
+        if arenas:
+            runtime.join_all(arenas[0].device)
+        for ar in arenas:
+            distributed.all_reduce_gradients(ar)
+
+    @torch.no_grad()
+    def step(self, closure=None, reduce=True):
+        """reduce=False: the caller already ran reduce_gradients() (bench.py does, eagerly, between captured graph segments)."""
         arenas = self._arenas()
         if not arenas:
             raise ops._lib.FocalHipError("FocalAdamW: no arena-backed parameters (run the backbone on the GPU first)")
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         runtime.join_all(arenas[0].device)
-        for ar in arenas:
-            distributed.all_reduce_gradients(ar)  # data parallel: exact global-batch gradient = sum over ranks
+        if reduce:
+            self.reduce_gradients()
         g0 = self.param_groups[0]
         dev = arenas[0].device
         if self._step_state is None:
