@@ -177,33 +177,36 @@ def time_kernel(fn, iters=20):
 
 
 def roofline(a, step, device):
-    """Live measurement of the dominant kernel (largest total time in profiles/r1_h_kernel_stats.csv): the weight-gradient
-    GEMM template focal_gemm_kernel<bf16, A=f32 grad (transposed), B=bf16 act (transposed), fp32 atomic out, 64x64>, timed on
-    its largest instance: dW of the stage-0 audio MLP down-projection, dW[64,256] += g[M,64]^T h[M,256], M = B*576 tokens.
-    HBM-bound (AI = 2*64*256 / (64*4 + 256*2) = 43 flop/B): algorithmic bytes = read g (fp32) + read h + write dW once."""
+    """Live measurement of the dominant kernel (largest total time in the committed rocprofv3 summary, profiles/): the
+    weight-gradient GEMM template focal_gemm_kernel<bf16: A = dy (transposed), B = activation (transposed), fp32 atomic
+    out, 64x64 tiles, split over tokens>, timed on its largest instance exactly as the step launches it: dW of the stage-0
+    audio MLP down-projection, dW[64,256] += gm[M,64]^T h[M,256], M = 2 views x B x 576 tokens (gm = the residual-stream
+    gradient, already multiplied by the branch's dropout mask by the LayerNorm backward that produced it).
+    HBM-bound (AI = 2*64*256 / ((64 + 256)*2) = 51 flop/B): algorithmic bytes = read gm + read h + write dW once."""
     ops = step.ops
     if a.model != "SW_Transformer":
         return roofline_deepsense(a, step, device)
     ct = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     es = 2 if ct == torch.bfloat16 else 4
     geo = step.backbone.geometry["shake"]["audio"]["stages"][0]
-    M, C = a.batch * geo["H"] * geo["W"], geo["C"]
+    views = 2 if getattr(step.backbone, "views_share_pass", False) else 1
+    M, C = views * a.batch * geo["H"] * geo["W"], geo["C"]
     N, K = C, 4 * C  # the forward linear is [M, K=4C] -> [M, N=C]
-    from focal_amd._lib import ACT_GELU, EPI_RESIDUAL
-    g = torch.randn(M, N, device=device)
+    from focal_amd._lib import ACT_GELU
+    g = torch.randn(M, N, device=device).to(ct)
     h = torch.randn(M, K, device=device).to(ct)
     dw = torch.zeros(N, K, device=device)
     db = torch.zeros(N, device=device)
-    d = ops.linear_desc(ops.code(ct), M, N, K, ops.code(ct), ops.code(torch.float32), ACT_GELU, EPI_RESIDUAL)
+    d = ops.linear_desc(ops.code(ct), M, N, K, ops.code(ct), ops.code(ct), ACT_GELU)
     ms = time_kernel(lambda: ops.linear_bwd_weight(d, g, h, dw, db), iters=a.roofline_iters)
-    bytes_alg = M * N * 4 + M * K * es + N * K * 4
+    bytes_alg = M * N * es + M * K * es + N * K * 4
     flops = 2.0 * M * N * K
     gbs = bytes_alg / (ms * 1e-3) / 1e9
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r1_pmc_roofline_kernel.json")
+    tf = os.path.join(ROOT, "profiles", "r1_l_pmc_roofline_kernel.json")
     if os.path.exists(tf):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --roofline-only` (see the file's note)
         traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-    return {"bound": "hbm", "kernel": "focal_gemm_kernel<dW: g[%d,%d]f32^T x h[%d,%d]%s -> fp32 atomics, 64x64 tiles>" % (M, N, M, K, a.dtype),
+    return {"bound": "hbm", "kernel": "focal_gemm_kernel<dW: gm[%d,%d]%s^T x h[%d,%d]%s -> fp32 atomics, 64x64 tiles>" % (M, N, a.dtype, M, K, a.dtype),
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "algorithmic_bytes": bytes_alg, "ms_per_launch": round(ms, 5),
             "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}

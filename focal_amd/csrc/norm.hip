@@ -75,6 +75,40 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+
+// The residual-stream gradient g that this kernel completes is consumed next by the two GEMMs of a residual branch as
+// g * (dropout x drop-path mask of that branch's output).  Emitting that product here, once, in the operand dtype, lets
+// both GEMMs run as plain kernels: regenerating the mask in their operand loaders cost more VALU than the GEMM itself
+// (it is recomputed for every column tile) and made them read fp32.  Index convention = the forward epilogue's:
+// element (row, col) of the [M, ncols] token tensor -> row * ncols + col; sample = row / rows_per_sample.
+struct DropMask {
+  DropCtx e, p;
+  int on_e, on_p, rps, ncols;
+};
+__device__ __forceinline__ DropMask make_mask(const focal_drop_desc& d, int ncols) {
+  DropMask m;
+  m.on_e = d.p_elem > 0.f;
+  m.on_p = d.p_path > 0.f;
+  m.rps = d.rows_per_sample > 0 ? d.rows_per_sample : 1;
+  m.ncols = ncols;
+  m.e = make_drop(d.rng, d.stream_elem, d.p_elem);
+  m.p = make_drop(d.rng, d.stream_path, d.p_path);
+  return m;
+}
+template <typename TY> __device__ __forceinline__ void store_masked4(TY* out, long off, float4 v, const DropMask& m) {
+  float a[4] = {v.x, v.y, v.z, v.w};
+  const uint32_t row = (uint32_t)(off / m.ncols);
+  const float pm = m.on_p ? drop_mult(m.p, row / (uint32_t)m.rps) : 1.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a[k] *= m.on_e ? pm * drop_mult(m.e, (uint32_t)off + k) : pm;
+  if (sizeof(TY) == 4) *reinterpret_cast<float4*>(out + off) = make_float4(a[0], a[1], a[2], a[3]);
+  else {
+    bf16x4 t;
+    t[0] = (bf16_t)a[0]; t[1] = (bf16_t)a[1]; t[2] = (bf16_t)a[2]; t[3] = (bf16_t)a[3];
+    *reinterpret_cast<bf16x4*>(out + off) = t;
+  }
+}
+
 template <typename TY> __device__ __forceinline__ float4 load_dy4(const TY* p);
 template <> __device__ __forceinline__ float4 load_dy4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
 template <> __device__ __forceinline__ float4 load_dy4<bf16_t>(const bf16_t* p) {
@@ -89,7 +123,9 @@ template <typename TY, int NV>
 __global__ __launch_bounds__(1024) void ln_bwd_kernel(const TY* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      float* __restrict__ dx, int accumulate, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows, int C, int lpr, RowMap map) {
+                                                     float* __restrict__ dbeta, int rows, int C, int lpr, RowMap map,
+                                                     TY* __restrict__ dxm, focal_drop_desc dd, int mcols) {
+  const DropMask mk = make_mask(dd, mcols);
   extern __shared__ __attribute__((aligned(16))) float part[];  // [waves per block][2][C]
   const int lane = threadIdx.x & 63;
   const int rpw = 64 / lpr;
@@ -132,6 +168,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const TY* __restrict__ dy,
         o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
       }
       *reinterpret_cast<float4*>(dst) = o;
+      if (dxm) store_masked4(dxm, dst - dx, o, mk);
     }
   }
   // Column partials: fold the rows that share a wave with xor-shuffles, park one [2][C] row per wave in LDS (plain
@@ -196,21 +233,51 @@ extern "C" int focal_layernorm_fwd(const focal_ln_desc* d, const float* x, const
 
 extern "C" int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const float* x, const float* stats,
                                    const float* gamma, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
-                                   void* stream) {
+                                   void* dx_masked, const focal_drop_desc* mask, void* stream) {
   int lpr, nv;
   RowMap map;
   if (int rc = ln_geometry(d, &lpr, &nv, &map)) return rc;
   FOCAL_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta, "layernorm_bwd: null tensor");
   const int rpw = 64 / lpr;
   const int tpb = d->C >= 512 ? 256 : 1024, maxb = 256;
+  focal_drop_desc dd;
+  memset(&dd, 0, sizeof(dd));
+  if (mask) dd = *mask;
+  FOCAL_CHECK_ARG(!mask || dx_masked, "layernorm_bwd: mask without dx_masked");
+  const int mcols = d->gather ? d->Cin : d->C;  // columns of the token tensor dx lives in
   int blocks = ceil_div(d->rows, rpw * (tpb / 64) * 2);  // ~2 rows per wave
   if (blocks > maxb) blocks = maxb;
   hipStream_t st = (hipStream_t)stream;
   const size_t sm = (size_t)(tpb / 64) * 2 * d->C * sizeof(float);
-#define LN_BWD(TY, NV) hipLaunchKernelGGL((ln_bwd_kernel<TY, NV>), dim3(blocks), dim3(tpb), sm, st, (const TY*)dy, x, stats, gamma, dx, accumulate_dx, dgamma, dbeta, d->rows, d->C, lpr, map)
+#define LN_BWD(TY, NV) hipLaunchKernelGGL((ln_bwd_kernel<TY, NV>), dim3(blocks), dim3(tpb), sm, st, (const TY*)dy, x, stats, gamma, dx, accumulate_dx, dgamma, dbeta, d->rows, d->C, lpr, map, (TY*)dx_masked, dd, mcols)
   if (d->dtype == FOCAL_F32) { if (nv == 1) LN_BWD(float, 1); else if (nv == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
   else { if (nv == 1) LN_BWD(bf16_t, 1); else if (nv == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
 #undef LN_BWD
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+// out[r][c] = dtype(g[r][c] * mask(r, c)): the same product for a gradient that no LayerNorm backward completes (the one
+// entering the last block of an encoder).
+template <typename TY>
+__global__ __launch_bounds__(256) void mask_cast_kernel(const float* __restrict__ g, TY* __restrict__ out, long n4, focal_drop_desc dd, int ncols) {
+  const DropMask mk = make_mask(dd, ncols);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256)
+    store_masked4(out, e * 4, reinterpret_cast<const float4*>(g)[e], mk);
+}
+
+extern "C" int focal_mask_cast(int dtype, int rows, int C, const float* g, const focal_drop_desc* mask, void* out, void* stream) {
+  FOCAL_CHECK_ARG(dtype == FOCAL_F32 || dtype == FOCAL_BF16, "mask_cast: bad dtype");
+  FOCAL_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && g && out, "mask_cast: bad arguments");
+  focal_drop_desc dd;
+  memset(&dd, 0, sizeof(dd));
+  if (mask) dd = *mask;
+  const long n4 = (long)rows * C / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FOCAL_F32) hipLaunchKernelGGL((mask_cast_kernel<float>), dim3(blocks), dim3(256), 0, st, g, (float*)out, n4, dd, C);
+  else hipLaunchKernelGGL((mask_cast_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, g, (bf16_t*)out, n4, dd, C);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -139,12 +139,27 @@ def layernorm_fwd(x, gamma, beta, out_dtype, gather=None, desc=None):
     return y, stats
 
 
-def layernorm_bwd(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None):
+def layernorm_bwd(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None, dx_masked=None, mask=None):
+    """dx_masked (dy.dtype, same shape as dx) <- dx * mask for the residual branch that consumes dx next (mask=None: a
+    plain dtype copy)."""
     _need_cuda(dy, x, stats, gamma, dx, dgamma, dbeta)
     rows, Cc = dy.shape
     d = desc or ln_desc(code(dy.dtype), rows, Cc, gather=gather)
+    if dx_masked is not None:
+        assert dx_masked.dtype == dy.dtype and dx_masked.numel() == dx.numel()
+        mask = mask or NO_DROP
     check(_lib.load().focal_layernorm_bwd(C.byref(d), _p(dy), _p(x), _p(stats), _p(gamma), _p(dx), int(accumulate),
-                                          _p(dgamma), _p(dbeta), _stream()))
+                                          _p(dgamma), _p(dbeta), _p(dx_masked), C.byref(mask) if mask is not None else None,
+                                          _stream()))
+
+
+def mask_cast(g, mask, dtype):
+    """dtype(g * mask) for an fp32 [rows, C] gradient (see focal_mask_cast)."""
+    _need_cuda(g)
+    rows, Cc = g.shape
+    out = torch.empty(rows, Cc, dtype=dtype, device=g.device)
+    check(_lib.load().focal_mask_cast(code(dtype), rows, Cc, _p(g), C.byref(mask or NO_DROP), _p(out), _stream()))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ Linear family

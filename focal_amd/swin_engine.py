@@ -117,7 +117,14 @@ class SwinModEncoder:
         g = torch.empty_like(xf)
         ops.linear_bwd_data(d_in_b, dfeat, ar.operand(f"{pin}.weight"), None, g)
         merges = {m["after_block"]: m for m in saved["merges"]}
-        for k in range(len(saved["blocks"]) - 1, -1, -1):
+        blocks = saved["blocks"]
+        cc = ops.code(ct)
+        # gm = ct(g * mask): the residual-stream gradient times the dropout x drop-path mask of the branch that consumes it
+        # next, written once by whichever kernel completes g (LayerNorm backward, or mask_cast for the first one); the
+        # branch's dX / dW GEMMs then run as plain `ct` kernels instead of regenerating the mask per column tile.
+        last = blocks[-1]
+        gm = ops.mask_cast(g.view(last["M"], last["C"]), last["d_fc2"].out_drop, ct)
+        for k in range(len(blocks) - 1, -1, -1):
             if (k + 1) in merges:  # a PatchMerging sits between block k and block k+1
                 mg = merges[k + 1]
                 pm, d_red = mg["pm"], mg["d_red"]
@@ -125,24 +132,29 @@ class SwinModEncoder:
                 da4 = torch.empty_like(mg["a4"])
                 ops.linear_bwd_data(d_red, g, ar.operand(f"{pm}.reduction.weight"), None, da4)
                 g = torch.empty_like(mg["x"])
+                gm = torch.empty(mg["x"].shape, dtype=ct, device=dev)
                 ops.layernorm_bwd(da4, mg["x"], mg["st4"], ar.master(f"{pm}.norm.weight"), g, False,
-                                  ar.g(f"{pm}.norm.weight"), ar.g(f"{pm}.norm.bias"), gather=mg["gather"])
-            s = saved["blocks"][k]
+                                  ar.g(f"{pm}.norm.weight"), ar.g(f"{pm}.norm.bias"), gather=mg["gather"],
+                                  dx_masked=gm, mask=blocks[k]["d_fc2"].out_drop)
+            s = blocks[k]
             pb, M, Cc = s["pb"], s["M"], s["C"]
+            gm = gm.view(M, Cc)
             # ---- MLP branch: x_out = x_mid + mask * (h W2^T + b2), h = drop(gelu(a2 W1^T + b1))
-            ops.linear_bwd_weight(s["d_fc2"], g, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
+            d_fc2_b = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, cc, ACT_GELU)  # dy = gm: operand dtype, already masked
+            ops.linear_bwd_weight(d_fc2_b, gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
             du = torch.empty_like(s["h"])
-            ops.linear_bwd_data(s["d_fc2"], g, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
+            ops.linear_bwd_data(d_fc2_b, gm, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
             ops.linear_bwd_weight(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
             dc = torch.empty_like(s["a2"])
             ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
             del du
             ops.layernorm_bwd(dc, s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g, True,
-                              ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"))
+                              ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), dx_masked=gm, mask=s["d_proj"].out_drop)
             # ---- attention branch: x_mid = x + mask * (o Wp^T + bp)
-            ops.linear_bwd_weight(s["d_proj"], g, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
+            d_proj_b = ops.linear_desc(cc, M, Cc, Cc, cc, cc)
+            ops.linear_bwd_weight(d_proj_b, gm, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
             do = dc  # reuse the [M, C] CT buffer
-            ops.linear_bwd_data(s["d_proj"], g, ar.operand(f"{pb}.attn.proj.weight"), None, do)
+            ops.linear_bwd_data(d_proj_b, gm, ar.operand(f"{pb}.attn.proj.weight"), None, do)
             dqkv = torch.empty_like(s["qkv"])
             ops.window_attn_bwd(s["d_att"], s["qkv"], ar.master(f"{pb}.attn.relative_position_bias_table"), do, dqkv,
                                 ar.g(f"{pb}.attn.relative_position_bias_table"))
@@ -150,9 +162,12 @@ class SwinModEncoder:
             da = do
             ops.linear_bwd_data(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), None, da)
             del dqkv
+            # the next consumer of g: block k-1's MLP branch, unless a PatchMerging (handled above) or the embedding comes first
+            nxt = blocks[k - 1]["d_fc2"].out_drop if (k > 0 and k not in merges) else None
             ops.layernorm_bwd(da, s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g, True,
-                              ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"))
-            saved["blocks"][k] = None  # free this block's activations as we go
+                              ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"),
+                              dx_masked=gm if nxt is not None else None, mask=nxt)
+            blocks[k] = None  # free this block's activations as we go
         # g now holds dL/d(patch-embed tokens); the embedding is frozen and its input is a leaf -> stop here.
 
 

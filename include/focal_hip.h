@@ -71,12 +71,18 @@ int focal_pad_patch_embed_ln_fwd(const focal_embed_desc* d, const float* x, cons
  * [rows, 2] = {mean, rstd}.  gather = 1 is PatchMerging's 2x2 gather fused in front of its LayerNorm
  * (SwinModules.py:388-399): x is [B, H, W, Cin], rows = B*(H/2)*(W/2), C = 4*Cin.
  * Backward: dx (fp32) += or = the input gradient (scattered back to [B, H, W, Cin] when gather = 1);
- * dgamma / dbeta (fp32 [C]) are accumulated (+=). */
+ * dgamma / dbeta (fp32 [C]) are accumulated (+=).
+ * dx_masked / mask (both optional): additionally writes dtype(dx * mask) -- dx being the COMPLETED residual-stream
+ * gradient -- where mask is the dropout x drop-path mask of the residual branch that consumes dx next (the forward
+ * epilogue's index convention); that branch's dX / dW GEMMs then take it as a plain `dtype` dy (y_dtype = dtype, no
+ * residual epilogue in their descriptor).  focal_mask_cast is the same product for a gradient no LayerNorm completes. */
 typedef struct { int dtype; int rows, C; float eps; int gather; int B, H, W, Cin; } focal_ln_desc;
 int focal_layernorm_fwd(const focal_ln_desc* d, const float* x, const float* gamma, const float* beta, void* y,
                         float* stats, void* stream);
 int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const float* x, const float* stats,
-                        const float* gamma, float* dx, int accumulate_dx, float* dgamma, float* dbeta, void* stream);
+                        const float* gamma, float* dx, int accumulate_dx, float* dgamma, float* dbeta,
+                        void* dx_masked, const focal_drop_desc* mask, void* stream);
+int focal_mask_cast(int dtype, int rows, int C, const float* g, const focal_drop_desc* mask, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ Linear family
  * y[M, N] = epilogue( x[M, K] . w[N, K]^T + bias ), i.e. nn.Linear of models/SwinModules.py:22-34,113-116,375 and

@@ -411,3 +411,34 @@ def test_window_attention_dropout_fwd_bwd_consistent(ops):
     h1, h2 = torch.empty_like(g1), torch.zeros_like(table)
     ops.window_attn_bwd(d16, qkv.bfloat16(), table, do.bfloat16(), h1, h2)
     assert rel_err(h1.float(), g1.float()) < 2e-2 and rel_err(h2, g2) < 2e-2
+
+
+def test_masked_gradient_copy_matches_forward_mask(ops):
+    """layernorm_bwd's dx_masked / mask_cast output = completed dx * (the mask the forward residual epilogue drew), in
+    both row layouts (plain and PatchMerging gather)."""
+    from focal_amd._lib import EPI_RESIDUAL
+    B, H, W, Cin = 4, 6, 12, 64
+    M, L = B * H * W, H * W
+    state = ops.new_rng_state(9, DEV)
+    dd = ops.drop_desc(state, 21, 0.2, 25, 0.1, L)
+    # forward mask through the residual epilogue: y = 0 + mask * (1 @ I)
+    y, _ = ops.linear(torch.ones(M, Cin, device=DEV), torch.eye(Cin, device=DEV), None, compute=torch.float32, y_dtype=torch.float32,
+                      resid=torch.zeros(M, Cin, device=DEV), epilogue=EPI_RESIDUAL, out_drop=dd)
+    g = rnd(M, Cin, seed=5)
+    assert torch.equal(ops.mask_cast(g, dd, torch.float32), g * y)
+    assert rel_err(ops.mask_cast(g, dd, torch.bfloat16).float(), g * y) < 5e-3
+    # plain LayerNorm backward, accumulate into an existing gradient
+    x, gam = rnd(M, Cin, seed=1), rnd(Cin, seed=2)
+    _, st = ops.layernorm_fwd(x, gam, torch.zeros_like(gam), torch.float32)
+    dy = rnd(M, Cin, seed=3)
+    dx, dxm = g.clone(), torch.empty(M, Cin, device=DEV)
+    ops.layernorm_bwd(dy, x, st, gam, dx, True, torch.zeros_like(gam), torch.zeros_like(gam), dx_masked=dxm, mask=dd)
+    assert torch.equal(dxm, dx * y)
+    # gather layout: rows of the merged grid scatter back into [B, H, W, Cin] tokens
+    gather = (B, H, W, Cin)
+    g4 = rnd(4 * Cin, seed=6)
+    _, st4 = ops.layernorm_fwd(x, g4, torch.zeros_like(g4), torch.float32, gather=gather)
+    dy4 = rnd(M // 4, 4 * Cin, seed=7)
+    dx4, dxm4 = torch.empty(M, Cin, device=DEV), torch.empty(M, Cin, device=DEV)
+    ops.layernorm_bwd(dy4, x, st4, g4, dx4, False, torch.zeros_like(g4), torch.zeros_like(g4), gather=gather, dx_masked=dxm4, mask=dd)
+    assert torch.equal(dxm4, dx4 * y)

@@ -134,3 +134,44 @@ def test_three_adamw_steps_follow_reference(cfg, ct):
         p = dict(net.named_parameters())["mod_projectors.audio.2.weight"].detach().reshape(-1).cpu().double()
         step = max(1, p.numel() // 32)
         assert (p[::step][:32] - torch.from_numpy(fx["adamw.probe_after3"])).abs().max().item() < 2e-4
+
+
+def test_dropout_on_backward_matches_forward_masks(cfg):
+    """With every dropout rate at its MOD.yaml value and the device seed frozen, the masks are a fixed function of the element
+    index, so the training-mode encoder is a deterministic differentiable function: its analytic gradient (which regenerates
+    each mask in a different kernel than the forward drew it in) must match central differences.  A single forward/backward
+    mask disagreement shows up as an O(1) error."""
+    from models.SW_Transformer import SW_Transformer
+    from oracle.weights import fill_state_dict_
+    args = make_args(cfg, "SW_Transformer", torch.device("cuda"), "fp32")
+    net = SW_Transformer(args)
+    fill_state_dict_(net.state_dict())
+    net = net.to("cuda").train()
+    x1, _ = inputs(cfg, B=4)
+    r = {m: torch.randn(4, 256, device="cuda", generator=torch.Generator("cuda").manual_seed(i)) for i, m in enumerate(cfg["modality_names"])}
+
+    def value():
+        net._fwd_calls = 0  # same RNG stream ids on every evaluation
+        out = net(x1, class_head=False, proj_head=False)
+        return sum((out[m] * r[m]).sum() for m in out)
+
+    net.arena().zero_grad()
+    value().backward()
+    torch.cuda.synchronize()
+    params = dict(net.named_parameters())
+    names = ["freq_interval_layers.shake.audio.0.blocks.1.mlp.fc2.weight", "freq_interval_layers.shake.audio.1.blocks.0.attn.proj.weight",
+             "freq_interval_layers.shake.seismic.2.blocks.3.mlp.fc1.weight", "freq_interval_layers.shake.audio.0.downsample.reduction.weight",
+             "freq_interval_layers.shake.seismic.0.blocks.0.norm1.weight", "freq_interval_layers.shake.audio.2.blocks.2.attn.qkv.weight"]
+    for i, n in enumerate(names):
+        p = params[n]
+        d = torch.randn(p.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(100 + i))
+        ana = (p.grad * d).sum().item()
+        eps = 2e-3 / max(d.abs().max().item(), 1e-6)
+        with torch.no_grad():
+            p.add_(eps * d)
+            up = value().item()
+            p.add_(-2 * eps * d)
+            dn = value().item()
+            p.add_(eps * d)
+        num = (up - dn) / (2 * eps)
+        assert abs(num - ana) < 3e-2 * max(abs(ana), abs(num), 1e-3), (n, num, ana)
