@@ -4,6 +4,7 @@
 // (m = n2*m1 + m2, k = k1 + n1*k2).  For the MOD audio rows n = 1600 = 40 x 40; n2 = 1 degenerates to the direct
 // DFT used for the 20-point seismic rows.  The twiddle table holds {cos, -sin}(2 pi j / n), j < n, computed in
 // fp64 on the host.
+#include <stdlib.h>
 #include "common.hpp"
 
 __global__ __launch_bounds__(256) void fft_realpack_kernel(const float* __restrict__ x, const float* __restrict__ tw,
@@ -65,6 +66,156 @@ __global__ __launch_bounds__(256) void fft_realpack_kernel(const float* __restri
   }
 }
 
+// ---- matrix-core form of the same four-step DFT (n1, n2 <= 48, multiples of 8): both stages are small real GEMMs, so
+// they run on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) instead of 6 LDS reads per complex MAC on the VALU path above.
+// Two rows per workgroup iteration (2*n2 and 2*n1 are multiples of the 16-row MFMA tile):
+//   stage 1   Y[(row, m2)][k1] = sum_m1 x[row][n2*m1 + m2] * W_n1[m1][k1]         A straight from global, K = n1
+//   twiddle   Y *= W_n^(m2 k1), in registers; Y -> LDS as Yr / Yi [row][m2][k1]
+//   stage 2   X[(row, k1)][k2] = sum_m2 Y[row][m2][k1] * W_n2[m2][k2] (complex)    K = 2*n2 over (Yr | Yi)
+// Each wave owns whole 16-row tiles and walks the three 16-column pairs (re tile, im tile), so a lane always holds the
+// real and imaginary part of the same element.  Output rows leave as 16-byte stores (4 consecutive k1 per lane).
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// N1 / N2 are compile-time: the index arithmetic below is full of divisions by them (runtime divisors cost ~40
+// instructions each and dominated the first version of this kernel).
+template <int N1, int N2>
+__global__ __launch_bounds__(256) void fft_realpack_mfma_kernel(const float* __restrict__ x, const float* __restrict__ tw,
+                                                                float* __restrict__ out, focal_fft_desc d, int rows) {
+  constexpr int P = 48;  // padded tile pitch (3 x 16)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int n = N1 * N2, n1 = N1, n2 = N2;
+  float* twc = smem;                 // [n]  cos(2 pi j / n)
+  float* tws = twc + n;              // [n] -sin
+  float* w1c = tws + n;              // [n1][P]  W_n1[m1][k1]  (zero beyond k1 >= n1)
+  float* w1s = w1c + n1 * P;
+  constexpr bool same = n1 == n2;    // square factorisation (MOD audio: 40 x 40): one table serves both stages
+  float* w2c = same ? w1c : w1s + n1 * P;  // [n2][P]  W_n2[m2][k2]
+  float* w2s = same ? w1s : w2c + n2 * P;
+  float* yr = (same ? w1s : w2s) + n2 * P;  // [2][n2][P]
+  float* yi = yr + 2 * n2 * P;
+  float* xs = yi + 2 * n2 * P;       // [2][n]  the two input rows of this pass
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lj = lane & 15, lg = lane >> 4;
+  for (int i = tid; i < n; i += 256) { twc[i] = tw[2 * i]; tws[i] = tw[2 * i + 1]; }
+  for (int i = tid; i < n1 * P; i += 256) {
+    const int m = i / P, k = i % P;
+    const int t = ((m * k) % n1) * n2;
+    w1c[i] = k < n1 ? tw[2 * t] : 0.f;
+    w1s[i] = k < n1 ? tw[2 * t + 1] : 0.f;
+  }
+  for (int i = tid; i < (same ? 0 : n2 * P); i += 256) {
+    const int m = i / P, k = i % P;
+    const int t = ((m * k) % n2) * n1;
+    w2c[i] = k < n2 ? tw[2 * t] : 0.f;
+    w2s[i] = k < n2 ? tw[2 * t + 1] : 0.f;
+  }
+  constexpr int mt1 = 2 * n2 / 16, mt2 = 2 * n1 / 16;  // 16-row tiles of stage 1 / stage 2
+  // the next pass's rows are fetched (coalesced, 16 B per lane) while stage 2 of the current pass runs
+  constexpr int XV = (2 * n / 4 + 255) / 256;  // float4 per thread
+  float4 xn[XV];
+  auto fetch = [&](int pair) {
+    const float4* src = reinterpret_cast<const float4*>(x + (long)pair * 2 * n);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int e = tid + 256 * i;
+      xn[i] = (e < 2 * n / 4 && pair < rows / 2) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int e = tid + 256 * i;
+      if (e < 2 * n / 4) reinterpret_cast<float4*>(xs)[e] = xn[i];
+    }
+  };
+  fetch(blockIdx.x);
+  stash();
+  for (int pair = blockIdx.x; pair < rows / 2; pair += gridDim.x) {
+    __syncthreads();  // tables and xs ready; previous pass done with yr / yi
+    const float* x0 = xs;
+    // ---- stage 1
+    constexpr int np1 = (n1 + 15) / 16, np2 = (n2 + 15) / 16;  // 16-column (re, im) tile pairs
+    for (int u = wave; u < mt1 * np1; u += 4) {  // unit = (16-row tile, column pair)
+      const int mt = u / np1, p = u - mt * np1;
+      const int f = 16 * mt + lj, row = f / n2, m2 = f - row * n2;  // this lane's A row
+      const float* xa = x0 + row * n + m2;
+      float a[12];
+#pragma unroll
+      for (int ks = 0; ks < 12; ++ks) {
+        const int m1 = 4 * ks + lg;
+        a[ks] = m1 < n1 ? xa[n2 * m1] : 0.f;
+      }
+      {
+        // four independent accumulator chains (even / odd k-steps): back-to-back dependent MFMAs would wait out the
+        // matrix pipe's latency on every step
+        f4 re = {0.f, 0.f, 0.f, 0.f}, im = re, re2 = re, im2 = re;
+#pragma unroll
+        for (int ks = 0; ks < 12; ks += 2) {
+          if (4 * ks >= n1) break;
+          const int bi = (4 * ks + lg) * P + 16 * p + lj;
+          re = mfma4(a[ks], w1c[bi], re);
+          im = mfma4(a[ks], w1s[bi], im);
+          if (4 * (ks + 1) < n1) {
+            re2 = mfma4(a[ks + 1], w1c[bi + 4 * P], re2);
+            im2 = mfma4(a[ks + 1], w1s[bi + 4 * P], im2);
+          }
+        }
+        re += re2;
+        im += im2;
+        const int k1 = 16 * p + lj;
+        if (k1 < n1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int fo = 16 * mt + 4 * lg + r, ro = fo / n2, mo = fo - ro * n2;
+            const int t = (mo * k1) % n;
+            const float c = twc[t], sn = tws[t];
+            yr[(ro * n2 + mo) * P + k1] = re[r] * c - im[r] * sn;
+            yi[(ro * n2 + mo) * P + k1] = re[r] * sn + im[r] * c;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    fetch(pair + gridDim.x);
+    // ---- stage 2
+    for (int u = wave; u < mt2 * np2; u += 4) {
+      const int mt = u / np2, p = u - mt * np2;
+      const int f = 16 * mt + lj, row = f / n1, k1 = f - row * n1;
+      const float* ya = yr + row * n2 * P + k1;
+      const float* yb = yi + row * n2 * P + k1;
+      const int fo = 16 * mt + 4 * lg, ro = fo / n1, ko = fo - ro * n1;  // this lane's 4 output k1: ko .. ko + 3
+      const int grow = pair * 2 + ro;
+      const int ci = grow % d.I, bc = grow / d.I;  // row = (b*C + c)*I + i
+      float* ore = out + ((long)(2 * bc) * d.I + ci) * n + ko;
+      float* oim = out + ((long)(2 * bc + 1) * d.I + ci) * n + ko;
+      {
+        f4 re = {0.f, 0.f, 0.f, 0.f}, im = re, re2 = re, im2 = re;
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+          if (4 * ks >= n2) break;
+          const int m2 = 4 * ks + lg;
+          const float ar = ya[m2 * P], ai = yb[m2 * P];
+          const int bi = m2 * P + 16 * p + lj;
+          const float c = w2c[bi], sn = w2s[bi];
+          re = mfma4(ar, c, re);
+          im = mfma4(ar, sn, im);
+          re2 = mfma4(ai, -sn, re2);
+          im2 = mfma4(ai, c, im2);
+        }
+        re += re2;
+        im += im2;
+        const int k2 = 16 * p + lj;
+        if (k2 < n2) {
+          *reinterpret_cast<float4*>(ore + n1 * k2) = make_float4(re[0], re[1], re[2], re[3]);
+          *reinterpret_cast<float4*>(oim + n1 * k2) = make_float4(im[0], im[1], im[2], im[3]);
+        }
+      }
+    }
+    stash();  // xs is free since the barrier after stage 1
+  }
+}
+
 extern "C" int focal_fft_realpack_fwd(const focal_fft_desc* d, const float* x, const float* twiddle, float* out,
                                       void* stream) {
   FOCAL_CHECK_ARG(d && x && twiddle && out, "fft_realpack: null argument");
@@ -72,6 +223,29 @@ extern "C" int focal_fft_realpack_fwd(const focal_fft_desc* d, const float* x, c
   const size_t sm = (size_t)5 * d->n * sizeof(float);
   FOCAL_CHECK_ARG(sm <= 64 * 1024, "fft_realpack: n=%d too long for the LDS-resident DFT", d->n);
   const int rows = d->B * d->C * d->I;
+  const bool mfma_shape = (d->n1 == d->n2) && (d->n1 == 8 || d->n1 == 16 || d->n1 == 24 || d->n1 == 32 || d->n1 == 40 || d->n1 == 48);
+  if (mfma_shape && rows % 2 == 0 && !getenv("FOCAL_FFT_VALU")) {
+    const size_t smm = (size_t)(2 * d->n + 2 * 48 * d->n1 + (d->n1 == d->n2 ? 0 : 2 * 48 * d->n2) + 4 * 48 * d->n2 + 2 * d->n) * sizeof(float);
+    static size_t lds_granted = 48 * 1024;
+    if (smm > lds_granted) {  // above the default dynamic-LDS grant: raise it for this kernel (160 KB per CU on gfx950)
+      hipError_t e = hipSuccess;
+#define FFT_ATTR(N_) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_realpack_mfma_kernel<N_, N_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smm)
+      FFT_ATTR(8); FFT_ATTR(16); FFT_ATTR(24); FFT_ATTR(32); FFT_ATTR(40); FFT_ATTR(48);
+#undef FFT_ATTR
+      if (e != hipSuccess) {
+        focal_set_error("fft_realpack: cannot reserve %zu bytes of LDS: %s", smm, hipGetErrorString(e));
+        return FOCAL_EHIP;
+      }
+      lds_granted = smm;
+    }
+    static const int maxb = getenv("FOCAL_FFT_BLOCKS") ? atoi(getenv("FOCAL_FFT_BLOCKS")) : 1024;
+    int blocks = rows / 2 < maxb ? rows / 2 : maxb;
+#define FFT_GO(N_) case N_: hipLaunchKernelGGL((fft_realpack_mfma_kernel<N_, N_>), dim3(blocks), dim3(256), smm, (hipStream_t)stream, x, twiddle, out, *d, rows); break
+    switch (d->n1) { FFT_GO(8); FFT_GO(16); FFT_GO(24); FFT_GO(32); FFT_GO(40); default: FFT_GO(48); }
+#undef FFT_GO
+    FOCAL_LAUNCH_CHECK();
+    return FOCAL_OK;
+  }
   int blocks = rows < 4096 ? rows : 4096;
   hipLaunchKernelGGL(fft_realpack_kernel, dim3(blocks), dim3(256), sm, (hipStream_t)stream, x, twiddle, out, *d, rows);
   FOCAL_LAUNCH_CHECK();

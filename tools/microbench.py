@@ -108,3 +108,9 @@ for tag, H, W, C in GEO:
         report(f"{tag} attn_fwd shift={sh} [{M}x{3 * C}]", timeit(lambda: ops.window_attn_fwd(d, qkv, table, o)), M * 4 * C * ES, 4.0 * M * 9 * C)
         do, dqkv, dt = rnd(M, C, dtype=CT), torch.empty_like(qkv), torch.zeros_like(table)
         report(f"{tag} attn_bwd shift={sh}", timeit(lambda: ops.window_attn_bwd(d, qkv, table, do, dqkv, dt)), M * 8 * C * ES, 10.0 * M * 9 * C)
+
+if not ONLY or ONLY == "fft":
+    for nm, shape in (("audio", (256, 1, 10, 1600)), ("seismic", (256, 1, 10, 20))):
+        xt = rnd(*shape)
+        n_el = xt.numel()
+        report(f"fft_realpack {nm} {list(shape)}", timeit(lambda: ops.fft_realpack(xt)), n_el * 4 * 3)
