@@ -108,6 +108,9 @@ PROTOTYPES = {
     "focal_bn_act_bwd": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P, P, C.c_int, P]),
     "focal_gru_gate_fwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, C.c_int, P, P, P, P, P, P, P]),
     "focal_gru_gate_bwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, C.c_int, P, C.c_long, C.c_long, C.c_float, P, P, P, P, P, P, P, P]),
+    "focal_gru_seq_fwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), P, P]),
+    "focal_gru_seq_bwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, P, C.c_long, C.c_long, C.c_float, C.POINTER(P), C.POINTER(P), C.POINTER(P),
+                                    C.POINTER(P), C.POINTER(P), P]),
     "focal_mean_time": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, P]),
     "focal_dropout": (C.c_int, [C.c_long, P, P, P, C.c_uint32, C.c_float, P]),
     "focal_axpy": (C.c_int, [C.c_long, C.c_float, P, P, P]),

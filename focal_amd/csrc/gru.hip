@@ -52,6 +52,191 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(focal_gru_desc d, int
   }
 }
 
+// ---------------------------------------------------------------------------------------------- whole-sequence kernels
+// The recurrence is 10 strictly sequential steps of a tiny product ([B,H] x [H,3H]) plus gate math: launched per step it is
+// pure launch latency (~370 launches of 4-12 us per DeepSense step).  Here one launch runs the whole sequence of one layer,
+// both directions (blockIdx.y): a workgroup owns 16 samples for all T steps; W_hh (bf16, 3H x H = 393 KB at H = 256) is
+// read once per workgroup as MFMA operand fragments (16 B per lane, straight from its [3H][H] storage) and kept in
+// registers, 49 KB per wave; the hidden
+// state lives in registers (fp32, the lane that produces h[m][j] is the lane that needs it next step) with a bf16 copy in
+// LDS for the other operand.  D = W-fragment x h-fragment, so a lane holds 4 consecutive hidden units of ONE sample for all
+// three gates: every global access (gi, hs, out, save) is a 16-byte vector.  8 waves; wave w owns hidden units [w*H/8, (w+1)*H/8).
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 gbf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 gbf16x4;
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+struct GruDirFwd { const float* gi; const bf16_t* whh; const float* bhh; float* hs; float* save; };
+struct GruFwdArgs { GruDirFwd d[2]; };
+struct GruDirBwd { const bf16_t* whh_t; const float* hs; const float* save; float* dgi; float* dgh; };
+struct GruBwdArgs { GruDirBwd d[2]; };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+
+template <int H>
+__global__ __launch_bounds__(512) void gru_seq_fwd_kernel(focal_gru_desc gd, GruFwdArgs args, float* __restrict__ out) {
+  constexpr int QT = H / 128, PH = H + 8;  // 8 waves: wave w owns hidden units [w*H/8, (w+1)*H/8)
+  __shared__ __attribute__((aligned(16))) bf16_t hb[16 * PH];
+  const int dir = blockIdx.y;
+  const GruDirFwd p = args.d[dir];
+  const int B = gd.B, T = gd.T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lm = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x * 16 + lm;
+  const bool ok = b < B;
+  const int jw = wave * 16 * QT;
+  const long n = (long)B * H;
+  float hprev[QT][4];
+#pragma unroll
+  for (int q = 0; q < QT; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hprev[q][r] = 0.f;
+  // This wave's slice of W_hh (3 gates x 16*QT rows x H) is loaded ONCE and stays in registers for all T steps
+  // (H = 256: 48 fragments = 192 VGPRs): streaming it from L2 every step left the kernel latency-bound (17 us / step).
+  gbf16x8 wreg[3][QT][H / 32];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int q = 0; q < QT; ++q)
+#pragma unroll
+      for (int ks = 0; ks < H / 32; ++ks)
+        wreg[g][q][ks] = *reinterpret_cast<const gbf16x8*>(p.whh + (long)(g * H + jw + 16 * q + lm) * H + 32 * ks + 8 * lg);
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    gf32x4 acc[3][QT];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int q = 0; q < QT; ++q) acc[g][q] = gf32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {  // h_0 = 0: the first step's recurrent product is just the bias
+#pragma unroll
+      for (int ks = 0; ks < H / 32; ++ks) {
+        const gbf16x8 hf = *reinterpret_cast<const gbf16x8*>(hb + lm * PH + 32 * ks + 8 * lg);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int q = 0; q < QT; ++q) acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[g][q][ks], hf, acc[g][q], 0, 0, 0);
+      }
+    }
+    float hnew[QT][4];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      const int j0 = jw + 16 * q + 4 * lg;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* gir = p.gi + ((long)b * T + t) * 3 * H + j0;
+      const float4 gr = ok ? ld4(gir) : z4, gz = ok ? ld4(gir + H) : z4, gn = ok ? ld4(gir + 2 * H) : z4;
+      const float4 br = ld4(p.bhh + j0), bz = ld4(p.bhh + H + j0), bn = ld4(p.bhh + 2 * H + j0);
+      const float gra[4] = {gr.x, gr.y, gr.z, gr.w}, gza[4] = {gz.x, gz.y, gz.z, gz.w}, gna[4] = {gn.x, gn.y, gn.z, gn.w};
+      const float bra[4] = {br.x, br.y, br.z, br.w}, bza[4] = {bz.x, bz.y, bz.z, bz.w}, bna[4] = {bn.x, bn.y, bn.z, bn.w};
+      float rr[4], zz[4], nn[4], gh[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        rr[r] = sigmoid_f(gra[r] + acc[0][q][r] + bra[r]);
+        zz[r] = sigmoid_f(gza[r] + acc[1][q][r] + bza[r]);
+        gh[r] = acc[2][q][r] + bna[r];
+        nn[r] = tanhf(gna[r] + rr[r] * gh[r]);
+        hnew[q][r] = (1.f - zz[r]) * nn[r] + zz[r] * hprev[q][r];
+        hprev[q][r] = hnew[q][r];
+      }
+      if (ok) {
+        const long e = (long)b * H + j0;
+        st4(p.hs + (long)(s + 1) * n + e, hnew[q]);
+        st4(out + ((long)b * T + t) * 2 * H + dir * H + j0, hnew[q]);
+        float* sv = p.save + (long)s * 4 * n + e;
+        st4(sv, rr); st4(sv + n, zz); st4(sv + 2 * n, nn); st4(sv + 3 * n, gh);
+      }
+    }
+    __syncthreads();  // every wave has read this step's h fragments
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      gbf16x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (__bf16)(ok ? hnew[q][r] : 0.f);
+      *reinterpret_cast<gbf16x4*>(hb + lm * PH + jw + 16 * q + 4 * lg) = v;
+    }
+    __syncthreads();
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(512) void gru_seq_bwd_kernel(focal_gru_desc gd, GruBwdArgs args, const float* __restrict__ dout, long ld_b,
+                                                          long ld_t, float scale) {
+  constexpr int QT = H / 128, PG = 3 * H + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t gb[16 * PG];
+  const int dir = blockIdx.y;
+  const GruDirBwd p = args.d[dir];
+  const int B = gd.B, T = gd.T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lm = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x * 16 + lm;
+  const bool ok = b < B;
+  const int jw = wave * 16 * QT;
+  const long n = (long)B * H;
+  float dhz[QT][4], dhrec[QT][4];
+#pragma unroll
+  for (int q = 0; q < QT; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dhz[q][r] = dhrec[q][r] = 0.f;
+  gbf16x8 wreg[QT][3 * H / 32];  // this wave's rows of W_hh^T, resident for all steps
+#pragma unroll
+  for (int q = 0; q < QT; ++q)
+#pragma unroll
+    for (int ks = 0; ks < 3 * H / 32; ++ks)
+      wreg[q][ks] = *reinterpret_cast<const gbf16x8*>(p.whh_t + (long)(jw + 16 * q + lm) * 3 * H + 32 * ks + 8 * lg);
+  for (int s = T - 1; s >= 0; --s) {
+    const int t = dir ? T - 1 - s : s;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      const int j0 = jw + 16 * q + 4 * lg;
+      const long e = (long)b * H + j0;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 d4 = ok ? ld4(dout + (long)b * ld_b + (long)t * ld_t + dir * H + j0) : z4;
+      const float* sv = p.save + (long)s * 4 * n + e;
+      const float4 r4 = ok ? ld4(sv) : z4, zz4 = ok ? ld4(sv + n) : z4, n4 = ok ? ld4(sv + 2 * n) : z4, g4 = ok ? ld4(sv + 3 * n) : z4;
+      const float4 h4 = ok ? ld4(p.hs + (long)s * n + e) : z4;
+      const float da[4] = {d4.x, d4.y, d4.z, d4.w}, ra[4] = {r4.x, r4.y, r4.z, r4.w}, za[4] = {zz4.x, zz4.y, zz4.z, zz4.w};
+      const float na[4] = {n4.x, n4.y, n4.z, n4.w}, ga[4] = {g4.x, g4.y, g4.z, g4.w}, ha[4] = {h4.x, h4.y, h4.z, h4.w};
+      float dr[4], dz[4], dn[4], dnr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dh = scale * da[r] + dhrec[q][r] + dhz[q][r];
+        dn[r] = dh * (1.f - za[r]) * (1.f - na[r] * na[r]);
+        dz[r] = dh * (ha[r] - na[r]) * za[r] * (1.f - za[r]);
+        dr[r] = dn[r] * ga[r] * ra[r] * (1.f - ra[r]);
+        dnr[r] = dn[r] * ra[r];
+        dhz[q][r] = dh * za[r];
+      }
+      if (ok) {
+        float* gir = p.dgi + ((long)b * T + t) * 3 * H + j0;
+        st4(gir, dr); st4(gir + H, dz); st4(gir + 2 * H, dn);
+        float* ghr = p.dgh + ((long)s * B + b) * 3 * H + j0;
+        st4(ghr, dr); st4(ghr + H, dz); st4(ghr + 2 * H, dnr);
+      }
+      gbf16x4 v0, v1, v2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v0[r] = (__bf16)dr[r]; v1[r] = (__bf16)dz[r]; v2[r] = (__bf16)dnr[r]; }
+      bf16_t* row = gb + lm * PG + j0;
+      *reinterpret_cast<gbf16x4*>(row) = v0;
+      *reinterpret_cast<gbf16x4*>(row + H) = v1;
+      *reinterpret_cast<gbf16x4*>(row + 2 * H) = v2;
+    }
+    if (s > 0) {  // dh_{s-1} += dgh_s . W_hh  (through the [H][3H] transposed copy: 16 contiguous bytes per lane again)
+      __syncthreads();
+      gf32x4 acc[QT];
+#pragma unroll
+      for (int q = 0; q < QT; ++q) acc[q] = gf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3 * H / 32; ++ks) {
+        const gbf16x8 gf = *reinterpret_cast<const gbf16x8*>(gb + lm * PG + 32 * ks + 8 * lg);
+#pragma unroll
+        for (int q = 0; q < QT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[q][ks], gf, acc[q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < QT; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dhrec[q][r] = acc[q][r];
+      __syncthreads();
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void mean_time_kernel(int B, int T, int D, const float* __restrict__ x, float* __restrict__ y) {
   const int n = B * D;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
@@ -110,6 +295,48 @@ extern "C" int focal_dropout(long n, const float* x, float* y, const uint32_t* r
 extern "C" int focal_axpy(long n, float a, const float* x, float* y, void* stream) {
   FOCAL_CHECK_ARG(x && y && n >= 0, "axpy: bad argument");
   hipLaunchKernelGGL(axpy_kernel, dim3(gblocks(n)), dim3(256), 0, (hipStream_t)stream, n, a, x, y);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+extern "C" int focal_gru_seq_fwd(const focal_gru_desc* d, int n_dir, const float* const* gi, const void* const* whh, const float* const* bhh,
+                                 float* const* hs, float* const* save, float* out, void* stream) {
+  FOCAL_CHECK_ARG(d && gi && whh && bhh && hs && save && out && n_dir >= 1 && n_dir <= 2, "gru_seq_fwd: bad argument");
+  if (d->H != 128 && d->H != 256) {
+    focal_set_error("gru_seq_fwd: hidden size %d not in {128, 256} (use the per-step kernels)", d->H);
+    return FOCAL_EUNSUPPORTED;
+  }
+  GruFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < n_dir; ++i) {
+    FOCAL_CHECK_ARG(gi[i] && whh[i] && bhh[i] && hs[i] && save[i], "gru_seq_fwd: null tensor");
+    a.d[i] = GruDirFwd{gi[i], (const bf16_t*)whh[i], bhh[i], hs[i], save[i]};
+  }
+  const dim3 grid(ceil_div(d->B, 16), n_dir);
+  if (d->H == 256) hipLaunchKernelGGL((gru_seq_fwd_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, *d, a, out);
+  else hipLaunchKernelGGL((gru_seq_fwd_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, *d, a, out);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+extern "C" int focal_gru_seq_bwd(const focal_gru_desc* d, int n_dir, const float* dout, long ld_b, long ld_t, float scale,
+                                 const void* const* whh_t, const float* const* hs, const float* const* save, float* const* dgi,
+                                 float* const* dgh, void* stream) {
+  FOCAL_CHECK_ARG(d && dout && whh_t && hs && save && dgi && dgh && n_dir >= 1 && n_dir <= 2, "gru_seq_bwd: bad argument");
+  FOCAL_CHECK_ARG(ld_b % 4 == 0 && ld_t % 4 == 0, "gru_seq_bwd: dout strides must be multiples of 4");
+  if (d->H != 128 && d->H != 256) {
+    focal_set_error("gru_seq_bwd: hidden size %d not in {128, 256} (use the per-step kernels)", d->H);
+    return FOCAL_EUNSUPPORTED;
+  }
+  GruBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < n_dir; ++i) {
+    FOCAL_CHECK_ARG(whh_t[i] && hs[i] && save[i] && dgi[i] && dgh[i], "gru_seq_bwd: null tensor");
+    a.d[i] = GruDirBwd{(const bf16_t*)whh_t[i], hs[i], save[i], dgi[i], dgh[i]};
+  }
+  const dim3 grid(ceil_div(d->B, 16), n_dir);
+  if (d->H == 256) hipLaunchKernelGGL((gru_seq_bwd_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
+  else hipLaunchKernelGGL((gru_seq_bwd_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

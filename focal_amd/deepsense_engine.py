@@ -80,6 +80,9 @@ class DeepSenseModEncoder:
             F = x_l.shape[1]
             out = torch.empty(B, T, 2 * H, dtype=torch.float32, device=y.device)
             lsv = dict(x=x_l, dirs=[])
+            # bf16 operands: the whole 10-step recurrence of this layer, both directions, is ONE launch (focal_gru_seq_fwd);
+            # the exact-fp32 mode keeps one GEMM + one gate kernel per step
+            seq = ct == torch.bfloat16 and H in (128, 256)
             for di, suf in enumerate(("", "_reverse")):
                 wih, whh = f"{self.rnn}.weight_ih_l{layer}{suf}", f"{self.rnn}.weight_hh_l{layer}{suf}"
                 bih, bhh = f"{self.rnn}.bias_ih_l{layer}{suf}", f"{self.rnn}.bias_hh_l{layer}{suf}"
@@ -89,12 +92,20 @@ class DeepSenseModEncoder:
                 d_hh = ops.linear_desc(cc, B, 3 * H, H, f32, f32)
                 hs = torch.zeros(T + 1, B, H, dtype=torch.float32, device=y.device)  # hs[0] = h0 = 0
                 save = torch.empty(T, 4, B, H, dtype=torch.float32, device=y.device)
-                gh = torch.empty(B, 3 * H, dtype=torch.float32, device=y.device)
-                for s in range(T):
-                    t = s if di == 0 else T - 1 - s
-                    ops.linear_fwd(d_hh, hs[s], ar.operand(whh), ar.master(bhh), None, gh)
-                    ops.gru_gate_fwd(gd, t, di * H, gi, gh, hs[s], hs[s + 1], out, save[s])
-                lsv["dirs"].append(dict(names=(wih, whh, bih, bhh), d_ih=d_ih, d_hh=d_hh, hs=hs, save=save))
+                if not seq:
+                    gh = torch.empty(B, 3 * H, dtype=torch.float32, device=y.device)
+                    for s in range(T):
+                        t = s if di == 0 else T - 1 - s
+                        ops.linear_fwd(d_hh, hs[s], ar.operand(whh), ar.master(bhh), None, gh)
+                        ops.gru_gate_fwd(gd, t, di * H, gi, gh, hs[s], hs[s + 1], out, save[s])
+                lsv["dirs"].append(dict(names=(wih, whh, bih, bhh), d_ih=d_ih, d_hh=d_hh, hs=hs, save=save, gi=gi))
+            if seq:
+                dirs = lsv["dirs"]
+                ops.gru_seq_fwd(gd, [d["gi"] for d in dirs], [ar.operand(d["names"][1]) for d in dirs],
+                                [ar.master(d["names"][3]) for d in dirs], [d["hs"] for d in dirs], [d["save"] for d in dirs], out)
+            for d in lsv["dirs"]:
+                del d["gi"]
+            lsv["seq"] = seq
             sv["gru"].append(lsv)
             if layer + 1 < geo["n_rnn"]:
                 if p_drop > 0:  # nn.GRU applies dropout to the outputs of every layer but the last
@@ -123,21 +134,31 @@ class DeepSenseModEncoder:
             x_l = lsv["x"]
             F = x_l.shape[1]
             dx = None
+            bufs = []
+            for di, dsv in enumerate(lsv["dirs"]):
+                dgi = torch.empty(B * T, 3 * H, dtype=torch.float32, device=dev)
+                dgh = torch.empty(T, B, 3 * H, dtype=torch.float32, device=dev)
+                bufs.append((dgi, dgh))
+            if lsv["seq"]:
+                dirs = lsv["dirs"]
+                whh_t = [ops.permute_pack(ar.master(d["names"][1]), 1, 3 * H, H, ct) for d in dirs]  # [H][3H] bf16
+                ops.gru_seq_bwd(gd, dout, ld_b, ld_t, scale, whh_t, [d["hs"] for d in dirs], [d["save"] for d in dirs],
+                                [b_[0] for b_ in bufs], [b_[1] for b_ in bufs])
             for di, dsv in enumerate(lsv["dirs"]):
                 wih, whh, bih, bhh = dsv["names"]
                 hs, save = dsv["hs"], dsv["save"]
-                dgi = torch.empty(B * T, 3 * H, dtype=torch.float32, device=dev)
-                dgh = torch.empty(T, B, 3 * H, dtype=torch.float32, device=dev)
-                dhz = torch.empty(2, B, H, dtype=torch.float32, device=dev)
-                dh_rec = torch.empty(B, H, dtype=torch.float32, device=dev)
-                have = False
-                for s in range(T - 1, -1, -1):
-                    t = s if di == 0 else T - 1 - s
-                    ops.gru_gate_bwd(gd, t, di * H, dout, ld_b, ld_t, scale, dh_rec if have else None, dhz[(s + 1) & 1] if have else None,
-                                     save[s], hs[s], dgi, dgh[s], dhz[s & 1])
-                    if s > 0:
-                        ops.linear_bwd_data(dsv["d_hh"], dgh[s], ar.operand(whh), None, dh_rec)
-                        have = True
+                dgi, dgh = bufs[di]
+                if not lsv["seq"]:
+                    dhz = torch.empty(2, B, H, dtype=torch.float32, device=dev)
+                    dh_rec = torch.empty(B, H, dtype=torch.float32, device=dev)
+                    have = False
+                    for s in range(T - 1, -1, -1):
+                        t = s if di == 0 else T - 1 - s
+                        ops.gru_gate_bwd(gd, t, di * H, dout, ld_b, ld_t, scale, dh_rec if have else None, dhz[(s + 1) & 1] if have else None,
+                                         save[s], hs[s], dgi, dgh[s], dhz[s & 1])
+                        if s > 0:
+                            ops.linear_bwd_data(dsv["d_hh"], dgh[s], ar.operand(whh), None, dh_rec)
+                            have = True
                 d_hh_all = ops.linear_desc(cc, T * B, 3 * H, H, f32, f32)
                 ops.linear_bwd_weight(d_hh_all, dgh, hs[:T], ar.g(whh), ar.g(bhh))
                 ops.linear_bwd_weight(dsv["d_ih"], dgi, x_l, ar.g(wih), ar.g(bih))

@@ -348,6 +348,20 @@ def gru_gate_bwd(d, t, dir_off, dout, ld_b, ld_t, scale, dh_rec, dhz_in, save, h
                                          _p(h_prev), _p(dgi), _p(dgh), _p(dhz_out), _stream()))
 
 
+def _parr(tensors):
+    return (C.c_void_p * len(tensors))(*[_p(t) for t in tensors])
+
+
+def gru_seq_fwd(d, gi, whh, bhh, hs, save, out):
+    """Whole-sequence GRU layer, one launch for len(gi) directions (lists of per-direction tensors)."""
+    check(_lib.load().focal_gru_seq_fwd(C.byref(d), len(gi), _parr(gi), _parr(whh), _parr(bhh), _parr(hs), _parr(save), _p(out), _stream()))
+
+
+def gru_seq_bwd(d, dout, ld_b, ld_t, scale, whh_t, hs, save, dgi, dgh):
+    check(_lib.load().focal_gru_seq_bwd(C.byref(d), len(hs), _p(dout), ld_b, ld_t, scale, _parr(whh_t), _parr(hs), _parr(save), _parr(dgi),
+                                        _parr(dgh), _stream()))
+
+
 def mean_time(x, B, T, D):
     y = torch.empty(B, D, dtype=torch.float32, device=x.device)
     check(_lib.load().focal_mean_time(B, T, D, _p(x), _p(y), _stream()))

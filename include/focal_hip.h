@@ -187,6 +187,16 @@ int focal_gru_gate_fwd(const focal_gru_desc* d, int t, int dir_offset, const flo
 int focal_gru_gate_bwd(const focal_gru_desc* d, int t, int dir_offset, const float* dout, long ld_b, long ld_t, float scale,
                        const float* dh_rec, const float* dhz_in, const float* save, const float* h_prev, float* dgi, float* dgh,
                        float* dhz_out, void* stream);
+/* Whole-sequence form (bf16 W_hh; H in {128, 256}): ONE launch runs all T steps of one layer for n_dir (1 or 2) directions
+ * (direction 0 walks t = 0..T-1, direction 1 t = T-1..0 and writes out[..., H:2H]).  Per-direction HOST arrays of device
+ * pointers: gi [B*T, 3H] (b_ih included), whh bf16 [3H, H], bhh [3H], hs [T+1, B, H] (hs[0] = h0, written from hs[1]),
+ * save [T, 4, B, H] indexed by step s.  Backward: whh_t = bf16 [H, 3H] (the transposed W_hh), dgi [B*T, 3H], dgh [T, B, 3H]
+ * (step-indexed) are written for the weight / input gradient GEMMs; dout as in focal_gru_gate_bwd. */
+int focal_gru_seq_fwd(const focal_gru_desc* d, int n_dir, const float* const* gi, const void* const* whh, const float* const* bhh,
+                      float* const* hs, float* const* save, float* out, void* stream);
+int focal_gru_seq_bwd(const focal_gru_desc* d, int n_dir, const float* dout, long ld_b, long ld_t, float scale,
+                      const void* const* whh_t, const float* const* hs, const float* const* save, float* const* dgi,
+                      float* const* dgh, void* stream);
 int focal_mean_time(int B, int T, int D, const float* x, float* y, void* stream);                       /* y[b] = mean_t x[b][t] */
 int focal_dropout(long n, const float* x, float* y, const uint32_t* rng, uint32_t stream_id, float p, void* stream); /* y = x * mask */
 int focal_axpy(long n, float a, const float* x, float* y, void* stream);                                   /* y += a * x */

@@ -442,3 +442,56 @@ def test_masked_gradient_copy_matches_forward_mask(ops):
     dx4, dxm4 = torch.empty(M, Cin, device=DEV), torch.empty(M, Cin, device=DEV)
     ops.layernorm_bwd(dy4, x, st4, g4, dx4, False, torch.zeros_like(g4), torch.zeros_like(g4), gather=gather, dx_masked=dxm4, mask=dd)
     assert torch.equal(dxm4, dx4 * y)
+
+
+@pytest.mark.parametrize("B,H", [(40, 256), (16, 128)])
+def test_gru_whole_sequence_kernels_match_per_step_path(ops, B, H):
+    """focal_gru_seq_fwd / _bwd (one launch per layer, both directions, bf16 W_hh) against the per-step GEMM + gate kernels
+    given the same bf16 operands; B = 40 exercises the partial 16-sample tile."""
+    T = 10
+    f32c, bfc = ops.code(torch.float32), ops.code(torch.bfloat16)
+    gd = ops.GRUDesc(B, T, H)
+    gi = [rnd(B * T, 3 * H, seed=300 + d) for d in range(2)]
+    whh = [rnd(3 * H, H, scale=H ** -0.5, seed=310 + d) for d in range(2)]
+    bhh = [rnd(3 * H, scale=0.1, seed=320 + d) for d in range(2)]
+    w16 = [w.bfloat16() for w in whh]
+    d_hh = ops.linear_desc(bfc, B, 3 * H, H, f32c, f32c)
+    ref = dict(out=torch.zeros(B, T, 2 * H, device=DEV), hs=[], save=[])
+    for di in range(2):
+        hs = torch.zeros(T + 1, B, H, device=DEV)
+        save = torch.empty(T, 4, B, H, device=DEV)
+        gh = torch.empty(B, 3 * H, device=DEV)
+        for s in range(T):
+            t = s if di == 0 else T - 1 - s
+            ops.linear_fwd(d_hh, hs[s], w16[di], bhh[di], None, gh)
+            ops.gru_gate_fwd(gd, t, di * H, gi[di], gh, hs[s], hs[s + 1], ref["out"], save[s])
+        ref["hs"].append(hs)
+        ref["save"].append(save)
+    out = torch.zeros(B, T, 2 * H, device=DEV)
+    hs = [torch.zeros(T + 1, B, H, device=DEV) for _ in range(2)]
+    save = [torch.empty(T, 4, B, H, device=DEV) for _ in range(2)]
+    ops.gru_seq_fwd(gd, gi, w16, bhh, hs, save, out)
+    assert rel_err(out, ref["out"]) < 2e-3
+    for di in range(2):
+        assert rel_err(hs[di], ref["hs"][di]) < 2e-3 and rel_err(save[di], ref["save"][di]) < 2e-3
+    # backward from the SAME saved state: layer-0 style dout [B*T, 2H]
+    dout = rnd(B * T, 2 * H, seed=330)
+    ld_b, ld_t = T * 2 * H, 2 * H
+    got = [(torch.empty(B * T, 3 * H, device=DEV), torch.empty(T, B, 3 * H, device=DEV)) for _ in range(2)]
+    whh_t = [ops.permute_pack(w, 1, 3 * H, H, torch.bfloat16) for w in whh]
+    ops.gru_seq_bwd(gd, dout, ld_b, ld_t, 1.0, whh_t, ref["hs"], ref["save"], [g[0] for g in got], [g[1] for g in got])
+    for di in range(2):
+        dgi = torch.empty(B * T, 3 * H, device=DEV)
+        dgh = torch.empty(T, B, 3 * H, device=DEV)
+        dhz = torch.empty(2, B, H, device=DEV)
+        dh_rec = torch.empty(B, H, device=DEV)
+        have = False
+        for s in range(T - 1, -1, -1):
+            t = s if di == 0 else T - 1 - s
+            ops.gru_gate_bwd(gd, t, di * H, dout, ld_b, ld_t, 1.0, dh_rec if have else None, dhz[(s + 1) & 1] if have else None,
+                             ref["save"][di][s], ref["hs"][di][s], dgi, dgh[s], dhz[s & 1])
+            if s > 0:
+                ops.linear_bwd_data(d_hh, dgh[s], w16[di], None, dh_rec)
+                have = True
+        assert rel_err(got[di][0], dgi) < 5e-3, di
+        assert rel_err(got[di][1], dgh) < 5e-3, di
