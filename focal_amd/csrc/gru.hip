@@ -64,18 +64,35 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(focal_gru_desc d, int
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 gbf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 gbf16x4;
 typedef float gf32x4 __attribute__((ext_vector_type(4)));
+#ifndef GRU_NW
+#define GRU_NW 8
+#endif
 struct GruDirFwd { const float* gi; const bf16_t* whh; const float* bhh; float* hs; float* save; };
 struct GruFwdArgs { GruDirFwd d[2]; };
 struct GruDirBwd { const bf16_t* whh_t; const float* hs; const float* save; float* dgi; float* dgh; };
 struct GruBwdArgs { GruDirBwd d[2]; };
 
+// Gate nonlinearities for the whole-sequence kernels: raw v_rcp / v_exp (1 ulp) instead of the IEEE divide and libm tanh of
+// the per-step fp32-parity kernels -- with two waves per SIMD the libm forms were ~2 us of VALU per step.
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for every global store of the
+// step (hs / out / save, ~1-2 us of write latency) twice per step; nothing here communicates through global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 
-template <int H>
-__global__ __launch_bounds__(512) void gru_seq_fwd_kernel(focal_gru_desc gd, GruFwdArgs args, float* __restrict__ out) {
-  constexpr int QT = H / 128, PH = H + 8;  // 8 waves: wave w owns hidden units [w*H/8, (w+1)*H/8)
-  __shared__ __attribute__((aligned(16))) bf16_t hb[16 * PH];
+template <int H, int NW>
+__global__ __launch_bounds__(NW * 64) void gru_seq_fwd_kernel(focal_gru_desc gd, GruFwdArgs args, float* __restrict__ out) {
+  constexpr int QT = H / (16 * NW), PH = H + 8;  // NW waves: wave w owns hidden units [w*H/NW, (w+1)*H/NW)
+  // dynamic LDS: [n-gate W fragments: NW*QT*(H/32)*64 x 16 B][hb: 16 x PH bf16][bh: 3H f32]
+  extern __shared__ __attribute__((aligned(16))) unsigned char gru_lds[];
+  constexpr int KS = H / 32;
+  constexpr int XS = QT > 1 ? 1 : 0;  // trailing k-steps of the z gate that also live in LDS (register budget, see below)
+  gbf16x8* wl = reinterpret_cast<gbf16x8*>(gru_lds);
+  gbf16x8* wx = wl + NW * QT * KS * 64;
+  bf16_t* hb = reinterpret_cast<bf16_t*>(gru_lds + (size_t)NW * QT * (KS + XS) * 64 * 16);
+  float* bh = reinterpret_cast<float*>(hb + 16 * PH);
   const int dir = blockIdx.y;
   const GruDirFwd p = args.d[dir];
   const int B = gd.B, T = gd.T;
@@ -89,16 +106,40 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(focal_gru_desc gd, Gru
   for (int q = 0; q < QT; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) hprev[q][r] = 0.f;
-  // This wave's slice of W_hh (3 gates x 16*QT rows x H) is loaded ONCE and stays in registers for all T steps
-  // (H = 256: 48 fragments = 192 VGPRs): streaming it from L2 every step left the kernel latency-bound (17 us / step).
-  gbf16x8 wreg[3][QT][H / 32];
+  // This wave's slice of W_hh (3 gates x 16*QT rows x H) is loaded ONCE and stays on chip for all T steps: the r and z
+  // gates in registers (H = 256: 30 fragments = 120 VGPRs), the n gate and the z gate's last k-step in LDS in fragment
+  // order.  The split is set by the register budget: ONE spilled fragment costs an `s_waitcnt vmcnt(0)` per step, i.e. the
+  // acknowledgement of the previous step's 12 result stores (spill reloads are vector-memory loads): 7 us / step.
+  // Streaming W_hh from L2 every step instead left the kernel latency-bound at 17 us / step.
+  gbf16x8 wreg[2][QT][KS];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
     for (int q = 0; q < QT; ++q)
 #pragma unroll
-      for (int ks = 0; ks < H / 32; ++ks)
-        wreg[g][q][ks] = *reinterpret_cast<const gbf16x8*>(p.whh + (long)(g * H + jw + 16 * q + lm) * H + 32 * ks + 8 * lg);
+      for (int ks = 0; ks < KS; ++ks) {
+        const gbf16x8 w = *reinterpret_cast<const gbf16x8*>(p.whh + (long)(g * H + jw + 16 * q + lm) * H + 32 * ks + 8 * lg);
+        if (g == 2) wl[((wave * QT + q) * KS + ks) * 64 + lane] = w;
+        else if (g == 1 && ks >= KS - XS) wx[((wave * QT + q) * XS + ks - (KS - XS)) * 64 + lane] = w;
+        else wreg[g][q][ks] = w;
+      }
+  // Vector-memory results return in issue order, loads and stores alike: a load issued AFTER a step's 12 result stores cannot
+  // be consumed before those stores are acknowledged (microseconds).  So the input projections of step s+1 are requested
+  // BEFORE the stores of step s, and b_hh sits in LDS (ds_read does not queue behind vector memory).
+  for (int i = threadIdx.x; i < 3 * H; i += NW * 64) bh[i] = p.bhh[i];
+  float4 gr4[QT], gz4[QT], gn4[QT];
+  auto fetch_gi = [&](int s_) {
+    const int t_ = dir ? T - 1 - s_ : s_;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      const float* gir = p.gi + ((long)b * T + t_) * 3 * H + jw + 16 * q + 4 * lg;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool go = ok && s_ < T;
+      gr4[q] = go ? ld4(gir) : z4; gz4[q] = go ? ld4(gir + H) : z4; gn4[q] = go ? ld4(gir + 2 * H) : z4;
+    }
+  };
+  fetch_gi(0);
+  lds_barrier();
   for (int s = 0; s < T; ++s) {
     const int t = dir ? T - 1 - s : s;
     gf32x4 acc[3][QT];
@@ -111,40 +152,44 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(focal_gru_desc gd, Gru
       for (int ks = 0; ks < H / 32; ++ks) {
         const gbf16x8 hf = *reinterpret_cast<const gbf16x8*>(hb + lm * PH + 32 * ks + 8 * lg);
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int q = 0; q < QT; ++q) acc[g][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[g][q][ks], hf, acc[g][q], 0, 0, 0);
+        for (int q = 0; q < QT; ++q) {
+          acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[0][q][ks], hf, acc[0][q], 0, 0, 0);
+          acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ks >= KS - XS ? wx[((wave * QT + q) * XS + (ks >= KS - XS ? ks - (KS - XS) : 0)) * 64 + lane] : wreg[1][q][ks], hf, acc[1][q], 0, 0, 0);
+          acc[2][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[((wave * QT + q) * KS + ks) * 64 + lane], hf, acc[2][q], 0, 0, 0);
+        }
       }
     }
-    float hnew[QT][4];
+    float hnew[QT][4], rr[QT][4], zz[QT][4], nn[QT][4], gh[QT][4];
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
       const int j0 = jw + 16 * q + 4 * lg;
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float* gir = p.gi + ((long)b * T + t) * 3 * H + j0;
-      const float4 gr = ok ? ld4(gir) : z4, gz = ok ? ld4(gir + H) : z4, gn = ok ? ld4(gir + 2 * H) : z4;
-      const float4 br = ld4(p.bhh + j0), bz = ld4(p.bhh + H + j0), bn = ld4(p.bhh + 2 * H + j0);
+      const float4 gr = gr4[q], gz = gz4[q], gn = gn4[q];
+      const float4 br = ld4(bh + j0), bz = ld4(bh + H + j0), bn = ld4(bh + 2 * H + j0);
       const float gra[4] = {gr.x, gr.y, gr.z, gr.w}, gza[4] = {gz.x, gz.y, gz.z, gz.w}, gna[4] = {gn.x, gn.y, gn.z, gn.w};
       const float bra[4] = {br.x, br.y, br.z, br.w}, bza[4] = {bz.x, bz.y, bz.z, bz.w}, bna[4] = {bn.x, bn.y, bn.z, bn.w};
-      float rr[4], zz[4], nn[4], gh[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        rr[r] = sigmoid_f(gra[r] + acc[0][q][r] + bra[r]);
-        zz[r] = sigmoid_f(gza[r] + acc[1][q][r] + bza[r]);
-        gh[r] = acc[2][q][r] + bna[r];
-        nn[r] = tanhf(gna[r] + rr[r] * gh[r]);
-        hnew[q][r] = (1.f - zz[r]) * nn[r] + zz[r] * hprev[q][r];
+        rr[q][r] = sigmoid_fast(gra[r] + acc[0][q][r] + bra[r]);
+        zz[q][r] = sigmoid_fast(gza[r] + acc[1][q][r] + bza[r]);
+        gh[q][r] = acc[2][q][r] + bna[r];
+        nn[q][r] = tanh_fast(gna[r] + rr[q][r] * gh[q][r]);
+        hnew[q][r] = (1.f - zz[q][r]) * nn[q][r] + zz[q][r] * hprev[q][r];
         hprev[q][r] = hnew[q][r];
       }
-      if (ok) {
+    }
+    fetch_gi(s + 1);
+    if (ok) {
+#pragma unroll
+      for (int q = 0; q < QT; ++q) {
+        const int j0 = jw + 16 * q + 4 * lg;
         const long e = (long)b * H + j0;
         st4(p.hs + (long)(s + 1) * n + e, hnew[q]);
         st4(out + ((long)b * T + t) * 2 * H + dir * H + j0, hnew[q]);
         float* sv = p.save + (long)s * 4 * n + e;
-        st4(sv, rr); st4(sv + n, zz); st4(sv + 2 * n, nn); st4(sv + 3 * n, gh);
+        st4(sv, rr[q]); st4(sv + n, zz[q]); st4(sv + 2 * n, nn[q]); st4(sv + 3 * n, gh[q]);
       }
     }
-    __syncthreads();  // every wave has read this step's h fragments
+    lds_barrier();  // every wave has read this step's h fragments
 #pragma unroll
     for (int q = 0; q < QT; ++q) {
       gbf16x4 v;
@@ -152,15 +197,18 @@ __global__ __launch_bounds__(512) void gru_seq_fwd_kernel(focal_gru_desc gd, Gru
       for (int r = 0; r < 4; ++r) v[r] = (__bf16)(ok ? hnew[q][r] : 0.f);
       *reinterpret_cast<gbf16x4*>(hb + lm * PH + jw + 16 * q + 4 * lg) = v;
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
-template <int H>
-__global__ __launch_bounds__(512) void gru_seq_bwd_kernel(focal_gru_desc gd, GruBwdArgs args, const float* __restrict__ dout, long ld_b,
-                                                          long ld_t, float scale) {
-  constexpr int QT = H / 128, PG = 3 * H + 8;
-  __shared__ __attribute__((aligned(16))) bf16_t gb[16 * PG];
+template <int H, int NW>
+__global__ __launch_bounds__(NW * 64) void gru_seq_bwd_kernel(focal_gru_desc gd, GruBwdArgs args, const float* __restrict__ dout, long ld_b,
+                                                              long ld_t, float scale) {
+  constexpr int QT = H / (16 * NW), PG = 3 * H + 8;
+  constexpr int KS = 3 * H / 32, KR = 2 * KS / 3;  // k-steps of the product; the first KR live in registers, the rest in LDS
+  extern __shared__ __attribute__((aligned(16))) unsigned char gru_lds[];
+  gbf16x8* wl = reinterpret_cast<gbf16x8*>(gru_lds);
+  bf16_t* gb = reinterpret_cast<bf16_t*>(gru_lds + (size_t)NW * QT * (KS - KR) * 64 * 16);
   const int dir = blockIdx.y;
   const GruDirBwd p = args.d[dir];
   const int B = gd.B, T = gd.T;
@@ -174,12 +222,15 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(focal_gru_desc gd, Gru
   for (int q = 0; q < QT; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) dhz[q][r] = dhrec[q][r] = 0.f;
-  gbf16x8 wreg[QT][3 * H / 32];  // this wave's rows of W_hh^T, resident for all steps
+  gbf16x8 wreg[QT][KR];  // this wave's rows of W_hh^T, resident for all steps (registers + LDS, as in the forward kernel)
 #pragma unroll
   for (int q = 0; q < QT; ++q)
 #pragma unroll
-    for (int ks = 0; ks < 3 * H / 32; ++ks)
-      wreg[q][ks] = *reinterpret_cast<const gbf16x8*>(p.whh_t + (long)(jw + 16 * q + lm) * 3 * H + 32 * ks + 8 * lg);
+    for (int ks = 0; ks < KS; ++ks) {
+      const gbf16x8 w = *reinterpret_cast<const gbf16x8*>(p.whh_t + (long)(jw + 16 * q + lm) * 3 * H + 32 * ks + 8 * lg);
+      if (ks < KR) wreg[q][ks] = w;
+      else wl[((wave * QT + q) * (KS - KR) + ks - KR) * 64 + lane] = w;
+    }
   for (int s = T - 1; s >= 0; --s) {
     const int t = dir ? T - 1 - s : s;
 #pragma unroll
@@ -218,21 +269,24 @@ __global__ __launch_bounds__(512) void gru_seq_bwd_kernel(focal_gru_desc gd, Gru
       *reinterpret_cast<gbf16x4*>(row + 2 * H) = v2;
     }
     if (s > 0) {  // dh_{s-1} += dgh_s . W_hh  (through the [H][3H] transposed copy: 16 contiguous bytes per lane again)
-      __syncthreads();
+      lds_barrier();
       gf32x4 acc[QT];
 #pragma unroll
       for (int q = 0; q < QT; ++q) acc[q] = gf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 3 * H / 32; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const gbf16x8 gf = *reinterpret_cast<const gbf16x8*>(gb + lm * PG + 32 * ks + 8 * lg);
 #pragma unroll
-        for (int q = 0; q < QT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[q][ks], gf, acc[q], 0, 0, 0);
+        for (int q = 0; q < QT; ++q) {
+          const gbf16x8 w = ks < KR ? wreg[q][ks < KR ? ks : 0] : wl[((wave * QT + q) * (KS - KR) + (ks < KR ? 0 : ks - KR)) * 64 + lane];
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, gf, acc[q], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int q = 0; q < QT; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dhrec[q][r] = acc[q][r];
-      __syncthreads();
+      lds_barrier();
     }
   }
 }
@@ -313,8 +367,17 @@ extern "C" int focal_gru_seq_fwd(const focal_gru_desc* d, int n_dir, const float
     a.d[i] = GruDirFwd{gi[i], (const bf16_t*)whh[i], bhh[i], hs[i], save[i]};
   }
   const dim3 grid(ceil_div(d->B, 16), n_dir);
-  if (d->H == 256) hipLaunchKernelGGL((gru_seq_fwd_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, *d, a, out);
-  else hipLaunchKernelGGL((gru_seq_fwd_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, *d, a, out);
+  const int H = d->H;
+  const size_t lds = (size_t)(H / 16) * (H / 32 + (H > 128 ? 1 : 0)) * 64 * 16 + (size_t)16 * (H + 8) * 2 + (size_t)3 * H * 4;
+  static bool granted = false;
+  if (!granted) {  // up to 143 KB of the CU's 160 KB: above the default dynamic-LDS grant
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_kernel<256, GRU_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_kernel<128, GRU_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { focal_set_error("gru_seq_fwd: cannot reserve LDS: %s", hipGetErrorString(e)); return FOCAL_EHIP; }
+    granted = true;
+  }
+  if (H == 256) hipLaunchKernelGGL((gru_seq_fwd_kernel<256, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, out);
+  else hipLaunchKernelGGL((gru_seq_fwd_kernel<128, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, out);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -335,8 +398,17 @@ extern "C" int focal_gru_seq_bwd(const focal_gru_desc* d, int n_dir, const float
     a.d[i] = GruDirBwd{(const bf16_t*)whh_t[i], hs[i], save[i], dgi[i], dgh[i]};
   }
   const dim3 grid(ceil_div(d->B, 16), n_dir);
-  if (d->H == 256) hipLaunchKernelGGL((gru_seq_bwd_kernel<256>), grid, dim3(512), 0, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
-  else hipLaunchKernelGGL((gru_seq_bwd_kernel<128>), grid, dim3(512), 0, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
+  const int H = d->H;
+  const size_t lds = (size_t)(H / 16) * (H / 32) * 64 * 16 + (size_t)16 * (3 * H + 8) * 2;
+  static bool granted = false;
+  if (!granted) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_bwd_kernel<256, GRU_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_bwd_kernel<128, GRU_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { focal_set_error("gru_seq_bwd: cannot reserve LDS: %s", hipGetErrorString(e)); return FOCAL_EHIP; }
+    granted = true;
+  }
+  if (H == 256) hipLaunchKernelGGL((gru_seq_bwd_kernel<256, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
+  else hipLaunchKernelGGL((gru_seq_bwd_kernel<128, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -114,3 +114,19 @@ if not ONLY or ONLY == "fft":
         xt = rnd(*shape)
         n_el = xt.numel()
         report(f"fft_realpack {nm} {list(shape)}", timeit(lambda: ops.fft_realpack(xt)), n_el * 4 * 3)
+
+if ONLY == "gru":
+    Bq, T, H = int(os.environ.get("FOCAL_MB_GRU_B", "256")), int(os.environ.get("FOCAL_MB_GRU_T", "10")), 256
+    gd = ops.GRUDesc(Bq, T, H)
+    gi = [rnd(Bq * T, 3 * H) for _ in range(2)]
+    w16 = [rnd(3 * H, H, dtype=torch.bfloat16) * 0.06 for _ in range(2)]
+    bh = [rnd(3 * H) * 0.1 for _ in range(2)]
+    hs = [torch.zeros(T + 1, Bq, H, device=DEV) for _ in range(2)]
+    sv = [torch.empty(T, 4, Bq, H, device=DEV) for _ in range(2)]
+    out = torch.empty(Bq, T, 2 * H, device=DEV)
+    report("gru_seq_fwd B=256 T=10 H=256 x2 dirs", timeit(lambda: ops.gru_seq_fwd(gd, gi, w16, bh, hs, sv, out)), 0)
+    wt = [rnd(H, 3 * H, dtype=torch.bfloat16) * 0.06 for _ in range(2)]
+    dout = rnd(Bq * T, 2 * H)
+    dgi = [torch.empty(Bq * T, 3 * H, device=DEV) for _ in range(2)]
+    dgh = [torch.empty(T, Bq, 3 * H, device=DEV) for _ in range(2)]
+    report("gru_seq_bwd B=256 T=10 H=256 x2 dirs", timeit(lambda: ops.gru_seq_bwd(gd, dout, T * 2 * H, 2 * H, 1.0, wt, hs, sv, dgi, dgh)), 0)
