@@ -4,6 +4,7 @@
 //   * inter-convs / flatten+1x1: MFMA GEMMs whose A (or, for dW, B) operand is a sliding window over tokens
 //               (PRO_CONV in gemm.hpp) -- a [1,k] "same" conv over channel-last rows is a GEMM with lda = C_in < K;
 //   * the small weight re-layouts between the reference's [Cout][Cin][1][k] storage and the GEMM operand orders.
+#include <stdlib.h>
 #include "gemm.hpp"
 
 #define CIN_TOK 64
@@ -115,6 +116,126 @@ __global__ __launch_bounds__(256) void conv_in_bwd_weight_kernel(const float* __
   }
 }
 
+// ---- matrix-core forms for the patchifying case (stride == k, no padding, S_in == S_out * k: the audio in-conv, K = 160).
+// The VALU kernels above spend most of their time in per-element index arithmetic (98 / 127 us against a 10 us traffic
+// bound); here a 64-token tile of patches is staged in LDS with 16-byte loads (a token's taps are contiguous per input
+// channel) and the contraction runs on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), so the layer stays fp32 end to end.
+typedef float cf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cf4 cmfma(float a, float b, cf4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int K, int KP>
+__device__ __forceinline__ void conv_in_stage_patches(const float* __restrict__ x, float* patch, const focal_conv_in_desc& d, int t0,
+                                                      int total, int tid) {
+  constexpr int UPT = K / 4;  // float4 units per token
+  for (int u = tid; u < CIN_TOK * UPT; u += 256) {
+    const int t = u / UPT, kq = u - t * UPT, tok = t0 + t;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tok < total) {
+      const int so = tok % d.S_out, r = tok / d.S_out, ii = r % d.I, b = r / d.I;
+      const int kk = 4 * kq, c = kk / d.k, tt = kk - c * d.k;
+      v = *reinterpret_cast<const float4*>(x + (((long)b * d.cin + c) * d.I + ii) * d.S_in + so * d.k + tt);
+    }
+    *reinterpret_cast<float4*>(patch + t * KP + 4 * kq) = v;
+  }
+}
+
+// z[tok][n] = bias[n] + sum_kk patch[tok][kk] * w[n][kk].  Wave w owns tokens 16w..16w+15 of the tile and all 64 channels;
+// the filter bank lives in registers as MFMA fragments (K = 160: 160 VGPRs) for the whole (grid-strided) kernel.
+template <int K>
+__global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ z,
+                                                               focal_conv_in_desc d, int total) {
+  constexpr int KP = K + 4, KS = K / 4;
+  __shared__ __attribute__((aligned(16))) float patch[CIN_TOK * KP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
+  float wf[4][KS];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[nt][ks] = w[(16 * nt + lm) * K + 4 * ks + lg];
+  float4 bv[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bias + 16 * nt + 4 * lg);
+  for (int t0 = blockIdx.x * CIN_TOK; t0 < total; t0 += gridDim.x * CIN_TOK) {
+    __syncthreads();
+    conv_in_stage_patches<K, KP>(x, patch, d, t0, total, tid);
+    __syncthreads();
+    cf4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = cf4{bv[nt].x, bv[nt].y, bv[nt].z, bv[nt].w};
+    const float* pr = patch + (16 * wave + lm) * KP + lg;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float pf = pr[4 * ks];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = cmfma(wf[nt][ks], pf, acc[nt]);
+    }
+    const int tok = t0 + 16 * wave + lm;
+    if (tok < total) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        *reinterpret_cast<float4*>(z + (long)tok * 64 + 16 * nt + 4 * lg) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+    }
+  }
+}
+
+// dw[n][kk] += sum_tok dz[tok][n] * patch[tok][kk], dbias[n] += sum_tok dz[tok][n].  40 output tiles (4 x 10 of 16 x 16), ten per
+// wave, accumulated in registers over this workgroup's chunks; they leave through an LDS copy of the [64][K] block so that every
+// atomic wave-instruction covers 256 contiguous bytes.
+template <typename TZ, int K>
+__global__ __launch_bounds__(256) void conv_in_bwd_weight_mfma_kernel(const float* __restrict__ x, const TZ* __restrict__ dz,
+                                                                      float* __restrict__ dw, float* __restrict__ dbias,
+                                                                      focal_conv_in_desc d, int total, int chunks_per_wg) {
+  constexpr int KP = K + 16, GP = 80, NKT = K / 16, TPW = 4 * NKT / 4;  // tiles per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;             // [CIN_TOK][KP]   (reused as the [64][K] staging block at the end)
+  float* g = smem + CIN_TOK * KP;  // [CIN_TOK][GP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
+  cf4 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) acc[i] = cf4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int ch = 0; ch < chunks_per_wg; ++ch) {
+    const int t0 = (blockIdx.x * chunks_per_wg + ch) * CIN_TOK;
+    if (t0 >= total) break;
+    __syncthreads();
+    conv_in_stage_patches<K, KP>(x, patch, d, t0, total, tid);
+    for (int i = tid; i < CIN_TOK * 16; i += 256) {  // 16 float4 per token row
+      const int t = i >> 4, c4 = (i & 15) * 4, tok = t0 + t;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (tok < total) loadN<4>(dz + (long)tok * 64 + c4, v);
+      *reinterpret_cast<float4*>(g + t * GP + c4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      for (int t = 0; t < CIN_TOK; ++t) bsum += g[t * GP + tid];
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int tile = wave + 4 * i, mt = tile / NKT, kt = tile - mt * NKT;
+      const float* ga = g + lg * GP + 16 * mt + lm;
+      const float* pb = patch + lg * KP + 16 * kt + lm;
+#pragma unroll
+      for (int ks = 0; ks < CIN_TOK / 4; ++ks) acc[i] = cmfma(ga[4 * ks * GP], pb[4 * ks * KP], acc[i]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int tile = wave + 4 * i, mt = tile / NKT, kt = tile - mt * NKT;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) patch[(16 * mt + 4 * lg + r) * K + 16 * kt + lm] = acc[i][r];
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * K; i += 256) atomicAdd(dw + i, patch[i]);
+  if (tid < 64 && dbias) atomicAdd(dbias + tid, bsum);
+}
+
+static bool conv_in_is_patchify(const focal_conv_in_desc* d) {
+  return d->stride == d->k && d->pad_left == 0 && d->S_in == d->S_out * d->k && d->k % 4 == 0 && d->cin * d->k == 160 && d->C == 64 &&
+         !getenv("FOCAL_CONV_IN_VALU");
+}
+
 static int conv_in_check(const focal_conv_in_desc* d) {
   FOCAL_CHECK_ARG(d != nullptr, "conv_in: null descriptor");
   FOCAL_CHECK_ARG(d->C == 64, "conv_in: %d output channels unsupported (64 only)", d->C);
@@ -127,6 +248,13 @@ extern "C" int focal_conv_in_fwd(const focal_conv_in_desc* d, const float* x, co
   if (int rc = conv_in_check(d)) return rc;
   FOCAL_CHECK_ARG(x && w && bias && z, "conv_in_fwd: null tensor");
   const int K = d->cin * d->k, total = d->B * d->I * d->S_out;
+  if (conv_in_is_patchify(d)) {
+    int blocks = ceil_div(total, CIN_TOK);
+    if (blocks > 768) blocks = 768;
+    hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<160>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, z, *d, total);
+    FOCAL_LAUNCH_CHECK();
+    return FOCAL_OK;
+  }
   const size_t sm = ((size_t)K * d->C + (size_t)CIN_TOK * (K + 1)) * sizeof(float);
   int blocks = ceil_div(total, CIN_TOK);
   if (blocks > 2048) blocks = 2048;
@@ -140,6 +268,20 @@ extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float
   if (int rc = conv_in_check(d)) return rc;
   FOCAL_CHECK_ARG(x && dz && dw, "conv_in_bwd_weight: null tensor");
   const int K = d->cin * d->k, total = d->B * d->I * d->S_out;
+  if (conv_in_is_patchify(d)) {
+    const int chunks = ceil_div(total, CIN_TOK);
+    int cpw = ceil_div(chunks, 256);
+    if (cpw < 1) cpw = 1;
+    const int blocks = ceil_div(chunks, cpw);
+    const size_t smm = ((size_t)CIN_TOK * (160 + 16) + (size_t)CIN_TOK * 80) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dz_dtype == FOCAL_F32)
+      hipLaunchKernelGGL((conv_in_bwd_weight_mfma_kernel<float, 160>), dim3(blocks), dim3(256), smm, st, x, (const float*)dz, dw, dbias, *d, total, cpw);
+    else
+      hipLaunchKernelGGL((conv_in_bwd_weight_mfma_kernel<bf16_t, 160>), dim3(blocks), dim3(256), smm, st, x, (const bf16_t*)dz, dw, dbias, *d, total, cpw);
+    FOCAL_LAUNCH_CHECK();
+    return FOCAL_OK;
+  }
   FOCAL_CHECK_ARG(K + d->C <= 256, "conv_in_bwd_weight: cin*k + C must be <= 256");
   const size_t sm = ((size_t)CIN_TOK * (K + 1) + (size_t)CIN_TOK * (d->C + 4)) * sizeof(float);
   const int chunks = ceil_div(total, CIN_TOK);
