@@ -136,28 +136,47 @@ class Step:
         self.seg_c()
 
     def capture(self, stream):
-        """hipGraphs of the three segments (one shared memory pool); returns the replay callable.  On one rank the
-        collectives are no-ops and the three graphs replay back to back."""
+        """Returns the replay callable: one hipGraph of the whole step on one rank; with N > 1 ranks, hipGraphs of the three
+        segments (one shared memory pool) with the two collectives issued eagerly between their replays.
+
+        Everything is captured TWICE into the same graph-private pool and the second set is the one replayed: the first capture
+        grows the pool segment by segment, the second sub-allocates the same tensors from the segments that now exist, and
+        that placement replays 2.5 % faster (8.29 -> 8.08 ms, reproducible; the first set is kept alive so its blocks stay put)."""
         self.opt.sync_lr()
-        ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, stream=stream):
-            self.seg_a()
-        self.exchange()  # eager, autograd-aware: links segment B's backward to segment A's forward
-        with torch.cuda.graph(gb, pool=ga.pool(), stream=stream):
-            self.seg_b()
-        self.reduce()
-        with torch.cuda.graph(gc, pool=ga.pool(), stream=stream):
-            self.seg_c()
         multi = self.dist.is_dist()
-        packed = self.packed if multi else None
+        pool, self._warm_graphs = None, []
+        for attempt in range(2):
+            if not multi:
+                # one rank: no collectives to interleave -> one graph for the whole step (each extra graph launch costs
+                # ~0.1 ms of idle GPU per step)
+                whole = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(whole, pool=pool, stream=stream):
+                    self.run()
+                graphs = (whole,)
+            else:
+                ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, pool=pool, stream=stream):
+                    self.seg_a()
+                self.exchange()  # eager, autograd-aware: links segment B's backward to segment A's forward
+                with torch.cuda.graph(gb, pool=ga.pool(), stream=stream):
+                    self.seg_b()
+                self.reduce()
+                with torch.cuda.graph(gc, pool=ga.pool(), stream=stream):
+                    self.seg_c()
+                graphs = (ga, gb, gc)
+            pool = graphs[0].pool()
+            if attempt == 0:
+                self._warm_graphs = graphs
+        if not multi:
+            return graphs[0].replay
+        ga, gb, gc = graphs
+        packed = self.packed
 
         def replay():
             ga.replay()
-            if multi:
-                self.dist.replay_exchange(packed)
+            self.dist.replay_exchange(packed)
             gb.replay()
-            if multi:
-                self.opt.reduce_gradients()
+            self.opt.reduce_gradients()
             gc.replay()
         return replay
 
@@ -320,9 +339,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        lag = os.environ.get("FOCAL_BENCH_LAGGED_LOSS") == "1"  # diagnostic: read step k-1's loss after launching step k
+        prev = None
         for _ in range(a.steps):
             run()
-            step.loss.item()  # the reference syncs on loss.item() every step (pretrain.py:74)
+            if lag:
+                if prev is not None:
+                    prev.item()
+                prev = step.loss.clone()
+            else:
+                step.loss.item()  # the reference syncs on loss.item() every step (pretrain.py:74)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
