@@ -145,7 +145,7 @@ class Step:
         self.opt.sync_lr()
         multi = self.dist.is_dist()
         pool, self._warm_graphs = None, []
-        for attempt in range(2):
+        for attempt in range(1 if os.environ.get("FOCAL_BENCH_SINGLE_CAPTURE") == "1" else 2):
             if not multi:
                 # one rank: no collectives to interleave -> one graph for the whole step (each extra graph launch costs
                 # ~0.1 ms of idle GPU per step)

@@ -43,7 +43,7 @@ _SIDE = {}
 
 def side_stream(device, index):
     """index 0 = the caller's current stream; index >= 1 = a dedicated side stream of this device."""
-    if index == 0:
+    if index == 0 or os.environ.get("FOCAL_NO_STREAMS") == "1":
         return torch.cuda.current_stream(device)
     key = (torch.device(device), index)
     if key not in _SIDE:
