@@ -8,10 +8,11 @@
 
 // Per-channel partial sums -> global: lanes that hold the same channels are folded with xor-shuffles, each wave parks one
 // [2][C] row in LDS (plain stores: LDS float atomics serialise per lane), the 4 waves are summed and every channel leaves
-// as one atomic per workgroup.  `red` is [4][2][C] floats; a[k] belongs to channel c + k of the first half, b[k] of the second.
+// as one atomic per workgroup (16-wave workgroups, at most one per CU: the atomics onto one address are a serial chain).
+// `red` is [waves][2][C] floats; a[k] belongs to channel c + k of the first half, b[k] of the second.
 __device__ __forceinline__ void bn_commit_sums(float* red, float* __restrict__ sums, float (&a)[4], float (&b)[4], int C, int c) {
-  const int lpr = C / 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 8 * C; i += 256) red[i] = 0.f;
+  const int lpr = C / 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < nw * 2 * C; i += blockDim.x) red[i] = 0.f;
   for (int o = lpr; o < 64; o <<= 1) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { a[k] += __shfl_xor(a[k], o, 64); b[k] += __shfl_xor(b[k], o, 64); }
@@ -23,18 +24,33 @@ __device__ __forceinline__ void bn_commit_sums(float* red, float* __restrict__ s
     *reinterpret_cast<float4*>(row + C + c) = make_float4(b[0], b[1], b[2], b[3]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256)
-    atomicAdd(sums + i, red[i] + red[2 * C + i] + red[4 * C + i] + red[6 * C + i]);
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += red[w * 2 * C + i];
+    atomicAdd(sums + i, t);
+  }
 }
 
 // sums[0..C) = sum z, sums[C..2C) = sum z^2   (sums must be zeroed by the caller-side launcher)
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ z, float* __restrict__ sums, long rows, int C) {
+__global__ __launch_bounds__(1024) void bn_partial_kernel(const float* __restrict__ z, float* __restrict__ sums, long rows, int C) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][C]
   const int lpr = C / 4;                 // lanes per row
-  const int rpb = 256 / lpr;             // rows per block-iteration
+  const int rpb = blockDim.x / lpr;      // rows per block-iteration
   const int li = threadIdx.x % lpr, sub = threadIdx.x / lpr;
   float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
-  for (long r = (long)blockIdx.x * rpb + sub; r < rows; r += (long)gridDim.x * rpb) {
+  const long step = (long)gridDim.x * rpb;
+  long r = (long)blockIdx.x * rpb + sub;
+  for (; r + 3 * step < rows; r += 4 * step) {  // four independent 16-byte loads in flight per lane
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(z + (r + u * step) * C + li * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+      q.x += v[u].x * v[u].x; q.y += v[u].y * v[u].y; q.z += v[u].z * v[u].z; q.w += v[u].w * v[u].w;
+    }
+  }
+  for (; r < rows; r += step) {
     const float4 v = *reinterpret_cast<const float4*>(z + r * C + li * 4);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
@@ -76,15 +92,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   const DropCtx dc = make_drop(rng, stream, p);
   const bool drop_on = p > 0.f;
   const long n4 = rows * C / 4;
+  const int cshift = (C & (C - 1)) == 0 ? __builtin_ctz(C) : -1;  // power-of-two channel count: shift / mask, no 64-bit division
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
-    const long r = (e * 4) / C;
-    const int c = (int)((e * 4) % C);
+    const long r = cshift >= 0 ? (e * 4) >> cshift : (e * 4) / C;
+    const int c = cshift >= 0 ? (int)((e * 4) & (C - 1)) : (int)((e * 4) % C);
     const float4 v = reinterpret_cast<const float4*>(z)[e];
     const float4 mu = *reinterpret_cast<const float4*>(mean_rstd + c), rs = *reinterpret_cast<const float4*>(mean_rstd + C + c);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
     float o[4] = {(v.x - mu.x) * rs.x * ga.x + be.x, (v.y - mu.y) * rs.y * ga.y + be.y, (v.z - mu.z) * rs.z * ga.z + be.z,
                   (v.w - mu.w) * rs.w * ga.w + be.w};
-    const uint32_t sample = (uint32_t)(r / rows_per_sample);
+    const uint32_t sample = drop_on ? ((uint32_t)r / (uint32_t)rows_per_sample) : 0u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       o[k] = gelu_f(o[k]);
@@ -120,20 +137,20 @@ __device__ __forceinline__ void bn_da4(const float4 v, const float4 g, const flo
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ g,
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __restrict__ z, const float* __restrict__ g,
                                                             const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ sums, long rows, int C,
                                                             int rows_per_sample, const uint32_t* rng, uint32_t stream, float p) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][C]
   const DropCtx dc = make_drop(rng, stream, p);
   const bool drop_on = p > 0.f;
-  const int lpr = C / 4, rpb = 256 / lpr;
+  const int lpr = C / 4, rpb = blockDim.x / lpr;
   const int li = threadIdx.x % lpr, sub = threadIdx.x / lpr, c = li * 4;
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   for (long r = (long)blockIdx.x * rpb + sub; r < rows; r += (long)gridDim.x * rpb) {
     float da[4], zh[4];
     bn_da4(*reinterpret_cast<const float4*>(z + r * C + c), *reinterpret_cast<const float4*>(g + r * C + c), mean_rstd, gamma, beta, c, C,
-           dc, drop_on, (uint32_t)(r / rows_per_sample), da, zh);
+           dc, drop_on, drop_on ? ((uint32_t)r / (uint32_t)rows_per_sample) : 0u, da, zh);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s1[k] += da[k]; s2[k] += da[k] * zh[k]; }
   }
@@ -159,12 +176,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int i = threadIdx.x; i < C; i += 256) { dbeta[i] += sums[i]; dgamma[i] += sums[C + i]; }
   }
   const long n4 = rows * C / 4;
+  const int cshift = (C & (C - 1)) == 0 ? __builtin_ctz(C) : -1;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
-    const long r = (e * 4) / C;
-    const int c = (int)((e * 4) % C);
+    const long r = cshift >= 0 ? (e * 4) >> cshift : (e * 4) / C;
+    const int c = cshift >= 0 ? (int)((e * 4) & (C - 1)) : (int)((e * 4) % C);
     float da[4], zh[4], o[4];
     bn_da4(reinterpret_cast<const float4*>(z)[e], reinterpret_cast<const float4*>(g)[e], mean_rstd, gamma, beta, c, C, dc, drop_on,
-           (uint32_t)(r / rows_per_sample), da, zh);
+           drop_on ? ((uint32_t)r / (uint32_t)rows_per_sample) : 0u, da, zh);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       o[k] = gamma[c + k] * mean_rstd[C + c + k] * (da[k] - sums[c + k] * inv_n - zh[k] * sums[C + c + k] * inv_n);
@@ -205,9 +223,9 @@ extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scr
   if (training != FOCAL_BN_FINALIZE) {
     FOCAL_CHECK_ARG(z, "bn_stats: null tensor");
     (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
-    int blocks = stream_blocks(d->rows, C);
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(256), 8 * C * sizeof(float), st, z, scratch, (long)d->rows, C);
+    int blocks = ceil_div((long)d->rows * C / 4, 1024 * 2);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(1024), 32 * C * sizeof(float), st, z, scratch, (long)d->rows, C);
   }
   if (training != FOCAL_BN_PARTIAL) {
     FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
@@ -244,9 +262,9 @@ extern "C" int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const fl
   const int C = d->C;
   if (phase != FOCAL_BN_FINALIZE) {
     (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
-    int rb = stream_blocks(d->rows, C);
-    if (rb > 512) rb = 512;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(256), 8 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
+    int rb = ceil_div((long)d->rows * C / 4, 1024 * 2);
+    if (rb > 256) rb = 256;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(1024), 32 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
                        (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
   }
   if (phase == FOCAL_BN_PARTIAL) {  // the parameter gradients are the LOCAL sums (the gradient all-reduce adds the other ranks')
