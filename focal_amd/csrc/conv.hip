@@ -116,6 +116,57 @@ __global__ __launch_bounds__(256) void conv_in_bwd_weight_kernel(const float* __
   }
 }
 
+// Small filters (K = cin * k <= 16, the seismic [1,3] in-conv: K = 6): the kernel above would keep K of its 256 threads busy.
+// Here thread (n = tid & 63, kg = tid >> 6) owns dw[n][kg], dw[n][kg + 4], ...; same staging, same contiguous atomics.
+template <typename TZ, int C0>
+__global__ __launch_bounds__(256) void conv_in_bwd_weight_smallk_kernel(const float* __restrict__ x, const TZ* __restrict__ dz,
+                                                                        float* __restrict__ dw, float* __restrict__ dbias,
+                                                                        focal_conv_in_desc d, int K, int total, int chunks_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int KP = K + 1, GP = C0 + 4;
+  float* patch = smem;              // [CIN_TOK][KP]
+  float* g = smem + CIN_TOK * KP;   // [CIN_TOK][GP]
+  const int tid = threadIdx.x, n = tid & (C0 - 1), kg = tid / C0;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int ch = 0; ch < chunks_per_wg; ++ch) {
+    const int t0 = (blockIdx.x * chunks_per_wg + ch) * CIN_TOK;
+    if (t0 >= total) break;
+    __syncthreads();
+    for (int i = tid; i < CIN_TOK * K; i += 256) {
+      const int t = i / K, kk = i - t * K, tok = t0 + t;
+      float v = 0.f;
+      if (tok < total) {
+        const int so = tok % d.S_out, r = tok / d.S_out, ii = r % d.I, b = r / d.I;
+        const int c = kk / d.k, tt = kk - c * d.k;
+        const int col = so * d.stride + tt - d.pad_left;
+        if (col >= 0 && col < d.S_in) v = x[(((long)b * d.cin + c) * d.I + ii) * d.S_in + col];
+      }
+      patch[t * KP + kk] = v;
+    }
+    for (int i = tid; i < CIN_TOK * C0; i += 256) {
+      const int t = i / C0, c = i % C0, tok = t0 + t;
+      g[t * GP + c] = tok < total ? to_f32(dz[(long)tok * C0 + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int t = 0; t < CIN_TOK; ++t) {
+      const float gv = g[t * GP + n];
+      if (kg == 0) bsum += gv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = kg + 4 * j;
+        if (kk < K) acc[j] += gv * patch[t * KP + kk];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kk = kg + 4 * j;
+    if (kk < K) atomicAdd(dw + (long)n * K + kk, acc[j]);
+  }
+  if (kg == 0 && dbias) atomicAdd(dbias + n, bsum);
+}
+
 // ---- matrix-core forms for the patchifying case (stride == k, no padding, S_in == S_out * k: the audio in-conv, K = 160).
 // The VALU kernels above spend most of their time in per-element index arithmetic (98 / 127 us against a 10 us traffic
 // bound); here a 64-token tile of patches is staged in LDS with 16-byte loads (a token's taps are contiguous per input
@@ -279,6 +330,20 @@ extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float
       hipLaunchKernelGGL((conv_in_bwd_weight_mfma_kernel<float, 160>), dim3(blocks), dim3(256), smm, st, x, (const float*)dz, dw, dbias, *d, total, cpw);
     else
       hipLaunchKernelGGL((conv_in_bwd_weight_mfma_kernel<bf16_t, 160>), dim3(blocks), dim3(256), smm, st, x, (const bf16_t*)dz, dw, dbias, *d, total, cpw);
+    FOCAL_LAUNCH_CHECK();
+    return FOCAL_OK;
+  }
+  if (K <= 16) {
+    const size_t sms = ((size_t)CIN_TOK * (K + 1) + (size_t)CIN_TOK * (d->C + 4)) * sizeof(float);
+    const int chunks = ceil_div(total, CIN_TOK);
+    int cpw = ceil_div(chunks, 512);
+    if (cpw < 1) cpw = 1;
+    const int blocks = ceil_div(chunks, cpw);
+    hipStream_t st = (hipStream_t)stream;
+    if (dz_dtype == FOCAL_F32)
+      hipLaunchKernelGGL((conv_in_bwd_weight_smallk_kernel<float, 64>), dim3(blocks), dim3(256), sms, st, x, (const float*)dz, dw, dbias, *d, K, total, cpw);
+    else
+      hipLaunchKernelGGL((conv_in_bwd_weight_smallk_kernel<bf16_t, 64>), dim3(blocks), dim3(256), sms, st, x, (const bf16_t*)dz, dw, dbias, *d, K, total, cpw);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
