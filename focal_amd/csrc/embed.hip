@@ -3,6 +3,7 @@
 // window is read exactly once, tokens are written once.  64 tokens per workgroup: patches and the transposed
 // filter bank are staged in LDS, each thread produces 16 channels of one token, LayerNorm over the 4 threads of a
 // token by wave shuffles.
+#include <stdlib.h>
 #include "common.hpp"
 
 #define EMB_TOK 64
@@ -78,6 +79,84 @@ __global__ __launch_bounds__(256) void patch_embed_ln_kernel(const float* __rest
   }
 }
 
+// ---- matrix-core form for K = cin * pw = 80, C0 = 64 (the MOD audio patch embedding): the kernel above spends most of its
+// time in per-element index arithmetic (100 us against a 25 us traffic bound).  A 64-token tile of patches is staged with
+// 16-byte loads (a token's pw taps are contiguous per input channel), the contraction runs on the exact-fp32 MFMA with the
+// filter bank resident in registers as fragments, and LayerNorm is finished in registers: a lane holds 16 channels of one
+// token, the other 48 are in the three lanes 16 apart.
+typedef float ef4 __attribute__((ext_vector_type(4)));
+template <int K>
+__global__ __launch_bounds__(256) void patch_embed_ln_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ tokens,
+                                                                  focal_embed_desc d, int total_tokens) {
+  constexpr int KP = K + 4, KS = K / 4, UPT = K / 4;
+  __shared__ __attribute__((aligned(16))) float patch[EMB_TOK * KP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
+  float wf[4][KS];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[nt][ks] = w[(16 * nt + lm) * K + 4 * ks + lg];
+  float4 bv[4], gv[4], be[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    bv[nt] = *reinterpret_cast<const float4*>(bias + 16 * nt + 4 * lg);
+    gv[nt] = *reinterpret_cast<const float4*>(gamma + 16 * nt + 4 * lg);
+    be[nt] = *reinterpret_cast<const float4*>(beta + 16 * nt + 4 * lg);
+  }
+  for (int t0 = blockIdx.x * EMB_TOK; t0 < total_tokens; t0 += gridDim.x * EMB_TOK) {
+    __syncthreads();
+    for (int u = tid; u < EMB_TOK * UPT; u += 256) {
+      const int t = u / UPT, kq = u - t * UPT, tok = t0 + t;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tok < total_tokens) {
+        const int px = tok % d.Wp, r = tok / d.Wp, py = r % d.Hp, b = r / d.Hp;
+        const int kk = 4 * kq, c = kk / d.pw, tt = kk - c * d.pw;
+        const int col = px * d.pw + tt;
+        if (py < d.I && col < d.S) v = *reinterpret_cast<const float4*>(x + (((long)b * d.cin + c) * d.I + py) * d.S + col);  // else: zero padding
+      }
+      *reinterpret_cast<float4*>(patch + t * KP + 4 * kq) = v;
+    }
+    __syncthreads();
+    ef4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = ef4{bv[nt].x, bv[nt].y, bv[nt].z, bv[nt].w};
+    const float* pr = patch + (16 * wave + lm) * KP + lg;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float pf = pr[4 * ks];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][ks], pf, acc[nt], 0, 0, 0);
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) s1 += acc[nt][0] + acc[nt][1] + acc[nt][2] + acc[nt][3];
+    s1 += __shfl_xor(s1, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 * (1.0f / 64.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s2 += (acc[nt][r] - mean) * (acc[nt][r] - mean);
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = rsqrtf(s2 * (1.0f / 64.0f) + d.eps);
+    const int tok = t0 + 16 * wave + lm;
+    if (tok < total_tokens) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float ga[4] = {gv[nt].x, gv[nt].y, gv[nt].z, gv[nt].w}, ba[4] = {be[nt].x, be[nt].y, be[nt].z, be[nt].w};
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (acc[nt][r] - mean) * rstd * ga[r] + ba[r];
+        *reinterpret_cast<float4*>(tokens + (long)tok * 64 + 16 * nt + 4 * lg) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
 extern "C" int focal_pad_patch_embed_ln_fwd(const focal_embed_desc* d, const float* x, const float* w, const float* b,
                                             const float* gamma, const float* beta, float* tokens, void* stream) {
   FOCAL_CHECK_ARG(d && x && w && b && gamma && beta && tokens, "pad_patch_embed_ln: null argument");
@@ -87,9 +166,16 @@ extern "C" int focal_pad_patch_embed_ln_fwd(const focal_embed_desc* d, const flo
   const size_t sm = ((size_t)K * d->C0 + (size_t)EMB_TOK * (K + 1)) * sizeof(float);
   FOCAL_CHECK_ARG(sm <= 64 * 1024, "pad_patch_embed_ln: patch of %d values does not fit in LDS", K);
   const int total = d->B * d->Hp * d->Wp;
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 80 && d->C0 == 64 && d->pw % 4 == 0 && d->S % 4 == 0 && !getenv("FOCAL_EMBED_VALU")) {
+    int mb = ceil_div(total, EMB_TOK);
+    if (mb > 1024) mb = 1024;
+    hipLaunchKernelGGL((patch_embed_ln_mfma_kernel<80>), dim3(mb), dim3(256), 0, st, x, w, b, gamma, beta, tokens, *d, total);
+    FOCAL_LAUNCH_CHECK();
+    return FOCAL_OK;
+  }
   int blocks = ceil_div(total, EMB_TOK);
   if (blocks > 2048) blocks = 2048;
-  hipStream_t st = (hipStream_t)stream;
   if (d->C0 == 64) hipLaunchKernelGGL((patch_embed_ln_kernel<64>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total);
   else hipLaunchKernelGGL((patch_embed_ln_kernel<128>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total);
   FOCAL_LAUNCH_CHECK();
