@@ -144,6 +144,9 @@ class Step:
         that placement replays 2.5 % faster (8.29 -> 8.08 ms, reproducible; the first set is kept alive so its blocks stay put)."""
         self.opt.sync_lr()
         multi = self.dist.is_dist()
+        # with a process group alive its watchdog thread polls events (cudaEventQuery) at any time: under the default "global"
+        # capture mode that would invalidate a capture in progress, "thread_local" restricts the checks to the capturing thread
+        mode = {"capture_error_mode": "thread_local"} if multi else {}
         pool, self._warm_graphs = None, []
         for attempt in range(1 if os.environ.get("FOCAL_BENCH_SINGLE_CAPTURE") == "1" else 2):
             if not multi:
@@ -155,13 +158,13 @@ class Step:
                 graphs = (whole,)
             else:
                 ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, pool=pool, stream=stream):
+                with torch.cuda.graph(ga, pool=pool, stream=stream, **mode):
                     self.seg_a()
                 self.exchange()  # eager, autograd-aware: links segment B's backward to segment A's forward
-                with torch.cuda.graph(gb, pool=ga.pool(), stream=stream):
+                with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
                     self.seg_b()
                 self.reduce()
-                with torch.cuda.graph(gc, pool=ga.pool(), stream=stream):
+                with torch.cuda.graph(gc, pool=ga.pool(), stream=stream, **mode):
                     self.seg_c()
                 graphs = (ga, gb, gc)
             pool = graphs[0].pool()
