@@ -148,3 +148,32 @@ def test_three_adamw_steps_follow_reference(cfg, ct):
         p = dict(net.named_parameters())["mod_projectors.audio.2.weight"].detach().reshape(-1).cpu().double()
         step = max(1, p.numel() // 32)
         assert (p[::step][:32] - torch.from_numpy(fx["adamw.probe_after3"])).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("ct", ["fp32", "bf16"])
+def test_full_batch_equals_small_batches_eval(cfg, ct):
+    """BASELINE size (B = 256): in eval mode (running statistics) a window's DeepSense embedding must not depend on the rest of
+    the batch -- rows of the B = 256 forward equal the B = 8 forward of the same windows (pinned by the reference fixtures).
+    In train mode BatchNorm couples the batch, so there the check is against the statistics: a batch made of 32 copies of
+    an 8-window block has the block's batch statistics, hence the block's embeddings."""
+    args, net, _, _ = build(cfg, ct)
+    g = torch.Generator().manual_seed(6)
+    x8 = {"shake": {"audio": torch.randn(8, 2, 10, 1600, generator=g).cuda(), "seismic": torch.randn(8, 2, 10, 20, generator=g).cuda()}}
+    xr = {"shake": {"audio": torch.randn(256, 2, 10, 1600, generator=g).cuda(), "seismic": torch.randn(256, 2, 10, 20, generator=g).cuda()}}
+    for m in xr["shake"]:
+        xr["shake"][m][96:104] = x8["shake"][m]
+    net.eval()
+    with torch.no_grad():
+        small = net(x8, class_head=False, proj_head=True)
+        full = net(xr, class_head=False, proj_head=True)
+    tol = 1e-5 if ct == "fp32" else 3e-2   # bf16: the whole-sequence GRU kernel partitions the batch in tiles of 16
+    for m in small:
+        assert scale_err(full[m][96:104], small[m]) < tol, m
+    net.train()
+    rep = {"shake": {m: v.repeat(32, 1, 1, 1) for m, v in x8["shake"].items()}}
+    with torch.no_grad():
+        a = net(x8, class_head=False, proj_head=True)
+        b = net(rep, class_head=False, proj_head=True)
+    for m in a:
+        assert scale_err(b[m][:8], a[m]) < (1e-4 if ct == "fp32" else 3e-2), m
+        assert scale_err(b[m][248:], a[m]) < (1e-4 if ct == "fp32" else 3e-2), m

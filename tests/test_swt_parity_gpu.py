@@ -175,3 +175,38 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
             p.add_(eps * d)
         num = (up - dn) / (2 * eps)
         assert abs(num - ana) < 3e-2 * max(abs(ana), abs(num), 1e-3), (n, num, ana)
+
+
+@pytest.mark.parametrize("ct", ["fp32", "bf16"])
+def test_full_batch_equals_small_batches(cfg, ct):
+    """BASELINE size (B = 256 windows, both views in one pass = 512): SW_Transformer has no batch statistics, so
+    (1) the embeddings of a window must not depend on what else is in the batch: rows of the B = 256 forward equal the B = 8
+        forward of the same windows (the B = 8 path is pinned by the reference fixtures), up to the summation order of the
+        split-K atomics in mod_in;
+    (2) the gradient of a sum of per-window terms is additive over batch chunks: grad(B = 256) = grad(first 128) + grad(last
+        128), which exercises the split-K / atomic weight-gradient path at full size against itself at half size."""
+    args, net, _, _ = build(cfg, ct)
+    net.train()
+    B = 256
+    g = torch.Generator().manual_seed(5)
+    x = {"shake": {"audio": torch.randn(B, 2, 10, 1600, generator=g).cuda(), "seismic": torch.randn(B, 2, 10, 20, generator=g).cuda()}}
+    sub = lambda lo, hi: {"shake": {m: v[lo:hi] for m, v in x["shake"].items()}}
+    r = {m: torch.randn(B, 256, generator=g).cuda() for m in cfg["modality_names"]}
+
+    def grads(lo, hi):
+        net.arena().zero_grad()
+        out = net(sub(lo, hi), class_head=False, proj_head=True)
+        sum((out[m] * r[m][lo:hi]).sum() for m in out).backward()
+        torch.cuda.synchronize()
+        return {m: out[m].detach().clone() for m in out}, net.arena().grad.clone()
+
+    full, gfull = grads(0, B)
+    small, _ = grads(40, 48)
+    for m in full:
+        a, b_ = full[m][40:48], small[m]
+        # not bit-exact: mod_in is a split-K GEMM whose fp32 atomics arrive in any order
+        assert (a - b_).abs().max().item() <= (1e-5 if ct == "fp32" else 1e-2) * max(1.0, b_.abs().max().item()), m
+    _, g1 = grads(0, B // 2)
+    _, g2 = grads(B // 2, B)
+    err = (gfull - (g1 + g2)).abs().max().item() / gfull.abs().max().item()
+    assert err < (1e-5 if ct == "fp32" else 2e-3), err
