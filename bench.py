@@ -96,7 +96,7 @@ class Step:
 
     def views(self):
         v1 = {l: {m: self.ops.fft_realpack(x) for m, x in mm.items()} for l, mm in self.x.items()}
-        v2 = {l: {m: self.ops.fft_realpack(x * -1.1) for m, x in mm.items()} for l, mm in self.x.items()}
+        v2 = {l: {m: self.ops.fft_realpack(x, scale=-1.1) for m, x in mm.items()} for l, mm in self.x.items()}  # negation + scaling, folded into the DFT
         return v1, v2
 
     # The step in three capturable segments with the two data-parallel collectives between them:
@@ -372,7 +372,7 @@ def main():
                "config": {"workload": f"{a.model} + FOCAL pretrain step, {a.batch} MOD-shaped 2-modality windows/GPU "
                                       f"(global batch {a.batch * world}), train mode, DFT + fwd x2 + loss + bwd + AdamW",
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graphed, **({"DIAGNOSTIC_no_dropout": True} if a.no_dropout else {}),
-                          "views": "identity / negate*1.1, then DFT", "last_loss": round(last_loss, 4)},
+                          "views": "identity / negation+scaling (x * -1.1) folded into the DFT", "last_loss": round(last_loss, 4)},
                "model_flops_frac_of_bf16_mfma_peak": round(wps / world * FLOP_PER_WINDOW[a.model] / (MFMA_BF16_PEAK_TF * 1e12), 5),
                "roofline": rl, "cpu_baseline": cb}
         print(json.dumps(out))

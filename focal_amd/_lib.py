@@ -25,6 +25,11 @@ class FFTDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "C", "I", "n", "n1", "n2")]
 
 
+class AugDesc(C.Structure):
+    _fields_ = [("scale", C.c_float), ("flip", C.c_int), ("use_perm", C.c_int), ("perm", C.c_int * 32), ("phase_cos", C.c_float),
+                ("phase_sin", C.c_float)]
+
+
 class EmbedDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "cin", "I", "S", "Hp", "Wp", "pw", "C0")] + [("eps", C.c_float)]
 
@@ -81,6 +86,7 @@ PROTOTYPES = {
     "focal_last_error": (C.c_char_p, []),
     "focal_rng_advance": (C.c_int, [P, P]),
     "focal_fft_realpack_fwd": (C.c_int, [C.POINTER(FFTDesc), P, P, P, P]),
+    "focal_augment_fft_fwd": (C.c_int, [C.POINTER(FFTDesc), C.POINTER(AugDesc), P, P, P, P]),
     "focal_pad_patch_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P]),
     "focal_layernorm_fwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, P]),
     "focal_layernorm_bwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, C.c_int, P, P, P, C.POINTER(DropDesc), P]),

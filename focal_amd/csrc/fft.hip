@@ -7,8 +7,30 @@
 #include <stdlib.h>
 #include "common.hpp"
 
+// View augmentations that commute with (or fold into) the transform, applied while the rows are staged / stored instead of as
+// separate passes over the window (the reference data_augmenter package): scaling / negation (x * a), horizontal flip (intervals and samples
+// reversed), interval permutation, and the frequency-domain phase shift (every bin rotated by one angle).
+struct AugParams {
+  float scale, pc, ps;
+  int flip, use_perm;
+  int perm[FOCAL_AUG_MAX_INTERVALS];
+};
+static AugParams aug_identity() {
+  AugParams a;
+  memset(&a, 0, sizeof(a));
+  a.scale = 1.f; a.pc = 1.f;
+  return a;
+}
+// source row of output row `row` = (bc, i)
+__device__ __forceinline__ int aug_src_row(const AugParams& a, int row, int I) {
+  const int i = row % I, bc = row / I;
+  int j = a.use_perm ? a.perm[i] : i;
+  if (a.flip) j = I - 1 - j;
+  return bc * I + j;
+}
+
 __global__ __launch_bounds__(256) void fft_realpack_kernel(const float* __restrict__ x, const float* __restrict__ tw,
-                                                           float* __restrict__ out, focal_fft_desc d, int rows) {
+                                                           float* __restrict__ out, focal_fft_desc d, int rows, AugParams aug) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = d.n, n1 = d.n1, n2 = d.n2;
   float* xs = smem;            // [n]
@@ -23,8 +45,8 @@ __global__ __launch_bounds__(256) void fft_realpack_kernel(const float* __restri
   }
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     __syncthreads();
-    const float* xr = x + (long)row * n;
-    for (int i = tid; i < n; i += 256) xs[i] = xr[i];
+    const float* xr = x + (long)aug_src_row(aug, row, d.I) * n;
+    for (int i = tid; i < n; i += 256) xs[i] = aug.scale * xr[aug.flip ? n - 1 - i : i];
     __syncthreads();
     // stage 1: for each m2, n1-point DFT over m1, then twiddle W_n^{m2 k1}
     for (int o = tid; o < n; o += 256) {
@@ -60,8 +82,8 @@ __global__ __launch_bounds__(256) void fft_realpack_kernel(const float* __restri
         ph += k2;
         if (ph >= n2) ph -= n2;
       }
-      ore[k] = re;
-      oim[k] = im;
+      ore[k] = re * aug.pc - im * aug.ps;
+      oim[k] = re * aug.ps + im * aug.pc;
     }
   }
 }
@@ -81,7 +103,7 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_a
 // instructions each and dominated the first version of this kernel).
 template <int N1, int N2>
 __global__ __launch_bounds__(256) void fft_realpack_mfma_kernel(const float* __restrict__ x, const float* __restrict__ tw,
-                                                                float* __restrict__ out, focal_fft_desc d, int rows) {
+                                                                float* __restrict__ out, focal_fft_desc d, int rows, AugParams aug) {
   constexpr int P = 48;  // padded tile pitch (3 x 16)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int n = N1 * N2, n1 = N1, n2 = N2;
@@ -115,11 +137,22 @@ __global__ __launch_bounds__(256) void fft_realpack_mfma_kernel(const float* __r
   constexpr int XV = (2 * n / 4 + 255) / 256;  // float4 per thread
   float4 xn[XV];
   auto fetch = [&](int pair) {
-    const float4* src = reinterpret_cast<const float4*>(x + (long)pair * 2 * n);
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int e = tid + 256 * i;
-      xn[i] = (e < 2 * n / 4 && pair < rows / 2) ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < 2 * n / 4 && pair < rows / 2) {
+        const int rl = e / (n / 4), q = e - rl * (n / 4);
+        const float4* src = reinterpret_cast<const float4*>(x + (long)aug_src_row(aug, pair * 2 + rl, d.I) * n);
+        if (aug.flip) {
+          const float4 t = src[n / 4 - 1 - q];
+          v = make_float4(t.w, t.z, t.y, t.x);
+        } else {
+          v = src[q];
+        }
+        v.x *= aug.scale; v.y *= aug.scale; v.z *= aug.scale; v.w *= aug.scale;
+      }
+      xn[i] = v;
     }
   };
   auto stash = [&]() {
@@ -207,8 +240,9 @@ __global__ __launch_bounds__(256) void fft_realpack_mfma_kernel(const float* __r
         im += im2;
         const int k2 = 16 * p + lj;
         if (k2 < n2) {
-          *reinterpret_cast<float4*>(ore + n1 * k2) = make_float4(re[0], re[1], re[2], re[3]);
-          *reinterpret_cast<float4*>(oim + n1 * k2) = make_float4(im[0], im[1], im[2], im[3]);
+          const f4 orr = re * aug.pc - im * aug.ps, oii = re * aug.ps + im * aug.pc;
+          *reinterpret_cast<float4*>(ore + n1 * k2) = make_float4(orr[0], orr[1], orr[2], orr[3]);
+          *reinterpret_cast<float4*>(oim + n1 * k2) = make_float4(oii[0], oii[1], oii[2], oii[3]);
         }
       }
     }
@@ -216,8 +250,7 @@ __global__ __launch_bounds__(256) void fft_realpack_mfma_kernel(const float* __r
   }
 }
 
-extern "C" int focal_fft_realpack_fwd(const focal_fft_desc* d, const float* x, const float* twiddle, float* out,
-                                      void* stream) {
+static int fft_launch(const focal_fft_desc* d, const AugParams& aug, const float* x, const float* twiddle, float* out, void* stream) {
   FOCAL_CHECK_ARG(d && x && twiddle && out, "fft_realpack: null argument");
   FOCAL_CHECK_ARG(d->n1 >= 1 && d->n2 >= 1 && d->n1 * d->n2 == d->n, "fft_realpack: n1*n2 != n");
   const size_t sm = (size_t)5 * d->n * sizeof(float);
@@ -240,14 +273,37 @@ extern "C" int focal_fft_realpack_fwd(const focal_fft_desc* d, const float* x, c
     }
     static const int maxb = getenv("FOCAL_FFT_BLOCKS") ? atoi(getenv("FOCAL_FFT_BLOCKS")) : 1024;
     int blocks = rows / 2 < maxb ? rows / 2 : maxb;
-#define FFT_GO(N_) case N_: hipLaunchKernelGGL((fft_realpack_mfma_kernel<N_, N_>), dim3(blocks), dim3(256), smm, (hipStream_t)stream, x, twiddle, out, *d, rows); break
+#define FFT_GO(N_) case N_: hipLaunchKernelGGL((fft_realpack_mfma_kernel<N_, N_>), dim3(blocks), dim3(256), smm, (hipStream_t)stream, x, twiddle, out, *d, rows, aug); break
     switch (d->n1) { FFT_GO(8); FFT_GO(16); FFT_GO(24); FFT_GO(32); FFT_GO(40); default: FFT_GO(48); }
 #undef FFT_GO
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
   int blocks = rows < 4096 ? rows : 4096;
-  hipLaunchKernelGGL(fft_realpack_kernel, dim3(blocks), dim3(256), sm, (hipStream_t)stream, x, twiddle, out, *d, rows);
+  hipLaunchKernelGGL(fft_realpack_kernel, dim3(blocks), dim3(256), sm, (hipStream_t)stream, x, twiddle, out, *d, rows, aug);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
+}
+
+extern "C" int focal_fft_realpack_fwd(const focal_fft_desc* d, const float* x, const float* twiddle, float* out, void* stream) {
+  return fft_launch(d, aug_identity(), x, twiddle, out, stream);
+}
+
+extern "C" int focal_augment_fft_fwd(const focal_fft_desc* d, const focal_aug_desc* a, const float* x, const float* twiddle, float* out,
+                                     void* stream) {
+  FOCAL_CHECK_ARG(d && a, "augment_fft: null descriptor");
+  AugParams p = aug_identity();
+  p.scale = a->scale;
+  p.flip = a->flip != 0;
+  p.use_perm = a->use_perm != 0;
+  p.pc = a->phase_cos;
+  p.ps = a->phase_sin;
+  if (p.use_perm) {
+    FOCAL_CHECK_ARG(d->I <= FOCAL_AUG_MAX_INTERVALS, "augment_fft: %d intervals exceed the permutation table (%d)", d->I, FOCAL_AUG_MAX_INTERVALS);
+    for (int i = 0; i < d->I; ++i) {
+      FOCAL_CHECK_ARG(a->perm[i] >= 0 && a->perm[i] < d->I, "augment_fft: permutation entry %d out of range", a->perm[i]);
+      p.perm[i] = a->perm[i];
+    }
+  }
+  return fft_launch(d, p, x, twiddle, out, stream);
 }

@@ -89,8 +89,11 @@ def _factor(n):
     return n // best, best
 
 
-def fft_realpack(x):
-    """[B, C, I, n] real fp32 -> [B, 2C, I, n] (Re/Im channel pairs of the full two-sided spectrum)."""
+def fft_realpack(x, scale=1.0, flip=False, perm=None, phase=0.0):
+    """[B, C, I, n] real fp32 -> [B, 2C, I, n] (Re/Im channel pairs of the full two-sided spectrum).
+
+    Optional view augmentation folded into the transform (focal_augment_fft_fwd): x * scale, horizontal flip (intervals and
+    samples reversed), interval order `perm` (sequence of I ints), and a rotation of every bin by `phase` radians."""
     _need_cuda(x)
     B, Cc, I, n = x.shape
     key = (n, x.device)
@@ -101,7 +104,19 @@ def fft_realpack(x):
     n1, n2 = _factor(n)
     out = torch.empty(B, 2 * Cc, I, n, dtype=torch.float32, device=x.device)
     d = FFTDesc(B, Cc, I, n, n1, n2)
-    check(_lib.load().focal_fft_realpack_fwd(C.byref(d), _p(x), _p(_TWIDDLES[key]), _p(out), _stream()))
+    if scale == 1.0 and not flip and perm is None and phase == 0.0:
+        check(_lib.load().focal_fft_realpack_fwd(C.byref(d), _p(x), _p(_TWIDDLES[key]), _p(out), _stream()))
+        return out
+    a = _lib.AugDesc()
+    a.scale, a.flip, a.use_perm = float(scale), int(bool(flip)), int(perm is not None)
+    a.phase_cos, a.phase_sin = math.cos(phase), math.sin(phase)
+    if perm is not None:
+        perm = [int(v) for v in perm]
+        if sorted(perm) != list(range(I)):
+            raise ValueError(f"perm must be a permutation of range({I})")
+        for i, v in enumerate(perm):
+            a.perm[i] = v
+    check(_lib.load().focal_augment_fft_fwd(C.byref(d), C.byref(a), _p(x), _p(_TWIDDLES[key]), _p(out), _stream()))
     return out
 
 

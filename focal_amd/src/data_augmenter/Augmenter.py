@@ -2,8 +2,9 @@
 
 `forward("random", time_loc_inputs)` draws ONE augmenter from the configured pool per call, flips a coin per
 (location, modality) as the reference's augmenter classes do, and always ends with the time->frequency transform,
-which runs on the HIP DFT kernel (`focal_fft_realpack_fwd`).  Augmentations are host-driven torch tensor edits on
-device tensors -- they sit BEFORE the parity boundary and are stochastic / unseeded in the reference.
+which runs on the HIP DFT kernel.  The augmentation arithmetic (negation, scaling, horizontal flip, interval
+permutation, phase shift) is folded into that kernel (`focal_augment_fft_fwd`); only the random draws stay on the host,
+unseeded as in the reference.
 Deviation: `time_warp` / `mag_warp` wrap tsai's random-spline transforms, whose source is not available in this
 build environment; they are applied as identity (their coin flip is still drawn) and logged once.
 """
@@ -23,20 +24,23 @@ if _ROOT not in sys.path:
 from focal_amd import ops  # noqa: E402
 
 
+# Every augmenter is a host-side DRAW (what the reference's classes do with `random()` / `torch.normal` / `torch.randperm`)
+# returning keyword arguments of `ops.fft_realpack`: the arithmetic itself is folded into the DFT kernel
+# (focal_augment_fft_fwd), so a view costs one pass over the window instead of an augmentation pass plus a transform pass.
 def _negation(x, cfg):  # NegationAugmenter.py:34
-    return -x
+    return dict(scale=-1.0)
 
 
 def _scaling(x, cfg):  # ScalingAugmenter.py:35-36: one N(1, std) factor per (loc, mod)
-    return x * float(np.random.normal(1.0, cfg["std"]))
+    return dict(scale=float(np.random.normal(1.0, cfg["std"])))
 
 
 def _horizontal_flip(x, cfg):  # HorizontalFlipAugmenter.py:34: flip intervals and samples
-    return torch.flip(x, dims=[2, 3])
+    return dict(flip=True)
 
 
 def _permutation(x, cfg):  # PermutationAugmenter.py:35-36: one random interval order for the whole batch
-    return x[:, :, torch.randperm(x.shape[2], device=x.device), :]
+    return dict(perm=torch.randperm(x.shape[2]).tolist())
 
 
 _WARNED = set()
@@ -47,17 +51,12 @@ def _spline_warp_unavailable(name):
         if name not in _WARNED:
             _WARNED.add(name)
             logging.warning(f"{name}: tsai spline warp unavailable in this build; applied as identity")
-        return x
+        return {}
     return fn
 
 
 def _phase_shift(x, cfg):  # PhaseShiftAugmenter.py:39-54: rotate every complex bin by one random angle
-    b, c, i, s = x.shape
-    ang = (random() - 0.5) * 2 * math.pi
-    z = x.reshape(b, c // 2, 2, i, s)
-    re, im = z[:, :, 0], z[:, :, 1]
-    ca, sa = math.cos(ang), math.sin(ang)
-    return torch.stack([re * ca - im * sa, re * sa + im * ca], 2).reshape(b, c, i, s)
+    return dict(phase=(random() - 0.5) * 2 * math.pi)
 
 
 TIME_AUGMENTERS = {"no": None, "negation": _negation, "scaling": _scaling, "horizontal_flip": _horizontal_flip,
@@ -97,27 +96,24 @@ class Augmenter:
             raise Exception(f"Invalid augmentation option: {option}")
         return out if labels is None else (out, labels)
 
-    def _apply(self, fn, name, inputs):
-        if fn is None:
-            return inputs
+    def _draw(self, fn, name, inputs):
+        """Per (location, modality): the reference's coin flip, then the augmenter's own draw -> fft_realpack keyword arguments."""
         out = {}
         for loc in self.locations:
             out[loc] = {}
             for mod in self.modalities:
-                x = inputs[loc][mod]
-                out[loc][mod] = fn(x, self.args.dataset_config.get(name, {})) if random() < self.args.dataset_config[name]["prob"] else x
+                hit = fn is not None and random() < self.args.dataset_config[name]["prob"]
+                out[loc][mod] = fn(inputs[loc][mod], self.args.dataset_config.get(name, {})) if hit else {}
         return out
 
     def forward_random(self, time_loc_inputs):
+        """ONE augmenter from the (time + freq) pool per call (reference :76-113); its arithmetic runs inside the DFT kernel."""
         k = np.random.randint(len(self.aug_names))
         name = self.aug_names[k]
-        x = time_loc_inputs
-        if k < len(self.time_aug_names):
-            x = self._apply(TIME_AUGMENTERS[name], name, x)
-        f = self.fft_preprocess(x)
-        if k >= len(self.time_aug_names):
-            f = self._apply(FREQ_AUGMENTERS[name], name, f)
-        return f
+        fn = TIME_AUGMENTERS[name] if k < len(self.time_aug_names) else FREQ_AUGMENTERS[name]
+        kw = self._draw(fn, name, time_loc_inputs)
+        return {loc: {mod: ops.fft_realpack(x.contiguous(), **kw[loc][mod]) for mod, x in mods.items()}
+                for loc, mods in time_loc_inputs.items()}
 
     def move_to_target_device(self, time_loc_inputs, labels):
         dev = self.args.device

@@ -57,6 +57,18 @@ typedef struct {
  * DFT; n2 = 1 gives a direct DFT); `twiddle` is a device table of n {cos, -sin}(2 pi k / n) pairs. */
 typedef struct { int B, C, I, n, n1, n2; } focal_fft_desc;
 int focal_fft_realpack_fwd(const focal_fft_desc* d, const float* x, const float* twiddle, float* out, void* stream);
+/* Same transform with one FOCAL view augmentation folded in (the data_augmenter package), applied to the whole
+ * [B, C, I, n] tensor as the reference does per (location, modality):
+ *   time domain, before the DFT:  x' = scale * x            NegationAugmenter.py:34 (scale = -1), ScalingAugmenter.py:35-36
+ *                                 x'[i][s] = x[I-1-i][n-1-s]  HorizontalFlipAugmenter.py:34 (torch.flip dims 2, 3)
+ *                                 x'[i] = x[perm[i]]          PermutationAugmenter.py:35-36 (one order for the whole batch)
+ *   frequency domain, after it:   every bin times e^(i*angle)  PhaseShiftAugmenter.py:39-54
+ * The reference applies exactly one of them per call; if several are set they compose as permute(flip(scale * x)), then the
+ * rotation.  The random draws (coin flips, factor, order, angle) stay on the host, as in the reference. */
+#define FOCAL_AUG_MAX_INTERVALS 32
+typedef struct { float scale; int flip; int use_perm; int perm[FOCAL_AUG_MAX_INTERVALS]; float phase_cos, phase_sin; } focal_aug_desc;
+int focal_augment_fft_fwd(const focal_fft_desc* d, const focal_aug_desc* a, const float* x, const float* twiddle, float* out,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 8: embed
  * SW_Transformer.pad_input + PatchEmbed (models/SW_Transformer.py:184-208, models/SwinModules.py:547-558):

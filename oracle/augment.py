@@ -1,0 +1,63 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+CPU restatement of the FOCAL view augmentations that the MI355X path folds into the DFT (include/focal_hip.h:
+focal_augment_fft_fwd).  The reference draws its randomness inside each augmenter (`random()`, `torch.normal`,
+`torch.randperm`); here every draw is an explicit argument so that the arithmetic can be pinned
+(tests/golden/gen_golden.py forces the same draws inside the reference classes and stores both sides)."""
+import math
+
+import torch
+
+from .step import fft_realpack as _fft_dict
+
+
+def fft_realpack(x):
+    """Single-tensor form of oracle.step.fft_realpack (Augmenter.fft_preprocess, data_augmenter/Augmenter.py:141-158)."""
+    return _fft_dict({"_": {"_": x}})["_"]["_"]
+
+
+def negation(x):
+    """NegationAugmenter.forward, data_augmenter/NegationAugmenter.py:34."""
+    return -x
+
+
+def scaling(x, factor):
+    """ScalingAugmenter.forward, data_augmenter/ScalingAugmenter.py:35-36: one N(1, std) factor per (loc, mod)."""
+    return x * factor
+
+
+def horizontal_flip(x):
+    """HorizontalFlipAugmenter.forward, data_augmenter/HorizontalFlipAugmenter.py:34: intervals and samples reversed."""
+    return torch.flip(x, dims=[2, 3])
+
+
+def permutation(x, order):
+    """PermutationAugmenter.forward, data_augmenter/PermutationAugmenter.py:35-36: one interval order for the whole batch."""
+    return x[:, :, torch.as_tensor(order, dtype=torch.long), :]
+
+
+def phase_shift(f, angle):
+    """PhaseShiftAugmenter.forward, data_augmenter/PhaseShiftAugmenter.py:39-54 on the packed [b, 2c, i, s] spectrum:
+    |z| (cos(arg z + angle), sin(arg z + angle)) = z * e^{i angle}."""
+    b, c, i, s = f.shape
+    z = f.reshape(b, c // 2, 2, i, s)
+    re, im = z[:, :, 0], z[:, :, 1]
+    ca, sa = math.cos(angle), math.sin(angle)
+    return torch.stack([re * ca - im * sa, re * sa + im * ca], 2).reshape(b, c, i, s)
+
+
+def augmented_view(x, name, draw=None):
+    """Augmenter.forward_random for ONE chosen augmenter applied to one (loc, mod) tensor (data_augmenter/Augmenter.py:76-113):
+    time-domain augmenters act before the DFT, `phase_shift` after it.  `draw` = factor / order / angle where one is needed."""
+    if name == "negation":
+        x = negation(x)
+    elif name == "scaling":
+        x = scaling(x, draw)
+    elif name == "horizontal_flip":
+        x = horizontal_flip(x)
+    elif name == "permutation":
+        x = permutation(x, draw)
+    elif name not in ("no", "phase_shift"):
+        raise ValueError(name)
+    f = fft_realpack(x)
+    return phase_shift(f, draw) if name == "phase_shift" else f

@@ -495,3 +495,65 @@ def test_gru_whole_sequence_kernels_match_per_step_path(ops, B, H):
                 have = True
         assert rel_err(got[di][0], dgi) < 5e-3, di
         assert rel_err(got[di][1], dgh) < 5e-3, di
+
+
+@pytest.mark.parametrize("name", ["negation", "scaling", "horizontal_flip", "permutation", "phase_shift"])
+def test_augmentation_folded_into_dft_matches_reference(ops, name):
+    """focal_augment_fft_fwd against outputs of the reference augmenter classes (forced draws) followed / preceded by the
+    reference FFT packing: tests/golden/augment_b2_seed77.npz."""
+    import numpy as np
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment_b2_seed77.npz"))
+    kw = {"negation": dict(scale=-1.0), "scaling": dict(scale=float(fx["draw.scaling"])), "horizontal_flip": dict(flip=True),
+          "permutation": dict(perm=[int(v) for v in fx["draw.permutation"]]), "phase_shift": dict(phase=float(fx["draw.phase_shift"]))}[name]
+    for k in [k[3:] for k in fx.files if k.startswith("in.")]:
+        x = torch.from_numpy(fx[f"in.{k}"]).to(DEV)
+        ref = torch.from_numpy(fx[f"{name}.{k}"]).to(DEV)
+        out = ops.fft_realpack(x, **kw)
+        n = x.shape[-1]
+        assert (out.double() - ref.double()).abs().max().item() < 2e-4 * math.sqrt(n) * max(1.0, abs(kw.get("scale", 1.0))), (name, k)
+    # combinations compose: x' = permute(flip(scale * x)) before the transform, rotation after it
+    x = rnd(2, 1, 10, 1600, seed=88)
+    perm = [9, 8, 0, 1, 2, 3, 7, 6, 5, 4]
+    got = ops.fft_realpack(x, scale=0.5, flip=True, perm=perm, phase=0.3)
+    xk = torch.flip(0.5 * x.cpu(), dims=[2, 3])[:, :, torch.tensor(perm), :]
+    f = torch.view_as_real(torch.fft.fft(xk.double(), dim=-1)).permute(0, 1, 4, 2, 3).reshape(2, 2, 10, 1600)
+    c, s_ = math.cos(0.3), math.sin(0.3)
+    ref = torch.stack([f[:, 0] * c - f[:, 1] * s_, f[:, 0] * s_ + f[:, 1] * c], 1)
+    assert (got.cpu().double() - ref).abs().max().item() < 2e-4 * 40
+
+
+def test_product_augmenter_random_views_follow_the_oracle(ops, cfg, monkeypatch):
+    """data_augmenter.Augmenter.forward("random"): whatever it draws, the tensor it returns is the oracle's view for that draw."""
+    from conftest import make_args
+    from data_augmenter import Augmenter as A
+    from oracle import augment as oa
+    args = make_args(cfg, "SW_Transformer", torch.device(DEV), "bf16")
+    aug = A.Augmenter(args)
+    calls = []
+    real = A.ops.fft_realpack
+
+    def spy(x, **kw):
+        calls.append((x, kw))
+        return real(x, **kw)
+    monkeypatch.setattr(A.ops, "fft_realpack", spy)
+    tx = {"shake": {"audio": torch.randn(2, 1, 10, 1600), "seismic": torch.randn(2, 1, 10, 20)}}
+    seen = set()
+    for _ in range(24):
+        calls.clear()
+        out = aug.forward("random", tx)
+        assert list(out["shake"].keys()) == ["audio", "seismic"]
+        for (x, kw), m in zip(calls, ("audio", "seismic")):
+            seen.update(kw.keys())
+            ref = x.cpu()
+            if "scale" in kw:
+                ref = oa.scaling(ref, kw["scale"])
+            if kw.get("flip"):
+                ref = oa.horizontal_flip(ref)
+            if "perm" in kw:
+                ref = oa.permutation(ref, kw["perm"])
+            f = oa.fft_realpack(ref)
+            if "phase" in kw:
+                f = oa.phase_shift(f, kw["phase"])
+            assert (out["shake"][m].cpu() - f).abs().max().item() < 2e-4 * math.sqrt(x.shape[-1]) * 2
+    assert {"scale", "flip", "perm", "phase"} <= seen  # 24 draws from a 7-entry pool at p = 0.5 each: all four kinds appear

@@ -201,3 +201,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.focal_abi_version() == _lib.ABI_VERSION
     import ctypes as C
     assert C.sizeof(_lib.DropDesc) == 32 and C.sizeof(_lib.LinearDesc) == 9 * 4 + 4 + 32
+
+
+def test_augment_oracle_matches_reference_fixture():
+    """oracle/augment.py against outputs of the reference augmenter classes with forced draws
+    (tests/golden/gen_golden_augment.py): bit-exact for the time-domain augmenters, 1e-5 for the phase shift."""
+    import numpy as np
+    import torch
+    from oracle import augment as oa
+    fx = np.load(os.path.join(GOLD, "augment_b2_seed77.npz"))
+    draws = {"negation": None, "scaling": float(fx["draw.scaling"]), "horizontal_flip": None,
+             "permutation": [int(v) for v in fx["draw.permutation"]], "phase_shift": float(fx["draw.phase_shift"])}
+    keys = [k[3:] for k in fx.files if k.startswith("in.")]
+    assert keys
+    for name, draw in draws.items():
+        for lm in keys:
+            x = torch.from_numpy(fx[f"in.{lm}"])
+            ref = torch.from_numpy(fx[f"{name}.{lm}"])
+            got = oa.augmented_view(x, name, draw)
+            if name == "phase_shift":
+                assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
+            else:
+                assert torch.equal(got, ref), (name, lm)
