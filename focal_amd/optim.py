@@ -80,3 +80,28 @@ class FocalAdamW(torch.optim.Optimizer):
                         g0["weight_decay"])
         for ar in arenas:
             ar.mark_shadow_fresh()
+
+    # ---- resume support (the reference saves weights only; SURVEY 8f rank 3 asks for optimizer state as well)
+    def train_state(self):
+        """Everything `step()` depends on besides the weights: the step count and both moment buffers of every arena."""
+        torch.cuda.synchronize()
+        arenas = self._arenas()
+        return {"step": int(self._step_state[1].item()) if self._step_state is not None else 0,
+                "lr": float(self.param_groups[0]["lr"]),
+                "moments": [tuple(t.detach().cpu().clone() for t in ar.moments()) for ar in arenas]}
+
+    def load_train_state(self, state):
+        arenas = self._arenas()
+        if len(arenas) != len(state["moments"]):
+            raise ops._lib.FocalHipError("FocalAdamW.load_train_state: arena count differs (run one forward/backward first)")
+        for ar, (m, v) in zip(arenas, state["moments"]):
+            am, av = ar.moments()
+            if am.numel() != m.numel():
+                raise ops._lib.FocalHipError("FocalAdamW.load_train_state: moment size differs from the arena")
+            am.copy_(m.to(am.device))
+            av.copy_(v.to(av.device))
+        dev = arenas[0].device
+        if self._step_state is None:
+            self._step_state = ops.new_rng_state(0, dev)
+        self._step_state[1] = int(state["step"])
+        self.param_groups[0]["lr"] = float(state["lr"])

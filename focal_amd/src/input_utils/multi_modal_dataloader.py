@@ -14,6 +14,7 @@ class SyntheticSequenceLoader:
         cfg = args.dataset_config
         self.cfg, self.batch_size, self.num_batches, self.seed = cfg, batch_size, num_batches, seed
         self.device = device or args.device
+        self.task = getattr(args, "task", None)
         seq = cfg["seq_len"]
         if batch_size % seq != 0:
             raise ValueError(f"batch size {batch_size} must hold whole subsequences of {seq} windows (models/loss.py:152-155)")
@@ -32,7 +33,8 @@ class SyntheticSequenceLoader:
                     shape = (self.batch_size, cfg["loc_mod_in_time_channels"][loc][mod], cfg["num_segments"],
                              cfg["loc_mod_spectrum_len"][loc][mod])
                     batch[loc][mod] = torch.randn(shape, generator=g)
-            labels = torch.zeros(self.batch_size, dtype=torch.long)
+            n_cls = cfg.get(getattr(self, "task", None) or "vehicle_classification", {}).get("num_classes", 2)
+            labels = torch.randint(0, n_cls, (self.batch_size,), generator=g)  # synthetic class labels (KNN validation needs > 1 class)
             yield batch, labels
 
 

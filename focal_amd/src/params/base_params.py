@@ -17,6 +17,8 @@ def parse_base_args(option="train"):
     p.add_argument("-compute_dtype", type=str, default=None, help="[build extension] bf16 (default) or fp32 matrix-core operands.")
     p.add_argument("-epochs", type=int, default=None, help="[build extension] override train_epochs.")
     p.add_argument("-synthetic_batches", type=int, default=8, help="[build extension] batches per synthetic epoch.")
+    p.add_argument("-resume", action="store_true", help="[build extension] continue from the latest weights + optimizer state.")
+    p.add_argument("-sync_bn", action="store_true", help="[build extension] DeepSense under torchrun: cross-rank BatchNorm statistics.")
     args = p.parse_args()
     args.option = option
     return args

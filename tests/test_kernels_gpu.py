@@ -557,3 +557,20 @@ def test_product_augmenter_random_views_follow_the_oracle(ops, cfg, monkeypatch)
                 f = oa.phase_shift(f, kw["phase"])
             assert (out["shake"][m].cpu() - f).abs().max().item() < 2e-4 * math.sqrt(x.shape[-1]) * 2
     assert {"scale", "flip", "perm", "phase"} <= seen  # 24 draws from a 7-entry pool at p = 0.5 each: all four kinds appear
+
+
+def test_gpu_knn_matches_sklearn(ops):
+    """train_utils.knn.GpuKNNClassifier (distances from the fp32 MFMA GEMM, top-5, majority vote, ties to the smallest label)
+    against sklearn.neighbors.KNeighborsClassifier() -- the estimator the reference fits (train_utils/knn.py:38-40)."""
+    from sklearn.neighbors import KNeighborsClassifier
+    from train_utils.knn import GpuKNNClassifier
+    g = torch.Generator().manual_seed(3)
+    centers = torch.randn(7, 512, generator=g) * 0.12
+    ytr = torch.randint(0, 7, (3000,), generator=g)
+    xtr = centers[ytr] + torch.randn(3000, 512, generator=g)
+    yq = torch.randint(0, 7, (1000,), generator=g)
+    xq = centers[yq] + torch.randn(1000, 512, generator=g)
+    ref = KNeighborsClassifier().fit(xtr.numpy(), ytr.numpy()).predict(xq.numpy())
+    got = GpuKNNClassifier().fit(xtr.to(DEV), ytr.to(DEV)).predict(xq.to(DEV)).cpu().numpy()
+    assert (got == ref).mean() >= 0.999, (got != ref).sum()   # (an exact distance tie at the 5th neighbour may order differently)
+    assert 0.25 < (got == yq.numpy()).mean() < 0.999          # a real classification problem, neither trivial nor hopeless

@@ -210,3 +210,51 @@ def test_full_batch_equals_small_batches(cfg, ct):
     _, g2 = grads(B // 2, B)
     err = (gfull - (g1 + g2)).abs().max().item() / gfull.abs().max().item()
     assert err < (1e-5 if ct == "fp32" else 2e-3), err
+
+
+def test_optimizer_train_state_round_trip(cfg):
+    """Resume support: weights + FocalAdamW.train_state() restore the run -- the step taken after a reload equals the step the
+    original run takes next (up to the summation order of the gradient atomics)."""
+    from train_utils.optimizer import define_optimizer
+    args, net, focal, loss_fn = build(cfg, "fp32")
+    net.train()
+    opt = define_optimizer(args, focal.parameters())
+    x1, x2 = inputs(cfg)
+
+    def one_step():
+        opt.zero_grad()
+        a, b = focal(x1, x2, proj_head=True)
+        loss_fn(a, b).backward()
+        opt.step()
+    one_step()
+    one_step()
+    w2 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    s2 = opt.train_state()
+    assert s2["step"] == 2
+    one_step()
+    w3 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(w2)
+    opt.zero_grad()
+    for ar in opt._arenas():  # scramble the live state so that the reload has something to restore
+        m, v = ar.moments()
+        m.normal_()
+        v.uniform_()
+    opt._step_state[1] = 77
+    one_step()
+    wbad = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(w2)
+    opt.zero_grad()
+    opt.load_train_state(s2)
+    one_step()
+    w3b = net.state_dict()
+
+    def update_error(w):  # relative L2 distance between the parameter updates (AdamW steps are ~lr per element, so a handful of
+        num = den = 0.0    # elements with near-zero gradients flip with the summation order of the atomics: compare in bulk)
+        for k in w3:
+            if w3[k].is_floating_point() and k in dict(net.named_parameters()):
+                d_ref = (w3[k] - w2[k]).double()
+                num += ((w[k] - w2[k]).double() - d_ref).pow(2).sum().item()
+                den += d_ref.pow(2).sum().item()
+        return (num / max(den, 1e-30)) ** 0.5
+    assert update_error(w3b) < 2e-2, update_error(w3b)
+    assert update_error(wbad) > 0.3, update_error(wbad)  # negative control: the scrambled state takes a different step
