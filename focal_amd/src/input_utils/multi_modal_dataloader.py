@@ -1,9 +1,9 @@
 """Batches of whole subsequences for FOCAL pretraining.
 
 The reference loads one `.pt` dict per window through a torch DataLoader with a sequence-aware batch sampler
-(input_utils/multi_modal_dataloader.py:12-78, multi_modal_dataset.py:58-130).  Feeding 1e4-1e5 windows/s from
-per-sample files is a separate "next" component; this build ships the synthetic equivalent the
-benchmark and tests use: seeded N(0,1) time-domain windows in the reference's collated layout
+(input_utils/multi_modal_dataloader.py:12-78, multi_modal_dataset.py:58-130); `create_dataloader` keeps that path, adds a
+packed-shard loader for feeding 1e4-1e5 windows/s (input_utils/packed_shards.py) and the synthetic source
+the benchmark and tests use: seeded N(0,1) time-domain windows in the reference's collated layout
 `({loc: {mod: [B, c, i, s]}}, labels)`, batch = `batch_size // seq_len` subsequences of `seq_len` windows.
 """
 import torch
@@ -38,10 +38,53 @@ class SyntheticSequenceLoader:
             yield batch, labels
 
 
+class BatchSeqSampler(torch.utils.data.Sampler):
+    """Batches of whole subsequences in one shuffled order per epoch (reference :51-78)."""
+
+    def __init__(self, args, batch_size, dataset):
+        self.dataset = dataset
+        self.subseq_batch_size = batch_size // args.dataset_config["seq_len"]
+        self.subseq_count = len(dataset.subseqs)
+        self.subseq_indices = list(range(self.subseq_count))
+
+    def __iter__(self):
+        import random
+        random.shuffle(self.subseq_indices)
+        for b in range(0, self.subseq_count, self.subseq_batch_size):
+            out = []
+            for sid in self.subseq_indices[b:b + self.subseq_batch_size]:
+                out.extend(self.dataset.subseq_to_sample_idx[self.dataset.subseqs[sid]])
+            yield out
+
+    def __len__(self):
+        return -(-self.subseq_count // self.subseq_batch_size)
+
+
+def _index_file(option, args):
+    if option == "train":
+        if args.train_mode not in {"supervised"} and args.stage == "pretrain":
+            return args.dataset_config["pretrain_index_file"]
+        return args.dataset_config[args.task]["train_index_file"]
+    return args.dataset_config[args.task]["val_index_file" if option == "val" else "test_index_file"]
+
+
 def create_dataloader(option, args, batch_size=64, workers=5):
-    index_file = args.dataset_config.get("pretrain_index_file", "synthetic")
-    if index_file != "synthetic":
-        raise NotImplementedError("per-sample .pt loading is not part of this round's hot path; set "
-                                  "pretrain_index_file: \"synthetic\" (see DESIGN.md, 'what comes next')")
-    n = getattr(args, "synthetic_batches", 8)
-    return SyntheticSequenceLoader(args, batch_size, num_batches=n if option == "train" else 1, seed=1234 if option == "train" else 99)
+    """reference :12-48.  Index file "synthetic" -> seeded synthetic windows; a directory holding a packed shard
+    (input_utils/packed_shards.py: pack_index) -> the prefetching packed loader; otherwise the reference's per-sample `.pt`
+    files through a torch DataLoader, with the sequence-aware batch sampler for contrastive pretraining."""
+    index_file = _index_file(option, args)
+    if index_file == "synthetic":
+        n = getattr(args, "synthetic_batches", 8)
+        return SyntheticSequenceLoader(args, batch_size, num_batches=n if option == "train" else 1, seed=1234 if option == "train" else 99)
+    import os
+    if os.path.isdir(index_file):
+        from input_utils.packed_shards import PackedSequenceLoader
+        return PackedSequenceLoader(args, index_file, batch_size, shuffle=(option == "train"))
+    from torch.utils.data import DataLoader
+    from input_utils.multi_modal_dataset import MultiModalDataset, MultiModalSequenceDataset
+    if args.sequence_sampler and args.train_mode == "contrastive" and args.stage == "pretrain":
+        dataset = MultiModalSequenceDataset(args, index_file)
+        batch_size = min(batch_size, len(dataset) * args.dataset_config["seq_len"])
+        return DataLoader(dataset, batch_sampler=BatchSeqSampler(args, batch_size, dataset), num_workers=workers)
+    dataset = MultiModalDataset(args, index_file, getattr(args, "label_ratio", 1) if option == "train" else 1)
+    return DataLoader(dataset, batch_size=min(batch_size, len(dataset)), shuffle=(option == "train"), num_workers=workers)

@@ -28,3 +28,52 @@ def test_train_py_runs_validates_checkpoints_and_resumes(model, tmp_path):
     log2 = r2.stdout + r2.stderr
     assert r2.returncode == 0, log2[-3000:]
     assert "Total processing time" in log2
+
+
+def test_pretraining_from_packed_shards_and_from_sample_files(cfg, tmp_path):
+    """Real-data paths: MOD-shaped `.pt` samples -> (a) the reference-style DataLoader with the sequence-aware batch sampler,
+    (b) a packed shard with the prefetching loader; one pretraining epoch from each on the HIP path, same first-step loss."""
+    import copy
+    import random
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "focal_amd", "src"))
+    from conftest import make_args
+    from data_augmenter.Augmenter import Augmenter
+    from input_utils.multi_modal_dataloader import create_dataloader
+    from input_utils.packed_shards import pack_index
+    from train_utils.model_selection import init_backbone_model, init_loss_func, init_pretrain_framework
+    from train_utils.loss_calc_utils import calc_pretrain_loss
+    g = torch.Generator().manual_seed(4)
+    files = []
+    for s in range(4):
+        for k in range(8):
+            f = str(tmp_path / f"seq{s}_shake_{k}.pt")
+            torch.save({"label": torch.tensor(k % 3), "flag": {"shake": {"audio": True, "seismic": True}},
+                        "data": {"shake": {"audio": torch.randn(1, 10, 1600, generator=g), "seismic": torch.randn(1, 10, 20, generator=g)}}}, f)
+            files.append(f)
+    idx = tmp_path / "index.txt"
+    idx.write_text("\n".join(files) + "\n")
+    losses = {}
+    for kind in ("files", "packed"):
+        c = copy.deepcopy(cfg)
+        for k in ("dropout_ratio", "drop_path_rate", "attn_drop_rate"):
+            c["SW_Transformer"][k] = 0.0
+        c["FOCAL"]["random_augmenters"] = {"time_augmenters": ["no"], "freq_augmenters": ["no"]}
+        args = make_args(c, "SW_Transformer", torch.device("cuda"), "fp32")
+        args.batch_size, args.workers, args.sequence_sampler, args.label_ratio = 16, 0, True, 1.0
+        c["pretrain_index_file"] = str(idx) if kind == "files" else pack_index(args, str(idx), str(tmp_path / "pack"))
+        torch.manual_seed(0)
+        random.seed(9)
+        loader = create_dataloader("train", args, batch_size=16, workers=0)
+        assert len(loader) == 2
+        model = init_pretrain_framework(args, init_backbone_model(args))
+        from oracle.weights import fill_state_dict_
+        fill_state_dict_(model.backbone.state_dict())
+        model.train()
+        loss_fn, aug = init_loss_func(args), Augmenter(args)
+        vals = []
+        for time_loc_inputs, labels in loader:
+            assert labels.shape[0] == 16
+            vals.append(calc_pretrain_loss(args, model, aug, loss_fn, time_loc_inputs).item())
+        losses[kind] = vals
+    assert all(abs(a - b) < 1e-4 * max(1.0, abs(a)) for a, b in zip(losses["files"], losses["packed"])), losses
