@@ -76,7 +76,7 @@ class GRUDesc(C.Structure):
 
 
 class AdamWDesc(C.Structure):
-    _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+    _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("l2_decay", C.c_int)]
 
 
 P = C.c_void_p
@@ -96,6 +96,11 @@ PROTOTYPES = {
     "focal_linear_bwd_weight": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_window_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P]),
     "focal_window_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P]),
+    "focal_fusion_attn_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint32, C.c_float, P]),
+    "focal_fusion_attn_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P, P]),
+    "focal_cross_entropy": (C.c_int, [C.c_int, C.c_int, P, P, P, P, P]),
+    "focal_small_linear_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, P, P, P]),
+    "focal_small_linear_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P]),
     "focal_loss_head_workspace": (C.c_size_t, [C.POINTER(LossDesc)]),
     "focal_loss_head": (C.c_int, [C.POINTER(LossDesc), C.POINTER(P), P, C.POINTER(P), P, C.c_size_t, P]),
     "focal_adamw_multi": (C.c_int, [C.POINTER(AdamWDesc), C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P),

@@ -9,14 +9,24 @@ DEAD_PREFIXES = ("patch_embed.", "class_layer.", "mod_fusion_layers.", "absolute
                  "loc_fusion_layers.", "loc_context_layers.", "loc_fusion_layer.")
 
 
+HEAD_PREFIXES = ("class_layer.", "mod_fusion_layers.")
+
+
 def is_hot(name):
     """Parameters that receive a gradient in FOCAL pretraining."""
     return not name.startswith(DEAD_PREFIXES)
 
 
+def is_hot_with_head(name):
+    """Classifier / finetune stage: the head (class layer, modality fusion) joins the arena; it is what finetuning trains
+    (general_utils/weight_utils.py:61-80), the encoder weights stay there as the frozen operands of the forward pass."""
+    return is_hot(name) or name.startswith(HEAD_PREFIXES)
+
+
 class HipBackbone(nn.Module):
     def _init_hip(self, args):
         self.compute_dtype = runtime.compute_dtype_from(args)
+        self._hot = is_hot_with_head if (getattr(args, "stage", "pretrain") == "finetune" or getattr(args, "train_mode", "") == "supervised") else is_hot
         self._arena = None
         self._named = None
         self._fwd_calls = 0
@@ -28,7 +38,7 @@ class HipBackbone(nn.Module):
 
     def arena(self):
         if self._arena is None or not self._arena.intact():
-            self._arena = ParamArena(self, is_hot, self.compute_dtype)
+            self._arena = ParamArena(self, self._hot, self.compute_dtype)
             self._named = None
         self._arena.sync_shadow()
         return self._arena

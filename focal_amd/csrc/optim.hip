@@ -23,7 +23,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   const float lr = lr_dev[0];
   const float t = (float)rng_state[1];
   const float bc1 = 1.0f - powf(d.beta1, t), bc2 = 1.0f - powf(d.beta2, t);
-  const float step = lr / bc1, isq = rsqrtf(bc2), decay = 1.0f - lr * d.weight_decay;
+  // weight decay: decoupled (AdamW: p *= 1 - lr * wd) or, with d.l2_decay, torch.optim.Adam's L2 form (g += wd * p)
+  const float step = lr / bc1, isq = rsqrtf(bc2), decay = d.l2_decay ? 1.0f : 1.0f - lr * d.weight_decay;
+  const float l2 = d.l2_decay ? d.weight_decay : 0.0f;
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -31,8 +33,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     float4 mm = reinterpret_cast<float4*>(m)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
 #define ADAM1(c)                                              \
-    mm.c = d.beta1 * mm.c + (1.0f - d.beta1) * gg.c;          \
-    vv.c = d.beta2 * vv.c + (1.0f - d.beta2) * gg.c * gg.c;   \
+    const float g_##c = gg.c + l2 * pp.c;                     \
+    mm.c = d.beta1 * mm.c + (1.0f - d.beta1) * g_##c;         \
+    vv.c = d.beta2 * vv.c + (1.0f - d.beta2) * g_##c * g_##c; \
     pp.c = pp.c * decay - step * mm.c / (sqrtf(vv.c) * isq + d.eps);
     ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1

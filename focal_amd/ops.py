@@ -63,13 +63,13 @@ def cast_bf16(src, dst):
     check(_lib.load().focal_cast_bf16(_p(src), _p(dst), src.numel(), _stream()))
 
 
-def adamw_multi(segments, lr_dev, rng_state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05):
+def adamw_multi(segments, lr_dev, rng_state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, l2_decay=False):
     """segments: list of (p, g, m, v, shadow_or_None) flat tensors (lengths multiples of 4)."""
     n = len(segments)
     arr = lambda i: (C.c_void_p * n)(*[_p(s[i]) for s in segments])
     has_shadow = any(s[4] is not None for s in segments)
     lens = (C.c_long * n)(*[s[0].numel() for s in segments])
-    d = AdamWDesc(beta1, beta2, eps, weight_decay)
+    d = AdamWDesc(beta1, beta2, eps, weight_decay, int(l2_decay))
     check(_lib.load().focal_adamw_multi(C.byref(d), n, arr(0), arr(1), arr(2), arr(3), arr(4) if has_shadow else None,
                                         lens, _p(lr_dev), _p(rng_state), _stream()))
 
@@ -375,6 +375,40 @@ def gru_seq_fwd(d, gi, whh, bhh, hs, save, out):
 def gru_seq_bwd(d, dout, ld_b, ld_t, scale, whh_t, hs, save, dgi, dgh):
     check(_lib.load().focal_gru_seq_bwd(C.byref(d), len(hs), _p(dout), ld_b, ld_t, scale, _parr(whh_t), _parr(hs), _parr(save), _parr(dgi),
                                         _parr(dgh), _stream()))
+
+
+def fusion_attn_fwd(B, M, E, heads, q, kv, out, probs, weights, rng, stream_id, p_drop):
+    check(_lib.load().focal_fusion_attn_fwd(B, M, E, heads, _p(q), _p(kv), _p(out), _p(probs), _p(weights), _p(rng), stream_id, p_drop, _stream()))
+
+
+def fusion_attn_bwd(B, M, E, heads, q, kv, probs, weights, dout, dq, dkv):
+    check(_lib.load().focal_fusion_attn_bwd(B, M, E, heads, _p(q), _p(kv), _p(probs), _p(weights), _p(dout), _p(dq), _p(dkv), _stream()))
+
+
+def small_linear_fwd(x, w, bias):
+    B, K = x.shape
+    y = torch.empty(B, w.shape[0], dtype=torch.float32, device=x.device)
+    check(_lib.load().focal_small_linear_fwd(B, w.shape[0], K, _p(x), _p(w), _p(bias), _p(y), _stream()))
+    return y
+
+
+def small_linear_bwd(dy, x, w, dw, dbias, need_dx=True):
+    B, K = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    check(_lib.load().focal_small_linear_bwd(B, w.shape[0], K, _p(dy), _p(x), _p(w), _p(dw), _p(dbias), _p(dx), _stream()))
+    return dx
+
+
+def cross_entropy(logits, labels):
+    """nn.CrossEntropyLoss() (mean): returns (loss [1] fp32, dlogits [B, C])."""
+    _need_cuda(logits, labels)
+    B, Cn = logits.shape
+    logits = logits.float().contiguous()
+    labels = labels.long().contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    check(_lib.load().focal_cross_entropy(B, Cn, _p(logits), _p(labels), _p(loss), _p(dlogits), _stream()))
+    return loss, dlogits
 
 
 def mean_time(x, B, T, D):

@@ -10,8 +10,10 @@ from . import distributed, ops, runtime
 
 
 class FocalAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, l2_decay=False):
+        """l2_decay=True gives torch.optim.Adam semantics (g += wd * p): the reference's finetune optimizer."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._l2 = bool(l2_decay)
         self._lr_dev = None
         self._lr_host = None
         self._step_state = None  # device {., step}: this optimizer's own step counter (AdamW bias correction)
@@ -29,6 +31,21 @@ class FocalAdamW(torch.optim.Optimizer):
                     seen.add(id(ar))
                     arenas.append(ar)
         return arenas
+
+    def _span(self, ar):
+        """[lo, hi) of the arena this optimizer updates.  Pretraining: everything.  Finetuning hands the optimizer only the
+        head's parameters (general_utils/weight_utils.py:61-80): they sit back to back at the arena's end, and the frozen
+        encoder weights in front of them must not even see weight decay -- torch skips parameters it was not given."""
+        mine = {id(p) for g in self.param_groups for p in g["params"]}
+        owned = [(ar.index[n][0], ar.index[n][1], id(p) in mine) for n, p in ar.params.items()]
+        if all(t for _, _, t in owned):
+            return 0, ar.size
+        sel = [(o, k) for o, k, t in owned if t]
+        lo, hi = min(o for o, _ in sel), max(o + k for o, k in sel)
+        hi = min(ar.size, (hi + 7) // 8 * 8)
+        if any((lo <= o < hi) and not t for o, _, t in owned):
+            raise ops._lib.FocalHipError("FocalAdamW: the parameters to update are not contiguous in the arena")
+        return lo, hi
 
     def zero_grad(self, set_to_none=True):
         # gradients are views of the arena's grad buffer: zero the buffer, keep the views
@@ -75,9 +92,10 @@ class FocalAdamW(torch.optim.Optimizer):
         segs = []
         for ar in arenas:
             m, v = ar.moments()
-            segs.append((ar.flat, ar.grad, m, v, ar.shadow))
+            lo, hi = self._span(ar)
+            segs.append((ar.flat[lo:hi], ar.grad[lo:hi], m[lo:hi], v[lo:hi], ar.shadow[lo:hi] if ar.shadow is not None else None))
         ops.adamw_multi(segs, self._lr_dev, self._step_state, g0["betas"][0], g0["betas"][1], g0["eps"],
-                        g0["weight_decay"])
+                        g0["weight_decay"], self._l2)
         for ar in arenas:
             ar.mark_shadow_fresh()
 

@@ -59,7 +59,11 @@ def _phase_shift(x, cfg):  # PhaseShiftAugmenter.py:39-54: rotate every complex 
     return dict(phase=(random() - 0.5) * 2 * math.pi)
 
 
-TIME_AUGMENTERS = {"no": None, "negation": _negation, "scaling": _scaling, "horizontal_flip": _horizontal_flip,
+def _mixup_unavailable(x, cfg):  # MixupAugmenter mixes samples AND labels (supervised `fixed` pipeline only): not on this path
+    raise NotImplementedError("mixup belongs to the supervised `fixed` augmentation pipeline, which this build does not run")
+
+
+TIME_AUGMENTERS = {"no": None, "mixup": _mixup_unavailable, "negation": _negation, "scaling": _scaling, "horizontal_flip": _horizontal_flip,
                    "permutation": _permutation, "time_warp": _spline_warp_unavailable("time_warp"),
                    "mag_warp": _spline_warp_unavailable("mag_warp")}
 FREQ_AUGMENTERS = {"no": None, "phase_shift": _phase_shift}

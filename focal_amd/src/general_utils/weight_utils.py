@@ -1,4 +1,4 @@
-"""Weight helpers on the pretraining path (reference: general_utils/weight_utils.py:9-25, 85-94)."""
+"""Weight helpers (reference: general_utils/weight_utils.py:9-25, 61-94)."""
 import torch
 
 
@@ -18,3 +18,14 @@ def freeze_patch_embedding(args, default_model):
             if "patch_embed" in name:
                 param.requires_grad = False
     return default_model
+
+
+def set_learnable_params_finetune(args, classifier):
+    """reference :61-80: FOCAL finetuning trains the class layer and the modality fusion layer, everything else is frozen."""
+    learnable = []
+    for name, param in classifier.named_parameters():
+        hit = ("class_layer" in name or "mod_fusion_layer" in name) if args.learn_framework in {"FOCAL"} else "class_layer" in name
+        param.requires_grad = hit
+        if hit:
+            learnable.append(param)
+    return learnable

@@ -13,6 +13,7 @@ if _ROOT not in sys.path:
 from focal_amd import runtime  # noqa: E402
 from focal_amd.backbone import HipBackbone, run_stage  # noqa: E402
 from focal_amd.deepsense_engine import DeepSenseModEncoder  # noqa: E402
+from focal_amd.head_engine import ClassifierHead  # noqa: E402
 from focal_amd.swin_engine import ProjectorHead  # noqa: E402
 from models.ConvModules import ConvBlock  # noqa: E402
 from models.FusionModules import MeanFusionBlock  # noqa: E402
@@ -79,6 +80,7 @@ class DeepSense(HipBackbone):
         self._encoders = {(loc, mod): DeepSenseModEncoder(self, loc, mod, mi)
                           for loc in self.locations for mi, mod in enumerate(self.modalities)}
         self._heads = {mod: ProjectorHead(self, mod) for mod in self.modalities}
+        self._class_head = ClassifierHead(self)
         self._buffers_by_name = None
 
     def buffer(self, name):
@@ -89,7 +91,7 @@ class DeepSense(HipBackbone):
 
     def forward_encoder(self, freq_x, class_head=True, proj_head=False, defer_join=False):
         if class_head:
-            raise NotImplementedError("class_head=True (supervised / finetune head) is outside the MI355X FOCAL pretraining hot path")
+            return self.forward_classifier(freq_x)
         loc = self.locations[0]
         view = self._fwd_calls
         self._fwd_calls = (self._fwd_calls + 1) & 0xFFFF
@@ -109,6 +111,18 @@ class DeepSense(HipBackbone):
         if not defer_join:  # FOCAL.forward joins once after both views so that their encoders overlap
             runtime.join_all(dev)
         return out
+
+    def forward_classifier(self, freq_x):
+        """`backbone(freq_x, class_head=True)` -> logits (reference: models/DeepSense.py:154-157).  This is the finetuning path: the encoders in front run
+        forward-only (finetuning freezes them, general_utils/weight_utils.py:61-80), the head -- the class layer on the concatenated features -- is one
+        differentiable node (focal_amd/head_engine.py)."""
+        if self._hot.__name__ != "is_hot_with_head":
+            raise NotImplementedError("class_head=True needs the classifier head in the parameter arena: build the model with "
+                                      "args.stage = 'finetune' (or supervised train_mode)")
+        with torch.no_grad():
+            feats = self.forward_encoder(freq_x, class_head=False, proj_head=False)
+        x = torch.cat([feats[m] for m in self.modalities], dim=1)
+        return run_stage(self, self._class_head, x, self.training)
 
     def forward(self, freq_x, class_head=True, proj_head=False, defer_join=False):
         return self.forward_encoder(freq_x, class_head, proj_head, defer_join)

@@ -16,6 +16,7 @@ if _ROOT not in sys.path:
 
 from focal_amd import runtime  # noqa: E402
 from focal_amd.backbone import HipBackbone, run_stage  # noqa: E402
+from focal_amd.head_engine import ClassifierHead  # noqa: E402
 from focal_amd.swin_engine import ProjectorHead, SwinModEncoder  # noqa: E402
 from input_utils.padding_utils import get_padded_size  # noqa: E402
 from models.FusionModules import TransformerFusionBlock  # noqa: E402
@@ -107,11 +108,11 @@ class SW_Transformer(HipBackbone):
         self._encoders = {(loc, mod): SwinModEncoder(self, loc, mod, mi)
                           for loc in self.locations for mi, mod in enumerate(self.modalities)}
         self._heads = {mod: ProjectorHead(self, mod) for mod in self.modalities}
+        self._class_head = ClassifierHead(self, "mod_fusion_layers", cfg["loc_head_num"], cfg["dropout_ratio"])
 
     def forward_encoder(self, freq_x, class_head=True, proj_head=False, defer_join=False):
         if class_head:
-            raise NotImplementedError("class_head=True (supervised / finetune head) is outside the MI355X FOCAL pretraining "
-                                      "hot path; use class_head=False")
+            return self.forward_classifier(freq_x)
         loc = self.locations[0]
         view = self._fwd_calls
         self._fwd_calls = (self._fwd_calls + 1) & 0xFFFF
@@ -131,6 +132,18 @@ class SW_Transformer(HipBackbone):
         if not defer_join:  # FOCAL.forward joins once after both views so that their encoders overlap
             runtime.join_all(dev)
         return out
+
+    def forward_classifier(self, freq_x):
+        """`backbone(freq_x, class_head=True)` -> logits (reference: models/SW_Transformer.py:269-276).  This is the finetuning path: the encoders in front run
+        forward-only (finetuning freezes them, general_utils/weight_utils.py:61-80), the head -- modality fusion + class layer -- is one
+        differentiable node (focal_amd/head_engine.py)."""
+        if self._hot.__name__ != "is_hot_with_head":
+            raise NotImplementedError("class_head=True needs the classifier head in the parameter arena: build the model with "
+                                      "args.stage = 'finetune' (or supervised train_mode)")
+        with torch.no_grad():
+            feats = self.forward_encoder(freq_x, class_head=False, proj_head=False)
+        x = torch.stack([feats[m] for m in self.modalities], dim=1)  # [b, M, c] (the reference's [b, 1, M, c] with i = 1)
+        return run_stage(self, self._class_head, x, self.training)
 
     def forward(self, freq_x, class_head=True, proj_head=False, defer_join=False):
         return self.forward_encoder(freq_x, class_head, proj_head, defer_join)

@@ -50,3 +50,27 @@ class FOCALLoss(nn.Module):
     def forward(self, mod_features1, mod_features2, index=None):
         feats = [mod_features1[m] for m in self.modalities] + [mod_features2[m] for m in self.modalities]
         return _LossHeadFn.apply(self, len(self.modalities), *feats)
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, dlogits = ops.cross_entropy(logits, labels)
+        ctx.save_for_backward(dlogits)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None
+
+
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss() of the finetune / supervised stages (reference: train_utils/model_selection.py:39-45), value and
+    gradient from one HIP launch (focal_cross_entropy); one-hot / soft labels are reduced to class indices as the reference's
+    evaluation does."""
+
+    def forward(self, logits, labels):
+        if labels.dim() > 1:
+            labels = labels.argmax(dim=1)
+        return _CrossEntropyFn.apply(logits, labels.to(logits.device))

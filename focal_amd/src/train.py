@@ -1,5 +1,5 @@
 """Entry point: `python train.py -model=SW_Transformer -dataset=MOD -learn_framework=FOCAL [-batch_size=N] [-gpu=0]`
-(reference: src/train.py:25-94).  Only the FOCAL pretraining stage is implemented in this build."""
+(reference: src/train.py:25-94).  FOCAL pretraining and finetuning (`-stage=finetune`) are implemented in this build."""
 import logging
 import os
 import sys
@@ -25,7 +25,10 @@ def train(args):
     if args.train_mode == "contrastive" and args.stage == "pretrain":
         return pretrain(args, classifier, augmenter, train_dataloader, val_dataloader, test_dataloader, loss_func,
                         len(train_dataloader))
-    raise Exception(f"Invalid stage ({args.stage}) provided: only FOCAL pretraining is implemented on the HIP path.")
+    if args.train_mode == "contrastive" and args.stage == "finetune":
+        from train_utils.finetune import finetune
+        return finetune(args, classifier, augmenter, train_dataloader, val_dataloader, test_dataloader, loss_func, len(train_dataloader))
+    raise Exception(f"Invalid stage ({args.stage}) provided: FOCAL pretraining and finetuning are implemented on the HIP path.")
 
 
 def main_train():

@@ -1,5 +1,5 @@
-"""Validation of a model under pretraining (reference: train_utils/eval_functions.py:10-26, 65-97, 99-137): mean pretraining
-loss on the split plus accuracy / macro-F1 / confusion matrix of the KNN estimator on the backbone features."""
+"""Validation (reference: train_utils/eval_functions.py:10-137): under pretraining the mean pretraining loss plus accuracy /
+macro-F1 / confusion matrix of the KNN estimator on the backbone features; under finetuning the classifier's own loss and metrics."""
 import logging
 
 import numpy as np
@@ -25,6 +25,21 @@ def eval_task_metrics(args, labels, predictions):
     return mean_acc, mean_f1, conf
 
 
+def eval_supervised_model(args, classifier, augmenter, dataloader, loss_func):
+    """Loss and task metrics of a classifier (reference :29-62)."""
+    classifier.eval()
+    losses, preds, labs = [], [], []
+    with torch.no_grad():
+        for time_loc_inputs, labels in dataloader:
+            freq_loc_inputs, labels = augmenter.forward("no", time_loc_inputs, labels)
+            logits = classifier(freq_loc_inputs)
+            losses.append(loss_func(logits, labels).item())
+            labels = labels.argmax(dim=1) if labels.dim() > 1 else labels
+            preds.append(logits.argmax(dim=1).cpu().numpy())
+            labs.append(labels.cpu().numpy())
+    return float(np.mean(losses)), eval_task_metrics(args, np.concatenate(labs), np.concatenate(preds))
+
+
 def eval_pretrained_model(args, default_model, estimator, augmenter, dataloader, loss_func):
     default_model.eval()
     feats, labels, losses = [], [], []
@@ -39,11 +54,16 @@ def eval_pretrained_model(args, default_model, estimator, augmenter, dataloader,
 
 
 def val_and_logging(args, epoch, model, augmenter, val_loader, test_loader, loss_func, train_loss, estimator=None):
-    logging.info(f"Train {args.train_mode} loss: {train_loss: .5f} \n")
+    if args.train_mode in {"contrastive"} and args.stage == "pretrain":
+        logging.info(f"Train {args.train_mode} loss: {train_loss: .5f} \n")
+    else:
+        logging.info(f"Training loss: {train_loss: .5f} \n")
     if args.train_mode == "supervised" or args.stage == "finetune":
-        raise NotImplementedError("supervised / finetune evaluation is outside the FOCAL pretraining path (DESIGN.md section 6)")
-    val_loss, val_metrics = eval_pretrained_model(args, model, estimator, augmenter, val_loader, loss_func)
-    test_loss, test_metrics = eval_pretrained_model(args, model, estimator, augmenter, test_loader, loss_func)
+        val_loss, val_metrics = eval_supervised_model(args, model, augmenter, val_loader, loss_func)
+        test_loss, test_metrics = eval_supervised_model(args, model, augmenter, test_loader, loss_func)
+    else:
+        val_loss, val_metrics = eval_pretrained_model(args, model, estimator, augmenter, val_loader, loss_func)
+        test_loss, test_metrics = eval_pretrained_model(args, model, estimator, augmenter, test_loader, loss_func)
     logging.info(f"Val loss: {val_loss: .5f}")
     logging.info(f"Val acc: {val_metrics[0]: .5f}, val f1: {val_metrics[1]: .5f}")
     logging.info(f"Val confusion matrix:\n {val_metrics[2]} \n")

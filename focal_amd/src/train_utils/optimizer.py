@@ -22,4 +22,6 @@ def define_optimizer(args, parameters):
     wd = cfg["weight_decay"][args.model] if isinstance(cfg["weight_decay"], dict) else cfg["weight_decay"]
     if cfg["name"] == "AdamW":
         return FocalAdamW(parameters, lr=cfg["start_lr"], weight_decay=wd)
-    raise NotImplementedError(f"Optimizer {cfg['name']} is outside the MI355X pretraining hot path (AdamW only).")
+    if cfg["name"] == "Adam":  # torch.optim.Adam: L2 weight decay folded into the gradient (the finetune optimizer)
+        return FocalAdamW(parameters, lr=cfg["start_lr"], weight_decay=wd, l2_decay=True)
+    raise NotImplementedError(f"Optimizer {cfg['name']} not implemented.")

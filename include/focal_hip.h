@@ -213,6 +213,24 @@ int focal_mean_time(int B, int T, int D, const float* x, float* y, void* stream)
 int focal_dropout(long n, const float* x, float* y, const uint32_t* rng, uint32_t stream_id, float p, void* stream); /* y = x * mask */
 int focal_axpy(long n, float a, const float* x, float* y, void* stream);                                   /* y += a * x */
 
+/* ------------------------------------------------------------------------------------------------ classifier head (8f rank 4)
+ * Finetuning path, `backbone(freq_x, class_head=True)` (models/SW_Transformer.py:269-276, models/FusionModules.py:61-140):
+ * focal_fusion_attn_*: the attention core of TransformerFusionBlock -- one query per sample (the mean of the M fused tokens,
+ * after in_proj) over the M modality tokens, nn.MultiheadAttention semantics with head_dim 64: q [B, E] (in_proj applied),
+ * kv [B*M, 2E] rows (b, j) = {k | v}, out [B, E] (before out_proj); probs / weights [B, heads, M] = softmax and softmax x
+ * attention-dropout mask (saved for backward).  Backward writes dq [B, E] and dkv [B*M, 2E].
+ * focal_cross_entropy: nn.CrossEntropyLoss(), mean reduction: loss[0] and dlogits = d loss / d logits in one launch. */
+int focal_fusion_attn_fwd(int B, int M, int E, int heads, const float* q, const float* kv, float* out, float* probs, float* weights,
+                          const uint32_t* rng, uint32_t stream_id, float p_drop, void* stream);
+int focal_fusion_attn_bwd(int B, int M, int E, int heads, const float* q, const float* kv, const float* probs, const float* weights,
+                          const float* dout, float* dq, float* dkv, void* stream);
+int focal_cross_entropy(int B, int C, const float* logits, const long* labels, float* loss, float* dlogits, void* stream);
+/* The class layer nn.Linear(K -> n_cls) (a few output columns, fp32): y = x w^T + bias; backward accumulates dw / dbias (+=) and
+ * writes dx when it is non-NULL. */
+int focal_small_linear_fwd(int B, int N, int K, const float* x, const float* w, const float* bias, float* y, void* stream);
+int focal_small_linear_bwd(int B, int N, int K, const float* dy, const float* x, const float* w, float* dw, float* dbias, float* dx,
+                           void* stream);
+
 /* ------------------------------------------------------------------------------------------------ rows 11-13: loss
  * FOCALLoss.forward (models/loss.py:139-218): 2 InfoNCE families on the shared / private halves, orthogonality,
  * temporal ranking.  feats / dfeats are HOST arrays of 2*n_mod device pointers, view-major
@@ -233,7 +251,7 @@ int focal_loss_head(const focal_loss_desc* d, const float* const* feats, float* 
  * trainable region; grad-less parameters are simply not listed, which is how torch skips them).  lr comes from a
  * device scalar and the step count from rng_state[1] (1-based after focal_rng_advance) so a captured graph stays
  * valid across epochs.  shadow (nullable) receives the bf16 copy of the updated weights for the matrix cores. */
-typedef struct { float beta1, beta2, eps, weight_decay; } focal_adamw_desc;
+typedef struct { float beta1, beta2, eps, weight_decay; int l2_decay; /* 0: decoupled decay (torch.optim.AdamW); 1: L2 form, g += wd * p (torch.optim.Adam, the finetune optimizer) */ } focal_adamw_desc;
 int focal_adamw_multi(const focal_adamw_desc* d, int nseg, float* const* p, const float* const* g, float* const* m,
                       float* const* v, void* const* shadow_bf16, const long* n, const float* lr_dev,
                       const uint32_t* rng_state, void* stream);

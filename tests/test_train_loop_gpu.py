@@ -77,3 +77,21 @@ def test_pretraining_from_packed_shards_and_from_sample_files(cfg, tmp_path):
             vals.append(calc_pretrain_loss(args, model, aug, loss_fn, time_loc_inputs).item())
         losses[kind] = vals
     assert all(abs(a - b) < 1e-4 * max(1.0, abs(a)) for a, b in zip(losses["files"], losses["packed"])), losses
+
+
+@pytest.mark.parametrize("model", ["SW_Transformer", "DeepSense"])
+def test_finetune_stage_runs_on_pretrained_weights(model):
+    """`train.py -stage=finetune` (reference: train_utils/finetune.py): loads the pretraining weights, trains the classifier
+    head only, validates with the classifier's own loss / accuracy, writes latest / best weights."""
+    src = os.path.join(ROOT, "focal_amd", "src")
+    base = [sys.executable, os.path.join(src, "train.py"), f"-model={model}", "-dataset=MOD", "-learn_framework=FOCAL",
+            "-batch_size=16", "-synthetic_batches=2"]
+    r = subprocess.run(base + ["-epochs=1"], capture_output=True, text=True, timeout=900, cwd=src)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    r = subprocess.run(base + ["-stage=finetune", "-epochs=2"], capture_output=True, text=True, timeout=900, cwd=src)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0, log[-3000:]
+    for needle in ("Training loss:", "Val acc:", "Test acc:", "Total processing time"):
+        assert needle in log, (needle, log[-2000:])
+    wdir = os.path.join(ROOT, "weights", f"MOD_{model}")
+    assert any(f.endswith("finetune_latest.pt") for f in os.listdir(wdir))
