@@ -9,6 +9,7 @@
 // Compute type CT is bf16 (v_mfma_f32_16x16x32_bf16) or f32 (v_mfma_f32_16x16x4_f32, exact fp32 -- the parity mode).
 // The MFMA is issued as D = Bfrag x Afrag so that a lane ends up with 4 consecutive n for one m: 8/16-byte stores.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 enum GemmPro { PRO_NONE = 0, PRO_GELU = 1, PRO_MASK = 2, PRO_CONV = 3 };
@@ -138,10 +139,22 @@ template <typename CT, typename TG, bool TRANS, int PRO, int BI, int BKM> struct
   static constexpr int NCH = (BK / EC) * BI / 256;  // 16-byte chunks per thread
   static constexpr int CPR = TRANS ? BI / EC : BK / EC;
   RawChunk<TG, EC> raw[NCH];
+  long off[NCH];  // element offset of each of this thread's chunks at r0 = 0: the 64-bit row * ld products are formed once per
+                  // workgroup, not once per k-step (they were ~6 vector instructions per load, three of them quarter-rate)
+
+  __device__ __forceinline__ void init(long ld, int i0, int tid) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = tid + 256 * j;
+      const int a = c / CPR, b = (c % CPR) * EC;
+      off[j] = TRANS ? (long)a * ld + (i0 + b) : (long)(i0 + a) * ld + b;
+    }
+  }
 
   // i_ext: extent of the non-reduced index, r_ext: extent of the reduced index (both in elements)
   __device__ __forceinline__ void load(const TG* base, long ld, int i0, int r0, int i_ext, int r_end, int tid,
                                        const MaskEval& me) {
+    const TG* step_base = base + (TRANS ? (long)r0 * ld : (long)r0);  // uniform: scalar arithmetic
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = tid + 256 * j;
@@ -150,12 +163,12 @@ template <typename CT, typename TG, bool TRANS, int PRO, int BI, int BKM> struct
         const int r = r0 + a, i = i0 + b;
         bool ok = (r < r_end) && (i < i_ext);
         if (PRO == PRO_CONV) ok = ok && me.conv_valid(r, i, me.pad);  // out-of-window taps are never dereferenced
-        raw_load(raw[j], base + (long)r * ld + i, ok);
+        raw_load(raw[j], step_base + off[j], ok);
       } else {  // memory [i][r]
         const int i = i0 + a, r = r0 + b;
         bool ok = (i < i_ext) && (r < r_end);
         if (PRO == PRO_CONV) ok = ok && me.conv_valid(i, r, me.pad);
-        raw_load(raw[j], base + (long)i * ld + r, ok);
+        raw_load(raw[j], step_base + off[j], ok);
       }
     }
   }
@@ -168,6 +181,13 @@ template <typename CT, typename TG, bool TRANS, int PRO, int BI, int BKM> struct
     for (int j = 0; j < NCH; ++j) {
       const int c = tid + 256 * j;
       const int a = c / CPR, b = (c % CPR) * EC;
+      if (std::is_same<TG, CT>::value && PRO == PRO_NONE && !CSUM) {
+        // already in the operand dtype and nothing to apply: a 16-byte copy (going through fp32 and back costs 12 vector
+        // instructions per chunk that the compiler cannot fold away -- NaN payloads -- 48 per k-step beside 8 MFMAs)
+#pragma unroll
+        for (int q = 0; q < RawChunk<TG, EC>::R; ++q) reinterpret_cast<uint4*>(lds + a * PITCH + b)[q] = raw[j].v[q];
+        continue;
+      }
       float f[8];
       raw_to_f32(raw[j], f);
       if (TRANS) apply_prologue<PRO>(f, EC, r0 + a, i0 + b, me);
@@ -369,6 +389,12 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
     }
     __syncthreads();
   };
+  sa0.init(p.lda, m0, tid);
+  sb0.init(p.ldb, n0, tid);
+  if (PF2) {
+    sa1.init(p.lda, m0, tid);
+    sb1.init(p.ldb, n0, tid);
+  }
   if (kt0 < kt1) {
     sa0.load(A, p.lda, m0, kt0 * BK, p.M, k_end, tid, meA);
     sb0.load(B, p.ldb, n0, kt0 * BK, p.N, k_end, tid, meB);
