@@ -98,19 +98,15 @@ __device__ __forceinline__ void tile_softmax(const AttnGeom& g, const TileIdx& t
     for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - m); sum += s[r]; }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[r] *= inv;
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float m = s[r];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-      float e = __expf(s[r] - m), sum = e;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-      s[r] = e / sum;
+      const float m = row16_max(s[r]);
+      const float e = __expf(s[r] - m);
+      s[r] = e * __builtin_amdgcn_rcpf(row16_sum(e));
     }
   }
 }
@@ -254,8 +250,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       const float m = (drop_on && ok) ? drop_mult(dc, (wbase + i) * g.N + j) : 1.f;
       const float dp = d1[r] * m;
       float dot = ok ? p1[r] * dp : 0.f;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
+      dot = row16_sum(dot);
       ds1[r] = ok ? p1[r] * (dp - dot) : 0.f;
       pd1[r] = ok ? p1[r] * m : 0.f;
       if (live) dbreg[r] += ds1[r];  // ds1 is 0 outside the window

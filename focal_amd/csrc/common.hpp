@@ -90,6 +90,27 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// All-reduce inside each row of 16 lanes with DPP modifiers (quad_perm xor 1, xor 2, row_half_mirror, row_mirror): four VALU
+// instructions, no LDS.  __shfl_xor compiles to ds_bpermute_b32 -- an LDS-pipe round trip and an s_waitcnt each; the MFMA
+// attention kernels did 74 of them per (window, head).
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);  // row_half_mirror (quads now hold equal values: i <-> 7 - i joins the two quads of a half)
+  v += dpp_f32<0x140>(v);  // row_mirror      (i <-> 15 - i joins the two halves)
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
