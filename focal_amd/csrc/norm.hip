@@ -18,6 +18,11 @@ struct RowMap {
 };
 
 __device__ __forceinline__ float group_sum(float v, int lpr) {
+  if (lpr >= 16) {  // the 16-lane part with DPP row operations (no LDS round trips), whole rows beyond that by shuffle
+    v = row16_sum(v);
+    for (int o = 16; o < lpr; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  }
   for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
