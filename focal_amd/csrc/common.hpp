@@ -79,6 +79,21 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
   cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
   pdf = 0.39894228040143268f * e;
 }
+// Two elements at a time on 2-wide vectors: the polynomial, the scalings and the final combinations compile to packed fp32
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), half the issue slots of the scalar form; v_exp / v_rcp stay per element.
+typedef float gelu_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_parts2(gelu_f2 x, gelu_f2& cdf, gelu_f2& pdf) {
+  const gelu_f2 ax = {fabsf(x.x), fabsf(x.y)};
+  const gelu_f2 z = ax * 0.70710678118654752f;
+  const gelu_f2 d = z * 0.3275911f + 1.0f;
+  const gelu_f2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const gelu_f2 nz2 = -(z * z);
+  const gelu_f2 e = {__expf(nz2.x), __expf(nz2.y)};
+  const gelu_f2 poly = t * (t * (t * (t * (t * 1.061405429f - 1.453152027f) + 1.421413741f) - 0.284496736f) + 0.254829592f);
+  const gelu_f2 h = poly * e * -0.5f + 0.5f;  // 0.5 * erf(|x| / sqrt 2)
+  cdf = gelu_f2{copysignf(h.x, x.x), copysignf(h.y, x.y)} + 0.5f;
+  pdf = e * 0.39894228040143268f;
+}
 __device__ __forceinline__ float gelu_f(float x) {
   float cdf, pdf;
   gelu_parts(x, cdf, pdf);

@@ -509,12 +509,14 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
         } else if (EPI == EPI_GELU_FWD) {
           float g[CPL];
 #pragma unroll
-          for (int e = 0; e < CPL; ++e) {
-            float cdf, pdf;
-            gelu_parts(v[e], cdf, pdf);
-            const float mult = meE.elem_mult(m, n + e);
-            g[e] = (cdf + v[e] * pdf) * mult;
-            v[e] = v[e] * cdf * mult;
+          for (int e = 0; e < CPL; e += 2) {
+            const gelu_f2 x = {v[e], v[e + 1]};
+            gelu_f2 cdf, pdf;
+            gelu_parts2(x, cdf, pdf);
+            const gelu_f2 mult = {meE.elem_mult(m, n + e), meE.elem_mult(m, n + e + 1)};
+            const gelu_f2 gg = (x * pdf + cdf) * mult, hh = x * cdf * mult;
+            g[e] = gg.x; g[e + 1] = gg.y;
+            v[e] = hh.x; v[e + 1] = hh.y;
           }
           storeN<CPL>(dst, v);
           storeN<CPL>(reinterpret_cast<TC*>(p.aux_out) + (long)m * p.ldc + n, g);
