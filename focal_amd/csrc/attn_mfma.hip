@@ -76,14 +76,17 @@ template <bool ROWS_ARE_KEYS> __device__ __forceinline__ TileIdx make_tile_idx(c
 // softmax of a score tile.  ROWS_ARE_KEYS: lane holds keys j = 4g + r of query i = l & 15 (S^T layout), otherwise
 // lane holds queries i = 4g + r and key j = l & 15 (S layout).  Returns probabilities in s[].
 template <bool ROWS_ARE_KEYS>
-__device__ __forceinline__ void tile_softmax(const AttnGeom& g, const TileIdx& t, float* s, int h, const float* bias_table, int reg_own) {
+__device__ __forceinline__ void tile_softmax(const AttnGeom& g, const TileIdx& t, float* s, const float* bias, int reg_own, bool edge) {
+  // bias[r] = relative-position bias of this lane's (i, j) for the current head: it depends on the lane and the head only, so the
+  // callers reload it when the head changes instead of fetching it from the table for every window
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const bool cross = __shfl(reg_own, t.qi[r], 64) != __shfl(reg_own, t.kj[r], 64);  // shuffles outside divergent code
+    bool cross = false;
+    if (edge) cross = __shfl(reg_own, t.qi[r], 64) != __shfl(reg_own, t.kj[r], 64);  // (wave-uniform branch: shuffles stay convergent)
     float v = -1.0e30f;
     if (t.ok[r]) {
-      v = s[r] * g.scale + bias_table[t.rel[r] + h];
-      if (g.shifted && cross) v += -100.0f;  // SwinModules.py:287
+      v = s[r] * g.scale + bias[r];
+      if (cross) v += -100.0f;  // SwinModules.py:287
     } else if (t.qpad[r]) {
       v = 0.f;
     }
@@ -142,10 +145,13 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
   const int C = g.C;
   const TileIdx tA = make_tile_idx<true>(g, lane);
   const int slot = lane & 15, sy = slot / g.ww, sx = slot - sy * g.ww;
+  float biasA[4] = {0.f, 0.f, 0.f, 0.f};
+  int h_cur = -1;
   for (int it = 0; it < iters; ++it) {
     const int item = (it * gridDim.x + blockIdx.x) * 4 + wave;
     const bool live = item < total_items;
     const int win = live ? item / g.heads : 0, h = live ? item % g.heads : 0;
+    const bool edge = g.shifted;  // (restricting this to the windows that really mix mask regions costs more in index arithmetic than it saves)
     int reg_own = 0;
     const int tok_own = slot < g.N ? slot_token(g, win, sy, sx, &reg_own) : 0;
     wave_lds_fence();  // previous iteration's fragment reads are issued before these tile writes
@@ -157,7 +163,12 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
 #pragma unroll
     for (int kk = 0; kk < HD / 16; ++kk) st = mma16x16(frag_rows(Kt, P, kk, lane), frag_rows(Qt, P, kk, lane), st);
     float p[4] = {st[0], st[1], st[2], st[3]};
-    tile_softmax<true>(g, tA, p, h, bias_table, reg_own);
+    if (h != h_cur) {
+      h_cur = h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) biasA[r] = tA.ok[r] ? bias_table[tA.rel[r] + h] : 0.f;
+    }
+    tile_softmax<true>(g, tA, p, biasA, reg_own, edge);
     const int i = lane & 15;
     if (drop_on) {
       const uint32_t base = (((uint32_t)win * g.heads + h) * g.N + i) * g.N;
@@ -211,10 +222,13 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       dbreg[r] = 0.f;
     }
   };
+  float biasA[4] = {0.f, 0.f, 0.f, 0.f}, biasB[4] = {0.f, 0.f, 0.f, 0.f};
+  int h_cur = -1;
   for (int it = 0; it < iters; ++it) {
     const int item = (it * gridDim.x + blockIdx.x) * NW + wave;
     const bool live = item < total_items;
     const int win = live ? item / g.heads : 0, h = live ? item % g.heads : 0;
+    const bool edge = g.shifted;  // (restricting this to the windows that really mix mask regions costs more in index arithmetic than it saves)
     if (live && h != h_acc) {
       flush_dbias();
       h_acc = h;
@@ -238,8 +252,16 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       d2 = mma16x16(fv, fg, d2);  // dPd^T
     }
     float p1[4] = {s1[0], s1[1], s1[2], s1[3]}, p2[4] = {s2[0], s2[1], s2[2], s2[3]};
-    tile_softmax<false>(g, tB, p1, h, bias_table, reg_own);
-    tile_softmax<true>(g, tA, p2, h, bias_table, reg_own);
+    if (h != h_cur) {
+      h_cur = h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        biasA[r] = tA.ok[r] ? bias_table[tA.rel[r] + h] : 0.f;
+        biasB[r] = tB.ok[r] ? bias_table[tB.rel[r] + h] : 0.f;
+      }
+    }
+    tile_softmax<false>(g, tB, p1, biasB, reg_own, edge);
+    tile_softmax<true>(g, tA, p2, biasA, reg_own, edge);
     const uint32_t wbase = ((uint32_t)win * g.heads + h) * g.N;
     // ---- layout 1: rows i = 4*grp + r, col j
     float ds1[4], pd1[4];
