@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
                                                                    const uint32_t* rng, uint32_t stream, float p_attn) {
   constexpr int P = HD + 4, TILE = 16 * P;
   __shared__ __attribute__((aligned(16))) bf16_t tiles[4][3][TILE];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: item, window and head arithmetic then runs on the SALU
   bf16_t* Qt = tiles[wave][0];
   bf16_t* Kt = tiles[wave][1];
   bf16_t* Vt = tiles[wave][2];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
   constexpr int P = HD + 4, TILE = 16 * P;
   __shared__ __attribute__((aligned(16))) bf16_t tiles[NW][4][TILE];
   __shared__ float dbacc[256];  // (2wh-1)(2ww-1) x heads <= 256 entries
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: item, window and head arithmetic then runs on the SALU
   bf16_t* Qt = tiles[wave][0];
   bf16_t* Kt = tiles[wave][1];
   bf16_t* Vt = tiles[wave][2];
