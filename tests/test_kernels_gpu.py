@@ -537,9 +537,14 @@ def test_product_augmenter_random_views_follow_the_oracle(ops, cfg, monkeypatch)
         calls.append((x, kw))
         return real(x, **kw)
     monkeypatch.setattr(A.ops, "fft_realpack", spy)
+    import random
+    import numpy as np
+    random.seed(12)  # the augmenter draws from `random`, numpy and torch: fix all three so the coverage check below is deterministic
+    np.random.seed(12)
+    torch.manual_seed(12)
     tx = {"shake": {"audio": torch.randn(2, 1, 10, 1600), "seismic": torch.randn(2, 1, 10, 20)}}
     seen = set()
-    for _ in range(24):
+    for _ in range(64):
         calls.clear()
         out = aug.forward("random", tx)
         assert list(out["shake"].keys()) == ["audio", "seismic"]
@@ -556,7 +561,7 @@ def test_product_augmenter_random_views_follow_the_oracle(ops, cfg, monkeypatch)
             if "phase" in kw:
                 f = oa.phase_shift(f, kw["phase"])
             assert (out["shake"][m].cpu() - f).abs().max().item() < 2e-4 * math.sqrt(x.shape[-1]) * 2
-    assert {"scale", "flip", "perm", "phase"} <= seen  # 24 draws from a 7-entry pool at p = 0.5 each: all four kinds appear
+    assert {"scale", "flip", "perm", "phase"} <= seen  # 64 seeded draws from a 7-entry pool at p = 0.5 each: all four kinds appear
 
 
 def test_gpu_knn_matches_sklearn(ops):
