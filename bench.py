@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=4)
     p.add_argument("--roofline-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
     p.add_argument("--roofline-iters", type=int, default=20)
+    p.add_argument("--no-roofline", action="store_true", help="profiling runs: skip the dominant-kernel timing loop (the JSON line then has roofline null)")
     return p.parse_args()
 
 
@@ -362,7 +363,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     last_loss = step.loss.item()
-    rl = roofline(a, step, device) if rank == 0 else None
+    rl = roofline(a, step, device) if (rank == 0 and not a.no_roofline) else None
     cb = cpu_baseline(a, step.cfg) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
     if rank == 0:
         wps = a.batch * world * a.steps / dt

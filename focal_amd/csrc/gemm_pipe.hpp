@@ -1,0 +1,235 @@
+// Pipelined bf16 GEMM for the deep Swin stages (M = 9 k - 74 k tokens, K, N = 128 - 1024):
+//
+//   C[m][n] = epi( sum_k A[m][k] * W[n][k] + bias[n] )        A: [M][K] bf16, W: [N][K] bf16 (both k-contiguous)
+//
+// The 64 x 64 kernel of gemm.hpp hides load latency with occupancy (5-6 workgroups per CU, one k-step in flight
+// each) and reads every fragment it multiplies from LDS 1.25 times per MFMA; at these shapes that leaves the matrix
+// pipe 12 % busy.  This kernel trades occupancy for a pipeline inside the workgroup:
+//   * 128-row tiles, 2 x 2 waves, 64 x (BN / 2) outputs per wave: 0.5 - 0.75 fragment reads per MFMA;
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into an
+//     NST-deep ring; NST - 1 k-steps are in flight while one is multiplied; ONE raw s_barrier per k-step with a
+//     counted s_waitcnt vmcnt (never a __syncthreads(): its fence would drain the ring);
+//   * an LDS-DMA wave-instruction writes 1 KB contiguously (8 rows x 128 B), so rows cannot be padded: the 16-byte
+//     chunk c of tile row r is stored at chunk position c ^ ((r >> 1) & 7) -- applied on the per-lane SOURCE address
+//     when filling and on the ds_read_b128 address when reading (16 lanes of a fragment read then cover all 64 banks).
+// The W operand is either [N][K] (forward) or [K][N] (TRB: the same weight read for a data gradient; fragments by
+// ds_read_b64_tr_b16 from a [64 k][BN] image with its own swizzle) -- no transposed copy of a weight exists in HBM.
+// Requires N % BN == 0, K % 64 == 0, 16-byte aligned rows (the dispatcher checks; everything else stays on gemm.hpp's
+// kernel); M may be ragged.
+#pragma once
+#include "gemm.hpp"
+
+template <int N> __device__ __forceinline__ void pipe_wait_barrier() {
+  // all of this wave's LDS-DMA pieces except the newest N have landed; then meet the other waves
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+typedef __attribute__((address_space(3))) void* pipe_lds_ptr;
+typedef const __attribute__((address_space(1))) void* pipe_glb_ptr;
+
+template <typename TC, int EPI, bool TRB, int BM, int BN, int NST, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const GemmParams p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int BK = 64;                       // bf16 elements = 128 B = one LDS row
+  constexpr int WR = BM / WGM, WC = BN / WGN;  // per-wave output
+  constexpr int TM = WR / 16, TN = WC / 16;
+  constexpr int ROWS = BM + BN;                // LDS rows per stage (A rows then W rows)
+  constexpr int STAGE_BYTES = ROWS * 128;
+  constexpr int LPW = ROWS / (8 * NW);         // LDS-DMA pieces (8 rows each) per wave per stage
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "a piece index must be an A piece or a W piece for all waves");
+  constexpr int WPITCH = WC + 4;
+  constexpr int EPI_BYTES = NW * 16 * WPITCH * 4;
+  constexpr int LDS_BYTES = NST * STAGE_BYTES > EPI_BYTES ? NST * STAGE_BYTES : EPI_BYTES;
+  extern __shared__ __attribute__((aligned(1024))) char pipe_lds[];
+  static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit in LDS");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = logical % ntiles, bz = logical / ntiles;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)bz * p.strideA;
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.B) + (long)bz * p.strideB;
+  TC* C = reinterpret_cast<TC*>(p.C) + (long)bz * p.strideC;
+  const int KT = p.K / BK;
+
+  // ---- fill plan: piece q = wave + 4 t covers stage rows 8 q .. 8 q + 7; lane -> (row 8 q + lane / 8, position lane % 8)
+  // and fetches chunk position ^ swizzle(row) of that row.  Per-lane byte offsets from the (uniform) operand bases.
+  uint32_t goff[LPW];
+  const char* gbase[LPW];
+  long gstep[LPW];  // bytes per k-step
+#pragma unroll
+  for (int t = 0; t < LPW; ++t) {
+    const int q = wave + NW * t;
+    if (8 * NW * t < BM) {  // piece index t is an A piece for all waves or a W piece for all waves
+      const int row = 8 * q + (lane >> 3), pos = lane & 7;
+      const int chunk = pos ^ ((row >> 1) & 7);
+      const int srow = min(row, p.M - 1 - m0);  // ragged last tile: re-read the last valid row (its products are never stored)
+      goff[t] = (uint32_t)(((long)srow * p.lda + chunk * 8) * 2);
+      gbase[t] = reinterpret_cast<const char*>(A + (long)m0 * p.lda);
+      gstep[t] = 128;
+    } else if (!TRB) {
+      const int row = 8 * q + (lane >> 3) - BM, pos = lane & 7;
+      const int chunk = pos ^ ((row >> 1) & 7);
+      goff[t] = (uint32_t)(((long)row * p.ldb + chunk * 8) * 2);
+      gbase[t] = reinterpret_cast<const char*>(W + (long)n0 * p.ldb);
+      gstep[t] = 128;
+    } else {
+      // W stored [k][n] (the weight of a data-gradient product): the stage image is [64 k][BN], rows of BN * 2 bytes; a piece is
+      // 4 (BN = 128) or 8 (BN = 64) k-rows.  16-byte chunk c of k-row r sits at position c ^ ((r & 3) << 1): the four k-rows
+      // that one ds_read_b64_tr_b16 lane group touches then fall in four different 32-byte bank groups.
+      constexpr int CPRW = BN / 8, RPP = 64 / CPRW;  // 16-byte chunks per k-row, k-rows per piece
+      const int krow = (q - BM / 8) * RPP + lane / CPRW, pos = lane % CPRW;
+      const int chunk = pos ^ ((krow & 3) << 1);
+      goff[t] = (uint32_t)(((long)krow * p.ldb + chunk * 8) * 2);
+      gbase[t] = reinterpret_cast<const char*>(W + n0);
+      gstep[t] = (long)64 * p.ldb * 2;
+    }
+  }
+  auto fill = [&](int kt, int stage) {
+#pragma unroll
+    for (int t = 0; t < LPW; ++t) {
+      const int q = wave + NW * t;
+      char* dst = pipe_lds + stage * STAGE_BYTES + q * 1024;
+      __builtin_amdgcn_global_load_lds((pipe_glb_ptr)(gbase[t] + (long)kt * gstep[t] + goff[t]), (pipe_lds_ptr)dst, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a stage: row (lane & 15) of a 16-row tile, chunk (kk * 4 + lane / 16) ^ swizzle
+  const int swz = (lane >> 1) & 7, g = lane >> 4;
+  const int fo0 = (lane & 15) * 128 + ((g ^ swz) << 4), fo1 = (lane & 15) * 128 + (((4 + g) ^ swz) << 4);
+  const int a_off = wm * WR * 128, b_off = (BM + wn * WC) * 128;
+  // transposed W: this lane reads k-row 8 g + q (and + 4), columns 4 p .. 4 p + 3 of a 16-column tile (q = (lane & 15) >> 2, p = lane & 3)
+  const int tr_krow = 8 * g + ((lane & 15) >> 2), tr_swz = ((lane & 15) >> 2) << 1;
+  const int tr_in = ((lane & 3) >> 1) * 16 + (lane & 1) * 8;  // byte offset of columns 4 p .. 4 p + 3 inside their pair of 16-byte chunks
+
+  auto compute = [&](int stage) {
+    const char* s = pipe_lds + stage * STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int fo = kk ? fo1 : fo0;
+      bf16x8 xa[TM], wb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(s + a_off + i * 2048 + fo);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!TRB) {
+          wb[j] = *reinterpret_cast<const bf16x8*>(s + b_off + j * 2048 + fo);
+        } else {
+          typedef __attribute__((address_space(3))) bf16x4* tr_ptr;
+          const char* a0 = s + BM * 128 + (kk * 32 + tr_krow) * (BN * 2) + ((((wn * WC + j * 16) >> 3) ^ tr_swz) << 4) + tr_in;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr)(a0));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr)(a0 + 4 * BN * 2));
+          wb[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mma16(wb[j], xa[i], acc[i][j]);
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < KT) fill(s, s);
+  int stage = 0, fstage = NST - 1;
+  for (int kt = 0; kt < KT; ++kt) {
+    // k-steps issued so far: min(KT, kt + NST - 1); step kt must have landed -> leave min(NST - 2, KT - 1 - kt) steps in flight
+    const int ahead = KT - 1 - kt;
+    if (NST >= 4 && ahead >= 2) pipe_wait_barrier<2 * LPW>();
+    else if (NST >= 3 && ahead >= 1) pipe_wait_barrier<(NST >= 3 ? LPW : 0)>();
+    else pipe_wait_barrier<0>();
+    if (kt + NST - 1 < KT) fill(kt + NST - 1, fstage);  // overwrites the stage multiplied in iteration kt - 1: every wave is past it
+    compute(stage);
+    stage = (stage + 1 == NST) ? 0 : stage + 1;
+    fstage = (fstage + 1 == NST) ? 0 : fstage + 1;
+  }
+  asm volatile("s_barrier" ::: "memory");  // the ring is re-used as epilogue staging
+
+  // ---- epilogue: transpose 16 rows at a time through a wave-private LDS region, then walk it row-major (16 B per lane)
+  float* est = reinterpret_cast<float*>(pipe_lds) + wave * 16 * WPITCH;
+  MaskEval meE;
+  if (EPI == EPI_RESID || EPI == EPI_GELU_FWD) meE.init(p.epi);
+  constexpr int CPL = (sizeof(TC) == 2) ? 8 : 4;
+  constexpr int LPR = WC / CPL, RPI = 64 / LPR;
+  const int c = (lane % LPR) * CPL, n = n0 + wn * WC + c;
+  float bias[CPL];
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) bias[e] = 0.f;
+  if (p.bias) loadN<CPL>(p.bias + n, bias);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const f32x4 v = acc[i][j] * p.alpha;
+      *reinterpret_cast<float4*>(est + (lane & 15) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    const int mbase = m0 + wm * WR + i * 16;
+#pragma unroll
+    for (int rr = 0; rr < 16; rr += RPI) {
+      const int row = rr + lane / LPR, m = mbase + row;
+      if (m >= p.M) continue;
+      float v[CPL];
+      loadN<CPL>(est + row * WPITCH + c, v);
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) v[e] += bias[e];
+      TC* dst = C + (long)m * p.ldc + n;
+      if (EPI == EPI_STORE) {
+        storeN<CPL>(dst, v);
+      } else if (EPI == EPI_RESID) {
+        float r[CPL];
+        loadN<CPL>(p.resid + (long)m * p.ldr + n, r);
+        const float rowm = meE.row_mult(m);
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
+        storeN<CPL>(dst, v);
+      } else if (EPI == EPI_MUL_AUX) {
+        float a[CPL];
+        loadN<CPL>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n, a);
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) v[e] *= a[e];
+        storeN<CPL>(dst, v);
+      } else if (EPI == EPI_GELU_FWD) {
+        float gq[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; e += 2) {
+          const gelu_f2 x = {v[e], v[e + 1]};
+          gelu_f2 cdf, pdf;
+          gelu_parts2(x, cdf, pdf);
+          const gelu_f2 mult = {meE.elem_mult(m, n + e), meE.elem_mult(m, n + e + 1)};
+          const gelu_f2 gg = (x * pdf + cdf) * mult, hh = x * cdf * mult;
+          gq[e] = gg.x; gq[e + 1] = gg.y;
+          v[e] = hh.x; v[e + 1] = hh.y;
+        }
+        storeN<CPL>(dst, v);
+        storeN<CPL>(reinterpret_cast<TC*>(p.aux_out) + (long)m * p.ldc + n, gq);
+      }
+    }
+  }
+}
+
+template <typename TC, int EPI, bool TRB, int BM, int BN, int NST, int WGM = 2, int WGN = 2>
+static inline hipError_t focal_launch_gemm_pipe(const GemmParams& p, hipStream_t stream) {
+  constexpr int LDS_BYTES = NST * (BM + BN) * 128;
+  auto kern = focal_gemm_pipe_kernel<TC, EPI, TRB, BM, BN, NST, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid(((p.M + BM - 1) / BM) * (p.N / BN) * p.batch);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), LDS_BYTES, stream, p);
+  return hipGetLastError();
+}

@@ -128,6 +128,48 @@ def test_linear_relu_out_bwd(ops):
     assert rel_err(dh, (dz @ w) * (h > 0)) < 1e-5
 
 
+# The LDS-DMA pipelined bf16 kernel (gemm_pipe.hpp) takes over when K >= 128, K % 64 == 0, N % 64 == 0, M >= 1024; both tile
+# shapes (N >= 384 and N % 128 == 0 -> 128 x 128, else 128 x 64), ragged M, every epilogue it implements, and the weight read
+# in its [K][N] orientation for the data gradient.  FOCAL_GEMM_NOPIPE=1 sends the same calls to the 64 x 64 kernel.
+@pytest.mark.parametrize("M,N,K", [(1100, 64, 128), (2048, 384, 128), (1333, 768, 256), (4608, 256, 1024), (1024, 192, 192)])
+def test_linear_pipelined_kernel_fwd_and_data_gradient(ops, M, N, K):
+    ct = torch.bfloat16
+    x, w, b = rnd(M, K, seed=21, dtype=ct), rnd(N, K, scale=K ** -0.5, seed=22, dtype=ct), rnd(N, seed=23)
+    y, _ = ops.linear(x, w, b, compute=ct)
+    assert rel_err(y.float(), x.float() @ w.float().t() + b) < 6e-3
+    yf, _ = ops.linear(x, w, b, compute=ct, y_dtype=torch.float32)
+    assert rel_err(yf, x.float() @ w.float().t() + b) < 3e-3
+    dy = rnd(M, N, seed=24, dtype=ct)
+    c = ops.code(ct)
+    d = ops.linear_desc(c, M, N, K, c, c)
+    dx = torch.full((M, K), float("nan"), dtype=ct, device=DEV)
+    ops.linear_bwd_data(d, dy, w, None, dx)
+    assert rel_err(dx.float(), dy.float() @ w.float()) < 6e-3
+
+
+def test_linear_pipelined_kernel_epilogues(ops):
+    from focal_amd._lib import ACT_GELU, EPI_GELU, EPI_RESIDUAL
+    ct = torch.bfloat16
+    M, C = 1300, 128
+    a, w1, b1 = rnd(M, C, seed=31, dtype=ct), rnd(4 * C, C, scale=C ** -0.5, seed=32, dtype=ct), rnd(4 * C, seed=33)
+    hg = torch.empty(M, 4 * C, dtype=ct, device=DEV)
+    h, _ = ops.linear(a, w1, b1, compute=ct, epilogue=EPI_GELU, act_grad=hg)
+    u = (a.float() @ w1.float().t() + b1).requires_grad_(True)
+    href = F.gelu(u)
+    href.sum().backward()
+    assert rel_err(h.float(), href) < 5e-3 and rel_err(hg.float(), u.grad) < 5e-3
+    w2, b2, r = rnd(C, 4 * C, scale=(4 * C) ** -0.5, seed=34, dtype=ct), rnd(C, seed=35), rnd(M, C, seed=36)
+    y, _ = ops.linear(h, w2, b2, compute=ct, y_dtype=torch.float32, resid=r, act_in=ACT_GELU, epilogue=EPI_RESIDUAL)
+    assert rel_err(y, r + h.float() @ w2.float().t() + b2) < 4e-3
+    # du = (gm W2) * h' with the pre-masked operand-dtype gradient (the Swin backward's fc2 data gradient)
+    gm = rnd(M, C, seed=37, dtype=ct)
+    c = ops.code(ct)
+    d = ops.linear_desc(c, M, C, 4 * C, c, c, ACT_GELU)
+    du = torch.empty(M, 4 * C, dtype=ct, device=DEV)
+    ops.linear_bwd_data(d, gm, w2, hg, du)
+    assert rel_err(du.float(), (gm.float() @ w2.float()) * hg.float()) < 8e-3
+
+
 # ---------------------------------------------------------------------------------------------- layer norm
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,C", [(4608, 64), (1153, 128), (300, 256), (77, 512)])
