@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=4)
     p.add_argument("--roofline-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3 --pmc passes)")
     p.add_argument("--roofline-iters", type=int, default=20)
+    p.add_argument("--from-host", action="store_true", help="diagnostic (never the reported `value`): every step's windows start in pinned "
+                   "host memory, as the reference's DataLoader hands them over; H2D on a copy stream one step ahead")
     p.add_argument("--no-roofline", action="store_true", help="profiling runs: skip the dominant-kernel timing loop (the JSON line then has roofline null)")
     return p.parse_args()
 
@@ -94,6 +96,37 @@ class Step:
                 shape = (a.batch, cfg["loc_mod_in_time_channels"][loc][mod], cfg["num_segments"], cfg["loc_mod_spectrum_len"][loc][mod])
                 self.x[loc][mod] = torch.randn(shape, generator=g).to(device)
         self.loss = torch.zeros((), device=device)
+        self.feed = None
+
+    def enable_host_feed(self):
+        """PCIe-inclusive mode: a pinned host copy of the batch (stands for the loader's pinned ring), two device staging sets and
+        a copy stream; step k+1's windows cross PCIe while step k computes, the step begins with a D2D copy into its inputs."""
+        flat = [(loc, mod) for loc in self.x for mod in self.x[loc]]
+        self.feed = {"host": {k: self.x[k[0]][k[1]].cpu().pin_memory() for k in flat},
+                     "stage": [{k: torch.empty_like(self.x[k[0]][k[1]]) for k in flat} for _ in range(2)],
+                     "stream": torch.cuda.Stream(), "ready": [torch.cuda.Event(), torch.cuda.Event()],
+                     "free": [torch.cuda.Event(), torch.cuda.Event()], "k": 0, "flat": flat}
+        self.feed_h2d(0)
+
+    def feed_h2d(self, slot):
+        f = self.feed
+        with torch.cuda.stream(f["stream"]):
+            f["stream"].wait_event(f["free"][slot])
+            for k in f["flat"]:
+                f["stage"][slot][k].copy_(f["host"][k], non_blocking=True)
+            f["ready"][slot].record(f["stream"])
+
+    def feed_step_inputs(self):
+        """Called on the compute stream before each step: consume the staged windows, start the next H2D."""
+        f = self.feed
+        slot = f["k"] & 1
+        st = torch.cuda.current_stream()
+        st.wait_event(f["ready"][slot])
+        for k in f["flat"]:
+            self.x[k[0]][k[1]].copy_(f["stage"][slot][k], non_blocking=True)
+        f["free"][slot].record(st)
+        f["k"] += 1
+        self.feed_h2d(f["k"] & 1)
 
     def views(self):
         v1 = {l: {m: self.ops.fft_realpack(x) for m, x in mm.items()} for l, mm in self.x.items()}
@@ -335,6 +368,13 @@ def main():
                 ok = int(flag.item())
             if ok:
                 run, graphed = replay, True
+        if a.from_host:
+            step.enable_host_feed()
+            inner = run
+
+            def run():
+                step.feed_step_inputs()
+                inner()
         for _ in range(a.warmup):
             run()
             step.loss.item()
@@ -373,6 +413,7 @@ def main():
                "config": {"workload": f"{a.model} + FOCAL pretrain step, {a.batch} MOD-shaped 2-modality windows/GPU "
                                       f"(global batch {a.batch * world}), train mode, DFT + fwd x2 + loss + bwd + AdamW",
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graphed, **({"DIAGNOSTIC_no_dropout": True} if a.no_dropout else {}),
+                          **({"DIAGNOSTIC_from_host": True} if a.from_host else {}),
                           "views": "identity / negation+scaling (x * -1.1) folded into the DFT", "last_loss": round(last_loss, 4)},
                "model_flops_frac_of_bf16_mfma_peak": round(wps / world * FLOP_PER_WINDOW[a.model] / (MFMA_BF16_PEAK_TF * 1e12), 5),
                "roofline": rl, "cpu_baseline": cb}
