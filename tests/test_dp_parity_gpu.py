@@ -20,3 +20,26 @@ def test_two_ranks_equal_single_device(model):
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert "worst gradient error" in r.stdout, tail
+
+
+@pytest.mark.parametrize("model", ["SW_Transformer", "DeepSense"])
+def test_bench_contract_with_two_ranks(model):
+    """The driver's N > 1 launch line, verbatim, on the box's one GPU (FOCAL_BENCH_TEST_BACKEND=gloo puts both ranks on cuda:0):
+    three hipGraph segments with the two collectives issued eagerly between replays, MAX-over-ranks timing, ONE JSON line from
+    rank 0 whose value is the whole-job rate."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8", FOCAL_BENCH_TEST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541" if model == "DeepSense" else "29542", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "2", "--batch", "16", "--model", model, "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, tail
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2" and out["config"]["hip_graph"] is True
+    assert out["value"] > 0 and abs(out["value"] - 32 / (out["ms_per_step"] * 1e-3)) < 0.02 * out["value"]
+    assert out["vs_baseline"] is None and out["cpu_baseline"] is None

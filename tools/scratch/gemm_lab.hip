@@ -61,7 +61,12 @@ int main() {
     const int M = sh.M, N = sh.N, K = sh.K;
     bf16_t *A, *W, *C;
     float *bias, *ref, *maxerr;
-    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
+    const int NB = getenv("LAB_COLD") ? 12 : 1;  // cold mode: every launch works on a different (A, C) pair, > 256 MB in rotation
+    const size_t a_elems = (size_t)M * K, c_elems = (size_t)M * N;
+    CK(hipMalloc(&A, a_elems * 2 * NB)); CK(hipMalloc(&W, (size_t)N * K * 2)); CK(hipMalloc(&C, c_elems * 2 * NB));
+    for (int b = 1; b < NB; ++b) fill_kernel<<<ceil_div((long)M * K, 256), 256>>>(A + b * a_elems, (long)M * K, 1u, 2.0f);
+    int rot = 0;
+    auto next = [&](GemmParams& q) { rot = (rot + 1) % NB; q.A = A + rot * a_elems; q.C = C + rot * c_elems; };
     CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&ref, (size_t)M * N * 4)); CK(hipMalloc(&maxerr, 4));
     fill_kernel<<<ceil_div((long)M * K, 256), 256>>>(A, (long)M * K, 1u, 2.0f);
     fill_kernel<<<ceil_div((long)N * K, 256), 256>>>(W, (long)N * K, 2u, 0.25f);
@@ -74,16 +79,17 @@ int main() {
     p.M = M; p.N = N; p.K = K; p.A = A; p.lda = K; p.B = W; p.ldb = K; p.C = C; p.ldc = N; p.batch = 1; p.splits = 1; p.alpha = 1.f; p.bias = bias;
     auto check = [&](const char* what) {
       CK(hipMemset(maxerr, 0, 4));
-      cmp_kernel<<<ceil_div((long)M * N, 256), 256>>>(ref, C, (long)M * N, maxerr);
+      cmp_kernel<<<ceil_div((long)M * N, 256), 256>>>(ref, C + rot * c_elems, (long)M * N, maxerr);
       float e;
       CK(hipMemcpy(&e, maxerr, 4, hipMemcpyDeviceToHost));
       if (!(e < 8e-3f) && p.splits == 1) printf("    !! %s max rel err %g\n", what, e);
-      CK(hipMemset(C, 0, (size_t)M * N * 2));
+      CK(hipMemset(C, 0, c_elems * 2 * NB));
     };
     const double gf = 2.0 * M * N * K * 1e-9;
     printf("%-9s [%6d x %4d] K=%4d :", sh.name, M, N, K);
     {
       const float us = time_us([&] {
+        next(p);
         dim3 grid(ceil_div(M, 64) * ceil_div(N, 64));
         hipLaunchKernelGGL((focal_gemm_kernel<bf16_t, bf16_t, bf16_t, bf16_t, false, false, PRO_NONE, PRO_NONE, EPI_STORE, 64, 64, 1>), grid, dim3(256), 0, 0, p);
       });
@@ -92,12 +98,19 @@ int main() {
     }
 #define VARIANT(BM, BN, NST, WGM, WGN)                                                             \
     if (N % BN == 0 && M % BM == 0) {                                                              \
-      const float us = time_us([&] { CK((focal_launch_gemm_pipe<bf16_t, EPI_STORE, false, BM, BN, NST, WGM, WGN>(p, 0))); }); \
+      const float us = time_us([&] { next(p); CK((focal_launch_gemm_pipe<bf16_t, EPI_STORE, false, BM, BN, NST, WGM, WGN>(p, 0))); }); \
       check(#BM "x" #BN "x" #NST);                                                                 \
       printf(" %dx%d/%d w%dx%d %5.1f |", BM, BN, NST, WGM, WGN, us);              \
     }
     VARIANT(128, 128, 2, 2, 2)
+    VARIANT(128, 128, 3, 2, 2)
+    VARIANT(128, 128, 3, 4, 2)
     VARIANT(128, 64, 2, 2, 2)
+    VARIANT(128, 64, 3, 2, 2)
+    VARIANT(128, 64, 4, 2, 2)
+    VARIANT(64, 64, 2, 2, 2)
+    VARIANT(64, 64, 4, 2, 2)
+    if (getenv("LAB_FWD_ONLY")) { printf("\n"); continue; }
     // ---- dX form: W stored [k][n] -> same product with Wt = W^T laid out [K][N]
     {
       bf16_t* Wt;
