@@ -129,8 +129,13 @@ class Step:
         self.feed_h2d(f["k"] & 1)
 
     def views(self):
-        v1 = {l: {m: self.ops.fft_realpack(x) for m, x in mm.items()} for l, mm in self.x.items()}
-        v2 = {l: {m: self.ops.fft_realpack(x, scale=-1.1) for m, x in mm.items()} for l, mm in self.x.items()}  # negation + scaling, folded into the DFT
+        # both views of a modality are written into the halves of one [2B, ...] tensor (what Augmenter.forward_random does for
+        # back-to-back draws): SW_Transformer runs them as one batch without a concatenation
+        both = {l: {m: torch.empty(2 * x.shape[0], 2 * x.shape[1], x.shape[2], x.shape[3], device=x.device) for m, x in mm.items()}
+                for l, mm in self.x.items()}
+        v1 = {l: {m: self.ops.fft_realpack(x, out=both[l][m][:x.shape[0]]) for m, x in mm.items()} for l, mm in self.x.items()}
+        v2 = {l: {m: self.ops.fft_realpack(x, scale=-1.1, out=both[l][m][x.shape[0]:]) for m, x in mm.items()}
+              for l, mm in self.x.items()}  # negation + scaling, folded into the DFT
         return v1, v2
 
     # The step in three capturable segments with the two data-parallel collectives between them:

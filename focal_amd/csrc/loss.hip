@@ -316,8 +316,25 @@ extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* fea
   hipStream_t st = (hipStream_t)stream;
   const int M = d->n_mod, B = d->B, dim = d->dim, seq = d->seq, b = pl.b, n2 = pl.n2, half = d->dim / 2;
   float* ws = reinterpret_cast<float*>(workspace);
-  (void)hipMemsetAsync(terms, 0, 5 * sizeof(float), st);
-  for (int i = 0; i < 2 * M; ++i) (void)hipMemsetAsync(dfeats[i], 0, (size_t)B * dim * sizeof(float), st);
+  // the binding hands over ONE allocation [2M gradients | terms]: a single memset node instead of 2M + 1
+  const size_t gbytes = (size_t)B * dim * sizeof(float);
+  // (any order of the 2M blocks inside it: the binding places a modality's two views next to each other)
+  float* lo = dfeats[0];
+  for (int i = 1; i < 2 * M; ++i) lo = dfeats[i] < lo ? dfeats[i] : lo;
+  bool packed = true;
+  unsigned seen = 0;
+  for (int i = 0; i < 2 * M; ++i) {
+    const size_t off = (size_t)(dfeats[i] - lo), slot = off / ((size_t)B * dim);
+    packed = packed && (off % ((size_t)B * dim) == 0) && slot < (size_t)(2 * M) && !(seen & (1u << slot));
+    if (slot < 32) seen |= 1u << slot;
+  }
+  packed = packed && (terms == lo + (size_t)2 * M * B * dim);
+  if (packed) {
+    (void)hipMemsetAsync(lo, 0, 2 * M * gbytes + 5 * sizeof(float), st);
+  } else {
+    (void)hipMemsetAsync(terms, 0, 5 * sizeof(float), st);
+    for (int i = 0; i < 2 * M; ++i) (void)hipMemsetAsync(dfeats[i], 0, gbytes, st);
+  }
 
   // ---- problem tables (view-major feature order: index v*M + m)
   PairTable nce, orth;

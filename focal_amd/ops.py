@@ -89,11 +89,12 @@ def _factor(n):
     return n // best, best
 
 
-def fft_realpack(x, scale=1.0, flip=False, perm=None, phase=0.0):
+def fft_realpack(x, scale=1.0, flip=False, perm=None, phase=0.0, out=None):
     """[B, C, I, n] real fp32 -> [B, 2C, I, n] (Re/Im channel pairs of the full two-sided spectrum).
 
     Optional view augmentation folded into the transform (focal_augment_fft_fwd): x * scale, horizontal flip (intervals and
-    samples reversed), interval order `perm` (sequence of I ints), and a rotation of every bin by `phase` radians."""
+    samples reversed), interval order `perm` (sequence of I ints), and a rotation of every bin by `phase` radians.
+    `out`: write into this contiguous [B, 2C, I, n] fp32 tensor (e.g. one half of a two-view batch) instead of allocating."""
     _need_cuda(x)
     B, Cc, I, n = x.shape
     key = (n, x.device)
@@ -102,7 +103,10 @@ def fft_realpack(x, scale=1.0, flip=False, perm=None, phase=0.0):
         ang = 2.0 * math.pi * k / n
         _TWIDDLES[key] = torch.stack([torch.cos(ang), -torch.sin(ang)], 1).to(torch.float32).contiguous().to(x.device)
     n1, n2 = _factor(n)
-    out = torch.empty(B, 2 * Cc, I, n, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(B, 2 * Cc, I, n, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (B, 2 * Cc, I, n) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("fft_realpack: `out` must be a contiguous fp32 [B, 2C, I, n] tensor on x's device")
     d = FFTDesc(B, Cc, I, n, n1, n2)
     if scale == 1.0 and not flip and perm is None and phase == 0.0:
         check(_lib.load().focal_fft_realpack_fwd(C.byref(d), _p(x), _p(_TWIDDLES[key]), _p(out), _stream()))
@@ -225,7 +229,7 @@ def window_attn_bwd(d, qkv, bias_table, dout, dqkv, dbias_table):
 _LOSS_WS = {}
 
 
-def loss_head(feats1, feats2, temperature, margin, weights, seq=4, no_private=False):
+def loss_head(feats1, feats2, temperature, margin, weights, seq=4, no_private=False, return_flat=False):
     """feats{1,2}: lists (modality order) of fp32 [B, dim].  Returns (terms[5] device tensor, grads1, grads2)."""
     feats = list(feats1) + list(feats2)
     _need_cuda(*feats)
@@ -242,11 +246,18 @@ def loss_head(feats1, feats2, temperature, margin, weights, seq=4, no_private=Fa
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
         _LOSS_WS[key] = ws
-    terms = torch.empty(5, dtype=torch.float32, device=dev)
-    grads = [torch.empty_like(f) for f in feats]
+    # one allocation [2M gradients | terms(5) + pad]: the library zeroes it with one memset, the autograd node scales it with one launch
+    n = B * dim
+    flat = torch.empty(2 * M * n + 8, dtype=torch.float32, device=dev)
+    # ABI order is view-major (index v * M + m); memory order is modality-major, so a modality's two view gradients are the
+    # two halves of one [2B, dim] block (what a backbone that ran both views as one batch wants back, without a concatenation)
+    grads = [flat[(m * 2 + v) * n:(m * 2 + v + 1) * n].view(B, dim) for v in range(2) for m in range(M)]
+    terms = flat[2 * M * n:2 * M * n + 5]
     fa = (C.c_void_p * (2 * M))(*[_p(f) for f in feats])
     ga = (C.c_void_p * (2 * M))(*[_p(g) for g in grads])
     check(lib.focal_loss_head(C.byref(d), fa, _p(terms), ga, _p(ws), ws.numel(), _stream()))
+    if return_flat:  # the gradients as ONE tensor (they are views of it)
+        return terms, grads[:M], grads[M:], flat[:2 * M * n]
     return terms, grads[:M], grads[M:]
 
 

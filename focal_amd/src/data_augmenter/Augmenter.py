@@ -116,8 +116,23 @@ class Augmenter:
         name = self.aug_names[k]
         fn = TIME_AUGMENTERS[name] if k < len(self.time_aug_names) else FREQ_AUGMENTERS[name]
         kw = self._draw(fn, name, time_loc_inputs)
-        return {loc: {mod: ops.fft_realpack(x.contiguous(), **kw[loc][mod]) for mod, x in mods.items()}
+        return {loc: {mod: ops.fft_realpack(x.contiguous(), out=self._view_slot(loc, mod, x), **kw[loc][mod]) for mod, x in mods.items()}
                 for loc, mods in time_loc_inputs.items()}
+
+    def _view_slot(self, loc, mod, x):
+        """Where this view's spectrum goes: the pretraining loop draws two views of the same windows back to back
+        (train_utils/pretrain.py), so the first call gets the first half of a fresh [2B, 2C, I, n] tensor and the second call (same
+        input tensor) the second half -- a backbone that runs both views as one batch then needs no concatenation."""
+        pend = self.__dict__.setdefault("_pending_pairs", {})
+        key = (loc, mod)
+        B = x.shape[0]
+        tag = (x.data_ptr(), tuple(x.shape), x.device)
+        hit = pend.pop(key, None)
+        if hit is not None and hit[0] == tag:
+            return hit[1][B:]
+        base = torch.empty(2 * B, 2 * x.shape[1], x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
+        pend[key] = (tag, base)
+        return base[:B]
 
     def move_to_target_device(self, time_loc_inputs, labels):
         dev = self.args.device

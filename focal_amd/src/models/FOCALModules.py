@@ -27,12 +27,11 @@ class FOCAL(nn.Module):
         if getattr(self.backbone, "views_share_pass", False):
             # A backbone without batch statistics (SW_Transformer: LayerNorm only) gives the same features whether the two
             # views are two batches or one batch of 2B; one pass halves the launch count and doubles every kernel's size.
-            both = {loc: {mod: torch.cat([x, aug_freq_input2[loc][mod]], dim=0) for mod, x in mods.items()}
+            both = {loc: {mod: _as_one_batch(x, aug_freq_input2[loc][mod]) for mod, x in mods.items()}
                     for loc, mods in aug_freq_input1.items()}
             feats = self.backbone(both, class_head=False, proj_head=proj_head)
-            first = next(iter(next(iter(aug_freq_input1.values())).values()))
-            b = first.shape[0]
-            return {m: f[:b] for m, f in feats.items()}, {m: f[b:] for m, f in feats.items()}
+            halves = {m: _SplitHalves.apply(f) for m, f in feats.items()}
+            return {m: h[0] for m, h in halves.items()}, {m: h[1] for m, h in halves.items()}
         kw = {}
         if "defer_join" in inspect.signature(self.backbone.forward).parameters:
             kw["defer_join"] = True
@@ -42,6 +41,37 @@ class FOCAL(nn.Module):
             from focal_amd import runtime
             runtime.join_all(next(self.backbone.parameters()).device)
         return mod_features1, mod_features2
+
+
+def _as_one_batch(x1, x2):
+    """The two views as one batch of 2B.  When they already are the two halves of one tensor (the augmenter / DFT wrote them
+    there: `ops.fft_realpack(..., out=both[:B])`), that tensor is used as is; otherwise they are concatenated."""
+    base = x1._base
+    if (base is not None and base is x2._base and base.is_contiguous() and x1.is_contiguous() and x2.is_contiguous()
+            and base.shape[0] == 2 * x1.shape[0] and base.shape[1:] == x1.shape[1:] and x1.shape == x2.shape
+            and x1.data_ptr() == base.data_ptr() and x2.data_ptr() == base.data_ptr() + x1.numel() * x1.element_size()
+            and not (x1.requires_grad or x2.requires_grad)):
+        return base
+    return torch.cat([x1, x2], dim=0)
+
+
+class _SplitHalves(torch.autograd.Function):
+    """f [2B, E] -> (f[:B], f[B:]).  Backward hands the encoder ONE [2B, E] gradient: when the two incoming gradients already
+    sit next to each other in memory (the loss head lays a modality's two views out that way) it is a view of them, no kernel;
+    plain slicing would cost two zero-fills, two copies and an add per modality."""
+
+    @staticmethod
+    def forward(ctx, f):
+        b = f.shape[0] // 2
+        return f[:b], f[b:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if (g1.is_contiguous() and g2.is_contiguous() and g1.dtype == g2.dtype and g1.shape == g2.shape
+                and g1.untyped_storage().data_ptr() == g2.untyped_storage().data_ptr()
+                and g2.data_ptr() == g1.data_ptr() + g1.numel() * g1.element_size()):
+            return g1.as_strided((2 * g1.shape[0],) + tuple(g1.shape[1:]), g1.stride())
+        return torch.cat([g1, g2], dim=0)
 
 
 def split_features(mod_features):

@@ -21,16 +21,16 @@ class _LossHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, n_mod, *feats):
         feats = [f.contiguous().float() for f in feats]
-        terms, g1, g2 = ops.loss_head(feats[:n_mod], feats[n_mod:], owner.temperature, owner.config["inter_rank_margin"],
-                                      owner.weights, owner.seq_len, owner.args.tag == "noPrivate")
+        terms, g1, g2, flat = ops.loss_head(feats[:n_mod], feats[n_mod:], owner.temperature, owner.config["inter_rank_margin"],
+                                            owner.weights, owner.seq_len, owner.args.tag == "noPrivate", return_flat=True)
         owner.last_terms = terms
-        ctx.grads = g1 + g2
+        ctx.grads, ctx.flat = g1 + g2, flat  # the gradients are views of one flat buffer
         return terms[4]
 
     @staticmethod
     def backward(ctx, gout):
-        grads = [g * gout for g in ctx.grads]
-        ctx.grads = None
+        ctx.flat.mul_(gout)  # one launch for all 2M gradients
+        grads, ctx.grads, ctx.flat = ctx.grads, None, None
         return (None, None, *grads)
 
 
