@@ -89,6 +89,7 @@ class ParamArena:
 
     def zero_grad(self):
         self.grad.zero_()
+        ops.zero_pool_reset(self.grad.device)  # the step's small accumulation buffers (ops.pool_zeros): one launch for all of them
 
     def moments(self):
         if self.exp_avg is None:

@@ -210,6 +210,8 @@ static int stream_blocks(long rows, int C) {
 extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scratch, float* mean_rstd, float* running_mean,
                               float* running_var, int training, void* stream) {
   if (int rc = bn_check(d)) return rc;
+  const bool prezeroed = (training & FOCAL_BN_SCRATCH_ZEROED) != 0;
+  training &= ~FOCAL_BN_SCRATCH_ZEROED;
   FOCAL_CHECK_ARG(training >= FOCAL_BN_EVAL && training <= FOCAL_BN_FINALIZE, "bn_stats: bad mode %d", training);
   hipStream_t st = (hipStream_t)stream;
   const int C = d->C;
@@ -222,7 +224,7 @@ extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scr
   FOCAL_CHECK_ARG(scratch, "bn_stats: null scratch");
   if (training != FOCAL_BN_FINALIZE) {
     FOCAL_CHECK_ARG(z, "bn_stats: null tensor");
-    (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
+    if (!prezeroed) (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
     int blocks = ceil_div((long)d->rows * C / 4, 1024 * 2);
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(1024), 32 * C * sizeof(float), st, z, scratch, (long)d->rows, C);
@@ -256,12 +258,14 @@ extern "C" int focal_bn_act_fwd(const focal_bn_desc* d, const float* z, const fl
 extern "C" int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const float* g, const float* mean_rstd, const float* gamma,
                                 const float* beta, float* scratch, void* dz, float* dgamma, float* dbeta, int phase, void* stream) {
   if (int rc = bn_check(d)) return rc;
+  const bool prezeroed = (phase & FOCAL_BN_SCRATCH_ZEROED) != 0;
+  phase &= ~FOCAL_BN_SCRATCH_ZEROED;
   FOCAL_CHECK_ARG(phase == FOCAL_BN_TRAIN || phase == FOCAL_BN_PARTIAL || phase == FOCAL_BN_FINALIZE, "bn_act_bwd: bad phase %d", phase);
   FOCAL_CHECK_ARG(z && g && mean_rstd && gamma && beta && scratch, "bn_act_bwd: null tensor");
   hipStream_t st = (hipStream_t)stream;
   const int C = d->C;
   if (phase != FOCAL_BN_FINALIZE) {
-    (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
+    if (!prezeroed) (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
     int rb = ceil_div((long)d->rows * C / 4, 1024 * 2);
     if (rb > 256) rb = 256;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(1024), 32 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,

@@ -179,7 +179,7 @@ class DeepSenseModEncoder:
         rows = B * I * S
         pout, d_out = sv["pout"], sv["d_out"]
         n_out = geo["C_out"]
-        dwp = torch.zeros(n_out, S * C, dtype=torch.float32, device=dev)
+        dwp = ops.zeros((n_out, S * C), dev)
         ops.linear_bwd_weight(d_out, dx, sv["ya_last"], dwp, ar.g(f"{pout}.bias"))
         ops.permute_unpack_add(dwp, ar.g(f"{pout}.weight"), n_out, C, S)
         d_out_data = ops.linear_desc(cc, B * I, n_out, S * C, f32, f32)  # gradient w.r.t. the fp32 residual stream
@@ -192,7 +192,7 @@ class DeepSenseModEncoder:
             pl = L["p"]
             dz = ops.bn_act_bwd(L["d_bn"], L["z"], g, L["mr"], ar.master(f"{pl}.batch_norm.weight"), ar.master(f"{pl}.batch_norm.bias"),
                                 ar.g(f"{pl}.batch_norm.weight"), ar.g(f"{pl}.batch_norm.bias"), ct, bb.sync_bn)
-            dwp = torch.zeros(C, k * C, dtype=torch.float32, device=dev)
+            dwp = ops.zeros((C, k * C), dev)
             ops.conv_bwd_weight(d_cv, dz, L["xa"], dwp, ar.g(f"{pl}.conv.bias"))
             ops.permute_unpack_add(dwp, ar.g(f"{pl}.conv.weight"), C, C, k)
             w_bwd = ops.conv_pack_bwd(d_cv, ar.master(f"{pl}.conv.weight"), ct)  # flipped taps, [C_in][k][C_out]

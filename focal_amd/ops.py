@@ -34,6 +34,55 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# ------------------------------------------------------------------------------------------------ per-step zero pool
+# Many kernels accumulate with atomics into small buffers that must start at zero (BatchNorm channel sums, split weight
+# gradients).  One memset per buffer is one graph node each (~100 per DeepSense step); instead they are slices of ONE fp32
+# pool that `zero_pool_reset` (called by the optimizer's zero_grad, after the side streams are joined) zeroes with a single
+# launch.  A slice is handed out once between two resets, so correctness never depends on the reset being called: without it
+# the pool simply runs out and callers fall back to their own zero-fill.
+_ZERO_POOL = {}
+_ZERO_POOL_FLOATS = 4 << 20
+
+
+def zero_pool_reset(device):
+    st = _ZERO_POOL.get(torch.device(device))
+    if st is None:
+        return
+    if st["ptr"] > 0:
+        st["buf"][:st["ptr"]].zero_()
+    st["ptr"] = 0
+
+
+def pool_zeros(n, device):
+    """n zero fp32 values from the pool, or None when the pool cannot serve them (caller then zero-fills itself)."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return None
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    st = _ZERO_POOL.get(dev)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None  # never create the pool inside a graph capture
+        st = _ZERO_POOL[dev] = {"buf": torch.zeros(_ZERO_POOL_FLOATS, dtype=torch.float32, device=dev), "ptr": 0}
+        torch.cuda.current_stream(dev).synchronize()  # created on whichever stream asked first; every stream must see the zeros
+    need = (n + 63) // 64 * 64
+    if st["ptr"] + need > _ZERO_POOL_FLOATS:
+        return None
+    out = st["buf"][st["ptr"]:st["ptr"] + n]
+    st["ptr"] += need
+    return out
+
+
+def zeros(shape, device):
+    """fp32 zeros of `shape`: a pool slice when possible, else torch.zeros."""
+    n = 1
+    for v in shape:
+        n *= int(v)
+    t = pool_zeros(n, device)
+    return t.view(*shape) if t is not None else torch.zeros(*shape, dtype=torch.float32, device=device)
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -325,19 +374,22 @@ def bn_stats(d, z, running_mean, running_var, training, sync=False):
     """mean / rstd of z [rows, C].  sync=True under torch.distributed: the 2C per-channel sums are all-reduced between the
     partial and the finalize kernels, so every rank normalises with the statistics of the GLOBAL batch (equal shards)."""
     dev = running_mean.device
-    scratch = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
+    scratch = pool_zeros(2 * d.C, dev) if training else None
+    pre = _lib.BN_SCRATCH_ZEROED if scratch is not None else 0
+    if scratch is None:
+        scratch = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
     mean_rstd = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
     lib = _lib.load()
     args = (_p(z), _p(scratch), _p(mean_rstd), _p(running_mean), _p(running_var))
     world = _sync_world() if (sync and training) else 1
     if world > 1:
         import torch.distributed as dist
-        check(lib.focal_bn_stats(C.byref(d), *args, _lib.BN_PARTIAL, _stream()))
+        check(lib.focal_bn_stats(C.byref(d), *args, _lib.BN_PARTIAL | pre, _stream()))
         dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
         d.stat_rows = d.rows * world
         check(lib.focal_bn_stats(C.byref(d), *args, _lib.BN_FINALIZE, _stream()))
     else:
-        check(lib.focal_bn_stats(C.byref(d), *args, _lib.BN_TRAIN if training else _lib.BN_EVAL, _stream()))
+        check(lib.focal_bn_stats(C.byref(d), *args, (_lib.BN_TRAIN | pre) if training else _lib.BN_EVAL, _stream()))
     return mean_rstd
 
 
@@ -349,19 +401,22 @@ def bn_act_fwd(d, z, mean_rstd, gamma, beta, resid, cast_dtype=None):
 
 
 def bn_act_bwd(d, z, g, mean_rstd, gamma, beta, dgamma, dbeta, out_dtype, sync=False):
-    scratch = torch.empty(2 * d.C, dtype=torch.float32, device=z.device)
+    scratch = pool_zeros(2 * d.C, z.device)
+    pre = _lib.BN_SCRATCH_ZEROED if scratch is not None else 0
+    if scratch is None:
+        scratch = torch.empty(2 * d.C, dtype=torch.float32, device=z.device)
     dz = torch.empty(z.shape, dtype=out_dtype, device=z.device)
     lib = _lib.load()
     args = (_p(z), _p(g), _p(mean_rstd), _p(gamma), _p(beta), _p(scratch), _p(dz), _p(dgamma), _p(dbeta))
     world = _sync_world() if sync else 1
     if world > 1:
         import torch.distributed as dist
-        check(lib.focal_bn_act_bwd(C.byref(d), *args, _lib.BN_PARTIAL, _stream()))
+        check(lib.focal_bn_act_bwd(C.byref(d), *args, _lib.BN_PARTIAL | pre, _stream()))
         dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
         d.stat_rows = d.rows * world
         check(lib.focal_bn_act_bwd(C.byref(d), *args, _lib.BN_FINALIZE, _stream()))
     else:
-        check(lib.focal_bn_act_bwd(C.byref(d), *args, _lib.BN_TRAIN, _stream()))
+        check(lib.focal_bn_act_bwd(C.byref(d), *args, _lib.BN_TRAIN | pre, _stream()))
     return dz
 
 

@@ -181,6 +181,9 @@ int focal_conv_bwd_weight(const focal_conv_desc* d, const void* dz, const void* 
  * stat_rows = 0 means rows. */
 typedef struct { int dtype; int rows, C, rows_per_sample; float eps, momentum, p_drop; const uint32_t* rng; uint32_t stream; int stat_rows; } focal_bn_desc;
 enum { FOCAL_BN_EVAL = 0, FOCAL_BN_TRAIN = 1, FOCAL_BN_PARTIAL = 2, FOCAL_BN_FINALIZE = 3 };
+/* OR into `training` / `phase`: the caller guarantees `scratch` holds zeros (e.g. a slice of a per-step zeroed pool), so the call
+ * does not enqueue its own memset (one launch less per BatchNorm pass). */
+#define FOCAL_BN_SCRATCH_ZEROED 16
 int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scratch, float* mean_rstd, float* running_mean, float* running_var,
                    int training, void* stream);
 int focal_bn_act_fwd(const focal_bn_desc* d, const float* z, const float* mean_rstd, const float* gamma, const float* beta,
