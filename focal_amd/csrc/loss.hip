@@ -17,6 +17,26 @@ struct PairProb { const float* e1; const float* e2; float* d1; float* d2; int of
 struct PairTable { PairProb p[LOSS_MAXP]; };
 struct RankTable { const float* x[LOSS_MAXQ]; float* d[LOSS_MAXQ]; };
 
+// Loss terms are sums over thousands of rows.  One atomic per row-wave onto the same word is a serial chain (~10 ns a link:
+// 8 k rows = 0.1 ms at a global batch of 2048, more than the similarity GEMM); the row kernels therefore run as <= LOSS_ROW_BLOCKS
+// persistent 4-wave workgroups, keep their contribution in a register across rows and issue ONE atomic per workgroup and term.
+#define LOSS_ROW_BLOCKS 512
+__device__ __forceinline__ void block_term_add(float v, float* dst) {  // v: per-wave value (lane 0 holds it); 256-thread workgroup
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) part[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = part[0] + part[1] + part[2] + part[3];
+    if (t != 0.f) atomicAdd(dst, t);
+  }
+}
+static inline int loss_row_blocks(long rows) {
+  const long b = (rows + 3) / 4;
+  return (int)(b > LOSS_ROW_BLOCKS ? LOSS_ROW_BLOCKS : (b < 1 ? 1 : b));
+}
+
 // ------------------------------------------------------------------------------------------------ InfoNCE
 // row r of problem (p, t): r < b -> e1[(r)*seq + t], else e2[(r-b)*seq + t]; transposition of loss.py:64-73.
 __global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int dim, int width,
@@ -40,15 +60,13 @@ __global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, in
 __global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, int nprob, int seq, int b, const float* __restrict__ S,
                                                        float* __restrict__ lse, float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n2 = 2 * b;
   const long rows = (long)nprob * seq * n2;
-  float contrib = 0.f;
-  int kind = 0;
-  if (row < rows) {
+  float acc0 = 0.f, acc1 = 0.f;  // contributions to terms[0] (shared family) / terms[1] (private family)
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
     const int i = row % n2;
     const int p = row / ((long)n2 * seq);
-    kind = tab.p[p0 + p].kind;
+    const int kind = tab.p[p0 + p].kind;
     const float* s = S + row * n2;
     float mx = -3.0e38f;
     for (int j = lane; j < n2; j += 64) if (j != i) mx = fmaxf(mx, s[j]);
@@ -59,11 +77,12 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, in
     const float l = mx + __logf(sum);
     if (lane == 0) {
       lse[row] = l;
-      contrib = (l - s[(i + b) % n2]) / (float)(seq * n2);
+      const float contrib = (l - s[(i + b) % n2]) / (float)(seq * n2);
+      if (kind == 0) acc0 += contrib; else acc1 += contrib;
     }
   }
-  // all four rows of a block belong to problems of possibly different kinds: one atomic per wave
-  if (lane == 0 && row < rows) atomicAdd(terms + kind, contrib);
+  block_term_add(acc0, terms + 0);
+  block_term_add(acc1, terms + 1);
 }
 
 // in place S -> W (times the family weight): W_ij = [j != i](e^{S_ij - lse_i} + e^{S_ij - lse_j}) - 2 [j == pos(i)]
@@ -151,27 +170,29 @@ __global__ __launch_bounds__(256) void rank_blockmean_kernel(int nq, int b, int 
 __global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float margin, const float* __restrict__ Dbar,
                                                          float* __restrict__ dDbar, float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)nq * b) return;
-  const int I = row % b;
-  const float* d = Dbar + row * b;
-  const float dii = d[I];
   const float inv = 1.0f / ((float)b * (float)(b - 1));
-  float loss = 0.f, cnt = 0.f;
-  for (int J = lane; J < b; J += 64) {
-    if (J == I) continue;
-    const float h = dii - d[J] + margin;
-    const bool on = h > 0.f;
-    loss += on ? h : 0.f;
-    cnt += on ? 1.f : 0.f;
-    dDbar[row * b + J] = on ? -inv : 0.f;
+  float acc = 0.f;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < (long)nq * b; row += (long)gridDim.x * 4) {
+    const int I = row % b;
+    const float* d = Dbar + row * b;
+    const float dii = d[I];
+    float loss = 0.f, cnt = 0.f;
+    for (int J = lane; J < b; J += 64) {
+      if (J == I) continue;
+      const float h = dii - d[J] + margin;
+      const bool on = h > 0.f;
+      loss += on ? h : 0.f;
+      cnt += on ? 1.f : 0.f;
+      dDbar[row * b + J] = on ? -inv : 0.f;
+    }
+    loss = wave_sum(loss);
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+      dDbar[row * b + I] = cnt * inv;
+      acc += loss * inv;
+    }
   }
-  loss = wave_sum(loss);
-  cnt = wave_sum(cnt);
-  if (lane == 0) {
-    dDbar[row * b + I] = cnt * inv;
-    atomicAdd(terms + 3, loss * inv);
-  }
+  block_term_add(acc, terms + 3);
 }
 
 // in place D -> E = w_rank * (A_pq + A_qp) / D_pq, A_pq = dDbar[I(p)][J(q)] / count(I, J); rowsum[p] = sum_q E_pq
@@ -213,28 +234,30 @@ __global__ __launch_bounds__(256) void rank_grad_kernel(RankTable tab, int nq, i
 __global__ __launch_bounds__(256) void orth_kernel(PairTable tab, int nprob, int B, int dim, int width, float w_orth,
                                                    float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)nprob * B) return;
-  const int p = row / B, s = row % B;
-  const PairProb pr = tab.p[p];
-  const float* x1 = pr.e1 + (long)s * dim + pr.off1;
-  const float* x2 = pr.e2 + (long)s * dim + pr.off2;
-  float d = 0.f, n1 = 0.f, n2 = 0.f;
-  for (int c = lane; c < width; c += 64) { const float a = x1[c], b2 = x2[c]; d += a * b2; n1 += a * a; n2 += b2 * b2; }
-  d = wave_sum(d); n1 = wave_sum(n1) + 1e-12f; n2 = wave_sum(n2) + 1e-12f;
-  const float den = sqrtf(n1 * n2);
-  const float cs = d / den;
-  if (cs > 0.f) {
-    const float k = w_orth / (float)B;
-    float* g1 = pr.d1 + (long)s * dim + pr.off1;
-    float* g2 = pr.d2 + (long)s * dim + pr.off2;
-    for (int c = lane; c < width; c += 64) {
-      const float a = x1[c], b2 = x2[c];
-      atomicAdd(g1 + c, k * (b2 / den - cs * a / n1));
-      atomicAdd(g2 + c, k * (a / den - cs * b2 / n2));
+  float acc = 0.f;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < (long)nprob * B; row += (long)gridDim.x * 4) {
+    const int p = row / B, s = row % B;
+    const PairProb pr = tab.p[p];
+    const float* x1 = pr.e1 + (long)s * dim + pr.off1;
+    const float* x2 = pr.e2 + (long)s * dim + pr.off2;
+    float d = 0.f, n1 = 0.f, n2 = 0.f;
+    for (int c = lane; c < width; c += 64) { const float a = x1[c], b2 = x2[c]; d += a * b2; n1 += a * a; n2 += b2 * b2; }
+    d = wave_sum(d); n1 = wave_sum(n1) + 1e-12f; n2 = wave_sum(n2) + 1e-12f;
+    const float den = sqrtf(n1 * n2);
+    const float cs = d / den;
+    if (cs > 0.f) {
+      const float k = w_orth / (float)B;
+      float* g1 = pr.d1 + (long)s * dim + pr.off1;
+      float* g2 = pr.d2 + (long)s * dim + pr.off2;
+      for (int c = lane; c < width; c += 64) {
+        const float a = x1[c], b2 = x2[c];
+        atomicAdd(g1 + c, k * (b2 / den - cs * a / n1));
+        atomicAdd(g2 + c, k * (a / den - cs * b2 / n2));
+      }
+      if (lane == 0) acc += cs / (float)B;
     }
-    if (lane == 0) atomicAdd(terms + 2, cs / (float)B);
   }
+  block_term_add(acc, terms + 2);
 }
 
 __global__ void loss_total_kernel(float* terms, float ws, float wp, float wo, float wr) {
@@ -373,7 +396,7 @@ extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* fea
     hipLaunchKernelGGL(nce_pack_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, dim, width, Zn, nrm);
     if (int rc = f32_gemm(false, n2, n2, width, Zn, width, (long)n2 * width, Zn, width, (long)n2 * width, S, n2, (long)n2 * n2,
                           nprob * seq, 1.0f / d->temperature, st)) return rc;
-    hipLaunchKernelGGL(nce_rows_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, S, lse, terms);
+    hipLaunchKernelGGL(nce_rows_kernel, dim3(loss_row_blocks(rows)), dim3(256), 0, st, nce, p0, nprob, seq, b, S, lse, terms);
     int eb = ceil_div(rows * n2, 256);
     if (eb > 8192) eb = 8192;
     hipLaunchKernelGGL(nce_weights_kernel, dim3(eb), dim3(256), 0, st, nce, p0, nprob, seq, b, S, lse, d->w_shared, d->w_private);
@@ -397,7 +420,7 @@ extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* fea
     int bb = ceil_div((long)Q * b * b, 256);
     if (bb > 4096) bb = 4096;
     hipLaunchKernelGGL(rank_blockmean_kernel, dim3(bb), dim3(256), 0, st, Q, b, seq, D, Dbar);
-    hipLaunchKernelGGL(rank_hinge_kernel, dim3(ceil_div((long)Q * b, 4)), dim3(256), 0, st, Q, b, d->margin, Dbar, dDbar, terms);
+    hipLaunchKernelGGL(rank_hinge_kernel, dim3(loss_row_blocks((long)Q * b)), dim3(256), 0, st, Q, b, d->margin, Dbar, dDbar, terms);
     hipLaunchKernelGGL(rank_coeff_kernel, dim3(ceil_div((long)Q * B, 4)), dim3(256), 0, st, Q, b, seq, d->w_rank, D, dDbar, rs);
     if (int rc = f32_gemm(true, B, dim, B, D, B, (long)B * B, X, dim, (long)B * dim, EX, dim, (long)B * dim, Q, 1.0f, st)) return rc;
     int gb = ceil_div((long)Q * B * dim, 256);
@@ -406,7 +429,7 @@ extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* fea
   }
 
   // ---- orthogonality
-  hipLaunchKernelGGL(orth_kernel, dim3(ceil_div((long)pl.O * B, 4)), dim3(256), 0, st, orth, pl.O, B, dim, half, d->w_orth, terms);
+  hipLaunchKernelGGL(orth_kernel, dim3(loss_row_blocks((long)pl.O * B)), dim3(256), 0, st, orth, pl.O, B, dim, half, d->w_orth, terms);
   hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, terms, d->w_shared, d->w_private, d->w_orth, d->w_rank);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
