@@ -6,6 +6,7 @@
 //   * the small weight re-layouts between the reference's [Cout][Cin][1][k] storage and the GEMM operand orders.
 #include <stdlib.h>
 #include "gemm.hpp"
+#include "patch_stage.hpp"
 
 #define CIN_TOK 64
 
@@ -174,42 +175,26 @@ __global__ __launch_bounds__(256) void conv_in_bwd_weight_smallk_kernel(const fl
 typedef float cf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ cf4 cmfma(float a, float b, cf4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-template <int K, int KP>
-__device__ __forceinline__ void conv_in_stage_patches(const float* __restrict__ x, float* patch, const focal_conv_in_desc& d, int t0,
-                                                      int total, int tid) {
-  constexpr int UPT = K / 4;  // float4 units per token
-  for (int u = tid; u < CIN_TOK * UPT; u += 256) {
-    const int t = u / UPT, kq = u - t * UPT, tok = t0 + t;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tok < total) {
-      const int so = tok % d.S_out, r = tok / d.S_out, ii = r % d.I, b = r / d.I;
-      const int kk = 4 * kq, c = kk / d.k, tt = kk - c * d.k;
-      v = *reinterpret_cast<const float4*>(x + (((long)b * d.cin + c) * d.I + ii) * d.S_in + so * d.k + tt);
-    }
-    *reinterpret_cast<float4*>(patch + t * KP + 4 * kq) = v;
-  }
-}
-
+// (patch tiles are staged by patch_stage.hpp: all of a thread's loads in flight before the first LDS write)
 // z[tok][n] = bias[n] + sum_kk patch[tok][kk] * w[n][kk].  Wave w owns tokens 16w..16w+15 of the tile and all 64 channels;
 // the filter bank lives in registers as MFMA fragments (K = 160: 160 VGPRs) for the whole (grid-strided) kernel.
 template <int K>
 __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ z,
-                                                               focal_conv_in_desc d, int total) {
+                                                               focal_conv_in_desc d, int total, PatchGeom pg) {
   constexpr int KP = K + 4, KS = K / 4;
   __shared__ __attribute__((aligned(16))) float patch[CIN_TOK * KP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
   float wf[4][KS];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[nt][ks] = w[(16 * nt + lm) * K + 4 * ks + lg];
+  load_filter_fragments<K>(w, patch, tid, wf);  // coalesced, through the (same-shaped) patch tile
   float4 bv[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const float4*>(bias + 16 * nt + 4 * lg);
+  PatchPlan<K, CIN_TOK> plan;
+  patch_stage_plan<K, CIN_TOK, KP>(plan, pg, tid);
   for (int t0 = blockIdx.x * CIN_TOK; t0 < total; t0 += gridDim.x * CIN_TOK) {
     __syncthreads();
-    conv_in_stage_patches<K, KP>(x, patch, d, t0, total, tid);
+    patch_stage_tile<K, CIN_TOK>(plan, pg, x, patch, t0, total);
     __syncthreads();
     cf4 acc[4];
 #pragma unroll
@@ -236,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_in_fwd_mfma_kernel(const float* __re
 template <typename TZ, int K>
 __global__ __launch_bounds__(256) void conv_in_bwd_weight_mfma_kernel(const float* __restrict__ x, const TZ* __restrict__ dz,
                                                                       float* __restrict__ dw, float* __restrict__ dbias,
-                                                                      focal_conv_in_desc d, int total, int chunks_per_wg) {
+                                                                      focal_conv_in_desc d, int total, int chunks_per_wg, PatchGeom pg) {
   constexpr int KP = K + 16, GP = 80, NKT = K / 16, TPW = 4 * NKT / 4;  // tiles per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* patch = smem;             // [CIN_TOK][KP]   (reused as the [64][K] staging block at the end)
@@ -246,16 +231,24 @@ __global__ __launch_bounds__(256) void conv_in_bwd_weight_mfma_kernel(const floa
 #pragma unroll
   for (int i = 0; i < TPW; ++i) acc[i] = cf4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
+  PatchPlan<K, CIN_TOK> plan;
+  patch_stage_plan<K, CIN_TOK, KP>(plan, pg, tid);
   for (int ch = 0; ch < chunks_per_wg; ++ch) {
     const int t0 = (blockIdx.x * chunks_per_wg + ch) * CIN_TOK;
     if (t0 >= total) break;
     __syncthreads();
-    conv_in_stage_patches<K, KP>(x, patch, d, t0, total, tid);
-    for (int i = tid; i < CIN_TOK * 16; i += 256) {  // 16 float4 per token row
-      const int t = i >> 4, c4 = (i & 15) * 4, tok = t0 + t;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (tok < total) loadN<4>(dz + (long)tok * 64 + c4, v);
-      *reinterpret_cast<float4*>(g + t * GP + c4) = make_float4(v[0], v[1], v[2], v[3]);
+    float gv[4][4];  // this thread's four 16-byte pieces of the dz tile: requested before the patch loads, written after them
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // 16 float4 per token row
+      const int i = tid + 256 * j, t = i >> 4, c4 = (i & 15) * 4, tok = t0 + t;
+      gv[j][0] = gv[j][1] = gv[j][2] = gv[j][3] = 0.f;
+      if (tok < total) loadN<4>(dz + (long)tok * 64 + c4, gv[j]);
+    }
+    patch_stage_tile<K, CIN_TOK>(plan, pg, x, patch, t0, total);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * j, t = i >> 4, c4 = (i & 15) * 4;
+      *reinterpret_cast<float4*>(g + t * GP + c4) = make_float4(gv[j][0], gv[j][1], gv[j][2], gv[j][3]);
     }
     __syncthreads();
     if (tid < 64) {
@@ -302,7 +295,8 @@ extern "C" int focal_conv_in_fwd(const focal_conv_in_desc* d, const float* x, co
   if (conv_in_is_patchify(d)) {
     int blocks = ceil_div(total, CIN_TOK);
     if (blocks > 768) blocks = 768;
-    hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<160>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, z, *d, total);
+    const PatchGeom pg = make_patch_geom(d->S_out, d->I, d->I, d->S_in, d->k, d->cin);
+    hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<160>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, z, *d, total, pg);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
@@ -326,10 +320,11 @@ extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float
     const int blocks = ceil_div(chunks, cpw);
     const size_t smm = ((size_t)CIN_TOK * (160 + 16) + (size_t)CIN_TOK * 80) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    const PatchGeom pg = make_patch_geom(d->S_out, d->I, d->I, d->S_in, d->k, d->cin);
     if (dz_dtype == FOCAL_F32)
-      hipLaunchKernelGGL((conv_in_bwd_weight_mfma_kernel<float, 160>), dim3(blocks), dim3(256), smm, st, x, (const float*)dz, dw, dbias, *d, total, cpw);
+      hipLaunchKernelGGL((conv_in_bwd_weight_mfma_kernel<float, 160>), dim3(blocks), dim3(256), smm, st, x, (const float*)dz, dw, dbias, *d, total, cpw, pg);
     else
-      hipLaunchKernelGGL((conv_in_bwd_weight_mfma_kernel<bf16_t, 160>), dim3(blocks), dim3(256), smm, st, x, (const bf16_t*)dz, dw, dbias, *d, total, cpw);
+      hipLaunchKernelGGL((conv_in_bwd_weight_mfma_kernel<bf16_t, 160>), dim3(blocks), dim3(256), smm, st, x, (const bf16_t*)dz, dw, dbias, *d, total, cpw, pg);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }

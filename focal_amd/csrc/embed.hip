@@ -5,6 +5,7 @@
 // token by wave shuffles.
 #include <stdlib.h>
 #include "common.hpp"
+#include "patch_stage.hpp"
 
 #define EMB_TOK 64
 
@@ -89,15 +90,12 @@ template <int K>
 __global__ __launch_bounds__(256) void patch_embed_ln_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float* __restrict__ tokens,
-                                                                  focal_embed_desc d, int total_tokens) {
-  constexpr int KP = K + 4, KS = K / 4, UPT = K / 4;
+                                                                  focal_embed_desc d, int total_tokens, PatchGeom pg) {
+  constexpr int KP = K + 4, KS = K / 4;
   __shared__ __attribute__((aligned(16))) float patch[EMB_TOK * KP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
   float wf[4][KS];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[nt][ks] = w[(16 * nt + lm) * K + 4 * ks + lg];
+  load_filter_fragments<K>(w, patch, tid, wf);  // (the patch tile has the same [64][K + 4] shape)
   float4 bv[4], gv[4], be[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -105,20 +103,16 @@ __global__ __launch_bounds__(256) void patch_embed_ln_mfma_kernel(const float* _
     gv[nt] = *reinterpret_cast<const float4*>(gamma + 16 * nt + 4 * lg);
     be[nt] = *reinterpret_cast<const float4*>(beta + 16 * nt + 4 * lg);
   }
+  PatchPlan<K, EMB_TOK> plan;
+  patch_stage_plan<K, EMB_TOK, KP>(plan, pg, tid);
+  // the NEXT tile's patches are requested while this one is multiplied (20 registers: still two waves per SIMD)
+  float4 stage[PatchPlan<K, EMB_TOK>::NIT];
+  if ((int)(blockIdx.x * EMB_TOK) < total_tokens) patch_stage_load<K, EMB_TOK>(plan, pg, x, blockIdx.x * EMB_TOK, total_tokens, stage);
   for (int t0 = blockIdx.x * EMB_TOK; t0 < total_tokens; t0 += gridDim.x * EMB_TOK) {
     __syncthreads();
-    for (int u = tid; u < EMB_TOK * UPT; u += 256) {
-      const int t = u / UPT, kq = u - t * UPT, tok = t0 + t;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tok < total_tokens) {
-        const int px = tok % d.Wp, r = tok / d.Wp, py = r % d.Hp, b = r / d.Hp;
-        const int kk = 4 * kq, c = kk / d.pw, tt = kk - c * d.pw;
-        const int col = px * d.pw + tt;
-        if (py < d.I && col < d.S) v = *reinterpret_cast<const float4*>(x + (((long)b * d.cin + c) * d.I + py) * d.S + col);  // else: zero padding
-      }
-      *reinterpret_cast<float4*>(patch + t * KP + 4 * kq) = v;
-    }
+    patch_stage_store<K, EMB_TOK>(plan, patch, stage);
     __syncthreads();
+    if (t0 + (int)(gridDim.x * EMB_TOK) < total_tokens) patch_stage_load<K, EMB_TOK>(plan, pg, x, t0 + gridDim.x * EMB_TOK, total_tokens, stage);
     ef4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = ef4{bv[nt].x, bv[nt].y, bv[nt].z, bv[nt].w};
@@ -169,8 +163,12 @@ extern "C" int focal_pad_patch_embed_ln_fwd(const focal_embed_desc* d, const flo
   hipStream_t st = (hipStream_t)stream;
   if (K == 80 && d->C0 == 64 && d->pw % 4 == 0 && d->S % 4 == 0 && !getenv("FOCAL_EMBED_VALU")) {
     int mb = ceil_div(total, EMB_TOK);
-    if (mb > 1024) mb = 1024;
-    hipLaunchKernelGGL((patch_embed_ln_mfma_kernel<80>), dim3(mb), dim3(256), 0, st, x, w, b, gamma, beta, tokens, *d, total);
+    // two resident workgroups per CU (208-230 VGPRs); more only repeats the filter-bank load (measured 61 / 74 / 102 / 178 us at
+    // 512 / 1024 / 2048 / 4608 workgroups before the bank went through LDS)
+    static const int mb_cap = getenv("FOCAL_EMBED_BLOCKS") ? atoi(getenv("FOCAL_EMBED_BLOCKS")) : 512;
+    if (mb > mb_cap) mb = mb_cap;
+    const PatchGeom pg = make_patch_geom(d->Wp, d->Hp, d->I, d->S, d->pw, d->cin);
+    hipLaunchKernelGGL((patch_embed_ln_mfma_kernel<80>), dim3(mb), dim3(256), 0, st, x, w, b, gamma, beta, tokens, *d, total, pg);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
