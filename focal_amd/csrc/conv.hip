@@ -119,6 +119,62 @@ __global__ __launch_bounds__(256) void conv_in_bwd_weight_kernel(const float* __
 
 // Small filters (K = cin * k <= 16, the seismic [1,3] in-conv: K = 6): the kernel above would keep K of its 256 threads busy.
 // Here thread (n = tid & 63, kg = tid >> 6) owns dw[n][kg], dw[n][kg + 4], ...; same staging, same contiguous atomics.
+// K = cin * k <= 16 (the seismic [1, 3] in-conv: 20 MFLOP in all).  A wave is the 64 output channels; it walks its own slice of
+// tokens straight from global memory -- one coalesced 128/256-byte row of dz per token, the token's K input samples through
+// wave-uniform (scalar) loads -- with the K + 1 running sums per channel in registers, no LDS tile and no barrier in the loop.
+// 16 waves per workgroup fold their sums through LDS and ONE wave issues the atomics: the 64 x K gradient is 12 cache lines, and
+// atomics into one line retire ~3.4 ns apart, so the number of workgroups (64) is what bounds the tail, not the math.
+template <typename TZ>
+__global__ __launch_bounds__(1024) void conv_in_bwd_weight_tiny_kernel(const float* __restrict__ x, const TZ* __restrict__ dz,
+                                                                       float* __restrict__ dw, float* __restrict__ dbias,
+                                                                       focal_conv_in_desc d, int K, int total, int tok_per_wave) {
+  __shared__ float red[16][17][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 16 + wave;
+  float acc[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) acc[kk] = 0.f;
+  float bsum = 0.f;
+  const int t_begin = gw * tok_per_wave, t_end = min(total, t_begin + tok_per_wave);
+  // lane kk < K fetches tap kk of the current token (one vector load for all K samples); v_readlane hands each to the whole wave
+  const int my_c = lane < K ? lane / d.k : 0, my_tt = lane < K ? lane - my_c * d.k : 0;
+  const long my_off = (long)my_c * d.I * d.S_in + my_tt - d.pad_left;
+  int so = t_begin % d.S_out, r0 = t_begin / d.S_out;  // wave-uniform; advanced incrementally (no division in the loop)
+  long row_base = (((long)(r0 / d.I) * d.cin) * d.I + (r0 % d.I)) * d.S_in;
+  int ii = r0 % d.I;
+#pragma unroll 4
+  for (int tok = t_begin; tok < t_end; ++tok) {
+    const float g = to_f32(dz[(long)tok * 64 + lane]);
+    const int col = so * d.stride + my_tt - d.pad_left;
+    float xv = 0.f;
+    if (lane < K && col >= 0 && col < d.S_in) xv = x[row_base + (long)so * d.stride + my_off];
+    bsum += g;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      if (kk < K) acc[kk] += g * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv), kk));
+    if (++so == d.S_out) {
+      so = 0;
+      if (++ii == d.I) { ii = 0; row_base += (long)(d.cin - 1) * d.I * d.S_in; }
+      row_base += d.S_in;
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) red[wave][kk][lane] = acc[kk];
+  red[wave][16][lane] = bsum;
+  __syncthreads();
+  if (wave == 0) {
+    for (int kk = 0; kk <= 16; ++kk) {
+      if (kk < K || kk == 16) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += red[w][kk][lane];
+        if (kk < 16) atomicAdd(dw + (long)lane * K + kk, v);
+        else if (dbias) atomicAdd(dbias + lane, v);
+      }
+    }
+  }
+}
+
 template <typename TZ, int C0>
 __global__ __launch_bounds__(256) void conv_in_bwd_weight_smallk_kernel(const float* __restrict__ x, const TZ* __restrict__ dz,
                                                                         float* __restrict__ dw, float* __restrict__ dbias,
@@ -134,20 +190,39 @@ __global__ __launch_bounds__(256) void conv_in_bwd_weight_smallk_kernel(const fl
     const int t0 = (blockIdx.x * chunks_per_wg + ch) * CIN_TOK;
     if (t0 >= total) break;
     __syncthreads();
-    for (int i = tid; i < CIN_TOK * K; i += 256) {
-      const int t = i / K, kk = i - t * K, tok = t0 + t;
-      float v = 0.f;
-      if (tok < total) {
+    // every load of the chunk is issued before the first LDS write (a load -> wait -> write loop costs one memory latency per
+    // iteration: 16 of them for the gradient tile alone, ~80 % of this kernel's time)
+    constexpr int EPT = 16 / (int)sizeof(TZ), NG = CIN_TOK * C0 / EPT / 256;  // 16-byte pieces of the dz tile per thread
+    float gv[NG][EPT];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int i = tid + 256 * j, t = i / (C0 / EPT), c = (i % (C0 / EPT)) * EPT, tok = t0 + t;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) gv[j][e] = 0.f;
+      if (tok < total) loadN<EPT>(dz + (long)tok * C0 + c, gv[j]);
+    }
+    float pv[4];  // K <= 16: at most 4 patch values per thread
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * j, t = i / K, kk = i - t * K, tok = t0 + t;
+      pv[j] = 0.f;
+      if (i < CIN_TOK * K && tok < total) {
         const int so = tok % d.S_out, r = tok / d.S_out, ii = r % d.I, b = r / d.I;
         const int c = kk / d.k, tt = kk - c * d.k;
         const int col = so * d.stride + tt - d.pad_left;
-        if (col >= 0 && col < d.S_in) v = x[(((long)b * d.cin + c) * d.I + ii) * d.S_in + col];
+        if (col >= 0 && col < d.S_in) pv[j] = x[(((long)b * d.cin + c) * d.I + ii) * d.S_in + col];
       }
-      patch[t * KP + kk] = v;
     }
-    for (int i = tid; i < CIN_TOK * C0; i += 256) {
-      const int t = i / C0, c = i % C0, tok = t0 + t;
-      g[t * GP + c] = tok < total ? to_f32(dz[(long)tok * C0 + c]) : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * j;
+      if (i < CIN_TOK * K) patch[(i / K) * KP + (i % K)] = pv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int i = tid + 256 * j, t = i / (C0 / EPT), c = (i % (C0 / EPT)) * EPT;
+#pragma unroll
+      for (int e = 0; e < EPT; e += 4) *reinterpret_cast<float4*>(g + t * GP + c + e) = make_float4(gv[j][e], gv[j][e + 1], gv[j][e + 2], gv[j][e + 3]);
     }
     __syncthreads();
     for (int t = 0; t < CIN_TOK; ++t) {
@@ -331,10 +406,24 @@ extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
+  if (K <= 16 && d->C == 64 && !getenv("FOCAL_CONVIN_DW_LDS")) {
+    static const int tiny_wg = getenv("FOCAL_CONVIN_DW_BLOCKS") ? atoi(getenv("FOCAL_CONVIN_DW_BLOCKS")) : 64;
+    const int waves = tiny_wg * 16;
+    const int tpw = ceil_div(total, waves);
+    const int blocks = ceil_div(ceil_div(total, tpw), 16);
+    hipStream_t st = (hipStream_t)stream;
+    if (dz_dtype == FOCAL_F32)
+      hipLaunchKernelGGL((conv_in_bwd_weight_tiny_kernel<float>), dim3(blocks), dim3(1024), 0, st, x, (const float*)dz, dw, dbias, *d, K, total, tpw);
+    else
+      hipLaunchKernelGGL((conv_in_bwd_weight_tiny_kernel<bf16_t>), dim3(blocks), dim3(1024), 0, st, x, (const bf16_t*)dz, dw, dbias, *d, K, total, tpw);
+    FOCAL_LAUNCH_CHECK();
+    return FOCAL_OK;
+  }
   if (K <= 16) {
     const size_t sms = ((size_t)CIN_TOK * (K + 1) + (size_t)CIN_TOK * (d->C + 4)) * sizeof(float);
     const int chunks = ceil_div(total, CIN_TOK);
-    int cpw = ceil_div(chunks, 512);
+    static const int wg_cap = getenv("FOCAL_CONVIN_DW_BLOCKS") ? atoi(getenv("FOCAL_CONVIN_DW_BLOCKS")) : 512;
+    int cpw = ceil_div(chunks, wg_cap);
     if (cpw < 1) cpw = 1;
     const int blocks = ceil_div(chunks, cpw);
     hipStream_t st = (hipStream_t)stream;
