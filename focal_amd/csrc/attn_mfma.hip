@@ -41,6 +41,31 @@ __device__ __forceinline__ void load_tile(bf16_t* tile, const bf16_t* base, long
   }
 }
 
+// Two-phase form: all of an item's tile loads are issued first (into registers), LDS is written later.  `load_tile` above
+// compiles to load -> s_waitcnt vmcnt(0) -> ds_write per tile: four exposed memory latencies per (window, head) in the
+// backward kernel, which was its whole duration (32 items per wave x ~5 us at stage 0).  With the register phase the NEXT
+// item's tiles are requested before the current item is multiplied, so the latency is hidden behind ~500 instructions.
+template <int HD> struct TileRegs { bf16x4 v[HD / 16]; };
+template <int HD>
+__device__ __forceinline__ void tile_fetch(TileRegs<HD>& r, const bf16_t* base, long row_stride, int tok_own, int N, int lane) {
+  constexpr int CPR = HD / 4;
+#pragma unroll
+  for (int q = 0; q < HD / 16; ++q) {
+    const int c = lane + 64 * q, t = c / CPR, dc = c % CPR;
+    const int tok = __shfl(tok_own, t, 64);
+    r.v[q] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (t < N) r.v[q] = *reinterpret_cast<const bf16x4*>(base + (long)tok * row_stride + dc * 4);
+  }
+}
+template <int HD> __device__ __forceinline__ void tile_commit(bf16_t* tile, const TileRegs<HD>& r, int lane) {
+  constexpr int P = HD + 4, CPR = HD / 4;
+#pragma unroll
+  for (int q = 0; q < HD / 16; ++q) {
+    const int c = lane + 64 * q, t = c / CPR, dc = c % CPR;
+    *reinterpret_cast<bf16x4*>(tile + t * P + dc * 4) = r.v[q];
+  }
+}
+
 // The LDS tiles are private to one wave and DS operations of a wave execute in issue order, so no workgroup barrier
 // is needed between filling a tile and reading fragments from it; this only stops the compiler from reordering.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -147,18 +172,37 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
   const int slot = lane & 15, sy = slot / g.ww, sx = slot - sy * g.ww;
   float biasA[4] = {0.f, 0.f, 0.f, 0.f};
   int h_cur = -1;
-  for (int it = 0; it < iters; ++it) {
+  // item state (uniform per wave) + this lane's token; the tiles of item it + 1 are in flight while item it is multiplied
+  auto item_of = [&](int it, bool& live, int& win, int& h) {
     const int item = (it * gridDim.x + blockIdx.x) * 4 + wave;
-    const bool live = item < total_items;
-    const int win = live ? item / g.heads : 0, h = live ? item % g.heads : 0;
+    live = item < total_items;
+    win = live ? item / g.heads : 0;
+    h = live ? item % g.heads : 0;
+  };
+  TileRegs<HD> rq, rk, rv;
+  bool live_n; int win_n, h_n, reg_n = 0, tok_n = 0;
+  item_of(0, live_n, win_n, h_n);
+  tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
+  tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
+  tile_fetch<HD>(rk, qkv + C + h_n * HD, 3 * C, tok_n, g.N, lane);
+  tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
+  for (int it = 0; it < iters; ++it) {
+    const bool live = live_n;
+    const int win = win_n, h = h_n, reg_own = reg_n, tok_own = tok_n;
     const bool edge = g.shifted;  // (restricting this to the windows that really mix mask regions costs more in index arithmetic than it saves)
-    int reg_own = 0;
-    const int tok_own = slot < g.N ? slot_token(g, win, sy, sx, &reg_own) : 0;
     wave_lds_fence();  // previous iteration's fragment reads are issued before these tile writes
-    load_tile<HD>(Qt, qkv + h * HD, 3 * C, tok_own, g.N, lane);
-    load_tile<HD>(Kt, qkv + C + h * HD, 3 * C, tok_own, g.N, lane);
-    load_tile<HD>(Vt, qkv + 2 * C + h * HD, 3 * C, tok_own, g.N, lane);
+    tile_commit<HD>(Qt, rq, lane);
+    tile_commit<HD>(Kt, rk, lane);
+    tile_commit<HD>(Vt, rv, lane);
     wave_lds_fence();
+    if (it + 1 < iters) {
+      item_of(it + 1, live_n, win_n, h_n);
+      reg_n = 0;
+      tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
+      tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
+      tile_fetch<HD>(rk, qkv + C + h_n * HD, 3 * C, tok_n, g.N, lane);
+      tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
+    }
     f32x4 st = {0.f, 0.f, 0.f, 0.f};  // S^T: rows j (keys), col i (query)
 #pragma unroll
     for (int kk = 0; kk < HD / 16; ++kk) st = mma16x16(frag_rows(Kt, P, kk, lane), frag_rows(Qt, P, kk, lane), st);
@@ -224,23 +268,43 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
   };
   float biasA[4] = {0.f, 0.f, 0.f, 0.f}, biasB[4] = {0.f, 0.f, 0.f, 0.f};
   int h_cur = -1;
-  for (int it = 0; it < iters; ++it) {
+  auto item_of = [&](int it, bool& live, int& win, int& h) {
     const int item = (it * gridDim.x + blockIdx.x) * NW + wave;
-    const bool live = item < total_items;
-    const int win = live ? item / g.heads : 0, h = live ? item % g.heads : 0;
+    live = item < total_items;
+    win = live ? item / g.heads : 0;
+    h = live ? item % g.heads : 0;
+  };
+  TileRegs<HD> rq, rk, rv, rg;
+  bool live_n; int win_n, h_n, reg_n = 0, tok_n = 0;
+  item_of(0, live_n, win_n, h_n);
+  tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
+  tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
+  tile_fetch<HD>(rk, qkv + C + h_n * HD, 3 * C, tok_n, g.N, lane);
+  tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
+  tile_fetch<HD>(rg, dout + h_n * HD, C, tok_n, g.N, lane);
+  for (int it = 0; it < iters; ++it) {
+    const bool live = live_n;
+    const int win = win_n, h = h_n, reg_own = reg_n, tok_own = tok_n;
     const bool edge = g.shifted;  // (restricting this to the windows that really mix mask regions costs more in index arithmetic than it saves)
     if (live && h != h_acc) {
       flush_dbias();
       h_acc = h;
     }
-    int reg_own = 0;
-    const int tok_own = slot < g.N ? slot_token(g, win, sy, sx, &reg_own) : 0;
     wave_lds_fence();
-    load_tile<HD>(Qt, qkv + h * HD, 3 * C, tok_own, g.N, lane);
-    load_tile<HD>(Kt, qkv + C + h * HD, 3 * C, tok_own, g.N, lane);
-    load_tile<HD>(Vt, qkv + 2 * C + h * HD, 3 * C, tok_own, g.N, lane);
-    load_tile<HD>(Gt, dout + h * HD, C, tok_own, g.N, lane);
+    tile_commit<HD>(Qt, rq, lane);
+    tile_commit<HD>(Kt, rk, lane);
+    tile_commit<HD>(Vt, rv, lane);
+    tile_commit<HD>(Gt, rg, lane);
     wave_lds_fence();
+    if (it + 1 < iters) {  // the next item's tiles fly while this one is multiplied
+      item_of(it + 1, live_n, win_n, h_n);
+      reg_n = 0;
+      tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
+      tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
+      tile_fetch<HD>(rk, qkv + C + h_n * HD, 3 * C, tok_n, g.N, lane);
+      tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
+      tile_fetch<HD>(rg, dout + h_n * HD, C, tok_n, g.N, lane);
+    }
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, d1 = s1, d2 = s1;
 #pragma unroll
     for (int kk = 0; kk < HD / 16; ++kk) {
