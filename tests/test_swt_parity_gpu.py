@@ -158,6 +158,11 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
     net.arena().zero_grad()
     value().backward()
     torch.cuda.synchronize()
+    # run-to-run noise of the forward value (fp32 atomics in the split-K products sum in arrival order): the central
+    # difference below divides it by 2 eps, so it is part of the tolerance (a mask mismatch is an O(1) relative error)
+    with torch.no_grad():
+        vals = [value().item() for _ in range(4)]
+    noise = max(vals) - min(vals) + 2e-7 * abs(vals[0])
     params = dict(net.named_parameters())
     names = ["freq_interval_layers.shake.audio.0.blocks.1.mlp.fc2.weight", "freq_interval_layers.shake.audio.1.blocks.0.attn.proj.weight",
              "freq_interval_layers.shake.seismic.2.blocks.3.mlp.fc1.weight", "freq_interval_layers.shake.audio.0.downsample.reduction.weight",
@@ -174,7 +179,7 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
             dn = value().item()
             p.add_(eps * d)
         num = (up - dn) / (2 * eps)
-        assert abs(num - ana) < 3e-2 * max(abs(ana), abs(num), 1e-3), (n, num, ana)
+        assert abs(num - ana) < 3e-2 * max(abs(ana), abs(num), 1e-3) + 2 * noise / (2 * eps), (n, num, ana, noise, eps)
 
 
 @pytest.mark.parametrize("ct", ["fp32", "bf16"])
