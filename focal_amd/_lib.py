@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfocal_hip.so")
+LIB_PATH = os.environ.get("FOCAL_HIP_LIB") or os.path.join(_HERE, "libfocal_hip.so")  # (override: A/B runs of two builds on one box)
 
 FOCAL_F32, FOCAL_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU_OUT = 0, 1, 2
