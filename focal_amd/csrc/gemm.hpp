@@ -476,29 +476,11 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
       // half the store instructions at equal bytes)
       constexpr int CPL = (sizeof(TC) == 2) ? 8 : 4;
       constexpr int LPR = WN / CPL, RPI = 64 / LPR;  // lanes per row, rows per wave-instruction
-      constexpr int NROW = RP / RPI;                 // row groups per pass
       const int c = (lane % LPR) * CPL, n = nbase + c;
       float bias[CPL];
 #pragma unroll
       for (int e = 0; e < CPL; ++e) bias[e] = 0.f;
       if (p.bias && n < p.N) loadN<CPL>(p.bias + n, bias);
-      // the pass's residual / multiplier operands are requested in one batch BEFORE the row walk: inside it the compiler
-      // cannot move a load above the previous row's store (they may alias), which made every row group wait out a full
-      // memory latency (4-8 per tile)
-      float side[(EPI == EPI_RESID || EPI == EPI_MUL_AUX || EPI == EPI_RELU_BWD) ? NROW : 1][CPL];
-      if (EPI == EPI_RESID || EPI == EPI_MUL_AUX || EPI == EPI_RELU_BWD) {
-#pragma unroll
-        for (int q = 0; q < NROW; ++q) {
-          const int m = mbase + q * RPI + lane / LPR;
-#pragma unroll
-          for (int e = 0; e < CPL; ++e) side[q][e] = 0.f;
-          if (m < p.M && n < p.N) {
-            if (EPI == EPI_RESID) loadN<CPL>(p.resid + (long)m * p.ldr + n, side[q]);
-            else if (EPI == EPI_MUL_AUX) loadN<CPL>(reinterpret_cast<const CT*>(p.aux) + (long)m * p.ldaux + n, side[q]);
-            else loadN<CPL>(reinterpret_cast<const TC*>(p.aux) + (long)m * p.ldaux + n, side[q]);
-          }
-        }
-      }
 #pragma unroll
       for (int rr = 0; rr < RP; rr += RPI) {
         const int row = rr + lane / LPR;
@@ -512,13 +494,15 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
         if (EPI == EPI_STORE) {
           storeN<CPL>(dst, v);
         } else if (EPI == EPI_RESID) {
-          const float* r = side[rr / RPI];
+          float r[CPL];
+          loadN<CPL>(p.resid + (long)m * p.ldr + n, r);
           const float rowm = meE.row_mult(m);
 #pragma unroll
           for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
           storeN<CPL>(dst, v);
         } else if (EPI == EPI_MUL_AUX) {
-          const float* a = side[rr / RPI];
+          float a[CPL];
+          loadN<CPL>(reinterpret_cast<const CT*>(p.aux) + (long)m * p.ldaux + n, a);
 #pragma unroll
           for (int e = 0; e < CPL; ++e) v[e] *= a[e];
           storeN<CPL>(dst, v);
@@ -541,7 +525,8 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
           for (int e = 0; e < CPL; ++e) v[e] = fmaxf(v[e], 0.f);
           storeN<CPL>(dst, v);
         } else if (EPI == EPI_RELU_BWD) {
-          const float* y = side[rr / RPI];
+          float y[CPL];
+          loadN<CPL>(reinterpret_cast<const TC*>(p.aux) + (long)m * p.ldaux + n, y);
 #pragma unroll
           for (int e = 0; e < CPL; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
           storeN<CPL>(dst, v);

@@ -176,22 +176,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
       *reinterpret_cast<float4*>(est + (lane & 15) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
     const int mbase = m0 + wm * WR + i * 16;
-    // residual / multiplier operands of these 16 rows: one batch of loads before the row walk (inside it a load cannot move
-    // above the previous row's store -- possible alias -- and every row group would wait out a memory latency)
-    constexpr int NROW = 16 / RPI;
-    float side[(EPI == EPI_RESID || EPI == EPI_MUL_AUX) ? NROW : 1][CPL];
-    if (EPI == EPI_RESID || EPI == EPI_MUL_AUX) {
-#pragma unroll
-      for (int q = 0; q < NROW; ++q) {
-        const int m = mbase + q * RPI + lane / LPR;
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) side[q][e] = 0.f;
-        if (m < p.M) {
-          if (EPI == EPI_RESID) loadN<CPL>(p.resid + (long)m * p.ldr + n, side[q]);
-          else loadN<CPL>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n, side[q]);
-        }
-      }
-    }
 #pragma unroll
     for (int rr = 0; rr < 16; rr += RPI) {
       const int row = rr + lane / LPR, m = mbase + row;
@@ -204,13 +188,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
       if (EPI == EPI_STORE) {
         storeN<CPL>(dst, v);
       } else if (EPI == EPI_RESID) {
-        const float* r = side[rr / RPI];
+        float r[CPL];
+        loadN<CPL>(p.resid + (long)m * p.ldr + n, r);
         const float rowm = meE.row_mult(m);
 #pragma unroll
         for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
         storeN<CPL>(dst, v);
       } else if (EPI == EPI_MUL_AUX) {
-        const float* a = side[rr / RPI];
+        float a[CPL];
+        loadN<CPL>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n, a);
 #pragma unroll
         for (int e = 0; e < CPL; ++e) v[e] *= a[e];
         storeN<CPL>(dst, v);
