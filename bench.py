@@ -264,7 +264,7 @@ def roofline(a, step, device):
     flops = 2.0 * M * N * K
     gbs = bytes_alg / (ms * 1e-3) / 1e9
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r1_q_pmc_roofline_kernel.json")
+    tf = os.path.join(ROOT, "profiles", "r1_u_pmc_roofline_kernel.json")
     if os.path.exists(tf):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --roofline-only` (see the file's note)
         traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
     return {"bound": "hbm", "kernel": "focal_gemm_kernel<dW: gm[%d,%d]%s^T x h[%d,%d]%s -> fp32 atomics, 64x64 tiles>" % (M, N, a.dtype, M, K, a.dtype),
