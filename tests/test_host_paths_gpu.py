@@ -1,0 +1,99 @@
+"""Host-side plumbing added around the HIP kernels: the per-step zero pool, the two-views-as-one-batch fast paths and their
+fallbacks.  Each fast path must give the same numbers as the plain path it replaces."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "focal_amd", "src"))
+
+
+def test_zero_pool_hands_out_zeroed_disjoint_slices_and_falls_back_when_exhausted():
+    from focal_amd import ops
+    dev = torch.device("cuda", 0)
+    ops.zero_pool_reset(dev)
+    a = ops.pool_zeros(100, dev)
+    b = ops.pool_zeros(7, dev)
+    assert a is not None and b is not None and a.numel() == 100 and b.numel() == 7
+    assert a.data_ptr() % 256 == 0 and b.data_ptr() % 256 == 0 and b.data_ptr() >= a.data_ptr() + 400
+    assert float(a.abs().sum()) == 0.0 and float(b.abs().sum()) == 0.0
+    a.fill_(3.0)
+    b.fill_(5.0)
+    ops.zero_pool_reset(dev)  # one launch re-zeroes everything handed out since the last reset
+    a2 = ops.pool_zeros(100, dev)
+    assert a2.data_ptr() == a.data_ptr() and float(a2.abs().sum()) == 0.0 and float(b.abs().sum()) == 0.0
+    # exhaustion: callers get None and zero-fill themselves; ops.zeros hides the difference
+    big = ops.pool_zeros(ops._ZERO_POOL_FLOATS, dev)
+    assert big is None
+    z = ops.zeros((ops._ZERO_POOL_FLOATS // 4096 + 1, 4096), dev)
+    assert z.shape[1] == 4096 and float(z.abs().sum()) == 0.0
+    ops.zero_pool_reset(dev)
+
+
+def test_batchnorm_with_pool_scratch_equals_private_scratch():
+    """focal_bn_stats / focal_bn_act_bwd with FOCAL_BN_SCRATCH_ZEROED (pool slice) vs their own memset."""
+    from focal_amd import ops
+    dev = torch.device("cuda", 0)
+    rows, C = 5120, 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    z = torch.randn(rows, C, generator=g).to(dev)
+    gy = torch.randn(rows, C, generator=g).to(dev)
+    gamma, beta = torch.rand(C, generator=g).to(dev) + 0.5, torch.randn(C, generator=g).to(dev)
+
+    def run(use_pool):
+        ops.zero_pool_reset(dev)
+        if not use_pool:  # exhaust the pool so that both calls fall back to a private, self-zeroed scratch
+            assert ops.pool_zeros(ops._ZERO_POOL_FLOATS - 64, dev) is not None
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        d = ops.bn_desc(ops.code(torch.float32), rows, C, 256, 0.0, None, 0)
+        mr = ops.bn_stats(d, z, rm, rv, True)
+        dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dz = ops.bn_act_bwd(d, z, gy, mr, gamma, beta, dgam, dbet, torch.float32)
+        return mr.clone(), rm.clone(), rv.clone(), dz.clone(), dgam.clone(), dbet.clone()
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-4)  # (channel sums are fp32 atomics in arrival order)
+    ops.zero_pool_reset(dev)
+
+
+def test_views_as_one_batch_and_split_halves_fast_paths_match_the_plain_ones():
+    from models.FOCALModules import _SplitHalves, _as_one_batch
+    dev = "cuda"
+    base = torch.randn(8, 3, 5, device=dev)
+    x1, x2 = base[:4], base[4:]
+    assert _as_one_batch(x1, x2) is base                       # adjacent halves of one tensor: no copy
+    y1, y2 = x1.clone(), x2.clone()
+    both = _as_one_batch(y1, y2)                               # unrelated tensors: concatenated
+    assert both.data_ptr() not in (y1.data_ptr(), y2.data_ptr()) and torch.equal(both, base)
+    assert _as_one_batch(base[:4], base[3:7]).shape[0] == 8 and _as_one_batch(base[:4], base[3:7]).data_ptr() != base.data_ptr()
+    # split: forward halves; backward = one [2B, E] gradient, a view when the incoming gradients are adjacent
+    f = torch.randn(6, 16, device=dev, requires_grad=True)
+    h1, h2 = _SplitHalves.apply(f)
+    flat = torch.randn(6 * 16, device=dev)
+    g1, g2 = flat[:48].view(3, 16), flat[48:].view(3, 16)
+    (gf,) = torch.autograd.grad([h1, h2], [f], [g1, g2])
+    assert gf.data_ptr() == flat.data_ptr() and torch.equal(gf, flat.view(6, 16))
+    f2 = f.detach().clone().requires_grad_(True)
+    k1, k2 = _SplitHalves.apply(f2)
+    (gf2,) = torch.autograd.grad([k1, k2], [f2], [g1.clone(), g2.clone()])  # separate allocations: concatenated
+    assert torch.equal(gf2, flat.view(6, 16))
+    ref = f.detach().clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad([ref[:3], ref[3:]], [ref], [g1, g2])
+    assert torch.equal(gr, gf)
+
+
+def test_dft_writes_views_into_one_batch_tensor():
+    from focal_amd import ops
+    x = torch.randn(4, 2, 10, 1600, device="cuda")
+    both = torch.empty(8, 4, 10, 1600, device="cuda")
+    a = ops.fft_realpack(x, out=both[:4])
+    b = ops.fft_realpack(x, scale=-1.1, out=both[4:])
+    assert a.data_ptr() == both.data_ptr() and b.data_ptr() == both[4:].data_ptr()
+    assert torch.allclose(a, ops.fft_realpack(x)) and torch.allclose(b, ops.fft_realpack(x, scale=-1.1))
+    with pytest.raises(ValueError):
+        ops.fft_realpack(x, out=both[:3])
