@@ -17,8 +17,35 @@ ES = 2 if CT == torch.bfloat16 else 4
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
 
 
+COLD = os.environ.get("FOCAL_MB_COLD") == "1"
+_FLUSH = None
+
+
+def timeit_cold(fn, iters=12):
+    """Every timed launch starts with nothing cache-resident: a 768 MB fill (3 x the 256 MB infinity cache) runs before it, and
+    only the launch itself sits between the two events.  This is how kernels meet their operands inside the training step
+    (warm back-to-back replays flatter the numbers by 15-40 %)."""
+    global _FLUSH
+    if _FLUSH is None:
+        _FLUSH = torch.empty(768 << 18, dtype=torch.float32, device=DEV)  # 768 MB
+    for _ in range(2):
+        fn()
+    tot = 0.0
+    for i in range(iters):
+        _FLUSH.fill_(float(i))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / iters * 1e3  # us (includes ~2 us of eager launch + event overhead)
+
+
 def timeit(fn, iters=20):
     """Time `fn` by replaying a captured hipGraph of `iters` launches (no host launch overhead in the number)."""
+    if COLD:
+        return timeit_cold(fn)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         for _ in range(3):
