@@ -4,13 +4,15 @@
 //   backward  da = g * mask * gelu'(.)  ->  s1 = sum da, s2 = sum da * zhat  (= dbeta, dgamma)
 //             dz = gamma * rstd * (da - s1/n - zhat * s2/n)
 // All streaming, HBM-bound; per-channel reductions: registers -> wave shuffles -> LDS rows -> one atomic per channel per workgroup.
+#include <stdlib.h>
 #include "common.hpp"
 
 // Per-channel partial sums -> global: lanes that hold the same channels are folded with xor-shuffles, each wave parks one
 // [2][C] row in LDS (plain stores: LDS float atomics serialise per lane), the 4 waves are summed and every channel leaves
 // as one atomic per workgroup (16-wave workgroups, at most one per CU: the atomics onto one address are a serial chain).
 // `red` is [waves][2][C] floats; a[k] belongs to channel c + k of the first half, b[k] of the second.
-__device__ __forceinline__ void bn_commit_sums(float* red, float* __restrict__ sums, float (&a)[4], float (&b)[4], int C, int c) {
+__device__ __forceinline__ void bn_commit_sums(float* red, float* __restrict__ sums, float (&a)[4], float (&b)[4], int C, int c,
+                                               bool wait_performed = false) {
   const int lpr = C / 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int i = threadIdx.x; i < nw * 2 * C; i += blockDim.x) red[i] = 0.f;
   for (int o = lpr; o < 64; o <<= 1) {
@@ -27,12 +29,21 @@ __device__ __forceinline__ void bn_commit_sums(float* red, float* __restrict__ s
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
     float t = 0.f;
     for (int w = 0; w < nw; ++w) t += red[w * 2 * C + i];
-    atomicAdd(sums + i, t);
+    if (wait_performed) {
+      const float old = __hip_atomic_fetch_add(sums + i, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(old));  // keep the returning form: its result arriving means the add is done at L2
+    } else {
+      atomicAdd(sums + i, t);
+    }
   }
 }
 
 // sums[0..C) = sum z, sums[C..2C) = sum z^2   (sums must be zeroed by the caller-side launcher)
-__global__ __launch_bounds__(1024) void bn_partial_kernel(const float* __restrict__ z, float* __restrict__ sums, long rows, int C) {
+// TRAIN mode (fin.mean_rstd != null): the LAST workgroup to commit its sums (arrival counter at sums[2C]) finalises the statistics
+// -- one launch less per BatchNorm layer; nobody waits, so this is safe whatever else shares the chip.
+struct BnFinalize { float* mean_rstd; float* run_mean; float* run_var; long stat_rows; float eps, momentum; };
+__global__ __launch_bounds__(1024) void bn_partial_kernel(const float* __restrict__ z, float* __restrict__ sums, long rows, int C,
+                                                          BnFinalize fin) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][C]
   const int lpr = C / 4;                 // lanes per row
   const int rpb = blockDim.x / lpr;      // rows per block-iteration
@@ -56,7 +67,28 @@ __global__ __launch_bounds__(1024) void bn_partial_kernel(const float* __restric
     q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
   }
   float a[4] = {s.x, s.y, s.z, s.w}, b[4] = {q.x, q.y, q.z, q.w};
-  bn_commit_sums(red, sums, a, b, C, li * 4);
+  bn_commit_sums(red, sums, a, b, C, li * 4, fin.mean_rstd != nullptr);
+  if (fin.mean_rstd == nullptr) return;
+  __shared__ int is_last;
+  // (no __threadfence(): a device-scope fence writes back / invalidates L2 on this part and cost 25 % of the DeepSense step.
+  //  The sums were added with RETURNING atomics, i.e. they are performed at L2 before the barrier below lets thread 0 draw
+  //  the ticket; the last workgroup reads them back with atomics as well.)
+  __syncthreads();
+  if (threadIdx.x == 0) is_last = atomicAdd(reinterpret_cast<unsigned int*>(sums + 2 * C), 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!is_last) return;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float n = (float)fin.stat_rows;
+    const float mean = atomicAdd(sums + c, 0.f) / n;  // (coherent read of the accumulated sums)
+    float var = atomicAdd(sums + C + c, 0.f) / n - mean * mean;
+    var = fmaxf(var, 0.f);
+    fin.mean_rstd[c] = mean;
+    fin.mean_rstd[C + c] = rsqrtf(var + fin.eps);
+    if (fin.run_mean) {
+      fin.run_mean[c] = (1.f - fin.momentum) * fin.run_mean[c] + fin.momentum * mean;
+      fin.run_var[c] = (1.f - fin.momentum) * fin.run_var[c] + fin.momentum * var * (n / fmaxf(n - 1.f, 1.f));
+    }
+  }
 }
 
 // mean_rstd[0..C) = mean, [C..2C) = rstd; running stats: momentum update with the UNBIASED variance (torch semantics)
@@ -222,17 +254,23 @@ extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scr
     return FOCAL_OK;
   }
   FOCAL_CHECK_ARG(scratch, "bn_stats: null scratch");
+  const long n_stat = d->stat_rows > 0 ? d->stat_rows : d->rows;
   if (training != FOCAL_BN_FINALIZE) {
     FOCAL_CHECK_ARG(z, "bn_stats: null tensor");
-    if (!prezeroed) (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
+    if (!prezeroed) (void)hipMemsetAsync(scratch, 0, (2 * C + 1) * sizeof(float), st);
     int blocks = ceil_div((long)d->rows * C / 4, 1024 * 2);
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(1024), 32 * C * sizeof(float), st, z, scratch, (long)d->rows, C);
+    BnFinalize fin = {nullptr, nullptr, nullptr, n_stat, d->eps, d->momentum};
+    static const bool no_fuse = getenv("FOCAL_BN_NOFUSE") != nullptr;
+    if (training == FOCAL_BN_TRAIN && !no_fuse) {
+      FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
+      fin.mean_rstd = mean_rstd; fin.run_mean = running_mean; fin.run_var = running_var;
+    }
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(1024), 32 * C * sizeof(float), st, z, scratch, (long)d->rows, C, fin);
   }
-  if (training != FOCAL_BN_PARTIAL) {
+  if (training == FOCAL_BN_FINALIZE || (training == FOCAL_BN_TRAIN && getenv("FOCAL_BN_NOFUSE"))) {
     FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
-    const long n = d->stat_rows > 0 ? d->stat_rows : d->rows;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, mean_rstd, running_mean, running_var, n, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, mean_rstd, running_mean, running_var, n_stat, C,
                        d->eps, d->momentum);
   }
   FOCAL_LAUNCH_CHECK();
@@ -265,7 +303,7 @@ extern "C" int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const fl
   hipStream_t st = (hipStream_t)stream;
   const int C = d->C;
   if (phase != FOCAL_BN_FINALIZE) {
-    if (!prezeroed) (void)hipMemsetAsync(scratch, 0, 2 * C * sizeof(float), st);
+    if (!prezeroed) (void)hipMemsetAsync(scratch, 0, (2 * C + 1) * sizeof(float), st);
     int rb = ceil_div((long)d->rows * C / 4, 1024 * 2);
     if (rb > 256) rb = 256;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(1024), 32 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,

@@ -374,10 +374,10 @@ def bn_stats(d, z, running_mean, running_var, training, sync=False):
     """mean / rstd of z [rows, C].  sync=True under torch.distributed: the 2C per-channel sums are all-reduced between the
     partial and the finalize kernels, so every rank normalises with the statistics of the GLOBAL batch (equal shards)."""
     dev = running_mean.device
-    scratch = pool_zeros(2 * d.C, dev) if training else None
+    scratch = pool_zeros(2 * d.C + 1, dev) if training else None  # {sum, sum of squares} + the statistics kernel's arrival counter
     pre = _lib.BN_SCRATCH_ZEROED if scratch is not None else 0
     if scratch is None:
-        scratch = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
+        scratch = torch.empty(2 * d.C + 1, dtype=torch.float32, device=dev)
     mean_rstd = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
     lib = _lib.load()
     args = (_p(z), _p(scratch), _p(mean_rstd), _p(running_mean), _p(running_var))
@@ -385,7 +385,7 @@ def bn_stats(d, z, running_mean, running_var, training, sync=False):
     if world > 1:
         import torch.distributed as dist
         check(lib.focal_bn_stats(C.byref(d), *args, _lib.BN_PARTIAL | pre, _stream()))
-        dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
+        dist.all_reduce(scratch[:2 * d.C], op=dist.ReduceOp.SUM)
         d.stat_rows = d.rows * world
         check(lib.focal_bn_stats(C.byref(d), *args, _lib.BN_FINALIZE, _stream()))
     else:
@@ -401,10 +401,10 @@ def bn_act_fwd(d, z, mean_rstd, gamma, beta, resid, cast_dtype=None):
 
 
 def bn_act_bwd(d, z, g, mean_rstd, gamma, beta, dgamma, dbeta, out_dtype, sync=False):
-    scratch = pool_zeros(2 * d.C, z.device)
+    scratch = pool_zeros(2 * d.C + 1, z.device)
     pre = _lib.BN_SCRATCH_ZEROED if scratch is not None else 0
     if scratch is None:
-        scratch = torch.empty(2 * d.C, dtype=torch.float32, device=z.device)
+        scratch = torch.empty(2 * d.C + 1, dtype=torch.float32, device=z.device)
     dz = torch.empty(z.shape, dtype=out_dtype, device=z.device)
     lib = _lib.load()
     args = (_p(z), _p(g), _p(mean_rstd), _p(gamma), _p(beta), _p(scratch), _p(dz), _p(dgamma), _p(dbeta))
@@ -412,7 +412,7 @@ def bn_act_bwd(d, z, g, mean_rstd, gamma, beta, dgamma, dbeta, out_dtype, sync=F
     if world > 1:
         import torch.distributed as dist
         check(lib.focal_bn_act_bwd(C.byref(d), *args, _lib.BN_PARTIAL | pre, _stream()))
-        dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
+        dist.all_reduce(scratch[:2 * d.C], op=dist.ReduceOp.SUM)
         d.stat_rows = d.rows * world
         check(lib.focal_bn_act_bwd(C.byref(d), *args, _lib.BN_FINALIZE, _stream()))
     else:

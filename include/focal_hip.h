@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FOCAL_ABI_VERSION 1
+#define FOCAL_ABI_VERSION 2
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -169,7 +169,8 @@ int focal_conv_bwd_weight(const focal_conv_desc* d, const void* dz, const void* 
 
 /* BatchNorm2d(eps 1e-5, momentum 0.1) + GELU + Dropout2d + residual of ConvLayer2D (ConvModules.py:98-112,203-204).
  * focal_bn_stats: training -> batch mean / biased variance of z [rows, C] into mean_rstd [2C] and the momentum update of the
- * running buffers (unbiased variance); eval -> mean_rstd from the running buffers.  scratch: 2C floats.
+ * running buffers (unbiased variance); eval -> mean_rstd from the running buffers.  scratch: 2C + 1 floats (the sums and an arrival counter:
+ * in FOCAL_BN_TRAIN mode the last workgroup of the statistics kernel finalises mean / rstd / running buffers itself).
  * focal_bn_act_fwd: y = resid + drop2d(gelu(gamma * zhat + beta)) (fp32), optional `dtype` copy y_cast for the next GEMM.
  * focal_bn_act_bwd: dz (`dtype`) from g = dL/dy (fp32); dgamma / dbeta accumulated (+=).
  * Data-parallel exact ("sync") statistics: the per-channel sums are exposed so that the caller can all-reduce the 2C
