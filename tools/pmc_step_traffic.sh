@@ -8,7 +8,7 @@ root=$(pwd)
 STEPS=4; WARM=2
 mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcs_${tag}_$c -o $c -- python3 $root/bench.py --no-graph --no-cpu-baseline --no-roofline --steps $STEPS --warmup $WARM "$@" > /tmp/pmcs_${tag}_$c.log 2>&1
 done
 python3 - "$tag" "$root" $STEPS $WARM <<'PY' | tee $root/gpurun_out/${1}_step_traffic.txt
@@ -23,20 +23,29 @@ def fam(n):
     for k in ("ln_bwd", "ln_fwd", "window_attn_bwd", "window_attn_fwd", "patch_embed", "fft_realpack", "adamw", "mask_cast", "copyBuffer", "fillBuffer"):
         if k in n: return k
     return "other"
-tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
-for ci, c in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
+tot = collections.defaultdict(lambda: [0.0, 0.0, 0, 0.0, 0.0])  # fetch KB, write KB, launches, MFMA-busy cycles, duration ns
+for ci, c in enumerate(("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES")):
     fs = glob.glob(f"/tmp/pmcs_{tag}_{c}/**/*counter_collection.csv", recursive=True)
     for r in csv.DictReader(open(fs[0])):
         if r["Counter_Name"] != c: continue
         e = tot[fam(r["Kernel_Name"])]
-        e[ci] += float(r["Counter_Value"])
+        if ci < 2:
+            e[ci] += float(r["Counter_Value"])
+        else:
+            e[3] += float(r["Counter_Value"])
+            e[4] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         if ci == 0: e[2] += 1
 n = steps + warm
-print(f"HBM traffic per step (mean over {n} eager steps incl. warmup; KB counters -> GB):")
-gt = 0.0
-for k, (f, w, cnt) in sorted(tot.items(), key=lambda kv: -(2 * kv[1][0] + kv[1][1])):
-    gb = (2 * f + w) * 1024 / n / 1e9
+print(f"Per kernel family, whole run of {n} eager steps (+ bench.py's two arena-building steps): fabric traffic = (2*FETCH_SIZE + WRITE_SIZE) KB,")
+print("serialised kernel time and MFMA-busy cycles from the SQ_VALU_MFMA_BUSY_CYCLES pass; GB/s against the 8 TB/s HBM peak, MFMA busy =")
+print("busy cycles / (time x 2.4 GHz x 1024 SIMDs).  Traffic includes infinity-cache hits (the counters sit at the L2 <-> fabric boundary).")
+gt, tt = 0.0, 0.0
+for k, (f, w, cnt, busy, dur) in sorted(tot.items(), key=lambda kv: -(2 * kv[1][0] + kv[1][1])):
+    gb = (2 * f + w) * 1024 / 1e9
     gt += gb
-    print(f"  {k:22s} read {2*f*1024/n/1e9:7.3f} GB  write {w*1024/n/1e9:7.3f} GB  total {gb:7.3f} GB   launches/step {cnt/n:6.1f}")
-print(f"  TOTAL {gt:.3f} GB/step")
+    tt += dur
+    gbs = gb / (dur * 1e-9) if dur else 0.0
+    mf = busy / (dur * 1e-9 * 2.4e9 * 1024) if dur else 0.0
+    print(f"  {k:22s} read {2*f*1024/1e9:8.3f} GB  write {w*1024/1e9:8.3f} GB  time {dur/1e6:8.3f} ms  {gbs:7.0f} GB/s ({gbs/8000*100:4.1f} % of peak)  MFMA busy {mf*100:5.1f} %  launches {cnt:6d}")
+print(f"  TOTAL {gt:.3f} GB in {tt/1e6:.3f} ms of kernel time = {gt/(tt*1e-9):.0f} GB/s")
 PY
