@@ -93,6 +93,7 @@ PROTOTYPES = {
     "focal_layernorm_bwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, C.c_int, P, P, P, C.POINTER(DropDesc), P]),
     "focal_mask_cast": (C.c_int, [C.c_int, C.c_int, C.c_int, P, C.POINTER(DropDesc), P, P]),
     "focal_linear_fwd": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P, P]),
+    "focal_linear_resid_ln_fwd": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P, P, C.c_float, P, P, P]),
     "focal_linear_bwd_data": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_window_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P]),

@@ -13,7 +13,8 @@
 #include "common.hpp"
 
 enum GemmPro { PRO_NONE = 0, PRO_GELU = 1, PRO_MASK = 2, PRO_CONV = 3 };
-enum GemmEpi { EPI_STORE = 0, EPI_RESID = 1, EPI_MUL_AUX = 2, EPI_RELU = 3, EPI_RELU_BWD = 4, EPI_ATOMIC = 5, EPI_GELU_FWD = 6 };
+enum GemmEpi { EPI_STORE = 0, EPI_RESID = 1, EPI_MUL_AUX = 2, EPI_RELU = 3, EPI_RELU_BWD = 4, EPI_ATOMIC = 5, EPI_GELU_FWD = 6,
+               EPI_RESID_LN = 7 };  // EPI_RESID, then LayerNorm of the finished row (N == 64 == one wave's tile width): y_ln, statistics
 
 struct MaskParams {
   const uint32_t* seed;  // device word (null -> seed 0)
@@ -38,6 +39,8 @@ struct GemmParams {
   void* aux_out;                  // TC [M][N], ldc: EPI_GELU_FWD writes d gelu/dx * dropout mask here
   MaskParams proA, proB, epi;
   float* colsumA;                 // f32 [M] (+=): sum_r proA(A)[m][r]; only with transposed A (bias gradient)
+  // EPI_RESID_LN: the next LayerNorm, applied to the finished residual row (aux_out = its CT output [M][N], ldc)
+  const float* ln_gamma; const float* ln_beta; float* ln_stats; float ln_eps;  // stats f32 [M][2] = {mean, rstd}
 };
 
 struct MaskEval {
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   MaskEval meA, meB, meE;
   if (PROA != PRO_NONE) meA.init(p.proA);
   if (PROB != PRO_NONE) meB.init(p.proB);
-  if (EPI == EPI_RESID || EPI == EPI_GELU_FWD) meE.init(p.epi);
+  if (EPI == EPI_RESID || EPI == EPI_GELU_FWD || EPI == EPI_RESID_LN) meE.init(p.epi);
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -500,6 +503,29 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
 #pragma unroll
           for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
           storeN<CPL>(dst, v);
+        } else if (EPI == EPI_RESID_LN) {
+          // (launcher guarantees N == BN == 64, fp32 C: CPL = 4, the 16 lanes of a DPP row hold one whole output row)
+          float r[CPL];
+          loadN<CPL>(p.resid + (long)m * p.ldr + n, r);
+          const float rowm = meE.row_mult(m);
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
+          storeN<CPL>(dst, v);
+          float s1 = 0.f;
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) s1 += v[e];
+          const float mean = row16_sum(s1) * (1.0f / 64.0f);
+          float s2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) s2 += (v[e] - mean) * (v[e] - mean);
+          const float rstd = rsqrtf(row16_sum(s2) * (1.0f / 64.0f) + p.ln_eps);
+          float g[CPL], bt[CPL], y[CPL];
+          loadN<CPL>(p.ln_gamma + n, g);
+          loadN<CPL>(p.ln_beta + n, bt);
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) y[e] = (v[e] - mean) * rstd * g[e] + bt[e];
+          storeN<CPL>(reinterpret_cast<CT*>(p.aux_out) + (long)m * p.ldc + n, y);
+          if ((lane % LPR) == 0) *reinterpret_cast<float2*>(p.ln_stats + 2 * (long)m) = make_float2(mean, rstd);
         } else if (EPI == EPI_MUL_AUX) {
           float a[CPL];
           loadN<CPL>(reinterpret_cast<const CT*>(p.aux) + (long)m * p.ldaux + n, a);

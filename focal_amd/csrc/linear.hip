@@ -67,6 +67,35 @@ extern "C" int focal_linear_fwd(const focal_linear_desc* d, const void* x, const
   return focal_launch_gemm(s, p, (hipStream_t)stream);
 }
 
+extern "C" int focal_linear_resid_ln_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias,
+                                         const float* resid, float* y, const float* gamma, const float* beta, float eps,
+                                         void* y_ln, float* stats, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  FOCAL_CHECK_ARG(x && w && y && resid && gamma && beta && y_ln && stats, "linear_resid_ln_fwd: null tensor");
+  FOCAL_CHECK_ARG(d->epilogue == FOCAL_EPI_RESIDUAL && d->y_dtype == FOCAL_F32 && d->x_dtype == d->dtype && d->splits <= 1,
+                  "linear_resid_ln_fwd: needs the residual epilogue, fp32 y and dtype-typed x");
+  FOCAL_CHECK_ARG(d->N == 64, "linear_resid_ln_fwd: N = %d (the fused LayerNorm needs 64-column rows)", d->N);
+  GemmSpec s;
+  s.compute = d->dtype;
+  s.a_dtype = d->x_dtype; s.b_dtype = d->dtype; s.c_dtype = FOCAL_F32;
+  s.tra = false; s.trb = false; s.proA = PRO_NONE; s.proB = PRO_NONE; s.epi = EPI_RESID_LN;
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.A = x; p.lda = d->K;
+  p.B = w; p.ldb = d->K;
+  p.C = y; p.ldc = d->N;
+  p.batch = 1; p.splits = 1; p.alpha = 1.f;
+  p.bias = bias;
+  p.resid = resid; p.ldr = d->N;
+  p.aux_out = y_ln;
+  p.ln_gamma = gamma; p.ln_beta = beta; p.ln_stats = stats; p.ln_eps = eps;
+  p.proA = no_mask();
+  p.proB = no_mask();
+  p.epi = to_mask(d->out_drop, d->N);
+  return focal_launch_gemm(s, p, (hipStream_t)stream);
+}
+
 extern "C" int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy, const void* w, const void* x, void* dx,
                                      void* stream) {
   if (int rc = check_desc(d)) return rc;

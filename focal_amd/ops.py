@@ -239,6 +239,16 @@ def linear_fwd(d, x, w, bias, resid, y, act_grad=None):
     check(_lib.load().focal_linear_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(resid), _p(y), _p(act_grad), _stream()))
 
 
+def linear_resid_ln_fwd(d, x, w, bias, resid, y, gamma, beta, out_dtype, eps=1e-5):
+    """y = resid + drop(x w^T + bias) and, from the same kernel, (LayerNorm(y), stats) of the Swin LayerNorm that follows
+    (N == 64 only).  Returns (y_ln [M, N] out_dtype, stats [M, 2])."""
+    y_ln = torch.empty(d.M, d.N, dtype=out_dtype, device=y.device)
+    stats = torch.empty(d.M, 2, dtype=torch.float32, device=y.device)
+    check(_lib.load().focal_linear_resid_ln_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(resid), _p(y), _p(gamma), _p(beta), eps,
+                                                _p(y_ln), _p(stats), _stream()))
+    return y_ln, stats
+
+
 def linear_bwd_data(d, dy, w, x, dx):
     check(_lib.load().focal_linear_bwd_data(C.byref(d), _p(dy), _p(w), _p(x), _p(dx), _stream()))
 

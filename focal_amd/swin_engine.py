@@ -10,6 +10,8 @@ Per block (M = B*H*W tokens, C channels, CT = matrix-core operand dtype):
   saved     x, st1, a1, qkv, o, x_mid, st2, a2, h, h'   (x fp32; the rest in CT; dropout masks are regenerated)
   backward  the residual-gradient stream g (fp32 [M, C]) is updated in place through the block.
 """
+import os
+
 import torch
 
 from . import ops
@@ -48,6 +50,10 @@ class SwinModEncoder:
         p_attn = bb.attn_drop_rate if training else 0.0
         saved = {"B": B, "view": view, "training": training, "blocks": [], "merges": []}
         uid = 0
+        # At 64 channels a GEMM wave owns whole rows, so the residual GEMMs also emit the LayerNorm that follows them (norm2
+        # after proj, the next block's norm1 after fc2): no separate pass over the residual stream for those LayerNorms.
+        fuse_ln = os.environ.get("FOCAL_NO_LN_FUSE") != "1"
+        pre_ln = None  # (a1, st1) of the next block when the previous fc2 already produced them
         for si, st in enumerate(geo["stages"]):
             H, W, Cc = st["H"], st["W"], st["C"]
             L = H * W
@@ -56,7 +62,11 @@ class SwinModEncoder:
                 pb = f"{self.pre}.{si}.blocks.{bi}"
                 wh, ww, sh, sw = bb.block_windows[(self.loc, self.mod, si, bi)]
                 p_path = bb.drop_path_rates[self.mod][uid] if training else 0.0
-                a1, st1 = ops.layernorm_fwd(x, ar.master(f"{pb}.norm1.weight"), ar.master(f"{pb}.norm1.bias"), ct)
+                if pre_ln is not None:
+                    a1, st1 = pre_ln
+                    pre_ln = None
+                else:
+                    a1, st1 = ops.layernorm_fwd(x, ar.master(f"{pb}.norm1.weight"), ar.master(f"{pb}.norm1.bias"), ct)
                 d_qkv = ops.linear_desc(cc, M, 3 * Cc, Cc, cc, cc)
                 qkv = torch.empty(M, 3 * Cc, dtype=ct, device=x.device)
                 ops.linear_fwd(d_qkv, a1, ar.operand(f"{pb}.attn.qkv.weight"), ar.master(f"{pb}.attn.qkv.bias"), None, qkv)
@@ -67,8 +77,12 @@ class SwinModEncoder:
                 d_proj = ops.linear_desc(cc, M, Cc, Cc, cc, f32, ACT_NONE, EPI_RESIDUAL,
                                          out_drop=self._drop(rng, view, uid, 0, p_drop, p_path, L))
                 x_mid = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
-                ops.linear_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"), x, x_mid)
-                a2, st2 = ops.layernorm_fwd(x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
+                if fuse_ln and Cc == 64:
+                    a2, st2 = ops.linear_resid_ln_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"),
+                                                      x, x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
+                else:
+                    ops.linear_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"), x, x_mid)
+                    a2, st2 = ops.layernorm_fwd(x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
                 d_fc1 = ops.linear_desc(cc, M, 4 * Cc, Cc, cc, cc, ACT_NONE, EPI_GELU,
                                         out_drop=self._drop(rng, view, uid, 1, p_drop, 0.0, L))
                 h = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)
@@ -77,7 +91,12 @@ class SwinModEncoder:
                 d_fc2 = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, f32, ACT_GELU, EPI_RESIDUAL,
                                         out_drop=self._drop(rng, view, uid, 2, p_drop, p_path, L))
                 x_out = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
-                ops.linear_fwd(d_fc2, h, ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_mid, x_out)
+                if fuse_ln and Cc == 64 and bi + 1 < st["depth"]:
+                    nb = f"{self.pre}.{si}.blocks.{bi + 1}"
+                    pre_ln = ops.linear_resid_ln_fwd(d_fc2, h, ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"),
+                                                     x_mid, x_out, ar.master(f"{nb}.norm1.weight"), ar.master(f"{nb}.norm1.bias"), ct)
+                else:
+                    ops.linear_fwd(d_fc2, h, ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_mid, x_out)
                 saved["blocks"].append(dict(pb=pb, x=x, st1=st1, a1=a1, qkv=qkv, o=o, x_mid=x_mid, st2=st2, a2=a2, h=h, hg=hg,
                                             d_qkv=d_qkv, d_att=d_att, d_proj=d_proj, d_fc1=d_fc1, d_fc2=d_fc2,
                                             M=M, C=Cc))

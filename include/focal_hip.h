@@ -122,6 +122,13 @@ typedef struct {
 } focal_linear_desc;
 int focal_linear_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias, const float* resid,
                      void* y, void* act_grad, void* stream);
+/* y = resid + out_drop(DropPath(x w^T + bias)) (epilogue FOCAL_EPI_RESIDUAL, fp32 y) AND, from the same kernel, the LayerNorm
+ * that follows it in the Swin block (SwinModules.py:253,258: norm2 after the attention branch, the next block's norm1 after
+ * the MLP branch): y_ln = LayerNorm(y; gamma, beta, eps) in `dtype`, stats fp32 [M][2] = {mean, rstd}.  N must be 64 (one
+ * wave owns whole rows); other widths: focal_linear_fwd followed by focal_layernorm_fwd.  Saves one pass over the residual
+ * stream and one launch per LayerNorm. */
+int focal_linear_resid_ln_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias, const float* resid,
+                              float* y, const float* gamma, const float* beta, float eps, void* y_ln, float* stats, void* stream);
 int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy, const void* w, const void* x, void* dx,
                           void* stream);
 int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const void* x, float* dw, float* dbias,

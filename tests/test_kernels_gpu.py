@@ -170,6 +170,27 @@ def test_linear_pipelined_kernel_epilogues(ops):
     assert rel_err(du.float(), (gm.float() @ w2.float()) * hg.float()) < 8e-3
 
 
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,K", [(1152, 64), (4610, 256)])
+def test_linear_residual_with_fused_layernorm(ops, ct, M, K):
+    """focal_linear_resid_ln_fwd = focal_linear_fwd (residual epilogue) + focal_layernorm_fwd of its output, one kernel."""
+    from focal_amd._lib import ACT_NONE, EPI_RESIDUAL
+    N = 64
+    x, w, b = rnd(M, K, seed=41, dtype=ct), rnd(N, K, scale=K ** -0.5, seed=42, dtype=ct), rnd(N, seed=43)
+    r, gamma, beta = rnd(M, N, seed=44), rnd(N, seed=45) * 0.2 + 1.0, rnd(N, seed=46) * 0.1
+    c, f32 = ops.code(ct), ops.code(torch.float32)
+    d = ops.linear_desc(c, M, N, K, c, f32, ACT_NONE, EPI_RESIDUAL)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    y_ln, stats = ops.linear_resid_ln_fwd(d, x, w, b, r, y, gamma, beta, ct)
+    y_ref, _ = ops.linear(x, w, b, compute=ct, y_dtype=torch.float32, resid=r, epilogue=EPI_RESIDUAL)
+    assert torch.equal(y, y_ref)  # same kernel, same arithmetic
+    ln_ref, st_ref = ops.layernorm_fwd(y_ref, gamma, beta, ct)
+    assert rel_err(y_ln.float(), ln_ref.float()) < (1e-6 if ct == torch.float32 else 4e-3)
+    assert rel_err(stats.view(-1), st_ref.view(-1)) < 1e-5
+    ref = F.layer_norm(r + x.float() @ w.float().t() + b, (N,), gamma, beta, 1e-5)
+    assert rel_err(y_ln.float(), ref) < (1e-5 if ct == torch.float32 else 8e-3)
+
+
 # ---------------------------------------------------------------------------------------------- layer norm
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,C", [(4608, 64), (1153, 128), (300, 256), (77, 512)])
