@@ -89,6 +89,7 @@ PROTOTYPES = {
     "focal_fft_realpack_fwd": (C.c_int, [C.POINTER(FFTDesc), P, P, P, P]),
     "focal_augment_fft_fwd": (C.c_int, [C.POINTER(FFTDesc), C.POINTER(AugDesc), P, P, P, P]),
     "focal_pad_patch_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P]),
+    "focal_pad_patch_embed_ln2_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P, P, C.c_float, C.c_int, P, P, P]),
     "focal_layernorm_fwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, P]),
     "focal_layernorm_bwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, C.c_int, P, P, P, C.POINTER(DropDesc), P]),
     "focal_mask_cast": (C.c_int, [C.c_int, C.c_int, C.c_int, P, C.POINTER(DropDesc), P, P]),

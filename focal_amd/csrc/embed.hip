@@ -9,11 +9,21 @@
 
 #define EMB_TOK 64
 
+// Optional second LayerNorm over the 64 embedded channels (block 0's norm1, which reads exactly these tokens next): y_ln
+// (fp32 or bf16) and stats {mean, rstd} come out of the same kernel -- one launch and one read of the token tensor less.
+__device__ __forceinline__ void emb_store4(float* p, const float* f) { *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]); }
+__device__ __forceinline__ void emb_store4(bf16_t* p, const float* f) {
+  bf16x4 t;
+  t[0] = (bf16_t)f[0]; t[1] = (bf16_t)f[1]; t[2] = (bf16_t)f[2]; t[3] = (bf16_t)f[3];
+  *reinterpret_cast<bf16x4*>(p) = t;
+}
+struct EmbedLn2 { const float* gamma; const float* beta; void* y; float* stats; float eps; int bf16; };
+
 template <int C0>
 __global__ __launch_bounds__(256) void patch_embed_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ tokens,
-                                                             focal_embed_desc d, int K, int total_tokens) {
+                                                             focal_embed_desc d, int K, int total_tokens, EmbedLn2 l2) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int KP = K + 1;
   float* wt = smem;                 // [K][C0]   transposed filters
@@ -75,6 +85,32 @@ __global__ __launch_bounds__(256) void patch_embed_ln_kernel(const float* __rest
         o.z = (acc[n + 2] - mean) * rstd * gamma[q * CPT + n + 2] + beta[q * CPT + n + 2];
         o.w = (acc[n + 3] - mean) * rstd * gamma[q * CPT + n + 3] + beta[q * CPT + n + 3];
         *reinterpret_cast<float4*>(dst + n) = o;
+        acc[n] = o.x; acc[n + 1] = o.y; acc[n + 2] = o.z; acc[n + 3] = o.w;
+      }
+    }
+    if (l2.y != nullptr) {  // (uniform)
+      float t = 0.f;
+#pragma unroll
+      for (int n = 0; n < CPT; ++n) t += acc[n];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      const float m2 = t / C0;
+      float u = 0.f;
+#pragma unroll
+      for (int n = 0; n < CPT; ++n) u += (acc[n] - m2) * (acc[n] - m2);
+      u += __shfl_xor(u, 1, 64);
+      u += __shfl_xor(u, 2, 64);
+      const float r2 = rsqrtf(u / C0 + l2.eps);
+      if (tok < total_tokens) {
+#pragma unroll
+        for (int n = 0; n < CPT; n += 4) {
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = (acc[n + e] - m2) * r2 * l2.gamma[q * CPT + n + e] + l2.beta[q * CPT + n + e];
+          if (l2.bf16) emb_store4(reinterpret_cast<bf16_t*>(l2.y) + (long)tok * C0 + q * CPT + n, y);
+          else emb_store4(reinterpret_cast<float*>(l2.y) + (long)tok * C0 + q * CPT + n, y);
+        }
+        if (q == 0) *reinterpret_cast<float2*>(l2.stats + 2 * (long)tok) = make_float2(m2, r2);
       }
     }
   }
@@ -90,7 +126,7 @@ template <int K>
 __global__ __launch_bounds__(256) void patch_embed_ln_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float* __restrict__ tokens,
-                                                                  focal_embed_desc d, int total_tokens, PatchGeom pg) {
+                                                                  focal_embed_desc d, int total_tokens, PatchGeom pg, EmbedLn2 l2) {
   constexpr int KP = K + 4, KS = K / 4;
   __shared__ __attribute__((aligned(16))) float patch[EMB_TOK * KP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
@@ -148,11 +184,42 @@ __global__ __launch_bounds__(256) void patch_embed_ln_mfma_kernel(const float* _
         *reinterpret_cast<float4*>(tokens + (long)tok * 64 + 16 * nt + 4 * lg) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
+    if (l2.y != nullptr) {  // (uniform) second LayerNorm on the values just stored
+      float t = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const float ga[4] = {gv[nt].x, gv[nt].y, gv[nt].z, gv[nt].w}, ba[4] = {be[nt].x, be[nt].y, be[nt].z, be[nt].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[nt][r] = (acc[nt][r] - mean) * rstd * ga[r] + ba[r]; t += acc[nt][r]; }
+      }
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      const float m2 = t * (1.0f / 64.0f);
+      float u = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u += (acc[nt][r] - m2) * (acc[nt][r] - m2);
+      u += __shfl_xor(u, 16, 64);
+      u += __shfl_xor(u, 32, 64);
+      const float r2 = rsqrtf(u * (1.0f / 64.0f) + l2.eps);
+      if (tok < total_tokens) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          float y[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[r] = (acc[nt][r] - m2) * r2 * l2.gamma[16 * nt + 4 * lg + r] + l2.beta[16 * nt + 4 * lg + r];
+          if (l2.bf16) emb_store4(reinterpret_cast<bf16_t*>(l2.y) + (long)tok * 64 + 16 * nt + 4 * lg, y);
+          else emb_store4(reinterpret_cast<float*>(l2.y) + (long)tok * 64 + 16 * nt + 4 * lg, y);
+        }
+        if (lg == 0) *reinterpret_cast<float2*>(l2.stats + 2 * (long)tok) = make_float2(m2, r2);
+      }
+    }
   }
 }
 
-extern "C" int focal_pad_patch_embed_ln_fwd(const focal_embed_desc* d, const float* x, const float* w, const float* b,
-                                            const float* gamma, const float* beta, float* tokens, void* stream) {
+static int embed_launch(const focal_embed_desc* d, const float* x, const float* w, const float* b, const float* gamma, const float* beta,
+                        float* tokens, EmbedLn2 l2, void* stream) {
   FOCAL_CHECK_ARG(d && x && w && b && gamma && beta && tokens, "pad_patch_embed_ln: null argument");
   FOCAL_CHECK_ARG(d->C0 == 64 || d->C0 == 128, "pad_patch_embed_ln: embed dim %d not in {64, 128}", d->C0);
   FOCAL_CHECK_ARG(d->Hp >= d->I && d->Wp * d->pw >= d->S && d->pw > 0, "pad_patch_embed_ln: padded grid smaller than the input");
@@ -168,14 +235,29 @@ extern "C" int focal_pad_patch_embed_ln_fwd(const focal_embed_desc* d, const flo
     static const int mb_cap = getenv("FOCAL_EMBED_BLOCKS") ? atoi(getenv("FOCAL_EMBED_BLOCKS")) : 512;
     if (mb > mb_cap) mb = mb_cap;
     const PatchGeom pg = make_patch_geom(d->Wp, d->Hp, d->I, d->S, d->pw, d->cin);
-    hipLaunchKernelGGL((patch_embed_ln_mfma_kernel<80>), dim3(mb), dim3(256), 0, st, x, w, b, gamma, beta, tokens, *d, total, pg);
+    hipLaunchKernelGGL((patch_embed_ln_mfma_kernel<80>), dim3(mb), dim3(256), 0, st, x, w, b, gamma, beta, tokens, *d, total, pg, l2);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
   int blocks = ceil_div(total, EMB_TOK);
   if (blocks > 2048) blocks = 2048;
-  if (d->C0 == 64) hipLaunchKernelGGL((patch_embed_ln_kernel<64>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total);
-  else hipLaunchKernelGGL((patch_embed_ln_kernel<128>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total);
+  if (d->C0 == 64) hipLaunchKernelGGL((patch_embed_ln_kernel<64>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total, l2);
+  else hipLaunchKernelGGL((patch_embed_ln_kernel<128>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total, l2);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
+}
+
+extern "C" int focal_pad_patch_embed_ln_fwd(const focal_embed_desc* d, const float* x, const float* w, const float* b,
+                                            const float* gamma, const float* beta, float* tokens, void* stream) {
+  const EmbedLn2 none = {nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+  return embed_launch(d, x, w, b, gamma, beta, tokens, none, stream);
+}
+
+extern "C" int focal_pad_patch_embed_ln2_fwd(const focal_embed_desc* d, const float* x, const float* w, const float* b,
+                                             const float* gamma, const float* beta, float* tokens, const float* gamma2,
+                                             const float* beta2, float eps2, int ln_dtype, void* y_ln, float* stats, void* stream) {
+  FOCAL_CHECK_ARG(gamma2 && beta2 && y_ln && stats, "pad_patch_embed_ln2: null argument");
+  FOCAL_CHECK_ARG(ln_dtype == FOCAL_F32 || ln_dtype == FOCAL_BF16, "pad_patch_embed_ln2: bad dtype %d", ln_dtype);
+  const EmbedLn2 l2 = {gamma2, beta2, y_ln, stats, eps2, ln_dtype == FOCAL_BF16};
+  return embed_launch(d, x, w, b, gamma, beta, tokens, l2, stream);
 }

@@ -174,14 +174,22 @@ def fft_realpack(x, scale=1.0, flip=False, perm=None, phase=0.0, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ row 8
-def pad_patch_embed_ln(x, w, b, gamma, beta, Hp, Wp, pw, eps=1e-5):
+def pad_patch_embed_ln(x, w, b, gamma, beta, Hp, Wp, pw, eps=1e-5, next_ln=None):
+    """next_ln = (gamma2, beta2, out_dtype): also return (LayerNorm(tokens), stats) of the LayerNorm that follows (C0 == 64)."""
     _need_cuda(x, w, b, gamma, beta)
     B, cin, I, S = x.shape
     C0 = w.shape[0]
     out = torch.empty(B * Hp * Wp, C0, dtype=torch.float32, device=x.device)
     d = EmbedDesc(B, cin, I, S, Hp, Wp, pw, C0, eps)
-    check(_lib.load().focal_pad_patch_embed_ln_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(out), _stream()))
-    return out
+    if next_ln is None:
+        check(_lib.load().focal_pad_patch_embed_ln_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(out), _stream()))
+        return out
+    g2, b2, dt = next_ln
+    y_ln = torch.empty(B * Hp * Wp, C0, dtype=dt, device=x.device)
+    stats = torch.empty(B * Hp * Wp, 2, dtype=torch.float32, device=x.device)
+    check(_lib.load().focal_pad_patch_embed_ln2_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(gamma), _p(beta), _p(out), _p(g2), _p(b2),
+                                                    1e-5, code(dt), _p(y_ln), _p(stats), _stream()))
+    return out, y_ln, stats
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm

@@ -42,8 +42,17 @@ class SwinModEncoder:
             x_freq = x_freq.float().contiguous()
         pe = f"patch_embed.{self.loc}.{self.mod}"
         P = bb.param  # cold parameters (frozen patch embedding) are read where they live
-        x = ops.pad_patch_embed_ln(x_freq, P(f"{pe}.proj.weight"), P(f"{pe}.proj.bias"), P(f"{pe}.norm.weight"),
-                                   P(f"{pe}.norm.bias"), geo["grid"][0], geo["grid"][1], geo["patch"][1])
+        fuse_ln = os.environ.get("FOCAL_NO_LN_FUSE") != "1"
+        pre_ln = None  # (a1, st1) of the next block when the kernel before it already produced them
+        first = f"{self.pre}.0.blocks.0"
+        if fuse_ln and geo["stages"][0]["C"] == 64:  # the embedding kernel also emits block 0's norm1
+            x, a1_0, st1_0 = ops.pad_patch_embed_ln(x_freq, P(f"{pe}.proj.weight"), P(f"{pe}.proj.bias"), P(f"{pe}.norm.weight"),
+                                                    P(f"{pe}.norm.bias"), geo["grid"][0], geo["grid"][1], geo["patch"][1],
+                                                    next_ln=(ar.master(f"{first}.norm1.weight"), ar.master(f"{first}.norm1.bias"), ct))
+            pre_ln = (a1_0, st1_0)
+        else:
+            x = ops.pad_patch_embed_ln(x_freq, P(f"{pe}.proj.weight"), P(f"{pe}.proj.bias"), P(f"{pe}.norm.weight"),
+                                       P(f"{pe}.norm.bias"), geo["grid"][0], geo["grid"][1], geo["patch"][1])
         if bb.config["APE"]:
             raise ops._lib.FocalHipError("absolute position embedding (APE: True) is outside the HIP hot path")
         p_drop = bb.drop_rate if training else 0.0
@@ -52,8 +61,6 @@ class SwinModEncoder:
         uid = 0
         # At 64 channels a GEMM wave owns whole rows, so the residual GEMMs also emit the LayerNorm that follows them (norm2
         # after proj, the next block's norm1 after fc2): no separate pass over the residual stream for those LayerNorms.
-        fuse_ln = os.environ.get("FOCAL_NO_LN_FUSE") != "1"
-        pre_ln = None  # (a1, st1) of the next block when the previous fc2 already produced them
         for si, st in enumerate(geo["stages"]):
             H, W, Cc = st["H"], st["W"], st["C"]
             L = H * W

@@ -77,6 +77,11 @@ int focal_augment_fft_fwd(const focal_fft_desc* d, const focal_aug_desc* a, cons
 typedef struct { int B, cin, I, S, Hp, Wp, pw, C0; float eps; } focal_embed_desc;
 int focal_pad_patch_embed_ln_fwd(const focal_embed_desc* d, const float* x, const float* w, const float* b,
                                  const float* gamma, const float* beta, float* tokens, void* stream);
+/* The same, plus the LayerNorm that reads these tokens next (block 0's norm1, SwinModules.py:253): y_ln = LayerNorm(tokens;
+ * gamma2, beta2, eps2) in `ln_dtype` and stats fp32 [tokens][2] = {mean, rstd} from the same kernel. */
+int focal_pad_patch_embed_ln2_fwd(const focal_embed_desc* d, const float* x, const float* w, const float* b,
+                                  const float* gamma, const float* beta, float* tokens, const float* gamma2, const float* beta2,
+                                  float eps2, int ln_dtype, void* y_ln, float* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm(eps 1e-5) of models/SwinModules.py:253,258,376.  x fp32 [rows, C]; y `dtype`; stats fp32

@@ -293,6 +293,23 @@ def test_pad_patch_embed_ln(ops, S, pw, Hp, Wp, cin):
     assert (out - ref).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S,pw,Hp,Wp,cin", [(1600, 40, 12, 48, 2), (20, 1, 12, 24, 2)])
+def test_pad_patch_embed_with_fused_next_layernorm(ops, ct, S, pw, Hp, Wp, cin):
+    """focal_pad_patch_embed_ln2_fwd = the embedding kernel + focal_layernorm_fwd of its tokens (block 0's norm1)."""
+    B, I, C0 = 3, 10, 64
+    x = rnd(B, cin, I, S, seed=51)
+    w, b = rnd(C0, cin, 1, pw, scale=(cin * pw) ** -0.5, seed=52), rnd(C0, seed=53) * 0.1
+    g, be = rnd(C0, seed=54) * 0.1 + 1.0, rnd(C0, seed=55) * 0.1
+    g2, be2 = rnd(C0, seed=56) * 0.2 + 1.0, rnd(C0, seed=57) * 0.1
+    tok_ref = ops.pad_patch_embed_ln(x, w, b, g, be, Hp, Wp, pw)
+    tok, y_ln, stats = ops.pad_patch_embed_ln(x, w, b, g, be, Hp, Wp, pw, next_ln=(g2, be2, ct))
+    assert torch.equal(tok, tok_ref)
+    ln_ref, st_ref = ops.layernorm_fwd(tok_ref, g2, be2, ct)
+    assert rel_err(y_ln.float(), ln_ref.float()) < (1e-6 if ct == torch.float32 else 4e-3)
+    assert rel_err(stats.view(-1), st_ref.view(-1)) < 1e-5
+
+
 @pytest.mark.parametrize("n", [1600, 20, 64, 360])
 def test_fft_realpack(ops, n):
     x = rnd(3, 2, 10, n, seed=50)
