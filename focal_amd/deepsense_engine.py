@@ -48,7 +48,7 @@ class DeepSenseModEncoder:
         y, ya = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pin}.batch_norm.weight"), ar.master(f"{pin}.batch_norm.bias"), None, ct)
         sv["in"] = dict(d=d_in, z=z, mr=mr, d_bn=d_bn, p=pin)
         if training:
-            buf(f"{pin}.batch_norm.num_batches_tracked").add_(1)
+            bb.bump_bn_counters(self.pre)  # every BatchNorm of this encoder: num_batches_tracked += 1, one launch
         k = geo["k"]
         d_cv = ops.conv_desc(cc, rows, S, C, C, k)
         for li in range(geo["n_inter"]):
@@ -61,8 +61,6 @@ class DeepSenseModEncoder:
             y_next, ya_next = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pl}.batch_norm.weight"), ar.master(f"{pl}.batch_norm.bias"), y, ct)
             sv["layers"].append(dict(p=pl, z=z, mr=mr, d_bn=d_bn, xa=ya))
             y, ya = y_next, ya_next
-            if training:
-                buf(f"{pl}.batch_norm.num_batches_tracked").add_(1)
         sv["d_cv"] = d_cv
         pout = f"{self.pre}.conv_layer_out"
         n_out = geo["C_out"]

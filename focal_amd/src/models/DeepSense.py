@@ -83,6 +83,22 @@ class DeepSense(HipBackbone):
         self._class_head = ClassifierHead(self)
         self._buffers_by_name = None
 
+    def bump_bn_counters(self, prefix):
+        """num_batches_tracked += 1 for every BatchNorm under `prefix` (torch does it per layer in forward, nn/modules/batchnorm.py).
+        The counters of one encoder are 0-dim views of ONE int64 tensor, so this is a single launch instead of one per layer;
+        state_dict() / load_state_dict() see ordinary per-layer buffers."""
+        cache = self.__dict__.setdefault("_bn_counter_blocks", {})
+        mods = [m for n, m in self.named_modules() if n.startswith(prefix + ".") and isinstance(m, nn.BatchNorm2d)]
+        blk = cache.get(prefix)
+        stale = blk is None or any(m.num_batches_tracked.untyped_storage().data_ptr() != blk.untyped_storage().data_ptr() for m in mods)
+        if stale:  # first use, or .to(device) replaced the buffers
+            blk = torch.stack([m.num_batches_tracked.detach().reshape(()) for m in mods]).contiguous()
+            for i, m in enumerate(mods):
+                m._buffers["num_batches_tracked"] = blk[i]
+            cache[prefix] = blk
+            self._buffers_by_name = None
+        blk.add_(1)
+
     def buffer(self, name):
         if self._buffers_by_name is None or self._buffers_by_name.get("__dev") != next(self.parameters()).device:
             self._buffers_by_name = dict(self.named_buffers())
