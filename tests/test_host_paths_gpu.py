@@ -97,3 +97,31 @@ def test_dft_writes_views_into_one_batch_tensor():
     assert torch.allclose(a, ops.fft_realpack(x)) and torch.allclose(b, ops.fft_realpack(x, scale=-1.1))
     with pytest.raises(ValueError):
         ops.fft_realpack(x, out=both[:3])
+
+
+def test_augmenter_writes_back_to_back_views_into_one_batch_tensor():
+    """Two consecutive `forward("random", same windows)` calls (the pretraining loop's two views) land in the two halves of one
+    tensor, so FOCAL.forward can run them as one batch without a copy; any other call pattern simply gets fresh tensors."""
+    import yaml
+    from conftest import make_args
+    from data_augmenter import Augmenter as A
+    from models.FOCALModules import _as_one_batch
+    with open(os.path.join(ROOT, "focal_amd", "src", "data", "MOD.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    args = make_args(cfg, "SW_Transformer", torch.device("cuda"), "bf16")
+    aug = A.Augmenter(args)
+    loc = cfg["location_names"][0]
+    x = {loc: {m: torch.randn(4, cfg["loc_mod_in_time_channels"][loc][m], cfg["num_segments"], cfg["loc_mod_spectrum_len"][loc][m],
+                              device="cuda") for m in cfg["modality_names"]}}
+    v1 = aug.forward("random", x)
+    v2 = aug.forward("random", x)
+    for m in cfg["modality_names"]:
+        a, b = v1[loc][m], v2[loc][m]
+        assert a._base is not None and a._base is b._base and b.data_ptr() == a.data_ptr() + a.numel() * 4
+        assert _as_one_batch(a, b) is a._base
+    other = {loc: {m: t.clone() for m, t in x[loc].items()}}
+    v3 = aug.forward("random", other)   # different windows: starts a new pair
+    v4 = aug.forward("random", x)       # not the partner of v3
+    for m in cfg["modality_names"]:
+        assert v3[loc][m]._base is not v4[loc][m]._base
+        assert _as_one_batch(v3[loc][m], v4[loc][m]).shape[0] == 8  # concatenated
