@@ -69,6 +69,14 @@ struct MaskEval {
   __device__ __forceinline__ float elem_mult(int row, int col) const {
     return on_e ? drop_mult(e, (uint32_t)row * (uint32_t)ncols + (uint32_t)col) : 1.0f;
   }
+  // Two neighbouring elements (col even) from ONE hash: its two 16-bit halves against a 16-bit threshold.  Only for sites whose
+  // mask is consumed where it is drawn and never regenerated elsewhere (the fc1 GELU epilogue: the saved derivative carries it).
+  __device__ __forceinline__ gelu_f2 elem_mult_pair(int row, int col) const {
+    if (!on_e) return gelu_f2{1.0f, 1.0f};
+    const uint32_t idx = ((uint32_t)row * (uint32_t)ncols + (uint32_t)col) >> 1;
+    const uint32_t h = focal_mix32(idx ^ e.key), t16 = e.thresh >> 8;
+    return gelu_f2{(h & 0xffffu) < t16 ? 0.0f : e.scale, (h >> 16) < t16 ? 0.0f : e.scale};
+  }
 };
 
 template <typename CT> struct GemmCfg;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
             const gelu_f2 x = {v[e], v[e + 1]};
             gelu_f2 cdf, pdf;
             gelu_parts2(x, cdf, pdf);
-            const gelu_f2 mult = {meE.elem_mult(m, n + e), meE.elem_mult(m, n + e + 1)};
+            const gelu_f2 mult = meE.elem_mult_pair(m, n + e);
             const gelu_f2 gg = (x * pdf + cdf) * mult, hh = x * cdf * mult;
             g[e] = gg.x; g[e + 1] = gg.y;
             v[e] = hh.x; v[e + 1] = hh.y;

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
           const gelu_f2 x = {v[e], v[e + 1]};
           gelu_f2 cdf, pdf;
           gelu_parts2(x, cdf, pdf);
-          const gelu_f2 mult = {meE.elem_mult(m, n + e), meE.elem_mult(m, n + e + 1)};
+          const gelu_f2 mult = meE.elem_mult_pair(m, n + e);
           const gelu_f2 gg = (x * pdf + cdf) * mult, hh = x * cdf * mult;
           gq[e] = gg.x; gq[e + 1] = gg.y;
           v[e] = hh.x; v[e + 1] = hh.y;

@@ -365,6 +365,35 @@ def test_dropout_statistics_and_replay(ops):
     assert not torch.equal(y2 > 0, y > 0)
 
 
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 64), (4096, 512, 128)])
+def test_gelu_epilogue_dropout_rate_scale_and_consistency(ops, ct, M, N, K):
+    """Mlp.drop inside the fc1 epilogue (both GEMM kernels: 64 x 64 at K = 64, pipelined at K = 128): keep rate 1 - p,
+    survivors scaled by 1 / (1 - p), the saved derivative carries exactly the same mask, a new mask after the seed advances.
+    (This site draws one hash per PAIR of elements: 16-bit thresholds.)"""
+    from focal_amd._lib import EPI_GELU
+    p = 0.2
+    state = ops.new_rng_state(11, DEV)
+    a = (torch.rand(M, K, device=DEV) + 0.5).to(ct)          # positive inputs, positive weights: gelu(u) > 0, gelu'(u) > 0
+    w = (torch.rand(N, K, device=DEV) * K ** -0.5 + 0.05).to(ct)
+    dd = ops.drop_desc(state, 21, p, 0, 0.0, 1)
+    hg = torch.empty(M, N, dtype=ct, device=DEV)
+    h, _ = ops.linear(a, w, None, compute=ct, epilogue=EPI_GELU, act_grad=hg, out_drop=dd)
+    hg0 = torch.empty(M, N, dtype=ct, device=DEV)
+    h0, _ = ops.linear(a, w, None, compute=ct, epilogue=EPI_GELU, act_grad=hg0)
+    kept = h != 0
+    assert abs(kept.float().mean().item() - (1 - p)) < 4e-3
+    assert torch.equal(kept, hg != 0)
+    assert rel_err(h[kept].float(), h0[kept].float() / (1 - p)) < (1e-6 if ct == torch.float32 else 8e-3)
+    assert rel_err(hg[kept].float(), hg0[kept].float() / (1 - p)) < (1e-6 if ct == torch.float32 else 8e-3)
+    # neighbours are independent: P(both of a pair kept) = (1 - p)^2
+    both = (kept[:, 0::2] & kept[:, 1::2]).float().mean().item()
+    assert abs(both - (1 - p) ** 2) < 5e-3
+    ops.rng_advance(state)
+    h2, _ = ops.linear(a, w, None, compute=ct, epilogue=EPI_GELU, act_grad=hg, out_drop=dd)
+    assert not torch.equal(h2 != 0, kept)
+
+
 # ---------------------------------------------------------------------------------------------- DeepSense pieces
 @pytest.mark.parametrize("S_in,k,stride,pad", [(1600, 80, 80, 0), (20, 3, 1, 1)])
 def test_conv_in(ops, S_in, k, stride, pad):
