@@ -419,6 +419,7 @@ def main():
                                       f"(global batch {a.batch * world}), train mode, DFT + fwd x2 + loss + bwd + AdamW",
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graphed, **({"DIAGNOSTIC_no_dropout": True} if a.no_dropout else {}),
                           **({"DIAGNOSTIC_from_host": True} if a.from_host else {}),
+**({"DIAGNOSTIC_ABLATED_INVALID": os.environ["FOCAL_ABLATE"]} if os.environ.get("FOCAL_ABLATE") else {}),
                           "views": "identity / negation+scaling (x * -1.1) folded into the DFT", "last_loss": round(last_loss, 4)},
                "model_flops_frac_of_bf16_mfma_peak": round(wps / world * FLOP_PER_WINDOW[a.model] / (MFMA_BF16_PEAK_TF * 1e12), 5),
                "roofline": rl, "cpu_baseline": cb}

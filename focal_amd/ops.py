@@ -6,6 +6,7 @@ immediately; none of them has a CPU implementation.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -32,6 +33,16 @@ def _stream():
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+# FOCAL_ABLATE=<name>[,<name>...]: TIMING DIAGNOSTIC ONLY -- the named op families return without launching (their outputs stay
+# uninitialised, results are garbage).  bench.py refuses to print a normal line with it set; tools/scratch/ablate.sh uses it to
+# measure what each family contributes to the graph-replayed step with the real two-stream concurrency (a profiler serialises).
+_ABLATE = frozenset(x for x in os.environ.get("FOCAL_ABLATE", "").split(",") if x)
+
+
+def _ablated(name):
+    return name in _ABLATE
 
 
 # ------------------------------------------------------------------------------------------------ per-step zero pool
@@ -211,7 +222,8 @@ def layernorm_fwd(x, gamma, beta, out_dtype, gather=None, desc=None):
     d = desc or ln_desc(code(out_dtype), rows, Cc, gather=gather)
     y = torch.empty(rows, Cc, dtype=out_dtype, device=x.device)
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
-    check(_lib.load().focal_layernorm_fwd(C.byref(d), _p(x), _p(gamma), _p(beta), _p(y), _p(stats), _stream()))
+    if not _ablated("layernorm_fwd"):
+        check(_lib.load().focal_layernorm_fwd(C.byref(d), _p(x), _p(gamma), _p(beta), _p(y), _p(stats), _stream()))
     return y, stats
 
 
@@ -224,6 +236,8 @@ def layernorm_bwd(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=Non
     if dx_masked is not None:
         assert dx_masked.dtype == dy.dtype and dx_masked.numel() == dx.numel()
         mask = mask or NO_DROP
+    if _ablated("layernorm_bwd"):
+        return
     check(_lib.load().focal_layernorm_bwd(C.byref(d), _p(dy), _p(x), _p(stats), _p(gamma), _p(dx), int(accumulate),
                                           _p(dgamma), _p(dbeta), _p(dx_masked), C.byref(mask) if mask is not None else None,
                                           _stream()))
@@ -244,6 +258,8 @@ def linear_desc(dtype_code, M, N, K, x_dtype, y_dtype, act_in=ACT_NONE, epilogue
 
 
 def linear_fwd(d, x, w, bias, resid, y, act_grad=None):
+    if _ablated("linear_fwd"):
+        return
     check(_lib.load().focal_linear_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(resid), _p(y), _p(act_grad), _stream()))
 
 
@@ -258,10 +274,14 @@ def linear_resid_ln_fwd(d, x, w, bias, resid, y, gamma, beta, out_dtype, eps=1e-
 
 
 def linear_bwd_data(d, dy, w, x, dx):
+    if _ablated("linear_bwd_data"):
+        return
     check(_lib.load().focal_linear_bwd_data(C.byref(d), _p(dy), _p(w), _p(x), _p(dx), _stream()))
 
 
 def linear_bwd_weight(d, dy, x, dw, dbias):
+    if _ablated("linear_bwd_weight"):
+        return
     check(_lib.load().focal_linear_bwd_weight(C.byref(d), _p(dy), _p(x), _p(dw), _p(dbias), _stream()))
 
 
@@ -284,10 +304,14 @@ def attn_desc(dtype_code, B, H, W, Cc, heads, wh, ww, sh, sw, p_attn=0.0, rng=No
 
 
 def window_attn_fwd(d, qkv, bias_table, out):
+    if _ablated("window_attn_fwd"):
+        return
     check(_lib.load().focal_window_attn_fwd(C.byref(d), _p(qkv), _p(bias_table), _p(out), _stream()))
 
 
 def window_attn_bwd(d, qkv, bias_table, dout, dqkv, dbias_table):
+    if _ablated("window_attn_bwd"):
+        return
     check(_lib.load().focal_window_attn_bwd(C.byref(d), _p(qkv), _p(bias_table), _p(dout), _p(dqkv), _p(dbias_table),
                                             _stream()))
 
