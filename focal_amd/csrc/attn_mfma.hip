@@ -239,6 +239,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
                                                                    int iters, const uint32_t* rng, uint32_t stream, float p_attn) {
   constexpr int P = HD + 4, TILE = 16 * P;
   __shared__ __attribute__((aligned(16))) bf16_t tiles[NW][4][TILE];
+  __shared__ __attribute__((aligned(16))) bf16_t trt[NW][16 * 20];  // dS tile, written [j][i], read back transposed (see below)
   __shared__ float dbacc[256];  // (2wh-1)(2ww-1) x heads <= 256 entries
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: item, window and head arithmetic then runs on the SALU
   bf16_t* Qt = tiles[wave][0];
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
   const DropCtx dc = make_drop(rng, stream, p_attn);
   const bool drop_on = p_attn > 0.f;
   const int C = g.C, grp = lane >> 4, col = lane & 15;
-  const TileIdx tA = make_tile_idx<true>(g, lane), tB = make_tile_idx<false>(g, lane);
+  const TileIdx tB = make_tile_idx<false>(g, lane);
   const int slot = lane & 15, sy = slot / g.ww, sx = slot - sy * g.ww;
   // Relative-position-bias gradient: a lane owns the same (i, j) -- hence the same table row -- in every window, so it
   // accumulates in registers and touches LDS only when the head it works on changes (never, when 4 * gridDim is a
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       dbreg[r] = 0.f;
     }
   };
-  float biasA[4] = {0.f, 0.f, 0.f, 0.f}, biasB[4] = {0.f, 0.f, 0.f, 0.f};
+  float biasB[4] = {0.f, 0.f, 0.f, 0.f};
   int h_cur = -1;
   auto item_of = [&](int it, bool& live, int& win, int& h) {
     const int item = (it * gridDim.x + blockIdx.x) * NW + wave;
@@ -305,27 +306,25 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
       tile_fetch<HD>(rg, dout + h_n * HD, C, tok_n, g.N, lane);
     }
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, d1 = s1, d2 = s1;
+    // Only the (rows i, col j) orientation of the score tile is evaluated here (the forward kernel needs the other one): S, the
+    // softmax, dPd and dS once.  dQ needs dS^T as its B operand; instead of a second pair of MFMAs, a second softmax and a second
+    // set of dropout hashes (~130 of this loop's ~500 instructions), the bf16 dS tile goes through 640 bytes of wave-private
+    // LDS: written [j][i] (8 bytes per lane), read back with the hardware transpose read.
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, d1 = s1;
 #pragma unroll
     for (int kk = 0; kk < HD / 16; ++kk) {
       const bf16x4 fq = frag_rows(Qt, P, kk, lane), fk = frag_rows(Kt, P, kk, lane);
       const bf16x4 fv = frag_rows(Vt, P, kk, lane), fg = frag_rows(Gt, P, kk, lane);
       s1 = mma16x16(fq, fk, s1);  // S   : rows i, col j
-      s2 = mma16x16(fk, fq, s2);  // S^T : rows j, col i
       d1 = mma16x16(fg, fv, d1);  // dPd : rows i, col j
-      d2 = mma16x16(fv, fg, d2);  // dPd^T
     }
-    float p1[4] = {s1[0], s1[1], s1[2], s1[3]}, p2[4] = {s2[0], s2[1], s2[2], s2[3]};
+    float p1[4] = {s1[0], s1[1], s1[2], s1[3]};
     if (h != h_cur) {
       h_cur = h;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        biasA[r] = tA.ok[r] ? bias_table[tA.rel[r] + h] : 0.f;
-        biasB[r] = tB.ok[r] ? bias_table[tB.rel[r] + h] : 0.f;
-      }
+      for (int r = 0; r < 4; ++r) biasB[r] = tB.ok[r] ? bias_table[tB.rel[r] + h] : 0.f;
     }
     tile_softmax<false>(g, tB, p1, biasB, reg_own, edge);
-    tile_softmax<true>(g, tA, p2, biasA, reg_own, edge);
     const uint32_t wbase = ((uint32_t)win * g.heads + h) * g.N;
     // ---- layout 1: rows i = 4*grp + r, col j
     float ds1[4], pd1[4];
@@ -341,25 +340,11 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       pd1[r] = ok ? p1[r] * m : 0.f;
       if (live) dbreg[r] += ds1[r];  // ds1 is 0 outside the window
     }
-    // ---- layout 2: rows j = 4*grp + r, col i
-    float ds2[4], dpv[4];
-    float dot2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = 4 * grp + r, i = col;
-      const bool ok = i < g.N && j < g.N;
-      const float m = (drop_on && ok) ? drop_mult(dc, (wbase + i) * g.N + j) : 1.f;
-      dpv[r] = d2[r] * m;
-      dot2 += ok ? p2[r] * dpv[r] : 0.f;
-    }
-    dot2 += __shfl_xor(dot2, 16, 64);
-    dot2 += __shfl_xor(dot2, 32, 64);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = col < g.N && (4 * grp + r) < g.N;
-      ds2[r] = ok ? p2[r] * (dpv[r] - dot2) : 0.f;
-    }
-    const bf16x4 bds1 = pack4(ds1), bpd1 = pack4(pd1), bds2 = pack4(ds2);
+    const bf16x4 bds1 = pack4(ds1), bpd1 = pack4(pd1);
+    bf16_t* tw = trt[wave];
+    *reinterpret_cast<bf16x4*>(tw + col * 20 + 4 * grp) = bds1;  // tile_T[j = col][i = 4 grp .. 4 grp + 3]
+    wave_lds_fence();
+    const bf16x4 bds2 = frag_cols(tw, 20, 0, lane);              // lane (col i) <- rows j = 4 grp .. 4 grp + 3 : dS^T
     const bool st_ok = live && col < g.N;
     bf16_t* dst = dqkv + (long)tok_own * 3 * C + h * HD + 4 * grp;
 #pragma unroll
