@@ -265,6 +265,10 @@ static int attn_geometry(const focal_attn_desc* d, AttnGeom* g) {
   g->wh = d->wh; g->ww = d->ww; g->sh = d->sh; g->sw = d->sw; g->N = d->wh * d->ww;
   g->nWx = d->W / d->ww; g->nW = (d->H / d->wh) * g->nWx;
   g->shifted = (d->sh > 0 && d->sw > 0) ? 1 : 0;  // `min(shift_size) > 0`, SwinModules.py:262,305
+  auto magic = [](int dv) { return (uint32_t)(((1ull << 32) + dv - 1) / dv); };
+  g->m_heads = magic(g->heads); g->m_nW = magic(g->nW); g->m_nWx = magic(g->nWx);
+  FOCAL_CHECK_ARG((double)d->B * g->nW * g->heads * (double)(g->heads > g->nW ? g->heads : g->nW) < 4.0e9,
+                  "window_attn: too many (window, head) items for the 32-bit index arithmetic");
   g->scale = 1.0f / sqrtf((float)g->hd);
   FOCAL_CHECK_ARG(g->hd == 16 || g->hd == 32 || g->hd == 64, "window_attn: head_dim %d not in {16, 32, 64}", g->hd);
   FOCAL_CHECK_ARG(g->heads * g->N <= 256, "window_attn: heads * window tokens > 256");

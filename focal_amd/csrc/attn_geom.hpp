@@ -7,7 +7,18 @@
 struct AttnGeom {
   int B, H, W, C, heads, hd, wh, ww, sh, sw, N, nWx, nW, shifted;
   float scale;
+  // ceil(2^32 / d) for d = heads, nW, nWx: n / d == mulhi(n, magic) exactly while n * d < 2^32 (items, windows: checked on the
+  // host).  The MFMA kernels decompose a wave-uniform item index per (window, head): as runtime divisions that was ~150 scalar
+  // instructions per item, a third of the forward kernel's instruction stream.
+  uint32_t m_heads, m_nW, m_nWx;
 };
+__host__ __device__ __forceinline__ uint32_t att_div(uint32_t n, uint32_t magic, uint32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return d == 1 ? n : __umulhi(n, magic);
+#else
+  return n / d;
+#endif
+}
 
 __device__ __forceinline__ int att_token(const AttnGeom& g, int win, int i, int* region) {
   const int b = win / g.nW, wl = win % g.nW;

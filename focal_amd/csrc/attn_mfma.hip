@@ -141,8 +141,8 @@ __device__ __forceinline__ void tile_softmax(const AttnGeom& g, const TileIdx& t
 
 // token index of this lane's window slot; slot coordinates (sy, sx) are loop-invariant, only the window decomposes
 __device__ __forceinline__ int slot_token(const AttnGeom& g, int win, int sy, int sx, int* region) {
-  const int b = win / g.nW, wl = win - b * g.nW;
-  const int wy = wl / g.nWx, wx = wl - wy * g.nWx;
+  const int b = (int)att_div((uint32_t)win, g.m_nW, (uint32_t)g.nW), wl = win - b * g.nW;
+  const int wy = (int)att_div((uint32_t)wl, g.m_nWx, (uint32_t)g.nWx), wx = wl - wy * g.nWx;
   const int Y = wy * g.wh + sy, X = wx * g.ww + sx;
   const int rh = Y < g.H - g.wh ? 0 : (Y < g.H - g.sh ? 1 : 2);
   const int rw = X < g.W - g.ww ? 0 : (X < g.W - g.sw ? 1 : 2);
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
   auto item_of = [&](int it, bool& live, int& win, int& h) {
     const int item = (it * gridDim.x + blockIdx.x) * 4 + wave;
     live = item < total_items;
-    win = live ? item / g.heads : 0;
-    h = live ? item % g.heads : 0;
+    win = live ? (int)att_div((uint32_t)item, g.m_heads, (uint32_t)g.heads) : 0;
+    h = live ? item - win * g.heads : 0;
   };
   TileRegs<HD> rq, rk, rv;
   bool live_n; int win_n, h_n, reg_n = 0, tok_n = 0;
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
   auto item_of = [&](int it, bool& live, int& win, int& h) {
     const int item = (it * gridDim.x + blockIdx.x) * NW + wave;
     live = item < total_items;
-    win = live ? item / g.heads : 0;
-    h = live ? item % g.heads : 0;
+    win = live ? (int)att_div((uint32_t)item, g.m_heads, (uint32_t)g.heads) : 0;
+    h = live ? item - win * g.heads : 0;
   };
   TileRegs<HD> rq, rk, rv, rg;
   bool live_n; int win_n, h_n, reg_n = 0, tok_n = 0;
