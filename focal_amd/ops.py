@@ -391,15 +391,21 @@ def conv_pack_bwd(d, w, dtype):
 
 def conv_fwd(d, x, w_fwd, bias):
     z = torch.empty(d.rows, d.C_out, dtype=torch.float32, device=x.device)
+    if _ablated("conv_fwd"):
+        return z
     check(_lib.load().focal_conv_fwd(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(z), _stream()))
     return z
 
 
 def conv_bwd_data(d, dz, w_bwd, g_in, g_out):
+    if _ablated("conv_bwd_data"):
+        return
     check(_lib.load().focal_conv_bwd_data(C.byref(d), _p(dz), _p(w_bwd), _p(g_in), _p(g_out), _stream()))
 
 
 def conv_bwd_weight(d, dz, x, dw_packed, dbias):
+    if _ablated("conv_bwd_weight"):
+        return
     check(_lib.load().focal_conv_bwd_weight(C.byref(d), _p(dz), _p(x), _p(dw_packed), _p(dbias), _stream()))
 
 
@@ -421,6 +427,8 @@ def bn_stats(d, z, running_mean, running_var, training, sync=False):
     if scratch is None:
         scratch = torch.empty(2 * d.C + 1, dtype=torch.float32, device=dev)
     mean_rstd = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
+    if _ablated("bn_stats"):
+        return mean_rstd
     lib = _lib.load()
     args = (_p(z), _p(scratch), _p(mean_rstd), _p(running_mean), _p(running_var))
     world = _sync_world() if (sync and training) else 1
@@ -438,6 +446,8 @@ def bn_stats(d, z, running_mean, running_var, training, sync=False):
 def bn_act_fwd(d, z, mean_rstd, gamma, beta, resid, cast_dtype=None):
     y = torch.empty_like(z)
     ya = torch.empty(z.shape, dtype=cast_dtype, device=z.device) if cast_dtype not in (None, torch.float32) else None
+    if _ablated("bn_act_fwd"):
+        return y, (ya if ya is not None else y)
     check(_lib.load().focal_bn_act_fwd(C.byref(d), _p(z), _p(mean_rstd), _p(gamma), _p(beta), _p(resid), _p(y), _p(ya), _stream()))
     return y, (ya if ya is not None else y)
 
@@ -448,6 +458,8 @@ def bn_act_bwd(d, z, g, mean_rstd, gamma, beta, dgamma, dbeta, out_dtype, sync=F
     if scratch is None:
         scratch = torch.empty(2 * d.C + 1, dtype=torch.float32, device=z.device)
     dz = torch.empty(z.shape, dtype=out_dtype, device=z.device)
+    if _ablated("bn_act_bwd"):
+        return dz
     lib = _lib.load()
     args = (_p(z), _p(g), _p(mean_rstd), _p(gamma), _p(beta), _p(scratch), _p(dz), _p(dgamma), _p(dbeta))
     world = _sync_world() if sync else 1
@@ -477,10 +489,14 @@ def _parr(tensors):
 
 def gru_seq_fwd(d, gi, whh, bhh, hs, save, out):
     """Whole-sequence GRU layer, one launch for len(gi) directions (lists of per-direction tensors)."""
+    if _ablated("gru_seq_fwd"):
+        return
     check(_lib.load().focal_gru_seq_fwd(C.byref(d), len(gi), _parr(gi), _parr(whh), _parr(bhh), _parr(hs), _parr(save), _p(out), _stream()))
 
 
 def gru_seq_bwd(d, dout, ld_b, ld_t, scale, whh_t, hs, save, dgi, dgh):
+    if _ablated("gru_seq_bwd"):
+        return
     check(_lib.load().focal_gru_seq_bwd(C.byref(d), len(hs), _p(dout), ld_b, ld_t, scale, _parr(whh_t), _parr(hs), _parr(save), _parr(dgi),
                                         _parr(dgh), _stream()))
 
