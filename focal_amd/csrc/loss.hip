@@ -39,13 +39,21 @@ static inline int loss_row_blocks(long rows) {
 
 // ------------------------------------------------------------------------------------------------ InfoNCE
 // row r of problem (p, t): r < b -> e1[(r)*seq + t], else e2[(r-b)*seq + t]; transposition of loss.py:64-73.
-__global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int dim, int width,
+// Every (problem, step) block holds n2p = round_up(2b, 4) rows: the fp32 GEMM moves 16-byte chunks along its reduction index, so
+// the logical 2b (any b >= 2: the last batch of an epoch may hold an odd number of subsequences) is padded with zero rows /
+// columns that every row kernel skips.
+__global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, int dim, int width,
                                                        float* __restrict__ Zn, float* __restrict__ nrm) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long rows = (long)nprob * seq * 2 * b;
+  const long rows = (long)nprob * seq * n2p;
   if (row >= rows) return;
-  const int r = row % (2 * b), t = (row / (2 * b)) % seq, p = row / (2L * b * seq);
+  const int r = row % n2p, t = (row / n2p) % seq, p = row / ((long)n2p * seq);
+  if (r >= 2 * b) {  // padding row
+    for (int c = lane; c < width; c += 64) Zn[row * width + c] = 0.f;
+    if (lane == 0) nrm[row] = 1.f;
+    return;
+  }
   const PairProb pr = tab.p[p0 + p];
   const float* src = (r < b) ? pr.e1 + ((long)r * seq + t) * dim + pr.off1 : pr.e2 + ((long)(r - b) * seq + t) * dim + pr.off2;
   float ss = 0.f;
@@ -57,17 +65,18 @@ __global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, in
 }
 
 // one wave per row i of S[p,t]: lse over j != i, loss_i = lse_i - S[i][pos(i)]
-__global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, int nprob, int seq, int b, const float* __restrict__ S,
+__global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, const float* __restrict__ S,
                                                        float* __restrict__ lse, float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
   const int n2 = 2 * b;
-  const long rows = (long)nprob * seq * n2;
+  const long rows = (long)nprob * seq * n2p;
   float acc0 = 0.f, acc1 = 0.f;  // contributions to terms[0] (shared family) / terms[1] (private family)
   for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
-    const int i = row % n2;
-    const int p = row / ((long)n2 * seq);
+    const int i = row % n2p;
+    if (i >= n2) continue;  // padding row (wave-uniform)
+    const int p = row / ((long)n2p * seq);
     const int kind = tab.p[p0 + p].kind;
-    const float* s = S + row * n2;
+    const float* s = S + row * n2p;
     float mx = -3.0e38f;
     for (int j = lane; j < n2; j += 64) if (j != i) mx = fmaxf(mx, s[j]);
     mx = wave_max(mx);
@@ -86,19 +95,19 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, in
 }
 
 // in place S -> W (times the family weight): W_ij = [j != i](e^{S_ij - lse_i} + e^{S_ij - lse_j}) - 2 [j == pos(i)]
-__global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0, int nprob, int seq, int b, float* __restrict__ S,
+__global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, float* __restrict__ S,
                                                           const float* __restrict__ lse, float w_shared, float w_private) {
   const int n2 = 2 * b;
-  const long total = (long)nprob * seq * n2 * n2;
+  const long total = (long)nprob * seq * n2p * n2p;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int j = e % n2;
-    const long row = e / n2;
-    const int i = row % n2;
+    const int j = e % n2p;
+    const long row = e / n2p;
+    const int i = row % n2p;
     const long base = row - i;  // first row of this (p, t)
-    const int p = row / ((long)n2 * seq);
+    const int p = row / ((long)n2p * seq);
     const float wk = tab.p[p0 + p].kind == 0 ? w_shared : w_private;
     float w = 0.f;
-    if (j != i) {
+    if (j != i && i < n2 && j < n2) {
       const float s = S[e];
       w = __expf(s - lse[row]) + __expf(s - lse[base + j]);
       if (j == (i + b) % n2) w -= 2.0f;
@@ -108,14 +117,15 @@ __global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0,
 }
 
 // dz = (dzn - zn (zn . dzn)) / ||z||, scattered (+=) to the right sample / half of the source embeddings
-__global__ __launch_bounds__(256) void nce_unpack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int dim, int width,
+__global__ __launch_bounds__(256) void nce_unpack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, int dim, int width,
                                                          const float* __restrict__ Zn, const float* __restrict__ nrm,
                                                          const float* __restrict__ dZn) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long rows = (long)nprob * seq * 2 * b;
+  const long rows = (long)nprob * seq * n2p;
   if (row >= rows) return;
-  const int r = row % (2 * b), t = (row / (2 * b)) % seq, p = row / (2L * b * seq);
+  const int r = row % n2p, t = (row / n2p) % seq, p = row / ((long)n2p * seq);
+  if (r >= 2 * b) return;
   const PairProb pr = tab.p[p0 + p];
   float* dst = (r < b) ? pr.d1 + ((long)r * seq + t) * dim + pr.off1 : pr.d2 + ((long)(r - b) * seq + t) * dim + pr.off2;
   float dot = 0.f;
@@ -126,12 +136,18 @@ __global__ __launch_bounds__(256) void nce_unpack_kernel(PairTable tab, int p0, 
 }
 
 // ------------------------------------------------------------------------------------------------ ranking
-__global__ __launch_bounds__(256) void rank_pack_kernel(RankTable tab, int nq, int B, int dim, float* __restrict__ X,
+// (Bp = round_up(B, 4) rows per problem, zero padding: same reason as n2p above)
+__global__ __launch_bounds__(256) void rank_pack_kernel(RankTable tab, int nq, int B, int Bp, int dim, float* __restrict__ X,
                                                         float* __restrict__ sq) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)nq * B) return;
-  const int q = row / B, s = row % B;
+  if (row >= (long)nq * Bp) return;
+  const int q = row / Bp, s = row % Bp;
+  if (s >= B) {
+    for (int c = lane; c < dim; c += 64) X[row * dim + c] = 0.f;
+    if (lane == 0) sq[row] = 0.f;
+    return;
+  }
   const float* src = tab.x[q] + (long)s * dim;
   float ss = 0.f;
   for (int c = lane; c < dim; c += 64) { const float v = src[c]; X[row * dim + c] = v; ss += v * v; }
@@ -140,22 +156,22 @@ __global__ __launch_bounds__(256) void rank_pack_kernel(RankTable tab, int nq, i
 }
 
 // in place G -> D = sqrt(max(0, |x_p|^2 + |x_q|^2 - 2 G_pq)), D_pp = 0   (torch.cdist mm path, loss.py:117)
-__global__ __launch_bounds__(256) void rank_dist_kernel(int nq, int B, float* __restrict__ G, const float* __restrict__ sq) {
-  const long total = (long)nq * B * B;
+__global__ __launch_bounds__(256) void rank_dist_kernel(int nq, int B, int Bp, float* __restrict__ G, const float* __restrict__ sq) {
+  const long total = (long)nq * Bp * Bp;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int c = e % B;
-    const long row = e / B;
-    const int r = row % B;
+    const int c = e % Bp;
+    const long row = e / Bp;
+    const int r = row % Bp;
     const long qb = row - r;
     const float d2 = sq[row] + sq[qb + c] - 2.0f * G[e];
-    G[e] = (r == c) ? 0.f : sqrtf(fmaxf(d2, 0.f));
+    G[e] = (r == c || r >= B || c >= B) ? 0.f : sqrtf(fmaxf(d2, 0.f));
   }
 }
 
 // Dbar[q][I][J] = mean of the seq x seq block (self pairs excluded), loss.py:118-124
-__global__ __launch_bounds__(256) void rank_blockmean_kernel(int nq, int b, int seq, const float* __restrict__ D, float* __restrict__ Dbar) {
+__global__ __launch_bounds__(256) void rank_blockmean_kernel(int nq, int b, int seq, int Bp, const float* __restrict__ D, float* __restrict__ Dbar) {
   const long total = (long)nq * b * b;
-  const int B = b * seq;
+  const int B = Bp;  // row pitch of D
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int J = e % b, I = (e / b) % b, q = e / ((long)b * b);
     const float* base = D + ((long)q * B + (long)I * seq) * B + (long)J * seq;
@@ -196,22 +212,22 @@ __global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float ma
 }
 
 // in place D -> E = w_rank * (A_pq + A_qp) / D_pq, A_pq = dDbar[I(p)][J(q)] / count(I, J); rowsum[p] = sum_q E_pq
-__global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq, float w_rank, float* __restrict__ D,
+__global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq, int Bp, float w_rank, float* __restrict__ D,
                                                          const float* __restrict__ dDbar, float* __restrict__ rowsum) {
   const int lane = threadIdx.x & 63;
   const int B = b * seq;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)nq * B) return;
-  const int p = row % B, q = row / B, I = p / seq;
+  if (row >= (long)nq * Bp) return;
+  const int p = row % Bp, q = row / Bp, I = p / seq;
   const float* dd = dDbar + (long)q * b * b;
-  float* drow = D + row * B;
+  float* drow = D + row * Bp;
   float rs = 0.f;
-  for (int c = lane; c < B; c += 64) {
+  for (int c = lane; c < Bp; c += 64) {
     const int J = c / seq;
     const float cnt = (float)(seq * seq - (I == J ? seq : 0));
     const float dist = drow[c];
     float e = 0.f;
-    if (c != p && dist > 1e-12f) e = w_rank * (dd[(long)I * b + J] + dd[(long)J * b + I]) / (cnt * dist);
+    if (c != p && p < B && c < B && dist > 1e-12f) e = w_rank * (dd[(long)I * b + J] + dd[(long)J * b + I]) / (cnt * dist);
     drow[c] = e;
     rs += e;
   }
@@ -219,12 +235,13 @@ __global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq,
   if (lane == 0) rowsum[row] = rs;
 }
 
-__global__ __launch_bounds__(256) void rank_grad_kernel(RankTable tab, int nq, int B, int dim, const float* __restrict__ X,
+__global__ __launch_bounds__(256) void rank_grad_kernel(RankTable tab, int nq, int B, int Bp, int dim, const float* __restrict__ X,
                                                         const float* __restrict__ rowsum, const float* __restrict__ EX) {
-  const long total = (long)nq * B * dim;
+  const long total = (long)nq * Bp * dim;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long row = e / dim;
-    const int c = e % dim, q = row / B, s = row % B;
+    const int c = e % dim, q = row / Bp, s = row % Bp;
+    if (s >= B) continue;
     atomicAdd(tab.d[q] + (long)s * dim + c, rowsum[row] * X[e] - EX[e]);
   }
 }
@@ -266,7 +283,7 @@ __global__ void loss_total_kernel(float* terms, float ws, float wp, float wo, fl
 
 // ------------------------------------------------------------------------------------------------ host side
 struct LossPlan {
-  int b, n2, P_sh, P_pr, w_sh, w_pr, Q, O;
+  int b, n2, n2p, Bp, P_sh, P_pr, w_sh, w_pr, Q, O;
   size_t off_zn, off_nrm, off_S, off_lse, off_dzn, off_X, off_sq, off_D, off_dbar, off_ddbar, off_rs, off_ex, total;
 };
 
@@ -278,7 +295,8 @@ static int loss_plan(const focal_loss_desc* d, LossPlan* pl) {
   const int M = d->n_mod;
   pl->b = d->B / d->seq;
   pl->n2 = 2 * pl->b;
-  FOCAL_CHECK_ARG(pl->n2 % 4 == 0 && d->B % 4 == 0, "loss_head: 2*batch/seq must be a multiple of 4");
+  pl->n2p = (pl->n2 + 3) & ~3;   // pitches of the similarity / distance matrices (16-byte chunks along the GEMM reduction index)
+  pl->Bp = (d->B + 3) & ~3;
   pl->P_sh = 2 * (M * (M - 1) / 2);
   pl->P_pr = M;
   pl->w_sh = d->no_private ? d->dim : d->dim / 2;
@@ -286,7 +304,7 @@ static int loss_plan(const focal_loss_desc* d, LossPlan* pl) {
   pl->Q = 2 * M;
   pl->O = 2 * (M + M * (M - 1) / 2);
   FOCAL_CHECK_ARG(pl->P_sh + pl->P_pr <= LOSS_MAXP && pl->O <= LOSS_MAXO && pl->Q <= LOSS_MAXQ, "loss_head: too many modality pairs");
-  const size_t rows_sh = (size_t)pl->P_sh * d->seq * pl->n2, rows_pr = (size_t)pl->P_pr * d->seq * pl->n2;
+  const size_t rows_sh = (size_t)pl->P_sh * d->seq * pl->n2p, rows_pr = (size_t)pl->P_pr * d->seq * pl->n2p;
   const size_t zn = rows_sh * pl->w_sh + rows_pr * pl->w_pr;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
@@ -294,12 +312,12 @@ static int loss_plan(const focal_loss_desc* d, LossPlan* pl) {
   pl->off_dzn = take(zn);
   pl->off_nrm = take(rows_sh + rows_pr);
   pl->off_lse = take(rows_sh + rows_pr);
-  pl->off_S = take((rows_sh + rows_pr) * pl->n2);
-  pl->off_X = take((size_t)pl->Q * d->B * d->dim);
-  pl->off_ex = take((size_t)pl->Q * d->B * d->dim);
-  pl->off_sq = take((size_t)pl->Q * d->B);
-  pl->off_rs = take((size_t)pl->Q * d->B);
-  pl->off_D = take((size_t)pl->Q * d->B * d->B);
+  pl->off_S = take((rows_sh + rows_pr) * pl->n2p);
+  pl->off_X = take((size_t)pl->Q * pl->Bp * d->dim);
+  pl->off_ex = take((size_t)pl->Q * pl->Bp * d->dim);
+  pl->off_sq = take((size_t)pl->Q * pl->Bp);
+  pl->off_rs = take((size_t)pl->Q * pl->Bp);
+  pl->off_D = take((size_t)pl->Q * pl->Bp * pl->Bp);
   pl->off_dbar = take((size_t)pl->Q * pl->b * pl->b);
   pl->off_ddbar = take((size_t)pl->Q * pl->b * pl->b);
   pl->total = o * sizeof(float);
@@ -337,7 +355,7 @@ extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* fea
     return FOCAL_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int M = d->n_mod, B = d->B, dim = d->dim, seq = d->seq, b = pl.b, n2 = pl.n2, half = d->dim / 2;
+  const int M = d->n_mod, B = d->B, dim = d->dim, seq = d->seq, b = pl.b, n2 = pl.n2, n2p = pl.n2p, Bp = pl.Bp, half = d->dim / 2;
   float* ws = reinterpret_cast<float*>(workspace);
   // the binding hands over ONE allocation [2M gradients | terms]: a single memset node instead of 2M + 1
   const size_t gbytes = (size_t)B * dim * sizeof(float);
@@ -386,23 +404,23 @@ extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* fea
   for (int grp = 0; grp < 2; ++grp) {
     const int p0 = grp == 0 ? 0 : pl.P_sh, nprob = grp == 0 ? pl.P_sh : pl.P_pr, width = grp == 0 ? pl.w_sh : pl.w_pr;
     if (nprob == 0) continue;
-    const long rows = (long)nprob * seq * n2;
+    const long rows = (long)nprob * seq * n2p;
     float* Zn = ws + pl.off_zn + zoff;
     float* dZn = ws + pl.off_dzn + zoff;
     float* nrm = ws + pl.off_nrm + roff;
     float* lse = ws + pl.off_lse + roff;
-    float* S = ws + pl.off_S + roff * n2;
+    float* S = ws + pl.off_S + roff * n2p;
     const int rb = ceil_div(rows, 4);
-    hipLaunchKernelGGL(nce_pack_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, dim, width, Zn, nrm);
-    if (int rc = f32_gemm(false, n2, n2, width, Zn, width, (long)n2 * width, Zn, width, (long)n2 * width, S, n2, (long)n2 * n2,
+    hipLaunchKernelGGL(nce_pack_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, n2p, dim, width, Zn, nrm);
+    if (int rc = f32_gemm(false, n2p, n2p, width, Zn, width, (long)n2p * width, Zn, width, (long)n2p * width, S, n2p, (long)n2p * n2p,
                           nprob * seq, 1.0f / d->temperature, st)) return rc;
-    hipLaunchKernelGGL(nce_rows_kernel, dim3(loss_row_blocks(rows)), dim3(256), 0, st, nce, p0, nprob, seq, b, S, lse, terms);
-    int eb = ceil_div(rows * n2, 256);
+    hipLaunchKernelGGL(nce_rows_kernel, dim3(loss_row_blocks(rows)), dim3(256), 0, st, nce, p0, nprob, seq, b, n2p, S, lse, terms);
+    int eb = ceil_div(rows * n2p, 256);
     if (eb > 8192) eb = 8192;
-    hipLaunchKernelGGL(nce_weights_kernel, dim3(eb), dim3(256), 0, st, nce, p0, nprob, seq, b, S, lse, d->w_shared, d->w_private);
-    if (int rc = f32_gemm(true, n2, width, n2, S, n2, (long)n2 * n2, Zn, width, (long)n2 * width, dZn, width, (long)n2 * width,
+    hipLaunchKernelGGL(nce_weights_kernel, dim3(eb), dim3(256), 0, st, nce, p0, nprob, seq, b, n2p, S, lse, d->w_shared, d->w_private);
+    if (int rc = f32_gemm(true, n2p, width, n2p, S, n2p, (long)n2p * n2p, Zn, width, (long)n2p * width, dZn, width, (long)n2p * width,
                           nprob * seq, 1.0f / ((float)seq * n2 * d->temperature), st)) return rc;
-    hipLaunchKernelGGL(nce_unpack_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, dim, width, Zn, nrm, dZn);
+    hipLaunchKernelGGL(nce_unpack_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, n2p, dim, width, Zn, nrm, dZn);
     zoff += (size_t)rows * width;
     roff += rows;
   }
@@ -412,20 +430,20 @@ extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* fea
     const int Q = pl.Q;
     float* X = ws + pl.off_X; float* EX = ws + pl.off_ex; float* sq = ws + pl.off_sq; float* rs = ws + pl.off_rs;
     float* D = ws + pl.off_D; float* Dbar = ws + pl.off_dbar; float* dDbar = ws + pl.off_ddbar;
-    hipLaunchKernelGGL(rank_pack_kernel, dim3(ceil_div((long)Q * B, 4)), dim3(256), 0, st, rk, Q, B, dim, X, sq);
-    if (int rc = f32_gemm(false, B, B, dim, X, dim, (long)B * dim, X, dim, (long)B * dim, D, B, (long)B * B, Q, 1.0f, st)) return rc;
-    int eb = ceil_div((long)Q * B * B, 256);
+    hipLaunchKernelGGL(rank_pack_kernel, dim3(ceil_div((long)Q * Bp, 4)), dim3(256), 0, st, rk, Q, B, Bp, dim, X, sq);
+    if (int rc = f32_gemm(false, Bp, Bp, dim, X, dim, (long)Bp * dim, X, dim, (long)Bp * dim, D, Bp, (long)Bp * Bp, Q, 1.0f, st)) return rc;
+    int eb = ceil_div((long)Q * Bp * Bp, 256);
     if (eb > 8192) eb = 8192;
-    hipLaunchKernelGGL(rank_dist_kernel, dim3(eb), dim3(256), 0, st, Q, B, D, sq);
+    hipLaunchKernelGGL(rank_dist_kernel, dim3(eb), dim3(256), 0, st, Q, B, Bp, D, sq);
     int bb = ceil_div((long)Q * b * b, 256);
     if (bb > 4096) bb = 4096;
-    hipLaunchKernelGGL(rank_blockmean_kernel, dim3(bb), dim3(256), 0, st, Q, b, seq, D, Dbar);
+    hipLaunchKernelGGL(rank_blockmean_kernel, dim3(bb), dim3(256), 0, st, Q, b, seq, Bp, D, Dbar);
     hipLaunchKernelGGL(rank_hinge_kernel, dim3(loss_row_blocks((long)Q * b)), dim3(256), 0, st, Q, b, d->margin, Dbar, dDbar, terms);
-    hipLaunchKernelGGL(rank_coeff_kernel, dim3(ceil_div((long)Q * B, 4)), dim3(256), 0, st, Q, b, seq, d->w_rank, D, dDbar, rs);
-    if (int rc = f32_gemm(true, B, dim, B, D, B, (long)B * B, X, dim, (long)B * dim, EX, dim, (long)B * dim, Q, 1.0f, st)) return rc;
-    int gb = ceil_div((long)Q * B * dim, 256);
+    hipLaunchKernelGGL(rank_coeff_kernel, dim3(ceil_div((long)Q * Bp, 4)), dim3(256), 0, st, Q, b, seq, Bp, d->w_rank, D, dDbar, rs);
+    if (int rc = f32_gemm(true, Bp, dim, Bp, D, Bp, (long)Bp * Bp, X, dim, (long)Bp * dim, EX, dim, (long)Bp * dim, Q, 1.0f, st)) return rc;
+    int gb = ceil_div((long)Q * Bp * dim, 256);
     if (gb > 8192) gb = 8192;
-    hipLaunchKernelGGL(rank_grad_kernel, dim3(gb), dim3(256), 0, st, rk, Q, B, dim, X, rs, EX);
+    hipLaunchKernelGGL(rank_grad_kernel, dim3(gb), dim3(256), 0, st, rk, Q, B, Bp, dim, X, rs, EX);
   }
 
   // ---- orthogonality

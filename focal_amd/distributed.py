@@ -11,8 +11,53 @@ import torch
 import torch.distributed as dist
 
 
+import contextlib
+
+_LOCAL_ONLY = [0]
+
+
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not _LOCAL_ONLY[0]
+
+
+def world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+@contextlib.contextmanager
+def local_only():
+    """Inside: the data path issues no collective (rank 0's validation / checkpoint branch runs alone while the other
+    ranks wait at the barrier that follows it)."""
+    _LOCAL_ONLY[0] += 1
+    try:
+        yield
+    finally:
+        _LOCAL_ONLY[0] -= 1
+
+
+@torch.no_grad()
+def broadcast_module(module, src=0):
+    """Identical initial weights / buffers on every rank (the reference seeds nothing: each process would draw its own)."""
+    if not is_dist():
+        return
+    for t in list(module.state_dict().values()):
+        if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
+            dist.broadcast(t, src)
+
+
+@torch.no_grad()
+def all_gather_rows(t):
+    """[n, ...] per rank (equal n) -> [W * n, ...], rank-major."""
+    if not is_dist():
+        return t
+    t = t.contiguous()
+    out = torch.empty((dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out
 
 
 _STATIC = {}

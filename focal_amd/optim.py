@@ -105,7 +105,7 @@ class FocalAdamW(torch.optim.Optimizer):
         torch.cuda.synchronize()
         arenas = self._arenas()
         return {"step": int(self._step_state[1].item()) if self._step_state is not None else 0,
-                "lr": float(self.param_groups[0]["lr"]),
+                "lr": float(self.param_groups[0]["lr"]),  # informational: on resume the replayed scheduler owns the LR
                 "moments": [tuple(t.detach().cpu().clone() for t in ar.moments()) for ar in arenas]}
 
     def load_train_state(self, state):
@@ -122,4 +122,3 @@ class FocalAdamW(torch.optim.Optimizer):
         if self._step_state is None:
             self._step_state = ops.new_rng_state(0, dev)
         self._step_state[1] = int(state["step"])
-        self.param_groups[0]["lr"] = float(state["lr"])

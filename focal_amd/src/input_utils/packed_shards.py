@@ -46,7 +46,8 @@ def pack_index(args, index_file, out_dir):
 
 
 class PackedSequenceLoader:
-    def __init__(self, args, pack_dir, batch_size, shuffle=True, device=None, prefetch=2, seed=0, resident=None):
+    def __init__(self, args, pack_dir, batch_size, shuffle=True, device=None, prefetch=2, seed=0, resident=None, shard=True):
+        """shard=False: the whole batch on every rank that iterates (validation / test sets, which rank 0 evaluates alone)."""
         with open(os.path.join(pack_dir, MANIFEST)) as fh:
             man = json.load(fh)
         self.args, self.device = args, device if device is not None else args.device
@@ -67,23 +68,27 @@ class PackedSequenceLoader:
         self.subseq_batch = batch_size // seq_len
         self.shuffle, self.prefetch, self.seed, self.epoch = shuffle, prefetch, seed, 0
         import torch.distributed as dist
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.world = dist.get_world_size() if (shard and dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         if self.subseq_batch % self.world != 0:
             raise ValueError(f"{self.subseq_batch} subsequences per global batch do not split over {self.world} ranks")
 
     def __len__(self):
-        return int(np.ceil(len(self.subseqs) / self.subseq_batch))
+        if self.world == 1:
+            return int(np.ceil(len(self.subseqs) / self.subseq_batch))
+        full, rem = divmod(len(self.subseqs), self.subseq_batch)
+        return full + (1 if (rem // self.world) * self.world >= 2 else 0)
 
     def batches(self):
         """Sample-index lists of this rank's share of every global batch, in the reference's order."""
         order = list(range(len(self.subseqs)))
         if self.shuffle:
             random.Random(self.seed + self.epoch).shuffle(order) if self.world > 1 else random.shuffle(order)
-        per = self.subseq_batch // self.world
+        from input_utils.multi_modal_dataloader import rank_share
         for lo in range(0, len(order), self.subseq_batch):
-            chunk = order[lo:lo + self.subseq_batch]
-            mine = chunk[self.rank * per:(self.rank + 1) * per] if self.world > 1 else chunk
+            # equal shares on every rank, also for the short last batch of an epoch (its remainder is dropped): the ranks must run
+            # the same number of steps with the same local batch, or the all-gather / all-reduce of that step cannot match
+            mine = rank_share(order[lo:lo + self.subseq_batch], self.world, self.rank)
             idx = []
             for s in mine:
                 idx.extend(self.subseq_to_sample_idx[self.subseqs[s]])

@@ -11,13 +11,43 @@ _DEFAULT_TASK = {"ACIDS": "vehicle_classification", "MOD": "vehicle_classificati
                  "HAR4": "activity_classification"}
 
 
-def select_device(device=""):
+def parse_device_list(device=""):
+    """`-gpu` as the reference parses it (params/params_util.py:20-55): "0", "cuda:0", "0,1,2,3" -> list of device indices."""
     device = str(device).strip().lower().replace("cuda:", "").replace("none", "")
     if device in ("cpu", "mps"):
         raise RuntimeError("this build is the MI355X HIP path of FOCAL pretraining; -gpu=cpu has no implementation here "
                            "(the CPU oracle lives under oracle/ and is test infrastructure only)")
+    return [int(x) for x in device.split(",") if x != ""] or [0]
+
+
+def local_device_index(device=""):
+    """Device index of THIS process: LOCAL_RANK under a data-parallel launch (torchrun, or train.py's own `-gpu=0,1,...`
+    spawn, which narrows HIP_VISIBLE_DEVICES to the listed devices), else the first listed device.  FOCAL_DIST_ONE_DEVICE=1
+    (tests on a 1-GPU box) puts every rank on device 0."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return 0 if os.environ.get("FOCAL_DIST_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    return parse_device_list(device)[0]
+
+
+def init_distributed(device=""):
+    """One process per GPU: under WORLD_SIZE > 1 create the process group BEFORE the first HIP call, bound to this
+    rank's device (backend "nccl" = RCCL over xGMI; FOCAL_DIST_BACKEND=gloo for CPU-side / single-GPU tests)."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("FOCAL_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_device_index(device)))
+    else:
+        dist.init_process_group(backend)
+
+
+def select_device(device=""):
+    local = local_device_index(device)
+    init_distributed(device)
     assert torch.cuda.is_available(), "no ROCm device visible"
-    local = int(os.environ.get("LOCAL_RANK", device.split(",")[0] if device else 0))
     torch.cuda.set_device(local)
     return torch.device("cuda", local)
 
@@ -30,6 +60,8 @@ def get_train_mode(learn_framework):
 
 def set_auto_params(args):
     args.device = select_device(str(args.gpu if args.gpu is not None else 0))
+    args.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    args.rank = int(os.environ.get("RANK", "0")) if args.world_size > 1 else 0
     args.half = False
     args.task = _DEFAULT_TASK[args.dataset] if args.task is None else args.task
     here = os.path.dirname(os.path.abspath(__file__))

@@ -31,9 +31,39 @@ def train(args):
     raise Exception(f"Invalid stage ({args.stage}) provided: FOCAL pretraining and finetuning are implemented on the HIP path.")
 
 
+def spawn_data_parallel(devices):
+    """`-gpu=0,1,...,7` (the reference already parses device lists, params/params_util.py:34-38, but trains on the first one):
+    one child process per listed GPU, each a rank of an RCCL data-parallel job -- what `torchrun --nproc-per-node N train.py`
+    does, without the launcher.  Runs before anything touches the GPU in this process."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(len(devices)):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(len(devices)), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HIP_VISIBLE_DEVICES=",".join(str(d) for d in devices))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    sys.exit(max(codes, key=abs))
+
+
 def main_train():
-    logging.basicConfig(level=logging.INFO, format="%(message)s")
-    train(parse_train_params())
+    from params.base_params import parse_base_args
+    from params.params_util import parse_device_list
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        devices = parse_device_list(parse_base_args("train").gpu)
+        if len(devices) > 1:
+            spawn_data_parallel(devices)
+    rank = int(os.environ.get("RANK", "0"))
+    logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(message)s")
+    try:
+        train(parse_train_params())
+    finally:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -64,4 +64,8 @@ def compute_knn(args, classifier, augmenter, data_loader_train):
             aug_freq_loc_inputs, _ = augmenter.forward("no", time_loc_inputs, y)
             feats.append(extract_sample_features(args, classifier, aug_freq_loc_inputs))
             labels.append(y.argmax(dim=1) if y.dim() > 1 else y)
-    return GpuKNNClassifier().fit(torch.cat(feats), torch.cat(labels))
+    feats, labels = torch.cat(feats), torch.cat(labels).to(feats[0].device)
+    from focal_amd import distributed as fdist
+    if fdist.is_dist():  # the training loader hands every rank an equal share: the estimator is fitted on all of them
+        feats, labels = fdist.all_gather_rows(feats), fdist.all_gather_rows(labels)
+    return GpuKNNClassifier().fit(feats, labels)

@@ -13,6 +13,12 @@ class _EpochScheduler:
     def value(self, base_lr, t):
         raise NotImplementedError
 
+    def _init_warmup(self):
+        """timm writes `warmup_lr_init` to the param groups at construction when warm-up is on: epoch 0 runs at it."""
+        if getattr(self, "warmup_t", 0) > 0:
+            for g in self.optimizer.param_groups:
+                g["lr"] = self.warmup_lr_init
+
     def step(self, epoch):
         for g, b in zip(self.optimizer.param_groups, self.base):
             g["lr"] = self.value(b, epoch)
@@ -25,6 +31,7 @@ class CosineLRScheduler(_EpochScheduler):
         super().__init__(optimizer)
         self.t_initial, self.lr_min = t_initial, lr_min
         self.warmup_t, self.warmup_lr_init, self.warmup_prefix = warmup_t, warmup_lr_init, warmup_prefix
+        self._init_warmup()
 
     def value(self, base_lr, t):
         if t < self.warmup_t:
@@ -40,6 +47,7 @@ class StepLRScheduler(_EpochScheduler):
     def __init__(self, optimizer, decay_t, decay_rate=1.0, warmup_t=0, warmup_lr_init=0.0, **_):
         super().__init__(optimizer)
         self.decay_t, self.decay_rate, self.warmup_t, self.warmup_lr_init = decay_t, decay_rate, warmup_t, warmup_lr_init
+        self._init_warmup()
 
     def value(self, base_lr, t):
         if t < self.warmup_t:

@@ -1,8 +1,12 @@
 """FOCAL pretraining loop (reference: train_utils/pretrain.py:21-107): per batch zero_grad -> loss -> backward ->
-step -> loss.item().  Under torchrun (WORLD_SIZE > 1) the batch is the local shard of a data-parallel job: the
-projected embeddings are all-gathered and gradients all-reduced over RCCL (focal_amd/distributed.py)."""
+step -> loss.item().  Under a data-parallel launch (torchrun, or `train.py -gpu=0,1,...`; the process group is created by
+params/params_util.py before the first HIP call) the batch is this rank's share of the global batch: the projected embeddings
+are all-gathered and gradients all-reduced over RCCL (focal_amd/distributed.py); weights start identical on every rank
+(broadcast from rank 0); the every-10-epochs branch fits the KNN estimator on the features of ALL ranks' training shares, then
+rank 0 alone validates, logs and writes the checkpoints while the others wait at a barrier."""
 import logging
 import os
+import sys
 
 import numpy as np
 import torch
@@ -16,12 +20,20 @@ from train_utils.lr_scheduler import define_lr_scheduler
 from train_utils.model_selection import init_pretrain_framework
 from train_utils.optimizer import define_optimizer
 
+_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+from focal_amd import distributed as fdist  # noqa: E402
+from focal_amd import runtime  # noqa: E402
+
 
 def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, test_dataloader, loss_func, num_batches):
     default_model = init_pretrain_framework(args, backbone_model)
     optimizer = define_optimizer(args, default_model.parameters())
     lr_scheduler = define_lr_scheduler(args, optimizer)
     default_model = freeze_patch_embedding(args, default_model)
+    fdist.broadcast_module(default_model)
+    rank0 = fdist.rank() == 0
 
     logging.info("---------------------------Start Pretraining Classifier-------------------------------")
     start = time_sync()
@@ -34,12 +46,14 @@ def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, 
     best_val_loss = np.inf
     start_epoch = 0
     resume = getattr(args, "resume", False) and os.path.exists(train_state) and os.path.exists(latest_weight)
-    if resume:  # (the reference has no resume; weights + optimizer moments + step + epoch restore the run exactly)
+    if resume:  # (the reference has no resume; weights + optimizer moments + step + dropout stream + epoch restore the run)
         default_model.backbone.load_state_dict(torch.load(latest_weight, map_location="cpu"))
         st = torch.load(train_state, map_location="cpu")
         start_epoch, best_val_loss = st["epoch"] + 1, st["best_val_loss"]
         for e in range(start_epoch):
-            lr_scheduler.step(e)
+            lr_scheduler.step(e)  # the replayed schedule owns the learning rate (the saved state holds the PREVIOUS epoch's)
+        if st.get("rng") is not None:
+            runtime.rng_state(args.device).copy_(st["rng"].to(args.device))
     windows = 0
     for epoch in range(start_epoch, epochs):
         default_model.train()
@@ -52,19 +66,25 @@ def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, 
                 optimizer.load_train_state(st["optimizer"])  # the arena exists once a backward has run
             optimizer.step()
             train_loss_list.append(loss.item())
-            windows += args.batch_size
+            windows += next(iter(next(iter(time_loc_inputs.values())).values())).shape[0] * fdist.world()
         if epoch % 10 == 0:
             terms = loss_func.last_terms.tolist() if getattr(loss_func, "last_terms", None) is not None else []
             logging.info(f"epoch {epoch}: terms[shared,private,orth,rank,total]={terms}")
-            # KNN estimator on the training features, then validation / test loss + accuracy (reference :76-92)
+            # KNN estimator on the training features (every rank's share, gathered), then validation / test loss + accuracy
+            # (reference :76-92) and the checkpoints on rank 0 only
             knn_estimator = compute_knn(args, default_model.backbone, augmenter, train_dataloader)
-            val_acc, val_loss = val_and_logging(args, epoch, default_model, augmenter, val_dataloader, test_dataloader, loss_func,
-                                               float(np.mean(train_loss_list)), estimator=knn_estimator)
-            torch.save(default_model.backbone.state_dict(), latest_weight)
-            if val_loss < best_val_loss:
-                best_val_loss = val_loss
-                torch.save(default_model.backbone.state_dict(), best_weight)
-            torch.save({"epoch": epoch, "best_val_loss": best_val_loss, "optimizer": optimizer.train_state()}, train_state)
+            if rank0:
+                with fdist.local_only():
+                    val_acc, val_loss = val_and_logging(args, epoch, default_model, augmenter, val_dataloader, test_dataloader,
+                                                       loss_func, float(np.mean(train_loss_list)), estimator=knn_estimator)
+                torch.save(default_model.backbone.state_dict(), latest_weight)
+                if val_loss < best_val_loss:
+                    best_val_loss = val_loss
+                    torch.save(default_model.backbone.state_dict(), best_weight)
+                torch.save({"epoch": epoch, "best_val_loss": best_val_loss, "optimizer": optimizer.train_state(),
+                            "rng": runtime.rng_state(args.device).cpu()}, train_state)
+            if fdist.is_dist():
+                torch.distributed.barrier()
         lr_scheduler.step(epoch)
     end = time_sync()
     logging.info(f"Total processing time: {(end - start): .3f} s  ({windows / max(end - start, 1e-9):.1f} windows/s)")

@@ -75,3 +75,77 @@ def test_gather_is_identity_without_process_group():
     assert not is_dist()
     d = [{"a": torch.ones(2, 3)}, {"a": torch.zeros(2, 3)}]
     assert gather_features(d) is d
+
+
+def _share_worker(rank, world, port, out, tmp):
+    """Both loaders of the data path under 2 gloo ranks on a subsequence count that does NOT divide the global batch: every
+    rank must see the same number of batches with the same local size, the shares must be disjoint and, together, be the
+    leading part of the single-process batch."""
+    import sys
+    import types
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for p in (root, os.path.join(root, "focal_amd", "src")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from input_utils.multi_modal_dataloader import BatchSeqSampler
+    from input_utils.multi_modal_dataset import MultiModalSequenceDataset
+    from input_utils.packed_shards import PackedSequenceLoader
+    cfg = {"seq_len": 4, "location_names": ["shake"], "modality_names": ["audio", "seismic"]}
+    args = types.SimpleNamespace(dataset="MOD", dataset_config=cfg, task="vehicle_classification", device=torch.device("cpu"),
+                                 train_mode="contrastive", stage="pretrain", sequence_sampler=True)
+    ds = MultiModalSequenceDataset(args, os.path.join(tmp, "index.txt"))
+    sampler = BatchSeqSampler(args, 16, ds, seed=5)           # global batch: 4 subsequences; 11 subsequences in the index
+    a = [list(b) for b in sampler]
+    assert len(a) == len(sampler)
+    packed = PackedSequenceLoader(args, os.path.join(tmp, "pack"), 16, shuffle=True, device=torch.device("cpu"), seed=5)
+    b = list(packed.batches())
+    assert len(b) == len(packed)
+    whole = PackedSequenceLoader(args, os.path.join(tmp, "pack"), 16, shuffle=False, device=torch.device("cpu"), shard=False)
+    out[rank] = {"sampler": a, "packed": b, "n_sub": len(ds.subseqs), "whole": [len(x) for x in whole.batches()]}
+    dist.destroy_process_group()
+
+
+def test_two_rank_loaders_take_equal_shares_of_a_ragged_epoch(tmp_path):
+    import sys
+    import types
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for p in (root, os.path.join(root, "focal_amd", "src")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from input_utils.packed_shards import pack_index
+    files = []
+    g = torch.Generator().manual_seed(3)
+    for seq, n in (("runA_shake", 17), ("runB_shake", 14), ("runC_shake", 9)):   # 5 + 4 + 3 = 12 ... minus: 17->5, 14->4, 9->3
+        for k in range(n):
+            f = os.path.join(str(tmp_path), f"{seq}_{k}.pt")
+            torch.save({"label": torch.tensor(len(files) % 3), "flag": {"shake": {"audio": True, "seismic": True}},
+                        "data": {"shake": {"audio": torch.randn(1, 10, 16, generator=g), "seismic": torch.randn(1, 10, 4, generator=g)}}}, f)
+            files.append(f)
+    files = files[:-5]  # 17 + 14 + 4 windows -> 5 + 4 + 1 = 10 subsequences... keep it ragged against a global batch of 4
+    (tmp_path / "index.txt").write_text("\n".join(files) + "\n")
+    cfg = {"seq_len": 4, "location_names": ["shake"], "modality_names": ["audio", "seismic"]}
+    args = types.SimpleNamespace(dataset="MOD", dataset_config=cfg, task="vehicle_classification", device=torch.device("cpu"),
+                                 train_mode="contrastive", stage="pretrain", sequence_sampler=True)
+    pack_index(args, str(tmp_path / "index.txt"), str(tmp_path / "pack"))
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_share_worker, args=(world, port, out, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    n_sub = r0["n_sub"]
+    assert n_sub % 4 != 0, "the fixture must leave a short last batch"
+    for kind in ("sampler", "packed"):
+        a, b = r0[kind], r1[kind]
+        assert len(a) == len(b) and len(a) >= 2, kind                               # same number of steps on both ranks
+        assert [len(x) for x in a] == [len(x) for x in b], kind                     # same local batch at every step
+        assert all(len(x) % 4 == 0 and len(x) >= 4 for x in a), kind                # whole subsequences
+        full = n_sub // 4
+        assert all(len(x) == 8 for x in a[:full]), kind                             # 2 of the 4 subsequences each
+        rem = n_sub % 4
+        assert len(a) == full + (1 if (rem // 2) * 2 >= 2 else 0), kind
+        if len(a) > full:
+            assert len(a[-1]) == (rem // 2) * 4, kind                               # the remainder's odd subsequence is dropped
+    # un-sharded loaders (validation / test) hand the whole batch to whichever rank iterates them
+    assert r0["whole"] == r1["whole"] and sum(r0["whole"]) == n_sub * 4

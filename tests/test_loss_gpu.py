@@ -42,14 +42,17 @@ def test_loss_head_matches_reference_fixture(cfg, name, model):
             assert err < 1e-3, (key, err.item())
 
 
-@pytest.mark.parametrize("M,B,no_private", [(2, 16, False), (4, 32, False), (2, 32, True), (3, 2048, False)])
-def test_loss_head_matches_oracle(cfg, M, B, no_private):
-    """Other modality counts / the global batch of config 4 (b = 512) / the noPrivate tag, against the oracle."""
+@pytest.mark.parametrize("M,B,no_private,seq", [(2, 16, False, 4), (4, 32, False, 4), (2, 32, True, 4), (3, 2048, False, 4),
+                                                (2, 12, False, 4), (2, 20, False, 4), (3, 8, False, 4), (2, 15, False, 3), (2, 10, True, 2)])
+def test_loss_head_matches_oracle(cfg, M, B, no_private, seq):
+    """Other modality counts / the global batch of config 4 (b = 512) / the noPrivate tag / ragged last batches of an epoch (an
+    odd number b = 3, 5 of subsequences, b = 2, other subsequence lengths: the reference accepts any b >= 2), against the oracle."""
     import copy
 
     from focal_amd import ops
     from oracle.loss import focal_loss_terms
     c = copy.deepcopy(cfg)
+    c["seq_len"] = seq
     mods = [f"m{i}" for i in range(M)]
     c["modality_names"] = mods
     f1, f2 = _views(B, mods, 100 + M, 1.2)
