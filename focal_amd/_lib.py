@@ -14,7 +14,7 @@ ACT_NONE, ACT_GELU, ACT_RELU_OUT = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class DropDesc(C.Structure):
@@ -44,6 +44,11 @@ class LinearDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("x_dtype", C.c_int),
                 ("y_dtype", C.c_int), ("act_in", C.c_int), ("epilogue", C.c_int), ("splits", C.c_int),
                 ("out_drop", DropDesc)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("C", C.c_int), ("hidden", C.c_int), ("drop_hidden", DropDesc),
+                ("drop_out", DropDesc), ("ln_eps", C.c_float)]
 
 
 class AttnDesc(C.Structure):
@@ -88,6 +93,7 @@ PROTOTYPES = {
     "focal_rng_advance": (C.c_int, [P, P]),
     "focal_fft_realpack_fwd": (C.c_int, [C.POINTER(FFTDesc), P, P, P, P]),
     "focal_augment_fft_fwd": (C.c_int, [C.POINTER(FFTDesc), C.POINTER(AugDesc), P, P, P, P]),
+    "focal_warp_fwd": (C.c_int, [C.c_int, C.c_int, P, P, P, P, C.c_int, P, P]),
     "focal_pad_patch_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P]),
     "focal_pad_patch_embed_ln2_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P, P, C.c_float, C.c_int, P, P, P]),
     "focal_layernorm_fwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, P]),
@@ -97,6 +103,9 @@ PROTOTYPES = {
     "focal_linear_resid_ln_fwd": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P, P, C.c_float, P, P, P]),
     "focal_linear_bwd_data": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
+    "focal_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "focal_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P]),
+    "focal_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P]),
     "focal_window_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P]),
     "focal_window_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P]),
     "focal_fusion_attn_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint32, C.c_float, P]),

@@ -1,0 +1,326 @@
+// Backward of the fused Swin MLP branch at 64 channels (see mlp.hip for the forward and the reference lines).
+//
+// One pass over gm = dL/dx_out (already x the branch's dropout / drop-path mask, bf16) and a2 (the saved LayerNorm output)
+// produces dL/da2 and all four parameter gradients; the hidden activation h and its derivative are RECOMPUTED per tile instead of
+// being read back from two [M, 256] tensors by four GEMM launches:
+//
+//   per 128-token tile, 32 hidden units at a time (8 waves, 16 tokens each in phase A):
+//     phase A   u = a2 W1c^T + b1c -> h = drop(gelu(u)), h' = drop(gelu'(u))        (recompute; mask regenerated from the hash)
+//               dh = gm W2c -> du = dh . h'                                         (accumulator layouts match: no shuffles)
+//               da2 += du W1c                                                       (du re-enters the matrix core from registers)
+//               h, du -> LDS (bf16, [token][32])
+//     phase B   dW2c += gm^T h, dW1c += du^T a2 over all 128 tokens: every wave owns 2 of the chunk's 16 output tiles and keeps its
+//               16 x 8 = 128 tiles... i.e. 16 accumulators (64 VGPRs) for the WHOLE kernel -- the weight gradient leaves the CU once,
+//               as 256-byte contiguous fp32 atomics staged through LDS.
+//   phases of consecutive chunks overlap (double-buffered h / du tiles, one barrier per chunk).
+//
+// Operands that are contracted over their row index (W2 for dh, W1 for da2, gm / a2 / h / du for the weight gradients) are read
+// with ds_read_b64_tr_b16; all LDS images are XOR-swizzled so that both their direct and their transposed fragment reads are
+// bank-conflict free (derivations next to each swizzle function).
+#include "gemm.hpp"
+#include "mlp.hpp"
+
+namespace {
+
+constexpr int C = MLP_C, H = MLP_H, BM = 128;
+// LDS map (bytes).  Every image is laid out so that (a) its fragment reads -- direct ds_read_b128 and / or transposed
+// ds_read_b64_tr_b16 -- are bank-conflict free and (b) an address is (per-lane base) + (compile-time constant): the swizzles only mix
+// LANE-dependent bits, loop indices select sub-images.  (The first version XOR-ed loop constants into the chunk index: half of the
+// kernel's 4 700 vector instructions per tile were address arithmetic, and the kernel ran VALU-bound at 1/13 of the MFMA rate.)
+constexpr int L_W1 = 0;                  // 2 half images (c < 32 | c >= 32) of [256 h][32 c] bf16: 64-B rows, chunk ^ P[(h >> 2) & 3]
+constexpr int L_W2 = 32768;              // 16 sub-images (16 hidden units each) of [64 c][16 h] bf16: 32-B rows at row' = c ^ ((c >> 3 & 1) << 2)
+constexpr int L_GM = 65536;              // [128 m][64 c] bf16: 128-B rows, chunk ^ sw_tile(m)
+constexpr int L_A2 = L_GM + 16384;
+constexpr int L_HB = L_A2 + 16384;       // 2 buffers x { h, du } x 2 sub-tiles (16 hidden units) of [128 m][16] bf16: 32-B rows at row'(m)
+constexpr int L_B1 = L_HB + 32768;       // [256] f32
+constexpr int L_END = L_B1 + 1024;
+constexpr int LDS_BWD_BYTES = L_END;     // 129 KB: one workgroup per CU
+
+typedef __attribute__((address_space(3))) bf16x4* lds_tr_ptr;
+
+// chunk swizzle of the W1 half images: conflict-free for the direct reads of 16 consecutive rows (ds_read_b128 serves lanes
+// {0-3, 12-15, 20-27} etc. together: the four 4-row blocks of a tile must land on different 16-byte columns for both chunk parities)
+// and for the transposed reads over rows 32 q + 4 g + {0..3}
+__device__ __forceinline__ int sw_p(int blk) { return (0x1230 >> (4 * (blk & 3))) & 3; }  // {0, 3, 2, 1}
+// token tiles (gm, a2): direct reads of 16 consecutive rows, transposed reads over rows 32 ks + 8 g + {0..3} (+4): bits 1 and 3 of the row
+__device__ __forceinline__ int sw_tile(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }
+// 32-byte-row images: rows r and r + 8 would share banks; swapping the two 4-row halves of every second 8-row block separates them
+__device__ __forceinline__ int rowp(int r) { return r ^ (((r >> 3) & 1) << 2); }
+
+__device__ __forceinline__ int a_w1(int h, int c) { return L_W1 + (c >> 5) * 16384 + h * 64 + (((((c & 31) >> 3)) ^ sw_p(h >> 2)) << 4) + (c & 7) * 2; }
+__device__ __forceinline__ int a_w2(int c, int h) { return L_W2 + (h >> 4) * 2048 + rowp(c) * 32 + (h & 15) * 2; }
+__device__ __forceinline__ int a_tile(int base, int row, int col) { return base + row * 128 + ((((col >> 3)) ^ sw_tile(row)) << 4) + (col & 7) * 2; }
+
+__device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
+__device__ __forceinline__ bf16x4 tr_read(const char* lds, int addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr_ptr)(lds + addr)); }
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would expose the full HBM latency of the
+// next tile's prefetch at the first barrier behind it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float sum8(bf16x8 v) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += (float)v[e];
+  return s;
+}
+
+__global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(const MlpBwdParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool c_side_first = wave < 4;   // waves 0-3 own dW2 tiles (c-tile cw, all hidden tiles), waves 4-7 dW1 tiles (all hidden tiles, c-tile cw)
+  const int cw = wave & 3;
+
+  // ---- weights -> LDS
+  {
+    uint4 v1[4], v2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v1[i] = reinterpret_cast<const uint4*>(p.w1)[tid + 512 * i];
+      v2[i] = reinterpret_cast<const uint4*>(p.w2)[tid + 512 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 512 * i;
+      *reinterpret_cast<uint4*>(lds + a_w1(q >> 3, (q & 7) * 8)) = v1[i];
+      // a 16-byte chunk of a W2 row = 8 hidden units of one c: the 8-unit half of one sub-image row
+      *reinterpret_cast<uint4*>(lds + a_w2(q >> 5, (q & 31) * 8)) = v2[i];
+    }
+    if (tid < H) reinterpret_cast<float*>(lds + L_B1)[tid] = p.b1[tid];
+  }
+
+  MaskEval meH;
+  meH.init(p.drop_h);
+
+  // ---- per-lane address bases (everything else is a compile-time offset)
+  const int mloc = wave * 16 + l15;                                                    // this lane's token inside a tile (phase A)
+  const int b_w1d = L_W1 + l15 * 64 + ((g ^ sw_p(l15 >> 2)) << 4);                     // + (c half) * 16384 + h0 * 64
+  int b_w1t[2];                                                                        // + (c tile >> 1) * 16384 + q * 2048 (+ 1024: rows + 16)
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) b_w1t[jb] = L_W1 + (4 * g + tq) * 64 + ((((2 * jb + (tp >> 1))) ^ sw_p(g)) << 4) + (tp & 1) * 8;
+  const int rp_lo = rowp(8 * g + tq) * 32 + tp * 8, rp_hi = rowp(8 * g + tq + 4) * 32 + tp * 8;
+  const int b_w2_lo = L_W2 + rp_lo, b_w2_hi = L_W2 + rp_hi;                            // + (hidden tile) * 2048 + kk * 1024
+  const int hsel = c_side_first ? 0 : 8192;                                            // waves 0-3 contract h, waves 4-7 du
+  const int b_hb_lo = L_HB + hsel + rp_lo, b_hb_hi = L_HB + hsel + rp_hi;              // + buf * 16384 + t * 4096 + ks * 1024
+  const int b_hw = L_HB + rowp(mloc) * 32 + 8 * g;                                     // + buf * 16384 (+ 8192: du) + t * 4096
+  const int b_tr = (c_side_first ? L_GM : L_A2) + (8 * g + tq) * 128 + ((((2 * cw + (tp >> 1))) ^ sw_tile(8 * g + tq)) << 4) + (tp & 1) * 8;  // + ks * 4096 (+ 512)
+  int b_td[2];                                                                         // direct fragments of this lane's token: + 0 (gm) | 16384 (a2)
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) b_td[kk] = L_GM + mloc * 128 + (((4 * kk + g) ^ sw_tile(mloc)) << 4);
+  const int b_b1 = L_B1 + 16 * g;                                                      // + hidden * 4
+  int b_st[2];                                                                         // staging chunks of a token tile (gm; a2 = + 16384)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + 512 * i;
+    b_st[i] = L_GM + (q >> 3) * 128 + (((q & 7) ^ sw_tile(q >> 3)) << 4);
+  }
+
+  f32x4 acc[16];  // this wave's weight-gradient tiles, indexed by hidden tile (0..15)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbh[16];  // waves 4-7: partial sums of du over this wave's k-step (db1), per hidden tile
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dbh[i] = 0.f;
+  float dbc = 0.f;  // waves 0-3: partial sum of gm over tokens for column 16 cw + l15 (db2)
+
+  const int ntiles = (p.M + BM - 1) / BM;
+  // this thread's 2 + 2 staging chunks of a token tile: chunk id = tid + 512 i -> row id >> 3, 16-byte column chunk id & 7
+  uint4 pg[2], pa[2];
+  auto prefetch = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 512 * i;
+      const long m = (long)tile * BM + (q >> 3);
+      const bool ok = m < p.M;
+      pg[i] = ok ? *reinterpret_cast<const uint4*>(p.gm + m * C + (q & 7) * 8) : make_uint4(0, 0, 0, 0);
+      pa[i] = ok ? *reinterpret_cast<const uint4*>(p.a + m * C + (q & 7) * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- token tile -> LDS (the previous tile's last barrier has passed: nobody reads the old one any more)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(lds + b_st[i]) = pg[i];
+      *reinterpret_cast<uint4*>(lds + b_st[i] + 16384) = pa[i];
+    }
+    lds_barrier();
+    if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+
+    const int m = tile * BM + mloc;
+    bf16x8 xa[2], xg[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      xg[kk] = *reinterpret_cast<const bf16x8*>(lds + b_td[kk]);
+      xa[kk] = *reinterpret_cast<const bf16x8*>(lds + b_td[kk] + 16384);
+    }
+    f32x4 dc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto phase_a = [&](int q) {  // hidden units 32 q .. 32 q + 31
+      const int buf = (q & 1) * 16384;
+      bf16x8 duf;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ht = 2 * q + t;  // hidden tile (16 units)
+        f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f}, dh = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 w1f = *reinterpret_cast<const bf16x8*>(lds + b_w1d + kk * 16384 + ht * 1024);
+          u = mma16(w1f, xa[kk], u);
+          // W2^T fragment: hidden unit 16 ht + l15, contraction over c = 32 kk + 8 g .. + 7 (rows of the sub-image)
+          const bf16x8 w2f = join(tr_read(lds, b_w2_lo + ht * 2048 + kk * 1024), tr_read(lds, b_w2_hi + ht * 2048 + kk * 1024));
+          dh = mma16(w2f, xg[kk], dh);
+        }
+        const int hcol = 16 * ht + 4 * g;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(lds + b_b1 + ht * 64);
+        bf16x4 hq, dq;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const gelu_f2 x = {u[e] + bb[e], u[e + 1] + bb[e + 1]};
+          gelu_f2 cdf, pdf;
+          gelu_parts2(x, cdf, pdf);
+          const gelu_f2 mult = meH.elem_mult_pair(m, hcol + e);
+          const gelu_f2 hh = x * cdf * mult, gg = (x * pdf + cdf) * mult;
+          const gelu_f2 dd = gelu_f2{dh[e], dh[e + 1]} * gg;
+          hq[e] = (bf16_t)hh.x; hq[e + 1] = (bf16_t)hh.y;
+          dq[e] = (bf16_t)dd.x; dq[e + 1] = (bf16_t)dd.y;
+        }
+        *reinterpret_cast<bf16x4*>(lds + b_hw + buf + t * 4096) = hq;
+        *reinterpret_cast<bf16x4*>(lds + b_hw + buf + 8192 + t * 4096) = dq;
+        duf[4 * t] = dq[0]; duf[4 * t + 1] = dq[1]; duf[4 * t + 2] = dq[2]; duf[4 * t + 3] = dq[3];
+      }
+      // da2 += du W1c: contraction slots (g, e) <-> hidden 32 q + 16 (e >> 2) + 4 g + (e & 3), the order du sits in registers
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int a0 = b_w1t[j & 1] + (j >> 1) * 16384 + q * 2048;
+        const bf16x8 w1t = join(tr_read(lds, a0), tr_read(lds, a0 + 1024));
+        dc[j] = mma16(w1t, duf, dc[j]);
+      }
+    };
+
+    auto phase_b = [&](int q) {
+      const int buf = (q & 1) * 16384;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 fc = join(tr_read(lds, b_tr + ks * 4096), tr_read(lds, b_tr + ks * 4096 + 512));
+        bf16x8 fh[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fh[t] = join(tr_read(lds, b_hb_lo + buf + t * 4096 + ks * 1024), tr_read(lds, b_hb_hi + buf + t * 4096 + ks * 1024));
+        if (c_side_first) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[2 * q + t] = mma16(fc, fh[t], acc[2 * q + t]);   // dW2[c][h]
+          if (q == 0) dbc += sum8(fc);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[2 * q + t] = mma16(fh[t], fc, acc[2 * q + t]);   // dW1[h][c]
+          if (ks == cw) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dbh[2 * q + t] += sum8(fh[t]);
+          }
+        }
+      }
+    };
+
+    phase_a(0);
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      phase_b(q);
+      if (q < 7) phase_a(q + 1);
+      lds_barrier();
+    }
+
+    // ---- dL/da2 for this wave's 16 tokens
+    if (m < p.M) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) store4(p.da + (long)m * C + 16 * j + 4 * g, dc[j]);
+    }
+  }
+
+  // ---- flush: tiles -> LDS ([64][256] dW2 then [256][64] dW1, fp32), then 256-byte contiguous atomics
+  float* F2 = reinterpret_cast<float*>(lds);
+  float* F1 = reinterpret_cast<float*>(lds + 65536);
+#pragma unroll
+  for (int ht = 0; ht < 16; ++ht) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (c_side_first) F2[(16 * cw + 4 * g + r) * H + 16 * ht + l15] = acc[ht][r];
+      else F1[(16 * ht + 4 * g + r) * C + 16 * cw + l15] = acc[ht][r];
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i) {
+    const int idx = tid + 512 * i;
+    atomicAdd(p.dw2 + idx, F2[idx]);
+    atomicAdd(p.dw1 + idx, F1[idx]);
+  }
+  // bias gradients: fold the 4 contraction groups of a fragment, then one atomic per column and wave
+  if (c_side_first) {
+    dbc += __shfl_xor(dbc, 16, 64);
+    dbc += __shfl_xor(dbc, 32, 64);
+    if (g == 0 && p.db2) atomicAdd(p.db2 + 16 * cw + l15, dbc);
+  } else if (p.db1) {
+#pragma unroll
+    for (int ht = 0; ht < 16; ++ht) {
+      float v = dbh[ht];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) atomicAdd(p.db1 + 16 * ht + l15, v);
+    }
+  }
+}
+
+}  // namespace
+
+static MaskParams mlp_bwd_mask(const focal_drop_desc& d, int ncols) {
+  MaskParams m;
+  m.seed = d.rng;
+  m.stream_elem = d.stream_elem;
+  m.p_elem = d.p_elem;
+  m.stream_path = d.stream_path;
+  m.p_path = d.p_path;
+  m.rows_per_sample = d.rows_per_sample;
+  m.ncols = ncols;
+  return m;
+}
+
+extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void* a, const void* w1, const float* b1, const void* w2,
+                             void* da, float* dw1, float* db1, float* dw2, float* db2, const float* ln_x, const float* ln_stats,
+                             const float* ln_gamma, float* g, void* gm_next, const focal_drop_desc* next_mask, float* dgamma,
+                             float* dbeta, void* stream) {
+  if (int rc = mlp_check_desc(d, "mlp_bwd")) return rc;
+  FOCAL_CHECK_ARG(gm && a && w1 && b1 && w2 && dw1 && dw2, "mlp_bwd: null tensor");
+  if (ln_x != nullptr) {
+    focal_set_error("mlp_bwd: the fused LayerNorm backward is not built in this version (pass ln_x = NULL and run focal_layernorm_bwd)");
+    return FOCAL_EUNSUPPORTED;
+  }
+  FOCAL_CHECK_ARG(da != nullptr, "mlp_bwd: da is required without the fused LayerNorm backward");
+  (void)ln_stats; (void)ln_gamma; (void)g; (void)gm_next; (void)next_mask; (void)dgamma; (void)dbeta;
+  MlpBwdParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->M;
+  p.gm = reinterpret_cast<const bf16_t*>(gm);
+  p.a = reinterpret_cast<const bf16_t*>(a);
+  p.w1 = reinterpret_cast<const bf16_t*>(w1);
+  p.b1 = b1;
+  p.w2 = reinterpret_cast<const bf16_t*>(w2);
+  p.da = reinterpret_cast<bf16_t*>(da);
+  p.dw1 = dw1; p.db1 = db1; p.dw2 = dw2; p.db2 = db2;
+  p.drop_h = mlp_bwd_mask(d->drop_hidden, MLP_H);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD_BYTES) != hipSuccess) {
+      focal_set_error("mlp_bwd: cannot reserve %d bytes of LDS", LDS_BWD_BYTES);
+      return FOCAL_EHIP;
+    }
+    attr_set = true;
+  }
+  const int ntiles = (d->M + BM - 1) / BM;
+  const int grid = ntiles < 256 ? ntiles : 256;  // one persistent 8-wave workgroup per CU
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid), dim3(512), LDS_BWD_BYTES, (hipStream_t)stream, p);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU_OUT, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RESIDUAL, FOCAL_BF16, FOCAL_F32,
                    AdamWDesc, AttnDesc, BNDesc, ConvDesc, ConvInDesc, DropDesc, EmbedDesc, FFTDesc, GRUDesc, LinearDesc,
-                   LNDesc, LossDesc, check)
+                   LNDesc, LossDesc, MlpDesc, check)
 
 _TORCH2CODE = {torch.float32: FOCAL_F32, torch.bfloat16: FOCAL_BF16}
 _CODE2TORCH = {v: k for k, v in _TORCH2CODE.items()}
@@ -184,6 +184,24 @@ def fft_realpack(x, scale=1.0, flip=False, perm=None, phase=0.0, out=None):
     return out
 
 
+def mag_warp(x, mult):
+    """[B, C, I, S] fp32 x mult [I*S] (device fp32): the magnitude warp of focal_warp_fwd."""
+    _need_cuda(x, mult)
+    B, Cc, I, S = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().focal_warp_fwd(B * Cc, I * S, _p(x), _p(mult), None, None, 0, _p(y), _stream()))
+    return y
+
+
+def time_warp(x, k0, w):
+    """[B, C, I, S] fp32 resampled along the flattened (I, S) axis with the tables of focal_amd.warp.time_warp_tables (device)."""
+    _need_cuda(x, k0, w)
+    B, Cc, I, S = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().focal_warp_fwd(B * Cc, I * S, _p(x), None, _p(k0), _p(w), w.shape[1], _p(y), _stream()))
+    return y
+
+
 # ------------------------------------------------------------------------------------------------ row 8
 def pad_patch_embed_ln(x, w, b, gamma, beta, Hp, Wp, pw, eps=1e-5, next_ln=None):
     """next_ln = (gamma2, beta2, out_dtype): also return (LayerNorm(tokens), stats) of the LayerNorm that follows (C0 == 64)."""
@@ -296,6 +314,48 @@ def linear(x, w, bias=None, *, compute, y_dtype=None, resid=None, act_in=ACT_NON
     y = (torch.zeros if splits > 1 else torch.empty)(M, N, dtype=y_dtype, device=x.device)
     linear_fwd(d, x, w, bias, resid, y, act_grad)
     return y, d
+
+
+# ------------------------------------------------------------------------------------------------ fused MLP branch
+def mlp_supported(dtype, Cc, hidden):
+    return bool(_lib.load().focal_mlp_supported(code(dtype), Cc, hidden))
+
+
+def mlp_desc(dtype_code, M, Cc, hidden, drop_hidden=None, drop_out=None, ln_eps=1e-5):
+    return MlpDesc(dtype_code, M, Cc, hidden, drop_hidden or NO_DROP, drop_out or NO_DROP, ln_eps)
+
+
+def mlp_fwd(d, a, resid, w1, b1, w2, b2, y, next_ln=None):
+    """y = resid + drop_out(drop_hidden(gelu(a w1^T + b1)) w2^T + b2) (focal_mlp_fwd); next_ln = (gamma, beta) also returns
+    (LayerNorm(y) in a's dtype, stats) of the LayerNorm that reads y next."""
+    _need_cuda(a, resid, w1, b1, w2, b2, y)
+    if next_ln is None:
+        if not _ablated("mlp_fwd"):
+            check(_lib.load().focal_mlp_fwd(C.byref(d), _p(a), _p(resid), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), None, None, None, None,
+                                            _stream()))
+        return None
+    y_ln = torch.empty(d.M, d.C, dtype=a.dtype, device=a.device)
+    stats = torch.empty(d.M, 2, dtype=torch.float32, device=a.device)
+    if not _ablated("mlp_fwd"):
+        check(_lib.load().focal_mlp_fwd(C.byref(d), _p(a), _p(resid), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(next_ln[0]),
+                                        _p(next_ln[1]), _p(y_ln), _p(stats), _stream()))
+    return y_ln, stats
+
+
+def mlp_bwd(d, gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, ln=None):
+    """focal_mlp_bwd.  ln = dict(x=, stats=, gamma=, g=, gm_next=, next_mask=, dgamma=, dbeta=) fuses the norm2 backward behind it
+    (da is then not written)."""
+    _need_cuda(gm, a, w1, b1, w2, da, dw1, db1, dw2, db2)
+    if _ablated("mlp_bwd"):
+        return
+    if ln is None:
+        check(_lib.load().focal_mlp_bwd(C.byref(d), _p(gm), _p(a), _p(w1), _p(b1), _p(w2), _p(da), _p(dw1), _p(db1), _p(dw2), _p(db2),
+                                        None, None, None, None, None, None, None, None, _stream()))
+        return
+    mask = ln.get("next_mask") or NO_DROP
+    check(_lib.load().focal_mlp_bwd(C.byref(d), _p(gm), _p(a), _p(w1), _p(b1), _p(w2), _p(da), _p(dw1), _p(db1), _p(dw2), _p(db2),
+                                    _p(ln["x"]), _p(ln["stats"]), _p(ln["gamma"]), _p(ln["g"]), _p(ln.get("gm_next")), C.byref(mask),
+                                    _p(ln["dgamma"]), _p(ln["dbeta"]), _stream()))
 
 
 # ------------------------------------------------------------------------------------------------ row 10

@@ -5,8 +5,10 @@
 which runs on the HIP DFT kernel.  The augmentation arithmetic (negation, scaling, horizontal flip, interval
 permutation, phase shift) is folded into that kernel (`focal_augment_fft_fwd`); only the random draws stay on the host,
 unseeded as in the reference.
-Deviation: `time_warp` / `mag_warp` wrap tsai's random-spline transforms, whose source is not available in this
-build environment; they are applied as identity (their coin flip is still drawn) and logged once.
+`time_warp` / `mag_warp` wrap tsai's random-spline transforms, whose source is not available in this build environment: they
+are restated from tsai's published algorithm in focal_amd/warp.py (the curve, drawn on the host like every other augmenter's
+randomness) and run as one device pass in front of the transform (focal_warp_fwd); see that module for the one documented
+deviation (cardinal-form signal spline with clamped ends).
 """
 import logging
 import math
@@ -43,16 +45,18 @@ def _permutation(x, cfg):  # PermutationAugmenter.py:35-36: one random interval 
     return dict(perm=torch.randperm(x.shape[2]).tolist())
 
 
-_WARNED = set()
+def _time_warp(x, cfg):  # TimeWarpAugmenter.py:18,44 -> tsai TSTimeWarp (restated in focal_amd/warp.py): one curve per (loc, mod)
+    from focal_amd import warp
+    L = x.shape[2] * x.shape[3]
+    k0, w = warp.time_warp_tables(warp.warp_positions(L, warp.draw_knots(cfg["order"], cfg["magnitude"]), cfg["order"]))
+    return dict(pre=lambda t: ops.time_warp(t, torch.from_numpy(k0).to(t.device), torch.from_numpy(w).to(t.device)))
 
 
-def _spline_warp_unavailable(name):
-    def fn(x, cfg):
-        if name not in _WARNED:
-            _WARNED.add(name)
-            logging.warning(f"{name}: tsai spline warp unavailable in this build; applied as identity")
-        return {}
-    return fn
+def _mag_warp(x, cfg):  # MagWarpAugmenter.py:18,44 -> tsai TSMagWarp
+    from focal_amd import warp
+    L = x.shape[2] * x.shape[3]
+    mult = warp.random_curve(L, warp.draw_knots(cfg["order"], cfg["magnitude"]), cfg["order"]).astype(np.float32)
+    return dict(pre=lambda t: ops.mag_warp(t, torch.from_numpy(mult).to(t.device)))
 
 
 def _phase_shift(x, cfg):  # PhaseShiftAugmenter.py:39-54: rotate every complex bin by one random angle
@@ -64,8 +68,7 @@ def _mixup_unavailable(x, cfg):  # MixupAugmenter mixes samples AND labels (supe
 
 
 TIME_AUGMENTERS = {"no": None, "mixup": _mixup_unavailable, "negation": _negation, "scaling": _scaling, "horizontal_flip": _horizontal_flip,
-                   "permutation": _permutation, "time_warp": _spline_warp_unavailable("time_warp"),
-                   "mag_warp": _spline_warp_unavailable("mag_warp")}
+                   "permutation": _permutation, "time_warp": _time_warp, "mag_warp": _mag_warp}
 FREQ_AUGMENTERS = {"no": None, "phase_shift": _phase_shift}
 
 
@@ -116,8 +119,15 @@ class Augmenter:
         name = self.aug_names[k]
         fn = TIME_AUGMENTERS[name] if k < len(self.time_aug_names) else FREQ_AUGMENTERS[name]
         kw = self._draw(fn, name, time_loc_inputs)
-        return {loc: {mod: ops.fft_realpack(x.contiguous(), out=self._view_slot(loc, mod, x), **kw[loc][mod]) for mod, x in mods.items()}
-                for loc, mods in time_loc_inputs.items()}
+        out = {}
+        for loc, mods in time_loc_inputs.items():
+            out[loc] = {}
+            for mod, x in mods.items():
+                k = dict(kw[loc][mod])
+                pre = k.pop("pre", None)  # the spline warps are a pass of their own in front of the transform
+                src = pre(x.contiguous()) if pre is not None else x.contiguous()
+                out[loc][mod] = ops.fft_realpack(src, out=self._view_slot(loc, mod, x), **k)
+        return out
 
     def _view_slot(self, loc, mod, x):
         """Where this view's spectrum goes: the pretraining loop draws two views of the same windows back to back

@@ -65,7 +65,7 @@ def set_auto_params(args):
     args.half = False
     args.task = _DEFAULT_TASK[args.dataset] if args.task is None else args.task
     here = os.path.dirname(os.path.abspath(__file__))
-    args.dataset_config = load_yaml(os.path.join(here, "..", "data", f"{args.dataset}.yaml"))
+    args.dataset_config = load_yaml(getattr(args, "config", None) or os.path.join(here, "..", "data", f"{args.dataset}.yaml"))
     args.sequence_sampler = args.learn_framework in {"FOCAL"}
     args.workers = 10
     args.train_mode = get_train_mode(args.learn_framework)

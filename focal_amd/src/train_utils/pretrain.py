@@ -32,6 +32,8 @@ def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, 
     optimizer = define_optimizer(args, default_model.parameters())
     lr_scheduler = define_lr_scheduler(args, optimizer)
     default_model = freeze_patch_embedding(args, default_model)
+    if getattr(args, "init_weight", None):
+        default_model.backbone.load_state_dict(torch.load(args.init_weight, map_location="cpu"))
     fdist.broadcast_module(default_model)
     rank0 = fdist.rank() == 0
 

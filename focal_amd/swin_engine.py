@@ -43,6 +43,7 @@ class SwinModEncoder:
         pe = f"patch_embed.{self.loc}.{self.mod}"
         P = bb.param  # cold parameters (frozen patch embedding) are read where they live
         fuse_ln = os.environ.get("FOCAL_NO_LN_FUSE") != "1"
+        fuse_mlp = os.environ.get("FOCAL_NO_MLP_FUSE") != "1"
         pre_ln = None  # (a1, st1) of the next block when the kernel before it already produced them
         first = f"{self.pre}.0.blocks.0"
         if fuse_ln and geo["stages"][0]["C"] == 64:  # the embedding kernel also emits block 0's norm1
@@ -92,12 +93,27 @@ class SwinModEncoder:
                     a2, st2 = ops.layernorm_fwd(x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
                 d_fc1 = ops.linear_desc(cc, M, 4 * Cc, Cc, cc, cc, ACT_NONE, EPI_GELU,
                                         out_drop=self._drop(rng, view, uid, 1, p_drop, 0.0, L))
-                h = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)
-                hg = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)  # d h / d(pre-activation), dropout included
-                ops.linear_fwd(d_fc1, a2, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"), None, h, hg)
                 d_fc2 = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, f32, ACT_GELU, EPI_RESIDUAL,
                                         out_drop=self._drop(rng, view, uid, 2, p_drop, p_path, L))
                 x_out = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
+                d_mlp = h = hg = None
+                if fuse_mlp and ops.mlp_supported(ct, Cc, 4 * Cc):
+                    # the whole MLP branch in one kernel: the [M, 4C] hidden activation never reaches HBM and is recomputed in backward
+                    d_mlp = ops.mlp_desc(cc, M, Cc, 4 * Cc, d_fc1.out_drop, d_fc2.out_drop)
+                    nxt_ln = None
+                    if fuse_ln and bi + 1 < st["depth"]:
+                        nb = f"{self.pre}.{si}.blocks.{bi + 1}"
+                        nxt_ln = (ar.master(f"{nb}.norm1.weight"), ar.master(f"{nb}.norm1.bias"))
+                    pre_ln = ops.mlp_fwd(d_mlp, a2, x_mid, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
+                                         ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_out, next_ln=nxt_ln)
+                    saved["blocks"].append(dict(pb=pb, x=x, st1=st1, a1=a1, qkv=qkv, o=o, x_mid=x_mid, st2=st2, a2=a2, h=None, hg=None,
+                                                d_qkv=d_qkv, d_att=d_att, d_proj=d_proj, d_fc1=d_fc1, d_fc2=d_fc2, d_mlp=d_mlp, M=M, C=Cc))
+                    x = x_out
+                    uid += 1
+                    continue
+                h = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)
+                hg = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)  # d h / d(pre-activation), dropout included
+                ops.linear_fwd(d_fc1, a2, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"), None, h, hg)
                 if fuse_ln and Cc == 64 and bi + 1 < st["depth"]:
                     nb = f"{self.pre}.{si}.blocks.{bi + 1}"
                     pre_ln = ops.linear_resid_ln_fwd(d_fc2, h, ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"),
@@ -166,14 +182,19 @@ class SwinModEncoder:
             pb, M, Cc = s["pb"], s["M"], s["C"]
             gm = gm.view(M, Cc)
             # ---- MLP branch: x_out = x_mid + mask * (h W2^T + b2), h = drop(gelu(a2 W1^T + b1))
-            d_fc2_b = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, cc, ACT_GELU)  # dy = gm: operand dtype, already masked
-            ops.linear_bwd_weight(d_fc2_b, gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
-            du = torch.empty_like(s["h"])
-            ops.linear_bwd_data(d_fc2_b, gm, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
-            ops.linear_bwd_weight(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
             dc = torch.empty_like(s["a2"])
-            ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
-            del du
+            if s.get("d_mlp") is not None:  # fused branch: h and h' recomputed from a2, all four parameter gradients from one pass
+                ops.mlp_bwd(s["d_mlp"], gm, s["a2"], ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
+                            ar.operand(f"{pb}.mlp.fc2.weight"), dc, ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"),
+                            ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
+            else:
+                d_fc2_b = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, cc, ACT_GELU)  # dy = gm: operand dtype, already masked
+                ops.linear_bwd_weight(d_fc2_b, gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
+                du = torch.empty_like(s["h"])
+                ops.linear_bwd_data(d_fc2_b, gm, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
+                ops.linear_bwd_weight(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
+                ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
+                del du
             ops.layernorm_bwd(dc, s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g, True,
                               ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), dx_masked=gm, mask=s["d_proj"].out_drop)
             # ---- attention branch: x_mid = x + mask * (o Wp^T + bp)

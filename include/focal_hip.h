@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FOCAL_ABI_VERSION 2
+#define FOCAL_ABI_VERSION 3
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -69,6 +69,15 @@ int focal_fft_realpack_fwd(const focal_fft_desc* d, const float* x, const float*
 typedef struct { float scale; int flip; int use_perm; int perm[FOCAL_AUG_MAX_INTERVALS]; float phase_cos, phase_sin; } focal_aug_desc;
 int focal_augment_fft_fwd(const focal_fft_desc* d, const focal_aug_desc* a, const float* x, const float* twiddle, float* out,
                           void* stream);
+
+/* TimeWarp / MagWarp (data_augmenter/TimeWarpAugmenter.py:18,44, MagWarpAugmenter.py:18,44 -> tsai 0.3.7 TSTimeWarp / TSMagWarp;
+ * SURVEY 8f rank 1): one smooth random curve per call over the flattened (I*S) axis of [B, C, I, S], shared by batch and channels;
+ * x, y fp32 [rows = B*C][L = I*S].  Exactly one of the two table sets:
+ *   mult [L]                      y[r][n] = x[r][n] * mult[n]                                  (magnitude warp)
+ *   k0 [L] int32, w [L][taps]     y[r][n] = sum_t w[n][t] * x[r][clamp(k0[n] + t, 0, L-1)]     (time warp: the interpolating cubic
+ *                                 spline of each row evaluated at the warped positions, cardinal form; taps = 24)
+ * The curve (a dozen Gaussian knots) and the tables are drawn / built on the host, as the reference draws them in numpy. */
+int focal_warp_fwd(int rows, int L, const float* x, const float* mult, const int* k0, const float* w, int taps, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 8: embed
  * SW_Transformer.pad_input + PatchEmbed (models/SW_Transformer.py:184-208, models/SwinModules.py:547-558):
@@ -138,6 +147,28 @@ int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy, const void
                           void* stream);
 int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const void* x, float* dw, float* dbias,
                             void* stream);
+
+/* Fused MLP branch of a Swin block (models/SwinModules.py:18-34 Mlp.forward + the residual / DropPath of :339-341), bf16,
+ * C = 64 -> hidden = 256 -> C (Swin stage 0, where 2/3 of the model's hidden-activation bytes are; focal_mlp_supported says
+ * whether a shape is built):
+ *   fwd: y = resid + drop_out( drop_hidden(gelu(a w1^T + b1)) w2^T + b2 ); the hidden activation never reaches HBM.  With y_ln
+ *        non-NULL the LayerNorm that reads y next is emitted too (y_ln bf16 [M, C], ln_stats fp32 [M][2] = {mean, rstd}).
+ *   bwd: gm = dtype(dL/dy x drop_out mask) (what focal_layernorm_bwd / focal_mask_cast emit as dx_masked); the hidden
+ *        activation and its derivative are RECOMPUTED from `a` (dropout mask regenerated), da = dL/da (bf16), dw1 / db1 / dw2 /
+ *        db2 accumulated (+=) in fp32 -- one pass over gm and a instead of four GEMMs over two saved [M, 4C] tensors.
+ *        With ln_x non-NULL the norm2 backward is fused behind it: da is not written; instead g (fp32 [M, C], the residual-
+ *        stream gradient) += LayerNorm-backward(da; ln_x, ln_stats, ln_gamma), gm_next (bf16 [M, C], optional) = g x next_mask,
+ *        dgamma / dbeta accumulated.
+ * drop_hidden uses the pair hash of FOCAL_EPI_GELU (element index over [M, hidden]); drop_out the element / DropPath
+ * convention of FOCAL_EPI_RESIDUAL (over [M, C]). */
+typedef struct { int dtype; int M, C, hidden; focal_drop_desc drop_hidden, drop_out; float ln_eps; } focal_mlp_desc;
+int focal_mlp_supported(int dtype, int C, int hidden);
+int focal_mlp_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
+                  const float* b2, float* y, const float* ln_gamma, const float* ln_beta, void* y_ln, float* ln_stats, void* stream);
+int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void* a, const void* w1, const float* b1, const void* w2,
+                  void* da, float* dw1, float* db1, float* dw2, float* db2,
+                  const float* ln_x, const float* ln_stats, const float* ln_gamma, float* g, void* gm_next,
+                  const focal_drop_desc* next_mask, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 10: W-MSA
  * WindowAttention between its qkv and proj Linears (models/SwinModules.py:121-152) with the cyclic shift, window

@@ -46,6 +46,40 @@ def phase_shift(f, angle):
     return torch.stack([re * ca - im * sa, re * sa + im * ca], 2).reshape(b, c, i, s)
 
 
+def _tsai_curve(L, knots, order):
+    """tsai 0.3.7 `random_curve_generator` (tsai/data/transforms.py) with the Gaussian knot values passed in: a cubic spline
+    (scipy default end condition) through 3 (ord - 1) + 1 knots at linspace(-L, 2L - 1, ., dtype=int), evaluated on arange(L).
+    tsai is a pinned dependency of the reference (requirements.txt:91) that is absent from /root/reference and from this image:
+    restated from its published source -- PARITY UNPINNED for the two warps."""
+    import numpy as np
+    from scipy.interpolate import CubicSpline
+    xs = np.linspace(-L, 2 * L - 1, 3 * (order - 1) + 1, dtype=int)
+    return CubicSpline(xs, np.asarray(knots, np.float64), axis=-1)(np.arange(L))
+
+
+def mag_warp(x, knots, order=4):
+    """MagWarpAugmenter.forward (data_augmenter/MagWarpAugmenter.py:40-44) -> tsai TSMagWarp.encodes: o * curve on the [b, c, i*s]
+    reshape, one curve for the whole tensor."""
+    b, c, i, s = x.shape
+    curve = torch.from_numpy(_tsai_curve(i * s, knots, order)).to(x.dtype)
+    return (x.reshape(b, c, i * s) * curve).reshape(b, c, i, s)
+
+
+def time_warp(x, knots, order=6):
+    """TimeWarpAugmenter.forward (data_augmenter/TimeWarpAugmenter.py:40-44) -> tsai TSTimeWarp.encodes:
+    CubicSpline(arange(L), o)(random_cum_curve_generator(o)) -- the exact (banded, not-a-knot) signal spline."""
+    import numpy as np
+    from scipy.interpolate import CubicSpline
+    b, c, i, s = x.shape
+    L = i * s
+    cum = _tsai_curve(L, knots, order).cumsum()
+    cum -= cum[0]
+    cum /= cum[-1]
+    pos = np.clip(cum, 0, 1) * (L - 1)
+    f = CubicSpline(np.arange(L), x.reshape(b, c, L).double().numpy(), axis=-1)
+    return torch.from_numpy(f(pos)).to(x.dtype).reshape(b, c, i, s)
+
+
 def augmented_view(x, name, draw=None):
     """Augmenter.forward_random for ONE chosen augmenter applied to one (loc, mod) tensor (data_augmenter/Augmenter.py:76-113):
     time-domain augmenters act before the DFT, `phase_shift` after it.  `draw` = factor / order / angle where one is needed."""
@@ -57,6 +91,10 @@ def augmented_view(x, name, draw=None):
         x = horizontal_flip(x)
     elif name == "permutation":
         x = permutation(x, draw)
+    elif name == "mag_warp":
+        x = mag_warp(x, draw)
+    elif name == "time_warp":
+        x = time_warp(x, draw)
     elif name not in ("no", "phase_shift"):
         raise ValueError(name)
     f = fft_realpack(x)

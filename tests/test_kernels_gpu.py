@@ -688,3 +688,60 @@ def test_gpu_knn_matches_sklearn(ops):
     got = GpuKNNClassifier().fit(xtr.to(DEV), ytr.to(DEV)).predict(xq.to(DEV)).cpu().numpy()
     assert (got == ref).mean() >= 0.999, (got != ref).sum()   # (an exact distance tie at the 5th neighbour may order differently)
     assert 0.25 < (got == yq.numpy()).mean() < 0.999          # a real classification problem, neither trivial nor hopeless
+
+
+@pytest.mark.parametrize("I,S,C", [(10, 1600, 1), (10, 20, 2)])
+def test_spline_warps_on_device_match_the_oracle(ops, I, S, C):
+    """TimeWarp / MagWarp (data_augmenter/{Time,Mag}WarpAugmenter.py -> tsai): focal_warp_fwd with the host-built tables vs the
+    oracle's scipy restatement of tsai's algorithm with the same knot values."""
+    import numpy as np
+    from focal_amd import warp
+    from oracle import augment
+    x = rnd(8, C, I, S, seed=61)
+    L = I * S
+    kn = warp.draw_knots(4, 0.05, np.random.RandomState(2))
+    mult = torch.from_numpy(warp.random_curve(L, kn, 4).astype(np.float32)).to(DEV)
+    got = ops.mag_warp(x, mult)
+    ref = augment.mag_warp(x.cpu(), kn, 4)
+    assert (got.cpu() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+    assert (got - x).abs().max().item() > 1e-3                 # not the identity
+    kn = warp.draw_knots(6, 0.2, np.random.RandomState(3))
+    k0, w = warp.time_warp_tables(warp.warp_positions(L, kn, 6))
+    got = ops.time_warp(x, torch.from_numpy(k0).to(DEV), torch.from_numpy(w).to(DEV)).cpu().reshape(8, C, L)
+    ref = augment.time_warp(x.cpu(), kn, 6).reshape(8, C, L)
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 5e-5 * scale
+
+
+def test_product_augmenter_draws_real_spline_warps(ops, cfg, monkeypatch):
+    """`Augmenter.forward("random")` with the pool restricted to the two spline warps and the coin forced to heads: the view
+    differs from the un-augmented spectrum (no identity stand-in any more) and equals the oracle's view for the knots it drew."""
+    import copy
+    import numpy as np
+    import torch as T
+    from conftest import make_args
+    from data_augmenter import Augmenter as A
+    from oracle import augment
+    for name, order in (("mag_warp", 4), ("time_warp", 6)):
+        c = copy.deepcopy(cfg)
+        c["FOCAL"]["random_augmenters"] = {"time_augmenters": [name], "freq_augmenters": []}
+        c[name]["prob"] = 1.0
+        aug = A.Augmenter(make_args(c, "SW_Transformer", T.device(DEV)))
+        drawn = []
+        from focal_amd import warp
+        real = warp.draw_knots
+
+        def spy(order_, magnitude, rng=np.random):
+            k = real(order_, magnitude, rng)
+            drawn.append(k)
+            return k
+        monkeypatch.setattr(warp, "draw_knots", spy)
+        x = {"shake": {"audio": rnd(4, 1, 10, 1600, seed=71).cpu(), "seismic": rnd(4, 1, 10, 20, seed=72).cpu()}}
+        out = aug.forward("random", x)
+        plain = aug.forward("no", x)
+        assert len(drawn) == 2  # one curve per (location, modality)
+        for i, mod in enumerate(c["modality_names"]):
+            assert rel_err(out["shake"][mod], plain["shake"][mod]) > 1e-3
+            ref = augment.augmented_view(x["shake"][mod], name, drawn[i])
+            assert rel_err(out["shake"][mod].cpu(), ref) < 1e-4
+        monkeypatch.setattr(warp, "draw_knots", real)
