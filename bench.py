@@ -28,7 +28,8 @@ for p in (ROOT, os.path.join(ROOT, "focal_amd", "src")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FLOP_PER_WINDOW = {"SW_Transformer": 4.376e9, "DeepSense": 0.809e9}  # SURVEY 8d (fwd+bwd, both views)
+FLOP_PER_WINDOW = {"SW_Transformer/MOD": 4.376e9, "DeepSense/MOD": 0.809e9}  # SURVEY 8d (fwd + bwd, both views); other
+# datasets: tests/golden/flops.json (torch.utils.flop_counter on the reference models, tests/golden/gen_flops.py)
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_PEAK_TF = 2500.0
 MFMA_F32_PEAK_TF = 157.3
@@ -37,9 +38,10 @@ MFMA_F32_PEAK_TF = 157.3
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--model", default="SW_Transformer")
+    p.add_argument("--dataset", default="MOD", help="MOD (2 modalities, BASELINE configs 2-4) or HAR4 (4-modality synthetic IMU, config 5)")
     p.add_argument("--batch", type=int, default=256, help="windows per GPU")
     p.add_argument("--dtype", default="bf16")
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -55,10 +57,20 @@ def parse():
     return p.parse_args()
 
 
-def make_args(cfg, model, device, dtype):
-    return argparse.Namespace(model=model, dataset="MOD", device=device, train_mode="contrastive", learn_framework="FOCAL",
-                              stage="pretrain", task="vehicle_classification", tag=None, dataset_config=cfg,
-                              compute_dtype=dtype)
+def make_args(cfg, model, device, dtype, dataset="MOD"):
+    return argparse.Namespace(model=model, dataset=dataset, device=device, train_mode="contrastive", learn_framework="FOCAL",
+                              stage="pretrain", task="vehicle_classification" if dataset == "MOD" else "activity_classification",
+                              tag=None, dataset_config=cfg, compute_dtype=dtype)
+
+
+def flops_per_window(model, dataset):
+    key = f"{model}/{dataset}"
+    f = os.path.join(ROOT, "tests", "golden", "flops.json")
+    if os.path.exists(f):
+        tab = json.load(open(f))
+        if key in tab:
+            return float(tab[key]["step_per_window"])
+    return FLOP_PER_WINDOW.get(key)
 
 
 class Step:
@@ -72,13 +84,13 @@ class Step:
         from train_utils.model_selection import init_backbone_model, init_loss_func, init_pretrain_framework
         from train_utils.optimizer import define_optimizer
         self.ops, self.dist = ops, distributed
-        cfg = load_yaml(os.path.join(ROOT, "focal_amd", "src", "data", "MOD.yaml"))
+        cfg = load_yaml(os.path.join(ROOT, "focal_amd", "src", "data", f"{a.dataset}.yaml"))
         if a.no_dropout:  # diagnostic only (measures what the mask generation costs); never the reported configuration
             for k in ("dropout_ratio", "drop_path_rate", "attn_drop_rate"):
                 cfg["SW_Transformer"][k] = 0.0
             cfg["DeepSense"]["dropout_ratio"] = 0.0
         self.cfg = cfg
-        args = make_args(cfg, a.model, device, a.dtype)
+        args = make_args(cfg, a.model, device, a.dtype, a.dataset)
         args.sync_bn = a.sync_bn
         torch.manual_seed(1234)
         self.backbone = init_backbone_model(args)
@@ -237,40 +249,154 @@ def time_kernel(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
+# ---------------------------------------------------------------------------------------------------------------- roofline
+# The dominant kernel is chosen and timed INSIDE the step (a warm back-to-back replay of one launch sits in the 256 MiB
+# Infinity Cache and flattered the number by 2.6x).  One eager step is run with a HIP-event pair around every launch of the
+# traced kernel families, recorded on the stream the launch goes to (each modality encoder has its own stream); launches are
+# grouped the way the committed rocprofv3 trace groups them (profiles/r2_*_instances.csv: kernel template x launch grid), so
+# `calls_per_step` / `avg_us` of the reported group can be checked against that file row by row.
+def _dw_bytes_flops(d):
+    es = 2 if d.dtype == 1 else 4
+    ey = 4 if d.y_dtype == 0 else es
+    ex = 4 if d.x_dtype == 0 else es
+    return d.M * d.N * ey + d.M * d.K * ex + d.N * d.K * 4, 2.0 * d.M * d.N * d.K
+
+
+class StepTracer:
+    """HIP events around every call of the traced op families during eager steps."""
+
+    def __init__(self, ops):
+        self.ops, self.rec, self.saved = ops, [], {}
+
+    def _wrap(self, name, describe):
+        orig = getattr(self.ops, name)
+        self.saved[name] = orig
+
+        def traced(*args, **kw):
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            out = orig(*args, **kw)
+            e1.record(st)
+            self.rec.append((describe(*args, **kw), e0, e1))
+            return out
+        setattr(self.ops, name, traced)
+
+    def install(self):
+        ops = self.ops
+        lib = __import__("focal_amd._lib", fromlist=["load"]).load()
+        import ctypes
+
+        def dw(d, dy, x, dw_, db):
+            wgs = lib.focal_linear_bwd_weight_workgroups(ctypes.byref(d))
+            b, f = _dw_bytes_flops(d)
+            return ("focal_gemm_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles>", f"{wgs} workgroups x 256", b, f, "hbm")
+
+        def lnb(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None, dx_masked=None, mask=None):
+            rows, C = dy.shape
+            es = dy.element_size()
+            b = rows * C * (es + 4 + (8 if accumulate else 4) + (es if dx_masked is not None else 0)) + rows * 8
+            return ("ln_bwd_kernel", "persistent grid (all LayerNorm backward launches)", b, 8.0 * rows * C, "hbm")
+
+        def mlpb(d, gm, a, *rest, **kw):
+            return ("mlp_bwd_kernel", "256 workgroups x 512 (persistent)", d.M * d.C * 6, 10.0 * d.M * d.C * d.hidden, "mfma")
+        self._wrap("linear_bwd_weight", dw)
+        self._wrap("layernorm_bwd", lnb)
+        self._wrap("mlp_bwd", mlpb)
+
+    def remove(self):
+        for k, v in self.saved.items():
+            setattr(self.ops, k, v)
+
+    def summary(self, steps):
+        torch.cuda.synchronize()
+        groups = {}
+        for (kern, shape, b, f, bound), e0, e1 in self.rec:
+            g = groups.setdefault((kern, shape, bound), [0, 0.0, 0.0, 0.0])
+            g[0] += 1
+            g[1] += e0.elapsed_time(e1) * 1e3  # us
+            g[2] += b
+            g[3] += f
+        return [dict(kernel=k[0], launch_shape=k[1], bound=k[2], calls_per_step=v[0] / steps, us_per_step=v[1] / steps,
+                     avg_us=v[1] / v[0], bytes_per_launch=v[2] / v[0], flops_per_launch=v[3] / v[0]) for k, v in groups.items()]
+
+
 def roofline(a, step, device):
-    """Live measurement of the dominant kernel (largest total time in the committed rocprofv3 summary, profiles/): the
-    weight-gradient GEMM template focal_gemm_kernel<bf16: A = dy (transposed), B = activation (transposed), fp32 atomic
-    out, 64x64 tiles, split over tokens>, timed on its largest instance exactly as the step launches it: dW of the stage-0
-    audio MLP down-projection, dW[64,256] += gm[M,64]^T h[M,256], M = 2 views x B x 576 tokens (gm = the residual-stream
-    gradient, already multiplied by the branch's dropout mask by the LayerNorm backward that produced it).
-    HBM-bound (AI = 2*64*256 / ((64 + 256)*2) = 51 flop/B): algorithmic bytes = read gm + read h + write dW once."""
+    """`roofline` of the JSON line: the (kernel template, launch shape) group with the largest time per step among the traced
+    families, measured in the step.  HBM-bound groups: achieved = algorithmic bytes per launch / average launch duration against
+    the 8 TB/s peak; the fused MLP backward is compute-bound (its bytes are 6 B per token-channel): TFLOP/s against the dense bf16
+    MFMA peak.  `isolated` repeats the round-1 measurement (one instance, back-to-back launches) warm and cold for comparison."""
     ops = step.ops
     if a.model != "SW_Transformer":
         return roofline_deepsense(a, step, device)
+    tr = StepTracer(ops)
+    tr.install()
+    n_steps = 3
+    try:
+        # keep the GPU behind the host: ~15 ms of fills are queued first, so the step's launches (and their events) are consumed
+        # back to back and an event pair brackets kernel time, not host launch gaps
+        pad = torch.empty(256 << 20, dtype=torch.float32, device=device)
+        for _ in range(6):
+            pad.fill_(1.0)
+        for _ in range(n_steps):
+            step.run()
+        groups = tr.summary(n_steps)
+    finally:
+        tr.remove()
+    del pad
+    groups.sort(key=lambda g: -g["us_per_step"])
+    top = groups[0]
+    if top["bound"] == "hbm":
+        ach = top["bytes_per_launch"] / (top["avg_us"] * 1e-6) / 1e9
+        peak, unit = HBM_PEAK_GBS, "GB/s"
+    else:
+        ach = top["flops_per_launch"] / (top["avg_us"] * 1e-6) / 1e12
+        peak, unit = (MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF), "TFLOP/s"
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "r2_pmc_roofline_kernel.json")
+    if os.path.exists(tf):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same eager step (tools/pmc_roofline.sh)
+        traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+    out = {"bound": top["bound"], "kernel": f"{top['kernel']} [{top['launch_shape']}]", "achieved": round(ach, 1), "peak": peak, "unit": unit,
+           "frac": round(ach / peak, 4), "traffic": traffic, "measured": "in the step: HIP events around each launch of one eager step, averaged over the group",
+           "calls_per_step": round(top["calls_per_step"], 2), "avg_us": round(top["avg_us"], 2),
+           "algorithmic_bytes_per_launch": round(top["bytes_per_launch"]), "flops_per_launch": round(top["flops_per_launch"]),
+           "other_groups": [{"kernel": f"{g['kernel']} [{g['launch_shape']}]", "calls_per_step": round(g["calls_per_step"], 2),
+                             "avg_us": round(g["avg_us"], 2), "ms_per_step": round(g["us_per_step"] / 1e3, 4),
+                             "GBps": round(g["bytes_per_launch"] / (g["avg_us"] * 1e-6) / 1e9, 1),
+                             "TFLOPps": round(g["flops_per_launch"] / (g["avg_us"] * 1e-6) / 1e12, 1)} for g in groups[1:6]],
+           "isolated": roofline_isolated(a, step, device)}
+    return out
+
+
+def roofline_isolated(a, step, device):
+    """Round 1's measurement, kept as a cross-check: the largest weight-gradient instance (stage-0 audio qkv: dW[192,64] +=
+    dqkv[M,192]^T a1[M,64], M = 2 views x B x 576 tokens) launched back to back on one operand set (warm: it sits in the Infinity
+    Cache) and rotating through > 512 MB of operand sets (cold: every launch reads HBM, as in the step)."""
+    ops = step.ops
     ct = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     es = 2 if ct == torch.bfloat16 else 4
-    geo = step.backbone.geometry["shake"]["audio"]["stages"][0]
+    geo = step.backbone.geometry[step.cfg["location_names"][0]][step.cfg["modality_names"][-1]]["stages"][0]
     views = 2 if getattr(step.backbone, "views_share_pass", False) else 1
     M, C = views * a.batch * geo["H"] * geo["W"], geo["C"]
-    N, K = C, 4 * C  # the forward linear is [M, K=4C] -> [M, N=C]
-    from focal_amd._lib import ACT_GELU
-    g = torch.randn(M, N, device=device).to(ct)
-    h = torch.randn(M, K, device=device).to(ct)
-    dw = torch.zeros(N, K, device=device)
-    db = torch.zeros(N, device=device)
-    d = ops.linear_desc(ops.code(ct), M, N, K, ops.code(ct), ops.code(ct), ACT_GELU)
-    ms = time_kernel(lambda: ops.linear_bwd_weight(d, g, h, dw, db), iters=a.roofline_iters)
+    N, K = 3 * C, C
+    d = ops.linear_desc(ops.code(ct), M, N, K, ops.code(ct), ops.code(ct))
     bytes_alg = M * N * es + M * K * es + N * K * 4
-    flops = 2.0 * M * N * K
-    gbs = bytes_alg / (ms * 1e-3) / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "r1_u_pmc_roofline_kernel.json")
-    if os.path.exists(tf):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --roofline-only` (see the file's note)
-        traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-    return {"bound": "hbm", "kernel": "focal_gemm_kernel<dW: gm[%d,%d]%s^T x h[%d,%d]%s -> fp32 atomics, 64x64 tiles>" % (M, N, a.dtype, M, K, a.dtype),
-            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "algorithmic_bytes": bytes_alg, "ms_per_launch": round(ms, 5),
-            "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+    nsets = max(2, (640 << 20) // (M * (N + K) * es) + 1)
+    sets = [(torch.randn(M, N, device=device).to(ct), torch.randn(M, K, device=device).to(ct)) for _ in range(nsets)]
+    dw, db = torch.zeros(N, K, device=device), torch.zeros(N, device=device)
+    k = [0]
+
+    def warm():
+        ops.linear_bwd_weight(d, sets[0][0], sets[0][1], dw, db)
+
+    def cold():
+        g, x = sets[k[0] % nsets]
+        k[0] += 1
+        ops.linear_bwd_weight(d, g, x, dw, db)
+    ms_w, ms_c = time_kernel(warm, a.roofline_iters), time_kernel(cold, max(a.roofline_iters, 2 * nsets))
+    return {"kernel": "dW[%d,%d] += dy[%d,%d]^T x[%d,%d] (%s)" % (N, K, M, N, M, K, a.dtype), "algorithmic_bytes": bytes_alg,
+            "warm_us": round(ms_w * 1e3, 2), "warm_frac": round(bytes_alg / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "cold_us": round(ms_c * 1e3, 2), "cold_frac": round(bytes_alg / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def roofline_deepsense(a, step, device):
@@ -290,12 +416,16 @@ def roofline_deepsense(a, step, device):
     gbs = bytes_alg / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "focal_gemm_kernel<conv window> rows=%d K=%d N=%d" % (rows, k * C, C), "achieved": round(gbs, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "measured": "isolated, back-to-back launches (13 MB operands: cache-resident)",
             "ms_per_launch": round(ms, 5), "tflops": round(2.0 * rows * C * k * C / (ms * 1e-3) / 1e12, 1)}
 
 
 def cpu_baseline(a, cfg):
-    """The oracle (CPU restatement of the reference step: "port") timed on this box's host cores, bounded sample."""
-    from oracle.step import OracleTrainer
+    """The oracle (CPU restatement of the reference step: "port") timed on this box's host cores, bounded sample, under the GPU
+    leg's conditions: two DISTINCT views (x and -1.1 x), FFT + fwd x2 + loss + bwd + AdamW.  The reference loop itself cannot travel
+    to the GPU box; profiles/cpu_equivalence.json (tools/probe_reference_cpu.py, build container) records how much slower it is
+    than this port on the same cores -> `reference_ratio_probed`, `reference_equivalent_value`."""
+    from oracle.step import OracleTrainer, fft_realpack
     from oracle.weights import seeded_values, swt_state_spec, deepsense_state_spec, synthetic_time_input
     spec = swt_state_spec(cfg) if a.model == "SW_Transformer" else deepsense_state_spec(cfg)
     state = {}
@@ -313,19 +443,31 @@ def cpu_baseline(a, cfg):
     B = 32
     tr = OracleTrainer(a.model, cfg, state)
     x = synthetic_time_input(cfg, B, 5)
+    x2 = {l: {m: -1.1 * v for m, v in mm.items()} for l, mm in x.items()}
+    one = lambda: tr.step(freq_pair=(fft_realpack(x), fft_realpack(x2)))
     t0 = time.time()
-    tr.step(time_x=x)  # warm-up
+    one()  # warm-up
     warm = time.time() - t0
     t0 = time.time()
     n = 0
     while n < a.cpu_steps and (time.time() - t0) + warm < 25:
-        tr.step(time_x=x)
+        one()
         n += 1
     dt = time.time() - t0
     if n == 0:
         n, dt = 1, warm
-    return {"value": round(B * n / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of batch {B} (fp32, FFT+fwd x2+loss+bwd+AdamW, dropout off) after 1 warm-up"}
+    out = {"value": round(B * n / dt, 2), "unit": "windows/s", "cores": cores, "kind": "port",
+           "sample": f"{n} steps of batch {B} (fp32, two distinct views, FFT + fwd x2 + loss + bwd + AdamW, dropout off) after 1 warm-up"}
+    eq = os.path.join(ROOT, "profiles", "cpu_equivalence.json")
+    if os.path.exists(eq):
+        e = json.load(open(eq))
+        r = e["models"].get(a.model, {}).get("reference_over_oracle")
+        if r:
+            out["reference_ratio_probed"] = r
+            out["reference_equivalent_value"] = round(out["value"] * r, 2)
+            out["reference_ratio_note"] = (f"reference train loop / this port, both timed in the build container on {e['threads']} threads "
+                                           "(profiles/cpu_equivalence.json); the reference's Python cannot travel to the GPU box")
+    return out
 
 
 def main():
@@ -345,6 +487,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
     rank = dist.get_rank() if world > 1 else 0
+    if os.environ.get("FOCAL_ABLATE"):  # timing diagnostic (tools/ablate_shim.py): the JSON line is marked invalid below
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import ablate_shim
+        ablate_shim.install()
     step = Step(a, device)
     if a.roofline_only:
         print(json.dumps(roofline(a, step, device)))
@@ -415,13 +561,14 @@ def main():
         out = {"metric": "pretrain windows/sec (whole node), FOCAL " + a.model, "value": round(wps, 1), "unit": "windows/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": f"{a.model} + FOCAL pretrain step, {a.batch} MOD-shaped 2-modality windows/GPU "
+               "config": {"workload": f"{a.model} + FOCAL pretrain step, {a.batch} {a.dataset}-shaped {len(step.cfg['modality_names'])}-modality windows/GPU "
                                       f"(global batch {a.batch * world}), train mode, DFT + fwd x2 + loss + bwd + AdamW",
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graphed, **({"DIAGNOSTIC_no_dropout": True} if a.no_dropout else {}),
                           **({"DIAGNOSTIC_from_host": True} if a.from_host else {}),
 **({"DIAGNOSTIC_ABLATED_INVALID": os.environ["FOCAL_ABLATE"]} if os.environ.get("FOCAL_ABLATE") else {}),
                           "views": "identity / negation+scaling (x * -1.1) folded into the DFT", "last_loss": round(last_loss, 4)},
-               "model_flops_frac_of_bf16_mfma_peak": round(wps / world * FLOP_PER_WINDOW[a.model] / (MFMA_BF16_PEAK_TF * 1e12), 5),
+               "model_flops_frac_of_bf16_mfma_peak": round(wps / world * flops_per_window(a.model, a.dataset) / (MFMA_BF16_PEAK_TF * 1e12), 5),
+               "flops_per_window": flops_per_window(a.model, a.dataset),
                "roofline": rl, "cpu_baseline": cb}
         print(json.dumps(out))
     if world > 1:

@@ -9,6 +9,7 @@
 // Compute type CT is bf16 (v_mfma_f32_16x16x32_bf16) or f32 (v_mfma_f32_16x16x4_f32, exact fp32 -- the parity mode).
 // The MFMA is issued as D = Bfrag x Afrag so that a lane ends up with 4 consecutive n for one m: 8/16-byte stores.
 #pragma once
+#include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
 
@@ -568,6 +569,24 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
       }
     }
   }
+}
+
+// Launch plan of a weight-gradient GEMM (output [M][N], reduction over `rows` tokens split across workgroups): tile shape and split
+// count.  Shared by the dispatcher (gemm_dispatch.inc: launch_dw) and by focal_linear_bwd_weight_workgroups, which tells a caller
+// how a launch will show up in a profiler trace.
+static inline void focal_dw_plan(int M, int N, long rows, int* bm_out, int* bn_out, int* splits_out) {
+  int bm = M >= 256 ? 256 : (M >= 128 ? 128 : 64);
+  int bn = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+  while (bm * bn > 16384) { if (bm >= bn) bm >>= 1; else bn >>= 1; }
+  if (!getenv("FOCAL_GEMM_DW_WIDE")) bm = bn = 64;
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  static const long target_wg = getenv("FOCAL_DW_WGS") ? atol(getenv("FOCAL_DW_WGS")) : 512;
+  long splits = (target_wg + tiles - 1) / tiles;
+  static const long min_rows = getenv("FOCAL_DW_MIN_ROWS") ? atol(getenv("FOCAL_DW_MIN_ROWS")) : 256;  // reduction rows per workgroup, at least
+  const long max_splits = (rows + min_rows - 1) / min_rows;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  *bm_out = bm; *bn_out = bn; *splits_out = (int)splits;
 }
 
 // Host-side dispatch (gemm_dispatch.inc, instantiated per compute type in gemm_bf16.hip / gemm_f32.hip).

@@ -154,3 +154,10 @@ extern "C" int focal_linear_bwd_weight(const focal_linear_desc* d, const void* d
   p.colsumA = dbias;
   return focal_launch_gemm(s, p, (hipStream_t)stream);
 }
+
+extern "C" int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d) {
+  if (check_desc(d) != FOCAL_OK) return 0;
+  int bm, bn, splits;
+  focal_dw_plan(d->N, d->K, d->M, &bm, &bn, &splits);
+  return ((d->N + bm - 1) / bm) * ((d->K + bn - 1) / bn) * splits;
+}

@@ -20,7 +20,7 @@ constexpr int C = MLP_C, H = MLP_H;
 constexpr int LDS_W1 = 0, LDS_W2 = 32768, LDS_B1 = 65536, LDS_B2 = LDS_B1 + 1024, LDS_G = LDS_B2 + 256, LDS_BT = LDS_G + 256,
               LDS_FWD_BYTES = LDS_BT + 256;
 
-template <bool LN>
+template <bool LN, bool DROP>
 __global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpFwdParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
@@ -59,9 +59,11 @@ __global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpFwdParams p) {
   }
   __syncthreads();
 
-  MaskEval meH, meO;
-  meH.init(p.drop_h);
+  MaskEval meO;
   meO.init(p.drop_o);
+  MlpDropStream ds;
+  ds.init(p.drop_h);
+  const uint32_t ds_key = ds.s;
 
   // fragment addresses inside the images
   const int w1_row = l15 * 128, w1_sw = (l15 >> 1) & 7;           // + tile * 2048; chunk (4 kk + g) ^ w1_sw
@@ -78,12 +80,13 @@ __global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpFwdParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    uint32_t dst = DROP ? ds.start(ds_key, m, g) : 0u;
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {  // 64 hidden units at a time
       f32x4 u[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        u[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u[t] = *reinterpret_cast<const f32x4*>(lds + LDS_B1 + (q * 64 + t * 16 + 4 * g) * 4);  // the accumulator starts at the bias
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const bf16x8 w = *reinterpret_cast<const bf16x8*>(lds + LDS_W1 + (q * 4 + t) * 2048 + w1_row + (((4 * kk + g) ^ w1_sw) << 4));
@@ -93,14 +96,10 @@ __global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpFwdParams p) {
       bf16x8 hf[2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int hcol = q * 64 + t * 16 + 4 * g;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(lds + LDS_B1 + hcol * 4);
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
-          const gelu_f2 x = {u[t][e] + bb[e], u[t][e + 1] + bb[e + 1]};
-          gelu_f2 cdf, pdf;
-          gelu_parts2(x, cdf, pdf);
-          const gelu_f2 hh = x * cdf * meH.elem_mult_pair(m, hcol + e);
+          gelu_f2 hh = mlp_gelu_fwd(gelu_f2{u[t][e], u[t][e + 1]});
+          if (DROP) hh = mlp_mul2(hh, ds.next(dst));
           hf[t >> 1][(t & 1) * 4 + e] = (bf16_t)hh.x;
           hf[t >> 1][(t & 1) * 4 + e + 1] = (bf16_t)hh.y;
         }
@@ -202,20 +201,21 @@ extern "C" int focal_mlp_fwd(const focal_mlp_desc* d, const void* a, const float
   p.drop_h = mlp_mask(d->drop_hidden, MLP_H);
   p.drop_o = mlp_mask(d->drop_out, MLP_C);
   p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.y_ln = reinterpret_cast<bf16_t*>(y_ln); p.ln_stats = ln_stats; p.ln_eps = d->ln_eps;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD_BYTES);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD_BYTES);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
+  const bool drop = d->drop_hidden.p_elem > 0.f;
+  void (*kern)(const MlpFwdParams) = ln ? (drop ? mlp_fwd_kernel<true, true> : mlp_fwd_kernel<true, false>)
+                                        : (drop ? mlp_fwd_kernel<false, true> : mlp_fwd_kernel<false, false>);
+  static bool attr_set[4] = {false, false, false, false};
+  const int ki = (ln ? 2 : 0) + (drop ? 1 : 0);
+  if (!attr_set[ki]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD_BYTES) != hipSuccess) {
       focal_set_error("mlp_fwd: cannot reserve %d bytes of LDS", LDS_FWD_BYTES);
       return FOCAL_EHIP;
     }
-    attr_set = true;
+    attr_set[ki] = true;
   }
   const int nwg = (d->M + 127) / 128;
   const int grid = nwg < 512 ? nwg : 512;  // two 8-wave workgroups per CU, persistent over 16-row wave tiles
-  if (ln) hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(512), LDS_FWD_BYTES, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(512), LDS_FWD_BYTES, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_FWD_BYTES, (hipStream_t)stream, p);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -33,3 +33,111 @@ struct MlpBwdParams {
 };
 
 int mlp_check_desc(const focal_mlp_desc* d, const char* who);
+
+#if defined(__HIPCC__)
+// ---------------------------------------------------------------------------------------------- element math of the fused kernels
+// Both kernels are VALU-bound (the matrix cores sit idle ~85 % of the time: ~10 vector instructions per hidden element is the floor
+// for bias + erf-GELU + dropout + bf16 packing against 1/16 MFMA per element), so the element math is written for instruction
+// count: erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7) in the one-sided form
+//   gelu(x) = max(x, 0) - |x| hp(|x|),   hp(a) = 0.5 poly(t) exp(-a^2 / 2),  t = 1 / (1 + 0.3275911 a / sqrt 2)
+// (no copysign, no 0.5 + 0.5 erf), exp as a bare v_exp_f32 (base 2, the log2 e folded into the argument), everything else packed
+// fp32 (two elements per instruction).
+// Packed fp32 (v_pk_fma_f32 ...: two elements per instruction) vs scalar element math: measured equal on these kernels (same-box A/B of
+// two builds, profiles/r2_mlp_ab.txt: forward 77.7 vs 79.2 us, backward 182 vs 186 us at the stage-0 audio shape) -- a packed
+// instruction occupies the vector pipe about as long as the two scalar ones it replaces.  MLP_PK = 0 selects the scalar form.
+#ifndef MLP_PK
+#define MLP_PK 1
+#endif
+#if MLP_PK
+typedef gelu_f2 mlp_v;
+__device__ __forceinline__ mlp_v mlp_abs(mlp_v x) { return mlp_v{fabsf(x.x), fabsf(x.y)}; }
+__device__ __forceinline__ mlp_v mlp_rcp(mlp_v x) { return mlp_v{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+__device__ __forceinline__ mlp_v mlp_exp2(mlp_v x) { return mlp_v{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+__device__ __forceinline__ mlp_v mlp_relu(mlp_v x) { return mlp_v{fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)}; }
+__device__ __forceinline__ mlp_v mlp_copysign(mlp_v m, mlp_v s) { return mlp_v{copysignf(m.x, s.x), copysignf(m.y, s.y)}; }
+#else
+typedef float mlp_v;
+__device__ __forceinline__ mlp_v mlp_abs(mlp_v x) { return fabsf(x); }
+__device__ __forceinline__ mlp_v mlp_rcp(mlp_v x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ mlp_v mlp_exp2(mlp_v x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ mlp_v mlp_relu(mlp_v x) { return fmaxf(x, 0.f); }
+__device__ __forceinline__ mlp_v mlp_copysign(mlp_v m, mlp_v s) { return copysignf(m, s); }
+#endif
+struct MlpGelu {
+  mlp_v e, poly, ax;  // exp(-x^2/2), 0.5 poly(t), |x|
+};
+__device__ __forceinline__ MlpGelu mlp_gelu_core(mlp_v x) {
+  MlpGelu r;
+  r.ax = mlp_abs(x);
+  const mlp_v d = r.ax * (0.3275911f * 0.70710678118654752f) + 1.0f;
+  const mlp_v t = mlp_rcp(d);
+  const mlp_v a2 = (x * -0.72134752044448170f) * x;  // -x^2 / 2 * log2(e)
+  r.e = mlp_exp2(a2);
+  r.poly = t * (t * (t * (t * (t * (0.5f * 1.061405429f) - (0.5f * 1.453152027f)) + (0.5f * 1.421413741f)) - (0.5f * 0.284496736f)) + (0.5f * 0.254829592f));
+  return r;
+}
+__device__ __forceinline__ mlp_v mlp_gelu_fwd1(mlp_v x) {
+  const MlpGelu c = mlp_gelu_core(x);
+  return mlp_relu(x) - c.poly * c.e * c.ax;
+}
+// value and derivative: cdf = 0.5 + copysign(0.5 - hp, x), h = x cdf, h' = cdf + x pdf
+__device__ __forceinline__ void mlp_gelu_bwd1(mlp_v x, mlp_v& h, mlp_v& hg) {
+  const MlpGelu c = mlp_gelu_core(x);
+  const mlp_v om = c.poly * c.e * -1.0f + 0.5f;
+  const mlp_v cdf = mlp_copysign(om, x) + 0.5f;
+  h = x * cdf;
+  hg = x * (c.e * 0.39894228040143268f) + cdf;
+}
+__device__ __forceinline__ gelu_f2 mlp_mul2(gelu_f2 a, gelu_f2 b) {
+#if MLP_PK
+  return a * b;
+#else
+  return gelu_f2{a.x * b.x, a.y * b.y};
+#endif
+}
+// two neighbouring elements (the granularity of the dropout stream and of the bf16 packing)
+__device__ __forceinline__ gelu_f2 mlp_gelu_fwd(gelu_f2 x) {
+#if MLP_PK
+  return mlp_gelu_fwd1(x);
+#else
+  return gelu_f2{mlp_gelu_fwd1(x.x), mlp_gelu_fwd1(x.y)};
+#endif
+}
+__device__ __forceinline__ void mlp_gelu_bwd(gelu_f2 x, gelu_f2& h, gelu_f2& hg) {
+#if MLP_PK
+  mlp_gelu_bwd1(x, h, hg);
+#else
+  float h0, g0, h1, g1;
+  mlp_gelu_bwd1(x.x, h0, g0);
+  mlp_gelu_bwd1(x.y, h1, g1);
+  h = gelu_f2{h0, h1};
+  hg = gelu_f2{g0, g1};
+#endif
+}
+
+// Dropout on the hidden activation inside the fused kernels: a lane owns, for its token row m and its lane group g, the hidden units
+// {16 T + 4 g .. + 3 : T = 0..15}, i.e. 32 element pairs that BOTH kernels visit in ascending T.  One full hash per (row, group)
+// seeds a xorshift32 stream; every pair takes one step (6 full-rate instructions against a 2-multiply hash per pair) and uses the two
+// 16-bit halves of the state against a 16-bit threshold, exactly like the GEMM epilogue's pair hash.  The mask is a pure function of
+// (seed word, stream id, row, hidden unit): the backward kernel regenerates it.
+struct MlpDropStream {
+  uint32_t s, t16;
+  float scale;
+  __device__ __forceinline__ void init(const MaskParams& mp) {
+    const DropCtx c = make_drop(mp.seed, mp.stream_elem, mp.p_elem);
+    s = c.key;  // re-seeded per row by start()
+    t16 = c.thresh >> 8;
+    scale = c.scale;
+  }
+  __device__ __forceinline__ uint32_t start(uint32_t key, int row, int group) const {
+    const uint32_t v = focal_mix32((((uint32_t)row << 2) | (uint32_t)group) ^ key);
+    return v ? v : 0x9E3779B9u;
+  }
+  __device__ __forceinline__ gelu_f2 next(uint32_t& st) const {
+    st ^= st << 13;
+    st ^= st >> 17;
+    st ^= st << 5;
+    return gelu_f2{(st & 0xffffu) < t16 ? 0.0f : scale, (st >> 16) < t16 ? 0.0f : scale};
+  }
+};
+#endif

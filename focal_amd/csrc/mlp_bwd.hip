@@ -51,7 +51,8 @@ __device__ __forceinline__ int a_w1(int h, int c) { return L_W1 + (c >> 5) * 163
 __device__ __forceinline__ int a_w2(int c, int h) { return L_W2 + (h >> 4) * 2048 + rowp(c) * 32 + (h & 15) * 2; }
 __device__ __forceinline__ int a_tile(int base, int row, int col) { return base + row * 128 + ((((col >> 3)) ^ sw_tile(row)) << 4) + (col & 7) * 2; }
 
-__device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
+// (an element-wise bf16x8{lo[0], .., hi[3]} makes hipcc unpack and re-pack every 16-bit element: ~700 vector instructions per tile)
+__device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 __device__ __forceinline__ bf16x4 tr_read(const char* lds, int addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr_ptr)(lds + addr)); }
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would expose the full HBM latency of the
 // next tile's prefetch at the first barrier behind it
@@ -63,6 +64,7 @@ __device__ __forceinline__ float sum8(bf16x8 v) {
   return s;
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(const MlpBwdParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
@@ -88,8 +90,9 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(const MlpBwdParams p) {
     if (tid < H) reinterpret_cast<float*>(lds + L_B1)[tid] = p.b1[tid];
   }
 
-  MaskEval meH;
-  meH.init(p.drop_h);
+  MlpDropStream ds;
+  ds.init(p.drop_h);
+  const uint32_t ds_key = ds.s;
 
   // ---- per-lane address bases (everything else is a compile-time offset)
   const int mloc = wave * 16 + l15;                                                    // this lane's token inside a tile (phase A)
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(const MlpBwdParams p) {
     if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
 
     const int m = tile * BM + mloc;
+    uint32_t dst = DROP ? ds.start(ds_key, m, g) : 0u;
     bf16x8 xa[2], xg[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -158,13 +162,14 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(const MlpBwdParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) dc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto phase_a = [&](int q) {  // hidden units 32 q .. 32 q + 31
-      const int buf = (q & 1) * 16384;
-      bf16x8 duf;
+    // Phase A in two parts so that the matrix products of the next chunk can be issued BEFORE phase B of the current one and the
+    // vector work (GELU, masks, packing) after it: an in-order wave only overlaps MFMA with VALU when they alternate in program order.
+    f32x4 ua[2], dha[2];
+    auto phase_a1 = [&](int q) {  // u = a2 W1c^T + b1c, dh = gm W2c for hidden units 32 q .. 32 q + 31
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int ht = 2 * q + t;  // hidden tile (16 units)
-        f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f}, dh = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 u = *reinterpret_cast<const f32x4*>(lds + b_b1 + ht * 64), dh = f32x4{0.f, 0.f, 0.f, 0.f};  // u starts at the bias
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const bf16x8 w1f = *reinterpret_cast<const bf16x8*>(lds + b_w1d + kk * 16384 + ht * 1024);
@@ -173,24 +178,35 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(const MlpBwdParams p) {
           const bf16x8 w2f = join(tr_read(lds, b_w2_lo + ht * 2048 + kk * 1024), tr_read(lds, b_w2_hi + ht * 2048 + kk * 1024));
           dh = mma16(w2f, xg[kk], dh);
         }
-        const int hcol = 16 * ht + 4 * g;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(lds + b_b1 + ht * 64);
+        ua[t] = u;
+        dha[t] = dh;
+      }
+    };
+    auto phase_a2 = [&](int q) {  // h, h', du; du -> da2; h, du -> LDS
+      const int buf = (q & 1) * 16384;
+      bf16x4 dqs[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 u = ua[t], dh = dha[t];
         bf16x4 hq, dq;
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
-          const gelu_f2 x = {u[e] + bb[e], u[e + 1] + bb[e + 1]};
-          gelu_f2 cdf, pdf;
-          gelu_parts2(x, cdf, pdf);
-          const gelu_f2 mult = meH.elem_mult_pair(m, hcol + e);
-          const gelu_f2 hh = x * cdf * mult, gg = (x * pdf + cdf) * mult;
-          const gelu_f2 dd = gelu_f2{dh[e], dh[e + 1]} * gg;
+          gelu_f2 hh, gg;
+          mlp_gelu_bwd(gelu_f2{u[e], u[e + 1]}, hh, gg);
+          if (DROP) {
+            const gelu_f2 mult = ds.next(dst);
+            hh = mlp_mul2(hh, mult);
+            gg = mlp_mul2(gg, mult);
+          }
+          const gelu_f2 dd = mlp_mul2(gelu_f2{dh[e], dh[e + 1]}, gg);
           hq[e] = (bf16_t)hh.x; hq[e + 1] = (bf16_t)hh.y;
           dq[e] = (bf16_t)dd.x; dq[e + 1] = (bf16_t)dd.y;
         }
         *reinterpret_cast<bf16x4*>(lds + b_hw + buf + t * 4096) = hq;
         *reinterpret_cast<bf16x4*>(lds + b_hw + buf + 8192 + t * 4096) = dq;
-        duf[4 * t] = dq[0]; duf[4 * t + 1] = dq[1]; duf[4 * t + 2] = dq[2]; duf[4 * t + 3] = dq[3];
+        dqs[t] = dq;
       }
+      const bf16x8 duf = join(dqs[0], dqs[1]);
       // da2 += du W1c: contraction slots (g, e) <-> hidden 32 q + 16 (e >> 2) + 4 g + (e & 3), the order du sits in registers
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -200,35 +216,64 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(const MlpBwdParams p) {
       }
     };
 
+    // Phase B is the SAME instruction stream for all eight waves (a branch would cut the scheduling region and with it any MFMA /
+    // VALU interleaving): D[c][h'] = sum_m Cside[m][c] Hside[m][h'] with (Cside, Hside) = (gm, h) for waves 0-3 -> dW2[c][h'] and
+    // (a2, du) for waves 4-7 -> dW1[h'][c] transposed; only the per-lane base addresses differ.
     auto phase_b = [&](int q) {
       const int buf = (q & 1) * 16384;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 fc = join(tr_read(lds, b_tr + ks * 4096), tr_read(lds, b_tr + ks * 4096 + 512));
-        bf16x8 fh[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) fh[t] = join(tr_read(lds, b_hb_lo + buf + t * 4096 + ks * 1024), tr_read(lds, b_hb_hi + buf + t * 4096 + ks * 1024));
-        if (c_side_first) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) acc[2 * q + t] = mma16(fc, fh[t], acc[2 * q + t]);   // dW2[c][h]
-          if (q == 0) dbc += sum8(fc);
-        } else {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) acc[2 * q + t] = mma16(fh[t], fc, acc[2 * q + t]);   // dW1[h][c]
-          if (ks == cw) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) dbh[2 * q + t] += sum8(fh[t]);
-          }
+        for (int t = 0; t < 2; ++t) {
+          const bf16x8 fh = join(tr_read(lds, b_hb_lo + buf + t * 4096 + ks * 1024), tr_read(lds, b_hb_hi + buf + t * 4096 + ks * 1024));
+          acc[2 * q + t] = mma16(fc, fh, acc[2 * q + t]);
         }
       }
     };
+    // bias gradients (the only wave-dependent code, kept behind the interval's matrix work): db2 = column sums of gm (waves 0-3, once
+    // per tile), db1 = column sums of du (waves 4-7: wave 4 + cw takes the 32 tokens of k-step cw); the fragments are re-read
+    auto phase_db = [&](int q) {
+      const int buf = (q & 1) * 16384;
+      if (c_side_first) {
+        if (q == 0) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) dbc += sum8(join(tr_read(lds, b_tr + ks * 4096), tr_read(lds, b_tr + ks * 4096 + 512)));
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          dbh[2 * q + t] += sum8(join(tr_read(lds, b_hb_lo + buf + t * 4096 + cw * 1024), tr_read(lds, b_hb_hi + buf + t * 4096 + cw * 1024)));
+      }
+    };
 
-    phase_a(0);
+#ifndef MLP_SCHED
+#define MLP_SCHED 1
+#endif
+    phase_a1(0);
+    phase_a2(0);
     lds_barrier();
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
+#if MLP_SCHED == 0
       phase_b(q);
-      if (q < 7) phase_a(q + 1);
+      if (q < 7) { phase_a1(q + 1); phase_a2(q + 1); }
+      phase_db(q);
+#else
+      if (q < 7) phase_a1(q + 1);
+      phase_b(q);
+      if (q < 7) phase_a2(q + 1);
+#if MLP_SCHED == 2
+      // ask for an alternating issue order inside this barrier interval: one matrix instruction, then a run of vector instructions
+#pragma unroll
+      for (int i = 0; i < 20; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      phase_db(q);
+#endif
       lds_barrier();
     }
 
@@ -246,8 +291,8 @@ __global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(const MlpBwdParams p) {
   for (int ht = 0; ht < 16; ++ht) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (c_side_first) F2[(16 * cw + 4 * g + r) * H + 16 * ht + l15] = acc[ht][r];
-      else F1[(16 * ht + 4 * g + r) * C + 16 * cw + l15] = acc[ht][r];
+      if (c_side_first) F2[(16 * cw + 4 * g + r) * H + 16 * ht + l15] = acc[ht][r];   // D[c][h'] -> dW2[c][h']
+      else F1[(16 * ht + l15) * C + 16 * cw + 4 * g + r] = acc[ht][r];                 // D[c][h'] -> dW1[h'][c]
     }
   }
   __syncthreads();
@@ -310,17 +355,19 @@ extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void
   p.da = reinterpret_cast<bf16_t*>(da);
   p.dw1 = dw1; p.db1 = db1; p.dw2 = dw2; p.db2 = db2;
   p.drop_h = mlp_bwd_mask(d->drop_hidden, MLP_H);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD_BYTES) != hipSuccess) {
+  const bool drop = d->drop_hidden.p_elem > 0.f;
+  void (*kern)(const MlpBwdParams) = drop ? mlp_bwd_kernel<true> : mlp_bwd_kernel<false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[drop]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD_BYTES) != hipSuccess) {
       focal_set_error("mlp_bwd: cannot reserve %d bytes of LDS", LDS_BWD_BYTES);
       return FOCAL_EHIP;
     }
-    attr_set = true;
+    attr_set[drop] = true;
   }
   const int ntiles = (d->M + BM - 1) / BM;
   const int grid = ntiles < 256 ? ntiles : 256;  // one persistent 8-wave workgroup per CU
-  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid), dim3(512), LDS_BWD_BYTES, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BWD_BYTES, (hipStream_t)stream, p);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -35,16 +35,6 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-# FOCAL_ABLATE=<name>[,<name>...]: TIMING DIAGNOSTIC ONLY -- the named op families return without launching (their outputs stay
-# uninitialised, results are garbage).  bench.py refuses to print a normal line with it set; tools/scratch/ablate.sh uses it to
-# measure what each family contributes to the graph-replayed step with the real two-stream concurrency (a profiler serialises).
-_ABLATE = frozenset(x for x in os.environ.get("FOCAL_ABLATE", "").split(",") if x)
-
-
-def _ablated(name):
-    return name in _ABLATE
-
-
 # ------------------------------------------------------------------------------------------------ per-step zero pool
 # Many kernels accumulate with atomics into small buffers that must start at zero (BatchNorm channel sums, split weight
 # gradients).  One memset per buffer is one graph node each (~100 per DeepSense step); instead they are slices of ONE fp32
@@ -240,8 +230,7 @@ def layernorm_fwd(x, gamma, beta, out_dtype, gather=None, desc=None):
     d = desc or ln_desc(code(out_dtype), rows, Cc, gather=gather)
     y = torch.empty(rows, Cc, dtype=out_dtype, device=x.device)
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
-    if not _ablated("layernorm_fwd"):
-        check(_lib.load().focal_layernorm_fwd(C.byref(d), _p(x), _p(gamma), _p(beta), _p(y), _p(stats), _stream()))
+    check(_lib.load().focal_layernorm_fwd(C.byref(d), _p(x), _p(gamma), _p(beta), _p(y), _p(stats), _stream()))
     return y, stats
 
 
@@ -254,8 +243,6 @@ def layernorm_bwd(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=Non
     if dx_masked is not None:
         assert dx_masked.dtype == dy.dtype and dx_masked.numel() == dx.numel()
         mask = mask or NO_DROP
-    if _ablated("layernorm_bwd"):
-        return
     check(_lib.load().focal_layernorm_bwd(C.byref(d), _p(dy), _p(x), _p(stats), _p(gamma), _p(dx), int(accumulate),
                                           _p(dgamma), _p(dbeta), _p(dx_masked), C.byref(mask) if mask is not None else None,
                                           _stream()))
@@ -276,8 +263,6 @@ def linear_desc(dtype_code, M, N, K, x_dtype, y_dtype, act_in=ACT_NONE, epilogue
 
 
 def linear_fwd(d, x, w, bias, resid, y, act_grad=None):
-    if _ablated("linear_fwd"):
-        return
     check(_lib.load().focal_linear_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(resid), _p(y), _p(act_grad), _stream()))
 
 
@@ -292,14 +277,10 @@ def linear_resid_ln_fwd(d, x, w, bias, resid, y, gamma, beta, out_dtype, eps=1e-
 
 
 def linear_bwd_data(d, dy, w, x, dx):
-    if _ablated("linear_bwd_data"):
-        return
     check(_lib.load().focal_linear_bwd_data(C.byref(d), _p(dy), _p(w), _p(x), _p(dx), _stream()))
 
 
 def linear_bwd_weight(d, dy, x, dw, dbias):
-    if _ablated("linear_bwd_weight"):
-        return
     check(_lib.load().focal_linear_bwd_weight(C.byref(d), _p(dy), _p(x), _p(dw), _p(dbias), _stream()))
 
 
@@ -330,14 +311,12 @@ def mlp_fwd(d, a, resid, w1, b1, w2, b2, y, next_ln=None):
     (LayerNorm(y) in a's dtype, stats) of the LayerNorm that reads y next."""
     _need_cuda(a, resid, w1, b1, w2, b2, y)
     if next_ln is None:
-        if not _ablated("mlp_fwd"):
-            check(_lib.load().focal_mlp_fwd(C.byref(d), _p(a), _p(resid), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), None, None, None, None,
+        check(_lib.load().focal_mlp_fwd(C.byref(d), _p(a), _p(resid), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), None, None, None, None,
                                             _stream()))
         return None
     y_ln = torch.empty(d.M, d.C, dtype=a.dtype, device=a.device)
     stats = torch.empty(d.M, 2, dtype=torch.float32, device=a.device)
-    if not _ablated("mlp_fwd"):
-        check(_lib.load().focal_mlp_fwd(C.byref(d), _p(a), _p(resid), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(next_ln[0]),
+    check(_lib.load().focal_mlp_fwd(C.byref(d), _p(a), _p(resid), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(next_ln[0]),
                                         _p(next_ln[1]), _p(y_ln), _p(stats), _stream()))
     return y_ln, stats
 
@@ -346,8 +325,6 @@ def mlp_bwd(d, gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, ln=None):
     """focal_mlp_bwd.  ln = dict(x=, stats=, gamma=, g=, gm_next=, next_mask=, dgamma=, dbeta=) fuses the norm2 backward behind it
     (da is then not written)."""
     _need_cuda(gm, a, w1, b1, w2, da, dw1, db1, dw2, db2)
-    if _ablated("mlp_bwd"):
-        return
     if ln is None:
         check(_lib.load().focal_mlp_bwd(C.byref(d), _p(gm), _p(a), _p(w1), _p(b1), _p(w2), _p(da), _p(dw1), _p(db1), _p(dw2), _p(db2),
                                         None, None, None, None, None, None, None, None, _stream()))
@@ -364,14 +341,10 @@ def attn_desc(dtype_code, B, H, W, Cc, heads, wh, ww, sh, sw, p_attn=0.0, rng=No
 
 
 def window_attn_fwd(d, qkv, bias_table, out):
-    if _ablated("window_attn_fwd"):
-        return
     check(_lib.load().focal_window_attn_fwd(C.byref(d), _p(qkv), _p(bias_table), _p(out), _stream()))
 
 
 def window_attn_bwd(d, qkv, bias_table, dout, dqkv, dbias_table):
-    if _ablated("window_attn_bwd"):
-        return
     check(_lib.load().focal_window_attn_bwd(C.byref(d), _p(qkv), _p(bias_table), _p(dout), _p(dqkv), _p(dbias_table),
                                             _stream()))
 
@@ -451,21 +424,15 @@ def conv_pack_bwd(d, w, dtype):
 
 def conv_fwd(d, x, w_fwd, bias):
     z = torch.empty(d.rows, d.C_out, dtype=torch.float32, device=x.device)
-    if _ablated("conv_fwd"):
-        return z
     check(_lib.load().focal_conv_fwd(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(z), _stream()))
     return z
 
 
 def conv_bwd_data(d, dz, w_bwd, g_in, g_out):
-    if _ablated("conv_bwd_data"):
-        return
     check(_lib.load().focal_conv_bwd_data(C.byref(d), _p(dz), _p(w_bwd), _p(g_in), _p(g_out), _stream()))
 
 
 def conv_bwd_weight(d, dz, x, dw_packed, dbias):
-    if _ablated("conv_bwd_weight"):
-        return
     check(_lib.load().focal_conv_bwd_weight(C.byref(d), _p(dz), _p(x), _p(dw_packed), _p(dbias), _stream()))
 
 
@@ -487,8 +454,6 @@ def bn_stats(d, z, running_mean, running_var, training, sync=False):
     if scratch is None:
         scratch = torch.empty(2 * d.C + 1, dtype=torch.float32, device=dev)
     mean_rstd = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
-    if _ablated("bn_stats"):
-        return mean_rstd
     lib = _lib.load()
     args = (_p(z), _p(scratch), _p(mean_rstd), _p(running_mean), _p(running_var))
     world = _sync_world() if (sync and training) else 1
@@ -506,8 +471,6 @@ def bn_stats(d, z, running_mean, running_var, training, sync=False):
 def bn_act_fwd(d, z, mean_rstd, gamma, beta, resid, cast_dtype=None):
     y = torch.empty_like(z)
     ya = torch.empty(z.shape, dtype=cast_dtype, device=z.device) if cast_dtype not in (None, torch.float32) else None
-    if _ablated("bn_act_fwd"):
-        return y, (ya if ya is not None else y)
     check(_lib.load().focal_bn_act_fwd(C.byref(d), _p(z), _p(mean_rstd), _p(gamma), _p(beta), _p(resid), _p(y), _p(ya), _stream()))
     return y, (ya if ya is not None else y)
 
@@ -518,8 +481,6 @@ def bn_act_bwd(d, z, g, mean_rstd, gamma, beta, dgamma, dbeta, out_dtype, sync=F
     if scratch is None:
         scratch = torch.empty(2 * d.C + 1, dtype=torch.float32, device=z.device)
     dz = torch.empty(z.shape, dtype=out_dtype, device=z.device)
-    if _ablated("bn_act_bwd"):
-        return dz
     lib = _lib.load()
     args = (_p(z), _p(g), _p(mean_rstd), _p(gamma), _p(beta), _p(scratch), _p(dz), _p(dgamma), _p(dbeta))
     world = _sync_world() if sync else 1
@@ -549,14 +510,10 @@ def _parr(tensors):
 
 def gru_seq_fwd(d, gi, whh, bhh, hs, save, out):
     """Whole-sequence GRU layer, one launch for len(gi) directions (lists of per-direction tensors)."""
-    if _ablated("gru_seq_fwd"):
-        return
     check(_lib.load().focal_gru_seq_fwd(C.byref(d), len(gi), _parr(gi), _parr(whh), _parr(bhh), _parr(hs), _parr(save), _p(out), _stream()))
 
 
 def gru_seq_bwd(d, dout, ld_b, ld_t, scale, whh_t, hs, save, dgi, dgh):
-    if _ablated("gru_seq_bwd"):
-        return
     check(_lib.load().focal_gru_seq_bwd(C.byref(d), len(hs), _p(dout), ld_b, ld_t, scale, _parr(whh_t), _parr(hs), _parr(save), _parr(dgi),
                                         _parr(dgh), _stream()))
 

@@ -147,6 +147,9 @@ int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy, const void
                           void* stream);
 int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const void* x, float* dw, float* dbias,
                             void* stream);
+/* Number of workgroups focal_linear_bwd_weight launches for this descriptor (output tiles x token splits): lets a caller match its
+ * calls against the launch shapes of a profiler trace (bench.py's in-step roofline).  0 = invalid descriptor. */
+int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d);
 
 /* Fused MLP branch of a Swin block (models/SwinModules.py:18-34 Mlp.forward + the residual / DropPath of :339-341), bf16,
  * C = 64 -> hidden = 256 -> C (Swin stage 0, where 2/3 of the model's hidden-activation bytes are; focal_mlp_supported says

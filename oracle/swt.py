@@ -9,6 +9,17 @@ import torch.nn.functional as F
 
 from .config import block_window_and_shift, swt_geometry
 
+# bf16 operand emulation (SURVEY appendix D's method): with `emulate_bf16` the functions below round, in fp32 arithmetic, exactly
+# the tensors that the MI355X bf16 path stores or feeds to the matrix cores as bf16 -- linear-layer weights, LayerNorm outputs, qkv,
+# the attention probabilities and output, the GELU output, the fp32 activations entering mod_in / the projector -- and nothing else
+# (residual stream, statistics, softmax, biases, patch embedding stay fp32).  The HIP bf16 path must agree with THIS to a few 1e-3;
+# what separates either from the fp32 reference is operand rounding, not arithmetic.
+_EMULATE = [False]
+
+
+def _r(t):
+    return t.bfloat16().to(t.dtype) if _EMULATE[0] else t
+
 
 def relative_position_index(wh, ww):
     """[wh*ww, wh*ww] int64 index into the (2wh-1)(2ww-1) bias table.  models/SwinModules.py:101-111."""
@@ -50,7 +61,7 @@ def window_attention(P, pre, xw, heads, wh, ww, mask):
     """WindowAttention.forward, SwinModules.py:121-152 (dropouts are identity)."""
     Bw, N, C = xw.shape
     hd = C // heads
-    qkv = F.linear(xw, P[f"{pre}.qkv.weight"], P[f"{pre}.qkv.bias"]).view(Bw, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    qkv = _r(F.linear(xw, _r(P[f"{pre}.qkv.weight"]), P[f"{pre}.qkv.bias"])).view(Bw, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
     attn = q @ k.transpose(-2, -1)
     table = P[f"{pre}.relative_position_bias_table"]
@@ -59,16 +70,16 @@ def window_attention(P, pre, xw, heads, wh, ww, mask):
     if mask is not None:
         nW = mask.shape[0]
         attn = (attn.view(Bw // nW, nW, heads, N, N) + mask.to(attn.dtype)[None, :, None]).view(-1, heads, N, N)
-    attn = attn.softmax(-1)
-    out = (attn @ v).transpose(1, 2).reshape(Bw, N, C)
-    return F.linear(out, P[f"{pre}.proj.weight"], P[f"{pre}.proj.bias"])
+    attn = _r(attn.softmax(-1))
+    out = _r((attn @ v).transpose(1, 2).reshape(Bw, N, C))
+    return F.linear(out, _r(P[f"{pre}.proj.weight"]), P[f"{pre}.proj.bias"])
 
 
 def swin_block(P, pre, x, H, W, heads, window, block_idx, taps=None):
     """SwinTransformerBlock.forward, SwinModules.py:294-343."""
     B, L, C = x.shape
     wh, ww, sh, sw, shifted = block_window_and_shift(H, W, window, block_idx)
-    y = F.layer_norm(x, (C,), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], 1e-5).view(B, H, W, C)
+    y = _r(F.layer_norm(x, (C,), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], 1e-5)).view(B, H, W, C)
     mask = None
     if shifted:
         y = torch.roll(y, shifts=(-sh, -sw), dims=(1, 2))
@@ -78,10 +89,10 @@ def swin_block(P, pre, x, H, W, heads, window, block_idx, taps=None):
     if shifted:
         y = torch.roll(y, shifts=(sh, sw), dims=(1, 2))
     x = x + y.reshape(B, L, C)
-    z = F.layer_norm(x, (C,), P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], 1e-5)
-    z = F.linear(z, P[f"{pre}.mlp.fc1.weight"], P[f"{pre}.mlp.fc1.bias"])
-    z = F.gelu(z)  # exact erf form, SwinModules.py:19
-    z = F.linear(z, P[f"{pre}.mlp.fc2.weight"], P[f"{pre}.mlp.fc2.bias"])
+    z = _r(F.layer_norm(x, (C,), P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], 1e-5))
+    z = F.linear(z, _r(P[f"{pre}.mlp.fc1.weight"]), P[f"{pre}.mlp.fc1.bias"])
+    z = _r(F.gelu(z))  # exact erf form, SwinModules.py:19
+    z = F.linear(z, _r(P[f"{pre}.mlp.fc2.weight"]), P[f"{pre}.mlp.fc2.bias"])
     return x + z
 
 
@@ -90,8 +101,8 @@ def patch_merging(P, pre, x, H, W):
     B, L, C = x.shape
     x = x.view(B, H, W, C)
     x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).view(B, -1, 4 * C)
-    x = F.layer_norm(x, (4 * C,), P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-5)
-    return F.linear(x, P[f"{pre}.reduction.weight"])
+    x = _r(F.layer_norm(x, (4 * C,), P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-5))
+    return F.linear(x, _r(P[f"{pre}.reduction.weight"]))
 
 
 def pad_and_embed(P, cfg, x, loc, mod):
@@ -108,12 +119,18 @@ def pad_and_embed(P, cfg, x, loc, mod):
     return F.layer_norm(x, (c0,), P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-5)
 
 
-def swt_forward(P, cfg, freq_x, proj_head=True, taps=None):
+def swt_forward(P, cfg, freq_x, proj_head=True, taps=None, emulate_bf16=False):
     """SW_Transformer.forward(freq_x, class_head=False, proj_head=...), SW_Transformer.py:210-304.
 
     Returns {mod: [B, emb]} in `modality_names` order.  `taps`, if a dict, receives intermediate activations
     keyed by "<loc>.<mod>.<stage point>" for layer-by-layer parity checks.
     """
+    if emulate_bf16 != _EMULATE[0]:
+        _EMULATE[0] = emulate_bf16
+        try:
+            return swt_forward(P, cfg, freq_x, proj_head, taps, emulate_bf16)
+        finally:
+            _EMULATE[0] = not emulate_bf16
     sw = cfg["SW_Transformer"]
     assert len(cfg["location_names"]) == 1
     loc = cfg["location_names"][0]
@@ -135,7 +152,7 @@ def swt_forward(P, cfg, freq_x, proj_head=True, taps=None):
                 x = patch_merging(P, f"freq_interval_layers.{loc}.{mod}.{si}.downsample", x, st["H"], st["W"])
                 if taps is not None:
                     taps[f"{loc}.{mod}.merge{si}"] = x
-        x = F.linear(x.reshape(x.shape[0], -1), P[f"mod_in_layers.{loc}.{mod}.weight"], P[f"mod_in_layers.{loc}.{mod}.bias"])
+        x = F.linear(_r(x.reshape(x.shape[0], -1)), _r(P[f"mod_in_layers.{loc}.{mod}.weight"]), P[f"mod_in_layers.{loc}.{mod}.bias"])
         if taps is not None:
             taps[f"{loc}.{mod}.feat"] = x
         feats[mod] = x
@@ -143,6 +160,6 @@ def swt_forward(P, cfg, freq_x, proj_head=True, taps=None):
         return feats
     out = {}
     for mod in cfg["modality_names"]:
-        h = F.relu(F.linear(feats[mod], P[f"mod_projectors.{mod}.0.weight"], P[f"mod_projectors.{mod}.0.bias"]))
-        out[mod] = F.linear(h, P[f"mod_projectors.{mod}.2.weight"], P[f"mod_projectors.{mod}.2.bias"])
+        h = F.relu(F.linear(_r(feats[mod]), _r(P[f"mod_projectors.{mod}.0.weight"]), P[f"mod_projectors.{mod}.0.bias"]))
+        out[mod] = F.linear(_r(h), _r(P[f"mod_projectors.{mod}.2.weight"]), P[f"mod_projectors.{mod}.2.bias"])
     return out

