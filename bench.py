@@ -332,6 +332,10 @@ def roofline(a, step, device):
     tr = StepTracer(ops)
     tr.install()
     n_steps = 3
+    # One stream for the traced steps: the two modality encoders normally run on two streams, where a launch's event pair also spans
+    # the slow-down from the other stream's kernels (observed +20-45 %); rocprofv3 serialises the streams, and the committed trace
+    # this number must be checkable against was taken that way.  The step's `value` is measured with both streams, of course.
+    os.environ["FOCAL_NO_STREAMS"] = "1"
     try:
         # keep the GPU behind the host: ~15 ms of fills are queued first, so the step's launches (and their events) are consumed
         # back to back and an event pair brackets kernel time, not host launch gaps
@@ -343,6 +347,7 @@ def roofline(a, step, device):
         groups = tr.summary(n_steps)
     finally:
         tr.remove()
+        os.environ.pop("FOCAL_NO_STREAMS", None)
     del pad
     groups.sort(key=lambda g: -g["us_per_step"])
     top = groups[0]
@@ -353,11 +358,14 @@ def roofline(a, step, device):
         ach = top["flops_per_launch"] / (top["avg_us"] * 1e-6) / 1e12
         peak, unit = (MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF), "TFLOP/s"
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r2_pmc_roofline_kernel.json")
-    if os.path.exists(tf):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same eager step (tools/pmc_roofline.sh)
-        traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+    tf = os.path.join(ROOT, "profiles", "r2_pmc_groups.json")
+    if os.path.exists(tf):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same eager step (tools/pmc_step_traffic.sh)
+        gkey = ("dW:" + top["launch_shape"].split()[0]) if top["kernel"].startswith("focal_gemm_kernel<dW") else \
+               ("ln_bwd:all" if top["kernel"].startswith("ln_bwd") else "mlp_bwd:all")
+        traffic = json.load(open(tf))["groups"].get(gkey, {}).get("hbm_bytes_per_launch")
+        traffic = round(traffic) if traffic else None
     out = {"bound": top["bound"], "kernel": f"{top['kernel']} [{top['launch_shape']}]", "achieved": round(ach, 1), "peak": peak, "unit": unit,
-           "frac": round(ach / peak, 4), "traffic": traffic, "measured": "in the step: HIP events around each launch of one eager step, averaged over the group",
+           "frac": round(ach / peak, 4), "traffic": traffic, "measured": "in the step: HIP events around each launch of eager steps (one stream, as rocprofv3 sees them), averaged over the group",
            "calls_per_step": round(top["calls_per_step"], 2), "avg_us": round(top["avg_us"], 2),
            "algorithmic_bytes_per_launch": round(top["bytes_per_launch"]), "flops_per_launch": round(top["flops_per_launch"]),
            "other_groups": [{"kernel": f"{g['kernel']} [{g['launch_shape']}]", "calls_per_step": round(g["calls_per_step"], 2),

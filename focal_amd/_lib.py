@@ -94,6 +94,7 @@ PROTOTYPES = {
     "focal_fft_realpack_fwd": (C.c_int, [C.POINTER(FFTDesc), P, P, P, P]),
     "focal_augment_fft_fwd": (C.c_int, [C.POINTER(FFTDesc), C.POINTER(AugDesc), P, P, P, P]),
     "focal_warp_fwd": (C.c_int, [C.c_int, C.c_int, P, P, P, P, C.c_int, P, P]),
+    "focal_mixup_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "focal_pad_patch_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P]),
     "focal_pad_patch_embed_ln2_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P, P, C.c_float, C.c_int, P, P, P]),
     "focal_layernorm_fwd": (C.c_int, [C.POINTER(LNDesc), P, P, P, P, P, P]),
@@ -138,6 +139,7 @@ PROTOTYPES = {
     "focal_mean_time": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, P]),
     "focal_dropout": (C.c_int, [C.c_long, P, P, P, C.c_uint32, C.c_float, P]),
     "focal_axpy": (C.c_int, [C.c_long, C.c_float, P, P, P]),
+    "focal_mul": (C.c_int, [C.c_long, P, P, P]),
 }
 
 _lib = None

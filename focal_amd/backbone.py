@@ -23,10 +23,21 @@ def is_hot_with_head(name):
     return is_hot(name) or name.startswith(HEAD_PREFIXES)
 
 
+SUPERVISED_DEAD = ("absolute_pos_embed.", "mod_extractors.", "loc_fusion_layers.", "loc_context_layers.", "loc_fusion_layer.", "mod_projectors.")
+
+
+def is_hot_supervised(name):
+    """Supervised training from scratch (train_utils/supervised_train.py: every parameter is handed to the optimizer): everything
+    `backbone(freq_x, class_head=True)` touches gets a gradient -- the patch embedding included (it is frozen only in FOCAL
+    pretraining) -- and the projection heads of the contrastive path do not (torch skips their `grad is None`)."""
+    return not name.startswith(SUPERVISED_DEAD)
+
+
 class HipBackbone(nn.Module):
     def _init_hip(self, args):
         self.compute_dtype = runtime.compute_dtype_from(args)
-        self._hot = is_hot_with_head if (getattr(args, "stage", "pretrain") == "finetune" or getattr(args, "train_mode", "") == "supervised") else is_hot
+        self.supervised = getattr(args, "train_mode", "") == "supervised"
+        self._hot = is_hot_supervised if self.supervised else (is_hot_with_head if getattr(args, "stage", "pretrain") == "finetune" else is_hot)
         self._arena = None
         self._named = None
         self._fwd_calls = 0

@@ -346,6 +346,16 @@ extern "C" int focal_dropout(long n, const float* x, float* y, const uint32_t* r
   return FOCAL_OK;
 }
 
+__global__ __launch_bounds__(256) void mul_kernel(long n, const float* __restrict__ a, float* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] *= a[i];
+}
+extern "C" int focal_mul(long n, const float* a, float* y, void* stream) {
+  FOCAL_CHECK_ARG(a && y && n >= 0, "mul: bad argument");
+  hipLaunchKernelGGL(mul_kernel, dim3(gblocks(n)), dim3(256), 0, (hipStream_t)stream, n, a, y);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
 extern "C" int focal_axpy(long n, float a, const float* x, float* y, void* stream) {
   FOCAL_CHECK_ARG(x && y && n >= 0, "axpy: bad argument");
   hipLaunchKernelGGL(axpy_kernel, dim3(gblocks(n)), dim3(256), 0, (hipStream_t)stream, n, a, x, y);

@@ -64,3 +64,34 @@ extern "C" int focal_warp_fwd(int rows, int L, const float* x, const float* mult
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
+
+// Mixup / CutMix of the supervised `fixed` augmentation pipeline (reference: data_augmenter/MixupAugmenter.py ->
+// input_utils/mixup_utils.py:252-281, mode "random_batch"): ONE permutation of the batch, shared by every (location, modality);
+//   mixup : y[b] = lam x[b] + (1 - lam) x[perm[b]]
+//   cutmix: y[b][:, yl:yh, xl:xh] = x[perm[b]][:, yl:yh, xl:xh], elsewhere y[b] = x[b]     (one box per tensor)
+__global__ __launch_bounds__(256) void mixup_kernel(int B, long per_sample, int I, int S, const float* __restrict__ x, const int* __restrict__ perm,
+                                                    float lam, int cut, int yl, int yh, int xl, int xh, float* __restrict__ y) {
+  const long total = (long)B * per_sample;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int b = e / per_sample;
+    const long r = e - (long)b * per_sample;
+    const float a = x[e], o = x[(long)perm[b] * per_sample + r];
+    if (cut) {
+      const int s = r % S, i = (r / S) % I;
+      y[e] = (i >= yl && i < yh && s >= xl && s < xh) ? o : a;
+    } else {
+      y[e] = lam * a + (1.0f - lam) * o;
+    }
+  }
+}
+
+extern "C" int focal_mixup_fwd(int B, int C_, int I, int S, const float* x, const int* perm, float lam, int cut, int yl, int yh, int xl,
+                               int xh, float* y, void* stream) {
+  FOCAL_CHECK_ARG(B > 0 && C_ > 0 && I > 0 && S > 0 && x && perm && y && x != y, "mixup: bad arguments (in-place is not supported)");
+  const long per = (long)C_ * I * S;
+  long blocks = ((long)B * per + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mixup_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, B, per, I, S, x, perm, lam, cut, yl, yh, xl, xh, y);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}

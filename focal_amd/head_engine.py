@@ -8,7 +8,7 @@ Everything here is fp32 (activations of a few hundred KB); the products run on t
 import torch
 
 from . import ops
-from ._lib import ACT_NONE, EPI_NONE
+from ._lib import ACT_NONE, EPI_GELU, EPI_NONE
 
 
 class ClassifierHead:
@@ -62,8 +62,17 @@ class ClassifierHead:
             h = feats.contiguous()
         sv["h_in"] = h
         if "class_layer.2.weight" in ar.index:
-            raise NotImplementedError("class layer Linear -> GELU -> Linear (pretrained_head != 'linear') is not built: the shipped "
-                                      "configs finetune a linear head")
+            # Linear -> GELU -> Linear (`pretrained_head` != "linear", models/SW_Transformer.py:175-181): the hidden layer on the exact-fp32
+            # GEMM with the GELU epilogue (value and derivative from one launch), the few-column output layer as for the linear head
+            f32 = ops.code(torch.float32)
+            Bn, K = h.shape
+            N = ar.index["class_layer.0.weight"][2][0]
+            d0 = ops.linear_desc(f32, Bn, N, K, f32, f32, ACT_NONE, EPI_GELU)
+            h1, g1 = torch.empty(Bn, N, dtype=torch.float32, device=h.device), torch.empty(Bn, N, dtype=torch.float32, device=h.device)
+            ops.linear_fwd(d0, h, ar.master("class_layer.0.weight"), ar.master("class_layer.0.bias"), None, h1, g1)
+            sv.update(d0=d0, h1=h1, g1=g1)
+            logits = ops.small_linear_fwd(h1, ar.master("class_layer.2.weight"), ar.master("class_layer.2.bias"))
+            return logits, sv
         logits = ops.small_linear_fwd(h, ar.master("class_layer.0.weight"), ar.master("class_layer.0.bias"))
         return logits, sv
 
@@ -79,11 +88,23 @@ class ClassifierHead:
         ar = self.bb.arena()
         if dlogits.dtype != torch.float32 or not dlogits.is_contiguous():
             dlogits = dlogits.float().contiguous()
-        need_dx = self.fusion is not None
-        dh = ops.small_linear_bwd(dlogits, sv["h_in"], ar.master("class_layer.0.weight"), ar.g("class_layer.0.weight"),
-                                  ar.g("class_layer.0.bias"), need_dx)
+        train_encoders = getattr(self.bb, "supervised", False)  # supervised training: the gradient continues into the encoders
+        need_dx = self.fusion is not None or train_encoders
+        if "d0" in sv:
+            dh1 = ops.small_linear_bwd(dlogits, sv["h1"], ar.master("class_layer.2.weight"), ar.g("class_layer.2.weight"),
+                                       ar.g("class_layer.2.bias"), True)
+            ops.mul_(dh1, sv["g1"])  # through the GELU: the derivative saved by the forward epilogue
+            ops.linear_bwd_weight(sv["d0"], dh1, sv["h_in"], ar.g("class_layer.0.weight"), ar.g("class_layer.0.bias"))
+            dh = None
+            if need_dx:
+                dh = torch.empty_like(sv["h_in"])
+                d0b = ops.linear_desc(sv["d0"].dtype, sv["d0"].M, sv["d0"].N, sv["d0"].K, sv["d0"].x_dtype, sv["d0"].y_dtype)
+                ops.linear_bwd_data(d0b, dh1, ar.master("class_layer.0.weight"), None, dh)
+        else:
+            dh = ops.small_linear_bwd(dlogits, sv["h_in"], ar.master("class_layer.0.weight"), ar.g("class_layer.0.weight"),
+                                      ar.g("class_layer.0.bias"), need_dx)
         if self.fusion is None:
-            return None  # the encoders in front are frozen
+            return dh if train_encoders else None  # finetuning: the encoders in front are frozen
         pre, B, M, E = self.fusion, sv["B"], sv["M"], sv["E"]
         do = self._lin_bwd(sv["d_out"], dh, sv["o"], f"{pre}.mha.out_proj.weight", f"{pre}.mha.out_proj.bias")
         dq = torch.empty(B, E, dtype=torch.float32, device=do.device)
@@ -94,10 +115,10 @@ class ClassifierHead:
         dqin = self._proj_bwd(dq, sv["qin"], wq, bq)
         dxn = self._proj_bwd(dkv, sv["xn"], wkv, bkv)
         dxn.view(B, M, E).add_(dqin.view(B, 1, E) / M)  # the query is the mean of the M normalised tokens
-        dx = torch.empty_like(sv["x"])                  # gradient w.r.t. the (frozen) features: not propagated further
+        dx = torch.empty_like(sv["x"])                  # gradient w.r.t. the features (propagated further in supervised training only)
         ops.layernorm_bwd(dxn, sv["x"], sv["st"], ar.master(f"{pre}.norm1.weight"), dx, False,
                           ar.g(f"{pre}.norm1.weight"), ar.g(f"{pre}.norm1.bias"))
-        return None
+        return dx.view(B, M, E) if train_encoders else None
 
     def _proj_bwd(self, dy, x, w, b):
         cc, f32 = ops.code(self.bb.compute_dtype), ops.code(torch.float32)

@@ -192,6 +192,17 @@ def time_warp(x, k0, w):
     return y
 
 
+def mixup(x, perm, lam=1.0, box=None):
+    """focal_mixup_fwd: x fp32 [B, C, I, S], perm int32 [B] (device).  box = (yl, yh, xl, xh) -> CutMix paste, else lam-blend."""
+    _need_cuda(x, perm)
+    B, Cc, I, S = x.shape
+    y = torch.empty_like(x)
+    yl, yh, xl, xh = box if box is not None else (0, 0, 0, 0)
+    check(_lib.load().focal_mixup_fwd(B, Cc, I, S, _p(x), _p(perm), float(lam), int(box is not None), int(yl), int(yh), int(xl), int(xh),
+                                      _p(y), _stream()))
+    return y
+
+
 # ------------------------------------------------------------------------------------------------ row 8
 def pad_patch_embed_ln(x, w, b, gamma, beta, Hp, Wp, pw, eps=1e-5, next_ln=None):
     """next_ln = (gamma2, beta2, out_dtype): also return (LayerNorm(tokens), stats) of the LayerNorm that follows (C0 == 64)."""
@@ -561,6 +572,13 @@ def mean_time(x, B, T, D):
 def dropout(x, rng, stream_id, p):
     y = torch.empty_like(x)
     check(_lib.load().focal_dropout(x.numel(), _p(x), _p(y), _p(rng), stream_id, p, _stream()))
+    return y
+
+
+def mul_(y, a):
+    """y *= a (fp32, element-wise; focal_mul)."""
+    _need_cuda(y, a)
+    check(_lib.load().focal_mul(y.numel(), _p(a), _p(y), _stream()))
     return y
 
 

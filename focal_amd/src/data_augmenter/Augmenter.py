@@ -63,11 +63,46 @@ def _phase_shift(x, cfg):  # PhaseShiftAugmenter.py:39-54: rotate every complex 
     return dict(phase=(random() - 0.5) * 2 * math.pi)
 
 
-def _mixup_unavailable(x, cfg):  # MixupAugmenter mixes samples AND labels (supervised `fixed` pipeline only): not on this path
-    raise NotImplementedError("mixup belongs to the supervised `fixed` augmentation pipeline, which this build does not run")
+def _mixup_in_random_pool(x, cfg):  # MixupAugmenter mixes samples AND labels: it belongs to the supervised `fixed` pipeline
+    raise NotImplementedError("mixup is a `fixed`-pipeline augmenter (supervised training); it is not drawn as a FOCAL view")
 
 
-TIME_AUGMENTERS = {"no": None, "mixup": _mixup_unavailable, "negation": _negation, "scaling": _scaling, "horizontal_flip": _horizontal_flip,
+def draw_mixup(cfg, shapes):
+    """The host draws of one Mixup call in mode "random_batch" (input_utils/mixup_utils.py:154-176 `_params_per_batch`, :252-281
+    `_mix_batch_random`, :32-54 `rand_bbox`), in the reference's order: apply?, cutmix?, lambda, one batch permutation, and for
+    CutMix one box centre per (location, modality) tensor.  shapes = {(loc, mod): (B, C, I, S)} in iteration order.
+    Returns None (no mixing) or dict(lam=, cut=, perm=, boxes={(loc, mod): (yl, yh, xl, xh)})."""
+    if cfg.get("mode", "batch") != "random_batch" or cfg.get("cutmix_minmax") is not None:
+        raise NotImplementedError("Mixup: only mode 'random_batch' without cutmix_minmax (the shipped configuration) is built")
+    if not (np.random.rand() < cfg["prob"]):
+        return None
+    ma, ca = cfg["mixup_alpha"], cfg["cutmix_alpha"]
+    cut = False
+    if ma > 0.0 and ca > 0.0:
+        cut = bool(np.random.rand() < cfg["switch_prob"])
+        lam = np.random.beta(ca, ca) if cut else np.random.beta(ma, ma)
+    elif ma > 0.0:
+        lam = np.random.beta(ma, ma)
+    elif ca > 0.0:
+        cut, lam = True, np.random.beta(ca, ca)
+    else:
+        raise AssertionError("One of mixup_alpha > 0., cutmix_alpha > 0. should be true.")
+    lam = float(lam)
+    if lam == 1:
+        return None
+    B = next(iter(shapes.values()))[0]
+    out = dict(lam=lam, cut=cut, perm=torch.randperm(B), boxes={})
+    if cut:
+        for key, (_, _, I, S) in shapes.items():
+            ratio = np.sqrt(1 - lam)
+            cut_h, cut_w = int(I * ratio), int(S * ratio)
+            cy, cx = np.random.randint(0, I), np.random.randint(0, S)
+            out["boxes"][key] = (int(np.clip(cy - cut_h // 2, 0, I)), int(np.clip(cy + cut_h // 2, 0, I)),
+                                 int(np.clip(cx - cut_w // 2, 0, S)), int(np.clip(cx + cut_w // 2, 0, S)))
+    return out
+
+
+TIME_AUGMENTERS = {"no": None, "mixup": _mixup_in_random_pool, "negation": _negation, "scaling": _scaling, "horizontal_flip": _horizontal_flip,
                    "permutation": _permutation, "time_warp": _time_warp, "mag_warp": _mag_warp}
 FREQ_AUGMENTERS = {"no": None, "phase_shift": _phase_shift}
 
@@ -97,6 +132,8 @@ class Augmenter:
         time_loc_inputs, labels = self.move_to_target_device(time_loc_inputs, labels)
         if option == "random":
             out = self.forward_random(time_loc_inputs)
+        elif option == "fixed":
+            out = self.forward_fixed(time_loc_inputs, labels)
         elif option == "no":
             out = self.fft_preprocess(time_loc_inputs)
         else:
@@ -112,6 +149,36 @@ class Augmenter:
                 hit = fn is not None and random() < self.args.dataset_config[name]["prob"]
                 out[loc][mod] = fn(inputs[loc][mod], self.args.dataset_config.get(name, {})) if hit else {}
         return out
+
+    def forward_fixed(self, time_loc_inputs, labels=None):
+        """The supervised pipeline (reference :52-74): every configured time augmenter in order, the transform, every configured
+        frequency augmenter.  Built: `mixup` (focal_mixup_fwd) / `no` in the time domain, `phase_shift` (folded into the DFT) /
+        `no` in the frequency domain -- the shipped `fixed_augmenters`.
+        Reference quirk, reproduced: forward_fixed resets the labels to the ORIGINAL ones before the frequency stage (:66
+        `augmented_freq_loc_inputs, augmented_labels = freq_loc_inputs, labels`), so Mixup's mixed soft targets never reach the
+        loss -- the samples are mixed, the labels are not; this returns nothing but the spectra (the caller keeps its labels)."""
+        x = time_loc_inputs
+        for name in self.time_aug_names:
+            if name == "no":
+                continue
+            if name != "mixup":
+                raise NotImplementedError(f"fixed-pipeline time augmenter {name!r} is not built (shipped configs use mixup / no)")
+            draw = draw_mixup(self.args.dataset_config["mixup"], {(loc, mod): tuple(t.shape) for loc, mods in x.items() for mod, t in mods.items()})
+            if draw is not None:
+                perm = draw["perm"].to(torch.int32).to(self.args.device)
+                x = {loc: {mod: ops.mixup(t.contiguous(), perm, draw["lam"], draw["boxes"].get((loc, mod)) if draw["cut"] else None)
+                           for mod, t in mods.items()} for loc, mods in x.items()}
+        kw = {loc: {mod: {} for mod in mods} for loc, mods in x.items()}
+        for name in self.freq_aug_names:
+            if name == "no":
+                continue
+            if name != "phase_shift":
+                raise NotImplementedError(f"fixed-pipeline frequency augmenter {name!r} is not built (shipped configs use phase_shift / no)")
+            d = self._draw(FREQ_AUGMENTERS[name], name, x)
+            for loc in d:
+                for mod in d[loc]:
+                    kw[loc][mod].update(d[loc][mod])
+        return {loc: {mod: ops.fft_realpack(t.contiguous(), **kw[loc][mod]) for mod, t in mods.items()} for loc, mods in x.items()}
 
     def forward_random(self, time_loc_inputs):
         """ONE augmenter from the (time + freq) pool per call (reference :76-113); its arithmetic runs inside the DFT kernel."""
@@ -140,7 +207,16 @@ class Augmenter:
         hit = pend.pop(key, None)
         if hit is not None and hit[0] == tag:
             return hit[1][B:]
-        base = torch.empty(2 * B, 2 * x.shape[1], x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
+        # `static_views` (set by the graph-replaying training loop): the two-view tensor of a (location, modality) keeps its address
+        # from step to step, so a captured step can read it; the loop guarantees a step has finished reading before the next writes
+        if getattr(self, "static_views", False):
+            pool = self.__dict__.setdefault("_static_pairs", {})
+            shape = (2 * B, 2 * x.shape[1], x.shape[2], x.shape[3])
+            base = pool.get((key, shape, x.device))
+            if base is None:
+                base = pool[(key, shape, x.device)] = torch.empty(shape, dtype=torch.float32, device=x.device)
+        else:
+            base = torch.empty(2 * B, 2 * x.shape[1], x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
         pend[key] = (tag, base)
         return base[:B]
 

@@ -14,6 +14,10 @@ class SyntheticSequenceLoader:
         cfg = args.dataset_config
         self.cfg, self.batch_size, self.num_batches, self.seed = cfg, batch_size, num_batches, seed
         self.device = device or args.device
+        # every epoch yields the same seeded batches: they are generated once and kept (on the device when it is a GPU -- the data is
+        # synthetic, there is nothing to load -- so that an epoch measures the training step, not torch.randn on the host)
+        self.resident = getattr(args, "synthetic_resident", True) and torch.device(self.device).type == "cuda"
+        self._cache = None
         self.task = getattr(args, "task", None)
         seq = cfg["seq_len"]
         if batch_size % seq != 0:
@@ -23,6 +27,15 @@ class SyntheticSequenceLoader:
         return self.num_batches
 
     def __iter__(self):
+        if self._cache is None:
+            self._cache = []
+            for batch, labels in self._generate():
+                if self.resident:
+                    batch = {loc: {mod: t.to(self.device) for mod, t in mods.items()} for loc, mods in batch.items()}
+                self._cache.append((batch, labels))
+        return iter(self._cache)
+
+    def _generate(self):
         cfg = self.cfg
         rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
         for k in range(self.num_batches):

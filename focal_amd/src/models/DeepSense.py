@@ -132,11 +132,14 @@ class DeepSense(HipBackbone):
         """`backbone(freq_x, class_head=True)` -> logits (reference: models/DeepSense.py:154-157).  This is the finetuning path: the encoders in front run
         forward-only (finetuning freezes them, general_utils/weight_utils.py:61-80), the head -- the class layer on the concatenated features -- is one
         differentiable node (focal_amd/head_engine.py)."""
-        if self._hot.__name__ != "is_hot_with_head":
+        if self._hot.__name__ == "is_hot":
             raise NotImplementedError("class_head=True needs the classifier head in the parameter arena: build the model with "
                                       "args.stage = 'finetune' (or supervised train_mode)")
-        with torch.no_grad():
+        if self.supervised:  # supervised training from scratch (train_utils/supervised_train.py): the gradient flows on into the encoders
             feats = self.forward_encoder(freq_x, class_head=False, proj_head=False)
+        else:
+            with torch.no_grad():
+                feats = self.forward_encoder(freq_x, class_head=False, proj_head=False)
         x = torch.cat([feats[m] for m in self.modalities], dim=1)
         return run_stage(self, self._class_head, x, self.training)
 

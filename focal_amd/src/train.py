@@ -1,5 +1,6 @@
 """Entry point: `python train.py -model=SW_Transformer -dataset=MOD -learn_framework=FOCAL [-batch_size=N] [-gpu=0]`
-(reference: src/train.py:25-94).  FOCAL pretraining and finetuning (`-stage=finetune`) are implemented in this build."""
+(reference: src/train.py:25-94).  FOCAL pretraining, finetuning (`-stage=finetune`) and supervised training from scratch
+(`-learn_framework=no`) are implemented in this build."""
 import logging
 import os
 import sys
@@ -22,6 +23,9 @@ def train(args):
     classifier = init_backbone_model(args)
     args.classifier = classifier
     loss_func = init_loss_func(args)
+    if args.train_mode == "supervised":
+        from train_utils.supervised_train import supervised_train
+        return supervised_train(args, classifier, augmenter, train_dataloader, val_dataloader, test_dataloader, loss_func, len(train_dataloader))
     if args.train_mode == "contrastive" and args.stage == "pretrain":
         return pretrain(args, classifier, augmenter, train_dataloader, val_dataloader, test_dataloader, loss_func,
                         len(train_dataloader))

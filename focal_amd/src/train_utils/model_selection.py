@@ -32,7 +32,7 @@ def init_loss_func(args):
         if args.learn_framework in {"FOCAL"}:
             return FOCALLoss(args).to(args.device)
         raise NotImplementedError(f"Invalid {args.train_mode} framework {args.learn_framework} provided")
-    if args.stage == "finetune":
+    if args.stage == "finetune" or args.train_mode == "supervised":
         from models.loss import CrossEntropyLoss
         return CrossEntropyLoss()
     raise Exception(f"Train mode {args.train_mode} / stage {args.stage} is outside the MI355X path (FOCAL pretraining and finetuning)")

@@ -25,6 +25,7 @@ if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 from focal_amd import distributed as fdist  # noqa: E402
 from focal_amd import runtime  # noqa: E402
+from focal_amd.graph_step import CapturedTrainStep  # noqa: E402
 
 
 def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, test_dataloader, loss_func, num_batches):
@@ -56,19 +57,29 @@ def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, 
             lr_scheduler.step(e)  # the replayed schedule owns the learning rate (the saved state holds the PREVIOUS epoch's)
         if st.get("rng") is not None:
             runtime.rng_state(args.device).copy_(st["rng"].to(args.device))
+        default_model.backbone.arena()  # the optimizer state lives next to the parameter arena: build it, then restore the moments
+        optimizer.load_train_state(st["optimizer"])
     windows = 0
+    # the step body (zero_grad -> both views through the backbone -> loss -> backward -> AdamW) is replayed from a hipGraph once its
+    # shapes have repeated; the views themselves are drawn eagerly every step (focal_amd/graph_step.py)
+    graphed = CapturedTrainStep(default_model, loss_func, optimizer, enabled=not getattr(args, "no_graph", False))
+    augmenter.static_views = graphed.enabled
     for epoch in range(start_epoch, epochs):
         default_model.train()
         train_loss_list = []
+        epoch_t0, epoch_windows = time_sync(), 0
         for i, (time_loc_inputs, _) in enumerate(train_dataloader):
-            optimizer.zero_grad()
-            loss = calc_pretrain_loss(args, default_model, augmenter, loss_func, time_loc_inputs)
-            loss.backward()
-            if resume and i == 0 and epoch == start_epoch:
-                optimizer.load_train_state(st["optimizer"])  # the arena exists once a backward has run
-            optimizer.step()
+            view1 = augmenter.forward("random", time_loc_inputs)
+            view2 = augmenter.forward("random", time_loc_inputs)
+            loss = graphed(view1, view2)
             train_loss_list.append(loss.item())
-            windows += next(iter(next(iter(time_loc_inputs.values())).values())).shape[0] * fdist.world()
+            n = next(iter(next(iter(time_loc_inputs.values())).values())).shape[0] * fdist.world()
+            windows += n
+            epoch_windows += n
+        if epoch % 10 == 0 or epoch == epochs - 1:
+            dt = max(time_sync() - epoch_t0, 1e-9)
+            logging.info(f"epoch {epoch}: {epoch_windows / dt:.1f} windows/s ({epoch_windows} windows in {dt:.3f} s; "
+                         f"{graphed.replays} graph replays, {graphed.eager_steps} eager steps so far)")
         if epoch % 10 == 0:
             terms = loss_func.last_terms.tolist() if getattr(loss_func, "last_terms", None) is not None else []
             logging.info(f"epoch {epoch}: terms[shared,private,orth,rank,total]={terms}")

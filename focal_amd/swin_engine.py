@@ -46,7 +46,20 @@ class SwinModEncoder:
         fuse_mlp = os.environ.get("FOCAL_NO_MLP_FUSE") != "1"
         pre_ln = None  # (a1, st1) of the next block when the kernel before it already produced them
         first = f"{self.pre}.0.blocks.0"
-        if fuse_ln and geo["stages"][0]["C"] == 64:  # the embedding kernel also emits block 0's norm1
+        embed_saved = None
+        if getattr(bb, "supervised", False):
+            # Supervised training from scratch trains the patch embedding too (it is frozen only in FOCAL pretraining): the strided
+            # Conv2d runs on the patchifying convolution kernels that already have a weight gradient (focal_conv_in_*: DeepSense's first
+            # layer is the same operator), on the zero-padded spectrum; its LayerNorm on the LayerNorm kernels.  The fused
+            # pad + embed + LayerNorm kernel of the pretraining path has no backward.
+            Hp, Wp, pw = geo["grid"][0], geo["grid"][1], geo["patch"][1]
+            _, cin, I, S = x_freq.shape
+            xpad = torch.nn.functional.pad(x_freq, (0, Wp * pw - S, 0, Hp - I))  # data movement only
+            d_pe = ops.conv_in_desc(B, cin, Hp, Wp * pw, Wp, pw, pw, 0, geo["stages"][0]["C"])
+            z = ops.conv_in_fwd(d_pe, xpad, ar.master(f"{pe}.proj.weight"), ar.master(f"{pe}.proj.bias"))
+            x, st_e = ops.layernorm_fwd(z, ar.master(f"{pe}.norm.weight"), ar.master(f"{pe}.norm.bias"), torch.float32)
+            embed_saved = dict(d=d_pe, xpad=xpad, z=z, st=st_e)
+        elif fuse_ln and geo["stages"][0]["C"] == 64:  # the embedding kernel also emits block 0's norm1
             x, a1_0, st1_0 = ops.pad_patch_embed_ln(x_freq, P(f"{pe}.proj.weight"), P(f"{pe}.proj.bias"), P(f"{pe}.norm.weight"),
                                                     P(f"{pe}.norm.bias"), geo["grid"][0], geo["grid"][1], geo["patch"][1],
                                                     next_ln=(ar.master(f"{first}.norm1.weight"), ar.master(f"{first}.norm1.bias"), ct))
@@ -58,7 +71,7 @@ class SwinModEncoder:
             raise ops._lib.FocalHipError("absolute position embedding (APE: True) is outside the HIP hot path")
         p_drop = bb.drop_rate if training else 0.0
         p_attn = bb.attn_drop_rate if training else 0.0
-        saved = {"B": B, "view": view, "training": training, "blocks": [], "merges": []}
+        saved = {"B": B, "view": view, "training": training, "blocks": [], "merges": [], "embed": embed_saved}
         uid = 0
         # At 64 channels a GEMM wave owns whole rows, so the residual GEMMs also emit the LayerNorm that follows them (norm2
         # after proj, the next block's norm1 after fc2): no separate pass over the residual stream for those LayerNorms.
@@ -215,7 +228,14 @@ class SwinModEncoder:
                               ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"),
                               dx_masked=gm if nxt is not None else None, mask=nxt)
             blocks[k] = None  # free this block's activations as we go
-        # g now holds dL/d(patch-embed tokens); the embedding is frozen and its input is a leaf -> stop here.
+        # g now holds dL/d(patch-embed tokens).  FOCAL pretraining: the embedding is frozen and its input is a leaf -> stop here.
+        es = saved.get("embed")
+        if es is not None:  # supervised training: LayerNorm backward, then the convolution's weight / bias gradient
+            pe = f"patch_embed.{self.loc}.{self.mod}"
+            dz = torch.empty_like(es["z"])
+            ops.layernorm_bwd(g.view(es["z"].shape), es["z"], es["st"], ar.master(f"{pe}.norm.weight"), dz, False,
+                              ar.g(f"{pe}.norm.weight"), ar.g(f"{pe}.norm.bias"))
+            ops.conv_in_bwd_weight(es["d"], es["xpad"], dz, ar.g(f"{pe}.proj.weight"), ar.g(f"{pe}.proj.bias"))
 
 
 class ProjectorHead:

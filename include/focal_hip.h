@@ -79,6 +79,12 @@ int focal_augment_fft_fwd(const focal_fft_desc* d, const focal_aug_desc* a, cons
  * The curve (a dozen Gaussian knots) and the tables are drawn / built on the host, as the reference draws them in numpy. */
 int focal_warp_fwd(int rows, int L, const float* x, const float* mult, const int* k0, const float* w, int taps, float* y, void* stream);
 
+/* Mixup / CutMix of the supervised `fixed` pipeline (data_augmenter/MixupAugmenter.py -> input_utils/mixup_utils.py:252-281, mode
+ * "random_batch"): x, y fp32 [B, C, I, S] (y != x), perm int32 [B] = the ONE batch permutation of the call;
+ *   cut = 0: y[b] = lam x[b] + (1 - lam) x[perm[b]];   cut = 1: y[b][:, yl:yh, xl:xh] = x[perm[b]][:, yl:yh, xl:xh], y[b] = x[b] elsewhere. */
+int focal_mixup_fwd(int B, int C, int I, int S, const float* x, const int* perm, float lam, int cut, int yl, int yh, int xl, int xh,
+                    float* y, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ row 8: embed
  * SW_Transformer.pad_input + PatchEmbed (models/SW_Transformer.py:184-208, models/SwinModules.py:547-558):
  * zero-pad [B, cin, I, S] to (Hp*1, Wp*pw), Conv2d(cin -> C0, kernel = stride = [1, pw]), flatten, LayerNorm.
@@ -262,6 +268,7 @@ int focal_gru_seq_bwd(const focal_gru_desc* d, int n_dir, const float* dout, lon
 int focal_mean_time(int B, int T, int D, const float* x, float* y, void* stream);                       /* y[b] = mean_t x[b][t] */
 int focal_dropout(long n, const float* x, float* y, const uint32_t* rng, uint32_t stream_id, float p, void* stream); /* y = x * mask */
 int focal_axpy(long n, float a, const float* x, float* y, void* stream);                                   /* y += a * x */
+int focal_mul(long n, const float* a, float* y, void* stream);                                             /* y *= a (element-wise, fp32) */
 
 /* ------------------------------------------------------------------------------------------------ classifier head (8f rank 4)
  * Finetuning path, `backbone(freq_x, class_head=True)` (models/SW_Transformer.py:269-276, models/FusionModules.py:61-140):

@@ -80,6 +80,29 @@ def time_warp(x, knots, order=6):
     return torch.from_numpy(f(pos)).to(x.dtype).reshape(b, c, i, s)
 
 
+def mixup_bbox(I, S, lam, cy, cx):
+    """rand_bbox, input_utils/mixup_utils.py:32-54 (margin 0) with the two centre draws passed in: the box is cut from the LAST TWO
+    dims of the [b, c, i, s] tensor, i.e. img_h = i (intervals), img_w = s (samples)."""
+    import numpy as np
+    ratio = np.sqrt(1 - lam)
+    cut_h, cut_w = int(I * ratio), int(S * ratio)
+    yl, yh = int(np.clip(cy - cut_h // 2, 0, I)), int(np.clip(cy + cut_h // 2, 0, I))
+    xl, xh = int(np.clip(cx - cut_w // 2, 0, S)), int(np.clip(cx + cut_w // 2, 0, S))
+    return yl, yh, xl, xh
+
+
+def mixup_batch_random(x, perm, lam, box=None):
+    """Mixup._mix_batch_random on one (loc, mod) tensor, input_utils/mixup_utils.py:252-281: `perm` is the call's single
+    torch.randperm(b); box = (yl, yh, xl, xh) selects the CutMix branch (a paste from the permuted batch), else the lam blend."""
+    perm = torch.as_tensor(perm, dtype=torch.long)
+    if box is not None:
+        yl, yh, xl, xh = box
+        y = x.clone()
+        y[:, :, yl:yh, xl:xh] = x[perm][:, :, yl:yh, xl:xh]
+        return y
+    return x * lam + x[perm] * (1.0 - lam)
+
+
 def augmented_view(x, name, draw=None):
     """Augmenter.forward_random for ONE chosen augmenter applied to one (loc, mod) tensor (data_augmenter/Augmenter.py:76-113):
     time-domain augmenters act before the DFT, `phase_shift` after it.  `draw` = factor / order / angle where one is needed."""

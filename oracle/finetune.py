@@ -61,3 +61,24 @@ def finetune_loss_and_grads(model, P, cfg, freq_x, labels, train=False):
     loss = F.cross_entropy(logits, labels)
     grads = torch.autograd.grad(loss, [P[k] for k in keys], allow_unused=True)
     return logits.detach(), loss.detach(), dict(zip(keys, grads))
+
+
+def supervised_param_filter(name):
+    """Parameters that receive a gradient when the whole classifier is trained (train_utils/supervised_train.py:37 hands every
+    parameter to the optimizer; `backbone(freq_x, class_head=True)` never touches the contrastive projectors, the unused
+    absolute position embedding or DeepSense's single-location extras, whose `grad` stays None)."""
+    dead = ("absolute_pos_embed.", "mod_extractors.", "loc_fusion_layers.", "loc_context_layers.", "loc_fusion_layer.", "mod_projectors.")
+    return not name.startswith(dead)
+
+
+def supervised_loss_and_grads(model, P, cfg, freq_x, labels, train=True):
+    """One supervised step's loss and the gradient of EVERY trained parameter (patch embedding included)."""
+    P = dict(P)
+    keys = [k for k, v in P.items() if v.is_floating_point() and supervised_param_filter(k)
+            and not k.endswith(("running_mean", "running_var", "attn_mask"))]
+    for k in keys:
+        P[k] = P[k].detach().clone().requires_grad_(True)
+    logits = classifier_logits(model, P, cfg, freq_x, train=train, new_buffers={})
+    loss = F.cross_entropy(logits, labels)
+    grads = torch.autograd.grad(loss, [P[k] for k in keys], allow_unused=True)
+    return logits.detach(), loss.detach(), dict(zip(keys, grads))

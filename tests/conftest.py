@@ -34,3 +34,22 @@ def no_dropout(cfg):
     c["SW_Transformer"]["drop_path_rate"] = 0.0
     c["SW_Transformer"]["attn_drop_rate"] = 0.0
     return c
+
+
+_OBSERVED = {}
+
+
+def record_observed(key, value):
+    """Observed parity errors of this run -> gpurun_out/observed_parity.json (copied to tests/golden/OBSERVED_r2.json and
+    committed: VERDICT r1 asked for the measured errors behind every tolerance)."""
+    import json
+    _OBSERVED[key] = float(value)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "observed_parity.json")
+        old = json.load(open(path)) if os.path.exists(path) else {}
+        old.update(_OBSERVED)
+        json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass

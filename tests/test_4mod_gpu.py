@@ -35,15 +35,19 @@ def test_four_modality_step(ct):
     f1, f2 = focal(dev(synthetic_freq_input(cfg, 8, seed=303)), dev(synthetic_freq_input(cfg, 8, seed=404)), proj_head=True)
     assert list(f1.keys()) == ["acc", "gyr", "mag", "lig"]
     tol = 1e-3 if ct == "fp32" else 2.5e-2
+    from conftest import record_observed
     for m in f1:
         ref = torch.from_numpy(fx[f"train.emb1.{m}"])
-        assert ((f1[m].detach().cpu() - ref).abs().max() / ref.abs().max()).item() < tol, m
+        e = ((f1[m].detach().cpu() - ref).abs().max() / ref.abs().max()).item()
+        record_observed(f"swt4mod.train.emb.{m}.{ct}.max_err_over_max_ref", e)
+        assert e < tol, m
     net.arena().zero_grad()
     loss = loss_fn(f1, f2)
     loss.backward()
     terms = loss_fn.last_terms.cpu().numpy()
     for i, k in enumerate(("shared", "private", "orth", "rank", "total")):
         ref = float(fx[f"train.loss.{k}"])
+        record_observed(f"swt4mod.train.loss.{k}.{ct}.abs_err_over_max1", abs(terms[i] - ref) / max(1.0, abs(ref)))
         assert abs(terms[i] - ref) < (1e-3 if ct == "fp32" else 5e-2) * max(1.0, abs(ref)), (k, terms[i], ref)
     params = dict(net.named_parameters())
     bad = []

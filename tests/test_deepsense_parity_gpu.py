@@ -9,9 +9,11 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_args, no_dropout
+from conftest import make_args, no_dropout, record_observed
 
 pytestmark = pytest.mark.gpu
+# bf16 bounds (relative to scale); the observed values of the last GPU run are in tests/golden/OBSERVED_r2.json
+DS_EMB_TOL, DS_COS_TOL, DS_FEAT_TOL, DS_LOSS_FACTOR = 2.5e-2, 0.9995, 8e-2, 5
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -50,15 +52,19 @@ def test_eval_embeddings(cfg, ct, tol):
     for m in emb:
         ref = torch.from_numpy(fx[f"eval.emb.{m}"])
         e = scale_err(emb[m].cpu(), ref)
-        assert e < (1e-3 if ct == "fp32" else 2.5e-2), (m, e)
+        cos = torch.nn.functional.cosine_similarity(emb[m].cpu(), ref, dim=-1).min().item()
+        record_observed(f"deepsense.eval.emb.{m}.{ct}.max_err_over_max_ref", e)
+        record_observed(f"deepsense.eval.emb.{m}.{ct}.min_row_cosine", cos)
+        assert e < (1e-3 if ct == "fp32" else DS_EMB_TOL), (m, e)
         if ct == "fp32":
             assert (emb[m].cpu() - ref).abs().max().item() < tol
         else:
-            cos = torch.nn.functional.cosine_similarity(emb[m].cpu(), ref, dim=-1).min().item()
-            assert cos > 0.9995, (m, cos)
+            assert cos > DS_COS_TOL, (m, cos)
         # un-projected GRU features: 5 conv layers + 2x10 recurrent steps of bf16 operand rounding, and the eval
         # fixture runs BatchNorm on seeded (mismatched) running statistics, i.e. un-normalised activations
-        assert scale_err(feat[m].cpu(), torch.from_numpy(fx[f"eval.feat.{m}"])) < (1e-3 if ct == "fp32" else 8e-2)
+        ef = scale_err(feat[m].cpu(), torch.from_numpy(fx[f"eval.feat.{m}"]))
+        record_observed(f"deepsense.eval.feat.{m}.{ct}.max_err_over_max_ref", ef)
+        assert ef < (1e-3 if ct == "fp32" else DS_FEAT_TOL)
 
 
 @pytest.mark.parametrize("ct", ["fp32", "bf16"])
@@ -69,8 +75,10 @@ def test_train_step_loss_and_gradients(cfg, ct):
     x1, x2 = inputs(cfg)
     f1, f2 = focal(x1, x2, proj_head=True)
     for m in f1:
-        assert scale_err(f1[m].detach().cpu(), torch.from_numpy(fx[f"train.emb1.{m}"])) < (1e-3 if ct == "fp32" else 2.5e-2)
-        assert scale_err(f2[m].detach().cpu(), torch.from_numpy(fx[f"train.emb2.{m}"])) < (1e-3 if ct == "fp32" else 2.5e-2)
+        e1 = scale_err(f1[m].detach().cpu(), torch.from_numpy(fx[f"train.emb1.{m}"]))
+        e2 = scale_err(f2[m].detach().cpu(), torch.from_numpy(fx[f"train.emb2.{m}"]))
+        record_observed(f"deepsense.train.emb.{m}.{ct}.max_err_over_max_ref", max(e1, e2))
+        assert max(e1, e2) < (1e-3 if ct == "fp32" else DS_EMB_TOL), (m, e1, e2)
     net.arena().zero_grad()
     loss = loss_fn(f1, f2)
     loss.backward()
@@ -78,8 +86,9 @@ def test_train_step_loss_and_gradients(cfg, ct):
     rel = 1e-3 if ct == "fp32" else 1e-2
     for i, k in enumerate(("shared", "private", "orth", "rank", "total")):
         ref = float(fx[f"train.loss.{k}"])
-        assert abs(terms[i] - ref) < rel * max(1.0, abs(ref)) * (1 if ct == "fp32" else 5), (k, terms[i], ref)
-    assert abs(loss.item() - float(fx["train.loss.reference_total"])) < rel * 5 * abs(float(fx["train.loss.reference_total"]))
+        record_observed(f"deepsense.train.loss.{k}.{ct}.abs_err_over_max1", abs(terms[i] - ref) / max(1.0, abs(ref)))
+        assert abs(terms[i] - ref) < rel * max(1.0, abs(ref)) * (1 if ct == "fp32" else DS_LOSS_FACTOR), (k, terms[i], ref)
+    assert abs(loss.item() - float(fx["train.loss.reference_total"])) < rel * (5 if ct == "fp32" else DS_LOSS_FACTOR) * abs(float(fx["train.loss.reference_total"]))
     names, norms = [str(n) for n in fx["train.grad_names"]], fx["train.grad_norms"]
     params = dict(net.named_parameters())
     bad = []
@@ -177,3 +186,41 @@ def test_full_batch_equals_small_batches_eval(cfg, ct):
     for m in a:
         assert scale_err(b[m][:8], a[m]) < (1e-4 if ct == "fp32" else 3e-2), m
         assert scale_err(b[m][248:], a[m]) < (1e-4 if ct == "fp32" else 3e-2), m
+
+
+@pytest.mark.parametrize("ct", ["fp32", "bf16"])
+def test_full_batch_backward_equals_replicated_block(cfg, ct):
+    """BASELINE size (B = 256) BACKWARD in train mode.  BatchNorm couples the batch, so gradients are not additive over chunks; but
+    a batch made of 32 copies of an 8-window block has the block's batch statistics in every layer, and with the output
+    cotangent replicated the same way every per-channel mean inside the BatchNorm backward is the block's too: by symmetry
+    d/dW of sum_i <r_i, emb_i> over the 256 windows is exactly 32 x the block's gradient (whose kernels are pinned by the
+    reference fixture at B = 8).  Exercises conv / BatchNorm / GRU / weight-gradient kernels at full size, reductions included."""
+    args, net, _, _ = build(cfg, ct)
+    net.train()
+    g = torch.Generator().manual_seed(7)
+    x8 = {"shake": {"audio": torch.randn(8, 2, 10, 1600, generator=g).cuda(), "seismic": torch.randn(8, 2, 10, 20, generator=g).cuda()}}
+    r8 = {m: torch.randn(8, 256, generator=g).cuda() for m in cfg["modality_names"]}
+
+    def grads(x, r):
+        net.arena().zero_grad()
+        out = net(x, class_head=False, proj_head=True)
+        sum((out[m] * r[m]).sum() for m in out).backward()
+        torch.cuda.synchronize()
+        return net.arena().grad.clone()
+
+    g8 = grads(x8, r8)
+    rep = {"shake": {m: v.repeat(32, 1, 1, 1) for m, v in x8["shake"].items()}}
+    g256 = grads(rep, {m: v.repeat(32, 1) for m, v in r8.items()})
+    worst, err, scale = [], 0.0, 32.0 * g8.abs().max().item()
+    ar = net.arena()
+    for name, (off, n, shape) in ar.index.items():
+        if name.endswith("conv.bias"):
+            continue  # a conv bias in front of a train-mode BatchNorm has an analytically zero gradient: both sides are rounding noise
+        a, b = g256[off:off + n], 32.0 * g8[off:off + n]
+        err = max(err, (a - b).abs().max().item() / scale)
+        worst.append(((a - b).norm().item() / max(b.norm().item(), 1e-12), name))
+    worst.sort(reverse=True)
+    record_observed(f"deepsense.b256_backward_vs_32x_block.{ct}.max_err_over_max_grad", err)
+    record_observed(f"deepsense.b256_backward_vs_32x_block.{ct}.worst_param_rel_l2", worst[0][0])
+    assert err < (2e-4 if ct == "fp32" else 2e-2), (err, worst[:6])
+    assert worst[0][0] < (1e-3 if ct == "fp32" else 6e-2), worst[:6]

@@ -42,6 +42,35 @@ def test_loss_head_matches_reference_fixture(cfg, name, model):
             assert err < 1e-3, (key, err.item())
 
 
+def test_loss_head_global_batch_2048_matches_reference_fixture(cfg):
+    """BASELINE config 4's loss head: the 8-rank GLOBAL batch (2048 windows = 512 subsequences; S is [4, 1024, 1024] per InfoNCE
+    problem, D [2048, 2048] per ranking problem) against tests/golden/loss_swt_b2048.npz -- terms from the oracle in fp64, cross-
+    checked at generation against the reference's own FOCALLoss on the same embeddings; dL/dz on every 16th row."""
+    from focal_amd import ops
+    fx = np.load(os.path.join(GOLD, "loss_swt_b2048.npz"))
+    B, seed, scale = int(fx["B"]), int(fx["seed"]), float(fx["scale"])
+    mods = [str(m) for m in fx["mods"]]
+    f1, f2 = _views(B, mods, seed, scale)
+    fc = cfg["FOCAL"]
+    w = (fc["shared_contrastive_loss_weight"], fc["private_contrastive_loss_weight"], fc["orthogonal_loss_weight"], fc["rank_loss_weight"])
+    terms, g1, g2 = ops.loss_head([f1[m].cuda() for m in mods], [f2[m].cuda() for m in mods], fc["temperature"]["SW_Transformer"],
+                                  fc["inter_rank_margin"], w, cfg["seq_len"])
+    terms = terms.cpu().numpy()
+    from conftest import record_observed
+    for i, k in enumerate(("shared", "private", "orth", "rank", "total")):
+        ref = float(fx[f"loss.{k}"])
+        record_observed(f"loss.b2048.{k}.abs_err_over_max1", abs(terms[i] - ref) / max(1.0, abs(ref)))
+        assert abs(terms[i] - ref) < 1e-3 * max(1.0, abs(ref)), (k, terms[i], ref)
+    assert abs(terms[4] - float(fx["loss.reference_total"])) < 1e-3 * abs(float(fx["loss.reference_total"]))
+    for i, m in enumerate(mods):
+        for got, key in ((g1[i], f"demb1.{m}"), (g2[i], f"demb2.{m}")):
+            ref = torch.from_numpy(fx[key])
+            err = ((got.cpu()[::16] - ref).norm() / ref.norm()).item()
+            record_observed(f"loss.b2048.{key}.rel_l2", err)
+            assert err < 1e-3, (key, err)
+            assert abs(got.double().norm().item() - float(fx[key.replace(".", "_norm.", 1)])) < 1e-3 * float(fx[key.replace(".", "_norm.", 1)])
+
+
 @pytest.mark.parametrize("M,B,no_private,seq", [(2, 16, False, 4), (4, 32, False, 4), (2, 32, True, 4), (3, 2048, False, 4),
                                                 (2, 12, False, 4), (2, 20, False, 4), (3, 8, False, 4), (2, 15, False, 3), (2, 10, True, 2)])
 def test_loss_head_matches_oracle(cfg, M, B, no_private, seq):

@@ -223,3 +223,21 @@ def test_augment_oracle_matches_reference_fixture():
                 assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
             else:
                 assert torch.equal(got, ref), (name, lm)
+
+
+def test_mixup_oracle_reproduces_reference_fixture():
+    """oracle/augment.py::mixup_batch_random / mixup_bbox against the outputs of the reference's Mixup class with forced draws
+    (tests/golden/mixup_b6.npz, generated by tests/golden/gen_golden_supervised.py)."""
+    import numpy as np
+    from oracle.augment import mixup_batch_random, mixup_bbox
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "mixup_b6.npz"))
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    base = {"audio": torch.randn(6, 1, 10, 64, generator=g), "seismic": torch.randn(6, 1, 10, 20, generator=g)}
+    for tag, cut in (("mixup", False), ("cutmix", True)):
+        lam, perm = float(fx[f"{tag}.lam"]), [int(v) for v in fx[f"{tag}.perm"]]
+        for m, x in base.items():
+            box = None
+            if cut:
+                box = mixup_bbox(x.shape[2], x.shape[3], lam, *[int(v) for v in fx[f"{tag}.centre.{m}"]])
+                assert list(box) == [int(v) for v in fx[f"{tag}.box.{m}"]]
+            assert torch.equal(mixup_batch_random(x, perm, lam, box), torch.from_numpy(fx[f"{tag}.out.{m}"]))

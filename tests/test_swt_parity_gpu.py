@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_args, no_dropout
+from conftest import make_args, no_dropout, record_observed
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -50,13 +50,19 @@ def test_eval_embeddings(cfg, ct, tol):
     for m in emb:
         ref = torch.from_numpy(fx[f"eval.emb.{m}"])
         e = scale_err(emb[m].cpu(), ref)
-        assert e < (1e-3 if ct == "fp32" else 2.5e-2), (m, e)
+        cos = torch.nn.functional.cosine_similarity(emb[m].cpu(), ref, dim=-1).min().item()
+        ef = scale_err(feat[m].cpu(), torch.from_numpy(fx[f"eval.feat.{m}"]))
+        record_observed(f"swt.eval.emb.{m}.{ct}.max_err_over_max_ref", e)
+        record_observed(f"swt.eval.emb.{m}.{ct}.min_row_cosine", cos)
+        record_observed(f"swt.eval.feat.{m}.{ct}.max_err_over_max_ref", ef)
+        # bf16: north_star's 1e-2 as a relative-to-scale bound; operand rounding ALONE (the oracle in fp32 arithmetic with bf16-rounded
+        # operands, test_bf16_path_equals_operand_rounded_oracle) already costs 0.8e-2 - 1.0e-2 and a row cosine of 0.99996 here
+        assert e < (1e-3 if ct == "fp32" else 1.5e-2), (m, e)
         if ct == "fp32":
             assert (emb[m].cpu() - ref).abs().max().item() < tol
         else:
-            cos = torch.nn.functional.cosine_similarity(emb[m].cpu(), ref, dim=-1).min().item()
-            assert cos > 0.9995, (m, cos)
-        assert scale_err(feat[m].cpu(), torch.from_numpy(fx[f"eval.feat.{m}"])) < (1e-3 if ct == "fp32" else 2.5e-2)
+            assert cos > 0.9999, (m, cos)
+        assert ef < (1e-3 if ct == "fp32" else 1.5e-2)
 
 
 @pytest.mark.parametrize("ct", ["fp32", "bf16"])
@@ -67,8 +73,10 @@ def test_train_step_loss_and_gradients(cfg, ct):
     x1, x2 = inputs(cfg)
     f1, f2 = focal(x1, x2, proj_head=True)
     for m in f1:
-        assert scale_err(f1[m].detach().cpu(), torch.from_numpy(fx[f"train.emb1.{m}"])) < (1e-3 if ct == "fp32" else 2.5e-2)
-        assert scale_err(f2[m].detach().cpu(), torch.from_numpy(fx[f"train.emb2.{m}"])) < (1e-3 if ct == "fp32" else 2.5e-2)
+        e1 = scale_err(f1[m].detach().cpu(), torch.from_numpy(fx[f"train.emb1.{m}"]))
+        e2 = scale_err(f2[m].detach().cpu(), torch.from_numpy(fx[f"train.emb2.{m}"]))
+        record_observed(f"swt.train.emb.{m}.{ct}.max_err_over_max_ref", max(e1, e2))
+        assert max(e1, e2) < (1e-3 if ct == "fp32" else 1.5e-2), (m, e1, e2)
     net.arena().zero_grad()
     loss = loss_fn(f1, f2)
     loss.backward()
@@ -76,16 +84,21 @@ def test_train_step_loss_and_gradients(cfg, ct):
     rel = 1e-3 if ct == "fp32" else 1e-2
     for i, k in enumerate(("shared", "private", "orth", "rank", "total")):
         ref = float(fx[f"train.loss.{k}"])
-        assert abs(terms[i] - ref) < rel * max(1.0, abs(ref)) * (1 if ct == "fp32" else 5), (k, terms[i], ref)
-    assert abs(loss.item() - float(fx["train.loss.reference_total"])) < rel * 5 * abs(float(fx["train.loss.reference_total"]))
+        record_observed(f"swt.train.loss.{k}.{ct}.abs_err_over_max1", abs(terms[i] - ref) / max(1.0, abs(ref)))
+        # bf16: |d term| <= 1e-2 max(1, |term|) (north_star / SURVEY appendix D); with T = 0.07 an embedding error of 1e-2 moves an
+        # InfoNCE logit by up to 0.14, so the two contrastive terms get 2e-2
+        lim = rel * (1 if ct == "fp32" else (2 if k in ("shared", "private", "total") else 1))
+        assert abs(terms[i] - ref) < lim * max(1.0, abs(ref)), (k, terms[i], ref)
+    assert abs(loss.item() - float(fx["train.loss.reference_total"])) < rel * 2 * abs(float(fx["train.loss.reference_total"]))
     names, norms = [str(n) for n in fx["train.grad_names"]], fx["train.grad_norms"]
     params = dict(net.named_parameters())
-    bad = []
+    bad, worst_gn = [], 0.0
     for n, ref in zip(names, norms):
         g = params[n].grad
         assert g is not None, n
         got = g.double().norm().item()
         tol = 2e-3 if ct == "fp32" else 6e-2
+        worst_gn = max(worst_gn, abs(got - ref) / max(ref, 1e-6))
         if abs(got - ref) > tol * max(ref, 1e-6) + 1e-6:
             bad.append((n, got, ref))
         sl = torch.from_numpy(fx[f"train.gradslice.{n}"])
@@ -94,6 +107,8 @@ def test_train_step_loss_and_gradients(cfg, ct):
         mine = flat[::step][:16]
         if ct == "fp32":
             assert (mine - sl).abs().max().item() < 2e-3 * max(sl.abs().max().item(), ref / max(flat.numel() ** 0.5, 1), 1e-6) + 1e-6, n
+    record_observed(f"swt.train.grad_norm.{ct}.worst_rel_err", worst_gn)
+    record_observed(f"swt.train.grad_norm.{ct}.params_over_tol", len(bad))
     if ct == "fp32":
         assert not bad, bad[:8]
     else:
@@ -161,7 +176,10 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
     # run-to-run noise of the forward value (fp32 atomics in the split-K products sum in arrival order): the central
     # difference below divides it by 2 eps, so it is part of the tolerance (a mask mismatch is an O(1) relative error)
     with torch.no_grad():
-        vals = [value().item() for _ in range(4)]
+        vals = [value().item() for _ in range(8)]
+    # (observed: with the range of only 4 samples as the noise estimate and single evaluations on each side this check failed about
+    # one run in ten on an outlier of the atomics' summation order -- the same commit passed 3 of 3 re-runs; hence 8 samples for the
+    # estimate and the mean of 3 evaluations on each side of the difference)
     noise = max(vals) - min(vals) + 2e-7 * abs(vals[0])
     params = dict(net.named_parameters())
     names = ["freq_interval_layers.shake.audio.0.blocks.1.mlp.fc2.weight", "freq_interval_layers.shake.audio.1.blocks.0.attn.proj.weight",
@@ -174,9 +192,9 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
         eps = 2e-3 / max(d.abs().max().item(), 1e-6)
         with torch.no_grad():
             p.add_(eps * d)
-            up = value().item()
+            up = sum(value().item() for _ in range(3)) / 3
             p.add_(-2 * eps * d)
-            dn = value().item()
+            dn = sum(value().item() for _ in range(3)) / 3
             p.add_(eps * d)
         num = (up - dn) / (2 * eps)
         assert abs(num - ana) < 3e-2 * max(abs(ana), abs(num), 1e-3) + 2 * noise / (2 * eps), (n, num, ana, noise, eps)
@@ -263,3 +281,32 @@ def test_optimizer_train_state_round_trip(cfg):
         return (num / max(den, 1e-30)) ** 0.5
     assert update_error(w3b) < 2e-2, update_error(w3b)
     assert update_error(wbad) > 0.3, update_error(wbad)  # negative control: the scrambled state takes a different step
+
+
+def test_bf16_path_equals_operand_rounded_oracle(cfg):
+    """Where the bf16 path's distance to the fp32 reference comes from (SURVEY appendix D's method): the oracle in fp32 ARITHMETIC
+    with exactly the tensors rounded to bf16 that the HIP path stores or multiplies as bf16 (oracle/swt.py: emulate_bf16) is itself
+    0.7e-2 - 1.1e-2 (relative to scale) away from the fp32 reference; the HIP bf16 embeddings must be no farther."""
+    from oracle.swt import swt_forward
+    from oracle.weights import fill_state_dict_, synthetic_freq_input
+    fx = np.load(os.path.join(GOLD, "SW_Transformer_b8.npz"))
+    args, net, _, _ = build(cfg, "bf16")
+    net.eval()
+    x1, _ = inputs(cfg)
+    with torch.no_grad():
+        emb = net(x1, class_head=False, proj_head=True)
+    state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        emu = swt_forward(state, no_dropout(cfg), synthetic_freq_input(cfg, 8, seed=101), emulate_bf16=True)
+    for m in emb:
+        ref = torch.from_numpy(fx[f"eval.emb.{m}"])
+        to_emu, emu_to_ref, to_ref = scale_err(emb[m].cpu(), emu[m]), scale_err(emu[m], ref), scale_err(emb[m].cpu(), ref)
+        record_observed(f"swt.eval.emb.{m}.bf16.vs_operand_rounded_oracle", to_emu)
+        record_observed(f"swt.eval.emb.{m}.operand_rounded_oracle_vs_fp32_reference", emu_to_ref)
+        record_observed(f"swt.eval.emb.{m}.bf16.vs_fp32_reference", to_ref)
+        # bf16 rounding is chaotic in the accumulation order (a different fp32 summation order flips 1-ulp roundings, and eight blocks
+        # compound them), so the HIP path does not REPRODUCE the emulation element by element (observed 0.5e-2 - 0.8e-2 apart); the
+        # statement that holds is about magnitudes: the HIP bf16 path is no farther from the fp32 reference than the fp32-arithmetic
+        # evaluation with bf16-rounded operands is -- its distance is operand rounding, not kernel arithmetic.
+        assert to_ref < 1.25 * emu_to_ref + 1e-3, (m, to_ref, emu_to_ref)
+        assert to_emu < 1.25 * emu_to_ref + 1e-3, (m, to_emu, emu_to_ref)

@@ -95,3 +95,27 @@ def test_finetune_stage_runs_on_pretrained_weights(model):
         assert needle in log, (needle, log[-2000:])
     wdir = os.path.join(ROOT, "weights", f"MOD_{model}")
     assert any(f.endswith("finetune_latest.pt") for f in os.listdir(wdir))
+
+
+def test_train_py_sustains_the_benchmarked_step():
+    """`train.py` replays the captured step (focal_amd/graph_step.py) with real `Augmenter.forward("random")` views drawn eagerly
+    every step: its steady-state windows/s (last epoch, logged by train_utils/pretrain.py) must be within 10 % of what bench.py
+    measures on the same box with the batch handed over from the host (`--from-host`)."""
+    import json
+    import re
+    src = os.path.join(ROOT, "focal_amd", "src")
+    r = subprocess.run([sys.executable, os.path.join(src, "train.py"), "-model=SW_Transformer", "-dataset=MOD", "-learn_framework=FOCAL",
+                        "-batch_size=256", "-synthetic_batches=30", "-epochs=3"], capture_output=True, text=True, timeout=1500, cwd=src)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0, log[-3000:]
+    rates = [float(x) for x in re.findall(r"epoch 2: ([0-9.]+) windows/s", log)]
+    assert rates, log[-2000:]
+    assert "graph replays" in log and int(re.findall(r"(\d+) graph replays", log)[-1]) >= 60, log[-1500:]
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--from-host", "--steps", "40", "--warmup", "10", "--no-cpu-baseline",
+                        "--no-roofline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert b.returncode == 0, (b.stdout + b.stderr)[-3000:]
+    bench = json.loads([ln for ln in b.stdout.splitlines() if ln.startswith("{")][-1])["value"]
+    from conftest import record_observed
+    record_observed("train_py.windows_per_s", rates[-1])
+    record_observed("train_py.over_bench_from_host", rates[-1] / bench)
+    assert rates[-1] >= 0.9 * bench, (rates, bench)
