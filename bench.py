@@ -290,16 +290,16 @@ class StepTracer:
         def dw(d, dy, x, dw_, db):
             wgs = lib.focal_linear_bwd_weight_workgroups(ctypes.byref(d))
             b, f = _dw_bytes_flops(d)
-            return ("focal_gemm_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles>", f"{wgs} workgroups x 256", b, f, "hbm")
+            return ("focal_gemm_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles>", f"{wgs} workgroups x 256", b, f, "hbm", f"dW[{d.N},{d.K}] over {d.M} rows")
 
         def lnb(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None, dx_masked=None, mask=None):
             rows, C = dy.shape
             es = dy.element_size()
             b = rows * C * (es + 4 + (8 if accumulate else 4) + (es if dx_masked is not None else 0)) + rows * 8
-            return ("ln_bwd_kernel", "persistent grid (all LayerNorm backward launches)", b, 8.0 * rows * C, "hbm")
+            return ("ln_bwd_kernel", "persistent grid (all LayerNorm backward launches)", b, 8.0 * rows * C, "hbm", f"rows {rows} x C {C}")
 
         def mlpb(d, gm, a, *rest, **kw):
-            return ("mlp_bwd_kernel", "256 workgroups x 512 (persistent)", d.M * d.C * 6, 10.0 * d.M * d.C * d.hidden, "mfma")
+            return ("mlp_bwd_kernel", "256 workgroups x 512 (persistent)", d.M * d.C * 6, 10.0 * d.M * d.C * d.hidden, "mfma", f"M {d.M}")
         self._wrap("linear_bwd_weight", dw)
         self._wrap("layernorm_bwd", lnb)
         self._wrap("mlp_bwd", mlpb)
@@ -311,14 +311,23 @@ class StepTracer:
     def summary(self, steps):
         torch.cuda.synchronize()
         groups = {}
-        for (kern, shape, b, f, bound), e0, e1 in self.rec:
-            g = groups.setdefault((kern, shape, bound), [0, 0.0, 0.0, 0.0])
+        for (kern, shape, b, f, bound, inst), e0, e1 in self.rec:
+            g = groups.setdefault((kern, shape, bound), [0, 0.0, 0.0, 0.0, {}])
+            us = e0.elapsed_time(e1) * 1e3
             g[0] += 1
-            g[1] += e0.elapsed_time(e1) * 1e3  # us
+            g[1] += us
             g[2] += b
             g[3] += f
-        return [dict(kernel=k[0], launch_shape=k[1], bound=k[2], calls_per_step=v[0] / steps, us_per_step=v[1] / steps,
-                     avg_us=v[1] / v[0], bytes_per_launch=v[2] / v[0], flops_per_launch=v[3] / v[0]) for k, v in groups.items()]
+            i = g[4].setdefault(inst, [0, 0.0, b])
+            i[0] += 1
+            i[1] += us
+        out = []
+        for k, v in groups.items():
+            inst = sorted(({"instance": n, "calls_per_step": round(c / steps, 2), "avg_us": round(t / c, 2), "GBps": round(b / (t / c * 1e-6) / 1e9, 1)}
+                           for n, (c, t, b) in v[4].items()), key=lambda r: -r["calls_per_step"] * r["avg_us"])
+            out.append(dict(kernel=k[0], launch_shape=k[1], bound=k[2], calls_per_step=v[0] / steps, us_per_step=v[1] / steps,
+                            avg_us=v[1] / v[0], bytes_per_launch=v[2] / v[0], flops_per_launch=v[3] / v[0], instances=inst[:12]))
+        return out
 
 
 def roofline(a, step, device):
@@ -368,6 +377,7 @@ def roofline(a, step, device):
            "frac": round(ach / peak, 4), "traffic": traffic, "measured": "in the step: HIP events around each launch of eager steps (one stream, as rocprofv3 sees them), averaged over the group",
            "calls_per_step": round(top["calls_per_step"], 2), "avg_us": round(top["avg_us"], 2),
            "algorithmic_bytes_per_launch": round(top["bytes_per_launch"]), "flops_per_launch": round(top["flops_per_launch"]),
+           "instances": top["instances"],
            "other_groups": [{"kernel": f"{g['kernel']} [{g['launch_shape']}]", "calls_per_step": round(g["calls_per_step"], 2),
                              "avg_us": round(g["avg_us"], 2), "ms_per_step": round(g["us_per_step"] / 1e3, 4),
                              "GBps": round(g["bytes_per_launch"] / (g["avg_us"] * 1e-6) / 1e9, 1),

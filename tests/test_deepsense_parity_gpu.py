@@ -12,8 +12,12 @@ import torch
 from conftest import make_args, no_dropout, record_observed
 
 pytestmark = pytest.mark.gpu
-# bf16 bounds (relative to scale); the observed values of the last GPU run are in tests/golden/OBSERVED_r2.json
-DS_EMB_TOL, DS_COS_TOL, DS_FEAT_TOL, DS_LOSS_FACTOR = 2.5e-2, 0.9995, 8e-2, 5
+# bf16 bounds (relative to scale); the observed values of the last GPU run are in tests/golden/OBSERVED_r2.json.
+# Train mode (batch statistics, what pretraining runs): embeddings 1e-2 (observed 5.4e-3), loss terms 1e-2 max(1, |term|) (observed <= 1e-3).
+# The EVAL fixture normalises with seeded, deliberately mismatched running statistics, i.e. it pushes un-normalised activations of
+# scale ~30 through five conv layers and 20 recurrent steps: operand rounding is amplified there (observed 2.4e-2 / cosine 0.9996 on
+# the audio embedding, 4.9e-2 on the un-projected GRU features), which says nothing about a trained model's running statistics.
+DS_EMB_TOL, DS_EMB_TOL_EVAL, DS_COS_TOL, DS_FEAT_TOL, DS_LOSS_FACTOR = 1e-2, 3e-2, 0.9995, 6e-2, 1
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -55,7 +59,7 @@ def test_eval_embeddings(cfg, ct, tol):
         cos = torch.nn.functional.cosine_similarity(emb[m].cpu(), ref, dim=-1).min().item()
         record_observed(f"deepsense.eval.emb.{m}.{ct}.max_err_over_max_ref", e)
         record_observed(f"deepsense.eval.emb.{m}.{ct}.min_row_cosine", cos)
-        assert e < (1e-3 if ct == "fp32" else DS_EMB_TOL), (m, e)
+        assert e < (1e-3 if ct == "fp32" else DS_EMB_TOL_EVAL), (m, e)
         if ct == "fp32":
             assert (emb[m].cpu() - ref).abs().max().item() < tol
         else:
@@ -211,16 +215,22 @@ def test_full_batch_backward_equals_replicated_block(cfg, ct):
     g8 = grads(x8, r8)
     rep = {"shake": {m: v.repeat(32, 1, 1, 1) for m, v in x8["shake"].items()}}
     g256 = grads(rep, {m: v.repeat(32, 1) for m, v in r8.items()})
-    worst, err, scale = [], 0.0, 32.0 * g8.abs().max().item()
+    # fp32: equal up to summation order.  bf16: the two runs round differently (BatchNorm statistics and weight-gradient sums add 32x
+    # more terms in another order, which flips bf16 roundings of the activations that follow), so the comparison is in L2 -- over the
+    # whole arena and per weight tensor; bias-like parameters are sums of cancelling terms and carry that noise amplified
+    # (observed: 7 % on a GRU bias whose weights agree to 0.5 %), they only enter the global norm.
+    worst, num, den = [], 0.0, 0.0
     ar = net.arena()
     for name, (off, n, shape) in ar.index.items():
         if name.endswith("conv.bias"):
             continue  # a conv bias in front of a train-mode BatchNorm has an analytically zero gradient: both sides are rounding noise
-        a, b = g256[off:off + n], 32.0 * g8[off:off + n]
-        err = max(err, (a - b).abs().max().item() / scale)
-        worst.append(((a - b).norm().item() / max(b.norm().item(), 1e-12), name))
+        a, b = g256[off:off + n].double(), 32.0 * g8[off:off + n].double()
+        num, den = num + (a - b).pow(2).sum().item(), den + b.pow(2).sum().item()
+        if n >= 4096:
+            worst.append(((a - b).norm().item() / max(b.norm().item(), 1e-12), name))
     worst.sort(reverse=True)
-    record_observed(f"deepsense.b256_backward_vs_32x_block.{ct}.max_err_over_max_grad", err)
-    record_observed(f"deepsense.b256_backward_vs_32x_block.{ct}.worst_param_rel_l2", worst[0][0])
-    assert err < (2e-4 if ct == "fp32" else 2e-2), (err, worst[:6])
-    assert worst[0][0] < (1e-3 if ct == "fp32" else 6e-2), worst[:6]
+    total = (num / den) ** 0.5
+    record_observed(f"deepsense.b256_backward_vs_32x_block.{ct}.arena_rel_l2", total)
+    record_observed(f"deepsense.b256_backward_vs_32x_block.{ct}.worst_weight_rel_l2", worst[0][0])
+    assert total < (1e-5 if ct == "fp32" else 1.5e-2), (total, worst[:6])
+    assert worst[0][0] < (1e-4 if ct == "fp32" else 3e-2), worst[:6]
