@@ -578,7 +578,9 @@ static inline void focal_dw_plan(int M, int N, long rows, int* bm_out, int* bn_o
   int bm = M >= 256 ? 256 : (M >= 128 ? 128 : 64);
   int bn = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
   while (bm * bn > 16384) { if (bm >= bn) bm >>= 1; else bn >>= 1; }
-  if (!getenv("FOCAL_GEMM_DW_WIDE")) bm = bn = 64;
+  // wide tiles only for outputs of at least FOCAL_DW_WIDE_MIN elements (default: never -- see the note at launch_dw)
+  static const long wide_min = getenv("FOCAL_DW_WIDE_MIN") ? atol(getenv("FOCAL_DW_WIDE_MIN")) : (getenv("FOCAL_GEMM_DW_WIDE") ? 0 : (1L << 40));
+  if ((long)M * N < wide_min) bm = bn = 64;
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   static const long target_wg = getenv("FOCAL_DW_WGS") ? atol(getenv("FOCAL_DW_WGS")) : 512;
   long splits = (target_wg + tiles - 1) / tiles;

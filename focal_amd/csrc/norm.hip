@@ -145,8 +145,15 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const TY* __restrict__ dy,
     const int r = r0 + sub;
     const bool ok = r < rows;
     const float mean = ok ? stats[2 * (long)r] : 0.f, rstd = ok ? stats[2 * (long)r + 1] : 0.f;
-    float4 xh[NV], g[NV];
+    float4 xh[NV], g[NV], old[NV];
     float s1 = 0.f, s2 = 0.f;
+    // the residual-stream gradient this row's result is added to: requested together with x and dy (it does not depend on
+    // the row reductions; loading it after them exposed a second full memory latency per row)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = (k * lpr + li) * 4;
+      old[k] = (ok && accumulate) ? *reinterpret_cast<const float4*>(dx + map.offset(r, c)) : make_float4(0, 0, 0, 0);
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = (k * lpr + li) * 4;
@@ -168,10 +175,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const TY* __restrict__ dy,
       float* dst = dx + map.offset(r, c);
       float4 o = make_float4(rstd * (g[k].x - m1 - xh[k].x * m2), rstd * (g[k].y - m1 - xh[k].y * m2),
                              rstd * (g[k].z - m1 - xh[k].z * m2), rstd * (g[k].w - m1 - xh[k].w * m2));
-      if (accumulate) {
-        const float4 old = *reinterpret_cast<const float4*>(dst);
-        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-      }
+      o.x += old[k].x; o.y += old[k].y; o.z += old[k].z; o.w += old[k].w;
       *reinterpret_cast<float4*>(dst) = o;
       if (dxm) store_masked4(dxm, dst - dx, o, mk);
     }

@@ -48,7 +48,7 @@ for k, (f, w, cnt, busy, dur) in sorted(tot.items(), key=lambda kv: -(2 * kv[1][
     mf = busy / (dur * 1e-9 * 2.4e9 * 1024) if dur else 0.0
     print(f"  {k:22s} read {2*f*1024/1e9:8.3f} GB  write {w*1024/1e9:8.3f} GB  time {dur/1e6:8.3f} ms  {gbs:7.0f} GB/s ({gbs/8000*100:4.1f} % of peak)  MFMA busy {mf*100:5.1f} %  launches {cnt:6d}")
 print(f"  TOTAL {gt:.3f} GB in {tt/1e6:.3f} ms of kernel time = {gt/(tt*1e-9):.0f} GB/s")
-print(f"  per step: {gt / n:.3f} GB over {n} profiled steps (the two arena-building steps of bench.py included in the total, not in n)")
+print(f"  per step: {gt / (n + 2):.3f} GB ({n} bench steps + bench.py's two arena-building steps = {n + 2} steps in the total)")
 # per (kernel, launch grid) group: what bench.py's `roofline.traffic` quotes (HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, KB -> B)
 import json
 grp = collections.defaultdict(lambda: [0.0, 0.0, 0])

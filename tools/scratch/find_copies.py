@@ -1,0 +1,25 @@
+"""Where do the small device-to-device copies of one eager step come from?  (torch.profiler, python stacks of aten::copy_ / clone / cat)"""
+import os, sys, collections
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+sys.argv = ["bench.py", "--no-graph", "--no-cpu-baseline", "--no-roofline"]
+import torch
+import bench
+a = bench.parse()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+step = bench.Step(a, dev)
+for _ in range(3):
+    step.run()
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    step.run()
+    torch.cuda.synchronize()
+cnt = collections.Counter()
+for e in prof.events():
+    if e.name in ("aten::copy_", "aten::clone", "aten::cat", "aten::stack", "aten::fill_", "aten::zero_", "aten::contiguous", "aten::_to_copy", "aten::zeros", "aten::mul_"):
+        st = [s for s in (e.stack or []) if "focal_amd" in s or "bench.py" in s or "/src/" in s]
+        cnt[(e.name, str(e.input_shapes)[:60], st[0][-90:] if st else "?")] += 1
+for k, v in cnt.most_common(40):
+    print(v, k)
