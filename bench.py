@@ -290,7 +290,9 @@ class StepTracer:
         def dw(d, dy, x, dw_, db):
             wgs = lib.focal_linear_bwd_weight_workgroups(ctypes.byref(d))
             b, f = _dw_bytes_flops(d)
-            return ("focal_gemm_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles>", f"{wgs} workgroups x 256", b, f, "hbm", f"dW[{d.N},{d.K}] over {d.M} rows")
+            kern = ("focal_dw_wide_kernel<dW: dy^T x, fp32 atomics, 128x128 tiles, LDS-DMA ring>" if lib.focal_linear_bwd_weight_tile(ctypes.byref(d)) == 128
+                    else "focal_gemm_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles>")
+            return (kern, f"{wgs} workgroups x 256", b, f, "hbm", f"dW[{d.N},{d.K}] over {d.M} rows")
 
         def lnb(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None, dx_masked=None, mask=None):
             rows, C = dy.shape
@@ -445,7 +447,8 @@ def cpu_baseline(a, cfg):
     than this port on the same cores -> `reference_ratio_probed`, `reference_equivalent_value`."""
     from oracle.step import OracleTrainer, fft_realpack
     from oracle.weights import seeded_values, swt_state_spec, deepsense_state_spec, synthetic_time_input
-    spec = swt_state_spec(cfg) if a.model == "SW_Transformer" else deepsense_state_spec(cfg)
+    task = "vehicle_classification" if a.dataset == "MOD" else "activity_classification"
+    spec = swt_state_spec(cfg, task) if a.model == "SW_Transformer" else deepsense_state_spec(cfg, task)
     state = {}
     for k, shp in spec.items():
         if k.endswith(("relative_position_index", "num_batches_tracked")):

@@ -105,6 +105,7 @@ PROTOTYPES = {
     "focal_linear_bwd_data": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight_workgroups": (C.c_int, [C.POINTER(LinearDesc)]),
+    "focal_linear_bwd_weight_tile": (C.c_int, [C.POINTER(LinearDesc)]),
     "focal_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P]),
     "focal_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P]),

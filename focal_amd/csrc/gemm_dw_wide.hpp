@@ -1,0 +1,185 @@
+// Weight-gradient GEMM for the deep Swin stages (outputs of 384 x 128 ... 1024 x 256 over 9 k - 74 k tokens):
+//
+//   C[m][n] += sum_r A[r][m] * B[r][n]        A = dy [rows][M] bf16, B = x [rows][N] bf16 (both token-major: the contraction index
+//                                             is the memory row), C fp32 [M][N] accumulated with atomics, rows split over workgroups
+//
+// The 64 x 64 kernel of gemm.hpp (launch_dw) re-reads each activation panel once per 64 output columns -- 302 MB through L2 -> LDS
+// for the 47 MB of a dW[1024, 256] over 18 432 tokens -- reads two transposed fragments per MFMA and keeps one k-step in flight; it
+// runs those shapes at ~280 TFLOP/s / 1.4 TB/s, far from either roofline.  Round 2 tried wider tiles on that kernel (register
+// staging: latency-bound, slower) and an LDS-DMA ring with its 64 x 64 tiles (fragment-read bound, slower); this kernel is the
+// combination:
+//   * 128 x 128 outputs per workgroup, 2 x 2 waves of 64 x 64: half the L2 -> LDS bytes, one transposed 8-byte fragment read per MFMA;
+//   * both operands L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into an NST-deep ring of RPS-row stages, NST - 1 stages in flight,
+//     ONE raw s_barrier + counted vmcnt per stage;
+//   * rows are stored as they are ([r][128] = 256 B) and read as MFMA fragments with ds_read_b64_tr_b16; the 16-byte chunk c of row r
+//     sits at c ^ sw(r), sw(r) = (r & 3) << 1 | bit3(r) << 3: the eight rows {r0 .. r0 + 3, r0 + 8 .. r0 + 11} that the 32 lanes of
+//     one LDS pass touch (32 bytes each) fall in eight different 32-byte bank groups;
+//   * the bias gradient (column sums of A) is one extra MFMA per fragment against a ones operand in the workgroups of column 0;
+//   * accumulators leave through a wave-private LDS transpose as 256-byte contiguous atomic rows.
+// Requirements (the dispatcher checks; everything else stays on launch_dw): bf16 operands without a loader prologue, M % 128 == 0,
+// N % 128 == 0, rows % RPS == 0, 16-byte aligned rows, batch 1.
+#pragma once
+#include "gemm_pipe.hpp"
+
+template <int RPS, int NST, bool WITH_BIAS>
+__global__ __launch_bounds__(256) void focal_dw_wide_kernel(const GemmParams p) {
+  constexpr int A_BYTES = RPS * 256, STAGE_BYTES = 2 * A_BYTES;
+  constexpr int APIECES = RPS / 4;  // 1 KB pieces (4 rows) of the A part; as many for B
+  constexpr int LPW = RPS / 8;      // pieces per wave per stage
+  static_assert(APIECES % 4 == 0, "a piece index must be an A piece or a B piece for all four waves");
+  constexpr int WPITCH = 64 + 4;
+  static_assert(NST * STAGE_BYTES >= 4 * 16 * WPITCH * 4, "epilogue staging must fit in the ring");
+  extern __shared__ __attribute__((aligned(1024))) char dww_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = p.N / 128, ntiles = (p.M / 128) * tiles_n;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = logical % ntiles, sp = logical / ntiles;
+  const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+  const int KT = p.K / RPS;
+  const int kt_per = (KT + p.splits - 1) / p.splits;
+  const int kt0 = sp * kt_per, kt1 = min(KT, kt0 + kt_per);
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+  float* C = reinterpret_cast<float*>(p.C);
+
+  // ---- fill plan: piece q = wave + 4 t covers stage rows 4 q' .. 4 q' + 3 of A (q < APIECES) or B; lane -> row + lane / 16, position lane % 16
+  uint32_t goff[LPW];
+  const char* gbase[LPW];
+  long gstep[LPW];
+#pragma unroll
+  for (int t = 0; t < LPW; ++t) {
+    const int q = wave + 4 * t;
+    const bool isA = 4 * t < APIECES;
+    const int row = 4 * (isA ? q : q - APIECES) + (lane >> 4), pos = lane & 15;
+    const int chunk = pos ^ (((row & 3) << 1) | (((row >> 3) & 1) << 3));
+    if (isA) {
+      goff[t] = (uint32_t)(((long)row * p.lda + m0 + chunk * 8) * 2);
+      gbase[t] = reinterpret_cast<const char*>(A);
+      gstep[t] = (long)RPS * p.lda * 2;
+    } else {
+      goff[t] = (uint32_t)(((long)row * p.ldb + n0 + chunk * 8) * 2);
+      gbase[t] = reinterpret_cast<const char*>(B);
+      gstep[t] = (long)RPS * p.ldb * 2;
+    }
+  }
+  auto fill = [&](int kt, int stage) {
+#pragma unroll
+    for (int t = 0; t < LPW; ++t) {
+      const int q = wave + 4 * t;
+      char* dst = dww_lds + stage * STAGE_BYTES + q * 1024;
+      __builtin_amdgcn_global_load_lds((pipe_glb_ptr)(gbase[t] + (long)kt * gstep[t] + goff[t]), (pipe_lds_ptr)dst, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4], accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = WITH_BIAS && (n0 == 0) && (wn == 0);
+  // the column-sum MFMAs are issued by every wave (against a zero operand where the sums are not wanted): a branch here would split
+  // the k-step into basic blocks and stop the scheduler from moving the next fragment reads above this step's MFMAs
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)(do_bias ? 1.0f : 0.0f);
+
+  // transposed-fragment addresses inside a stage: row 8 g + tq (+ 4; + 32 kk), columns 16 tile + 4 tp .. + 3
+  const int row_lo = 8 * g + tq;
+  const int sw = ((row_lo & 3) << 1) | (((row_lo >> 3) & 1) << 3);  // unchanged by + 4 and + 32
+  int fr_a[4], fr_b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    fr_a[i] = row_lo * 256 + (((8 * wm + 2 * i + (tp >> 1)) ^ sw) << 4) + (tp & 1) * 8;
+    fr_b[i] = A_BYTES + row_lo * 256 + (((8 * wn + 2 * i + (tp >> 1)) ^ sw) << 4) + (tp & 1) * 8;
+  }
+  const uint32_t lds0 = pipe_lds_addr(dww_lds);
+  auto compute = [&](int stage) {
+    const uint32_t sb = lds0 + stage * STAGE_BYTES;
+    pipe_static_for<0, RPS / 32>([&](auto kc) {
+      constexpr int KO = decltype(kc)::value * 8192;
+      bf16x4 al[4], ah[4], bl[4], bh[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        al[i] = pipe_lds_read_tr<KO>(sb + fr_a[i]);
+        ah[i] = pipe_lds_read_tr<KO + 1024>(sb + fr_a[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bl[j] = pipe_lds_read_tr<KO>(sb + fr_b[j]);
+        bh[j] = pipe_lds_read_tr<KO + 1024>(sb + fr_b[j]);
+      }
+      bf16x8 xa[4], wb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xa[i] = __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3, 4, 5, 6, 7);
+        wb[i] = __builtin_shufflevector(bl[i], bh[i], 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      pipe_lds_wait(xa, wb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mma16(wb[j], xa[i], acc[i][j]);
+      if (WITH_BIAS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = mma16(ones, xa[i], accb[i]);
+      }
+    });
+  };
+
+  const int nk = kt1 - kt0;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) fill(kt0 + s, s);
+  int stage = 0, fstage = NST - 1;
+  for (int i = 0; i < nk; ++i) {
+    const int ahead = nk - 1 - i;  // stages issued beyond this one: min(NST - 2, ahead) stay in flight
+    if (NST >= 4 && ahead >= 2) pipe_wait_barrier<2 * LPW>();
+    else if (NST >= 3 && ahead >= 1) pipe_wait_barrier<LPW>();
+    else pipe_wait_barrier<0>();
+    if (i + NST - 1 < nk) fill(kt0 + i + NST - 1, fstage);
+    compute(stage);
+    stage = (stage + 1 == NST) ? 0 : stage + 1;
+    fstage = (fstage + 1 == NST) ? 0 : fstage + 1;
+  }
+  asm volatile("s_barrier" ::: "memory");  // the ring is re-used as epilogue staging
+
+  // ---- epilogue: D[n][m] accumulators -> this wave's [16 m][64 n] fp32 staging -> 256-byte contiguous atomics per output row
+  float* est = reinterpret_cast<float*>(dww_lds) + wave * 16 * WPITCH;
+  const int nc = n0 + 64 * wn + lane;
+  const float badd = (p.bias && sp == 0) ? p.bias[nc] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v = acc[i][j] * p.alpha;
+      *reinterpret_cast<float4*>(est + l15 * WPITCH + j * 16 + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier needed
+    float* crow = C + (long)(m0 + 64 * wm + 16 * i) * p.ldc + nc;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) atomicAdd(crow + (long)r * p.ldc, est[r * WPITCH + lane] + badd);
+    if (do_bias && g == 0) atomicAdd(p.colsumA + m0 + 64 * wm + 16 * i + l15, accb[i][0]);
+  }
+}
+
+template <int RPS, int NST>
+static inline hipError_t focal_launch_dw_wide(const GemmParams& p, hipStream_t stream) {
+  constexpr int LDS_BYTES = NST * RPS * 512;
+  auto kern = focal_dw_wide_kernel<RPS, NST, true>;
+  auto kern0 = focal_dw_wide_kernel<RPS, NST, false>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern0), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid((p.M / 128) * (p.N / 128) * p.splits);
+  if (p.colsumA) hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL(kern0, grid, dim3(256), LDS_BYTES, stream, p);
+  return hipGetLastError();
+}

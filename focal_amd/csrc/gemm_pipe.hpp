@@ -17,6 +17,7 @@
 // Requires N % BN == 0, K % 64 == 0, 16-byte aligned rows (the dispatcher checks; everything else stays on gemm.hpp's
 // kernel); M may be ragged.
 #pragma once
+#include <type_traits>
 #include "gemm.hpp"
 
 template <int N> __device__ __forceinline__ void pipe_wait_barrier() {
@@ -26,6 +27,38 @@ template <int N> __device__ __forceinline__ void pipe_wait_barrier() {
 
 typedef __attribute__((address_space(3))) void* pipe_lds_ptr;
 typedef const __attribute__((address_space(1))) void* pipe_glb_ptr;
+
+// LDS fragment reads as inline asm.  hipcc cannot tell which ring stage a visible LDS read touches, so it guards EVERY such read with
+// s_waitcnt vmcnt(0) while an LDS-DMA is in flight -- i.e. it waits for the prefetch it has just issued, and a ring of any depth
+// degenerates to load -> wait -> multiply (the r1 kernels ran like that; build/isa shows the wait in front of the first ds_read of
+// every k-step).  Reads the compiler cannot see are not guarded; the kernel orders them itself: the counted vmcnt of
+// pipe_wait_barrier before, pipe_lds_wait (lgkmcnt(0), tied to the fragment registers so no MFMA can move above it) after.
+__device__ __forceinline__ uint32_t pipe_lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF> __device__ __forceinline__ bf16x8 pipe_lds_read128(uint32_t a) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+template <int OFF> __device__ __forceinline__ bf16x4 pipe_lds_read_tr(uint32_t a) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+template <int NA, int NB> __device__ __forceinline__ void pipe_lds_wait(bf16x8 (&a)[NA], bf16x8 (&b)[NB]) {
+  static_assert(NA == 4 && (NB == 2 || NB == 4), "fragment counts of the 64-row wave tiles");
+  if constexpr (NB == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
+}
+template <int I, int N, typename F> __device__ __forceinline__ void pipe_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    pipe_static_for<I + 1, N>(f);
+  }
+}
 
 template <typename TC, int EPI, bool TRB, int BM, int BN, int NST, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const GemmParams p) {
@@ -106,38 +139,41 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment addresses inside a stage: row (lane & 15) of a 16-row tile, chunk (kk * 4 + lane / 16) ^ swizzle
+  static_assert(TM == 4, "pipe_lds_wait is written for 64-row wave tiles");
   const int swz = (lane >> 1) & 7, g = lane >> 4;
-  const int fo0 = (lane & 15) * 128 + ((g ^ swz) << 4), fo1 = (lane & 15) * 128 + (((4 + g) ^ swz) << 4);
+  const uint32_t lds0 = pipe_lds_addr(pipe_lds);
+  const uint32_t fo0 = lds0 + (lane & 15) * 128 + ((g ^ swz) << 4), fo1 = lds0 + (lane & 15) * 128 + (((4 + g) ^ swz) << 4);
   const int a_off = wm * WR * 128, b_off = (BM + wn * WC) * 128;
   // transposed W: this lane reads k-row 8 g + q (and + 4), columns 4 p .. 4 p + 3 of a 16-column tile (q = (lane & 15) >> 2, p = lane & 3)
   const int tr_krow = 8 * g + ((lane & 15) >> 2), tr_swz = ((lane & 15) >> 2) << 1;
   const int tr_in = ((lane & 3) >> 1) * 16 + (lane & 1) * 8;  // byte offset of columns 4 p .. 4 p + 3 inside their pair of 16-byte chunks
+  uint32_t tr_a[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) tr_a[j] = lds0 + BM * 128 + tr_krow * (BN * 2) + ((((wn * WC + j * 16) >> 3) ^ tr_swz) << 4) + tr_in;
 
   auto compute = [&](int stage) {
-    const char* s = pipe_lds + stage * STAGE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int fo = kk ? fo1 : fo0;
+    const uint32_t so = stage * STAGE_BYTES;
+    pipe_static_for<0, 2>([&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
+      const uint32_t fa = (kk ? fo1 : fo0) + so + a_off, fb = (kk ? fo1 : fo0) + so + b_off;
       bf16x8 xa[TM], wb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(s + a_off + i * 2048 + fo);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (!TRB) {
-          wb[j] = *reinterpret_cast<const bf16x8*>(s + b_off + j * 2048 + fo);
+      pipe_static_for<0, TM>([&](auto ic) { xa[decltype(ic)::value] = pipe_lds_read128<decltype(ic)::value * 2048>(fa); });
+      pipe_static_for<0, TN>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (!TRB) {
+          wb[j] = pipe_lds_read128<j * 2048>(fb);
         } else {
-          typedef __attribute__((address_space(3))) bf16x4* tr_ptr;
-          const char* a0 = s + BM * 128 + (kk * 32 + tr_krow) * (BN * 2) + ((((wn * WC + j * 16) >> 3) ^ tr_swz) << 4) + tr_in;
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr)(a0));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr)(a0 + 4 * BN * 2));
-          wb[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const bf16x4 lo = pipe_lds_read_tr<kk * 32 * BN * 2>(tr_a[j] + so);
+          const bf16x4 hi = pipe_lds_read_tr<kk * 32 * BN * 2 + 4 * BN * 2>(tr_a[j] + so);
+          wb[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-      }
+      });
+      pipe_lds_wait(xa, wb);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mma16(wb[j], xa[i], acc[i][j]);
-    }
+    });
   };
 
 #pragma unroll

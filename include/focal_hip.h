@@ -156,6 +156,9 @@ int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const vo
 /* Number of workgroups focal_linear_bwd_weight launches for this descriptor (output tiles x token splits): lets a caller match its
  * calls against the launch shapes of a profiler trace (bench.py's in-step roofline).  0 = invalid descriptor. */
 int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d);
+/* Output-tile edge of that launch: 64 (focal_gemm_kernel, 256 threads) or 128 (focal_dw_wide_kernel, the LDS-DMA kernel for outputs
+ * of >= 1024 x 256).  0 = invalid descriptor. */
+int focal_linear_bwd_weight_tile(const focal_linear_desc* d);
 
 /* Fused MLP branch of a Swin block (models/SwinModules.py:18-34 Mlp.forward + the residual / DropPath of :339-341), bf16,
  * C = 64 -> hidden = 256 -> C (Swin stage 0, where 2/3 of the model's hidden-activation bytes are; focal_mlp_supported says

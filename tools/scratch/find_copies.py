@@ -23,3 +23,19 @@ for e in prof.events():
         cnt[(e.name, str(e.input_shapes)[:60], st[0][-90:] if st else "?")] += 1
 for k, v in cnt.most_common(40):
     print(v, k)
+print("---- ops that launched a Memcpy / Memset")
+cnt = collections.Counter()
+for e in prof.events():
+    ks = [k for k in (getattr(e, "kernels", None) or []) if "emcpy" in k.name or "emset" in k.name or "copyBuffer" in k.name]
+    if ks:
+        st = [s for s in (e.stack or []) if "focal_amd" in s or "bench.py" in s or "/src/" in s]
+        cnt[(e.name, ks[0].name[:40], str(e.input_shapes)[:50], " <- ".join(x[-70:] for x in st[:2]) if st else "?")] += len(ks)
+for k, v in cnt.most_common(60):
+    print(v, k)
+print("---- device-side events named like copies")
+c2 = collections.Counter()
+for e in prof.events():
+    if ("emcpy" in e.name or "emset" in e.name or "copyBuffer" in e.name):
+        c2[(e.name[:60], str(e.device_type))] += 1
+for k, v in c2.most_common(20):
+    print(v, k)
