@@ -150,7 +150,7 @@ class Step:
               for l, mm in self.x.items()}  # negation + scaling, folded into the DFT
         return v1, v2
 
-    # The step in three capturable segments with the two data-parallel collectives between them:
+    # The step in capturable segments with the data-parallel collectives between them:
     #   A: zero_grad, views (DFT), both backbone passes, pack the embeddings     -> [all-gather embeddings]
     #   B: loss head on the global batch, backward                                -> [all-reduce gradient arena]
     #   C: AdamW, loss value
@@ -173,6 +173,22 @@ class Step:
         self.loss.copy_(loss.detach())
         self.feats = None
 
+    # With the loss head row-sharded over the ranks, segment B splits at the head's one small collective:
+    #   B1: similarity / distance rows, log-sum-exps, hinges of this rank's samples   -> [all-gather lse / diagonal means / partial terms]
+    #   B2: coefficient rows, dL/dz of this rank's samples, backward
+    def seg_b1(self):
+        self.feats = self.dist.unpack_gathered(self.gathered, self.keys, 2)
+        self.head = self.loss_fn.begin(*self.feats)
+
+    def exchange_head(self):
+        self.dist.exchange_loss_chunks(self.head)
+
+    def seg_b2(self):
+        loss = self.loss_fn.finish()
+        loss.backward()
+        self.loss.copy_(loss.detach())
+        self.feats = None
+
     def reduce(self):
         self.opt.reduce_gradients()
 
@@ -182,7 +198,12 @@ class Step:
     def run(self):
         self.seg_a()
         self.exchange()
-        self.seg_b()
+        if self.dist.shard_loss_head():
+            self.seg_b1()
+            self.exchange_head()
+            self.seg_b2()
+        else:
+            self.seg_b()
         self.reduce()
         self.seg_c()
 
@@ -208,28 +229,41 @@ class Step:
                     self.run()
                 graphs = (whole,)
             else:
-                ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                shard = self.dist.shard_loss_head()
+                ga, gb, gb2, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga, pool=pool, stream=stream, **mode):
                     self.seg_a()
                 self.exchange()  # eager, autograd-aware: links segment B's backward to segment A's forward
-                with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
-                    self.seg_b()
+                if shard:
+                    with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
+                        self.seg_b1()
+                    head = self.head
+                    self.exchange_head()
+                    with torch.cuda.graph(gb2, pool=ga.pool(), stream=stream, **mode):
+                        self.seg_b2()
+                else:
+                    head, gb2 = None, None
+                    with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
+                        self.seg_b()
                 self.reduce()
                 with torch.cuda.graph(gc, pool=ga.pool(), stream=stream, **mode):
                     self.seg_c()
-                graphs = (ga, gb, gc)
+                graphs = (ga, gb, gb2, gc)
             pool = graphs[0].pool()
             if attempt == 0:
                 self._warm_graphs = graphs
         if not multi:
             return graphs[0].replay
-        ga, gb, gc = graphs
+        ga, gb, gb2, gc = graphs
         packed = self.packed
 
         def replay():
             ga.replay()
             self.dist.replay_exchange(packed)
             gb.replay()
+            if gb2 is not None:
+                self.dist.exchange_loss_chunks(head)  # the persistent send / chunks buffers of the sharded head
+                gb2.replay()
             self.opt.reduce_gradients()
             gc.replay()
         return replay
@@ -290,7 +324,7 @@ class StepTracer:
         def dw(d, dy, x, dw_, db):
             wgs = lib.focal_linear_bwd_weight_workgroups(ctypes.byref(d))
             b, f = _dw_bytes_flops(d)
-            kern = ("focal_dw_wide_kernel<dW: dy^T x, fp32 atomics, 128x128 tiles, LDS-DMA ring>" if lib.focal_linear_bwd_weight_tile(ctypes.byref(d)) == 128
+            kern = ("focal_dw_ring_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles, LDS-DMA ring>" if lib.focal_linear_bwd_weight_kernel(ctypes.byref(d)) == 2
                     else "focal_gemm_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles>")
             return (kern, f"{wgs} workgroups x 256", b, f, "hbm", f"dW[{d.N},{d.K}] over {d.M} rows")
 
@@ -371,7 +405,7 @@ def roofline(a, step, device):
     traffic = None
     tf = os.path.join(ROOT, "profiles", "r2_pmc_groups.json")
     if os.path.exists(tf):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same eager step (tools/pmc_step_traffic.sh)
-        gkey = ("dW:" + top["launch_shape"].split()[0]) if top["kernel"].startswith("focal_gemm_kernel<dW") else \
+        gkey = ("dW:" + top["launch_shape"].split()[0]) if top["kernel"].startswith(("focal_gemm_kernel<dW", "focal_dw_ring_kernel")) else \
                ("ln_bwd:all" if top["kernel"].startswith("ln_bwd") else "mlp_bwd:all")
         traffic = json.load(open(tf))["groups"].get(gkey, {}).get("hbm_bytes_per_launch")
         traffic = round(traffic) if traffic else None
@@ -384,7 +418,27 @@ def roofline(a, step, device):
                              "avg_us": round(g["avg_us"], 2), "ms_per_step": round(g["us_per_step"] / 1e3, 4),
                              "GBps": round(g["bytes_per_launch"] / (g["avg_us"] * 1e-6) / 1e9, 1),
                              "TFLOPps": round(g["flops_per_launch"] / (g["avg_us"] * 1e-6) / 1e12, 1)} for g in groups[1:6]],
+           "families": _families(groups),
            "isolated": roofline_isolated(a, step, device)}
+    return out
+
+
+def _families(groups):
+    """The launch groups folded by what they compute (a family may span kernels and launch shapes: the weight gradients run on
+    focal_dw_ring_kernel, focal_gemm_kernel<dW ..> at several grids and inside mlp_bwd_kernel) -- the traced families only."""
+    fam = {}
+    for g in groups:
+        k = g["kernel"]
+        name = ("weight gradients (all dW launches)" if k.startswith(("focal_gemm_kernel<dW", "focal_dw_ring_kernel")) else k.split("<")[0].split(" ")[0])
+        f = fam.setdefault(name, [0.0, 0.0, 0.0, 0.0])
+        f[0] += g["calls_per_step"]
+        f[1] += g["us_per_step"]
+        f[2] += g["bytes_per_launch"] * g["calls_per_step"]
+        f[3] += g["flops_per_launch"] * g["calls_per_step"]
+    out = [{"family": n, "calls_per_step": round(f[0], 2), "ms_per_step": round(f[1] / 1e3, 4), "GBps": round(f[2] / (f[1] * 1e-6) / 1e9, 1),
+            "frac_of_hbm_peak": round(f[2] / (f[1] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "TFLOPps": round(f[3] / (f[1] * 1e-6) / 1e12, 1)}
+           for n, f in fam.items()]
+    out.sort(key=lambda e: -e["ms_per_step"])
     return out
 
 

@@ -105,7 +105,7 @@ PROTOTYPES = {
     "focal_linear_bwd_data": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight_workgroups": (C.c_int, [C.POINTER(LinearDesc)]),
-    "focal_linear_bwd_weight_tile": (C.c_int, [C.POINTER(LinearDesc)]),
+    "focal_linear_bwd_weight_kernel": (C.c_int, [C.POINTER(LinearDesc)]),
     "focal_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P]),
     "focal_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P]),
@@ -118,6 +118,9 @@ PROTOTYPES = {
     "focal_small_linear_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P]),
     "focal_loss_head_workspace": (C.c_size_t, [C.POINTER(LossDesc)]),
     "focal_loss_head": (C.c_int, [C.POINTER(LossDesc), C.POINTER(P), P, C.POINTER(P), P, C.c_size_t, P]),
+    "focal_loss_head_exchange_floats": (C.c_size_t, [C.POINTER(LossDesc), C.c_int]),
+    "focal_loss_head_shard_a": (C.c_int, [C.POINTER(LossDesc), C.c_int, C.c_int, C.POINTER(P), P, C.POINTER(P), P, P, C.c_size_t, P]),
+    "focal_loss_head_shard_b": (C.c_int, [C.POINTER(LossDesc), C.c_int, C.c_int, C.POINTER(P), P, C.POINTER(P), P, P, C.c_size_t, P]),
     "focal_adamw_multi": (C.c_int, [C.POINTER(AdamWDesc), C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P),
                                     C.POINTER(P), C.POINTER(P), C.POINTER(C.c_long), P, P, P]),
     "focal_cast_bf16": (C.c_int, [P, P, C.c_long, P]),

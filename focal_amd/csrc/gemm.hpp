@@ -591,20 +591,10 @@ static inline void focal_dw_plan(int M, int N, long rows, int* bm_out, int* bn_o
   *bm_out = bm; *bn_out = bn; *splits_out = (int)splits;
 }
 
-// Launch plan of the 128 x 128 LDS-DMA weight-gradient kernel (gemm_dw_wide.hpp): whether it takes the shape, and its split count.
-static inline bool focal_dw_wide_plan(int M, int N, long rows, int* splits_out) {
-  static const bool off = getenv("FOCAL_DW_NOWIDE") != nullptr;
-  static const long min_out = getenv("FOCAL_DWW_MIN_OUT") ? atol(getenv("FOCAL_DWW_MIN_OUT")) : 262144;
-  static const long target_wg = getenv("FOCAL_DWW_WGS") ? atol(getenv("FOCAL_DWW_WGS")) : 256;
-  static const long min_rows = getenv("FOCAL_DWW_MIN_ROWS") ? atol(getenv("FOCAL_DWW_MIN_ROWS")) : 256;
-  if (off || M % 128 || N % 128 || rows % 64 || (long)M * N < min_out) return false;
-  const long tiles = (long)(M / 128) * (N / 128);
-  long splits = (target_wg + tiles - 1) / tiles;
-  const long max_splits = rows / min_rows;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  *splits_out = (int)splits;
-  return true;
+// Shapes the LDS-DMA ring weight-gradient kernel (gemm_dw_ring.hpp) takes, given bf16 operands without a loader prologue.
+static inline bool focal_dw_ring_shape(int M, int N, long rows) {
+  static const bool off = getenv("FOCAL_DW_NORING") != nullptr;
+  return !off && M % 64 == 0 && N % 64 == 0 && rows % 64 == 0 && rows >= 64;
 }
 
 // Host-side dispatch (gemm_dispatch.inc, instantiated per compute type in gemm_bf16.hip / gemm_f32.hip).

@@ -2,7 +2,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "gemm_pipe.hpp"
-#include "gemm_dw_wide.hpp"
+#include "gemm_dw_ring.hpp"
 #define GEMM_CT bf16_t
 #define GEMM_FN focal_launch_gemm_bf16
 #include "gemm_dispatch.inc"

@@ -3,7 +3,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "gemm_pipe.hpp"
-#include "gemm_dw_wide.hpp"
+#include "gemm_dw_ring.hpp"
 #define GEMM_CT float
 #define GEMM_FN focal_launch_gemm_f32
 #include "gemm_dispatch.inc"

@@ -47,11 +47,13 @@ template <int OFF> __device__ __forceinline__ bf16x4 pipe_lds_read_tr(uint32_t a
   return v;
 }
 template <int NA, int NB> __device__ __forceinline__ void pipe_lds_wait(bf16x8 (&a)[NA], bf16x8 (&b)[NB]) {
-  static_assert(NA == 4 && (NB == 2 || NB == 4), "fragment counts of the 64-row wave tiles");
-  if constexpr (NB == 4)
+  static_assert((NA == 4 && (NB == 2 || NB == 4)) || (NA == 2 && NB == 2), "fragment counts of the wave tiles in use");
+  if constexpr (NA == 4 && NB == 4)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-  else
+  else if constexpr (NA == 4)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
 }
 template <int I, int N, typename F> __device__ __forceinline__ void pipe_static_for(F&& f) {
   if constexpr (I < N) {

@@ -155,29 +155,25 @@ extern "C" int focal_linear_bwd_weight(const focal_linear_desc* d, const void* d
   return focal_launch_gemm(s, p, (hipStream_t)stream);
 }
 
-// the launch plan of focal_linear_bwd_weight for this descriptor: (tile edge, workgroups)
-static bool dw_launch_plan(const focal_linear_desc* d, int* tile, int* wgs) {
+// the launch plan of focal_linear_bwd_weight for this descriptor: (kernel: 1 = focal_gemm_kernel, 2 = focal_dw_ring_kernel; workgroups)
+static bool dw_launch_plan(const focal_linear_desc* d, int* kernel, int* wgs) {
   if (check_desc(d) != FOCAL_OK) return false;
-  int ws = 0;
-  const bool masked = d->epilogue == FOCAL_EPI_RESIDUAL || (d->y_dtype == FOCAL_F32 && d->x_dtype != FOCAL_F32);
-  if (d->dtype == FOCAL_BF16 && d->x_dtype == FOCAL_BF16 && d->y_dtype == FOCAL_BF16 && !masked && focal_dw_wide_plan(d->N, d->K, d->M, &ws)) {
-    *tile = 128;
-    *wgs = (d->N / 128) * (d->K / 128) * ws;
-    return true;
-  }
   int bm, bn, splits;
   focal_dw_plan(d->N, d->K, d->M, &bm, &bn, &splits);
-  *tile = bm;
+  const bool masked = d->epilogue == FOCAL_EPI_RESIDUAL || (d->y_dtype == FOCAL_F32 && d->x_dtype != FOCAL_F32);
+  const bool ring = d->dtype == FOCAL_BF16 && d->x_dtype == FOCAL_BF16 && d->y_dtype == FOCAL_BF16 && !masked && bm == 64 && bn == 64 &&
+                    focal_dw_ring_shape(d->N, d->K, d->M);
+  *kernel = ring ? 2 : 1;
   *wgs = ((d->N + bm - 1) / bm) * ((d->K + bn - 1) / bn) * splits;
   return true;
 }
 
 extern "C" int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d) {
-  int tile, wgs;
-  return dw_launch_plan(d, &tile, &wgs) ? wgs : 0;
+  int kernel, wgs;
+  return dw_launch_plan(d, &kernel, &wgs) ? wgs : 0;
 }
 
-extern "C" int focal_linear_bwd_weight_tile(const focal_linear_desc* d) {
-  int tile, wgs;
-  return dw_launch_plan(d, &tile, &wgs) ? tile : 0;
+extern "C" int focal_linear_bwd_weight_kernel(const focal_linear_desc* d) {
+  int kernel, wgs;
+  return dw_launch_plan(d, &kernel, &wgs) ? kernel : 0;
 }

@@ -7,6 +7,19 @@
 //   ranking   G = X X^T -> D = cdist   -> block means, hinge -> E = (A + A^T) / D              -> dX = rowsum(E) X - E X
 //   orthogonality is row-local (one wave per sample).
 // Everything is fp32: with T = 0.07 the logits amplify cosine errors 14x.
+//
+// Row sharding over data-parallel ranks (focal_loss_head_shard_a / _b).  Every cross-sample matrix here is symmetric and the
+// gradient of a sample needs only ITS row of it: rank r of W owns the b / W subsequences it contributed (rows r0 .. r0 + bl - 1 of
+// each view half) and evaluates, over ALL columns, only those rows of S, of the softmax coefficients, of the distance matrix and of
+// its coefficients -- 1 / W of every GEMM and row pass.  Two things of the other ranks' rows enter a row of coefficients: the
+// log-sum-exp of the column's own row (softmax^T term) and the diagonal block mean of the column's subsequence (the transposed hinge).
+// Both are tiny vectors; phase A writes this rank's part of them (and its partial loss terms) into one exchange chunk, the caller
+// all-gathers the chunks (ONE small collective), phase B finishes.  focal_loss_head is the same code with one rank and no collective.
+struct Shard {
+  int r0, bl;        // first own subsequence, own subsequences (b / world)
+  int world, ch;     // ranks, floats per exchange chunk
+  int o_diag, o_terms;  // offsets inside a chunk: [lse of own rows: nblk_total * 2 bl | diag means: Q * bl | partial terms: 5 | pad]
+};
 #include "gemm.hpp"
 
 #define LOSS_MAXP 32   // InfoNCE problems  (2 views x mod pairs + mods)
@@ -64,19 +77,20 @@ __global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, in
   if (lane == 0) nrm[row] = n;
 }
 
-// one wave per row i of S[p,t]: lse over j != i, loss_i = lse_i - S[i][pos(i)]
-__global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, const float* __restrict__ S,
-                                                       float* __restrict__ lse, float* __restrict__ terms) {
+// one wave per OWN row i of S[p,t]: lse over j != i, loss_i = lse_i - S[i][pos(i)].  Own row w of block blk (w = h * bl + k: view half
+// h, own subsequence k) is row i = h * b + r0 + k of the block; its lse goes to slot (gb0 + blk) * 2 bl + w of this rank's chunk.
+__global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, Shard sh, int gb0,
+                                                       const float* __restrict__ S, float* __restrict__ lse_own, float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
-  const int n2 = 2 * b;
-  const long rows = (long)nprob * seq * n2p;
+  const int n2 = 2 * b, own = 2 * sh.bl;
+  const long rows = (long)nprob * seq * own;
   float acc0 = 0.f, acc1 = 0.f;  // contributions to terms[0] (shared family) / terms[1] (private family)
-  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
-    const int i = row % n2p;
-    if (i >= n2) continue;  // padding row (wave-uniform)
-    const int p = row / ((long)n2p * seq);
+  for (long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6); idx < rows; idx += (long)gridDim.x * 4) {
+    const long blk = idx / own;
+    const int w = idx % own, i = (w / sh.bl) * b + sh.r0 + (w % sh.bl);
+    const int p = blk / seq;
     const int kind = tab.p[p0 + p].kind;
-    const float* s = S + row * n2p;
+    const float* s = S + (blk * n2p + i) * n2p;
     float mx = -3.0e38f;
     for (int j = lane; j < n2; j += 64) if (j != i) mx = fmaxf(mx, s[j]);
     mx = wave_max(mx);
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, in
     sum = wave_sum(sum);
     const float l = mx + __logf(sum);
     if (lane == 0) {
-      lse[row] = l;
+      lse_own[(gb0 + blk) * own + w] = l;
       const float contrib = (l - s[(i + b) % n2]) / (float)(seq * n2);
       if (kind == 0) acc0 += contrib; else acc1 += contrib;
     }
@@ -94,40 +108,47 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, in
   block_term_add(acc1, terms + 1);
 }
 
-// in place S -> W (times the family weight): W_ij = [j != i](e^{S_ij - lse_i} + e^{S_ij - lse_j}) - 2 [j == pos(i)]
-__global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, float* __restrict__ S,
-                                                          const float* __restrict__ lse, float w_shared, float w_private) {
-  const int n2 = 2 * b;
-  const long total = (long)nprob * seq * n2p * n2p;
+// lse of row j (any rank's) of global block gb, from the gathered chunks
+__device__ __forceinline__ float lse_at(const float* __restrict__ xall, const Shard& sh, long gb, int j, int b) {
+  const int h = j >= b, s = j - h * b;
+  return xall[(long)(s / sh.bl) * sh.ch + gb * 2 * sh.bl + h * sh.bl + (s % sh.bl)];
+}
+
+// in place, OWN rows of S -> W (times the family weight): W_ij = [j != i](e^{S_ij - lse_i} + e^{S_ij - lse_j}) - 2 [j == pos(i)]
+__global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, Shard sh, int gb0,
+                                                          float* __restrict__ S, const float* __restrict__ xall, float w_shared, float w_private) {
+  const int n2 = 2 * b, own = 2 * sh.bl;
+  const long total = (long)nprob * seq * own * n2p;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int j = e % n2p;
-    const long row = e / n2p;
-    const int i = row % n2p;
-    const long base = row - i;  // first row of this (p, t)
-    const int p = row / ((long)n2p * seq);
+    const long idx = e / n2p, blk = idx / own;
+    const int w = idx % own, i = (w / sh.bl) * b + sh.r0 + (w % sh.bl);
+    const int p = blk / seq;
     const float wk = tab.p[p0 + p].kind == 0 ? w_shared : w_private;
-    float w = 0.f;
-    if (j != i && i < n2 && j < n2) {
-      const float s = S[e];
-      w = __expf(s - lse[row]) + __expf(s - lse[base + j]);
-      if (j == (i + b) % n2) w -= 2.0f;
+    float* sp = S + (blk * n2p + i) * n2p + j;
+    float wv = 0.f;
+    if (j != i && j < n2) {
+      const float sv = *sp;
+      wv = __expf(sv - lse_at(xall, sh, gb0 + blk, i, b)) + __expf(sv - lse_at(xall, sh, gb0 + blk, j, b));
+      if (j == (i + b) % n2) wv -= 2.0f;
     }
-    S[e] = w * wk;
+    *sp = wv * wk;
   }
 }
 
-// dz = (dzn - zn (zn . dzn)) / ||z||, scattered (+=) to the right sample / half of the source embeddings
-__global__ __launch_bounds__(256) void nce_unpack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, int dim, int width,
+// dz = (dzn - zn (zn . dzn)) / ||z||, scattered (+=) to the right sample / half of the source embeddings; own rows only
+__global__ __launch_bounds__(256) void nce_unpack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, int dim, int width, Shard sh,
                                                          const float* __restrict__ Zn, const float* __restrict__ nrm,
                                                          const float* __restrict__ dZn) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long rows = (long)nprob * seq * n2p;
-  if (row >= rows) return;
-  const int r = row % n2p, t = (row / n2p) % seq, p = row / ((long)n2p * seq);
-  if (r >= 2 * b) return;
+  const int lane = threadIdx.x & 63, own = 2 * sh.bl;
+  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= (long)nprob * seq * own) return;
+  const long blk = idx / own;
+  const int w = idx % own, h = w / sh.bl, sq_ = sh.r0 + (w % sh.bl);  // view half, subsequence
+  const int t = blk % seq, p = blk / seq;
+  const long row = blk * n2p + h * b + sq_;
   const PairProb pr = tab.p[p0 + p];
-  float* dst = (r < b) ? pr.d1 + ((long)r * seq + t) * dim + pr.off1 : pr.d2 + ((long)(r - b) * seq + t) * dim + pr.off2;
+  float* dst = (h == 0) ? pr.d1 + ((long)sq_ * seq + t) * dim + pr.off1 : pr.d2 + ((long)sq_ * seq + t) * dim + pr.off2;
   float dot = 0.f;
   for (int c = lane; c < width; c += 64) dot += Zn[row * width + c] * dZn[row * width + c];
   dot = wave_sum(dot);
@@ -155,41 +176,42 @@ __global__ __launch_bounds__(256) void rank_pack_kernel(RankTable tab, int nq, i
   if (lane == 0) sq[row] = ss;
 }
 
-// in place G -> D = sqrt(max(0, |x_p|^2 + |x_q|^2 - 2 G_pq)), D_pp = 0   (torch.cdist mm path, loss.py:117)
-__global__ __launch_bounds__(256) void rank_dist_kernel(int nq, int B, int Bp, float* __restrict__ G, const float* __restrict__ sq) {
-  const long total = (long)nq * Bp * Bp;
+// in place, own rows [rs0, rs0 + nr) of G -> D = sqrt(max(0, |x_p|^2 + |x_q|^2 - 2 G_pq)), D_pp = 0   (torch.cdist mm path, loss.py:117)
+__global__ __launch_bounds__(256) void rank_dist_kernel(int nq, int B, int Bp, int rs0, int nr, float* __restrict__ G, const float* __restrict__ sq) {
+  const long total = (long)nq * nr * Bp;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int c = e % Bp;
-    const long row = e / Bp;
-    const int r = row % Bp;
-    const long qb = row - r;
-    const float d2 = sq[row] + sq[qb + c] - 2.0f * G[e];
-    G[e] = (r == c || r >= B || c >= B) ? 0.f : sqrtf(fmaxf(d2, 0.f));
+    const int r = rs0 + (int)((e / Bp) % nr);
+    const long qb = (e / ((long)Bp * nr)) * Bp;
+    const long at = (qb + r) * Bp + c;
+    const float d2 = sq[qb + r] + sq[qb + c] - 2.0f * G[at];
+    G[at] = (r == c || c >= B) ? 0.f : sqrtf(fmaxf(d2, 0.f));
   }
 }
 
-// Dbar[q][I][J] = mean of the seq x seq block (self pairs excluded), loss.py:118-124
-__global__ __launch_bounds__(256) void rank_blockmean_kernel(int nq, int b, int seq, int Bp, const float* __restrict__ D, float* __restrict__ Dbar) {
-  const long total = (long)nq * b * b;
-  const int B = Bp;  // row pitch of D
+// Dbar[q][I][J] = mean of the seq x seq block (self pairs excluded), loss.py:118-124; own subsequences I, all J
+__global__ __launch_bounds__(256) void rank_blockmean_kernel(int nq, int b, int seq, int Bp, Shard sh, const float* __restrict__ D, float* __restrict__ Dbar) {
+  const long total = (long)nq * sh.bl * b;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int J = e % b, I = (e / b) % b, q = e / ((long)b * b);
-    const float* base = D + ((long)q * B + (long)I * seq) * B + (long)J * seq;
+    const int J = e % b, I = sh.r0 + (int)((e / b) % sh.bl), q = e / ((long)b * sh.bl);
+    const float* base = D + ((long)q * Bp + (long)I * seq) * Bp + (long)J * seq;
     float s = 0.f;
     for (int a = 0; a < seq; ++a)
-      for (int c = 0; c < seq; ++c) s += base[(long)a * B + c];  // the self pairs hold exact zeros
-    Dbar[e] = s / (float)(seq * seq - (I == J ? seq : 0));
+      for (int c = 0; c < seq; ++c) s += base[(long)a * Bp + c];  // the self pairs hold exact zeros
+    Dbar[((long)q * b + I) * b + J] = s / (float)(seq * seq - (I == J ? seq : 0));
   }
 }
 
-// one wave per (q, I): hinge over J != I (MarginRankingLoss(margin, y = -1), loss.py:127-135) and dL/dDbar
-__global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float margin, const float* __restrict__ Dbar,
-                                                         float* __restrict__ dDbar, float* __restrict__ terms) {
+// one wave per (q, own I): hinge over J != I (MarginRankingLoss(margin, y = -1), loss.py:127-135) and dL/dDbar of that row; the
+// row's diagonal mean goes to the exchange chunk (other ranks need it for the transposed hinge of their coefficient rows)
+__global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float margin, Shard sh, const float* __restrict__ Dbar,
+                                                         float* __restrict__ dDbar, float* __restrict__ diag_own, float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
   const float inv = 1.0f / ((float)b * (float)(b - 1));
   float acc = 0.f;
-  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < (long)nq * b; row += (long)gridDim.x * 4) {
-    const int I = row % b;
+  for (long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6); idx < (long)nq * sh.bl; idx += (long)gridDim.x * 4) {
+    const int I = sh.r0 + (int)(idx % sh.bl);
+    const long row = (idx / sh.bl) * b + I;
     const float* d = Dbar + row * b;
     const float dii = d[I];
     float loss = 0.f, cnt = 0.f;
@@ -205,29 +227,43 @@ __global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float ma
     cnt = wave_sum(cnt);
     if (lane == 0) {
       dDbar[row * b + I] = cnt * inv;
+      diag_own[idx] = dii;
       acc += loss * inv;
     }
   }
   block_term_add(acc, terms + 3);
 }
 
-// in place D -> E = w_rank * (A_pq + A_qp) / D_pq, A_pq = dDbar[I(p)][J(q)] / count(I, J); rowsum[p] = sum_q E_pq
-__global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq, int Bp, float w_rank, float* __restrict__ D,
-                                                         const float* __restrict__ dDbar, float* __restrict__ rowsum) {
+// in place, own rows of D -> E = w_rank * (A_pq + A_qp) / D_pq, A_pq = dDbar[I(p)][J(q)] / count(I, J); rowsum[p] = sum_q E_pq.
+// dDbar[J][I] of a column's subsequence J is re-derived from its diagonal mean (gathered) and Dbar[I][J] (block means are symmetric
+// up to the summation order of the 16 distances): -inv where the hinge of row J is active against I.
+__global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq, int Bp, float w_rank, float margin, Shard sh, float* __restrict__ D,
+                                                         const float* __restrict__ Dbar, const float* __restrict__ dDbar,
+                                                         const float* __restrict__ xall, float* __restrict__ rowsum) {
   const int lane = threadIdx.x & 63;
-  const int B = b * seq;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)nq * Bp) return;
-  const int p = row % Bp, q = row / Bp, I = p / seq;
-  const float* dd = dDbar + (long)q * b * b;
+  const int B = b * seq, nr = sh.bl * seq;
+  const float inv = 1.0f / ((float)b * (float)(b - 1));
+  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= (long)nq * nr) return;
+  const int q = idx / nr, p = sh.r0 * seq + (int)(idx % nr), I = p / seq;
+  const long row = (long)q * Bp + p;
+  const float* dd = dDbar + ((long)q * b + I) * b;
+  const float* db = Dbar + ((long)q * b + I) * b;
   float* drow = D + row * Bp;
   float rs = 0.f;
   for (int c = lane; c < Bp; c += 64) {
-    const int J = c / seq;
-    const float cnt = (float)(seq * seq - (I == J ? seq : 0));
-    const float dist = drow[c];
     float e = 0.f;
-    if (c != p && p < B && c < B && dist > 1e-12f) e = w_rank * (dd[(long)I * b + J] + dd[(long)J * b + I]) / (cnt * dist);
+    if (c != p && c < B) {
+      const int J = c / seq;
+      const float dist = drow[c];
+      if (dist > 1e-12f) {
+        const float cnt = (float)(seq * seq - (I == J ? seq : 0));
+        float a = dd[J];
+        if (J == I) a += a;
+        else if (xall[(long)(J / sh.bl) * sh.ch + sh.o_diag + q * sh.bl + (J % sh.bl)] - db[J] + margin > 0.f) a -= inv;
+        e = w_rank * a / (cnt * dist);
+      }
+    }
     drow[c] = e;
     rs += e;
   }
@@ -235,25 +271,24 @@ __global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq,
   if (lane == 0) rowsum[row] = rs;
 }
 
-__global__ __launch_bounds__(256) void rank_grad_kernel(RankTable tab, int nq, int B, int Bp, int dim, const float* __restrict__ X,
+__global__ __launch_bounds__(256) void rank_grad_kernel(RankTable tab, int nq, int Bp, int dim, int rs0, int nr, const float* __restrict__ X,
                                                         const float* __restrict__ rowsum, const float* __restrict__ EX) {
-  const long total = (long)nq * Bp * dim;
+  const long total = (long)nq * nr * dim;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long row = e / dim;
-    const int c = e % dim, q = row / Bp, s = row % Bp;
-    if (s >= B) continue;
-    atomicAdd(tab.d[q] + (long)s * dim + c, rowsum[row] * X[e] - EX[e]);
+    const int c = e % dim, s = rs0 + (int)((e / dim) % nr), q = e / ((long)dim * nr);
+    const long at = ((long)q * Bp + s) * dim + c;
+    atomicAdd(tab.d[q] + (long)s * dim + c, rowsum[(long)q * Bp + s] * X[at] - EX[at]);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ orthogonality
 // CosineEmbeddingLoss(target = -1, margin 0, mean) = mean(max(0, cos)), loss.py:89-106; one wave per sample.
-__global__ __launch_bounds__(256) void orth_kernel(PairTable tab, int nprob, int B, int dim, int width, float w_orth,
+__global__ __launch_bounds__(256) void orth_kernel(PairTable tab, int nprob, int B, int dim, int width, float w_orth, int rs0, int nr,
                                                    float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
   float acc = 0.f;
-  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < (long)nprob * B; row += (long)gridDim.x * 4) {
-    const int p = row / B, s = row % B;
+  for (long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6); idx < (long)nprob * nr; idx += (long)gridDim.x * 4) {
+    const int p = idx / nr, s = rs0 + (int)(idx % nr);
     const PairProb pr = tab.p[p];
     const float* x1 = pr.e1 + (long)s * dim + pr.off1;
     const float* x2 = pr.e2 + (long)s * dim + pr.off2;
@@ -277,23 +312,34 @@ __global__ __launch_bounds__(256) void orth_kernel(PairTable tab, int nprob, int
   block_term_add(acc, terms + 2);
 }
 
-__global__ void loss_total_kernel(float* terms, float ws, float wp, float wo, float wr) {
-  terms[4] = ws * terms[0] + wp * terms[1] + wo * terms[2] + wr * terms[3];
+// terms[0..3] = sum over ranks of the partial terms in the gathered chunks, terms[4] = their weighted sum
+__global__ void loss_total_kernel(float* terms, const float* __restrict__ xall, Shard sh, float ws, float wp, float wo, float wr) {
+  float t[4];
+  for (int k = 0; k < 4; ++k) {
+    t[k] = 0.f;
+    for (int r = 0; r < sh.world; ++r) t[k] += xall[(long)r * sh.ch + sh.o_terms + k];
+    terms[k] = t[k];
+  }
+  terms[4] = ws * t[0] + wp * t[1] + wo * t[2] + wr * t[3];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 struct LossPlan {
   int b, n2, n2p, Bp, P_sh, P_pr, w_sh, w_pr, Q, O;
-  size_t off_zn, off_nrm, off_S, off_lse, off_dzn, off_X, off_sq, off_D, off_dbar, off_ddbar, off_rs, off_ex, total;
+  size_t off_zn, off_nrm, off_S, off_dzn, off_X, off_sq, off_D, off_dbar, off_ddbar, off_rs, off_ex, off_xchg, total;
+  Shard sh;
+  int rank;
 };
 
-static int loss_plan(const focal_loss_desc* d, LossPlan* pl) {
+static int loss_plan(const focal_loss_desc* d, int rank, int world, LossPlan* pl) {
   FOCAL_CHECK_ARG(d != nullptr, "loss_head: null descriptor");
   FOCAL_CHECK_ARG(d->n_mod >= 1 && d->n_mod <= 4, "loss_head: n_mod=%d out of [1, 4]", d->n_mod);
   FOCAL_CHECK_ARG(d->seq >= 1 && d->B % d->seq == 0 && d->B / d->seq >= 2, "loss_head: batch %d must be >= 2 whole subsequences of %d", d->B, d->seq);
   FOCAL_CHECK_ARG(d->dim % 8 == 0 && d->dim <= 1024, "loss_head: dim %d unsupported", d->dim);
   const int M = d->n_mod;
   pl->b = d->B / d->seq;
+  FOCAL_CHECK_ARG(world >= 1 && rank >= 0 && rank < world, "loss_head: rank %d of %d", rank, world);
+  FOCAL_CHECK_ARG(pl->b % world == 0, "loss_head: %d subsequences do not split over %d ranks (every rank contributes the same number)", pl->b, world);
   pl->n2 = 2 * pl->b;
   pl->n2p = (pl->n2 + 3) & ~3;   // pitches of the similarity / distance matrices (16-byte chunks along the GEMM reduction index)
   pl->Bp = (d->B + 3) & ~3;
@@ -306,12 +352,19 @@ static int loss_plan(const focal_loss_desc* d, LossPlan* pl) {
   FOCAL_CHECK_ARG(pl->P_sh + pl->P_pr <= LOSS_MAXP && pl->O <= LOSS_MAXO && pl->Q <= LOSS_MAXQ, "loss_head: too many modality pairs");
   const size_t rows_sh = (size_t)pl->P_sh * d->seq * pl->n2p, rows_pr = (size_t)pl->P_pr * d->seq * pl->n2p;
   const size_t zn = rows_sh * pl->w_sh + rows_pr * pl->w_pr;
+  // exchange chunk of one rank: lse of its rows of every (problem, step) block, its diagonal block means, its partial loss terms
+  const int bl = pl->b / world;
+  const long nblk = (long)(pl->P_sh + pl->P_pr) * d->seq;
+  pl->rank = rank;
+  pl->sh.r0 = rank * bl; pl->sh.bl = bl; pl->sh.world = world;
+  pl->sh.o_diag = (int)(nblk * 2 * bl);
+  pl->sh.o_terms = pl->sh.o_diag + pl->Q * bl;
+  pl->sh.ch = (pl->sh.o_terms + 5 + 63) & ~63;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
   pl->off_zn = take(zn);
   pl->off_dzn = take(zn);
   pl->off_nrm = take(rows_sh + rows_pr);
-  pl->off_lse = take(rows_sh + rows_pr);
   pl->off_S = take((rows_sh + rows_pr) * pl->n2p);
   pl->off_X = take((size_t)pl->Q * pl->Bp * d->dim);
   pl->off_ex = take((size_t)pl->Q * pl->Bp * d->dim);
@@ -320,14 +373,21 @@ static int loss_plan(const focal_loss_desc* d, LossPlan* pl) {
   pl->off_D = take((size_t)pl->Q * pl->Bp * pl->Bp);
   pl->off_dbar = take((size_t)pl->Q * pl->b * pl->b);
   pl->off_ddbar = take((size_t)pl->Q * pl->b * pl->b);
+  pl->off_xchg = take((size_t)pl->sh.ch);  // the one-rank call's own chunk
   pl->total = o * sizeof(float);
   return FOCAL_OK;
 }
 
 extern "C" size_t focal_loss_head_workspace(const focal_loss_desc* d) {
   LossPlan pl;
-  if (loss_plan(d, &pl) != FOCAL_OK) return 0;
+  if (loss_plan(d, 0, 1, &pl) != FOCAL_OK) return 0;
   return pl.total;
+}
+
+extern "C" size_t focal_loss_head_exchange_floats(const focal_loss_desc* d, int world) {
+  LossPlan pl;
+  if (loss_plan(d, 0, world, &pl) != FOCAL_OK) return 0;
+  return (size_t)pl.sh.ch;
 }
 
 static int f32_gemm(bool trb, int M, int N, int K, const float* A, long lda, long sA, const float* B, long ldb, long sB, float* C,
@@ -345,18 +405,44 @@ static int f32_gemm(bool trb, int M, int N, int K, const float* A, long lda, lon
   return focal_launch_gemm(s, p, st);
 }
 
-extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* feats, float* terms, float* const* dfeats,
-                               void* workspace, size_t workspace_bytes, void* stream) {
-  LossPlan pl;
-  if (int rc = loss_plan(d, &pl)) return rc;
-  FOCAL_CHECK_ARG(feats && terms && dfeats && workspace, "loss_head: null argument");
-  if (workspace_bytes < pl.total) {
-    focal_set_error("loss_head: workspace %zu < required %zu bytes", workspace_bytes, pl.total);
-    return FOCAL_EWORKSPACE;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  const int M = d->n_mod, B = d->B, dim = d->dim, seq = d->seq, b = pl.b, n2 = pl.n2, n2p = pl.n2p, Bp = pl.Bp, half = d->dim / 2;
-  float* ws = reinterpret_cast<float*>(workspace);
+struct LossTables { PairTable nce, orth; RankTable rk; };
+
+static void loss_tables(const focal_loss_desc* d, const float* const* feats, float* const* dfeats, LossTables* t) {
+  const int M = d->n_mod, half = d->dim / 2;
+  memset(t, 0, sizeof(*t));
+  // ---- problem tables (view-major feature order: index v*M + m)
+  int np = 0;
+  for (int v = 0; v < 2; ++v)  // shared family, loss.py:162-178
+    for (int m1 = 0; m1 < M; ++m1)
+      for (int m2 = m1 + 1; m2 < M; ++m2)
+        t->nce.p[np++] = PairProb{feats[v * M + m1], feats[v * M + m2], dfeats[v * M + m1], dfeats[v * M + m2], 0, 0, 0};
+  for (int m = 0; m < M; ++m)  // private family, loss.py:181-186
+    t->nce.p[np++] = PairProb{feats[m], feats[M + m], dfeats[m], dfeats[M + m], half, half, 1};
+  int no = 0;
+  for (int v = 0; v < 2; ++v)  // loss.py:195-209
+    for (int m = 0; m < M; ++m) {
+      t->orth.p[no++] = PairProb{feats[v * M + m], feats[v * M + m], dfeats[v * M + m], dfeats[v * M + m], 0, half, 2};
+      for (int m2 = m + 1; m2 < M; ++m2)
+        t->orth.p[no++] = PairProb{feats[v * M + m], feats[v * M + m2], dfeats[v * M + m], dfeats[v * M + m2], half, half, 2};
+    }
+  for (int i = 0; i < 2 * M; ++i) { t->rk.x[i] = feats[i]; t->rk.d[i] = dfeats[i]; }
+}
+
+// The rows a rank owns in an [n2p]-row block are the two runs h * b + r0 .. + bl - 1 (h = view half): a product over own rows is one
+// batched GEMM per half (all ranks of one: the two runs are adjacent and cover the block, one GEMM as before).
+template <typename F> static int over_own_halves(const LossPlan& pl, F&& f) {
+  if (pl.sh.world == 1) return f(0, pl.n2p);
+  for (int h = 0; h < 2; ++h)
+    if (int rc = f(h * pl.b + pl.sh.r0, pl.sh.bl)) return rc;
+  return FOCAL_OK;
+}
+
+// Phase A: everything up to the quantities other ranks need -- zero the gradients, InfoNCE similarity rows + lse, the ranking
+// distances, block means and hinge rows, the orthogonality term; this rank's lse / diagonal means / partial terms -> `chunk`.
+static int loss_phase_a(const focal_loss_desc* d, const LossPlan& pl, const float* const* feats, float* terms, float* const* dfeats,
+                        float* chunk, float* ws, hipStream_t st) {
+  const int M = d->n_mod, B = d->B, dim = d->dim, seq = d->seq, b = pl.b, n2p = pl.n2p, Bp = pl.Bp, half = d->dim / 2;
+  const Shard sh = pl.sh;
   // the binding hands over ONE allocation [2M gradients | terms]: a single memset node instead of 2M + 1
   const size_t gbytes = (size_t)B * dim * sizeof(float);
   // (any order of the 2M blocks inside it: the binding places a modality's two views next to each other)
@@ -376,79 +462,136 @@ extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* fea
     (void)hipMemsetAsync(terms, 0, 5 * sizeof(float), st);
     for (int i = 0; i < 2 * M; ++i) (void)hipMemsetAsync(dfeats[i], 0, gbytes, st);
   }
-
-  // ---- problem tables (view-major feature order: index v*M + m)
-  PairTable nce, orth;
-  memset(&nce, 0, sizeof(nce));
-  memset(&orth, 0, sizeof(orth));
-  int np = 0;
-  for (int v = 0; v < 2; ++v)  // shared family, loss.py:162-178
-    for (int m1 = 0; m1 < M; ++m1)
-      for (int m2 = m1 + 1; m2 < M; ++m2)
-        nce.p[np++] = PairProb{feats[v * M + m1], feats[v * M + m2], dfeats[v * M + m1], dfeats[v * M + m2], 0, 0, 0};
-  for (int m = 0; m < M; ++m)  // private family, loss.py:181-186
-    nce.p[np++] = PairProb{feats[m], feats[M + m], dfeats[m], dfeats[M + m], half, half, 1};
-  int no = 0;
-  for (int v = 0; v < 2; ++v)  // loss.py:195-209
-    for (int m = 0; m < M; ++m) {
-      orth.p[no++] = PairProb{feats[v * M + m], feats[v * M + m], dfeats[v * M + m], dfeats[v * M + m], 0, half, 2};
-      for (int m2 = m + 1; m2 < M; ++m2)
-        orth.p[no++] = PairProb{feats[v * M + m], feats[v * M + m2], dfeats[v * M + m], dfeats[v * M + m2], half, half, 2};
-    }
-  RankTable rk;
-  memset(&rk, 0, sizeof(rk));
-  for (int i = 0; i < 2 * M; ++i) { rk.x[i] = feats[i]; rk.d[i] = dfeats[i]; }
+  float* pterms = chunk + sh.o_terms;  // partial terms of this rank
+  (void)hipMemsetAsync(pterms, 0, 5 * sizeof(float), st);
+  LossTables tb;
+  loss_tables(d, feats, dfeats, &tb);
 
   // ---- InfoNCE: the two families may have different widths (tag == "noPrivate"), so they run as two groups
   size_t zoff = 0, roff = 0;
+  int gb0 = 0;
   for (int grp = 0; grp < 2; ++grp) {
     const int p0 = grp == 0 ? 0 : pl.P_sh, nprob = grp == 0 ? pl.P_sh : pl.P_pr, width = grp == 0 ? pl.w_sh : pl.w_pr;
     if (nprob == 0) continue;
-    const long rows = (long)nprob * seq * n2p;
+    const long rows = (long)nprob * seq * n2p, own_rows = (long)nprob * seq * 2 * sh.bl;
+    float* Zn = ws + pl.off_zn + zoff;
+    float* nrm = ws + pl.off_nrm + roff;
+    float* S = ws + pl.off_S + roff * n2p;
+    hipLaunchKernelGGL(nce_pack_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, dim, width, Zn, nrm);
+    if (int rc = over_own_halves(pl, [&](int row0, int nrow) {
+          return f32_gemm(false, nrow, n2p, width, Zn + (long)row0 * width, width, (long)n2p * width, Zn, width, (long)n2p * width,
+                          S + (long)row0 * n2p, n2p, (long)n2p * n2p, nprob * seq, 1.0f / d->temperature, st);
+        })) return rc;
+    hipLaunchKernelGGL(nce_rows_kernel, dim3(loss_row_blocks(own_rows)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, sh, gb0, S, chunk, pterms);
+    zoff += (size_t)rows * width;
+    roff += rows;
+    gb0 += nprob * seq;
+  }
+
+  // ---- temporal ranking, loss.py:189-192: distances, block means and hinges of the own rows
+  {
+    const int Q = pl.Q, rs0 = sh.r0 * seq, nr = sh.bl * seq;
+    float* X = ws + pl.off_X; float* sq = ws + pl.off_sq;
+    float* D = ws + pl.off_D; float* Dbar = ws + pl.off_dbar; float* dDbar = ws + pl.off_ddbar;
+    hipLaunchKernelGGL(rank_pack_kernel, dim3(ceil_div((long)Q * Bp, 4)), dim3(256), 0, st, tb.rk, Q, B, Bp, dim, X, sq);
+    const int mrows = sh.world == 1 ? Bp : nr;
+    if (int rc = f32_gemm(false, mrows, Bp, dim, X + (long)rs0 * dim, dim, (long)Bp * dim, X, dim, (long)Bp * dim, D + (long)rs0 * Bp, Bp,
+                          (long)Bp * Bp, Q, 1.0f, st)) return rc;
+    int eb = ceil_div((long)Q * nr * Bp, 256);
+    if (eb > 8192) eb = 8192;
+    hipLaunchKernelGGL(rank_dist_kernel, dim3(eb), dim3(256), 0, st, Q, B, Bp, rs0, nr, D, sq);
+    int bb = ceil_div((long)Q * sh.bl * b, 256);
+    if (bb > 4096) bb = 4096;
+    hipLaunchKernelGGL(rank_blockmean_kernel, dim3(bb), dim3(256), 0, st, Q, b, seq, Bp, sh, D, Dbar);
+    hipLaunchKernelGGL(rank_hinge_kernel, dim3(loss_row_blocks((long)Q * sh.bl)), dim3(256), 0, st, Q, b, d->margin, sh, Dbar, dDbar,
+                       chunk + sh.o_diag, pterms);
+    // ---- orthogonality (row-local)
+    hipLaunchKernelGGL(orth_kernel, dim3(loss_row_blocks((long)pl.O * nr)), dim3(256), 0, st, tb.orth, pl.O, B, dim, half, d->w_orth, rs0, nr, pterms);
+  }
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+// Phase B: `xall` = the chunks of all ranks in rank order.  Softmax coefficient rows and dL/dz of the own InfoNCE rows, ranking
+// coefficients and gradient of the own samples, the loss terms.
+static int loss_phase_b(const focal_loss_desc* d, const LossPlan& pl, const float* const* feats, float* terms, float* const* dfeats,
+                        const float* xall, float* ws, hipStream_t st) {
+  const int B = d->B, dim = d->dim, seq = d->seq, b = pl.b, n2 = pl.n2, n2p = pl.n2p, Bp = pl.Bp;
+  const Shard sh = pl.sh;
+  LossTables tb;
+  loss_tables(d, feats, dfeats, &tb);
+  size_t zoff = 0, roff = 0;
+  int gb0 = 0;
+  for (int grp = 0; grp < 2; ++grp) {
+    const int p0 = grp == 0 ? 0 : pl.P_sh, nprob = grp == 0 ? pl.P_sh : pl.P_pr, width = grp == 0 ? pl.w_sh : pl.w_pr;
+    if (nprob == 0) continue;
+    const long rows = (long)nprob * seq * n2p, own_rows = (long)nprob * seq * 2 * sh.bl;
     float* Zn = ws + pl.off_zn + zoff;
     float* dZn = ws + pl.off_dzn + zoff;
     float* nrm = ws + pl.off_nrm + roff;
-    float* lse = ws + pl.off_lse + roff;
     float* S = ws + pl.off_S + roff * n2p;
-    const int rb = ceil_div(rows, 4);
-    hipLaunchKernelGGL(nce_pack_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, n2p, dim, width, Zn, nrm);
-    if (int rc = f32_gemm(false, n2p, n2p, width, Zn, width, (long)n2p * width, Zn, width, (long)n2p * width, S, n2p, (long)n2p * n2p,
-                          nprob * seq, 1.0f / d->temperature, st)) return rc;
-    hipLaunchKernelGGL(nce_rows_kernel, dim3(loss_row_blocks(rows)), dim3(256), 0, st, nce, p0, nprob, seq, b, n2p, S, lse, terms);
-    int eb = ceil_div(rows * n2p, 256);
+    int eb = ceil_div(own_rows * n2p, 256);
     if (eb > 8192) eb = 8192;
-    hipLaunchKernelGGL(nce_weights_kernel, dim3(eb), dim3(256), 0, st, nce, p0, nprob, seq, b, n2p, S, lse, d->w_shared, d->w_private);
-    if (int rc = f32_gemm(true, n2p, width, n2p, S, n2p, (long)n2p * n2p, Zn, width, (long)n2p * width, dZn, width, (long)n2p * width,
-                          nprob * seq, 1.0f / ((float)seq * n2 * d->temperature), st)) return rc;
-    hipLaunchKernelGGL(nce_unpack_kernel, dim3(rb), dim3(256), 0, st, nce, p0, nprob, seq, b, n2p, dim, width, Zn, nrm, dZn);
+    hipLaunchKernelGGL(nce_weights_kernel, dim3(eb), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, sh, gb0, S, xall, d->w_shared, d->w_private);
+    if (int rc = over_own_halves(pl, [&](int row0, int nrow) {
+          return f32_gemm(true, nrow, width, n2p, S + (long)row0 * n2p, n2p, (long)n2p * n2p, Zn, width, (long)n2p * width,
+                          dZn + (long)row0 * width, width, (long)n2p * width, nprob * seq, 1.0f / ((float)seq * n2 * d->temperature), st);
+        })) return rc;
+    hipLaunchKernelGGL(nce_unpack_kernel, dim3(ceil_div(own_rows, 4)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, dim, width, sh, Zn, nrm, dZn);
     zoff += (size_t)rows * width;
     roff += rows;
+    gb0 += nprob * seq;
   }
-
-  // ---- temporal ranking, loss.py:189-192
   {
-    const int Q = pl.Q;
-    float* X = ws + pl.off_X; float* EX = ws + pl.off_ex; float* sq = ws + pl.off_sq; float* rs = ws + pl.off_rs;
+    const int Q = pl.Q, rs0 = sh.r0 * seq, nr = sh.bl * seq;
+    float* X = ws + pl.off_X; float* EX = ws + pl.off_ex; float* rs = ws + pl.off_rs;
     float* D = ws + pl.off_D; float* Dbar = ws + pl.off_dbar; float* dDbar = ws + pl.off_ddbar;
-    hipLaunchKernelGGL(rank_pack_kernel, dim3(ceil_div((long)Q * Bp, 4)), dim3(256), 0, st, rk, Q, B, Bp, dim, X, sq);
-    if (int rc = f32_gemm(false, Bp, Bp, dim, X, dim, (long)Bp * dim, X, dim, (long)Bp * dim, D, Bp, (long)Bp * Bp, Q, 1.0f, st)) return rc;
-    int eb = ceil_div((long)Q * Bp * Bp, 256);
-    if (eb > 8192) eb = 8192;
-    hipLaunchKernelGGL(rank_dist_kernel, dim3(eb), dim3(256), 0, st, Q, B, Bp, D, sq);
-    int bb = ceil_div((long)Q * b * b, 256);
-    if (bb > 4096) bb = 4096;
-    hipLaunchKernelGGL(rank_blockmean_kernel, dim3(bb), dim3(256), 0, st, Q, b, seq, Bp, D, Dbar);
-    hipLaunchKernelGGL(rank_hinge_kernel, dim3(loss_row_blocks((long)Q * b)), dim3(256), 0, st, Q, b, d->margin, Dbar, dDbar, terms);
-    hipLaunchKernelGGL(rank_coeff_kernel, dim3(ceil_div((long)Q * Bp, 4)), dim3(256), 0, st, Q, b, seq, Bp, d->w_rank, D, dDbar, rs);
-    if (int rc = f32_gemm(true, Bp, dim, Bp, D, Bp, (long)Bp * Bp, X, dim, (long)Bp * dim, EX, dim, (long)Bp * dim, Q, 1.0f, st)) return rc;
-    int gb = ceil_div((long)Q * Bp * dim, 256);
+    hipLaunchKernelGGL(rank_coeff_kernel, dim3(ceil_div((long)Q * nr, 4)), dim3(256), 0, st, Q, b, seq, Bp, d->w_rank, d->margin, sh, D, Dbar, dDbar,
+                       xall, rs);
+    if (int rc = f32_gemm(true, nr, dim, Bp, D + (long)rs0 * Bp, Bp, (long)Bp * Bp, X, dim, (long)Bp * dim, EX + (long)rs0 * dim, dim,
+                          (long)Bp * dim, Q, 1.0f, st)) return rc;
+    int gb = ceil_div((long)Q * nr * dim, 256);
     if (gb > 8192) gb = 8192;
-    hipLaunchKernelGGL(rank_grad_kernel, dim3(gb), dim3(256), 0, st, rk, Q, B, Bp, dim, X, rs, EX);
+    hipLaunchKernelGGL(rank_grad_kernel, dim3(gb), dim3(256), 0, st, tb.rk, Q, Bp, dim, rs0, nr, X, rs, EX);
   }
-
-  // ---- orthogonality
-  hipLaunchKernelGGL(orth_kernel, dim3(loss_row_blocks((long)pl.O * B)), dim3(256), 0, st, orth, pl.O, B, dim, half, d->w_orth, terms);
-  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, terms, d->w_shared, d->w_private, d->w_orth, d->w_rank);
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, terms, xall, sh, d->w_shared, d->w_private, d->w_orth, d->w_rank);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
+}
+
+static int loss_args(const focal_loss_desc* d, int rank, int world, const float* const* feats, float* terms, float* const* dfeats,
+                     void* workspace, size_t workspace_bytes, LossPlan* pl) {
+  if (int rc = loss_plan(d, rank, world, pl)) return rc;
+  FOCAL_CHECK_ARG(feats && terms && dfeats && workspace, "loss_head: null argument");
+  if (workspace_bytes < pl->total) {
+    focal_set_error("loss_head: workspace %zu < required %zu bytes", workspace_bytes, pl->total);
+    return FOCAL_EWORKSPACE;
+  }
+  return FOCAL_OK;
+}
+
+extern "C" int focal_loss_head(const focal_loss_desc* d, const float* const* feats, float* terms, float* const* dfeats,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  LossPlan pl;
+  if (int rc = loss_args(d, 0, 1, feats, terms, dfeats, workspace, workspace_bytes, &pl)) return rc;
+  float* ws = reinterpret_cast<float*>(workspace);
+  float* chunk = ws + pl.off_xchg;
+  if (int rc = loss_phase_a(d, pl, feats, terms, dfeats, chunk, ws, (hipStream_t)stream)) return rc;
+  return loss_phase_b(d, pl, feats, terms, dfeats, chunk, ws, (hipStream_t)stream);
+}
+
+extern "C" int focal_loss_head_shard_a(const focal_loss_desc* d, int rank, int world, const float* const* feats, float* terms,
+                                       float* const* dfeats, float* chunk, void* workspace, size_t workspace_bytes, void* stream) {
+  LossPlan pl;
+  if (int rc = loss_args(d, rank, world, feats, terms, dfeats, workspace, workspace_bytes, &pl)) return rc;
+  FOCAL_CHECK_ARG(chunk != nullptr, "loss_head_shard_a: null exchange chunk");
+  return loss_phase_a(d, pl, feats, terms, dfeats, chunk, reinterpret_cast<float*>(workspace), (hipStream_t)stream);
+}
+
+extern "C" int focal_loss_head_shard_b(const focal_loss_desc* d, int rank, int world, const float* const* feats, float* terms,
+                                       float* const* dfeats, const float* chunks, void* workspace, size_t workspace_bytes, void* stream) {
+  LossPlan pl;
+  if (int rc = loss_args(d, rank, world, feats, terms, dfeats, workspace, workspace_bytes, &pl)) return rc;
+  FOCAL_CHECK_ARG(chunks != nullptr, "loss_head_shard_b: null exchange buffer");
+  return loss_phase_b(d, pl, feats, terms, dfeats, chunks, reinterpret_cast<float*>(workspace), (hipStream_t)stream);
 }

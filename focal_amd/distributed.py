@@ -7,6 +7,8 @@ The path shards by whole subsequences.  There is exactly one exchang
   * gradients: because every rank differentiates the SAME global loss w.r.t. its own samples, the exact gradient of
     the global-batch loss is the SUM over ranks -> one all-reduce(SUM) over the flat gradient arena (no averaging).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -133,6 +135,19 @@ def gather_features(feature_dicts):
         return feature_dicts
     packed, keys = pack_features(feature_dicts)
     return unpack_gathered(exchange_packed(packed), keys, len(feature_dicts))
+
+
+@torch.no_grad()
+def exchange_loss_chunks(head):
+    """The one collective inside the row-sharded loss head (ops.ShardedLossHead): every rank's log-sum-exps / diagonal block means /
+    partial loss terms, ~70 KB per rank at a global batch of 2048 -- latency-bound, one call."""
+    dist.all_gather_into_tensor(head.chunks.view(-1), head.send)
+
+
+def shard_loss_head():
+    """Row-shard the loss head over the ranks (default under data parallelism; FOCAL_LOSS_REPLICATED=1 keeps round 1's replicated
+    evaluation of the whole global batch on every rank)."""
+    return is_dist() and os.environ.get("FOCAL_LOSS_REPLICATED") != "1"
 
 
 def all_reduce_gradients(arena, bucket_bytes=64 << 20):

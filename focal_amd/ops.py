@@ -364,8 +364,7 @@ def window_attn_bwd(d, qkv, bias_table, dout, dqkv, dbias_table):
 _LOSS_WS = {}
 
 
-def loss_head(feats1, feats2, temperature, margin, weights, seq=4, no_private=False, return_flat=False):
-    """feats{1,2}: lists (modality order) of fp32 [B, dim].  Returns (terms[5] device tensor, grads1, grads2)."""
+def _loss_setup(feats1, feats2, temperature, margin, weights, seq, no_private):
     feats = list(feats1) + list(feats2)
     _need_cuda(*feats)
     M = len(feats1)
@@ -390,10 +389,50 @@ def loss_head(feats1, feats2, temperature, margin, weights, seq=4, no_private=Fa
     terms = flat[2 * M * n:2 * M * n + 5]
     fa = (C.c_void_p * (2 * M))(*[_p(f) for f in feats])
     ga = (C.c_void_p * (2 * M))(*[_p(g) for g in grads])
+    return lib, d, M, n, feats, flat, grads, terms, fa, ga, ws
+
+
+def loss_head(feats1, feats2, temperature, margin, weights, seq=4, no_private=False, return_flat=False):
+    """feats{1,2}: lists (modality order) of fp32 [B, dim].  Returns (terms[5] device tensor, grads1, grads2)."""
+    lib, d, M, n, feats, flat, grads, terms, fa, ga, ws = _loss_setup(feats1, feats2, temperature, margin, weights, seq, no_private)
     check(lib.focal_loss_head(C.byref(d), fa, _p(terms), ga, _p(ws), ws.numel(), _stream()))
     if return_flat:  # the gradients as ONE tensor (they are views of it)
         return terms, grads[:M], grads[M:], flat[:2 * M * n]
     return terms, grads[:M], grads[M:]
+
+
+class ShardedLossHead:
+    """The loss head of `world` data-parallel ranks, each over the rows of its own samples (focal_loss_head_shard_a / _b).
+    `phase_a(...)` fills the persistent `send` buffer [n]; the caller all-gathers it into `chunks` [world, n];
+    `phase_b()` returns what `loss_head(..., return_flat=True)` returns; only the rank's own rows of the gradients are non-zero."""
+
+    _BUF = {}
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.state = None
+
+    def exchange_buffers(self, d, dev):
+        n = _lib.load().focal_loss_head_exchange_floats(C.byref(d), self.world)
+        if n == 0:
+            raise _lib.FocalHipError(f"loss_head (sharded): {_lib.load().focal_last_error().decode()}")
+        key = (dev, self.world, n)
+        if key not in self._BUF:  # address-stable: captured graph segments write / read them, the collective between them is eager
+            self._BUF[key] = (torch.zeros(n, dtype=torch.float32, device=dev), torch.zeros(self.world, n, dtype=torch.float32, device=dev))
+        return self._BUF[key]
+
+    def phase_a(self, feats1, feats2, temperature, margin, weights, seq=4, no_private=False):
+        lib, d, M, n, feats, flat, grads, terms, fa, ga, ws = _loss_setup(feats1, feats2, temperature, margin, weights, seq, no_private)
+        self.send, self.chunks = self.exchange_buffers(d, feats[0].device)
+        check(lib.focal_loss_head_shard_a(C.byref(d), self.rank, self.world, fa, _p(terms), ga, _p(self.send), _p(ws), ws.numel(), _stream()))
+        self.state = (lib, d, M, n, feats, flat, grads, terms, fa, ga, ws)
+        return self.send, self.chunks
+
+    def phase_b(self):
+        lib, d, M, n, feats, flat, grads, terms, fa, ga, ws = self.state
+        self.state = None
+        check(lib.focal_loss_head_shard_b(C.byref(d), self.rank, self.world, fa, _p(terms), ga, _p(self.chunks), _p(ws), ws.numel(), _stream()))
+        return terms, grads[:M], grads[M:], flat[:2 * M * n]
 
 
 # ------------------------------------------------------------------------------------------------ rows 5-6 (DeepSense)

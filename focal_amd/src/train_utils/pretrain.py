@@ -68,14 +68,21 @@ def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, 
         default_model.train()
         train_loss_list = []
         epoch_t0, epoch_windows = time_sync(), 0
+        pending = None
         for i, (time_loc_inputs, _) in enumerate(train_dataloader):
+            # the views of step k are drawn (host: coin flips, warp tables, up to ~5 ms for a TimeWarp of the audio window) while the
+            # GPU still runs step k - 1; only then is that step's loss read (the reference's per-step `loss.item()`, one step late
+            # on the wall clock, same values): the static loss buffer of the captured step must be read before the next replay
             view1 = augmenter.forward("random", time_loc_inputs)
             view2 = augmenter.forward("random", time_loc_inputs)
-            loss = graphed(view1, view2)
-            train_loss_list.append(loss.item())
+            if pending is not None:
+                train_loss_list.append(pending.item())
+            pending = graphed(view1, view2)
             n = next(iter(next(iter(time_loc_inputs.values())).values())).shape[0] * fdist.world()
             windows += n
             epoch_windows += n
+        if pending is not None:
+            train_loss_list.append(pending.item())
         if epoch % 10 == 0 or epoch == epochs - 1:
             dt = max(time_sync() - epoch_t0, 1e-9)
             logging.info(f"epoch {epoch}: {epoch_windows / dt:.1f} windows/s ({epoch_windows} windows in {dt:.3f} s; "

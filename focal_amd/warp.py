@@ -73,30 +73,73 @@ def warp_positions(L, knots, order):
     return np.clip(c, 0.0, 1.0) * (L - 1)
 
 
+_END_WIN = 48
+_CACHE = {}
+
+
+def _interior_matrix():
+    """[4, TAPS]: row j = the prefilter response sqrt(3) z1^|.| placed where B-spline coefficient k - 1 + j gathers its samples."""
+    if "G" not in _CACHE:
+        g = math.sqrt(3.0) * _Z1 ** np.abs(np.arange(-RADIUS, RADIUS + 1))
+        G = np.zeros((4, TAPS))
+        for j in range(4):  # coefficient k - 1 + j gathers samples k - 1 + j - RADIUS .. k - 1 + j + RADIUS  -> taps j .. j + 2 RADIUS
+            G[j, j:j + 2 * RADIUS + 1] = g
+        _CACHE["G"] = G
+    return _CACHE["G"]
+
+
+def _end_window_spline():
+    """Piecewise-cubic coefficients of the 48 not-a-knot basis splines of a 48-sample window (computed once): value at position q
+    in segment i = floor(q) is c0[i] + t (c1[i] + t (c2[i] + t c3[i])), t = q - i, each c* a row of 48 basis weights."""
+    if "end" not in _CACHE:
+        win = _END_WIN
+        xk = np.arange(win, dtype=np.float64)
+        # evaluate every basis spline and its derivatives' finite form at 4 points per segment -> exact cubic coefficients
+        tt = np.array([0.0, 0.25, 0.5, 0.75])
+        q = (xk[:-1, None] + tt[None, :]).ravel()
+        vals = _natural_cubic_through(xk, np.eye(win), q).reshape(win - 1, 4, win)  # [segment, point, basis]
+        V = np.vander(tt, 4, increasing=True)  # [point, power]
+        coef = np.einsum("kp,spb->skb", np.linalg.inv(V), vals)  # [segment, power, basis]
+        _CACHE["end"] = coef
+    return _CACHE["end"]
+
+
+def _end_weights(q):
+    """[len(q), 48] basis weights of the end-window spline at positions q in [0, 47]."""
+    coef = _end_window_spline()
+    i = np.clip(np.floor(q).astype(np.int64), 0, _END_WIN - 2)
+    t = (q - i)[:, None]
+    c = coef[i]  # [n, 4, 48]
+    return c[:, 0] + t * (c[:, 1] + t * (c[:, 2] + t * c[:, 3]))
+
+
 def time_warp_tables(pos):
     """(k0 int32 [L], w float32 [L, TAPS]): y[n] = sum_t w[n, t] x[clamp(k0[n] + t)] evaluates the interpolating cubic spline of x at
     pos[n]: cubic B-spline weights of the 4 coefficients around pos, each coefficient = sqrt(3) sum_j z1^|j| x[. + j]."""
     pos = np.asarray(pos, np.float64)
     k = np.floor(pos).astype(np.int64)
     f = pos - k
-    bsp = np.stack([(1 - f) ** 3, 3 * f ** 3 - 6 * f ** 2 + 4, -3 * f ** 3 + 3 * f ** 2 + 3 * f + 1, f ** 3], 1) / 6.0  # coefficients k-1 .. k+2
-    g = math.sqrt(3.0) * _Z1 ** np.abs(np.arange(-RADIUS, RADIUS + 1))
-    w = np.zeros((len(pos), TAPS))
-    for j in range(4):  # coefficient k - 1 + j gathers samples k - 1 + j - RADIUS .. k - 1 + j + RADIUS  -> taps j .. j + 2 RADIUS
-        w[:, j:j + 2 * RADIUS + 1] += bsp[:, j:j + 1] * g[None, :]
+    f2 = f * f
+    f3 = f2 * f
+    bsp = np.stack([(1 - f) ** 3, 3 * f3 - 6 * f2 + 4, -3 * f3 + 3 * f2 + 3 * f + 1, f3], 1) * (1.0 / 6.0)  # coefficients k-1 .. k+2
+    # [L, 4] x [4, TAPS] as four fp32 outer products (a BLAS call on this tall-skinny shape takes 20 ms, the numpy float64 form 5 ms,
+    # this 1.7 ms at L = 16000 -- the host draws a view's tables between two 6 ms steps)
+    b32, G = bsp.astype(np.float32), _interior_matrix().astype(np.float32)
+    w = b32[:, 0:1] * G[0]
+    for j in range(1, 4):
+        w += b32[:, j:j + 1] * G[j]
     k0 = k - 1 - RADIUS
     # The two ends: the infinite (cardinal) form knows nothing about scipy's not-a-knot end condition, whose influence reaches ~12
     # samples inwards (0.27^12 = 1.5e-7).  There the weights are the exact ones: the spline basis of a 48-sample end window
     # (the far side of the window is 36+ samples away from every position it serves), first / last TAPS samples.
-    L, win, reach = len(pos), 48, TAPS // 2
+    L, win, reach = len(pos), _END_WIN, TAPS // 2
     if L >= win:
-        basis = np.eye(win)
         lo = pos < reach
         if lo.any():
-            w[lo] = _natural_cubic_through(np.arange(win), basis, pos[lo])[:, :TAPS]
+            w[lo] = _end_weights(pos[lo])[:, :TAPS]
             k0[lo] = 0
         hi = pos > L - 1 - reach
         if hi.any():
-            w[hi] = _natural_cubic_through(np.arange(win), basis, pos[hi] - (L - win))[:, win - TAPS:]
+            w[hi] = _end_weights(pos[hi] - (L - win))[:, win - TAPS:]
             k0[hi] = L - TAPS
-    return k0.astype(np.int32), w.astype(np.float32)
+    return k0.astype(np.int32), w

@@ -156,9 +156,9 @@ int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const vo
 /* Number of workgroups focal_linear_bwd_weight launches for this descriptor (output tiles x token splits): lets a caller match its
  * calls against the launch shapes of a profiler trace (bench.py's in-step roofline).  0 = invalid descriptor. */
 int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d);
-/* Output-tile edge of that launch: 64 (focal_gemm_kernel, 256 threads) or 128 (focal_dw_wide_kernel, the LDS-DMA kernel for outputs
- * of >= 1024 x 256).  0 = invalid descriptor. */
-int focal_linear_bwd_weight_tile(const focal_linear_desc* d);
+/* Which kernel that launch runs: 1 = focal_gemm_kernel (register-staged, any dtype / loader), 2 = focal_dw_ring_kernel (the LDS-DMA
+ * ring for bf16 shapes made of whole 64-tiles, given 16-byte aligned operands).  0 = invalid descriptor. */
+int focal_linear_bwd_weight_kernel(const focal_linear_desc* d);
 
 /* Fused MLP branch of a Swin block (models/SwinModules.py:18-34 Mlp.forward + the residual / DropPath of :339-341), bf16,
  * C = 64 -> hidden = 256 -> C (Swin stage 0, where 2/3 of the model's hidden-activation bytes are; focal_mlp_supported says
@@ -305,6 +305,22 @@ typedef struct {
 size_t focal_loss_head_workspace(const focal_loss_desc* d);
 int focal_loss_head(const focal_loss_desc* d, const float* const* feats, float* terms, float* const* dfeats,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* The same loss evaluated by `world` data-parallel ranks, each over the rows of its own samples (round 2).  `d` describes the GLOBAL
+ * batch (B = world x the rank's batch, rank-major sample order as an all-gather leaves it; b = B / seq must divide by world); feats
+ * are the gathered [B, dim] embeddings, identical on every rank.  Every cross-sample matrix of the loss is symmetric and a sample's
+ * gradient needs only its own row of it, so rank r computes 1 / world of every product and row pass:
+ *   _shard_a   zeroes dfeats / terms, evaluates the similarity rows, log-sum-exps, distances, block means and hinges of the rank's
+ *              rows and the orthogonality term, and writes what other ranks need of them -- lse of its rows, diagonal block means,
+ *              its partial loss terms -- into `chunk` (focal_loss_head_exchange_floats(d, world) floats);
+ *   (caller)   all-gathers the chunks in rank order -> `chunks` [world][that many floats]   (the ONE collective of the head: ~70 KB);
+ *   _shard_b   finishes: coefficient rows, dL/dz of the rank's own samples into their rows of dfeats (other rows stay zero), and the
+ *              global terms[5] (sum of the partial terms).
+ * Same workspace in both calls (focal_loss_head_workspace(d) bytes), untouched in between.  focal_loss_head is world = 1. */
+size_t focal_loss_head_exchange_floats(const focal_loss_desc* d, int world);
+int focal_loss_head_shard_a(const focal_loss_desc* d, int rank, int world, const float* const* feats, float* terms,
+                            float* const* dfeats, float* chunk, void* workspace, size_t workspace_bytes, void* stream);
+int focal_loss_head_shard_b(const focal_loss_desc* d, int rank, int world, const float* const* feats, float* terms,
+                            float* const* dfeats, const float* chunks, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 14: AdamW
  * torch.optim.AdamW (train_utils/optimizer.py:27-32) over `nseg` contiguous fp32 segments (the parameter arena's

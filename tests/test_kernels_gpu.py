@@ -75,7 +75,7 @@ def test_linear_split_k_and_relu(ops, ct):
 
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(4608, 192, 64), (1000, 64, 256), (144, 256, 1024), (2304, 512, 128),
-                                   (2304, 1024, 256), (4672, 256, 1024), (64, 1024, 256)])  # the last three: the 128 x 128 LDS-DMA kernel in bf16
+                                   (2304, 1024, 256), (4672, 256, 1024), (64, 1024, 256), (192, 64, 64)])  # whole 64-tiles: the LDS-DMA ring kernel in bf16
 def test_linear_bwd(ops, ct, M, N, K):
     x = rnd(M, K, seed=11, dtype=ct)
     w = rnd(N, K, scale=K ** -0.5, seed=12, dtype=ct)
@@ -85,10 +85,10 @@ def test_linear_bwd(ops, ct, M, N, K):
     dx = torch.empty(M, K, dtype=ct, device=DEV)
     ops.linear_bwd_data(d, dy, w, None, dx)
     assert rel_err(dx.float(), dy.float() @ w.float()) < (1e-5 if ct == torch.float32 else 6e-3)
-    if N * K >= 262144:
-        import ctypes
-        from focal_amd import _lib
-        assert _lib.load().focal_linear_bwd_weight_tile(ctypes.byref(d)) == (128 if ct == torch.bfloat16 and M % 64 == 0 else 64)
+    import ctypes
+    from focal_amd import _lib
+    ring = ct == torch.bfloat16 and M % 64 == 0 and N % 64 == 0 and K % 64 == 0   # the LDS-DMA ring kernel takes whole 64-tiles in bf16
+    assert _lib.load().focal_linear_bwd_weight_kernel(ctypes.byref(d)) == (2 if ring else 1)
     dw = torch.zeros(N, K, device=DEV)
     db = torch.zeros(N, device=DEV)
     ops.linear_bwd_weight(d, dy, x, dw, db)

@@ -115,3 +115,89 @@ def test_loss_head_matches_oracle(cfg, M, B, no_private, seq):
         pred = -eps * gn
         got = (t2[4] - terms[4].cuda())
         assert abs(got.item() - pred.item()) < 0.1 * abs(pred.item()), (got.item(), pred.item())
+
+
+def _sharded_head_in_one_process(world, feats1, feats2, T, margin, w, seq, no_private=False):
+    """What `world` data-parallel ranks compute with focal_loss_head_shard_a / _b, run one after the other on this device: every
+    rank has its own workspace and gradient buffer (they are separate processes in production), the chunk exchange is a copy."""
+    import ctypes as C
+
+    from focal_amd import _lib, ops
+    from focal_amd._lib import LossDesc
+    lib = _lib.load()
+    feats = [f.cuda().contiguous() for f in list(feats1) + list(feats2)]
+    M, (B, dim) = len(feats1), feats[0].shape
+    d = LossDesc(M, B, dim, seq, T, margin, w[0], w[1], w[2], w[3], int(no_private))
+    need = lib.focal_loss_head_workspace(C.byref(d))
+    n = lib.focal_loss_head_exchange_floats(C.byref(d), world)
+    assert need > 0 and n > 0, lib.focal_last_error()
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: C.c_void_p(t.data_ptr())
+    fa = (C.c_void_p * (2 * M))(*[f.data_ptr() for f in feats])
+    chunks = torch.zeros(world, n, device="cuda")
+    ranks = []
+    for r in range(world):
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        flat = torch.full((2 * M * B * dim + 8,), float("nan"), device="cuda")
+        grads = [flat[i * B * dim:(i + 1) * B * dim].view(B, dim) for i in range(2 * M)]
+        terms = flat[2 * M * B * dim:2 * M * B * dim + 5]
+        ga = (C.c_void_p * (2 * M))(*[g.data_ptr() for g in grads])
+        ops.check(lib.focal_loss_head_shard_a(C.byref(d), r, world, fa, P(terms), ga, P(chunks[r]), P(ws), ws.numel(), st))
+        ranks.append((ws, grads, terms, ga))
+    out_terms, own = [], []
+    for r, (ws, grads, terms, ga) in enumerate(ranks):
+        ops.check(lib.focal_loss_head_shard_b(C.byref(d), r, world, fa, P(terms), ga, P(chunks), P(ws), ws.numel(), st))
+        out_terms.append(terms.cpu())
+        own.append(grads)
+    # a rank's gradient rows: its own samples (the rest stays zero)
+    bl = B // world
+    full = []
+    for i in range(2 * M):
+        g = torch.zeros(B, dim)
+        for r in range(world):
+            gr = own[r][i].cpu()
+            assert torch.count_nonzero(gr[:r * bl]) == 0 and torch.count_nonzero(gr[(r + 1) * bl:]) == 0
+            g[r * bl:(r + 1) * bl] = gr[r * bl:(r + 1) * bl]
+        full.append(g)
+    for t in out_terms[1:]:
+        assert torch.equal(t, out_terms[0])  # every rank sums the same partial terms in the same order
+    return out_terms[0], full[:M], full[M:]
+
+
+@pytest.mark.parametrize("name,model,world", [("swt_b32", "SW_Transformer", 2), ("swt_b32", "SW_Transformer", 8), ("ds_b32", "DeepSense", 4),
+                                              ("swt_4mod_b32", "SW_Transformer", 2), ("swt_b2048", "SW_Transformer", 8)])
+def test_sharded_loss_head_matches_reference_fixture(cfg, name, model, world):
+    """The row-sharded head of `world` ranks reproduces the reference's loss terms and dL/dz on the same fixtures as the one-rank head
+    (the global batch of config 4 split over its 8 ranks included)."""
+    fx = np.load(os.path.join(GOLD, f"loss_{name}.npz"))
+    B, seed, scale = int(fx["B"]), int(fx["seed"]), float(fx["scale"])
+    mods = [str(m) for m in fx["mods"]]
+    f1, f2 = _views(B, mods, seed, scale)
+    fc = cfg["FOCAL"]
+    w = (fc["shared_contrastive_loss_weight"], fc["private_contrastive_loss_weight"], fc["orthogonal_loss_weight"], fc["rank_loss_weight"])
+    terms, g1, g2 = _sharded_head_in_one_process(world, [f1[m] for m in mods], [f2[m] for m in mods], fc["temperature"][model],
+                                                 fc["inter_rank_margin"], w, cfg["seq_len"])
+    sub = 16 if B == 2048 else 1  # the large fixture keeps every 16th row
+    for i, k in enumerate(("shared", "private", "orth", "rank", "total")):
+        ref = float(fx[f"loss.{k}"])
+        assert abs(terms[i].item() - ref) < 1e-3 * max(1.0, abs(ref)), (k, terms[i].item(), ref)
+    for i, m in enumerate(mods):
+        for got, key in ((g1[i], f"demb1.{m}"), (g2[i], f"demb2.{m}")):
+            ref = torch.from_numpy(fx[key])
+            err = ((got[::sub] - ref).norm() / ref.norm()).item()
+            assert err < 1e-3, (key, err)
+
+
+@pytest.mark.parametrize("M,B,world,no_private,seq", [(2, 24, 3, False, 4), (3, 16, 2, False, 4), (2, 20, 5, True, 2), (2, 12, 2, False, 3)])
+def test_sharded_loss_head_equals_one_rank_head(cfg, M, B, world, no_private, seq):
+    """Odd numbers of own subsequences, three modalities, the noPrivate tag, other subsequence lengths: sharded == one rank."""
+    from focal_amd import ops
+    mods = [f"m{i}" for i in range(M)]
+    f1, f2 = _views(B, mods, 300 + B, 1.1)
+    w = (1.0, 1.0, 3.0, 5.0)
+    a = [f1[m].cuda() for m in mods], [f2[m].cuda() for m in mods]
+    t1, g1, g2 = ops.loss_head(a[0], a[1], 0.07, 1.0, w, seq, no_private)
+    ts, s1, s2 = _sharded_head_in_one_process(world, [f1[m] for m in mods], [f2[m] for m in mods], 0.07, 1.0, w, seq, no_private)
+    assert torch.allclose(ts, t1.cpu(), rtol=2e-5, atol=1e-6), (ts, t1)
+    for got, ref in zip(s1 + s2, g1 + g2):
+        assert ((got - ref.cpu()).norm() / ref.norm()).item() < 2e-5

@@ -17,6 +17,9 @@ tag, root, steps, warm = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.arg
 def fam(n):
     n = re.sub(r"\(Gemm(Epi|Pro)\)", "", n)
     if "gemm_pipe" in n: return "gemm_pipe"
+    if "focal_dw_ring" in n: return "gemm dW"
+    if "mlp_bwd" in n: return "mlp_bwd"
+    if "mlp_fwd" in n: return "mlp_fwd"
     if "focal_gemm_kernel" in n:
         if "Lb1ELb1" in n or "true, true" in n: return "gemm dW"
         return "gemm fwd/dX 64x64"
@@ -57,7 +60,7 @@ for ci, c in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
     for r in csv.DictReader(open(fs[0])):
         if r["Counter_Name"] != c: continue
         wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
-        key = ("dW" if ("focal_gemm_kernel" in r["Kernel_Name"] and ("Lb1ELb1" in r["Kernel_Name"] or "true, true" in r["Kernel_Name"])) else
+        key = ("dW" if ("focal_dw_ring" in r["Kernel_Name"] or ("focal_gemm_kernel" in r["Kernel_Name"] and ("Lb1ELb1" in r["Kernel_Name"] or "true, true" in r["Kernel_Name"]))) else
                "ln_bwd" if "ln_bwd" in r["Kernel_Name"] else "mlp_bwd" if "mlp_bwd" in r["Kernel_Name"] else
                "mlp_fwd" if "mlp_fwd" in r["Kernel_Name"] else None)
         if key is None: continue

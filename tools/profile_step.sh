@@ -7,7 +7,7 @@ root=$(pwd)
 STEPS=10; WARM=3
 mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python3 $root/bench.py --no-graph --no-cpu-baseline --steps $STEPS --warmup $WARM "$@" > $root/gpurun_out/${tag}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python3 $root/bench.py --no-graph --no-cpu-baseline --no-roofline --steps $STEPS --warmup $WARM "$@" > $root/gpurun_out/${tag}_bench.log 2>&1
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
 cp "$f" $root/gpurun_out/${tag}_kernel_stats.csv
 python3 $root/profiles/summarize.py $root/gpurun_out/${tag}_kernel_stats.csv $((STEPS+WARM+2)) 30
