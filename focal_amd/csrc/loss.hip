@@ -56,8 +56,9 @@ static inline int loss_row_blocks(long rows) {
 // the logical 2b (any b >= 2: the last batch of an epoch may hold an odd number of subsequences) is padded with zero rows /
 // columns that every row kernel skips.
 __global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, int dim, int width,
-                                                       float* __restrict__ Zn, float* __restrict__ nrm) {
+                                                       float* __restrict__ Zn, float* __restrict__ nrm, float* __restrict__ zero5) {
   const int lane = threadIdx.x & 63;
+  if (zero5 != nullptr && blockIdx.x == 0 && threadIdx.x < 5) zero5[threadIdx.x] = 0.f;  // this rank's partial loss terms (first launch of the head)
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long rows = (long)nprob * seq * n2p;
   if (row >= rows) return;
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, in
 // one wave per OWN row i of S[p,t]: lse over j != i, loss_i = lse_i - S[i][pos(i)].  Own row w of block blk (w = h * bl + k: view half
 // h, own subsequence k) is row i = h * b + r0 + k of the block; its lse goes to slot (gb0 + blk) * 2 bl + w of this rank's chunk.
 __global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, Shard sh, int gb0,
-                                                       const float* __restrict__ S, float* __restrict__ lse_own, float* __restrict__ terms) {
+                                                       const float* __restrict__ S, float* __restrict__ lse_own, float* __restrict__ lse_full,
+                                                       float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
   const int n2 = 2 * b, own = 2 * sh.bl;
   const long rows = (long)nprob * seq * own;
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, in
     const float l = mx + __logf(sum);
     if (lane == 0) {
       lse_own[(gb0 + blk) * own + w] = l;
+      lse_full[blk * n2p + i] = l;
       const float contrib = (l - s[(i + b) % n2]) / (float)(seq * n2);
       if (kind == 0) acc0 += contrib; else acc1 += contrib;
     }
@@ -108,15 +111,28 @@ __global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, in
   block_term_add(acc1, terms + 1);
 }
 
-// lse of row j (any rank's) of global block gb, from the gathered chunks
-__device__ __forceinline__ float lse_at(const float* __restrict__ xall, const Shard& sh, long gb, int j, int b) {
-  const int h = j >= b, s = j - h * b;
-  return xall[(long)(s / sh.bl) * sh.ch + gb * 2 * sh.bl + h * sh.bl + (s % sh.bl)];
+// The gathered chunks [rank][lse of its rows | its diagonal means | ...] -> lse in block-row order [gb][n2p] and the diagonal means
+// [q][b] (so that the element-wise kernels index them without a division per element)
+__global__ __launch_bounds__(256) void xchg_unpack_kernel(Shard sh, int nblk, int b, int n2p, int Q, const float* __restrict__ xall,
+                                                          float* __restrict__ lse, float* __restrict__ diag) {
+  const int n2 = 2 * b;
+  const long nl = (long)nblk * n2, total = nl + (long)Q * b;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    if (e < nl) {
+      const long gb = e / n2;
+      const int j = e % n2, h = j >= b, s = j - h * b;
+      lse[gb * n2p + j] = xall[(long)(s / sh.bl) * sh.ch + gb * 2 * sh.bl + h * sh.bl + (s % sh.bl)];
+    } else {
+      const long t = e - nl;
+      const int q = t / b, J = t % b;
+      diag[t] = xall[(long)(J / sh.bl) * sh.ch + sh.o_diag + q * sh.bl + (J % sh.bl)];
+    }
+  }
 }
 
 // in place, OWN rows of S -> W (times the family weight): W_ij = [j != i](e^{S_ij - lse_i} + e^{S_ij - lse_j}) - 2 [j == pos(i)]
-__global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, Shard sh, int gb0,
-                                                          float* __restrict__ S, const float* __restrict__ xall, float w_shared, float w_private) {
+__global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, Shard sh,
+                                                          float* __restrict__ S, const float* __restrict__ lse, float w_shared, float w_private) {
   const int n2 = 2 * b, own = 2 * sh.bl;
   const long total = (long)nprob * seq * own * n2p;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -129,7 +145,7 @@ __global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0,
     float wv = 0.f;
     if (j != i && j < n2) {
       const float sv = *sp;
-      wv = __expf(sv - lse_at(xall, sh, gb0 + blk, i, b)) + __expf(sv - lse_at(xall, sh, gb0 + blk, j, b));
+      wv = __expf(sv - lse[blk * n2p + i]) + __expf(sv - lse[blk * n2p + j]);
       if (j == (i + b) % n2) wv -= 2.0f;
     }
     *sp = wv * wk;
@@ -205,7 +221,8 @@ __global__ __launch_bounds__(256) void rank_blockmean_kernel(int nq, int b, int 
 // one wave per (q, own I): hinge over J != I (MarginRankingLoss(margin, y = -1), loss.py:127-135) and dL/dDbar of that row; the
 // row's diagonal mean goes to the exchange chunk (other ranks need it for the transposed hinge of their coefficient rows)
 __global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float margin, Shard sh, const float* __restrict__ Dbar,
-                                                         float* __restrict__ dDbar, float* __restrict__ diag_own, float* __restrict__ terms) {
+                                                         float* __restrict__ dDbar, float* __restrict__ diag_own, float* __restrict__ diag_full,
+                                                         float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
   const float inv = 1.0f / ((float)b * (float)(b - 1));
   float acc = 0.f;
@@ -228,6 +245,7 @@ __global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float ma
     if (lane == 0) {
       dDbar[row * b + I] = cnt * inv;
       diag_own[idx] = dii;
+      diag_full[row] = dii;
       acc += loss * inv;
     }
   }
@@ -235,11 +253,11 @@ __global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float ma
 }
 
 // in place, own rows of D -> E = w_rank * (A_pq + A_qp) / D_pq, A_pq = dDbar[I(p)][J(q)] / count(I, J); rowsum[p] = sum_q E_pq.
-// dDbar[J][I] of a column's subsequence J is re-derived from its diagonal mean (gathered) and Dbar[I][J] (block means are symmetric
+// dDbar[J][I] of a column's subsequence J is re-derived from its diagonal mean (gathered: diag[q][J]) and Dbar[I][J] (block means are symmetric
 // up to the summation order of the 16 distances): -inv where the hinge of row J is active against I.
 __global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq, int Bp, float w_rank, float margin, Shard sh, float* __restrict__ D,
                                                          const float* __restrict__ Dbar, const float* __restrict__ dDbar,
-                                                         const float* __restrict__ xall, float* __restrict__ rowsum) {
+                                                         const float* __restrict__ diag, float* __restrict__ rowsum) {
   const int lane = threadIdx.x & 63;
   const int B = b * seq, nr = sh.bl * seq;
   const float inv = 1.0f / ((float)b * (float)(b - 1));
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq,
         const float cnt = (float)(seq * seq - (I == J ? seq : 0));
         float a = dd[J];
         if (J == I) a += a;
-        else if (xall[(long)(J / sh.bl) * sh.ch + sh.o_diag + q * sh.bl + (J % sh.bl)] - db[J] + margin > 0.f) a -= inv;
+        else if (diag[q * b + J] - db[J] + margin > 0.f) a -= inv;
         e = w_rank * a / (cnt * dist);
       }
     }
@@ -326,7 +344,7 @@ __global__ void loss_total_kernel(float* terms, const float* __restrict__ xall, 
 // ------------------------------------------------------------------------------------------------ host side
 struct LossPlan {
   int b, n2, n2p, Bp, P_sh, P_pr, w_sh, w_pr, Q, O;
-  size_t off_zn, off_nrm, off_S, off_dzn, off_X, off_sq, off_D, off_dbar, off_ddbar, off_rs, off_ex, off_xchg, total;
+  size_t off_zn, off_nrm, off_S, off_lse, off_diag, off_dzn, off_X, off_sq, off_D, off_dbar, off_ddbar, off_rs, off_ex, off_xchg, total;
   Shard sh;
   int rank;
 };
@@ -365,6 +383,8 @@ static int loss_plan(const focal_loss_desc* d, int rank, int world, LossPlan* pl
   pl->off_zn = take(zn);
   pl->off_dzn = take(zn);
   pl->off_nrm = take(rows_sh + rows_pr);
+  pl->off_lse = take(rows_sh + rows_pr);
+  pl->off_diag = take((size_t)pl->Q * pl->b);
   pl->off_S = take((rows_sh + rows_pr) * pl->n2p);
   pl->off_X = take((size_t)pl->Q * pl->Bp * d->dim);
   pl->off_ex = take((size_t)pl->Q * pl->Bp * d->dim);
@@ -462,8 +482,8 @@ static int loss_phase_a(const focal_loss_desc* d, const LossPlan& pl, const floa
     (void)hipMemsetAsync(terms, 0, 5 * sizeof(float), st);
     for (int i = 0; i < 2 * M; ++i) (void)hipMemsetAsync(dfeats[i], 0, gbytes, st);
   }
-  float* pterms = chunk + sh.o_terms;  // partial terms of this rank
-  (void)hipMemsetAsync(pterms, 0, 5 * sizeof(float), st);
+  float* pterms = chunk + sh.o_terms;  // partial terms of this rank (zeroed by the first pack launch)
+  bool zeroed = false;
   LossTables tb;
   loss_tables(d, feats, dfeats, &tb);
 
@@ -477,12 +497,15 @@ static int loss_phase_a(const focal_loss_desc* d, const LossPlan& pl, const floa
     float* Zn = ws + pl.off_zn + zoff;
     float* nrm = ws + pl.off_nrm + roff;
     float* S = ws + pl.off_S + roff * n2p;
-    hipLaunchKernelGGL(nce_pack_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, dim, width, Zn, nrm);
+    hipLaunchKernelGGL(nce_pack_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, dim, width, Zn, nrm,
+                       zeroed ? nullptr : pterms);
+    zeroed = true;
     if (int rc = over_own_halves(pl, [&](int row0, int nrow) {
           return f32_gemm(false, nrow, n2p, width, Zn + (long)row0 * width, width, (long)n2p * width, Zn, width, (long)n2p * width,
                           S + (long)row0 * n2p, n2p, (long)n2p * n2p, nprob * seq, 1.0f / d->temperature, st);
         })) return rc;
-    hipLaunchKernelGGL(nce_rows_kernel, dim3(loss_row_blocks(own_rows)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, sh, gb0, S, chunk, pterms);
+    hipLaunchKernelGGL(nce_rows_kernel, dim3(loss_row_blocks(own_rows)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, sh, gb0, S, chunk,
+                       ws + pl.off_lse + roff, pterms);
     zoff += (size_t)rows * width;
     roff += rows;
     gb0 += nprob * seq;
@@ -504,7 +527,7 @@ static int loss_phase_a(const focal_loss_desc* d, const LossPlan& pl, const floa
     if (bb > 4096) bb = 4096;
     hipLaunchKernelGGL(rank_blockmean_kernel, dim3(bb), dim3(256), 0, st, Q, b, seq, Bp, sh, D, Dbar);
     hipLaunchKernelGGL(rank_hinge_kernel, dim3(loss_row_blocks((long)Q * sh.bl)), dim3(256), 0, st, Q, b, d->margin, sh, Dbar, dDbar,
-                       chunk + sh.o_diag, pterms);
+                       chunk + sh.o_diag, ws + pl.off_diag, pterms);
     // ---- orthogonality (row-local)
     hipLaunchKernelGGL(orth_kernel, dim3(loss_row_blocks((long)pl.O * nr)), dim3(256), 0, st, tb.orth, pl.O, B, dim, half, d->w_orth, rs0, nr, pterms);
   }
@@ -520,8 +543,13 @@ static int loss_phase_b(const focal_loss_desc* d, const LossPlan& pl, const floa
   const Shard sh = pl.sh;
   LossTables tb;
   loss_tables(d, feats, dfeats, &tb);
+  if (sh.world > 1) {  // (one rank: phase A has written every row's lse / diagonal mean in place already)
+    const int nblk = (pl.P_sh + pl.P_pr) * seq;
+    int ub = ceil_div((long)nblk * n2 + (long)pl.Q * b, 256);
+    if (ub > 1024) ub = 1024;
+    hipLaunchKernelGGL(xchg_unpack_kernel, dim3(ub), dim3(256), 0, st, sh, nblk, b, n2p, pl.Q, xall, ws + pl.off_lse, ws + pl.off_diag);
+  }
   size_t zoff = 0, roff = 0;
-  int gb0 = 0;
   for (int grp = 0; grp < 2; ++grp) {
     const int p0 = grp == 0 ? 0 : pl.P_sh, nprob = grp == 0 ? pl.P_sh : pl.P_pr, width = grp == 0 ? pl.w_sh : pl.w_pr;
     if (nprob == 0) continue;
@@ -532,7 +560,8 @@ static int loss_phase_b(const focal_loss_desc* d, const LossPlan& pl, const floa
     float* S = ws + pl.off_S + roff * n2p;
     int eb = ceil_div(own_rows * n2p, 256);
     if (eb > 8192) eb = 8192;
-    hipLaunchKernelGGL(nce_weights_kernel, dim3(eb), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, sh, gb0, S, xall, d->w_shared, d->w_private);
+    hipLaunchKernelGGL(nce_weights_kernel, dim3(eb), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, sh, S, ws + pl.off_lse + roff, d->w_shared,
+                       d->w_private);
     if (int rc = over_own_halves(pl, [&](int row0, int nrow) {
           return f32_gemm(true, nrow, width, n2p, S + (long)row0 * n2p, n2p, (long)n2p * n2p, Zn, width, (long)n2p * width,
                           dZn + (long)row0 * width, width, (long)n2p * width, nprob * seq, 1.0f / ((float)seq * n2 * d->temperature), st);
@@ -540,14 +569,13 @@ static int loss_phase_b(const focal_loss_desc* d, const LossPlan& pl, const floa
     hipLaunchKernelGGL(nce_unpack_kernel, dim3(ceil_div(own_rows, 4)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, dim, width, sh, Zn, nrm, dZn);
     zoff += (size_t)rows * width;
     roff += rows;
-    gb0 += nprob * seq;
   }
   {
     const int Q = pl.Q, rs0 = sh.r0 * seq, nr = sh.bl * seq;
     float* X = ws + pl.off_X; float* EX = ws + pl.off_ex; float* rs = ws + pl.off_rs;
     float* D = ws + pl.off_D; float* Dbar = ws + pl.off_dbar; float* dDbar = ws + pl.off_ddbar;
     hipLaunchKernelGGL(rank_coeff_kernel, dim3(ceil_div((long)Q * nr, 4)), dim3(256), 0, st, Q, b, seq, Bp, d->w_rank, d->margin, sh, D, Dbar, dDbar,
-                       xall, rs);
+                       ws + pl.off_diag, rs);
     if (int rc = f32_gemm(true, nr, dim, Bp, D + (long)rs0 * Bp, Bp, (long)Bp * Bp, X, dim, (long)Bp * dim, EX + (long)rs0 * dim, dim,
                           (long)Bp * dim, Q, 1.0f, st)) return rc;
     int gb = ceil_div((long)Q * nr * dim, 256);
