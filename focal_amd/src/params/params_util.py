@@ -1,4 +1,5 @@
 """Derived run parameters (reference: params/params_util.py:20-138)."""
+import datetime
 import os
 
 import torch
@@ -39,9 +40,10 @@ def init_distributed(device=""):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = os.environ.get("FOCAL_DIST_BACKEND", "nccl")
     if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_device_index(device)))
+        # (rank 0 validates / fits the KNN estimator / writes checkpoints alone every 10 epochs while the others wait at a barrier)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_device_index(device)), timeout=datetime.timedelta(minutes=60))
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, timeout=datetime.timedelta(minutes=60))
 
 
 def select_device(device=""):

@@ -7,6 +7,6 @@ for i, r in enumerate(rows):
     if "copyBuffer" in r["Kernel_Name"]:
         prev = rows[i - 1]["Kernel_Name"][:70] if i else "-"
         nxt = rows[i + 1]["Kernel_Name"][:70] if i + 1 < len(rows) else "-"
-        ctx[(r["Grid_Size"], prev, nxt)] += 1
+        ctx[(r["Grid_Size_X"], prev, nxt)] += 1
 for k, v in ctx.most_common(30):
     print(v, k)
