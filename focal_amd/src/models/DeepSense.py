@@ -1,5 +1,6 @@
 """DeepSense backbone -- same constructor contract, forward signature, module tree and state_dict as the reference
-(models/DeepSense.py), executed on the MI355X HIP kernels.  FOCAL pretraining path only (`class_head=False`)."""
+(models/DeepSense.py), executed on the MI355X HIP kernels: the FOCAL pretraining path (`class_head=False`) and the classifier path
+(`class_head=True`: concatenated features -> class layer) of the finetune and supervised stages; multi-location fusion raises."""
 import os
 import sys
 

@@ -2,7 +2,9 @@
 reference (models/SW_Transformer.py), executed on the MI355X HIP kernels.
 
 `forward(freq_x, class_head=False, proj_head=...)` is the FOCAL pretraining path (reference :210-268, :294-304).
-The classifier path (`class_head=True`, attention fusion + class layer) is outside the hot path and raises.
+The classifier path (`class_head=True`: TransformerFusionBlock over the modality tokens + class layer, reference :244-276) runs for
+the finetune stage (frozen encoders, head trained) and for supervised training from scratch (gradient flows on into the encoders and
+the patch embedding); multi-location fusion raises.
 """
 import os
 import sys

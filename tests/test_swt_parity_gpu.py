@@ -151,6 +151,38 @@ def test_three_adamw_steps_follow_reference(cfg, ct):
         assert (p[::step][:32] - torch.from_numpy(fx["adamw.probe_after3"])).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("ct", ["fp32", "bf16"])
+def test_adamw_updates_equal_torch_adamw_on_the_same_gradients(cfg, ct):
+    """The optimizer in isolation from gradient rounding (the bf16 trajectory above can only be held to 'descends'): three steps of
+    the fused AdamW over the arena against torch.optim.AdamW fed the SAME gradients (the HIP path's own, copied out before each
+    step) from the same start -- masters equal to fp32 rounding, and in bf16 mode the shadow handed to the matrix cores is the
+    bf16 rounding of the updated master."""
+    from train_utils.optimizer import define_optimizer
+    args, net, focal, loss_fn = build(cfg, ct)
+    net.train()
+    opt = define_optimizer(args, focal.parameters())
+    x1, x2 = inputs(cfg)
+    ar = net.arena()
+    ref_p = torch.nn.Parameter(ar.flat.detach().clone())
+    oc = cfg["FOCAL"]["pretrain_optimizer"]
+    ref_opt = torch.optim.AdamW([ref_p], lr=oc["start_lr"], weight_decay=oc["weight_decay"])
+    for it in range(3):
+        opt.zero_grad()
+        a, b = focal(x1, x2, proj_head=True)
+        loss_fn(a, b).backward()
+        torch.cuda.synchronize()
+        ref_p.grad = ar.grad.detach().clone()
+        opt.step()
+        ref_opt.step()
+        torch.cuda.synchronize()
+        ar = net.arena()
+        err = (ar.flat - ref_p.detach()).abs().max().item()
+        record_observed(f"swt.adamw_vs_torch_same_grads.{ct}.step{it}.max_abs", err)
+        assert err < 1e-6, (it, err)  # a few ulps of the master (observed 2.4e-7 = 2 ulps at the LayerNorm gains, |p| ~ 1)
+        if ct == "bf16":
+            assert torch.equal(ar.shadow, ar.flat.bfloat16())
+
+
 def test_dropout_on_backward_matches_forward_masks(cfg):
     """With every dropout rate at its MOD.yaml value and the device seed frozen, the masks are a fixed function of the element
     index, so the training-mode encoder is a deterministic differentiable function: its analytic gradient (which regenerates
