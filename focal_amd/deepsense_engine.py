@@ -39,6 +39,11 @@ class DeepSenseModEncoder:
         rows = B * I * S
         buf = bb.buffer
         sv = dict(B=B, view=view, x=x_freq, layers=[])
+        # running-statistics order: this pass's BatchNorm updates come after the previous pass's (which may run on another stream)
+        order = getattr(self, "pass_order", None)
+        if order == 1 and getattr(self, "_bn_done", None) is not None:
+            torch.cuda.current_stream(x_freq.device).wait_event(self._bn_done)
+            self._bn_done = None
         # ---- conv stack
         pin = f"{self.pre}.conv_layer_in"
         d_in = ops.conv_in_desc(B, cin, I, S_in, S, geo["k_in"], geo["stride"], geo["pad_in"], C)
@@ -62,6 +67,9 @@ class DeepSenseModEncoder:
             sv["layers"].append(dict(p=pl, z=z, mr=mr, d_bn=d_bn, xa=ya))
             y, ya = y_next, ya_next
         sv["d_cv"] = d_cv
+        if order == 0:
+            self._bn_done = torch.cuda.Event()
+            self._bn_done.record(torch.cuda.current_stream(x_freq.device))
         pout = f"{self.pre}.conv_layer_out"
         n_out = geo["C_out"]
         w_out = ops.permute_pack(ar.master(f"{pout}.weight"), n_out, C, S, ct)  # [n][c*S + s] -> [n][s*C + c]

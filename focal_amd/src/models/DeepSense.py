@@ -106,7 +106,7 @@ class DeepSense(HipBackbone):
             self._buffers_by_name["__dev"] = next(self.parameters()).device
         return self._buffers_by_name[name]
 
-    def forward_encoder(self, freq_x, class_head=True, proj_head=False, defer_join=False):
+    def forward_encoder(self, freq_x, class_head=True, proj_head=False, defer_join=False, view_index=None):
         if class_head:
             return self.forward_classifier(freq_x)
         loc = self.locations[0]
@@ -119,9 +119,16 @@ class DeepSense(HipBackbone):
             raise FocalHipError("the FOCAL HIP path needs the model on a ROCm device (no CPU fallback)")
         cur = torch.cuda.current_stream(dev)
         out = {}
+        # The two views of a step also get their own streams (FOCAL_DS_VIEW_STREAMS=0: one stream per modality): the GRU sequence
+        # kernels are latency-bound launches of 32 workgroups, and view 2's convolution stack fills the chip under view 1's GRU.
+        # BatchNorm's running buffers must see view 1 before view 2: an encoder's pass starts after the previous pass of the same
+        # encoder has left its convolution stack (the last BatchNorm), see deepsense_engine.forward.
+        # (view_index: FOCAL.forward numbers its two backbone calls 0 / 1; any other caller runs one stream per modality)
+        view_streams = view_index is not None and os.environ.get("FOCAL_DS_VIEW_STREAMS", "1") != "0" and self.training
         for mi, mod in enumerate(self.modalities):
-            st = runtime.fork(dev, mi)
+            st = runtime.fork(dev, (view_index * len(self.modalities) if view_streams else 0) + mi)
             with torch.cuda.stream(st):
+                self._encoders[(loc, mod)].pass_order = view_index if view_streams else None
                 f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
                 out[mod] = run_stage(self, self._heads[mod], f) if proj_head else f
                 out[mod].record_stream(cur)
@@ -144,5 +151,5 @@ class DeepSense(HipBackbone):
         x = torch.cat([feats[m] for m in self.modalities], dim=1)
         return run_stage(self, self._class_head, x, self.training)
 
-    def forward(self, freq_x, class_head=True, proj_head=False, defer_join=False):
-        return self.forward_encoder(freq_x, class_head, proj_head, defer_join)
+    def forward(self, freq_x, class_head=True, proj_head=False, defer_join=False, view_index=None):
+        return self.forward_encoder(freq_x, class_head, proj_head, defer_join, view_index)

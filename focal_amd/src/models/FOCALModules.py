@@ -35,8 +35,9 @@ class FOCAL(nn.Module):
         kw = {}
         if "defer_join" in inspect.signature(self.backbone.forward).parameters:
             kw["defer_join"] = True
-        mod_features1 = self.backbone(aug_freq_input1, class_head=False, proj_head=proj_head, **kw)
-        mod_features2 = self.backbone(aug_freq_input2, class_head=False, proj_head=proj_head, **kw)
+        views = "view_index" in inspect.signature(self.backbone.forward).parameters  # the two passes may overlap on separate streams
+        mod_features1 = self.backbone(aug_freq_input1, class_head=False, proj_head=proj_head, **kw, **({"view_index": 0} if views else {}))
+        mod_features2 = self.backbone(aug_freq_input2, class_head=False, proj_head=proj_head, **kw, **({"view_index": 1} if views else {}))
         if kw:
             from focal_amd import runtime
             runtime.join_all(next(self.backbone.parameters()).device)
