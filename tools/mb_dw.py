@@ -15,6 +15,10 @@ SHAPES = [(18432, 1024, 256), (18432, 256, 1024), (9216, 1024, 256), (9216, 256,
           (18432, 256, 256), (18432, 768, 256), (73728, 384, 128), (73728, 128, 128), (294912, 192, 64), (294912, 64, 64)]
 
 
+if os.environ.get("FOCAL_MB_DW_SHAPES"):  # "rows,N,K;rows,N,K;..."
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["FOCAL_MB_DW_SHAPES"].split(";")]
+
+
 def main():
     cc = ops.code(BF)
     tot = 0.0

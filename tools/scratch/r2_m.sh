@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$(dirname "$0")/../.."
+S="512,1024,256;2048,1024,256;4608,1024,256;9216,1024,256;18432,1024,256;36864,1024,256;4608,256,256;18432,256,256;73728,128,128;294912,64,64;8192,64,64"
+echo "== ring kernel"; FOCAL_MB_DW_SHAPES="$S" python tools/mb_dw.py 2>&1 | grep -v amdgpu
+echo "== ring kernel without the atomic epilogue (lab build)"; FOCAL_HIP_LIB=focal_amd/lab/libfocal_hip_noatom.so  # build first: tools/scratch/build_variant.sh noatom "-DDW_RING_LAB_NO_ATOMICS" gemm_bf16.hip, with the macro added around the epilogue atomics
+ FOCAL_MB_DW_SHAPES="$S" python tools/mb_dw.py 2>&1 | grep -v amdgpu
+echo "== register-staged kernel"; FOCAL_DW_NORING=1 FOCAL_MB_DW_SHAPES="$S" python tools/mb_dw.py 2>&1 | grep -v amdgpu
