@@ -203,6 +203,36 @@ def test_library_exports_every_declared_symbol():
     assert C.sizeof(_lib.DropDesc) == 32 and C.sizeof(_lib.LinearDesc) == 9 * 4 + 4 + 32
 
 
+def test_host_side_launch_plans_of_the_abi():
+    """The planning entry points that touch no device: which kernel / how many workgroups a weight gradient launches, and the
+    exchange chunk of the row-sharded loss head (with its argument checks)."""
+    import ctypes as C
+    from focal_amd import _lib
+    lib = _lib.load()
+    bf, f32 = _lib.FOCAL_BF16, _lib.FOCAL_F32
+
+    def desc(M, N, K, dt, xdt, ydt):
+        d = _lib.LinearDesc()
+        d.dtype, d.M, d.N, d.K, d.x_dtype, d.y_dtype = dt, M, N, K, xdt, ydt
+        return d
+    d = desc(18432, 1024, 256, bf, bf, bf)           # whole 64-tiles in bf16: the LDS-DMA ring kernel, 64 tiles x 8 token splits
+    assert lib.focal_linear_bwd_weight_kernel(C.byref(d)) == 2 and lib.focal_linear_bwd_weight_workgroups(C.byref(d)) == 512
+    d = desc(1000, 64, 256, bf, bf, bf)              # ragged token count: the register-staged kernel
+    assert lib.focal_linear_bwd_weight_kernel(C.byref(d)) == 1
+    d = desc(18432, 1024, 256, bf, f32, f32)         # fp32 operands rounded in the loader: register-staged
+    assert lib.focal_linear_bwd_weight_kernel(C.byref(d)) == 1
+    d = desc(18432, 1024, 256, f32, f32, f32)
+    assert lib.focal_linear_bwd_weight_kernel(C.byref(d)) == 1
+    ld = _lib.LossDesc(2, 2048, 256, 4, 0.07, 1.0, 1.0, 1.0, 3.0, 5.0, 0)  # config 4's global batch: b = 512 subsequences
+    need = lib.focal_loss_head_workspace(C.byref(ld))
+    assert need > 0
+    n8, n1 = lib.focal_loss_head_exchange_floats(C.byref(ld), 8), lib.focal_loss_head_exchange_floats(C.byref(ld), 1)
+    # a rank's chunk: lse of its 2 x 64 rows in each of the 4 problems x 4 steps, 4 x 64 diagonal means, 5 partial terms (64-padded)
+    assert n8 == ((16 * 128 + 4 * 64 + 5 + 63) // 64) * 64 and n1 >= 8 * (n8 - 64)
+    assert lib.focal_loss_head_exchange_floats(C.byref(ld), 3) == 0     # 512 subsequences do not split over 3 ranks
+    assert b"split over 3 ranks" in lib.focal_last_error()
+
+
 def test_augment_oracle_matches_reference_fixture():
     """oracle/augment.py against outputs of the reference augmenter classes with forced draws
     (tests/golden/gen_golden_augment.py): bit-exact for the time-domain augmenters, 1e-5 for the phase shift."""
