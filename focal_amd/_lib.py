@@ -14,7 +14,7 @@ ACT_NONE, ACT_GELU, ACT_RELU_OUT = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class DropDesc(C.Structure):
