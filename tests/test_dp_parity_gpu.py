@@ -11,11 +11,12 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("model", ["SW_Transformer", "DeepSense"])
-def test_two_ranks_equal_single_device(model):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8")
+@pytest.mark.parametrize("model,shard", [("SW_Transformer", "1"), ("SW_Transformer", "0"), ("DeepSense", "1")])
+def test_two_ranks_equal_single_device(model, shard):
+    """shard = FOCAL_LOSS_SHARD: the loss head row-sharded over the two ranks (the default from 6 ranks up) or replicated."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8", FOCAL_LOSS_SHARD=shard)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533" if model == "DeepSense" else "29534", os.path.join(HERE, "dp_worker.py"), model, "16"]
+           "--master-port", "29533" if model == "DeepSense" else ("29534" if shard == "1" else "29535"), os.path.join(HERE, "dp_worker.py"), model, "16"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
@@ -29,7 +30,8 @@ def test_bench_contract_with_two_ranks(model):
     rank 0 whose value is the whole-job rate."""
     import json
     root = os.path.dirname(HERE)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8", FOCAL_BENCH_TEST_BACKEND="gloo")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8", FOCAL_BENCH_TEST_BACKEND="gloo",
+               FOCAL_LOSS_SHARD="1" if model == "SW_Transformer" else "0")  # both segmentations of the step (sharded / replicated head)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541" if model == "DeepSense" else "29542", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
            "--warmup", "2", "--batch", "16", "--model", model]  # no diagnostic flags: rank 0 also measures its roofline (local steps)
