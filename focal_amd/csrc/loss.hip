@@ -539,7 +539,7 @@ static int loss_phase_a(const focal_loss_desc* d, const LossPlan& pl, const floa
 // coefficients and gradient of the own samples, the loss terms.
 static int loss_phase_b(const focal_loss_desc* d, const LossPlan& pl, const float* const* feats, float* terms, float* const* dfeats,
                         const float* xall, float* ws, hipStream_t st) {
-  const int B = d->B, dim = d->dim, seq = d->seq, b = pl.b, n2 = pl.n2, n2p = pl.n2p, Bp = pl.Bp;
+  const int dim = d->dim, seq = d->seq, b = pl.b, n2 = pl.n2, n2p = pl.n2p, Bp = pl.Bp;
   const Shard sh = pl.sh;
   LossTables tb;
   loss_tables(d, feats, dfeats, &tb);

@@ -49,7 +49,6 @@ __device__ __forceinline__ int rowp(int r) { return r ^ (((r >> 3) & 1) << 2); }
 
 __device__ __forceinline__ int a_w1(int h, int c) { return L_W1 + (c >> 5) * 16384 + h * 64 + (((((c & 31) >> 3)) ^ sw_p(h >> 2)) << 4) + (c & 7) * 2; }
 __device__ __forceinline__ int a_w2(int c, int h) { return L_W2 + (h >> 4) * 2048 + rowp(c) * 32 + (h & 15) * 2; }
-__device__ __forceinline__ int a_tile(int base, int row, int col) { return base + row * 128 + ((((col >> 3)) ^ sw_tile(row)) << 4) + (col & 7) * 2; }
 
 // (an element-wise bf16x8{lo[0], .., hi[3]} makes hipcc unpack and re-pack every 16-bit element: ~700 vector instructions per tile)
 __device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
