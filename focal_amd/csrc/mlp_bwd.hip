@@ -4,15 +4,15 @@
 // produces dL/da2 and all four parameter gradients; the hidden activation h and its derivative are RECOMPUTED per tile instead of
 // being read back from two [M, 256] tensors by four GEMM launches:
 //
-//   per 128-token tile, 32 hidden units at a time (8 waves, 16 tokens each in phase A):
-//     phase A   u = a2 W1c^T + b1c -> h = drop(gelu(u)), h' = drop(gelu'(u))        (recompute; mask regenerated from the hash)
-//               dh = gm W2c -> du = dh . h'                                         (accumulator layouts match: no shuffles)
-//               da2 += du W1c                                                       (du re-enters the matrix core from registers)
-//               h, du -> LDS (bf16, [token][32])
-//     phase B   dW2c += gm^T h, dW1c += du^T a2 over all 128 tokens: every wave owns 2 of the chunk's 16 output tiles and keeps its
-//               16 x 8 = 128 tiles... i.e. 16 accumulators (64 VGPRs) for the WHOLE kernel -- the weight gradient leaves the CU once,
-//               as 256-byte contiguous fp32 atomics staged through LDS.
-//   phases of consecutive chunks overlap (double-buffered h / du tiles, one barrier per chunk).
+//   per 128-token tile, 32 hidden units at a time, two roles of 8 waves each:
+//     A waves   u = a2 W1c^T + b1c -> h = drop(gelu(u)), h' = drop(gelu'(u))        (recompute; mask regenerated from the hash)
+//     (16       dh = gm W2c -> du = dh . h'                                         (accumulator layouts match: no shuffles)
+//     tokens    da2 += du W1c                                                       (du re-enters the matrix core from registers)
+//     each)     h, du -> LDS (bf16, [token][32])
+//     B waves   dW2c += gm^T h, dW1c += du^T a2 over all 128 tokens of the PREVIOUS chunk: every B wave owns 2 of a chunk's 16 output
+//               tiles and keeps its 16 accumulators (64 VGPRs) for the WHOLE kernel -- the weight gradient leaves the CU once, as
+//               256-byte contiguous fp32 atomics staged through LDS.
+//   (double-buffered h / du tiles, one barrier per chunk).
 //
 // Operands that are contracted over their row index (W2 for dh, W1 for da2, gm / a2 / h / du for the weight gradients) are read
 // with ds_read_b64_tr_b16; all LDS images are XOR-swizzled so that both their direct and their transposed fragment reads are
@@ -63,257 +63,208 @@ __device__ __forceinline__ float sum8(bf16x8 v) {
   return s;
 }
 
+// The two halves of a barrier interval run on DIFFERENT waves: waves 0-7 ("A") recompute h / h' and produce du and dL/da2 for their
+// 16 tokens, waves 8-15 ("B") contract the previous chunk's h / du sub-tiles into the weight gradients.  The first version ran A then
+// B in every one of 8 waves and was latency-bound (39 % of its wave-cycles waiting, vector ALU 31 % / matrix pipe 9.5 % busy:
+// profiles/r2_mlp_pmc.txt); with the roles on separate waves an interval lasts max(A, B) instead of A + B and every SIMD holds four
+// waves instead of two: 186 -> 165 us at the stage-0 audio shape, +0.9 % on the step (same-box A/B, profiles/r2_mlp_ab.txt (3)).  Each
+// role is its own loop -- its own register budget: the B waves' 64 accumulator registers and the A waves' GELU temporaries never live
+// in the same wave (128 VGPRs, no spills) -- and both execute the same ten workgroup barriers per tile.
 template <bool DROP>
-__global__ __launch_bounds__(512, 2) void mlp_bwd_kernel(const MlpBwdParams p) {
+__global__ __launch_bounds__(1024, 4) void mlp_bwd_kernel(const MlpBwdParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool c_side_first = wave < 4;   // waves 0-3 own dW2 tiles (c-tile cw, all hidden tiles), waves 4-7 dW1 tiles (all hidden tiles, c-tile cw)
-  const int cw = wave & 3;
+  const bool role_a = wave < 8;
+  const int wa = wave & 7;
+  const bool c_side_first = wa < 4;   // B waves 8-11 own dW2 tiles (c-tile cw, all hidden tiles), 12-15 dW1 tiles (all hidden tiles, c-tile cw)
+  const int cw = wa & 3;
 
   // ---- weights -> LDS
   {
-    uint4 v1[4], v2[4];
+    uint4 v1[2], v2[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v1[i] = reinterpret_cast<const uint4*>(p.w1)[tid + 512 * i];
-      v2[i] = reinterpret_cast<const uint4*>(p.w2)[tid + 512 * i];
+    for (int i = 0; i < 2; ++i) {
+      v1[i] = reinterpret_cast<const uint4*>(p.w1)[tid + 1024 * i];
+      v2[i] = reinterpret_cast<const uint4*>(p.w2)[tid + 1024 * i];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = tid + 512 * i;
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 1024 * i;
       *reinterpret_cast<uint4*>(lds + a_w1(q >> 3, (q & 7) * 8)) = v1[i];
-      // a 16-byte chunk of a W2 row = 8 hidden units of one c: the 8-unit half of one sub-image row
       *reinterpret_cast<uint4*>(lds + a_w2(q >> 5, (q & 31) * 8)) = v2[i];
     }
     if (tid < H) reinterpret_cast<float*>(lds + L_B1)[tid] = p.b1[tid];
   }
-
-  MlpDropStream ds;
-  ds.init(p.drop_h);
-  const uint32_t ds_key = ds.s;
-
-  // ---- per-lane address bases (everything else is a compile-time offset)
-  const int mloc = wave * 16 + l15;                                                    // this lane's token inside a tile (phase A)
-  const int b_w1d = L_W1 + l15 * 64 + ((g ^ sw_p(l15 >> 2)) << 4);                     // + (c half) * 16384 + h0 * 64
-  int b_w1t[2];                                                                        // + (c tile >> 1) * 16384 + q * 2048 (+ 1024: rows + 16)
-#pragma unroll
-  for (int jb = 0; jb < 2; ++jb) b_w1t[jb] = L_W1 + (4 * g + tq) * 64 + ((((2 * jb + (tp >> 1))) ^ sw_p(g)) << 4) + (tp & 1) * 8;
-  const int rp_lo = rowp(8 * g + tq) * 32 + tp * 8, rp_hi = rowp(8 * g + tq + 4) * 32 + tp * 8;
-  const int b_w2_lo = L_W2 + rp_lo, b_w2_hi = L_W2 + rp_hi;                            // + (hidden tile) * 2048 + kk * 1024
-  const int hsel = c_side_first ? 0 : 8192;                                            // waves 0-3 contract h, waves 4-7 du
-  const int b_hb_lo = L_HB + hsel + rp_lo, b_hb_hi = L_HB + hsel + rp_hi;              // + buf * 16384 + t * 4096 + ks * 1024
-  const int b_hw = L_HB + rowp(mloc) * 32 + 8 * g;                                     // + buf * 16384 (+ 8192: du) + t * 4096
-  const int b_tr = (c_side_first ? L_GM : L_A2) + (8 * g + tq) * 128 + ((((2 * cw + (tp >> 1))) ^ sw_tile(8 * g + tq)) << 4) + (tp & 1) * 8;  // + ks * 4096 (+ 512)
-  int b_td[2];                                                                         // direct fragments of this lane's token: + 0 (gm) | 16384 (a2)
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) b_td[kk] = L_GM + mloc * 128 + (((4 * kk + g) ^ sw_tile(mloc)) << 4);
-  const int b_b1 = L_B1 + 16 * g;                                                      // + hidden * 4
-  int b_st[2];                                                                         // staging chunks of a token tile (gm; a2 = + 16384)
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int q = tid + 512 * i;
-    b_st[i] = L_GM + (q >> 3) * 128 + (((q & 7) ^ sw_tile(q >> 3)) << 4);
-  }
-
-  f32x4 acc[16];  // this wave's weight-gradient tiles, indexed by hidden tile (0..15)
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbh[16];  // waves 4-7: partial sums of du over this wave's k-step (db1), per hidden tile
-#pragma unroll
-  for (int i = 0; i < 16; ++i) dbh[i] = 0.f;
-  float dbc = 0.f;  // waves 0-3: partial sum of gm over tokens for column 16 cw + l15 (db2)
-
   const int ntiles = (p.M + BM - 1) / BM;
-  // this thread's 2 + 2 staging chunks of a token tile: chunk id = tid + 512 i -> row id >> 3, 16-byte column chunk id & 7
-  uint4 pg[2], pa[2];
+  // every thread stages one 16-byte chunk of gm and one of a2 per tile: chunk id = tid -> row tid >> 3, column chunk tid & 7
+  const int b_st = L_GM + (tid >> 3) * 128 + (((tid & 7) ^ sw_tile(tid >> 3)) << 4);
+  uint4 pg, pa;
   auto prefetch = [&](int tile) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = tid + 512 * i;
-      const long m = (long)tile * BM + (q >> 3);
-      const bool ok = m < p.M;
-      pg[i] = ok ? *reinterpret_cast<const uint4*>(p.gm + m * C + (q & 7) * 8) : make_uint4(0, 0, 0, 0);
-      pa[i] = ok ? *reinterpret_cast<const uint4*>(p.a + m * C + (q & 7) * 8) : make_uint4(0, 0, 0, 0);
-    }
+    const long m = (long)tile * BM + (tid >> 3);
+    const bool ok = m < p.M;
+    pg = ok ? *reinterpret_cast<const uint4*>(p.gm + m * C + (tid & 7) * 8) : make_uint4(0, 0, 0, 0);
+    pa = ok ? *reinterpret_cast<const uint4*>(p.a + m * C + (tid & 7) * 8) : make_uint4(0, 0, 0, 0);
+  };
+  auto stage = [&]() {
+    *reinterpret_cast<uint4*>(lds + b_st) = pg;
+    *reinterpret_cast<uint4*>(lds + b_st + 16384) = pa;
   };
   if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+  const int rp_lo = rowp(8 * g + tq) * 32 + tp * 8, rp_hi = rowp(8 * g + tq + 4) * 32 + tp * 8;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // ---- token tile -> LDS (the previous tile's last barrier has passed: nobody reads the old one any more)
+  if (role_a) {
+    // ================================================================================================= A: recompute, du, dL/da2
+    MlpDropStream ds;
+    ds.init(p.drop_h);
+    const uint32_t ds_key = ds.s;
+    const int mloc = wa * 16 + l15;
+    const int b_w1d = L_W1 + l15 * 64 + ((g ^ sw_p(l15 >> 2)) << 4);
+    int b_w1t[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<uint4*>(lds + b_st[i]) = pg[i];
-      *reinterpret_cast<uint4*>(lds + b_st[i] + 16384) = pa[i];
-    }
-    lds_barrier();
-    if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
-
-    const int m = tile * BM + mloc;
-    uint32_t dst = DROP ? ds.start(ds_key, m, g) : 0u;
-    bf16x8 xa[2], xg[2];
+    for (int jb = 0; jb < 2; ++jb) b_w1t[jb] = L_W1 + (4 * g + tq) * 64 + ((((2 * jb + (tp >> 1))) ^ sw_p(g)) << 4) + (tp & 1) * 8;
+    const int b_w2_lo = L_W2 + rp_lo, b_w2_hi = L_W2 + rp_hi;
+    const int b_hw = L_HB + rowp(mloc) * 32 + 8 * g;
+    int b_td[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      xg[kk] = *reinterpret_cast<const bf16x8*>(lds + b_td[kk]);
-      xa[kk] = *reinterpret_cast<const bf16x8*>(lds + b_td[kk] + 16384);
-    }
-    f32x4 dc[4];
+    for (int kk = 0; kk < 2; ++kk) b_td[kk] = L_GM + mloc * 128 + (((4 * kk + g) ^ sw_tile(mloc)) << 4);
+    const int b_b1 = L_B1 + 16 * g;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      stage();
+      lds_barrier();
+      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+      const int m = tile * BM + mloc;
+      uint32_t dst = DROP ? ds.start(ds_key, m, g) : 0u;
+      bf16x8 xa[2], xg[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Phase A in two parts so that the matrix products of the next chunk can be issued BEFORE phase B of the current one and the
-    // vector work (GELU, masks, packing) after it: an in-order wave only overlaps MFMA with VALU when they alternate in program order.
-    f32x4 ua[2], dha[2];
-    auto phase_a1 = [&](int q) {  // u = a2 W1c^T + b1c, dh = gm W2c for hidden units 32 q .. 32 q + 31
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int ht = 2 * q + t;  // hidden tile (16 units)
-        f32x4 u = *reinterpret_cast<const f32x4*>(lds + b_b1 + ht * 64), dh = f32x4{0.f, 0.f, 0.f, 0.f};  // u starts at the bias
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const bf16x8 w1f = *reinterpret_cast<const bf16x8*>(lds + b_w1d + kk * 16384 + ht * 1024);
-          u = mma16(w1f, xa[kk], u);
-          // W2^T fragment: hidden unit 16 ht + l15, contraction over c = 32 kk + 8 g .. + 7 (rows of the sub-image)
-          const bf16x8 w2f = join(tr_read(lds, b_w2_lo + ht * 2048 + kk * 1024), tr_read(lds, b_w2_hi + ht * 2048 + kk * 1024));
-          dh = mma16(w2f, xg[kk], dh);
-        }
-        ua[t] = u;
-        dha[t] = dh;
+      for (int kk = 0; kk < 2; ++kk) {
+        xg[kk] = *reinterpret_cast<const bf16x8*>(lds + b_td[kk]);
+        xa[kk] = *reinterpret_cast<const bf16x8*>(lds + b_td[kk] + 16384);
       }
-    };
-    auto phase_a2 = [&](int q) {  // h, h', du; du -> da2; h, du -> LDS
-      const int buf = (q & 1) * 16384;
-      bf16x4 dqs[2];
+      f32x4 dc[4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const f32x4 u = ua[t], dh = dha[t];
-        bf16x4 hq, dq;
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          gelu_f2 hh, gg;
-          mlp_gelu_bwd(gelu_f2{u[e], u[e + 1]}, hh, gg);
-          if (DROP) {
-            const gelu_f2 mult = ds.next(dst);
-            hh = mlp_mul2(hh, mult);
-            gg = mlp_mul2(gg, mult);
-          }
-          const gelu_f2 dd = mlp_mul2(gelu_f2{dh[e], dh[e + 1]}, gg);
-          hq[e] = (bf16_t)hh.x; hq[e + 1] = (bf16_t)hh.y;
-          dq[e] = (bf16_t)dd.x; dq[e + 1] = (bf16_t)dd.y;
-        }
-        *reinterpret_cast<bf16x4*>(lds + b_hw + buf + t * 4096) = hq;
-        *reinterpret_cast<bf16x4*>(lds + b_hw + buf + 8192 + t * 4096) = dq;
-        dqs[t] = dq;
-      }
-      const bf16x8 duf = join(dqs[0], dqs[1]);
-      // da2 += du W1c: contraction slots (g, e) <-> hidden 32 q + 16 (e >> 2) + 4 g + (e & 3), the order du sits in registers
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int a0 = b_w1t[j & 1] + (j >> 1) * 16384 + q * 2048;
-        const bf16x8 w1t = join(tr_read(lds, a0), tr_read(lds, a0 + 1024));
-        dc[j] = mma16(w1t, duf, dc[j]);
-      }
-    };
-
-    // Phase B is the SAME instruction stream for all eight waves (a branch would cut the scheduling region and with it any MFMA /
-    // VALU interleaving): D[c][h'] = sum_m Cside[m][c] Hside[m][h'] with (Cside, Hside) = (gm, h) for waves 0-3 -> dW2[c][h'] and
-    // (a2, du) for waves 4-7 -> dW1[h'][c] transposed; only the per-lane base addresses differ.
-    auto phase_b = [&](int q) {
-      const int buf = (q & 1) * 16384;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 fc = join(tr_read(lds, b_tr + ks * 4096), tr_read(lds, b_tr + ks * 4096 + 512));
+      for (int j = 0; j < 4; ++j) dc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto phase_a = [&](int q) {  // hidden units 32 q .. 32 q + 31: u, dh -> h, h', du -> LDS; da2 += du W1c
+        const int buf = (q & 1) * 16384;
+        bf16x4 dqs[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const bf16x8 fh = join(tr_read(lds, b_hb_lo + buf + t * 4096 + ks * 1024), tr_read(lds, b_hb_hi + buf + t * 4096 + ks * 1024));
-          acc[2 * q + t] = mma16(fc, fh, acc[2 * q + t]);
+          const int ht = 2 * q + t;
+          f32x4 u = *reinterpret_cast<const f32x4*>(lds + b_b1 + ht * 64), dh = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 w1f = *reinterpret_cast<const bf16x8*>(lds + b_w1d + kk * 16384 + ht * 1024);
+            u = mma16(w1f, xa[kk], u);
+            const bf16x8 w2f = join(tr_read(lds, b_w2_lo + ht * 2048 + kk * 1024), tr_read(lds, b_w2_hi + ht * 2048 + kk * 1024));
+            dh = mma16(w2f, xg[kk], dh);
+          }
+          bf16x4 hq, dq;
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            gelu_f2 hh, gg;
+            mlp_gelu_bwd(gelu_f2{u[e], u[e + 1]}, hh, gg);
+            if (DROP) {
+              const gelu_f2 mult = ds.next(dst);
+              hh = mlp_mul2(hh, mult);
+              gg = mlp_mul2(gg, mult);
+            }
+            const gelu_f2 dd = mlp_mul2(gelu_f2{dh[e], dh[e + 1]}, gg);
+            hq[e] = (bf16_t)hh.x; hq[e + 1] = (bf16_t)hh.y;
+            dq[e] = (bf16_t)dd.x; dq[e + 1] = (bf16_t)dd.y;
+          }
+          *reinterpret_cast<bf16x4*>(lds + b_hw + buf + t * 4096) = hq;
+          *reinterpret_cast<bf16x4*>(lds + b_hw + buf + 8192 + t * 4096) = dq;
+          dqs[t] = dq;
         }
-      }
-    };
-    // bias gradients (the only wave-dependent code, kept behind the interval's matrix work): db2 = column sums of gm (waves 0-3, once
-    // per tile), db1 = column sums of du (waves 4-7: wave 4 + cw takes the 32 tokens of k-step cw); the fragments are re-read
-    auto phase_db = [&](int q) {
-      const int buf = (q & 1) * 16384;
-      if (c_side_first) {
-        if (q == 0) {
+        const bf16x8 duf = join(dqs[0], dqs[1]);
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) dbc += sum8(join(tr_read(lds, b_tr + ks * 4096), tr_read(lds, b_tr + ks * 4096 + 512)));
+        for (int j = 0; j < 4; ++j) {
+          const int a0 = b_w1t[j & 1] + (j >> 1) * 16384 + q * 2048;
+          const bf16x8 w1t = join(tr_read(lds, a0), tr_read(lds, a0 + 1024));
+          dc[j] = mma16(w1t, duf, dc[j]);
         }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-          dbh[2 * q + t] += sum8(join(tr_read(lds, b_hb_lo + buf + t * 4096 + cw * 1024), tr_read(lds, b_hb_hi + buf + t * 4096 + cw * 1024)));
-      }
-    };
-
-#ifndef MLP_SCHED
-#define MLP_SCHED 1
-#endif
-    phase_a1(0);
-    phase_a2(0);
-    lds_barrier();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-#if MLP_SCHED == 0
-      phase_b(q);
-      if (q < 7) { phase_a1(q + 1); phase_a2(q + 1); }
-      phase_db(q);
-#else
-      if (q < 7) phase_a1(q + 1);
-      phase_b(q);
-      if (q < 7) phase_a2(q + 1);
-#if MLP_SCHED == 2
-      // ask for an alternating issue order inside this barrier interval: one matrix instruction, then a run of vector instructions
-#pragma unroll
-      for (int i = 0; i < 20; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-      }
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      phase_db(q);
-#endif
+      };
+      phase_a(0);
       lds_barrier();
-    }
-
-    // ---- dL/da2 for this wave's 16 tokens
-    if (m < p.M) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) store4(p.da + (long)m * C + 16 * j + 4 * g, dc[j]);
-    }
-  }
-
-  // ---- flush: tiles -> LDS ([64][256] dW2 then [256][64] dW1, fp32), then 256-byte contiguous atomics
-  float* F2 = reinterpret_cast<float*>(lds);
-  float* F1 = reinterpret_cast<float*>(lds + 65536);
+      for (int q = 0; q < 8; ++q) {
+        if (q < 7) phase_a(q + 1);
+        lds_barrier();
+      }
+      if (m < p.M) {
 #pragma unroll
-  for (int ht = 0; ht < 16; ++ht) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (c_side_first) F2[(16 * cw + 4 * g + r) * H + 16 * ht + l15] = acc[ht][r];   // D[c][h'] -> dW2[c][h']
-      else F1[(16 * ht + l15) * C + 16 * cw + 4 * g + r] = acc[ht][r];                 // D[c][h'] -> dW1[h'][c]
+        for (int j = 0; j < 4; ++j) store4(p.da + (long)m * C + 16 * j + 4 * g, dc[j]);
+      }
     }
-  }
-  __syncthreads();
-#pragma unroll 4
-  for (int i = 0; i < 32; ++i) {
-    const int idx = tid + 512 * i;
-    atomicAdd(p.dw2 + idx, F2[idx]);
-    atomicAdd(p.dw1 + idx, F1[idx]);
-  }
-  // bias gradients: fold the 4 contraction groups of a fragment, then one atomic per column and wave
-  if (c_side_first) {
-    dbc += __shfl_xor(dbc, 16, 64);
-    dbc += __shfl_xor(dbc, 32, 64);
-    if (g == 0 && p.db2) atomicAdd(p.db2 + 16 * cw + l15, dbc);
-  } else if (p.db1) {
+    __syncthreads();  // B waves have put their tiles into LDS
+  } else {
+    // ================================================================================================= B: weight / bias gradients
+    const int hsel = c_side_first ? 0 : 8192;
+    const int b_hb_lo = L_HB + hsel + rp_lo, b_hb_hi = L_HB + hsel + rp_hi;
+    const int b_tr = (c_side_first ? L_GM : L_A2) + (8 * g + tq) * 128 + ((((2 * cw + (tp >> 1))) ^ sw_tile(8 * g + tq)) << 4) + (tp & 1) * 8;
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbh[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dbh[i] = 0.f;
+    float dbc = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      stage();
+      lds_barrier();
+      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+      lds_barrier();  // chunk 0 of this tile is in LDS
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int buf = (q & 1) * 16384;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 fc = join(tr_read(lds, b_tr + ks * 4096), tr_read(lds, b_tr + ks * 4096 + 512));
+          if (c_side_first && q == 0) dbc += sum8(fc);  // db2: column sums of gm, once per tile
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const bf16x8 fh = join(tr_read(lds, b_hb_lo + buf + t * 4096 + ks * 1024), tr_read(lds, b_hb_hi + buf + t * 4096 + ks * 1024));
+            acc[2 * q + t] = mma16(fc, fh, acc[2 * q + t]);
+            if (!c_side_first && ks == cw) dbh[2 * q + t] += sum8(fh);  // db1: wave 12 + cw takes the 32 tokens of k-step cw
+          }
+        }
+        lds_barrier();
+      }
+    }
+    // ---- tiles -> LDS ([64][256] dW2 then [256][64] dW1, fp32)
+    float* F2 = reinterpret_cast<float*>(lds);
+    float* F1 = reinterpret_cast<float*>(lds + 65536);
 #pragma unroll
     for (int ht = 0; ht < 16; ++ht) {
-      float v = dbh[ht];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (g == 0) atomicAdd(p.db1 + 16 * ht + l15, v);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (c_side_first) F2[(16 * cw + 4 * g + r) * H + 16 * ht + l15] = acc[ht][r];
+        else F1[(16 * ht + l15) * C + 16 * cw + 4 * g + r] = acc[ht][r];
+      }
     }
+    if (c_side_first) {
+      dbc += __shfl_xor(dbc, 16, 64);
+      dbc += __shfl_xor(dbc, 32, 64);
+      if (g == 0 && p.db2) atomicAdd(p.db2 + 16 * cw + l15, dbc);
+    } else if (p.db1) {
+#pragma unroll
+      for (int ht = 0; ht < 16; ++ht) {
+        float v = dbh[ht];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) atomicAdd(p.db1 + 16 * ht + l15, v);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- 256-byte contiguous atomics of the two weight gradients, all 1024 threads
+  const float* F2 = reinterpret_cast<const float*>(lds);
+  const float* F1 = reinterpret_cast<const float*>(lds + 65536);
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int idx = tid + 1024 * i;
+    atomicAdd(p.dw2 + idx, F2[idx]);
+    atomicAdd(p.dw1 + idx, F1[idx]);
   }
 }
 
@@ -365,8 +316,8 @@ extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void
     attr_set[drop] = true;
   }
   const int ntiles = (d->M + BM - 1) / BM;
-  const int grid = ntiles < 256 ? ntiles : 256;  // one persistent 8-wave workgroup per CU
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BWD_BYTES, (hipStream_t)stream, p);
+  const int grid = ntiles < 256 ? ntiles : 256;  // one persistent 16-wave workgroup per CU
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), LDS_BWD_BYTES, (hipStream_t)stream, p);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
