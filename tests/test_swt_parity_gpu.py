@@ -224,11 +224,13 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
         eps = 2e-3 / max(d.abs().max().item(), 1e-6)
         with torch.no_grad():
             p.add_(eps * d)
-            up = sum(value().item() for _ in range(3)) / 3
+            ups = [value().item() for _ in range(5)]
             p.add_(-2 * eps * d)
-            dn = sum(value().item() for _ in range(3)) / 3
+            dns = [value().item() for _ in range(5)]
             p.add_(eps * d)
-        num = (up - dn) / (2 * eps)
+        # medians: a forward value is occasionally off by ~15x the usual run-to-run spread (seen once in ~8 runs of this test with
+        # 3-evaluation means: 4e-4 against a spread of 2.6e-5), which a mean passes on to the difference quotient
+        num = (float(np.median(ups)) - float(np.median(dns))) / (2 * eps)
         assert abs(num - ana) < 3e-2 * max(abs(ana), abs(num), 1e-3) + 2 * noise / (2 * eps), (n, num, ana, noise, eps)
 
 
