@@ -327,7 +327,7 @@ class StepTracer:
             b, f = _dw_bytes_flops(d)
             kern = ("focal_dw_ring_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles, LDS-DMA ring>" if lib.focal_linear_bwd_weight_kernel(ctypes.byref(d)) == 2
                     else "focal_gemm_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles>")
-            return (kern, f"{wgs} workgroups x 256", b, f, "hbm", f"dW[{d.N},{d.K}] over {d.M} rows")
+            return (kern, f"{wgs} workgroups x {512 if kern.startswith('focal_dw_ring') else 256}", b, f, "hbm", f"dW[{d.N},{d.K}] over {d.M} rows")
 
         def lnb(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None, dx_masked=None, mask=None):
             rows, C = dy.shape
@@ -336,7 +336,7 @@ class StepTracer:
             return ("ln_bwd_kernel", "persistent grid (all LayerNorm backward launches)", b, 8.0 * rows * C, "hbm", f"rows {rows} x C {C}")
 
         def mlpb(d, gm, a, *rest, **kw):
-            return ("mlp_bwd_kernel", "256 workgroups x 512 (persistent)", d.M * d.C * 6, 10.0 * d.M * d.C * d.hidden, "mfma", f"M {d.M}")
+            return ("mlp_bwd_kernel", "256 workgroups x 1024 (persistent)", d.M * d.C * 6, 10.0 * d.M * d.C * d.hidden, "mfma", f"M {d.M}")
         self._wrap("linear_bwd_weight", dw)
         self._wrap("layernorm_bwd", lnb)
         self._wrap("mlp_bwd", mlpb)

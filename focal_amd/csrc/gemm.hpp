@@ -597,6 +597,15 @@ static inline bool focal_dw_ring_shape(int M, int N, long rows) {
   return !off && M % 64 == 0 && N % 64 == 0 && rows % 64 == 0 && rows >= 64;
 }
 
+// Workgroups per output tile of the ring kernel when every workgroup takes two token slices (8 waves, two rings = 128 KB of LDS: ONE
+// workgroup per CU, so the launch must not exceed the 256 CUs by a few workgroups -- 288 would run as two rounds).
+static inline int focal_dw_ring_pairs(int M, int N, int splits) {
+  const int tiles = (M / 64) * (N / 64);
+  int pairs = (splits + 1) / 2;
+  if (tiles <= 256 && tiles * pairs > 256) pairs = 256 / tiles;
+  return pairs < 1 ? 1 : pairs;
+}
+
 // Host-side dispatch (gemm_dispatch.inc, instantiated per compute type in gemm_bf16.hip / gemm_f32.hip).
 // dtype codes: FOCAL_F32 / FOCAL_BF16.  Returns a focal error code.
 struct GemmSpec {

@@ -26,8 +26,11 @@
 #pragma once
 #include "gemm_pipe.hpp"
 
-template <int RPS, int NST, bool WITH_BIAS>
-__global__ __launch_bounds__(256) void focal_dw_ring_kernel(const GemmParams p) {
+template <int RPS, int NST, bool WITH_BIAS, int HALVES>
+__global__ __launch_bounds__(256 * HALVES) void focal_dw_ring_kernel(const GemmParams p) {
+  // HALVES = 2: two groups of four waves, each with its own ring and its own slice of the token range, work on the SAME output tile and
+  // add their accumulators through LDS before the one atomic pass -- the 8 waves a CU held as two workgroups, with half the atomic
+  // volume (the epilogue's fp32 atomics retire at ~1.3 TB/s at the memory side: 2-5 us per launch, profiles/r2_dw_fixed_cost.txt).
   constexpr int TILE = 64;
   constexpr int ROWB = TILE * 2;                 // bytes of a stage row (one operand)
   constexpr int CPR = ROWB / 16;                 // 16-byte chunks per row: 8
@@ -38,18 +41,20 @@ __global__ __launch_bounds__(256) void focal_dw_ring_kernel(const GemmParams p) 
   constexpr int WT = TILE / 2, NF = WT / 16;     // wave tile edge (2 x 2 waves), fragments per side: 2
   static_assert(APIECES % 4 == 0, "a piece index must be an A piece or a B piece for all four waves");
   constexpr int WPITCH = WT + 4;
-  static_assert(NST * STAGE_BYTES >= 4 * 16 * WPITCH * 4, "epilogue staging must fit in the ring");
-  extern __shared__ __attribute__((aligned(1024))) char dww_lds[];
+  static_assert(NST * STAGE_BYTES >= 4 * (NF * NF + NF) * 1024 && NST * STAGE_BYTES >= 4 * 16 * WPITCH * 4, "epilogue staging must fit in the ring");
+  extern __shared__ __attribute__((aligned(1024))) char dww_lds_all[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave8 >> 2, wave = wave8 & 3;
+  char* dww_lds = dww_lds_all + half * (NST * STAGE_BYTES);  // this half's ring
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = p.N / TILE, ntiles = (p.M / TILE) * tiles_n;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = logical % ntiles, sp = logical / ntiles;
   const int m0 = (tile / tiles_n) * TILE, n0 = (tile % tiles_n) * TILE;
   const int KT = p.K / RPS;
-  const int kt_per = (KT + p.splits - 1) / p.splits;
-  const int kt0 = sp * kt_per, kt1 = min(KT, kt0 + kt_per);
+  const int kt_per = (KT + p.splits * HALVES - 1) / (p.splits * HALVES);  // stages per token slice; slice = sp * HALVES + half
+  const int kt0 = min(KT, (sp * HALVES + half) * kt_per), kt1 = min(KT, kt0 + kt_per);
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
   float* C = reinterpret_cast<float*>(p.C);
@@ -150,17 +155,47 @@ __global__ __launch_bounds__(256) void focal_dw_ring_kernel(const GemmParams p) 
   for (int s = 0; s < NST - 1; ++s)
     if (s < nk) fill(kt0 + s, s);
   int stage = 0, fstage = NST - 1;
-  for (int i = 0; i < nk; ++i) {
+  // every wave of the workgroup meets the same number of barriers: the trip count is the slice length of a FULL slice (the last
+  // slices of the token range may be shorter or empty)
+  for (int i = 0; i < (HALVES == 1 ? nk : kt_per); ++i) {
     const int ahead = nk - 1 - i;  // stages issued beyond this one: min(NST - 2, ahead) stay in flight
     if (NST >= 4 && ahead >= 2) pipe_wait_barrier<2 * LPW>();
     else if (NST >= 3 && ahead >= 1) pipe_wait_barrier<LPW>();
     else pipe_wait_barrier<0>();
     if (i + NST - 1 < nk) fill(kt0 + i + NST - 1, fstage);
-    compute(stage);
+    if (HALVES == 1 || i < nk) compute(stage);
     stage = (stage + 1 == NST) ? 0 : stage + 1;
     fstage = (fstage + 1 == NST) ? 0 : fstage + 1;
   }
-  asm volatile("s_barrier" ::: "memory");  // the ring is re-used as epilogue staging
+  asm volatile("s_barrier" ::: "memory");  // the rings are re-used as epilogue staging
+  if (HALVES >= 2) {
+    // the other groups hand their accumulators over (16 bytes per lane and tile, each in its own ring), the first group adds them
+    if (half >= 1) {
+      float4* xch = reinterpret_cast<float4*>(dww_lds) + wave * (NF * NF + NF) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) xch[(i * NF + j) * 64] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        xch[(NF * NF + i) * 64] = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (half >= 1) return;
+#pragma unroll
+    for (int h = 1; h < HALVES; ++h) {
+      const float4* xch = reinterpret_cast<const float4*>(dww_lds_all + h * (NST * STAGE_BYTES)) + wave * (NF * NF + NF) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const float4 v = xch[(i * NF + j) * 64];
+          acc[i][j] += f32x4{v.x, v.y, v.z, v.w};
+        }
+        const float4 vb = xch[(NF * NF + i) * 64];
+        accb[i] += f32x4{vb.x, vb.y, vb.z, vb.w};
+      }
+    }
+  }
 
   // ---- epilogue: D[n][m] accumulators -> this wave's [16 m][32 n] fp32 staging -> contiguous atomics, two 128-byte output rows per
   // wave instruction
@@ -184,12 +219,12 @@ __global__ __launch_bounds__(256) void focal_dw_ring_kernel(const GemmParams p) 
   }
 }
 
-template <int RPS, int NST>
+template <int RPS, int NST, int HALVES>
 static inline hipError_t focal_launch_dw_ring(const GemmParams& p, hipStream_t stream) {
   constexpr int TILE = 64;
-  constexpr int LDS_BYTES = NST * RPS * TILE * 4;
-  auto kern = focal_dw_ring_kernel<RPS, NST, true>;
-  auto kern0 = focal_dw_ring_kernel<RPS, NST, false>;
+  constexpr int LDS_BYTES = HALVES * NST * RPS * TILE * 4;
+  auto kern = focal_dw_ring_kernel<RPS, NST, true, HALVES>;
+  auto kern0 = focal_dw_ring_kernel<RPS, NST, false, HALVES>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -198,7 +233,7 @@ static inline hipError_t focal_launch_dw_ring(const GemmParams& p, hipStream_t s
     attr_set = true;
   }
   dim3 grid((p.M / TILE) * (p.N / TILE) * p.splits);
-  if (p.colsumA) hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, stream, p);
-  else hipLaunchKernelGGL(kern0, grid, dim3(256), LDS_BYTES, stream, p);
+  if (p.colsumA) hipLaunchKernelGGL(kern, grid, dim3(256 * HALVES), LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL(kern0, grid, dim3(256 * HALVES), LDS_BYTES, stream, p);
   return hipGetLastError();
 }

@@ -164,6 +164,7 @@ static bool dw_launch_plan(const focal_linear_desc* d, int* kernel, int* wgs) {
   const bool ring = d->dtype == FOCAL_BF16 && d->x_dtype == FOCAL_BF16 && d->y_dtype == FOCAL_BF16 && !masked && bm == 64 && bn == 64 &&
                     focal_dw_ring_shape(d->N, d->K, d->M);
   *kernel = ring ? 2 : 1;
+  if (ring && splits >= 2) splits = focal_dw_ring_pairs(d->N, d->K, splits);  // two token slices per 8-wave workgroup (gemm_dw_ring.hpp)
   *wgs = ((d->N + bm - 1) / bm) * ((d->K + bn - 1) / bn) * splits;
   return true;
 }

@@ -158,7 +158,7 @@ int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const vo
  * calls against the launch shapes of a profiler trace (bench.py's in-step roofline).  0 = invalid descriptor. */
 int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d);
 /* Which kernel that launch runs: 1 = focal_gemm_kernel (register-staged, any dtype / loader), 2 = focal_dw_ring_kernel (the LDS-DMA
- * ring for bf16 shapes made of whole 64-tiles, given 16-byte aligned operands).  0 = invalid descriptor. */
+ * ring for bf16 shapes made of whole 64-tiles, given 16-byte aligned operands; 512-thread workgroups of two token slices each).  0 = invalid descriptor. */
 int focal_linear_bwd_weight_kernel(const focal_linear_desc* d);
 
 /* Fused MLP branch of a Swin block (models/SwinModules.py:18-34 Mlp.forward + the residual / DropPath of :339-341), bf16,
