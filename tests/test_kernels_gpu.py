@@ -99,6 +99,30 @@ def test_linear_bwd(ops, ct, M, N, K):
     assert rel_err(dw, 2 * (dy.float().t() @ x.float())) < (2e-5 if ct == torch.float32 else 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (128, 64, 192), (192, 192, 64), (320, 64, 64), (8256, 64, 64), (4160, 384, 128), (1088, 768, 256),
+                                   (960, 1024, 1024), (640, 2048, 1024), (70400, 64, 128), (33024, 128, 64), (2112, 256, 704)])
+def test_weight_gradient_ring_kernel_shapes(ops, M, N, K):
+    """The LDS-DMA ring kernel over its launch plans: one token slice per 4-wave workgroup (few rows), two slices per 8-wave workgroup with
+    the LDS reduction, slices of unequal or zero length (row counts that do not divide), 3 / 12 / 48 / 256 / 512 output tiles (the cap of
+    one workgroup per CU, and beyond it), with and without the bias gradient, accumulating into a non-zero buffer."""
+    import ctypes
+    from focal_amd import _lib
+    ct = torch.bfloat16
+    x, dy = rnd(M, K, seed=21, dtype=ct), rnd(M, N, seed=22, dtype=ct)
+    c = ops.code(ct)
+    d = ops.linear_desc(c, M, N, K, c, c)
+    assert _lib.load().focal_linear_bwd_weight_kernel(ctypes.byref(d)) == 2
+    ref = dy.float().t() @ x.float()
+    dw = torch.full((N, K), 0.5, device=DEV)
+    db = torch.full((N,), -1.0, device=DEV)
+    ops.linear_bwd_weight(d, dy, x, dw, db)
+    assert rel_err(dw - 0.5, ref) < 2e-4
+    assert rel_err(db + 1.0, dy.float().sum(0)) < 1e-4
+    dw2 = torch.zeros(N, K, device=DEV)
+    ops.linear_bwd_weight(d, dy, x, dw2, None)
+    assert rel_err(dw2, ref) < 2e-4
+
+
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
 def test_linear_bwd_fc2_chain(ops, ct):
     """fc2 of the Swin MLP: y = r + h W^T + b with fp32 dy -> du = (dy W) * h' and dW = dy^T h."""
