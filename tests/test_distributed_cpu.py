@@ -55,6 +55,23 @@ def _worker(rank, world, port, out):
     all_reduce_gradients(ar, bucket_bytes=4096)
     ref = torch.cat([Wr[m].grad.reshape(-1) for m in mods])
     err = ((ar.grad - ref).norm() / ref.norm()).item()
+    # the one collective inside the row-sharded loss head: every rank's chunk, in rank order, on persistent buffers
+    from focal_amd import distributed as fd
+
+    class Head:
+        send = torch.full((40,), float(rank + 1))
+        chunks = torch.zeros(world, 40)
+    fd.exchange_loss_chunks(Head)
+    assert all(torch.all(Head.chunks[r] == r + 1) for r in range(world))
+    # sharded by default from 6 ranks up; the switch forces either form; never inside local_only()
+    assert fd.shard_loss_head() is False
+    os.environ["FOCAL_LOSS_SHARD"] = "1"
+    assert fd.shard_loss_head() is True
+    with fd.local_only():
+        assert fd.shard_loss_head() is False
+    os.environ["FOCAL_LOSS_SHARD"] = "0"
+    assert fd.shard_loss_head() is False
+    del os.environ["FOCAL_LOSS_SHARD"]
     out[rank] = err
     dist.destroy_process_group()
 
