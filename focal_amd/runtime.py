@@ -59,6 +59,27 @@ def fork(device, index):
     return st
 
 
+def fork_point(device):
+    """An event on the caller's stream marking everything the encoders depend on (inputs, weights, zeroed gradients).  Side streams
+    that wait for THIS event -- not for the caller's stream as it is when their turn comes -- do not queue up behind the encoders
+    launched before them: until round 3 every fork waited for the work already enqueued on the caller's stream, i.e. for the whole
+    forward pass of the modality that ran there first, and the forward passes of the modalities never overlapped (only their
+    backward passes did, which autograd orders by the producing op)."""
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    return ev
+
+
+def fork_from(device, index, point):
+    """Stream `index` (0 = the caller's), ordered after `point` (see fork_point) only."""
+    if os.environ.get("FOCAL_FORK_LATE") == "1":  # A/B switch: the old behaviour
+        return fork(device, index)
+    st = side_stream(device, index)
+    if st != torch.cuda.current_stream(device):
+        st.wait_event(point)
+    return st
+
+
 def join_all(device):
     cur = torch.cuda.current_stream(device)
     for (dev, _), st in _SIDE.items():

@@ -200,23 +200,27 @@ class Augmenter:
         """Where this view's spectrum goes: the pretraining loop draws two views of the same windows back to back
         (train_utils/pretrain.py), so the first call gets the first half of a fresh [2B, 2C, I, n] tensor and the second call (same
         input tensor) the second half -- a backbone that runs both views as one batch then needs no concatenation."""
-        pend = self.__dict__.setdefault("_pending_pairs", {})
         key = (loc, mod)
         B = x.shape[0]
+        # `static_views` (set by the graph-replaying training loop): the two-view tensor of a (location, modality) keeps its address
+        # from step to step, so a captured step can read it; the loop guarantees a step has finished reading before the next writes.
+        # The halves are handed out strictly in turn (first, second, first, ...) per tensor: pairing by the input's address, as the
+        # non-static path below does, would hand the FIRST half out twice whenever a loader that sources its batches on the host
+        # makes `move_to_target_device` allocate a new device tensor per call -- view 2 would silently overwrite view 1.
+        if getattr(self, "static_views", False):
+            pool = self.__dict__.setdefault("_static_pairs", {})
+            shape = (2 * B, 2 * x.shape[1], x.shape[2], x.shape[3])
+            ent = pool.get((key, shape, x.device))
+            if ent is None:
+                ent = pool[(key, shape, x.device)] = [torch.empty(shape, dtype=torch.float32, device=x.device), 0]
+            ent[1] += 1
+            return ent[0][:B] if ent[1] % 2 == 1 else ent[0][B:]
+        pend = self.__dict__.setdefault("_pending_pairs", {})
         tag = (x.data_ptr(), tuple(x.shape), x.device)
         hit = pend.pop(key, None)
         if hit is not None and hit[0] == tag:
             return hit[1][B:]
-        # `static_views` (set by the graph-replaying training loop): the two-view tensor of a (location, modality) keeps its address
-        # from step to step, so a captured step can read it; the loop guarantees a step has finished reading before the next writes
-        if getattr(self, "static_views", False):
-            pool = self.__dict__.setdefault("_static_pairs", {})
-            shape = (2 * B, 2 * x.shape[1], x.shape[2], x.shape[3])
-            base = pool.get((key, shape, x.device))
-            if base is None:
-                base = pool[(key, shape, x.device)] = torch.empty(shape, dtype=torch.float32, device=x.device)
-        else:
-            base = torch.empty(2 * B, 2 * x.shape[1], x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
+        base = torch.empty(2 * B, 2 * x.shape[1], x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
         pend[key] = (tag, base)
         return base[:B]
 

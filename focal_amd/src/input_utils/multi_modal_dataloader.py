@@ -81,6 +81,11 @@ class BatchSeqSampler(torch.utils.data.Sampler):
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.seed, self.epoch = seed, 0
 
+    def set_epoch(self, epoch):
+        """The training epoch the next pass belongs to (the rank-consistent shuffle is seeded by it): passes that are not training
+        epochs -- the KNN fit over the training set -- and a resumed run then do not shift the sequence of orders."""
+        self.epoch, self._epoch_set = int(epoch), True
+
     def _batches(self):
         import random
         if self.world > 1:
@@ -100,7 +105,8 @@ class BatchSeqSampler(torch.utils.data.Sampler):
             for sid in mine:
                 out.extend(self.dataset.subseq_to_sample_idx[self.dataset.subseqs[sid]])
             yield out
-        self.epoch += 1
+        if not getattr(self, "_epoch_set", False):
+            self.epoch += 1
 
     def __len__(self):
         if self.world == 1:

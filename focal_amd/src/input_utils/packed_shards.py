@@ -79,6 +79,11 @@ class PackedSequenceLoader:
         full, rem = divmod(len(self.subseqs), self.subseq_batch)
         return full + (1 if (rem // self.world) * self.world >= 2 else 0)
 
+    def set_epoch(self, epoch):
+        """The training epoch the next pass belongs to (rank-consistent shuffling under torch.distributed is seeded by it): passes that
+        are not training epochs -- the KNN fit over the training set -- and a resumed run then do not shift the sequence of orders."""
+        self.epoch, self._epoch_set = int(epoch), True
+
     def batches(self):
         """Sample-index lists of this rank's share of every global batch, in the reference's order."""
         order = list(range(len(self.subseqs)))
@@ -130,7 +135,8 @@ class PackedSequenceLoader:
                 q.put((self._assemble(idx, slot), slot))
             q.put(None)
         threading.Thread(target=producer, daemon=True).start()
-        self.epoch += 1
+        if not getattr(self, "_epoch_set", False):
+            self.epoch += 1
         use_gpu = torch.cuda.is_available() and torch.device(self.device).type == "cuda"
         copy_stream = torch.cuda.Stream(device=self.device) if use_gpu else None
         while True:

@@ -125,8 +125,12 @@ class DeepSense(HipBackbone):
         # encoder has left its convolution stack (the last BatchNorm), see deepsense_engine.forward.
         # (view_index: FOCAL.forward numbers its two backbone calls 0 / 1; any other caller runs one stream per modality)
         view_streams = view_index is not None and os.environ.get("FOCAL_DS_VIEW_STREAMS", "1") != "0" and self.training
+        point = runtime.fork_point(dev)  # every encoder starts from here: none waits for the one launched before it
+        late = os.environ.get("FOCAL_FORK_LATE") == "1"
         for mi, mod in enumerate(self.modalities):
-            st = runtime.fork(dev, (view_index * len(self.modalities) if view_streams else 0) + mi)
+            # with one stream per (view, modality) no encoder runs on the caller's stream (index 0): view 2's forks would otherwise
+            # wait for the view-1 pass that was enqueued there
+            st = runtime.fork_from(dev, (view_index * len(self.modalities) + (0 if late else 1) if view_streams else 0) + mi, point)
             with torch.cuda.stream(st):
                 self._encoders[(loc, mod)].pass_order = view_index if view_streams else None
                 f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)

@@ -125,8 +125,9 @@ class SW_Transformer(HipBackbone):
             raise FocalHipError("the FOCAL HIP path needs the model on a ROCm device (no CPU fallback)")
         cur = torch.cuda.current_stream(dev)
         out = {}
+        point = runtime.fork_point(dev)  # every encoder starts from here: none waits for the one launched before it
         for mi, mod in enumerate(self.modalities):
-            st = runtime.fork(dev, (view % 2) * len(self.modalities) + mi)
+            st = runtime.fork_from(dev, (view % 2) * len(self.modalities) + mi, point)
             with torch.cuda.stream(st):
                 f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
                 out[mod] = run_stage(self, self._heads[mod], f) if proj_head else f

@@ -66,6 +66,9 @@ def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, 
     augmenter.static_views = graphed.enabled
     for epoch in range(start_epoch, epochs):
         default_model.train()
+        for owner in (train_dataloader, getattr(train_dataloader, "batch_sampler", None)):
+            if hasattr(owner, "set_epoch"):
+                owner.set_epoch(epoch)  # the data-parallel shuffle follows the training epoch (also after -resume)
         train_loss_list = []
         epoch_t0, epoch_windows = time_sync(), 0
         pending = None
@@ -73,6 +76,9 @@ def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, 
             # the views of step k are drawn (host: coin flips, warp tables, up to ~5 ms for a TimeWarp of the audio window) while the
             # GPU still runs step k - 1; only then is that step's loss read (the reference's per-step `loss.item()`, one step late
             # on the wall clock, same values): the static loss buffer of the captured step must be read before the next replay
+            # (the batch crosses to the device once; both draws then see the same device tensors, which is also what pairs the two
+            # views of a modality into the halves of one tensor, data_augmenter/Augmenter.py::_view_slot)
+            time_loc_inputs, _ = augmenter.move_to_target_device(time_loc_inputs, None)
             view1 = augmenter.forward("random", time_loc_inputs)
             view2 = augmenter.forward("random", time_loc_inputs)
             if pending is not None:

@@ -125,3 +125,33 @@ def test_augmenter_writes_back_to_back_views_into_one_batch_tensor():
     for m in cfg["modality_names"]:
         assert v3[loc][m]._base is not v4[loc][m]._base
         assert _as_one_batch(v3[loc][m], v4[loc][m]).shape[0] == 8  # concatenated
+
+
+def test_static_views_pair_host_sourced_batches():
+    """`static_views` (the graph-replaying loop): a loader that sources its batches on the HOST makes every `forward("random")`
+    call move them to a NEW device tensor, so the two draws of a step cannot be paired by the input's address (the second
+    view then overwrote the first one in the pooled tensor).  The halves are handed out in turn, and the step's tensor keeps its
+    address from step to step."""
+    import yaml
+    from conftest import make_args
+    from data_augmenter import Augmenter as A
+    with open(os.path.join(ROOT, "focal_amd", "src", "data", "MOD.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    args = make_args(cfg, "SW_Transformer", torch.device("cuda"), "bf16")
+    aug = A.Augmenter(args)
+    aug.static_views = True
+    loc = cfg["location_names"][0]
+    host = {loc: {m: torch.randn(4, cfg["loc_mod_in_time_channels"][loc][m], cfg["num_segments"], cfg["loc_mod_spectrum_len"][loc][m])
+                  for m in cfg["modality_names"]}}
+    bases = None
+    for step in range(3):
+        junk = torch.empty(1 << 20, device="cuda")  # perturbs the allocator between the two moves, as a warp's temporaries do
+        v1 = aug.forward("random", host)
+        del junk
+        v2 = aug.forward("random", host)
+        for m in cfg["modality_names"]:
+            a, b = v1[loc][m], v2[loc][m]
+            assert a._base is b._base and a.data_ptr() == a._base.data_ptr() and b.data_ptr() == a.data_ptr() + a.numel() * 4, (step, m)
+        now = {m: v1[loc][m]._base.data_ptr() for m in cfg["modality_names"]}
+        assert bases is None or bases == now
+        bases = now

@@ -81,3 +81,20 @@ def test_packed_loader_equals_per_sample_files(tmp_path):
         for j in range(0, len(idxs), 4):
             seqs = {names[i].rsplit("_", 1)[0] for i in idxs[j:j + 4]}
             assert len(seqs) == 1
+
+
+def test_device_list_spawns_ranks_only_for_focal_pretraining():
+    """`-gpu=0,1` starts a data-parallel job only where the loop is data-parallel (FOCAL pretraining); the supervised and finetune
+    stages take the first device, as the reference does with a device list (params/params_util.py:43) -- ranks of such a job would
+    each train their own model and write the same checkpoints."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("focal_train_entry", os.path.join(ROOT, "focal_amd", "src", "train.py"))
+    src = open(spec.origin).read()
+    ns = {}
+    start = src.index("def wants_data_parallel")
+    exec(src[start:src.index("def main_train")], ns)
+    w = ns["wants_data_parallel"]
+    assert w(argparse.Namespace(learn_framework="FOCAL", stage="pretrain"))
+    assert not w(argparse.Namespace(learn_framework="FOCAL", stage="finetune"))
+    assert not w(argparse.Namespace(learn_framework="no", stage="pretrain"))
