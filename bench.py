@@ -108,7 +108,8 @@ class Step:
             for mod in cfg["modality_names"]:
                 shape = (a.batch, cfg["loc_mod_in_time_channels"][loc][mod], cfg["num_segments"], cfg["loc_mod_spectrum_len"][loc][mod])
                 self.x[loc][mod] = torch.randn(shape, generator=g).to(device)
-        self.loss = torch.zeros((), device=device)
+        from focal_amd.graph_step import StepSegments
+        self.seg = StepSegments(self.model, self.loss_fn, self.opt, self.views, device)
         self.feed = None
 
     def enable_host_feed(self):
@@ -151,123 +152,17 @@ class Step:
               for l, mm in self.x.items()}  # negation + scaling, folded into the DFT
         return v1, v2
 
-    # The step in capturable segments with the data-parallel collectives between them:
-    #   A: zero_grad, views (DFT), both backbone passes, pack the embeddings     -> [all-gather embeddings]
-    #   B: loss head on the global batch, backward                                -> [all-reduce gradient arena]
-    #   C: AdamW, loss value
-    def seg_a(self):
-        self.opt.zero_grad()
-        v1, v2 = self.views()
-        self.feats = self.model(v1, v2, proj_head=True)
-        if self.dist.is_dist():
-            self.packed, self.keys = self.dist.pack_features(list(self.feats))
-
-    def exchange(self):
-        if self.dist.is_dist():
-            self.gathered = self.dist.exchange_packed(self.packed)  # the collective only: nothing else runs between segments
-
-    def seg_b(self):
-        if self.dist.is_dist():
-            self.feats = self.dist.unpack_gathered(self.gathered, self.keys, 2)
-        loss = self.loss_fn(*self.feats)
-        loss.backward()
-        self.loss.copy_(loss.detach())
-        self.feats = None
-
-    # With the loss head row-sharded over the ranks, segment B splits at the head's one small collective:
-    #   B1: similarity / distance rows, log-sum-exps, hinges of this rank's samples   -> [all-gather lse / diagonal means / partial terms]
-    #   B2: coefficient rows, dL/dz of this rank's samples, backward
-    def seg_b1(self):
-        self.feats = self.dist.unpack_gathered(self.gathered, self.keys, 2)
-        self.head = self.loss_fn.begin(*self.feats)
-
-    def exchange_head(self):
-        self.dist.exchange_loss_chunks(self.head)
-
-    def seg_b2(self):
-        loss = self.loss_fn.finish()
-        loss.backward()
-        self.loss.copy_(loss.detach())
-        self.feats = None
-
-    def reduce(self):
-        self.opt.reduce_gradients()
-
-    def seg_c(self):
-        self.opt.step(reduce=False)
-
+    # The step itself -- capturable segments with the data-parallel collectives between them -- is the product's
+    # (focal_amd/graph_step.py: StepSegments, also what train.py replays); here `views` is the DFT of the resident windows.
     def run(self):
-        self.seg_a()
-        self.exchange()
-        if self.dist.shard_loss_head():
-            self.seg_b1()
-            self.exchange_head()
-            self.seg_b2()
-        else:
-            self.seg_b()
-        self.reduce()
-        self.seg_c()
+        self.seg.run()
 
     def capture(self, stream):
-        """Returns the replay callable: one hipGraph of the whole step on one rank; with N > 1 ranks, hipGraphs of the three
-        segments (one shared memory pool) with the two collectives issued eagerly between their replays.
+        return self.seg.capture(stream)
 
-        Everything is captured TWICE into the same graph-private pool and the second set is the one replayed: the first capture
-        grows the pool segment by segment, the second sub-allocates the same tensors from the segments that now exist, and
-        that placement replays 2.5 % faster (8.29 -> 8.08 ms, reproducible; the first set is kept alive so its blocks stay put)."""
-        self.opt.sync_lr()
-        multi = self.dist.is_dist()
-        # with a process group alive its watchdog thread polls events (cudaEventQuery) at any time: under the default "global"
-        # capture mode that would invalidate a capture in progress, "thread_local" restricts the checks to the capturing thread
-        mode = {"capture_error_mode": "thread_local"} if multi else {}
-        pool, self._warm_graphs = None, []
-        for attempt in range(1 if os.environ.get("FOCAL_BENCH_SINGLE_CAPTURE") == "1" else 2):
-            if not multi:
-                # one rank: no collectives to interleave -> one graph for the whole step (each extra graph launch costs
-                # ~0.1 ms of idle GPU per step)
-                whole = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(whole, pool=pool, stream=stream):
-                    self.run()
-                graphs = (whole,)
-            else:
-                shard = self.dist.shard_loss_head()
-                ga, gb, gb2, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, pool=pool, stream=stream, **mode):
-                    self.seg_a()
-                self.exchange()  # eager, autograd-aware: links segment B's backward to segment A's forward
-                if shard:
-                    with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
-                        self.seg_b1()
-                    head = self.head
-                    self.exchange_head()
-                    with torch.cuda.graph(gb2, pool=ga.pool(), stream=stream, **mode):
-                        self.seg_b2()
-                else:
-                    head, gb2 = None, None
-                    with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
-                        self.seg_b()
-                self.reduce()
-                with torch.cuda.graph(gc, pool=ga.pool(), stream=stream, **mode):
-                    self.seg_c()
-                graphs = (ga, gb, gb2, gc)
-            pool = graphs[0].pool()
-            if attempt == 0:
-                self._warm_graphs = graphs
-        if not multi:
-            return graphs[0].replay
-        ga, gb, gb2, gc = graphs
-        packed = self.packed
-
-        def replay():
-            ga.replay()
-            self.dist.replay_exchange(packed)
-            gb.replay()
-            if gb2 is not None:
-                self.dist.exchange_loss_chunks(head)  # the persistent send / chunks buffers of the sharded head
-                gb2.replay()
-            self.opt.reduce_gradients()
-            gc.replay()
-        return replay
+    @property
+    def loss(self):
+        return self.seg.loss
 
 
 def time_kernel(fn, iters=20):

@@ -14,7 +14,7 @@ ACT_NONE, ACT_GELU, ACT_RELU_OUT = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class DropDesc(C.Structure):
@@ -44,6 +44,11 @@ class LinearDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("x_dtype", C.c_int),
                 ("y_dtype", C.c_int), ("act_in", C.c_int), ("epilogue", C.c_int), ("splits", C.c_int),
                 ("out_drop", DropDesc)]
+
+
+class DwProblem(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("M", C.c_int), ("N", C.c_int),
+                ("K", C.c_int), ("exclusive", C.c_int)]
 
 
 class MlpDesc(C.Structure):
@@ -102,10 +107,14 @@ PROTOTYPES = {
     "focal_mask_cast": (C.c_int, [C.c_int, C.c_int, C.c_int, P, C.POINTER(DropDesc), P, P]),
     "focal_linear_fwd": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P, P]),
     "focal_linear_resid_ln_fwd": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P, P, C.c_float, P, P, P]),
+    "focal_linear_resid_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_linear_bwd_data": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight_workgroups": (C.c_int, [C.POINTER(LinearDesc)]),
     "focal_linear_bwd_weight_kernel": (C.c_int, [C.POINTER(LinearDesc)]),
+    "focal_linear_bwd_weight_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(DwProblem), P]),
+    "focal_linear_bwd_weight_group_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "focal_linear_bwd_weight_group_workgroups": (C.c_int, [C.c_int, C.c_int, C.POINTER(DwProblem)]),
     "focal_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P]),
     "focal_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P]),

@@ -46,14 +46,29 @@ template <int OFF> __device__ __forceinline__ bf16x4 pipe_lds_read_tr(uint32_t a
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
   return v;
 }
+// The wait that orders the inline-asm fragment reads before the MFMAs: lgkmcnt(0) tied to the fragment registers (an MFMA is
+// register-only code, so nothing else stops the scheduler from moving it above a bare s_waitcnt).  Volatile asm statements keep their
+// program order, so fragments beyond the first statement's operand budget are tied by empty statements behind it.
+template <int N> __device__ __forceinline__ void pipe_tie(bf16x8 (&v)[N], int from) {
+#pragma unroll
+  for (int i = from; i + 3 < N; i += 4) asm volatile("" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]));
+}
 template <int NA, int NB> __device__ __forceinline__ void pipe_lds_wait(bf16x8 (&a)[NA], bf16x8 (&b)[NB]) {
-  static_assert((NA == 4 && (NB == 2 || NB == 4)) || (NA == 2 && NB == 2), "fragment counts of the wave tiles in use");
+  static_assert((NA == 4 && (NB == 2 || NB == 4)) || (NA == 2 && NB == 2) || ((NA == 1 || NA == 2) && (NB == 4 || NB == 8 || NB == 16)),
+                "fragment counts of the wave tiles in use");
   if constexpr (NA == 4 && NB == 4)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
   else if constexpr (NA == 4)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
-  else
+  else if constexpr (NA == 2 && NB == 2)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+  else {  // row-complete wave tiles (1 or 2 row fragments x 4 / 8 / 16 column fragments): every MFMA reads an `a` fragment
+    if constexpr (NA == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    pipe_tie(b, 4);
+  }
 }
 template <int I, int N, typename F> __device__ __forceinline__ void pipe_static_for(F&& f) {
   if constexpr (I < N) {
@@ -141,7 +156,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment addresses inside a stage: row (lane & 15) of a 16-row tile, chunk (kk * 4 + lane / 16) ^ swizzle
-  static_assert(TM == 4, "pipe_lds_wait is written for 64-row wave tiles");
   const int swz = (lane >> 1) & 7, g = lane >> 4;
   const uint32_t lds0 = pipe_lds_addr(pipe_lds);
   const uint32_t fo0 = lds0 + (lane & 15) * 128 + ((g ^ swz) << 4), fo1 = lds0 + (lane & 15) * 128 + (((4 + g) ^ swz) << 4);
@@ -198,7 +212,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
   // ---- epilogue: transpose 16 rows at a time through a wave-private LDS region, then walk it row-major (16 B per lane)
   float* est = reinterpret_cast<float*>(pipe_lds) + wave * 16 * WPITCH;
   MaskEval meE;
-  if (EPI == EPI_RESID || EPI == EPI_GELU_FWD) meE.init(p.epi);
+  if (EPI == EPI_RESID || EPI == EPI_GELU_FWD || EPI == EPI_RESID_LN) meE.init(p.epi);
+  static_assert(EPI != EPI_RESID_LN || (WGN == 1 && sizeof(TC) == 4), "the LayerNorm epilogue needs row-complete wave tiles and an fp32 residual stream");
   constexpr int CPL = (sizeof(TC) == 2) ? 8 : 4;
   constexpr int LPR = WC / CPL, RPI = 64 / LPR;
   const int c = (lane % LPR) * CPL, n = n0 + wn * WC + c;
@@ -232,6 +247,37 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
 #pragma unroll
         for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
         storeN<CPL>(dst, v);
+      } else if (EPI == EPI_RESID_LN) {
+        // y = resid + drop(v); then the LayerNorm that follows in the block, finished while the row is in registers: the LPR lanes of a
+        // row (16 / 32 / 64: a DPP row, two, or the whole wave) fold their sums -- statistics, normalised row and residual row leave
+        // together, no second pass over the residual stream
+        float r[CPL];
+        loadN<CPL>(p.resid + (long)m * p.ldr + n, r);
+        const float rowm = meE.row_mult(m);
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
+        storeN<CPL>(dst, v);
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) s1 += v[e];
+        s1 = row16_sum(s1);
+        if (LPR >= 32) s1 += __shfl_xor(s1, 16, 64);
+        if (LPR >= 64) s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 * (1.0f / WC);
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) s2 += (v[e] - mean) * (v[e] - mean);
+        s2 = row16_sum(s2);
+        if (LPR >= 32) s2 += __shfl_xor(s2, 16, 64);
+        if (LPR >= 64) s2 += __shfl_xor(s2, 32, 64);
+        const float rstd = rsqrtf(s2 * (1.0f / WC) + p.ln_eps);
+        float gq[CPL], bt[CPL], yq[CPL];
+        loadN<CPL>(p.ln_gamma + n, gq);
+        loadN<CPL>(p.ln_beta + n, bt);
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) yq[e] = (v[e] - mean) * rstd * gq[e] + bt[e];
+        storeN<CPL>(reinterpret_cast<bf16_t*>(p.aux_out) + (long)m * p.ldc + n, yq);
+        if ((lane % LPR) == 0) *reinterpret_cast<float2*>(p.ln_stats + 2 * (long)m) = make_float2(mean, rstd);
       } else if (EPI == EPI_MUL_AUX) {
         float a[CPL];
         loadN<CPL>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n, a);

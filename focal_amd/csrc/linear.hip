@@ -2,6 +2,7 @@
 // onto the MFMA GEMM templates of gemm.hpp.
 #include <stdlib.h>
 #include "gemm.hpp"
+#include "gemm_dw_group.hpp"
 
 static MaskParams to_mask(const focal_drop_desc& d, int ncols) {
   MaskParams m;
@@ -67,6 +68,12 @@ extern "C" int focal_linear_fwd(const focal_linear_desc* d, const void* x, const
   return focal_launch_gemm(s, p, (hipStream_t)stream);
 }
 
+extern "C" int focal_linear_resid_ln_supported(int dtype, int N, int K) {
+  if (N == 64) return 1;
+  static const bool off = getenv("FOCAL_NO_LN_FUSE_WIDE") != nullptr;
+  return !off && dtype == FOCAL_BF16 && (N == 128 || N == 256) && K % 64 == 0;
+}
+
 extern "C" int focal_linear_resid_ln_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias,
                                          const float* resid, float* y, const float* gamma, const float* beta, float eps,
                                          void* y_ln, float* stats, void* stream) {
@@ -74,7 +81,7 @@ extern "C" int focal_linear_resid_ln_fwd(const focal_linear_desc* d, const void*
   FOCAL_CHECK_ARG(x && w && y && resid && gamma && beta && y_ln && stats, "linear_resid_ln_fwd: null tensor");
   FOCAL_CHECK_ARG(d->epilogue == FOCAL_EPI_RESIDUAL && d->y_dtype == FOCAL_F32 && d->x_dtype == d->dtype && d->splits <= 1,
                   "linear_resid_ln_fwd: needs the residual epilogue, fp32 y and dtype-typed x");
-  FOCAL_CHECK_ARG(d->N == 64, "linear_resid_ln_fwd: N = %d (the fused LayerNorm needs 64-column rows)", d->N);
+  FOCAL_CHECK_ARG(focal_linear_resid_ln_supported(d->dtype, d->N, d->K), "linear_resid_ln_fwd: N = %d, K = %d (the fused LayerNorm needs 64-column rows, or bf16 with 128 / 256 columns and K %% 64 == 0)", d->N, d->K);
   GemmSpec s;
   s.compute = d->dtype;
   s.a_dtype = d->x_dtype; s.b_dtype = d->dtype; s.c_dtype = FOCAL_F32;
@@ -177,4 +184,55 @@ extern "C" int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d) {
 extern "C" int focal_linear_bwd_weight_kernel(const focal_linear_desc* d) {
   int kernel, wgs;
   return dw_launch_plan(d, &kernel, &wgs) ? kernel : 0;
+}
+
+// ---------------------------------------------------------------------------------------------- grouped weight gradients
+static bool dw_group_fits(const focal_dw_problem& q) {
+  return q.M > 0 && q.N > 0 && q.K > 0 && q.M % 64 == 0 && q.N % 128 == 0 && q.K % 128 == 0 && q.dy && q.x && q.dw &&
+         ((uintptr_t)q.dy % 16 == 0) && ((uintptr_t)q.x % 16 == 0) && ((uintptr_t)q.dw % 16 == 0);
+}
+
+extern "C" int focal_linear_bwd_weight_group_supported(int dtype, int M, int N, int K) {
+  static const bool off = getenv("FOCAL_DW_NOGROUP") != nullptr;
+  return !off && dtype == FOCAL_BF16 && M > 0 && M % 64 == 0 && N % 128 == 0 && K % 128 == 0;
+}
+
+static int dw_group_build(int dtype, int n, const focal_dw_problem* probs, DwGroupParams* gp, int* wgs) {
+  FOCAL_CHECK_ARG(dtype == FOCAL_BF16, "linear_bwd_weight_group: bf16 operands only (dtype %d)", dtype);
+  FOCAL_CHECK_ARG(n >= 1 && n <= DWG_MAX_PROBLEMS && probs, "linear_bwd_weight_group: 1 .. %d problems (got %d)", DWG_MAX_PROBLEMS, n);
+  memset(gp, 0, sizeof(*gp));
+  gp->nprob = n;
+  for (int i = 0; i < n; ++i) {
+    const focal_dw_problem& q = probs[i];
+    FOCAL_CHECK_ARG(dw_group_fits(q), "linear_bwd_weight_group: problem %d (M=%d N=%d K=%d) needs M %% 64 == 0, N, K %% 128 == 0 and 16-byte aligned tensors", i, q.M, q.N, q.K);
+    DwGroupProblem& p = gp->prob[i];
+    p.A = reinterpret_cast<const bf16_t*>(q.dy); p.lda = q.N;
+    p.B = reinterpret_cast<const bf16_t*>(q.x); p.ldb = q.K;
+    p.C = q.dw; p.ldc = q.K;
+    p.colsum = q.dbias;
+    p.M = q.N; p.N = q.K; p.rows = q.M;
+    p.exclusive = q.exclusive ? 1 : 0;
+  }
+  static const int target = getenv("FOCAL_DWG_WGS") ? atoi(getenv("FOCAL_DWG_WGS")) : 256;
+  static const int min_steps = getenv("FOCAL_DWG_MIN_STEPS") ? atoi(getenv("FOCAL_DWG_MIN_STEPS")) : 8;
+  *wgs = focal_dw_group_plan<64>(*gp, target, min_steps);
+  return FOCAL_OK;
+}
+
+extern "C" int focal_linear_bwd_weight_group(int dtype, int n, const focal_dw_problem* probs, void* stream) {
+  DwGroupParams gp;
+  int wgs = 0;
+  if (int rc = dw_group_build(dtype, n, probs, &gp, &wgs)) return rc;
+  hipError_t e = focal_launch_dw_group<64, 4>(gp, wgs, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    focal_set_error("linear_bwd_weight_group: launch failed: %s", hipGetErrorString(e));
+    return FOCAL_EHIP;
+  }
+  return FOCAL_OK;
+}
+
+extern "C" int focal_linear_bwd_weight_group_workgroups(int dtype, int n, const focal_dw_problem* probs) {
+  DwGroupParams gp;
+  int wgs = 0;
+  return dw_group_build(dtype, n, probs, &gp, &wgs) == FOCAL_OK ? wgs : 0;
 }

@@ -1,75 +1,218 @@
-"""The pretraining step as a replayed hipGraph (what bench.py measures, for `train.py`).
+"""The pretraining step as replayed hipGraphs -- one implementation for `bench.py` and for `train.py`.
 
-`train_utils/pretrain.py` launches ~700 kernels per SW_Transformer step through ctypes; eagerly that is host-bound (~10 ms per step
-against 6.5 ms of GPU work).  `CapturedTrainStep` captures [zero_grad -> FOCAL(view 1, view 2) -> loss head -> backward -> AdamW]
-once the shapes have repeated, and replays it; what stays eager per step is the part whose kernel sequence depends on host draws --
-the two augmented views (Augmenter.forward("random"): one DFT launch per modality and view, plus a warp pass when drawn), written
-into address-stable two-view buffers (`Augmenter.static_views`) that the captured step reads.  Dropout seeds and the AdamW step
-counter advance on the device, the learning rate is a device word: replays differ as steps should.
-A batch of another shape (the last batch of an epoch) or a data-parallel job (collectives between the segments) runs eagerly."""
+`train_utils/pretrain.py` launches ~350 kernels per SW_Transformer step through ctypes; eagerly that is host-bound (~10 ms per step
+against 6 ms of GPU work).  `StepSegments` is the step body [zero_grad -> views -> FOCAL(view 1, view 2) -> loss head -> backward ->
+AdamW] cut where the data-parallel collectives sit:
+
+    A : zero_grad, views, both backbone passes, pack the embeddings       -> [all-gather of the embeddings]
+    B : loss head on the global batch, backward                            -> [all-reduce of the gradient arena]
+    C : AdamW, loss value
+    (with the loss head row-sharded over the ranks B splits once more at the head's one small collective:
+     B1 similarity / distance rows, log-sum-exps, hinges  -> [all-gather of ~70 KB chunks] ->  B2 coefficients, dL/dz, backward)
+
+On one rank the whole step is ONE hipGraph; on N ranks every segment is a hipGraph (one shared memory pool) and the collectives are
+issued eagerly between their replays (RCCL calls stay outside capture), so 1 ... 8 ranks all replay graphs.  Dropout seeds and the
+AdamW step counter advance on the device, the learning rate is a device word: replays differ as steps should.
+
+`CapturedTrainStep` is the training loop's wrapper: what stays eager per step is the part whose kernel sequence depends on host draws
+-- the two augmented views (Augmenter.forward("random"): one DFT launch per modality and view, plus a warp pass when drawn), written
+into address-stable two-view buffers (`Augmenter.static_views`) that the captured step reads.  A batch of another shape (the last
+batch of an epoch) runs eagerly."""
+import logging
+import os
+
 import torch
 
 from . import distributed
 
 
+class StepSegments:
+    def __init__(self, model, loss_fn, opt, views, device):
+        """views(): -> (view1, view2) frequency-domain inputs; called inside segment A (bench.py: the DFT of the resident windows is
+        part of the step; train.py: the augmenter has already written the static view buffers, views() just returns them)."""
+        self.model, self.loss_fn, self.opt, self.views = model, loss_fn, opt, views
+        self.dist = distributed
+        self.loss = torch.zeros((), device=device)
+        self.feats = None
+
+    def seg_a(self):
+        self.opt.zero_grad()
+        v1, v2 = self.views()
+        self.feats = self.model(v1, v2, proj_head=True)
+        if self.dist.is_dist():
+            self.packed, self.keys = self.dist.pack_features(list(self.feats))
+
+    def exchange(self):
+        if self.dist.is_dist():
+            self.gathered = self.dist.exchange_packed(self.packed)  # the collective only: nothing else runs between segments
+
+    def seg_b(self):
+        if self.dist.is_dist():
+            self.feats = self.dist.unpack_gathered(self.gathered, self.keys, 2)
+        loss = self.loss_fn(*self.feats)
+        loss.backward()
+        self.loss.copy_(loss.detach())
+        self.feats = None
+
+    def seg_b1(self):
+        self.feats = self.dist.unpack_gathered(self.gathered, self.keys, 2)
+        self.head = self.loss_fn.begin(*self.feats)
+
+    def exchange_head(self):
+        self.dist.exchange_loss_chunks(self.head)
+
+    def seg_b2(self):
+        loss = self.loss_fn.finish()
+        loss.backward()
+        self.loss.copy_(loss.detach())
+        self.feats = None
+
+    def reduce(self):
+        self.opt.reduce_gradients()
+
+    def seg_c(self):
+        self.opt.step(reduce=False)
+
+    def run(self):
+        """One eager step (also what the captures record)."""
+        self.seg_a()
+        self.exchange()
+        if self.dist.shard_loss_head():
+            self.seg_b1()
+            self.exchange_head()
+            self.seg_b2()
+        else:
+            self.seg_b()
+        self.reduce()
+        self.seg_c()
+
+    def capture(self, stream):
+        """Returns the replay callable: one hipGraph of the whole step on one rank; with N > 1 ranks, hipGraphs of the segments (one
+        shared memory pool) with the collectives issued eagerly between their replays.
+
+        Everything is captured TWICE into the same graph-private pool and the second set is the one replayed: the first capture
+        grows the pool segment by segment, the second sub-allocates the same tensors from the segments that now exist, and
+        that placement replays 2.5 % faster (8.29 -> 8.08 ms, reproducible; the first set is kept alive so its blocks stay put)."""
+        self.opt.sync_lr()
+        multi = self.dist.is_dist()
+        # with a process group alive its watchdog thread polls events (cudaEventQuery) at any time: under the default "global"
+        # capture mode that would invalidate a capture in progress, "thread_local" restricts the checks to the capturing thread
+        mode = {"capture_error_mode": "thread_local"} if multi else {}
+        pool, self._warm_graphs = None, []
+        for attempt in range(1 if os.environ.get("FOCAL_BENCH_SINGLE_CAPTURE") == "1" else 2):
+            if not multi:
+                # one rank: no collectives to interleave -> one graph for the whole step (each extra graph launch costs
+                # ~0.1 ms of idle GPU per step)
+                whole = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(whole, pool=pool, stream=stream):
+                    self.run()
+                graphs = (whole,)
+            else:
+                shard = self.dist.shard_loss_head()
+                ga, gb, gb2, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, pool=pool, stream=stream, **mode):
+                    self.seg_a()
+                self.exchange()  # eager, autograd-aware: links segment B's backward to segment A's forward
+                if shard:
+                    with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
+                        self.seg_b1()
+                    head = self.head
+                    self.exchange_head()
+                    with torch.cuda.graph(gb2, pool=ga.pool(), stream=stream, **mode):
+                        self.seg_b2()
+                else:
+                    head, gb2 = None, None
+                    with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
+                        self.seg_b()
+                self.reduce()
+                with torch.cuda.graph(gc, pool=ga.pool(), stream=stream, **mode):
+                    self.seg_c()
+                graphs = (ga, gb, gb2, gc)
+            pool = graphs[0].pool()
+            if attempt == 0:
+                self._warm_graphs = graphs
+        self._graphs = graphs
+        if not multi:
+            return graphs[0].replay
+        ga, gb, gb2, gc = graphs
+        packed = self.packed
+
+        def replay():
+            ga.replay()
+            self.dist.replay_exchange(packed)
+            gb.replay()
+            if gb2 is not None:
+                self.dist.exchange_loss_chunks(head)  # the persistent send / chunks buffers of the sharded head
+                gb2.replay()
+            self.opt.reduce_gradients()
+            gc.replay()
+        return replay
+
+
+def agree(ok, device):
+    """Capture failures must not be rank-dependent (a rank falling back to eager while another replays would desynchronise the
+    collectives): the ranks agree on the outcome before using the graphs."""
+    if not distributed.is_dist():
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
 class CapturedTrainStep:
     def __init__(self, model, loss_func, optimizer, warm_steps=2, enabled=True):
         self.model, self.loss_func, self.opt = model, loss_func, optimizer
-        self.warm_steps, self.enabled = warm_steps, enabled and not distributed.is_dist()
-        self.key, self.graph, self.seen = None, None, 0
+        # cross-rank BatchNorm statistics (DeepSense, -sync_bn) put collectives INSIDE the backbone passes: nothing there to cut a
+        # segment at, so such a job stays eager
+        inner_collectives = distributed.is_dist() and bool(getattr(getattr(model, "backbone", None), "sync_bn", False))
+        self.warm_steps, self.enabled = warm_steps, enabled and not inner_collectives
+        self.key, self.replay, self.seen = None, None, 0
+        self.segments = None
         self.loss = None
         self.replays = self.eager_steps = 0
-
-    def _body(self, v1, v2):
-        self.opt.zero_grad()
-        f1, f2 = self.model(v1, v2, proj_head=True)
-        f1, f2 = distributed.gather_features([f1, f2])
-        loss = self.loss_func(f1, f2)
-        loss.backward()
-        self.opt.step()
-        return loss.detach()
 
     @staticmethod
     def _key(v1, v2):
         return tuple((t.data_ptr(), tuple(t.shape)) for v in (v1, v2) for mods in v.values() for t in mods.values())
 
+    def _segments(self, v1, v2):
+        dev = next(iter(next(iter(v1.values())).values())).device
+        return StepSegments(self.model, self.loss_func, self.opt, lambda: (v1, v2), dev)
+
     def __call__(self, v1, v2):
         """One optimiser step on the two views; returns the (device) loss of the step."""
         key = self._key(v1, v2)
-        if self.graph is not None and key == self.key:
+        if self.replay is not None and key == self.key:
             self.opt.sync_lr()
-            self.graph.replay()
+            self.replay()
             self.replays += 1
             return self.loss
         self.eager_steps += 1
-        out = self._body(v1, v2)
-        if not self.enabled or self.graph is not None:
+        seg = self._segments(v1, v2)
+        seg.run()
+        out = seg.loss
+        if not self.enabled or self.replay is not None:
             return out
         # capture once the same buffers have come round `warm_steps` times (arena, moments and workspaces exist by then)
         self.seen = self.seen + 1 if key == self.key else 1
         self.key = key
         if self.seen >= self.warm_steps:
+            ok = True
             try:
                 self._capture(v1, v2)
             except Exception as e:  # noqa: BLE001 -- capture is an optimisation: stay eager, say so once
-                import logging
+                ok = False
                 logging.warning(f"hipGraph capture of the training step unavailable ({type(e).__name__}: {e}); running eagerly")
-                self.enabled, self.graph = False, None
                 torch.cuda.synchronize()
+            if not agree(ok, out.device):  # every rank replays, or none does
+                self.enabled, self.replay = False, None
         return out
 
     def _capture(self, v1, v2):
         torch.cuda.synchronize()
-        self.opt.sync_lr()
-        self.loss = torch.zeros((), device=next(iter(next(iter(v1.values())).values())).device)
+        seg = self._segments(v1, v2)
         side = torch.cuda.Stream()
-        pool, keep = None, []
         with torch.cuda.stream(side):
-            for _ in range(2):  # captured twice into one pool, the second set is replayed (bench.py: Step.capture)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=side):
-                    self.loss.copy_(self._body(v1, v2))
-                pool = g.pool()
-                keep.append(g)
+            replay = seg.capture(side)
         torch.cuda.synchronize()
-        self._keep, self.graph = keep, keep[-1]
+        self.segments, self.loss, self.replay = seg, seg.loss, replay

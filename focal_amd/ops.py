@@ -279,12 +279,16 @@ def linear_fwd(d, x, w, bias, resid, y, act_grad=None):
 
 def linear_resid_ln_fwd(d, x, w, bias, resid, y, gamma, beta, out_dtype, eps=1e-5):
     """y = resid + drop(x w^T + bias) and, from the same kernel, (LayerNorm(y), stats) of the Swin LayerNorm that follows
-    (N == 64 only).  Returns (y_ln [M, N] out_dtype, stats [M, 2])."""
+    (N == 64; N == 128 / 256 in bf16: ops.resid_ln_supported).  Returns (y_ln [M, N] out_dtype, stats [M, 2])."""
     y_ln = torch.empty(d.M, d.N, dtype=out_dtype, device=y.device)
     stats = torch.empty(d.M, 2, dtype=torch.float32, device=y.device)
     check(_lib.load().focal_linear_resid_ln_fwd(C.byref(d), _p(x), _p(w), _p(bias), _p(resid), _p(y), _p(gamma), _p(beta), eps,
                                                 _p(y_ln), _p(stats), _stream()))
     return y_ln, stats
+
+
+def resid_ln_supported(dtype_code, N, K):
+    return bool(_lib.load().focal_linear_resid_ln_supported(dtype_code, N, K))
 
 
 def linear_bwd_data(d, dy, w, x, dx):
@@ -293,6 +297,29 @@ def linear_bwd_data(d, dy, w, x, dx):
 
 def linear_bwd_weight(d, dy, x, dw, dbias):
     check(_lib.load().focal_linear_bwd_weight(C.byref(d), _p(dy), _p(x), _p(dw), _p(dbias), _stream()))
+
+
+def dw_group_supported(dtype_code, M, N, K):
+    return bool(_lib.load().focal_linear_bwd_weight_group_supported(dtype_code, M, N, K))
+
+
+def _dw_problems(items, exclusive):
+    arr = (_lib.DwProblem * len(items))()
+    for i, (dy, x, dw, db) in enumerate(items):
+        _need_cuda(dy, x, dw, db)
+        arr[i] = _lib.DwProblem(_p(dy), _p(x), _p(dw), _p(db), dy.shape[0], dy.shape[1], x.shape[1], 1 if exclusive else 0)
+    return arr
+
+
+def linear_bwd_weight_group(dtype_code, items, exclusive=True):
+    """items: [(dy [M, N], x [M, K], dw [N, K] fp32, dbias [N] fp32 | None)] -- the weight gradients of several linear layers as ONE
+    launch (focal_linear_bwd_weight_group).  exclusive: nothing else adds to these dw while the launch runs."""
+    arr = _dw_problems(items, exclusive)
+    check(_lib.load().focal_linear_bwd_weight_group(dtype_code, len(items), arr, _stream()))
+
+
+def linear_bwd_weight_group_workgroups(dtype_code, items, exclusive=True):
+    return _lib.load().focal_linear_bwd_weight_group_workgroups(dtype_code, len(items), _dw_problems(items, exclusive))
 
 
 def linear(x, w, bias=None, *, compute, y_dtype=None, resid=None, act_in=ACT_NONE, epilogue=EPI_NONE, splits=1,

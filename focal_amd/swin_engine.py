@@ -73,8 +73,9 @@ class SwinModEncoder:
         p_attn = bb.attn_drop_rate if training else 0.0
         saved = {"B": B, "view": view, "training": training, "blocks": [], "merges": [], "embed": embed_saved}
         uid = 0
-        # At 64 channels a GEMM wave owns whole rows, so the residual GEMMs also emit the LayerNorm that follows them (norm2
-        # after proj, the next block's norm1 after fc2): no separate pass over the residual stream for those LayerNorms.
+        # Where a GEMM wave owns whole rows (64 channels: the 64 x 64 tile; 128 / 256 channels in bf16: the LDS-DMA kernel with
+        # row-complete wave tiles) the residual GEMMs also emit the LayerNorm that follows them (norm2 after proj, the next
+        # block's norm1 after fc2): no separate pass over the residual stream for those LayerNorms.
         for si, st in enumerate(geo["stages"]):
             H, W, Cc = st["H"], st["W"], st["C"]
             L = H * W
@@ -98,7 +99,7 @@ class SwinModEncoder:
                 d_proj = ops.linear_desc(cc, M, Cc, Cc, cc, f32, ACT_NONE, EPI_RESIDUAL,
                                          out_drop=self._drop(rng, view, uid, 0, p_drop, p_path, L))
                 x_mid = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
-                if fuse_ln and Cc == 64:
+                if fuse_ln and ops.resid_ln_supported(cc, Cc, Cc):
                     a2, st2 = ops.linear_resid_ln_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"),
                                                       x, x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
                 else:
@@ -127,7 +128,7 @@ class SwinModEncoder:
                 h = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)
                 hg = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)  # d h / d(pre-activation), dropout included
                 ops.linear_fwd(d_fc1, a2, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"), None, h, hg)
-                if fuse_ln and Cc == 64 and bi + 1 < st["depth"]:
+                if fuse_ln and ops.resid_ln_supported(cc, Cc, 4 * Cc) and bi + 1 < st["depth"]:
                     nb = f"{self.pre}.{si}.blocks.{bi + 1}"
                     pre_ln = ops.linear_resid_ln_fwd(d_fc2, h, ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"),
                                                      x_mid, x_out, ar.master(f"{nb}.norm1.weight"), ar.master(f"{nb}.norm1.bias"), ct)
@@ -177,6 +178,9 @@ class SwinModEncoder:
         # gm = ct(g * mask): the residual-stream gradient times the dropout x drop-path mask of the branch that consumes it
         # next, written once by whichever kernel completes g (LayerNorm backward, or mask_cast for the first one); the
         # branch's dX / dW GEMMs then run as plain `ct` kernels instead of regenerating the mask per column tile.
+        group_dw = os.environ.get("FOCAL_NO_DW_GROUP") != "1"
+        # one pass per step over this encoder's weights (both views in one batch): a gradient tile has a single writer per launch
+        exclusive_dw = bool(getattr(bb, "views_share_pass", False))
         last = blocks[-1]
         gm = ops.mask_cast(g.view(last["M"], last["C"]), last["d_fc2"].out_drop, ct)
         for k in range(len(blocks) - 1, -1, -1):
@@ -194,34 +198,58 @@ class SwinModEncoder:
             s = blocks[k]
             pb, M, Cc = s["pb"], s["M"], s["C"]
             gm = gm.view(M, Cc)
+            # The four weight gradients of a block (fc2, fc1, proj, qkv) as ONE launch on 128 x 128 tiles once all their operands
+            # exist (ops.linear_bwd_weight_group; stages 1-2: C >= 128): one ramp and one atomic epilogue instead of four, half the
+            # L2 -> LDS bytes per MAC.  Their operands stay alive until then, so the attention branch's masked gradient gets a buffer
+            # of its own instead of overwriting the MLP branch's.
+            grouped = group_dw and s.get("d_mlp") is None and ops.dw_group_supported(cc, M, Cc, 4 * Cc) and ops.dw_group_supported(cc, M, 3 * Cc, Cc)
+            dw_items = []
             # ---- MLP branch: x_out = x_mid + mask * (h W2^T + b2), h = drop(gelu(a2 W1^T + b1))
             dc = torch.empty_like(s["a2"])
+            du = None
             if s.get("d_mlp") is not None:  # fused branch: h and h' recomputed from a2, all four parameter gradients from one pass
                 ops.mlp_bwd(s["d_mlp"], gm, s["a2"], ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
                             ar.operand(f"{pb}.mlp.fc2.weight"), dc, ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"),
                             ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
             else:
                 d_fc2_b = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, cc, ACT_GELU)  # dy = gm: operand dtype, already masked
-                ops.linear_bwd_weight(d_fc2_b, gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
+                if grouped:
+                    dw_items.append((gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias")))
+                else:
+                    ops.linear_bwd_weight(d_fc2_b, gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
                 du = torch.empty_like(s["h"])
                 ops.linear_bwd_data(d_fc2_b, gm, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
-                ops.linear_bwd_weight(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
+                if grouped:
+                    dw_items.append((du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias")))
+                else:
+                    ops.linear_bwd_weight(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
                 ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
-                del du
+                if not grouped:
+                    du = None
+            gm_attn = torch.empty_like(gm) if grouped else gm
             ops.layernorm_bwd(dc, s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g, True,
-                              ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), dx_masked=gm, mask=s["d_proj"].out_drop)
+                              ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), dx_masked=gm_attn, mask=s["d_proj"].out_drop)
             # ---- attention branch: x_mid = x + mask * (o Wp^T + bp)
             d_proj_b = ops.linear_desc(cc, M, Cc, Cc, cc, cc)
-            ops.linear_bwd_weight(d_proj_b, gm, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
+            if grouped:
+                dw_items.append((gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias")))
+            else:
+                ops.linear_bwd_weight(d_proj_b, gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
             do = dc  # reuse the [M, C] CT buffer
-            ops.linear_bwd_data(d_proj_b, gm, ar.operand(f"{pb}.attn.proj.weight"), None, do)
+            ops.linear_bwd_data(d_proj_b, gm_attn, ar.operand(f"{pb}.attn.proj.weight"), None, do)
             dqkv = torch.empty_like(s["qkv"])
             ops.window_attn_bwd(s["d_att"], s["qkv"], ar.master(f"{pb}.attn.relative_position_bias_table"), do, dqkv,
                                 ar.g(f"{pb}.attn.relative_position_bias_table"))
-            ops.linear_bwd_weight(s["d_qkv"], dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias"))
+            if grouped:
+                dw_items.append((dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias")))
+            else:
+                ops.linear_bwd_weight(s["d_qkv"], dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias"))
             da = do
             ops.linear_bwd_data(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), None, da)
-            del dqkv
+            if grouped:
+                ops.linear_bwd_weight_group(cc, dw_items, exclusive=exclusive_dw)
+                dw_items = None
+            del dqkv, du
             # the next consumer of g: block k-1's MLP branch, unless a PatchMerging (handled above) or the embedding comes first
             nxt = blocks[k - 1]["d_fc2"].out_drop if (k > 0 and k not in merges) else None
             ops.layernorm_bwd(da, s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g, True,

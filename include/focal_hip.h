@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* 2: BatchNorm scratch of 2C + 1 floats; 3: fused MLP, warps, Mixup; 4: row-sharded loss head, weight-gradient launch queries */
-#define FOCAL_ABI_VERSION 4
+#define FOCAL_ABI_VERSION 5
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -145,11 +145,14 @@ int focal_linear_fwd(const focal_linear_desc* d, const void* x, const void* w, c
                      void* y, void* act_grad, void* stream);
 /* y = resid + out_drop(DropPath(x w^T + bias)) (epilogue FOCAL_EPI_RESIDUAL, fp32 y) AND, from the same kernel, the LayerNorm
  * that follows it in the Swin block (SwinModules.py:253,258: norm2 after the attention branch, the next block's norm1 after
- * the MLP branch): y_ln = LayerNorm(y; gamma, beta, eps) in `dtype`, stats fp32 [M][2] = {mean, rstd}.  N must be 64 (one
- * wave owns whole rows); other widths: focal_linear_fwd followed by focal_layernorm_fwd.  Saves one pass over the residual
+ * the MLP branch): y_ln = LayerNorm(y; gamma, beta, eps) in `dtype`, stats fp32 [M][2] = {mean, rstd}.  One wave must own whole
+ * rows: N = 64, or 128 / 256 in bf16 (focal_linear_resid_ln_supported); other widths: focal_linear_fwd followed by focal_layernorm_fwd.  Saves one pass over the residual
  * stream and one launch per LayerNorm. */
 int focal_linear_resid_ln_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias, const float* resid,
                               float* y, const float* gamma, const float* beta, float eps, void* y_ln, float* stats, void* stream);
+/* row widths the fused form takes: N == 64 (any dtype), N == 128 / 256 with bf16 operands and K % 64 == 0 (csrc/gemm_pipe.hpp with
+ * row-complete wave tiles) */
+int focal_linear_resid_ln_supported(int dtype, int N, int K);
 int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy, const void* w, const void* x, void* dx,
                           void* stream);
 int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const void* x, float* dw, float* dbias,
@@ -160,6 +163,22 @@ int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d);
 /* Which kernel that launch runs: 1 = focal_gemm_kernel (register-staged, any dtype / loader), 2 = focal_dw_ring_kernel (the LDS-DMA
  * ring for bf16 shapes made of whole 64-tiles, given 16-byte aligned operands; 512-thread workgroups of two token slices each).  0 = invalid descriptor. */
 int focal_linear_bwd_weight_kernel(const focal_linear_desc* d);
+
+/* The weight gradients of up to 8 linear layers in ONE launch (the four linears of a Swin block: qkv, proj, fc1, fc2): per problem
+ * dw[N, K] += dy[M, N]^T . x[M, K], dbias[N] += column sums of dy (dbias may be NULL) -- n calls of focal_linear_bwd_weight with
+ * plain `dtype` operands (bf16; dy already carries its dropout mask), as one kernel on 128 x 128 output tiles
+ * (csrc/gemm_dw_group.hpp).  Needs M % 64 == 0 and N, K % 128 == 0 per problem (focal_linear_bwd_weight_group_supported), 16-byte
+ * aligned tensors.  `exclusive` != 0 promises that nothing else adds to this dw while the launch runs (another stream, another
+ * problem of the same call): tiles that one workgroup owns then leave with plain read-add-write instead of atomics. */
+typedef struct {
+  const void* dy; const void* x; float* dw; float* dbias;
+  int M, N, K;
+  int exclusive;
+} focal_dw_problem;
+int focal_linear_bwd_weight_group(int dtype, int n, const focal_dw_problem* problems, void* stream);
+int focal_linear_bwd_weight_group_supported(int dtype, int M, int N, int K);
+/* workgroups that launch consists of (profiler-trace matching, as focal_linear_bwd_weight_workgroups); 0 = invalid */
+int focal_linear_bwd_weight_group_workgroups(int dtype, int n, const focal_dw_problem* problems);
 
 /* Fused MLP branch of a Swin block (models/SwinModules.py:18-34 Mlp.forward + the residual / DropPath of :339-341), bf16,
  * C = 64 -> hidden = 256 -> C (Swin stage 0, where 2/3 of the model's hidden-activation bytes are; focal_mlp_supported says

@@ -123,6 +123,63 @@ def test_weight_gradient_ring_kernel_shapes(ops, M, N, K):
     assert rel_err(dw2, ref) < 2e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(2304, 128, 128), (2304, 128, 512), (1000, 128, 128), (576, 256, 256), (592, 256, 1024), (64, 256, 256), (9216, 256, 1024)])
+def test_linear_resid_ln_wide(ops, M, N, K):
+    """focal_linear_resid_ln_fwd at 128 / 256 columns (bf16): y = resid + x w^T + b from the LDS-DMA GEMM with row-complete wave tiles,
+    LayerNorm(y) and its statistics from the same epilogue = focal_linear_fwd followed by focal_layernorm_fwd (ragged M included)."""
+    from focal_amd._lib import ACT_NONE, EPI_RESIDUAL
+    ct = torch.bfloat16
+    c, f32 = ops.code(ct), ops.code(torch.float32)
+    assert ops.resid_ln_supported(c, N, K)
+    x, w, b = rnd(M, K, seed=41, dtype=ct), rnd(N, K, scale=K ** -0.5, seed=42, dtype=ct), rnd(N, seed=43)
+    resid = rnd(M, N, seed=44)
+    gamma, beta = rnd(N, seed=45) * 0.1 + 1.0, rnd(N, seed=46) * 0.1
+    d = ops.linear_desc(c, M, N, K, c, f32, ACT_NONE, EPI_RESIDUAL)
+    y = torch.empty(M, N, device=DEV)
+    y_ln, stats = ops.linear_resid_ln_fwd(d, x, w, b, resid, y, gamma, beta, ct)
+    y_ref = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(d, x, w, b, resid, y_ref)
+    ln_ref, st_ref = ops.layernorm_fwd(y_ref, gamma, beta, ct)
+    assert rel_err(y, y_ref) < 1e-6
+    assert rel_err(stats, st_ref) < 1e-5
+    assert rel_err(y_ln.float(), ln_ref.float()) < 3e-3  # bf16 outputs of values that differ in the last fp32 bits
+    t = resid + x.float() @ w.float().t() + b
+    assert rel_err(y, t) < 1e-5
+    assert rel_err(y_ln.float(), F.layer_norm(t, (N,), gamma, beta, 1e-5)) < 4e-3
+
+
+@pytest.mark.parametrize("rows,C,exclusive", [(2304, 128, True), (2304, 128, False), (64, 128, True), (1152, 256, True), (4672, 256, False),
+                                              (36864, 128, True), (576, 256, True)])
+def test_weight_gradient_group_kernel(ops, rows, C, exclusive):
+    """focal_linear_bwd_weight_group: the four weight gradients of a Swin block (fc2 [C, 4C], fc1 [4C, C], proj [C, C], qkv [3C, C]) as
+    one launch on 128 x 128 tiles = four focal_linear_bwd_weight calls: several token slices per tile (atomics) and one (plain
+    read-add-write when `exclusive`), slices of unequal / zero length, accumulation into non-zero buffers, with and without bias."""
+    ct = torch.bfloat16
+    c = ops.code(ct)
+    shapes = [(C, 4 * C), (4 * C, C), (C, C), (3 * C, C)]
+    items, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        assert ops.dw_group_supported(c, rows, N, K)
+        dy, x = rnd(rows, N, seed=300 + i, dtype=ct), rnd(rows, K, seed=310 + i, dtype=ct)
+        dw = torch.full((N, K), 0.25 * (i + 1), device=DEV)
+        db = torch.full((N,), -1.0, device=DEV) if i != 2 else None
+        items.append((dy, x, dw, db))
+        refs.append((dy.float().t() @ x.float(), dy.float().sum(0)))
+    wgs = ops.linear_bwd_weight_group_workgroups(c, items, exclusive)
+    assert 0 < wgs <= max(256, sum((N // 128) * (K // 128) for N, K in shapes))
+    ops.linear_bwd_weight_group(c, items, exclusive=exclusive)
+    for i, ((dy, x, dw, db), (rw, rb)) in enumerate(zip(items, refs)):
+        assert rel_err(dw - 0.25 * (i + 1), rw) < 2e-4, i
+        if db is not None:
+            assert rel_err(db + 1.0, rb) < 1e-4, i
+    ops.linear_bwd_weight_group(c, items, exclusive=exclusive)  # accumulates
+    for i, ((dy, x, dw, db), (rw, rb)) in enumerate(zip(items, refs)):
+        assert rel_err(dw - 0.25 * (i + 1), 2 * rw) < 2e-4, i
+    assert not ops.dw_group_supported(c, rows, 64, 128) and not ops.dw_group_supported(c, rows + 8, 128, 128)
+    with pytest.raises(Exception):
+        ops.linear_bwd_weight_group(c, [(rnd(rows, 64, dtype=ct), rnd(rows, 128, dtype=ct), torch.zeros(64, 128, device=DEV), None)])
+
+
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
 def test_linear_bwd_fc2_chain(ops, ct):
     """fc2 of the Swin MLP: y = r + h W^T + b with fp32 dy -> du = (dy W) * h' and dW = dy^T h."""

@@ -34,8 +34,11 @@ def _launch(nproc, extra, env_extra, port):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=SRC)
 
 
-@pytest.mark.parametrize("model", ["SW_Transformer", "DeepSense"])
-def test_two_rank_train_py_matches_whole_batch_oracle(cfg, tmp_path, model):
+@pytest.mark.parametrize("model,nb", [("SW_Transformer", 2), ("DeepSense", 2), ("SW_Transformer", 6)])
+def test_two_rank_train_py_matches_whole_batch_oracle(cfg, tmp_path, model, nb):
+    """nb = 6: long enough for the ranks to capture the step (after two eager steps) and REPLAY it -- hipGraph segments with the
+    collectives issued eagerly between them (focal_amd/graph_step.py) -- for the rest of the epoch; the weights must still be the
+    whole-batch oracle's."""
     from oracle.step import OracleTrainer
     from oracle.weights import fill_state_dict_, synthetic_time_input  # noqa: F401
     from conftest import make_args
@@ -49,12 +52,16 @@ def test_two_rank_train_py_matches_whole_batch_oracle(cfg, tmp_path, model):
     fill_state_dict_(state)
     init = tmp_path / "init.pt"
     torch.save(state, str(init))
-    B, nb = 16, 2  # global batch 16 = 2 ranks x 8 windows, two steps in the epoch
+    B = 16  # global batch 16 = 2 ranks x 8 windows, nb steps in the epoch
     extra = [f"-model={model}", "-dataset=MOD", "-learn_framework=FOCAL", f"-batch_size={B}", f"-synthetic_batches={nb}", "-epochs=1",
              "-compute_dtype=fp32", f"-config={ypath}", f"-init_weight={init}"] + (["-sync_bn"] if model == "DeepSense" else [])
-    r = _launch(2, extra, {"FOCAL_DIST_BACKEND": "gloo", "FOCAL_DIST_ONE_DEVICE": "1"}, 29561 if model == "DeepSense" else 29562)
+    r = _launch(2, extra, {"FOCAL_DIST_BACKEND": "gloo", "FOCAL_DIST_ONE_DEVICE": "1"}, 29561 if model == "DeepSense" else 29562 + nb)
     log = r.stdout + r.stderr
     assert r.returncode == 0, log[-4000:]
+    import re
+    m = re.search(r"(\d+) graph replays, (\d+) eager steps", log)
+    assert m, log[-2000:]
+    assert int(m.group(1)) == max(0, nb - 2) and int(m.group(2)) == min(nb, 2), m.group(0)  # two eager steps (the second one ends with the capture), then replays
     assert log.count("Val loss:") == 1, "validation must run on rank 0 only"   # rank 1 logs at WARNING level and skips the branch
     got = torch.load(os.path.join(ROOT, "weights", f"MOD_{model}", f"MOD_{model}_pretrain_latest.pt"), map_location="cpu")
     # the oracle on the whole global batches: rank r's windows of batch k are seeded 1234 + k + 100003 r (SyntheticSequenceLoader)
