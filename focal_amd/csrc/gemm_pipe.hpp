@@ -223,12 +223,24 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
   if (p.bias) loadN<CPL>(p.bias + n, bias);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    const int mbase = m0 + wm * WR + i * 16;
+    // LayerNorm epilogue: the pass's residual rows are requested together, before the accumulators are staged (the row loop below has
+    // LDS traffic between its iterations -- staging reads, cross-lane sums -- and hipcc will not move a global load above those: left
+    // inside the loop each row exposed a full memory latency, 16 in a row at 256 channels).  Rows past M re-read the last row.
+    constexpr int NIT = 16 / RPI;
+    float rpre[EPI == EPI_RESID_LN ? NIT : 1][CPL];
+    if (EPI == EPI_RESID_LN) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int mm = min(mbase + it * RPI + lane / LPR, p.M - 1);
+        loadN<CPL>(p.resid + (long)mm * p.ldr + n, rpre[it]);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const f32x4 v = acc[i][j] * p.alpha;
       *reinterpret_cast<float4*>(est + (lane & 15) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    const int mbase = m0 + wm * WR + i * 16;
 #pragma unroll
     for (int rr = 0; rr < 16; rr += RPI) {
       const int row = rr + lane / LPR, m = mbase + row;
@@ -251,11 +263,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
         // y = resid + drop(v); then the LayerNorm that follows in the block, finished while the row is in registers: the LPR lanes of a
         // row (16 / 32 / 64: a DPP row, two, or the whole wave) fold their sums -- statistics, normalised row and residual row leave
         // together, no second pass over the residual stream
-        float r[CPL];
-        loadN<CPL>(p.resid + (long)m * p.ldr + n, r);
         const float rowm = meE.row_mult(m);
 #pragma unroll
-        for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
+        for (int e = 0; e < CPL; ++e) v[e] = rpre[EPI == EPI_RESID_LN ? rr / RPI : 0][e] + v[e] * rowm * meE.elem_mult(m, n + e);
         storeN<CPL>(dst, v);
         float s1 = 0.f;
 #pragma unroll

@@ -70,8 +70,7 @@ extern "C" int focal_linear_fwd(const focal_linear_desc* d, const void* x, const
 
 extern "C" int focal_linear_resid_ln_supported(int dtype, int N, int K) {
   if (N == 64) return 1;
-  static const bool off = getenv("FOCAL_NO_LN_FUSE_WIDE") != nullptr;
-  return !off && dtype == FOCAL_BF16 && (N == 128 || N == 256) && K % 64 == 0;
+  return dtype == FOCAL_BF16 && (N == 128 || N == 256) && K % 64 == 0;
 }
 
 extern "C" int focal_linear_resid_ln_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias,

@@ -18,6 +18,47 @@ from . import ops
 from ._lib import ACT_GELU, ACT_NONE, EPI_GELU, EPI_NONE, EPI_RESIDUAL
 
 
+class _DeferredWeightGrads:
+    """A block's weight-gradient launches on a side stream of the encoder.
+
+    submit(): the launches wait (event) for the operands the encoder's stream has just produced and run beside that stream's next
+    block.  The encoder's stream NEVER waits for them: under hipGraph capture a stream forked from a forked stream must be joined to
+    the capture's origin stream only -- joining it back into its parent segfaults hipStreamEndCapture (ROCm 7.2;
+    tools/scratch/graph_fork_nested.py: every flag set with the inner join 'i' dumps core, the same sets without it run) -- and the
+    origin joins every side stream before the optimizer anyway (runtime.join_all).  So the operands -- saved activations and gradient
+    temporaries the encoder would otherwise free or overwrite right away -- stay alive until the encoder's next forward pass, which is
+    ordered behind that join.  (Tensor.record_stream is no alternative: inside a capture it parks blocks until the capture ends for
+    every later allocation as well, which cost 15 % in r2.)"""
+
+    def __init__(self, device, index, enabled=True):
+        from . import runtime
+        self.enabled = enabled and os.environ.get("FOCAL_NO_STREAMS") != "1"
+        self.device, self.keep = device, []
+        self.stream = runtime.side_stream(device, 16 + index) if self.enabled else None
+
+    def submit(self, dtype_code, items, calls, exclusive):
+        """items: problems of one grouped launch; calls: single launches.  Returns True when they were deferred to the side stream."""
+        if not items and not calls:
+            return False
+        if not self.enabled:
+            if items:
+                ops.linear_bwd_weight_group(dtype_code, items, exclusive=exclusive)
+            for c in calls:
+                ops.linear_bwd_weight(*c)
+            return False
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        self.stream.wait_event(ready)
+        with torch.cuda.stream(self.stream):
+            if items:
+                ops.linear_bwd_weight_group(dtype_code, items, exclusive=exclusive)
+            for c in calls:
+                ops.linear_bwd_weight(*c)
+        self.keep.extend(t for it in items for t in it[:2])
+        self.keep.extend(t for c in calls for t in c[1:3])
+        return True
+
+
 class SwinModEncoder:
     def __init__(self, backbone, loc, mod, mod_index):
         self.bb = backbone
@@ -33,6 +74,12 @@ class SwinModEncoder:
     def forward(self, x_freq, view, training):
         """x_freq: [B, c, i, s] fp32 -> (feat [B, loc_out] fp32, saved state for backward)."""
         bb, geo, ar = self.bb, self.geo, self.bb.arena()
+        if getattr(self, "_dw_keep", None):
+            # operands of the previous backward pass's deferred weight gradients (see _DeferredWeightGrads): a training step has joined
+            # every side stream since (optimizer / zero_grad); any other caller is made to wait here, outside captures
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(x_freq.device).wait_stream(self._dw_stream)
+        self._dw_keep = None
         ct = bb.compute_dtype
         cc = ops.code(ct)
         f32 = ops.code(torch.float32)
@@ -44,6 +91,9 @@ class SwinModEncoder:
         P = bb.param  # cold parameters (frozen patch embedding) are read where they live
         fuse_ln = os.environ.get("FOCAL_NO_LN_FUSE") != "1"
         fuse_mlp = os.environ.get("FOCAL_NO_MLP_FUSE") != "1"
+        # 128 / 256 channels: the LayerNorm epilogue exists (row-complete wave tiles on the LDS-DMA GEMM) but loses to GEMM + LayerNorm
+        # as two launches in the step (-1 %: at 256 channels the fused fc2 takes 55-61 us against 35 + 11, profiles/r3_ln_wide_ab.txt)
+        fuse_wide = os.environ.get("FOCAL_LN_FUSE_WIDE") == "1"
         pre_ln = None  # (a1, st1) of the next block when the kernel before it already produced them
         first = f"{self.pre}.0.blocks.0"
         embed_saved = None
@@ -99,7 +149,7 @@ class SwinModEncoder:
                 d_proj = ops.linear_desc(cc, M, Cc, Cc, cc, f32, ACT_NONE, EPI_RESIDUAL,
                                          out_drop=self._drop(rng, view, uid, 0, p_drop, p_path, L))
                 x_mid = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
-                if fuse_ln and ops.resid_ln_supported(cc, Cc, Cc):
+                if fuse_ln and (Cc == 64 or fuse_wide) and ops.resid_ln_supported(cc, Cc, Cc):
                     a2, st2 = ops.linear_resid_ln_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"),
                                                       x, x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
                 else:
@@ -128,7 +178,7 @@ class SwinModEncoder:
                 h = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)
                 hg = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)  # d h / d(pre-activation), dropout included
                 ops.linear_fwd(d_fc1, a2, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"), None, h, hg)
-                if fuse_ln and ops.resid_ln_supported(cc, Cc, 4 * Cc) and bi + 1 < st["depth"]:
+                if fuse_ln and (Cc == 64 or fuse_wide) and ops.resid_ln_supported(cc, Cc, 4 * Cc) and bi + 1 < st["depth"]:
                     nb = f"{self.pre}.{si}.blocks.{bi + 1}"
                     pre_ln = ops.linear_resid_ln_fwd(d_fc2, h, ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"),
                                                      x_mid, x_out, ar.master(f"{nb}.norm1.weight"), ar.master(f"{nb}.norm1.bias"), ct)
@@ -181,6 +231,14 @@ class SwinModEncoder:
         group_dw = os.environ.get("FOCAL_NO_DW_GROUP") != "1"
         # one pass per step over this encoder's weights (both views in one batch): a gradient tile has a single writer per launch
         exclusive_dw = bool(getattr(bb, "views_share_pass", False))
+        # Nothing in the backward pass waits for a weight gradient (only the optimizer does), so a block's weight-gradient launches
+        # could leave the encoder's critical path -- the chain LayerNorm backward -> dX -> attention backward -> dX -> LayerNorm backward
+        # that the step time is made of (tools/timeline.py) -- for a side stream.  Measured (FOCAL_DW_STREAM=1, one rank, same-box
+        # A/B, profiles/r3_dw_stream_ab.txt): SW_Transformer 42 200 -> 38 300 windows/s, HAR4 33 700 -> 27 000.  The launches do overlap;
+        # what costs more is that their operands must outlive the block (see _DeferredWeightGrads), so every later temporary lands on
+        # memory the Infinity Cache does not hold.  Off by default; kept as the record of the experiment.
+        dwq = _DeferredWeightGrads(dev, self.mod_index, enabled=os.environ.get("FOCAL_DW_STREAM", "0") == "1")
+        self._dw_keep, self._dw_stream = dwq.keep, dwq.stream  # released by the next forward pass (behind the optimizer's join of all side streams)
         last = blocks[-1]
         gm = ops.mask_cast(g.view(last["M"], last["C"]), last["d_fc2"].out_drop, ct)
         for k in range(len(blocks) - 1, -1, -1):
@@ -203,7 +261,15 @@ class SwinModEncoder:
             # L2 -> LDS bytes per MAC.  Their operands stay alive until then, so the attention branch's masked gradient gets a buffer
             # of its own instead of overwriting the MLP branch's.
             grouped = group_dw and s.get("d_mlp") is None and ops.dw_group_supported(cc, M, Cc, 4 * Cc) and ops.dw_group_supported(cc, M, 3 * Cc, Cc)
-            dw_items = []
+            dw_items, dw_calls = [], []  # grouped problems / single launches (descriptor, dy, x, dw, dbias) of this block
+
+            def weight_grad(desc, dy, x, dw, db):
+                if grouped:
+                    dw_items.append((dy, x, dw, db))
+                elif dwq.enabled:
+                    dw_calls.append((desc, dy, x, dw, db))
+                else:
+                    ops.linear_bwd_weight(desc, dy, x, dw, db)
             # ---- MLP branch: x_out = x_mid + mask * (h W2^T + b2), h = drop(gelu(a2 W1^T + b1))
             dc = torch.empty_like(s["a2"])
             du = None
@@ -213,49 +279,41 @@ class SwinModEncoder:
                             ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
             else:
                 d_fc2_b = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, cc, ACT_GELU)  # dy = gm: operand dtype, already masked
-                if grouped:
-                    dw_items.append((gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias")))
-                else:
-                    ops.linear_bwd_weight(d_fc2_b, gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
+                weight_grad(d_fc2_b, gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
                 du = torch.empty_like(s["h"])
                 ops.linear_bwd_data(d_fc2_b, gm, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
-                if grouped:
-                    dw_items.append((du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias")))
-                else:
-                    ops.linear_bwd_weight(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
+                weight_grad(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
                 ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
-                if not grouped:
-                    du = None
-            gm_attn = torch.empty_like(gm) if grouped else gm
+            # (the MLP branch's gm is still an operand of a pending weight gradient unless the fused branch has consumed it)
+            gm_attn = torch.empty_like(gm) if (s.get("d_mlp") is None and (grouped or dwq.enabled)) else gm
             ops.layernorm_bwd(dc, s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g, True,
                               ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), dx_masked=gm_attn, mask=s["d_proj"].out_drop)
             # ---- attention branch: x_mid = x + mask * (o Wp^T + bp)
             d_proj_b = ops.linear_desc(cc, M, Cc, Cc, cc, cc)
-            if grouped:
-                dw_items.append((gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias")))
-            else:
-                ops.linear_bwd_weight(d_proj_b, gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
+            weight_grad(d_proj_b, gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
             do = dc  # reuse the [M, C] CT buffer
             ops.linear_bwd_data(d_proj_b, gm_attn, ar.operand(f"{pb}.attn.proj.weight"), None, do)
             dqkv = torch.empty_like(s["qkv"])
             ops.window_attn_bwd(s["d_att"], s["qkv"], ar.master(f"{pb}.attn.relative_position_bias_table"), do, dqkv,
                                 ar.g(f"{pb}.attn.relative_position_bias_table"))
-            if grouped:
-                dw_items.append((dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias")))
-            else:
-                ops.linear_bwd_weight(s["d_qkv"], dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias"))
+            weight_grad(s["d_qkv"], dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias"))
             da = do
             ops.linear_bwd_data(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), None, da)
-            if grouped:
-                ops.linear_bwd_weight_group(cc, dw_items, exclusive=exclusive_dw)
-                dw_items = None
+            deferred = dwq.submit(cc, dw_items, dw_calls, exclusive_dw)
             del dqkv, du
             # the next consumer of g: block k-1's MLP branch, unless a PatchMerging (handled above) or the embedding comes first
             nxt = blocks[k - 1]["d_fc2"].out_drop if (k > 0 and k not in merges) else None
+            if deferred and nxt is not None:
+                gm = torch.empty_like(gm)  # the old buffers are operands of the weight gradients now running beside this stream
             ops.layernorm_bwd(da, s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g, True,
                               ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"),
                               dx_masked=gm if nxt is not None else None, mask=nxt)
             blocks[k] = None  # free this block's activations as we go
+            dw_items = dw_calls = weight_grad = None
+        if dwq.enabled and not torch.cuda.is_current_stream_capturing():
+            # eager callers may read the gradients once autograd has joined THIS stream: fold the side stream in (a captured step's
+            # origin stream joins it before the optimizer instead -- see _DeferredWeightGrads for why not here)
+            torch.cuda.current_stream(dev).wait_stream(dwq.stream)
         # g now holds dL/d(patch-embed tokens).  FOCAL pretraining: the embedding is frozen and its input is a leaf -> stop here.
         es = saved.get("embed")
         if es is not None:  # supervised training: LayerNorm backward, then the convolution's weight / bias gradient

@@ -11,6 +11,8 @@ import torch
 
 from conftest import make_args, no_dropout, record_observed
 
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -209,31 +211,54 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
     # difference below divides it by 2 eps, so it is part of the tolerance (a mask mismatch is an O(1) relative error)
     with torch.no_grad():
         vals = [value().item() for _ in range(8)]
-    # (observed: with the range of only 4 samples as the noise estimate and single evaluations on each side this check failed about
-    # one run in ten on an outlier of the atomics' summation order -- the same commit passed 3 of 3 re-runs; hence 8 samples for the
-    # estimate and the mean of 3 evaluations on each side of the difference)
     noise = max(vals) - min(vals) + 2e-7 * abs(vals[0])
     params = dict(net.named_parameters())
     names = ["freq_interval_layers.shake.audio.0.blocks.1.mlp.fc2.weight", "freq_interval_layers.shake.audio.1.blocks.0.attn.proj.weight",
              "freq_interval_layers.shake.seismic.2.blocks.3.mlp.fc1.weight", "freq_interval_layers.shake.audio.0.downsample.reduction.weight",
              "freq_interval_layers.shake.seismic.0.blocks.0.norm1.weight", "freq_interval_layers.shake.audio.2.blocks.2.attn.qkv.weight"]
+    # ONE evaluation on each side of the central difference.  History (r2): about one run of this test in eight saw a single evaluation
+    # ~eps * |analytic| away from its siblings (the size of the perturbation's own effect, i.e. as if that one pass had not seen the
+    # weight update), and the test took medians of five.  Round 3 could not reproduce it: 60 000 evaluations of this very sequence in
+    # fresh processes -- streams on / off, a synchronize after the update, the late and the early stream fork, NaN-poisoned allocator
+    # caches (tools/scratch/dbg_fd_outlier.py, dbg_fd_test_repro.py, dbg_poison.py; profiles/r3_fd_outlier.txt) -- produced none.  So the
+    # check is single again (one repeat per side as the tripwire); should an evaluation ever disagree with its repeat, the evidence --
+    # every value, the pre-update value, the perturbation's own size -- is written down before more evaluations settle the quotient.
+    from conftest import record_observed
+    worst_repeat = 0.0
     for i, n in enumerate(names):
         p = params[n]
         d = torch.randn(p.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(100 + i))
         ana = (p.grad * d).sum().item()
         eps = 2e-3 / max(d.abs().max().item(), 1e-6)
         with torch.no_grad():
+            base = value().item()
             p.add_(eps * d)
-            ups = [value().item() for _ in range(5)]
+            up, up2 = value().item(), value().item()
             p.add_(-2 * eps * d)
-            dns = [value().item() for _ in range(5)]
+            dn, dn2 = value().item(), value().item()
             p.add_(eps * d)
-        # medians: with 3-evaluation means this quotient was off by 20 % in about one run of the test in eight (one evaluation 4e-4
-        # away, against a spread of 2.6e-5), which a mean passes on; 400 repeated forwards and 400 repeated backwards of the
-        # unperturbed net never deviated (tools/scratch/dbg_fwd_noise.py, dbg_bwd_race.py: max 3.8e-5 / < 1e-3), so the analytic
-        # side is not what moved
-        num = (float(np.median(ups)) - float(np.median(dns))) / (2 * eps)
+        rep = max(abs(up - up2), abs(dn - dn2))
+        worst_repeat = max(worst_repeat, rep / noise)
+        if rep >= 6 * noise:
+            # an evaluation disagrees with its own repeat right after a weight update: keep the evidence (gpurun_out/fd_outlier_events.json,
+            # tests/golden/OBSERVED_*.json), then let three more evaluations per side settle which value stands
+            import json
+            with torch.no_grad():
+                p.add_(eps * d)
+                ups = [up, up2] + [value().item() for _ in range(3)]
+                p.add_(-2 * eps * d)
+                dns = [dn, dn2] + [value().item() for _ in range(3)]
+                p.add_(eps * d)
+            ev = dict(param=n, base=base, up=ups, down=dns, noise=noise, eps_times_analytic=eps * ana)
+            path = os.path.join(ROOT, "gpurun_out", "fd_outlier_events.json")
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            old_ev = json.load(open(path)) if os.path.exists(path) else []
+            json.dump(old_ev + [ev], open(path, "w"), indent=1)
+            record_observed("swt.fd_dropout.outlier_events", len(old_ev) + 1)
+            up, dn = float(np.median(ups)), float(np.median(dns))
+        num = (up - dn) / (2 * eps)
         assert abs(num - ana) < 3e-2 * max(abs(ana), abs(num), 1e-3) + 2 * noise / (2 * eps), (n, num, ana, noise, eps)
+    record_observed("swt.fd_dropout.worst_repeat_over_noise", worst_repeat)
 
 
 @pytest.mark.parametrize("ct", ["fp32", "bf16"])

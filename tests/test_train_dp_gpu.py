@@ -82,17 +82,35 @@ def test_two_rank_train_py_matches_whole_batch_oracle(cfg, tmp_path, model, nb):
     # AdamW's first steps move every weight by ~lr whatever the gradient's size (m / sqrt(v) = +-1), so the update itself is the
     # yardstick, in L2 per tensor (an element whose gradient is at rounding level may flip its sign: 2 lr on that element).  A
     # wrong exchange (local instead of global negatives, a missing rank's gradient) changes the sign pattern wholesale.
-    worst = (0.0, None)
-    num = den = 0.0
-    for key in tr.train_keys:
-        ref = tr.P[key]
-        d2 = (ref - state[key]).double().pow(2).sum().item()
-        e2 = (got[key] - ref).double().pow(2).sum().item()
-        num, den = num + e2, den + d2
-        if d2 > 0 and ref.numel() >= 1024:
-            worst = max(worst, ((e2 / d2) ** 0.5, key))
-    assert den > 0 and (num / den) ** 0.5 < 0.03, ((num / den) ** 0.5, worst)
-    assert worst[0] < 0.15, worst
+    def update_error(a, ref):
+        worst, num, den = (0.0, None), 0.0, 0.0
+        for key in tr.train_keys:
+            d2 = (ref[key] - state[key]).double().pow(2).sum().item()
+            e2 = (a[key] - ref[key]).double().pow(2).sum().item()
+            num, den = num + e2, den + d2
+            if d2 > 0 and ref[key].numel() >= 1024:
+                worst = max(worst, ((e2 / d2) ** 0.5, key))
+        return (num / max(den, 1e-300)) ** 0.5, worst, den
+    err, worst, den = update_error(got, tr.P)
+    from conftest import record_observed
+    record_observed(f"train_dp.{model}.nb{nb}.update_error_vs_oracle", err)
+    if nb <= 2:
+        assert den > 0 and err < 0.03, (err, worst)
+        assert worst[0] < 0.15, worst
+    else:
+        # Six steps: rounding-level sign flips of the first steps compound (every later step starts from weights that differ by a
+        # few lr in a few elements), so the oracle comparison is loose here and the sharp check is against the SAME job launched
+        # eagerly (-no_graph): replayed segments + eager collectives must reproduce eager steps up to the summation order of atomics
+        assert den > 0 and err < 0.25, (err, worst)
+        r2 = _launch(2, extra + ["-no_graph"], {"FOCAL_DIST_BACKEND": "gloo", "FOCAL_DIST_ONE_DEVICE": "1"}, 29580)
+        assert r2.returncode == 0, (r2.stdout + r2.stderr)[-4000:]
+        assert "0 graph replays" in r2.stdout + r2.stderr
+        eager = torch.load(os.path.join(ROOT, "weights", f"MOD_{model}", f"MOD_{model}_pretrain_latest.pt"), map_location="cpu")
+        err_e, worst_e, _ = update_error(eager, tr.P)
+        err_ge, worst_ge, _ = update_error(got, eager)
+        record_observed(f"train_dp.{model}.nb{nb}.eager_update_error_vs_oracle", err_e)
+        record_observed(f"train_dp.{model}.nb{nb}.graph_vs_eager_update_error", err_ge)
+        assert err_ge < max(0.05, 0.75 * err), (err_ge, worst_ge, err, err_e)
     if model == "DeepSense":
         bad = []
         for key, v in tr.P.items():
