@@ -54,6 +54,10 @@ def parse():
     p.add_argument("--roofline-iters", type=int, default=20)
     p.add_argument("--from-host", action="store_true", help="diagnostic (never the reported `value`): every step's windows start in pinned "
                    "host memory, as the reference's DataLoader hands them over; H2D on a copy stream one step ahead")
+    p.add_argument("--views", default="fixed", choices=["fixed", "random"],
+                   help="fixed: identity / x * -1.1 folded into the DFT inside the captured step (the default, what `value` is quoted on); random: the "
+                        "product Augmenter's draws (data_augmenter/Augmenter.py: coin flips, permutation / flip / phase / warp tables on the host, one "
+                        "DFT launch per modality and view plus a warp pass when drawn) made eagerly before every replay, inside the timed region")
     p.add_argument("--no-roofline", action="store_true", help="profiling runs: skip the dominant-kernel timing loop (the JSON line then has roofline null)")
     return p.parse_args()
 
@@ -109,6 +113,12 @@ class Step:
                 shape = (a.batch, cfg["loc_mod_in_time_channels"][loc][mod], cfg["num_segments"], cfg["loc_mod_spectrum_len"][loc][mod])
                 self.x[loc][mod] = torch.randn(shape, generator=g).to(device)
         from focal_amd.graph_step import StepSegments
+        self.aug = None
+        if a.views == "random":
+            from data_augmenter.Augmenter import Augmenter
+            self.aug = Augmenter(args)
+            self.aug.static_views = True  # address-stable two-view buffers: the captured step reads them
+            self.draw_views()
         self.seg = StepSegments(self.model, self.loss_fn, self.opt, self.views, device)
         self.feed = None
 
@@ -142,7 +152,14 @@ class Step:
         f["k"] += 1
         self.feed_h2d(f["k"] & 1)
 
+    def draw_views(self):
+        """--views random: what train.py does before every replay (train_utils/pretrain.py): two draws of the product augmenter."""
+        self.v1 = self.aug.forward("random", self.x)
+        self.v2 = self.aug.forward("random", self.x)
+
     def views(self):
+        if self.aug is not None:
+            return self.v1, self.v2
         # both views of a modality are written into the halves of one [2B, ...] tensor (what Augmenter.forward_random does for
         # back-to-back draws): SW_Transformer runs them as one batch without a concatenation
         both = {l: {m: torch.empty(2 * x.shape[0], 2 * x.shape[1], x.shape[2], x.shape[3], device=x.device) for m, x in mm.items()}
@@ -192,8 +209,26 @@ def _dw_bytes_flops(d):
     return d.M * d.N * ey + d.M * d.K * ex + d.N * d.K * 4, 2.0 * d.M * d.N * d.K
 
 
+# ops of focal_amd.ops that launch nothing (descriptors, queries, allocation helpers): never traced
+_NOT_LAUNCHES = {"code", "torch_dtype", "zero_pool_reset", "pool_zeros", "zeros", "drop_desc", "new_rng_state", "linear_desc", "ln_desc",
+                 "mlp_desc", "attn_desc", "conv_desc", "conv_in_desc", "bn_desc", "mlp_supported", "dw_group_supported", "resid_ln_supported",
+                 "check", "linear_bwd_weight_group_workgroups", "linear", "gru_desc"}
+
+
+def _tensor_bytes(args, kw):
+    n = 0
+    for t in list(args) + list(kw.values()):
+        if isinstance(t, torch.Tensor):
+            n += t.numel() * t.element_size()
+        elif isinstance(t, (list, tuple)):
+            n += sum(u.numel() * u.element_size() for u in t if isinstance(u, torch.Tensor))
+    return n
+
+
 class StepTracer:
-    """HIP events around every call of the traced op families during eager steps."""
+    """HIP events around every libfocal_hip launch of eager steps (every public op of focal_amd.ops), recorded on the stream the launch
+    goes to.  Algorithmic bytes of a launch: the op's own formula where one is given below (weight gradients, LayerNorm backward, fused
+    MLP), otherwise every tensor argument once (inputs read once, outputs written once -- what a streaming or GEMM kernel has to move)."""
 
     def __init__(self, ops):
         self.ops, self.rec, self.saved = ops, [], {}
@@ -224,6 +259,14 @@ class StepTracer:
                     else "focal_gemm_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles>")
             return (kern, f"{wgs} workgroups x {512 if kern.startswith('focal_dw_ring') else 256}", b, f, "hbm", f"dW[{d.N},{d.K}] over {d.M} rows")
 
+        def dwg(dtype_code, items, exclusive=True):
+            wgs = ops.linear_bwd_weight_group_workgroups(dtype_code, items, exclusive)
+            b = sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + w.numel() * 4 for dy, x, w, _ in items)
+            f = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)
+            rows, C = items[0][0].shape[0], min(min(dy.shape[1], x.shape[1]) for dy, x, _, _ in items)
+            return ("focal_dw_group_kernel<the dW of a block's linears in one launch, 128x128 tiles, LDS-DMA ring>", f"{wgs} workgroups x 512", b, f, "hbm",
+                    f"{len(items)} dW of a C={C} block over {rows} rows")
+
         def lnb(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None, dx_masked=None, mask=None):
             rows, C = dy.shape
             es = dy.element_size()
@@ -232,9 +275,30 @@ class StepTracer:
 
         def mlpb(d, gm, a, *rest, **kw):
             return ("mlp_bwd_kernel", "256 workgroups x 1024 (persistent)", d.M * d.C * 6, 10.0 * d.M * d.C * d.hidden, "mfma", f"M {d.M}")
-        self._wrap("linear_bwd_weight", dw)
-        self._wrap("layernorm_bwd", lnb)
-        self._wrap("mlp_bwd", mlpb)
+
+        def generic(name):
+            def describe(*args, **kw):
+                d = args[0] if args and hasattr(args[0], "_fields_") else None
+                flops = 0.0
+                if d is not None and all(hasattr(d, k) for k in ("M", "N", "K")):
+                    flops = 2.0 * d.M * d.N * d.K
+                elif d is not None and all(hasattr(d, k) for k in ("rows", "C_in", "C_out", "k")):
+                    flops = 2.0 * d.rows * d.C_in * d.C_out * d.k
+                elif d is not None and all(hasattr(d, k) for k in ("B", "T", "H")):
+                    flops = 2.0 * d.B * d.T * 2 * 3 * d.H * d.H * (2 if name.endswith("bwd") else 1)
+                shp = " x ".join(str(tuple(t.shape)) for t in args if isinstance(t, torch.Tensor))[:70]
+                kern = name
+                if name in GEMM_OPS:  # one op, several kernel templates: group by what the dispatcher launched (rocprofv3 --stats rows)
+                    kern = f"{lib.focal_last_kernel().decode()} ({name})"
+                return (kern, "all launches of the kernel", _tensor_bytes(args, kw), flops, "hbm", shp)
+            return describe
+        GEMM_OPS = {"linear_fwd", "linear_bwd_data", "linear_resid_ln_fwd", "conv_fwd", "conv_bwd_data", "conv_bwd_weight"}
+        special = {"linear_bwd_weight": dw, "linear_bwd_weight_group": dwg, "layernorm_bwd": lnb, "mlp_bwd": mlpb}
+        for name in dir(ops):
+            fn = getattr(ops, name)
+            if (callable(fn) and not name.startswith("_") and name not in _NOT_LAUNCHES and not isinstance(fn, type)
+                    and getattr(fn, "__module__", "") == ops.__name__):
+                self._wrap(name, special.get(name) or generic(name))
 
     def remove(self):
         for k, v in self.saved.items():
@@ -262,23 +326,36 @@ class StepTracer:
         return out
 
 
+def _pmc_traffic(a, kern):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes over the same eager step (tools/pmc_step_traffic.sh:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections) -- or (None, why) when the committed file was not
+    taken from this bench.py / library (a stale byte count must not sit next to a live time)."""
+    tf = os.path.join(ROOT, "profiles", f"r3_pmc_groups_{a.model}_{a.dataset}.json")
+    if not os.path.exists(tf):
+        return None, "no PMC pass committed for this workload"
+    pg = json.load(open(tf))
+    key = kern.split("<")[0].split(" ")[0]
+    hit = pg.get("groups", {}).get(key)
+    if not hit:
+        return None, f"{os.path.basename(tf)} has no group {key!r}"
+    return round(hit["hbm_bytes_per_launch"]), f"profiles/{os.path.basename(tf)} (launch-weighted over the kernel's {hit['launches']} profiled launches; taken at library build {pg.get('lib_sha16')})"
+
+
 def roofline(a, step, device):
-    """`roofline` of the JSON line: the (kernel template, launch shape) group with the largest time per step among the traced
-    families, measured in the step.  HBM-bound groups: achieved = algorithmic bytes per launch / average launch duration against
-    the 8 TB/s peak; the fused MLP backward is compute-bound (its bytes are 6 B per token-channel): TFLOP/s against the dense bf16
-    MFMA peak.  `isolated` repeats the round-1 measurement (one instance, back-to-back launches) warm and cold for comparison."""
+    """`roofline` of the JSON line: the kernel with the largest time per step, measured in the step.  HBM-bound kernels: achieved =
+    algorithmic bytes per launch / average launch duration against the 8 TB/s peak; the fused MLP backward is compute-bound (its bytes
+    are 6 B per token-channel): TFLOP/s against the dense bf16 MFMA peak.  `isolated` (SW_Transformer on MOD) repeats the round-1
+    measurement (one instance, back-to-back launches) warm and cold for comparison."""
     ops = step.ops
-    if a.model != "SW_Transformer":
-        return roofline_deepsense(a, step, device)
     tr = StepTracer(ops)
     tr.install()
     n_steps = 3
-    # One stream for the traced steps: the two modality encoders normally run on two streams, where a launch's event pair also spans
-    # the slow-down from the other stream's kernels (observed +20-45 %); rocprofv3 serialises the streams, and the committed trace
-    # this number must be checkable against was taken that way.  The step's `value` is measured with both streams, of course.
+    # One stream for the traced steps: the modality encoders normally run on their own streams, where a launch's event pair also spans
+    # the slow-down from the other streams' kernels (observed +20-45 %); rocprofv3 serialises the streams, and the committed trace
+    # this number must be checkable against was taken that way.  The step's `value` is measured with all streams, of course.
     os.environ["FOCAL_NO_STREAMS"] = "1"
     try:
-        # keep the GPU behind the host: ~15 ms of fills are queued first, so the step's launches (and their events) are consumed
+        # keep the GPU behind the host: ~20 ms of fills are queued first, so the step's launches (and their events) are consumed
         # back to back and an event pair brackets kernel time, not host launch gaps
         pad = torch.empty(256 << 20, dtype=torch.float32, device=device)
         for _ in range(6):
@@ -286,6 +363,8 @@ def roofline(a, step, device):
         # (only rank 0 gets here: its traced steps are local -- no collective that the other ranks are not in)
         with step.dist.local_only():
             for _ in range(n_steps):
+                for _ in range(40):
+                    pad.fill_(1.0)
                 step.run()
         groups = tr.summary(n_steps)
     finally:
@@ -310,43 +389,35 @@ def roofline(a, step, device):
     else:
         ach = nflops / (us * 1e-6) / 1e12
         peak, unit = (MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF), "TFLOP/s"
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "r2_pmc_groups.json")
-    if os.path.exists(tf):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same eager step (tools/pmc_step_traffic.sh)
-        pg = json.load(open(tf))["groups"]
-        if kern.startswith(("focal_gemm_kernel<dW", "focal_dw_ring_kernel")):
-            keys = ["dW:" + g["launch_shape"].split()[0] for g in kg]
-        else:
-            keys = ["ln_bwd:all" if kern.startswith("ln_bwd") else "mlp_bwd:all"]
-        hit = [pg[k] for k in keys if k in pg]
-        if hit:  # launch-weighted mean over the kernel's launch shapes
-            traffic = round(sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hit) / max(sum(h["launches"] for h in hit), 1))
+    traffic, traffic_src = _pmc_traffic(a, kern)
 
     def grp(g):
         return {"kernel": f"{g['kernel']} [{g['launch_shape']}]", "calls_per_step": round(g["calls_per_step"], 2), "avg_us": round(g["avg_us"], 2),
                 "ms_per_step": round(g["us_per_step"] / 1e3, 4), "GBps": round(g["bytes_per_launch"] / (g["avg_us"] * 1e-6) / 1e9, 1),
                 "TFLOPps": round(g["flops_per_launch"] / (g["avg_us"] * 1e-6) / 1e12, 1)}
     out = {"bound": bound, "kernel": kern + " [all %d launch shapes]" % len(kg), "achieved": round(ach, 1), "peak": peak, "unit": unit,
-           "frac": round(ach / peak, 4), "traffic": traffic,
+           "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
            "measured": "in the step: HIP events around each launch of eager steps (one stream, as rocprofv3 sees them); algorithmic bytes of all the "
                        "kernel's launches / their total time",
            "calls_per_step": round(calls, 2), "avg_us": round(us / calls, 2), "ms_per_step": round(us / 1e3, 4),
+           "launches_per_step": round(sum(g["calls_per_step"] for g in groups), 1),
+           "kernel_ms_per_step": round(sum(g["us_per_step"] for g in groups) / 1e3, 3),
            "algorithmic_bytes_per_launch": round(nbytes / calls), "flops_per_launch": round(nflops / calls),
            "launch_shapes": [grp(g) for g in kg],
            "instances": kg[0]["instances"],
-           "other_groups": [grp(g) for g in groups if g["kernel"] != kern][:6],
+           "other_groups": [grp(g) for g in groups if g["kernel"] != kern][:8],
            "families": _families(groups),
-           "isolated": roofline_isolated(a, step, device)}
+           "isolated": roofline_isolated(a, step, device) if (a.model == "SW_Transformer" and a.dataset == "MOD") else None}
     return out
 
 
 def _families(groups):
     """The launch groups folded by what they compute (a family may span kernels and launch shapes: the weight gradients run on
-    focal_dw_ring_kernel, focal_gemm_kernel<dW ..> at several grids and inside mlp_bwd_kernel) -- the traced families only."""
+    focal_dw_group_kernel, focal_dw_ring_kernel, focal_gemm_kernel<dW ..> at several grids and inside mlp_bwd_kernel)."""
     fam = {}
     for g in groups:
         k = g["kernel"]
-        name = ("weight gradients (all dW launches)" if k.startswith(("focal_gemm_kernel<dW", "focal_dw_ring_kernel")) else k.split("<")[0].split(" ")[0])
+        name = ("weight gradients (all dW launches)" if k.startswith(("focal_gemm_kernel<dW", "focal_dw_ring_kernel", "focal_dw_group_kernel")) else k.split("<")[0].split(" ")[0])
         f = fam.setdefault(name, [0.0, 0.0, 0.0, 0.0])
         f[0] += g["calls_per_step"]
         f[1] += g["us_per_step"]
@@ -356,7 +427,7 @@ def _families(groups):
             "frac_of_hbm_peak": round(f[2] / (f[1] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "TFLOPps": round(f[3] / (f[1] * 1e-6) / 1e12, 1)}
            for n, f in fam.items()]
     out.sort(key=lambda e: -e["ms_per_step"])
-    return out
+    return out[:14]
 
 
 def roofline_isolated(a, step, device):
@@ -388,27 +459,6 @@ def roofline_isolated(a, step, device):
     return {"kernel": "dW[%d,%d] += dy[%d,%d]^T x[%d,%d] (%s)" % (N, K, M, N, M, K, a.dtype), "algorithmic_bytes": bytes_alg,
             "warm_us": round(ms_w * 1e3, 2), "warm_frac": round(bytes_alg / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "cold_us": round(ms_c * 1e3, 2), "cold_frac": round(bytes_alg / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-
-
-def roofline_deepsense(a, step, device):
-    """DeepSense's dominant kernel family: the [1,5] inter-conv as a sliding-window MFMA GEMM
-    (M = B*10*20 tokens, K = 5*64, N = 64): reads the bf16 activation once, writes the fp32 pre-BN output."""
-    ops = step.ops
-    ct = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    es = 2 if ct == torch.bfloat16 else 4
-    C, S, k = 64, 20, 5
-    rows = a.batch * 10 * S
-    x = torch.randn(rows, C, device=device).to(ct)
-    w = (torch.randn(C, k * C, device=device) * (k * C) ** -0.5).to(ct)
-    b = torch.zeros(C, device=device)
-    d = ops.conv_desc(ops.code(ct), rows, S, C, C, k)
-    ms = time_kernel(lambda: ops.conv_fwd(d, x, w, b))
-    bytes_alg = rows * C * es + rows * C * 4 + C * k * C * es
-    gbs = bytes_alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "focal_gemm_kernel<conv window> rows=%d K=%d N=%d" % (rows, k * C, C), "achieved": round(gbs, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-            "measured": "isolated, back-to-back launches (13 MB operands: cache-resident)",
-            "ms_per_launch": round(ms, 5), "tflops": round(2.0 * rows * C * k * C / (ms * 1e-3) / 1e12, 1)}
 
 
 def cpu_baseline(a, cfg):
@@ -511,6 +561,12 @@ def main():
                 ok = int(flag.item())
             if ok:
                 run, graphed = replay, True
+        if a.views == "random":
+            drawn = run
+
+            def run():
+                step.draw_views()
+                drawn()
         if a.from_host:
             step.enable_host_feed()
             inner = run
@@ -560,7 +616,9 @@ def main():
                           "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": graphed, **({"DIAGNOSTIC_no_dropout": True} if a.no_dropout else {}),
                           **({"DIAGNOSTIC_from_host": True} if a.from_host else {}),
 **({"DIAGNOSTIC_ABLATED_INVALID": os.environ["FOCAL_ABLATE"]} if os.environ.get("FOCAL_ABLATE") else {}),
-                          "views": "identity / negation+scaling (x * -1.1) folded into the DFT", "last_loss": round(last_loss, 4),
+                          "views": ("identity / negation+scaling (x * -1.1) folded into the DFT" if a.views == "fixed" else
+                                    "random: the product Augmenter's draws, made eagerly before every replay inside the timed region (DIAGNOSTIC: not the quoted configuration)"),
+                          "last_loss": round(last_loss, 4),
                           "parity": "this configuration (train mode, dropout / DropPath on) is covered by statistical and finite-difference tests; "
                                     "the same kernels with dropout off are pinned bit-for-tolerance against reference fixtures (tests/golden, DESIGN 1)"},
                "model_flops_frac_of_bf16_mfma_peak": round(wps / world * flops_per_window(a.model, a.dataset) / (MFMA_BF16_PEAK_TF * 1e12), 5),

@@ -95,6 +95,7 @@ P = C.c_void_p
 PROTOTYPES = {
     "focal_abi_version": (C.c_int, []),
     "focal_last_error": (C.c_char_p, []),
+    "focal_last_kernel": (C.c_char_p, []),
     "focal_rng_advance": (C.c_int, [P, P]),
     "focal_fft_realpack_fwd": (C.c_int, [C.POINTER(FFTDesc), P, P, P, P]),
     "focal_augment_fft_fwd": (C.c_int, [C.POINTER(FFTDesc), C.POINTER(AugDesc), P, P, P, P]),

@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // ----------------------------------------------------------------------------------------------- errors
 void focal_set_error(const char* fmt, ...);
+void focal_note_kernel(const char* fmt, ...);
 #define FOCAL_CHECK_ARG(cond, ...)                 \
   do {                                             \
     if (!(cond)) {                                 \

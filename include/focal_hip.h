@@ -34,6 +34,8 @@ enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPAC
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
 
 int focal_abi_version(void);
+/* diagnostics: the kernel template the GEMM-family entry points launched last on this thread ("" before the first one) */
+const char* focal_last_kernel(void);
 const char* focal_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------ RNG state
