@@ -143,6 +143,7 @@ PROTOTYPES = {
     "focal_conv_bwd_data": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
     "focal_conv_bwd_weight": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
     "focal_bn_stats": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, C.c_int, P]),
+    "focal_bn_running_combine": (C.c_int, [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.c_int, C.c_float, P]),
     "focal_bn_act_fwd": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P]),
     "focal_bn_act_bwd": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P, P, C.c_int, P]),
     "focal_gru_gate_fwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, C.c_int, P, P, P, P, P, P, P]),

@@ -327,3 +327,31 @@ extern "C" int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const fl
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ two views, one update
+// The reference runs the two augmented views of a step through the backbone one after the other, so every BatchNorm's running buffers
+// see view 1's batch statistics, then view 2's:  r <- (1 - m) ((1 - m) r + m s1) + m s2.  Passes that each update the buffers
+// themselves must therefore run in that order; passes that only record their statistics (focal_bn_stats with momentum 1 into a
+// per-pass sink) can run side by side, and this kernel applies the same two updates afterwards -- one launch for every running buffer
+// of an encoder.
+struct BnCombineTable { int n; float* run[FOCAL_BN_COMBINE_MAX]; const float* s1[FOCAL_BN_COMBINE_MAX]; const float* s2[FOCAL_BN_COMBINE_MAX]; };
+__global__ void bn_running_combine_kernel(BnCombineTable t, int C, float m) {
+  const int e = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float r1 = (1.f - m) * t.run[e][c] + m * t.s1[e][c];
+    t.run[e][c] = (1.f - m) * r1 + m * t.s2[e][c];
+  }
+}
+extern "C" int focal_bn_running_combine(int n, float* const* running, const float* const* view1, const float* const* view2, int C,
+                                        float momentum, void* stream) {
+  FOCAL_CHECK_ARG(n >= 1 && n <= FOCAL_BN_COMBINE_MAX && running && view1 && view2 && C > 0, "bn_running_combine: 1 .. %d buffers of C > 0 values", FOCAL_BN_COMBINE_MAX);
+  BnCombineTable t;
+  t.n = n;
+  for (int i = 0; i < n; ++i) {
+    FOCAL_CHECK_ARG(running[i] && view1[i] && view2[i], "bn_running_combine: null buffer %d", i);
+    t.run[i] = running[i]; t.s1[i] = view1[i]; t.s2[i] = view2[i];
+  }
+  hipLaunchKernelGGL(bn_running_combine_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, t, C, momentum);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}

@@ -9,6 +9,8 @@ Layout: activations are channel-last tokens [B*I*S, C] (row = (sample, interval,
 GRU: input projections for all 10 steps in one GEMM per direction; per step one [B,H]x[H,3H] GEMM + one gate
 kernel; backward mirrors it and ends with ONE weight-gradient GEMM per matrix over all steps.
 """
+import os
+
 import torch
 
 from . import ops
@@ -25,6 +27,32 @@ class DeepSenseModEncoder:
     def _stream(self, view, uid):
         return ((view * 8 + self.mod_index) * 64 + uid) * 8
 
+    def _sink(self, order, device):
+        """[BatchNorm layer, {mean, unbiased variance}, C]: where pass `order` of a step records its batch statistics."""
+        sinks = self.__dict__.setdefault("_sinks", {})
+        key = (order, torch.device(device))
+        if key not in sinks:
+            sinks[key] = torch.zeros(1 + self.geo["n_inter"], 2, self.geo["C"], dtype=torch.float32, device=device)
+        return sinks[key]
+
+    def finish_views(self, device):
+        """Both passes of a step have recorded their statistics: apply the two running-buffer updates (view 1's, then view 2's)."""
+        if getattr(self, "_sinks_filled", 0) != 3:
+            if getattr(self, "_sinks_filled", 0):
+                raise ops._lib.FocalHipError("DeepSense: one view's pass recorded BatchNorm statistics and the other did not")
+            return
+        self._sinks_filled = 0
+        buf = self.bb.buffer
+        names = [f"{self.pre}.conv_layer_in"] + [f"{self.pre}.conv_layers_inter.{li}" for li in range(self.geo["n_inter"])]
+        s0, s1 = self._sink(0, device), self._sink(1, device)
+        run, v1, v2 = [], [], []
+        for i, p in enumerate(names):
+            for j, which in enumerate(("running_mean", "running_var")):
+                run.append(buf(f"{p}.batch_norm.{which}"))
+                v1.append(s0[i, j])
+                v2.append(s1[i, j])
+        ops.bn_running_combine(run, v1, v2, 0.1)
+
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x_freq, view, training):
         bb, ar, geo = self.bb, self.bb.arena(), self.geo
@@ -39,17 +67,29 @@ class DeepSenseModEncoder:
         rows = B * I * S
         buf = bb.buffer
         sv = dict(B=B, view=view, x=x_freq, layers=[])
-        # running-statistics order: this pass's BatchNorm updates come after the previous pass's (which may run on another stream)
+        # The two views of a step run as two passes on their own streams (pass_order 0 / 1).  The reference's BatchNorm running buffers
+        # see view 1's statistics, then view 2's; rather than ordering the passes at their last BatchNorm (round 2: view 2's pass
+        # started ~0.45 ms late, all of it on the step's critical path), each pass records its batch statistics in a sink of its own
+        # (momentum 1: the "running" buffer it is given simply receives the statistic) and DeepSense.finish_views applies both updates
+        # afterwards in one launch (ops.bn_running_combine) -- the same two updates, in the reference's order.
         order = getattr(self, "pass_order", None)
-        if order == 1 and getattr(self, "_bn_done", None) is not None:
+        side_by_side = order is not None and training and os.environ.get("FOCAL_DS_ORDERED_VIEWS") != "1"
+        sink = self._sink(order, x_freq.device) if side_by_side else None
+        if order == 1 and not side_by_side and getattr(self, "_bn_done", None) is not None:
             torch.cuda.current_stream(x_freq.device).wait_event(self._bn_done)
             self._bn_done = None
+        momentum = 1.0 if side_by_side else 0.1
+
+        def running(prefix, i):
+            if side_by_side:
+                return sink[i, 0], sink[i, 1]
+            return buf(f"{prefix}.batch_norm.running_mean"), buf(f"{prefix}.batch_norm.running_var")
         # ---- conv stack
         pin = f"{self.pre}.conv_layer_in"
         d_in = ops.conv_in_desc(B, cin, I, S_in, S, geo["k_in"], geo["stride"], geo["pad_in"], C)
         z = ops.conv_in_fwd(d_in, x_freq, ar.master(f"{pin}.conv.weight"), ar.master(f"{pin}.conv.bias"))
-        d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 0))
-        mr = ops.bn_stats(d_bn, z, buf(f"{pin}.batch_norm.running_mean"), buf(f"{pin}.batch_norm.running_var"), training, bb.sync_bn)
+        d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 0), momentum=momentum)
+        mr = ops.bn_stats(d_bn, z, *running(pin, 0), training, bb.sync_bn)
         y, ya = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pin}.batch_norm.weight"), ar.master(f"{pin}.batch_norm.bias"), None, ct)
         sv["in"] = dict(d=d_in, z=z, mr=mr, d_bn=d_bn, p=pin)
         if training:
@@ -61,13 +101,15 @@ class DeepSenseModEncoder:
             w = ar.master(f"{pl}.conv.weight")  # [C, C, 1, k]
             w_fwd = ops.permute_pack(w, C, C, k, ct)
             z = ops.conv_fwd(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"))
-            d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 1 + li))
-            mr = ops.bn_stats(d_bn, z, buf(f"{pl}.batch_norm.running_mean"), buf(f"{pl}.batch_norm.running_var"), training, bb.sync_bn)
+            d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 1 + li), momentum=momentum)
+            mr = ops.bn_stats(d_bn, z, *running(pl, 1 + li), training, bb.sync_bn)
             y_next, ya_next = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pl}.batch_norm.weight"), ar.master(f"{pl}.batch_norm.bias"), y, ct)
             sv["layers"].append(dict(p=pl, z=z, mr=mr, d_bn=d_bn, xa=ya))
             y, ya = y_next, ya_next
         sv["d_cv"] = d_cv
-        if order == 0:
+        if side_by_side:
+            self._sinks_filled = getattr(self, "_sinks_filled", 0) | (1 << order)
+        elif order == 0:
             self._bn_done = torch.cuda.Event()
             self._bn_done.record(torch.cuda.current_stream(x_freq.device))
         pout = f"{self.pre}.conv_layer_out"

@@ -545,6 +545,12 @@ def bn_stats(d, z, running_mean, running_var, training, sync=False):
     return mean_rstd
 
 
+def bn_running_combine(running, view1, view2, momentum=0.1):
+    """running[i] <- (1 - m) ((1 - m) running[i] + m view1[i]) + m view2[i] for n same-sized fp32 buffers, one launch."""
+    _need_cuda(*running, *view1, *view2)
+    check(_lib.load().focal_bn_running_combine(len(running), _parr(running), _parr(view1), _parr(view2), running[0].numel(), momentum, _stream()))
+
+
 def bn_act_fwd(d, z, mean_rstd, gamma, beta, resid, cast_dtype=None):
     y = torch.empty_like(z)
     ya = torch.empty(z.shape, dtype=cast_dtype, device=z.device) if cast_dtype not in (None, torch.float32) else None

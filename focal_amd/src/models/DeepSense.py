@@ -140,6 +140,13 @@ class DeepSense(HipBackbone):
             runtime.join_all(dev)
         return out
 
+    def finish_views(self):
+        """After both views' passes of a step (FOCAL.forward): the BatchNorm running-buffer updates the passes recorded (see
+        focal_amd/deepsense_engine.py: the passes run side by side, the updates are applied here in the reference's order)."""
+        dev = next(self.parameters()).device
+        for enc in self._encoders.values():
+            enc.finish_views(dev)
+
     def forward_classifier(self, freq_x):
         """`backbone(freq_x, class_head=True)` -> logits (reference: models/DeepSense.py:154-157).  This is the finetuning path: the encoders in front run
         forward-only (finetuning freezes them, general_utils/weight_utils.py:61-80), the head -- the class layer on the concatenated features -- is one

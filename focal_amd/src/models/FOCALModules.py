@@ -41,6 +41,8 @@ class FOCAL(nn.Module):
         if kw:
             from focal_amd import runtime
             runtime.join_all(next(self.backbone.parameters()).device)
+        if hasattr(self.backbone, "finish_views"):
+            self.backbone.finish_views()
         return mod_features1, mod_features2
 
 

@@ -264,6 +264,13 @@ enum { FOCAL_BN_EVAL = 0, FOCAL_BN_TRAIN = 1, FOCAL_BN_PARTIAL = 2, FOCAL_BN_FIN
 #define FOCAL_BN_SCRATCH_ZEROED 16
 int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scratch, float* mean_rstd, float* running_mean, float* running_var,
                    int training, void* stream);
+/* The running-buffer updates of TWO passes (the two augmented views of a FOCAL step), applied after both have run: each pass records
+ * its batch statistics instead of updating the buffers (focal_bn_stats with d->momentum = 1 and a per-pass sink in place of the running
+ * buffers), this applies r <- (1 - m) ((1 - m) r + m s1) + m s2 to n buffers of C values in one launch -- what the reference's two
+ * sequential backbone calls leave behind (models/FOCALModules.py:21-34), without ordering the passes. */
+#define FOCAL_BN_COMBINE_MAX 24
+int focal_bn_running_combine(int n, float* const* running, const float* const* view1, const float* const* view2, int C, float momentum,
+                             void* stream);
 int focal_bn_act_fwd(const focal_bn_desc* d, const float* z, const float* mean_rstd, const float* gamma, const float* beta,
                      const float* resid, float* y, void* y_cast, void* stream);
 int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const float* g, const float* mean_rstd, const float* gamma,
