@@ -51,6 +51,10 @@ class DwProblem(C.Structure):
                 ("K", C.c_int), ("exclusive", C.c_int)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("A", C.c_int), ("B", C.c_int), ("C", C.c_int), ("kind", C.c_int)]
+
+
 class MlpDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("C", C.c_int), ("hidden", C.c_int), ("drop_hidden", DropDesc),
                 ("drop_out", DropDesc), ("ln_eps", C.c_float)]
@@ -138,6 +142,8 @@ PROTOTYPES = {
     "focal_conv_in_bwd_weight": (C.c_int, [C.POINTER(ConvInDesc), P, P, C.c_int, P, P, P]),
     "focal_permute_pack": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, C.c_int, P]),
     "focal_permute_unpack_add": (C.c_int, [C.c_int, C.c_int, C.c_int, P, P, P]),
+    "focal_pack_multi": (C.c_int, [C.c_int, C.c_int, C.POINTER(PackEntry), P]),
+    "focal_unpack_add_multi": (C.c_int, [C.c_int, C.POINTER(PackEntry), P]),
     "focal_conv_pack_bwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P]),
     "focal_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
     "focal_conv_bwd_data": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),

@@ -497,6 +497,68 @@ extern "C" int focal_conv_pack_bwd(const focal_conv_desc* d, const float* w, voi
   return FOCAL_OK;
 }
 
+// Every weight re-ordering of an encoder in ONE launch (DeepSense re-orders 13 small weights per pass -- four conv filters forward and
+// backward, the 1x1 output conv, four GRU W_hh -- and folds 5 packed weight gradients back: 18 launches of ~5 us on each pass's chain).
+struct PackTable { int n; focal_pack_entry e[FOCAL_PACK_MAX]; };
+template <typename TD> __global__ void pack_multi_kernel(PackTable t) {
+  const focal_pack_entry& q = t.e[blockIdx.y];
+  const long n = (long)q.A * q.B * q.C;
+  TD* dst = reinterpret_cast<TD*>(q.dst);
+  const float* src = reinterpret_cast<const float*>(q.src);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    if (q.kind == FOCAL_PACK_PERMUTE) {          // dst[a][c][b] = src[a][b][c]
+      const int b = e % q.B, c = (e / q.B) % q.C, a = e / ((long)q.B * q.C);
+      dst[e] = from_f32<TD>(src[((long)a * q.B + b) * q.C + c]);
+    } else {                                     // FOCAL_PACK_CONV_BWD: dst[ci][t][co] = src[co][ci][k-1-t]  (A = Co, B = Ci, C = k)
+      const int co = e % q.A, tt = (e / q.A) % q.C, ci = e / ((long)q.A * q.C);
+      dst[e] = from_f32<TD>(src[((long)co * q.B + ci) * q.C + (q.C - 1 - tt)]);
+    }
+  }
+}
+__global__ void unpack_add_multi_kernel(PackTable t) {
+  const focal_pack_entry& q = t.e[blockIdx.y];
+  const long n = (long)q.A * q.B * q.C;
+  float* dst = reinterpret_cast<float*>(q.dst);
+  const float* src = reinterpret_cast<const float*>(q.src);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const int c = e % q.C, b = (e / q.C) % q.B, a = e / ((long)q.B * q.C);  // dst[a][b][c] += src[a][c][b]
+    dst[e] += src[((long)a * q.C + c) * q.B + b];
+  }
+}
+static int pack_table(int n, const focal_pack_entry* e, PackTable* t, long* most) {
+  FOCAL_CHECK_ARG(n >= 1 && n <= FOCAL_PACK_MAX && e, "pack_multi: 1 .. %d entries", FOCAL_PACK_MAX);
+  t->n = n;
+  *most = 0;
+  for (int i = 0; i < n; ++i) {
+    FOCAL_CHECK_ARG(e[i].src && e[i].dst && e[i].A > 0 && e[i].B > 0 && e[i].C > 0 && (e[i].kind == FOCAL_PACK_PERMUTE || e[i].kind == FOCAL_PACK_CONV_BWD),
+                    "pack_multi: bad entry %d", i);
+    t->e[i] = e[i];
+    const long cnt = (long)e[i].A * e[i].B * e[i].C;
+    if (cnt > *most) *most = cnt;
+  }
+  return FOCAL_OK;
+}
+extern "C" int focal_pack_multi(int dtype, int n, const focal_pack_entry* entries, void* stream) {
+  FOCAL_CHECK_ARG(dtype == FOCAL_F32 || dtype == FOCAL_BF16, "pack_multi: bad dtype");
+  PackTable t;
+  long most;
+  if (int rc = pack_table(n, entries, &t, &most)) return rc;
+  const dim3 grid(min(64, ceil_div(most, 256)), n);
+  if (dtype == FOCAL_F32) hipLaunchKernelGGL((pack_multi_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, t);
+  else hipLaunchKernelGGL((pack_multi_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, t);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+extern "C" int focal_unpack_add_multi(int n, const focal_pack_entry* entries, void* stream) {
+  PackTable t;
+  long most;
+  if (int rc = pack_table(n, entries, &t, &most)) return rc;
+  for (int i = 0; i < n; ++i) FOCAL_CHECK_ARG(entries[i].kind == FOCAL_PACK_PERMUTE, "unpack_add_multi: entry %d is not a permutation", i);
+  hipLaunchKernelGGL(unpack_add_multi_kernel, dim3(min(64, ceil_div(most, 256)), n), dim3(256), 0, (hipStream_t)stream, t);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ [1,k] convs as GEMMs
 static int conv_check(const focal_conv_desc* d) {
   FOCAL_CHECK_ARG(d != nullptr, "conv: null descriptor");

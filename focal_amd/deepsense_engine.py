@@ -35,6 +35,40 @@ class DeepSenseModEncoder:
             sinks[key] = torch.zeros(1 + self.geo["n_inter"], 2, self.geo["C"], dtype=torch.float32, device=device)
         return sinks[key]
 
+    def prepare_packs(self):
+        """Every re-ordered weight this encoder's passes need -- the [1,k] filters for the forward GEMM and (flipped) for the data
+        gradient, the 1x1 output conv, the GRU's W_hh for the backward recurrence -- in ONE launch on the caller's stream, before the
+        passes fork: both views of a step read them (13 launches per pass in round 2, ~5 us each on every pass's chain)."""
+        bb, ar, geo = self.bb, self.bb.arena(), self.geo
+        ct = bb.compute_dtype
+        C, S, k, H = geo["C"], geo["S"], geo["k"], geo["H"]
+        dev = ar.device
+        store = self.__dict__.setdefault("_pack_store", {})
+
+        def dst(key, shape):
+            if key not in store or store[key].dtype != ct or store[key].device != dev:
+                store[key] = torch.empty(shape, dtype=ct, device=dev)
+            return store[key]
+        entries = []
+        for li in range(geo["n_inter"]):
+            w = ar.master(f"{self.pre}.conv_layers_inter.{li}.conv.weight")  # [C, C, 1, k]
+            entries.append((w, dst(("fwd", li), (C, k, C)), C, C, k, ops.PACK_PERMUTE))
+            entries.append((w, dst(("bwd", li), (C, k, C)), C, C, k, ops.PACK_CONV_BWD))
+        n_out = geo["C_out"]
+        entries.append((ar.master(f"{self.pre}.conv_layer_out.weight"), dst(("out",), (n_out, S, C)), n_out, C, S, ops.PACK_PERMUTE))
+        if ct == torch.bfloat16 and H in (128, 256):
+            for layer in range(geo["n_rnn"]):
+                for suf in ("", "_reverse"):
+                    entries.append((ar.master(f"{self.rnn}.weight_hh_l{layer}{suf}"), dst(("whh", layer, suf), (1, H, 3 * H)), 1, 3 * H, H, ops.PACK_PERMUTE))
+        for lo in range(0, len(entries), 16):
+            ops.pack_multi(entries[lo:lo + 16], ct)
+        self._packs = store
+
+    def _packed(self, key, make):
+        """The re-ordered weight `key` from this step's prepare_packs, or made on the spot (a caller that runs a pass on its own)."""
+        packs = getattr(self, "_packs", None)
+        return packs[key] if packs is not None and key in packs else make()
+
     def finish_views(self, device):
         """Both passes of a step have recorded their statistics: apply the two running-buffer updates (view 1's, then view 2's)."""
         if getattr(self, "_sinks_filled", 0) != 3:
@@ -99,7 +133,7 @@ class DeepSenseModEncoder:
         for li in range(geo["n_inter"]):
             pl = f"{self.pre}.conv_layers_inter.{li}"
             w = ar.master(f"{pl}.conv.weight")  # [C, C, 1, k]
-            w_fwd = ops.permute_pack(w, C, C, k, ct)
+            w_fwd = self._packed(("fwd", li), lambda: ops.permute_pack(w, C, C, k, ct))
             z = ops.conv_fwd(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"))
             d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 1 + li), momentum=momentum)
             mr = ops.bn_stats(d_bn, z, *running(pl, 1 + li), training, bb.sync_bn)
@@ -114,7 +148,7 @@ class DeepSenseModEncoder:
             self._bn_done.record(torch.cuda.current_stream(x_freq.device))
         pout = f"{self.pre}.conv_layer_out"
         n_out = geo["C_out"]
-        w_out = ops.permute_pack(ar.master(f"{pout}.weight"), n_out, C, S, ct)  # [n][c*S + s] -> [n][s*C + c]
+        w_out = self._packed(("out",), lambda: ops.permute_pack(ar.master(f"{pout}.weight"), n_out, C, S, ct))  # [n][c*S + s] -> [n][s*C + c]
         d_out = ops.linear_desc(cc, B * I, n_out, S * C, cc, f32)
         c_out = torch.empty(B * I, n_out, dtype=torch.float32, device=y.device)
         ops.linear_fwd(d_out, ya, w_out, ar.master(f"{pout}.bias"), None, c_out)
@@ -189,7 +223,8 @@ class DeepSenseModEncoder:
                 bufs.append((dgi, dgh))
             if lsv["seq"]:
                 dirs = lsv["dirs"]
-                whh_t = [ops.permute_pack(ar.master(d["names"][1]), 1, 3 * H, H, ct) for d in dirs]  # [H][3H] bf16
+                whh_t = [self._packed(("whh", layer, suf), lambda d=d: ops.permute_pack(ar.master(d["names"][1]), 1, 3 * H, H, ct))
+                         for d, suf in zip(dirs, ("", "_reverse"))]  # [H][3H] bf16
                 ops.gru_seq_bwd(gd, dout, ld_b, ld_t, scale, whh_t, [d["hs"] for d in dirs], [d["save"] for d in dirs],
                                 [b_[0] for b_ in bufs], [b_[1] for b_ in bufs])
             for di, dsv in enumerate(lsv["dirs"]):
@@ -227,9 +262,10 @@ class DeepSenseModEncoder:
         rows = B * I * S
         pout, d_out = sv["pout"], sv["d_out"]
         n_out = geo["C_out"]
+        unpack = []  # packed weight gradients, folded back into the arena's layout by ONE launch at the end of the pass
         dwp = ops.zeros((n_out, S * C), dev)
         ops.linear_bwd_weight(d_out, dx, sv["ya_last"], dwp, ar.g(f"{pout}.bias"))
-        ops.permute_unpack_add(dwp, ar.g(f"{pout}.weight"), n_out, C, S)
+        unpack.append((dwp, ar.g(f"{pout}.weight"), n_out, C, S))
         d_out_data = ops.linear_desc(cc, B * I, n_out, S * C, f32, f32)  # gradient w.r.t. the fp32 residual stream
         g = torch.empty(rows, C, dtype=torch.float32, device=dev)
         ops.linear_bwd_data(d_out_data, dx, sv["w_out"], None, g)
@@ -242,8 +278,8 @@ class DeepSenseModEncoder:
                                 ar.g(f"{pl}.batch_norm.weight"), ar.g(f"{pl}.batch_norm.bias"), ct, bb.sync_bn)
             dwp = ops.zeros((C, k * C), dev)
             ops.conv_bwd_weight(d_cv, dz, L["xa"], dwp, ar.g(f"{pl}.conv.bias"))
-            ops.permute_unpack_add(dwp, ar.g(f"{pl}.conv.weight"), C, C, k)
-            w_bwd = ops.conv_pack_bwd(d_cv, ar.master(f"{pl}.conv.weight"), ct)  # flipped taps, [C_in][k][C_out]
+            unpack.append((dwp, ar.g(f"{pl}.conv.weight"), C, C, k))
+            w_bwd = self._packed(("bwd", li), lambda: ops.conv_pack_bwd(d_cv, ar.master(f"{pl}.conv.weight"), ct))  # flipped taps, [C_in][k][C_out]
             ops.conv_bwd_data(d_cv, dz, w_bwd, g, g)  # g <- g + conv^T(dz), in place
             sv["layers"][li] = None
         Lin = sv["in"]
@@ -251,4 +287,5 @@ class DeepSenseModEncoder:
         dz = ops.bn_act_bwd(Lin["d_bn"], Lin["z"], g, Lin["mr"], ar.master(f"{pin}.batch_norm.weight"), ar.master(f"{pin}.batch_norm.bias"),
                             ar.g(f"{pin}.batch_norm.weight"), ar.g(f"{pin}.batch_norm.bias"), ct, bb.sync_bn)
         ops.conv_in_bwd_weight(Lin["d"], sv["x"], dz, ar.g(f"{pin}.conv.weight"), ar.g(f"{pin}.conv.bias"))
+        ops.unpack_add_multi(unpack)
         # the spectrum is a leaf: nothing flows further

@@ -489,6 +489,27 @@ def permute_unpack_add(src, dst, A, Bd, Cd):
     check(_lib.load().focal_permute_unpack_add(A, Bd, Cd, _p(src), _p(dst), _stream()))
 
 
+PACK_PERMUTE, PACK_CONV_BWD = 0, 1
+
+
+def pack_multi(entries, dtype):
+    """entries: [(src fp32, dst `dtype`, A, B, C, kind)] -- every re-ordering of an encoder's weights in one launch."""
+    arr = (_lib.PackEntry * len(entries))()
+    for i, (src, dst, A, Bd, Cd, kind) in enumerate(entries):
+        _need_cuda(src, dst)
+        arr[i] = _lib.PackEntry(_p(src), _p(dst), A, Bd, Cd, kind)
+    check(_lib.load().focal_pack_multi(code(dtype), len(entries), arr, _stream()))
+
+
+def unpack_add_multi(entries):
+    """entries: [(src packed fp32 [A][C][B], dst fp32 [A][B][C], A, B, C)]: dst += unpacked src, one launch."""
+    arr = (_lib.PackEntry * len(entries))()
+    for i, (src, dst, A, Bd, Cd) in enumerate(entries):
+        _need_cuda(src, dst)
+        arr[i] = _lib.PackEntry(_p(src), _p(dst), A, Bd, Cd, PACK_PERMUTE)
+    check(_lib.load().focal_unpack_add_multi(len(entries), arr, _stream()))
+
+
 def conv_desc(dtype_code, rows, S, C_in, C_out, k):
     return ConvDesc(dtype_code, rows, S, C_in, C_out, k)
 

@@ -125,6 +125,12 @@ class DeepSense(HipBackbone):
         # encoder has left its convolution stack (the last BatchNorm), see deepsense_engine.forward.
         # (view_index: FOCAL.forward numbers its two backbone calls 0 / 1; any other caller runs one stream per modality)
         view_streams = view_index is not None and os.environ.get("FOCAL_DS_VIEW_STREAMS", "1") != "0" and self.training
+        if view_index in (None, 0):
+            for enc in self._encoders.values():
+                if os.environ.get("FOCAL_DS_PACK_ONCE", "1") != "0":
+                    enc.prepare_packs()  # re-ordered weights for both views' passes: one launch per encoder, before the streams fork
+                else:
+                    enc._packs = None
         point = runtime.fork_point(dev)  # every encoder starts from here: none waits for the one launched before it
         late = os.environ.get("FOCAL_FORK_LATE") == "1"
         for mi, mod in enumerate(self.modalities):

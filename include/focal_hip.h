@@ -240,6 +240,14 @@ typedef struct { int dtype; int rows, S, C_in, C_out, k; } focal_conv_desc;
 int focal_permute_pack(int A, int Bd, int Cd, const float* src, void* dst, int dtype, void* stream);      /* dst[a][c][b] = src[a][b][c] */
 int focal_permute_unpack_add(int A, int Bd, int Cd, const float* src, float* dst, void* stream);          /* dst[a][b][c] += src[a][c][b] */
 int focal_conv_pack_bwd(const focal_conv_desc* d, const float* w, void* w_bwd, void* stream);
+/* Several re-orderings in one launch (an encoder's 13 per pass): kind FOCAL_PACK_PERMUTE = focal_permute_pack's dst[a][c][b] = src[a][b][c]
+ * (A, B, C as there), FOCAL_PACK_CONV_BWD = focal_conv_pack_bwd's dst[ci][t][co] = src[co][ci][k-1-t] with (A, B, C) = (C_out, C_in, k);
+ * src fp32, dst `dtype`.  focal_unpack_add_multi: dst[a][b][c] += src[a][c][b] per entry (fp32; focal_permute_unpack_add). */
+enum { FOCAL_PACK_PERMUTE = 0, FOCAL_PACK_CONV_BWD = 1 };
+#define FOCAL_PACK_MAX 16
+typedef struct { const void* src; void* dst; int A, B, C; int kind; } focal_pack_entry;
+int focal_pack_multi(int dtype, int n, const focal_pack_entry* entries, void* stream);
+int focal_unpack_add_multi(int n, const focal_pack_entry* entries, void* stream);
 int focal_conv_fwd(const focal_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* z, void* stream);
 int focal_conv_bwd_data(const focal_conv_desc* d, const void* dz, const void* w_bwd, const float* g_in, float* g_out, void* stream);
 int focal_conv_bwd_weight(const focal_conv_desc* d, const void* dz, const void* x, float* dw_packed, float* dbias, void* stream);
