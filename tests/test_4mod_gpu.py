@@ -59,3 +59,52 @@ def test_four_modality_step(ct):
         assert not bad, bad[:6]
     else:
         assert len(bad) <= max(1, len(fx["train.grad_names"]) * 3 // 100), bad[:6]
+
+
+@pytest.mark.parametrize("ct", ["fp32", "bf16"])
+def test_four_modality_full_batch_equals_small_batches(ct):
+    """BASELINE configs[4] at its per-GPU size (B = 256 windows; the reference fixture pins B = 8): SW_Transformer has no batch
+    statistics, so (1) rows of the B = 256 forward equal the B = 8 forward of the same windows, and (2) the gradient of a sum of
+    per-window terms is additive over batch chunks -- the four encoders' split-K / atomic / grouped weight-gradient launches at full
+    size against themselves at half size (dropout off; the same check test_swt_parity_gpu.py makes on MOD)."""
+    import argparse
+
+    from models.SW_Transformer import SW_Transformer
+    from oracle.config import load_config
+    from oracle.weights import fill_state_dict_
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cfg = no_dropout(load_config(os.path.join(root, "focal_amd", "src", "data", "HAR4.yaml")))
+    args = argparse.Namespace(model="SW_Transformer", dataset="HAR4", device=torch.device("cuda"), train_mode="contrastive",
+                              learn_framework="FOCAL", stage="pretrain", task="activity_classification", tag=None,
+                              dataset_config=cfg, compute_dtype=ct)
+    net = SW_Transformer(args)
+    fill_state_dict_(net.state_dict())
+    net = net.to("cuda").train()
+    B = 256
+    g = torch.Generator().manual_seed(7)
+    loc = cfg["location_names"][0]
+    x = {loc: {m: torch.randn(B, cfg["loc_mod_in_freq_channels"][loc][m], cfg["num_segments"], cfg["loc_mod_spectrum_len"][loc][m], generator=g).cuda()
+               for m in cfg["modality_names"]}}
+    sub = lambda lo, hi: {loc: {m: v[lo:hi] for m, v in x[loc].items()}}
+    r = {m: torch.randn(B, cfg["FOCAL"]["emb_dim"], generator=g).cuda() for m in cfg["modality_names"]}
+
+    def grads(lo, hi):
+        net.arena().zero_grad()
+        out = net(sub(lo, hi), class_head=False, proj_head=True)
+        sum((out[m] * r[m][lo:hi]).sum() for m in out).backward()
+        torch.cuda.synchronize()
+        return {m: out[m].detach().clone() for m in out}, net.arena().grad.clone()
+
+    from conftest import record_observed
+    full, gfull = grads(0, B)
+    small, _ = grads(40, 48)
+    for m in full:
+        a, b_ = full[m][40:48], small[m]
+        e = (a - b_).abs().max().item() / max(1.0, b_.abs().max().item())
+        record_observed(f"swt4mod.b256_vs_b8.emb.{m}.{ct}", e)
+        assert e <= (1e-5 if ct == "fp32" else 1e-2), (m, e)
+    _, g1 = grads(0, B // 2)
+    _, g2 = grads(B // 2, B)
+    err = (gfull - (g1 + g2)).abs().max().item() / gfull.abs().max().item()
+    record_observed(f"swt4mod.b256_grad_additivity.{ct}", err)
+    assert err < (1e-5 if ct == "fp32" else 2e-3), err

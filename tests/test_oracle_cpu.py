@@ -61,6 +61,27 @@ def test_oracle_eval_embeddings_match_reference(cfg, model):
         assert abs(v.double().norm().item() - n[0]) < 1e-4 * max(n[0], 1e-6), k
 
 
+def test_oracle_deepsense_eval_with_settled_statistics(cfg):
+    """The oracle on the reference's own settled running statistics (tests/golden/gen_golden_deepsense_settled.py)."""
+    from oracle import weights as ow
+    from oracle.deepsense import deepsense_forward
+    from conftest import no_dropout
+    fx = np.load(os.path.join(GOLD, "DeepSense_settled_b8.npz"))
+    c = no_dropout(cfg)
+    st = _state("DeepSense", c)
+    for k in fx.files:
+        if k.startswith("buffer."):
+            st[k[len("buffer."):]] = torch.from_numpy(fx[k])
+    x1 = ow.synthetic_freq_input(c, 8, seed=101)
+    with torch.no_grad():
+        emb = deepsense_forward(st, c, x1, proj_head=True, train=False)
+        feat = deepsense_forward(st, c, x1, proj_head=False, train=False)
+    for m in emb:
+        for got, key in ((emb[m], f"eval.emb.{m}"), (feat[m], f"eval.feat.{m}")):
+            ref = torch.from_numpy(fx[key])
+            assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), key
+
+
 @pytest.mark.parametrize("model", ["SW_Transformer", "DeepSense"])
 def test_oracle_train_step_matches_reference(cfg, model):
     """Loss terms, per-parameter gradient norms and (DeepSense) BatchNorm running statistics of one FOCAL step."""
