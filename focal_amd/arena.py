@@ -67,6 +67,17 @@ class ParamArena:
         src = self.flat if self.shadow is None else self.shadow
         return src[o:o + k].view(shp)
 
+    def spans(self, names):
+        """Maximal contiguous [lo, hi) element ranges of the arena covered by `names` (alignment gaps between neighbours included)."""
+        sel = sorted((self.index[n][0], self.index[n][0] + (self.index[n][1] + ALIGN - 1) // ALIGN * ALIGN) for n in names)
+        out = []
+        for lo, hi in sel:
+            if out and lo <= out[-1][1]:
+                out[-1][1] = max(out[-1][1], hi)
+            else:
+                out.append([lo, hi])
+        return [(lo, min(hi, self.size)) for lo, hi in out]
+
     def owns(self, p):
         return getattr(p, "_focal_arena", None) is self and p.data_ptr() >= self.flat.data_ptr() and \
             p.data_ptr() < self.flat.data_ptr() + self.flat.numel() * 4

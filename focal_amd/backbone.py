@@ -41,6 +41,10 @@ class HipBackbone(nn.Module):
         self._arena = None
         self._named = None
         self._fwd_calls = 0
+        # data parallel: encoders stop their backward pass where most gradient bytes are final (focal_amd/graph_step.py issues the first
+        # all-reduce bucket there) and park the rest here for backward_continue()
+        self.split_backward = False
+        self.pending_backward = []
         self.register_load_state_dict_post_hook(lambda module, keys: module._after_load())
 
     def _after_load(self):
@@ -58,6 +62,35 @@ class HipBackbone(nn.Module):
         if self._named is None:
             self._named = dict(self.named_parameters())
         return self._named[name]
+
+    def backward_continue(self):
+        """The parked second halves of the encoders' backward passes (split_backward), each on the stream its first half ran on,
+        all started from one fork point and joined back before returning."""
+        pend, self.pending_backward = self.pending_backward, []
+        if not pend:
+            return
+        dev = pend[0][2].device
+        cur = torch.cuda.current_stream(dev)
+        point = runtime.fork_point(dev)
+        with torch.no_grad():
+            for engine, saved, st in pend:
+                if st != cur:
+                    st.wait_event(point)
+                with torch.cuda.stream(st):
+                    engine.backward_rest(saved)
+        runtime.join_all(dev)
+
+    def final_after_first_phase(self):
+        """Names of the arena parameters whose gradients are final when the first phase of a split backward pass ends: everything but
+        the encoder stages in front of the last one (their blocks and the PatchMerging that follows them)."""
+        import re
+        ar = self.arena()
+        stage_of = {n: re.match(r"(freq_interval_layers\.[^.]+\.[^.]+)\.(\d+)\.", n) for n in ar.index}
+        last = {}
+        for m in stage_of.values():
+            if m:
+                last[m.group(1)] = max(last.get(m.group(1), 0), int(m.group(2)))
+        return [n for n, m in stage_of.items() if m is None or int(m.group(2)) == last[m.group(1)]]
 
     def rng_state(self):
         return runtime.rng_state(next(self.parameters()).device)

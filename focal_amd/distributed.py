@@ -157,6 +157,20 @@ def shard_loss_head():
     return world() >= 6
 
 
+def all_reduce_spans_async(arena, spans):
+    """SUM-reduce [lo, hi) ranges of the gradient arena without holding the caller's stream: the collective waits for what that
+    stream has enqueued so far and runs on the backend's own stream beside what comes next.  Returns the work handles
+    (wait_all() before anything reads the gradients)."""
+    if not is_dist():
+        return []
+    return [dist.all_reduce(arena.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True) for lo, hi in spans if hi > lo]
+
+
+def wait_all(works):
+    for w in works:
+        w.wait()  # (the caller's stream waits; the host does not block under RCCL)
+
+
 def all_reduce_gradients(arena, bucket_bytes=64 << 20):
     """SUM-reduce the arena's gradient buffer in place.  xGMI is point-to-point (7 links/GPU): a few large buckets
     keep every link busy; 46 MB (SW_Transformer fp32) is a single bucket."""

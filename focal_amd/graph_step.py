@@ -7,6 +7,8 @@ AdamW] cut where the data-parallel collectives sit:
     A : zero_grad, views, both backbone passes, pack the embeddings       -> [all-gather of the embeddings]
     B : loss head on the global batch, backward                            -> [all-reduce of the gradient arena]
     C : AdamW, loss value
+    (SW_Transformer: the backward pass stops where 88 % of the gradient bytes are final -- the last stage, mod_in and the projectors --
+     and the rest, R, runs beside the all-reduce of that first bucket:  B -> [async all-reduce, bucket 1] -> R -> [all-reduce, bucket 2])
     (with the loss head row-sharded over the ranks B splits once more at the head's one small collective:
      B1 similarity / distance rows, log-sum-exps, hinges  -> [all-gather of ~70 KB chunks] ->  B2 coefficients, dL/dz, backward)
 
@@ -34,6 +36,39 @@ class StepSegments:
         self.dist = distributed
         self.loss = torch.zeros((), device=device)
         self.feats = None
+        self._buckets = False  # decided at the first data-parallel step (the arena exists by then)
+
+    def buckets(self):
+        """(arena, [spans final after the first backward phase], [the other spans]) or None: one blocking all-reduce after backward."""
+        if self._buckets is False:
+            self._buckets = None
+            if self.dist.is_dist() and os.environ.get("FOCAL_NO_SPLIT_BACKWARD") != "1":
+                self._buckets = self.opt.reduce_buckets(self.model)
+        return self._buckets
+
+    def _backward(self, loss):
+        bb = getattr(self.model, "backbone", None)
+        split = self.buckets() is not None and bb is not None
+        if split:
+            bb.split_backward = True
+        try:
+            loss.backward()
+        finally:
+            if split:
+                bb.split_backward = False
+
+    def seg_rest(self):
+        """The parked part of a split backward pass (the encoder stages in front of the last one)."""
+        self.model.backbone.backward_continue()
+
+    def reduce_first(self):
+        ar, first, _ = self.buckets()
+        self.opt.reduce_async(ar, first)
+
+    def reduce_second(self):
+        ar, _, rest = self.buckets()
+        self.opt.reduce_async(ar, rest)
+        self.opt.wait_reductions()
 
     def seg_a(self):
         self.opt.zero_grad()
@@ -50,7 +85,7 @@ class StepSegments:
         if self.dist.is_dist():
             self.feats = self.dist.unpack_gathered(self.gathered, self.keys, 2)
         loss = self.loss_fn(*self.feats)
-        loss.backward()
+        self._backward(loss)
         self.loss.copy_(loss.detach())
         self.feats = None
 
@@ -63,12 +98,19 @@ class StepSegments:
 
     def seg_b2(self):
         loss = self.loss_fn.finish()
-        loss.backward()
+        self._backward(loss)
         self.loss.copy_(loss.detach())
         self.feats = None
 
     def reduce(self):
-        self.opt.reduce_gradients()
+        """Everything between the backward segment and AdamW: one blocking all-reduce, or (split backward pass) the first bucket's
+        all-reduce started, the rest of backward run beside it, then the second bucket."""
+        if self.buckets() is None:
+            self.opt.reduce_gradients()
+            return
+        self.reduce_first()
+        self.seg_rest()
+        self.reduce_second()
 
     def seg_c(self):
         self.opt.step(reduce=False)
@@ -124,17 +166,25 @@ class StepSegments:
                     head, gb2 = None, None
                     with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
                         self.seg_b()
-                self.reduce()
+                gr = None
+                if self.buckets() is None:
+                    self.reduce()
+                else:
+                    self.reduce_first()
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr, pool=ga.pool(), stream=stream, **mode):
+                        self.seg_rest()
+                    self.reduce_second()
                 with torch.cuda.graph(gc, pool=ga.pool(), stream=stream, **mode):
                     self.seg_c()
-                graphs = (ga, gb, gb2, gc)
+                graphs = (ga, gb, gb2, gc, gr)
             pool = graphs[0].pool()
             if attempt == 0:
                 self._warm_graphs = graphs
         self._graphs = graphs
         if not multi:
             return graphs[0].replay
-        ga, gb, gb2, gc = graphs
+        ga, gb, gb2, gc, gr = graphs
         packed = self.packed
 
         def replay():
@@ -144,7 +194,12 @@ class StepSegments:
             if gb2 is not None:
                 self.dist.exchange_loss_chunks(head)  # the persistent send / chunks buffers of the sharded head
                 gb2.replay()
-            self.opt.reduce_gradients()
+            if gr is None:
+                self.opt.reduce_gradients()
+            else:
+                self.reduce_first()   # bucket 1 (last stage, mod_in, projectors) travels ...
+                gr.replay()           # ... while the earlier stages' backward runs
+                self.reduce_second()
             gc.replay()
         return replay
 

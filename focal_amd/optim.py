@@ -73,6 +73,34 @@ class FocalAdamW(torch.optim.Optimizer):
             distributed.all_reduce_gradients(ar)
 
     @torch.no_grad()
+    def reduce_buckets(self, model):
+        """Data parallel, split backward pass (HipBackbone.split_backward): ([spans final after the first phase], [the rest]) per
+        arena, or None when the model's backward cannot be split (DeepSense; supervised stages)."""
+        bb = getattr(model, "backbone", model)
+        if not hasattr(bb, "final_after_first_phase") or not hasattr(bb, "_encoders"):
+            return None
+        if not all(hasattr(e, "backward_rest") for e in bb._encoders.values()):
+            return None
+        arenas = self._arenas()
+        if len(arenas) != 1 or arenas[0] is not bb.arena():
+            return None
+        ar = arenas[0]
+        first = set(bb.final_after_first_phase())
+        rest = [n for n in ar.index if n not in first]
+        if not rest:
+            return None
+        return ar, ar.spans(first), ar.spans(rest)
+
+    @torch.no_grad()
+    def reduce_async(self, ar, spans):
+        runtime.join_all(ar.device)
+        self._works = getattr(self, "_works", []) + distributed.all_reduce_spans_async(ar, spans)
+
+    def wait_reductions(self):
+        distributed.wait_all(getattr(self, "_works", []))
+        self._works = []
+
+    @torch.no_grad()
     def step(self, closure=None, reduce=True):
         """reduce=False: the caller already ran reduce_gradients() (bench.py does, eagerly, between captured graph segments)."""
         arenas = self._arenas()

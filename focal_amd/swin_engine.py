@@ -211,7 +211,11 @@ class SwinModEncoder:
         return feat, saved
 
     def backward(self, saved, dfeat):
-        """Accumulates every parameter gradient of this encoder into the arena; returns nothing (input is a leaf)."""
+        """Accumulates every parameter gradient of this encoder into the arena; returns nothing (input is a leaf).
+
+        Data parallel (bb.split_backward, set by focal_amd/graph_step.py): the pass stops once the LAST stage's blocks are done -- by
+        then the gradients of that stage, of mod_in and of the projector (88 % of the arena's bytes) are final and their all-reduce can
+        start -- and `backward_rest` runs the earlier stages beside that collective."""
         bb, ar = self.bb, self.bb.arena()
         ct = bb.compute_dtype
         dev = dfeat.device
@@ -222,6 +226,32 @@ class SwinModEncoder:
         ops.linear_bwd_weight(d_in_b, dfeat, xf, ar.g(f"{pin}.weight"), ar.g(f"{pin}.bias"))
         g = torch.empty_like(xf)
         ops.linear_bwd_data(d_in_b, dfeat, ar.operand(f"{pin}.weight"), None, g)
+        blocks = saved["blocks"]
+        last = blocks[-1]
+        gm = ops.mask_cast(g.view(last["M"], last["C"]), last["d_fc2"].out_drop, ct)
+        stop = 0
+        if getattr(bb, "split_backward", False) and saved["merges"] and saved.get("embed") is None:
+            stop = max(m["after_block"] for m in saved["merges"])  # first block of the last stage
+        state = dict(g=g, gm=gm, next=len(blocks) - 1)
+        self._backward_blocks(saved, state, stop)
+        if stop > 0:
+            saved["_resume"] = state
+            bb.pending_backward.append((self, saved, torch.cuda.current_stream(dev)))
+            return
+        self._backward_tail(saved, state)
+
+    def backward_rest(self, saved):
+        """The earlier stages of a split backward pass (see backward)."""
+        state = saved.pop("_resume")
+        self._backward_blocks(saved, state, 0)
+        self._backward_tail(saved, state)
+
+    def _backward_blocks(self, saved, state, stop):
+        """Blocks state["next"] .. stop, last first; state carries the residual-stream gradient g and its masked operand copy gm."""
+        bb, ar = self.bb, self.bb.arena()
+        ct = bb.compute_dtype
+        g, gm = state["g"], state["gm"]
+        dev = g.device
         merges = {m["after_block"]: m for m in saved["merges"]}
         blocks = saved["blocks"]
         cc = ops.code(ct)
@@ -238,10 +268,10 @@ class SwinModEncoder:
         # what costs more is that their operands must outlive the block (see _DeferredWeightGrads), so every later temporary lands on
         # memory the Infinity Cache does not hold.  Off by default; kept as the record of the experiment.
         dwq = _DeferredWeightGrads(dev, self.mod_index, enabled=os.environ.get("FOCAL_DW_STREAM", "0") == "1")
-        self._dw_keep, self._dw_stream = dwq.keep, dwq.stream  # released by the next forward pass (behind the optimizer's join of all side streams)
-        last = blocks[-1]
-        gm = ops.mask_cast(g.view(last["M"], last["C"]), last["d_fc2"].out_drop, ct)
-        for k in range(len(blocks) - 1, -1, -1):
+        if dwq.enabled:
+            self._dw_keep, self._dw_stream = (getattr(self, "_dw_keep", None) or []) + dwq.keep, dwq.stream  # released by the next forward pass
+            dwq.keep = self._dw_keep
+        for k in range(state["next"], stop - 1, -1):
             if (k + 1) in merges:  # a PatchMerging sits between block k and block k+1
                 mg = merges[k + 1]
                 pm, d_red = mg["pm"], mg["d_red"]
@@ -314,6 +344,12 @@ class SwinModEncoder:
             # eager callers may read the gradients once autograd has joined THIS stream: fold the side stream in (a captured step's
             # origin stream joins it before the optimizer instead -- see _DeferredWeightGrads for why not here)
             torch.cuda.current_stream(dev).wait_stream(dwq.stream)
+        state.update(g=g, gm=gm, next=stop - 1)
+
+    def _backward_tail(self, saved, state):
+        bb, ar = self.bb, self.bb.arena()
+        ct = bb.compute_dtype
+        g = state["g"]
         # g now holds dL/d(patch-embed tokens).  FOCAL pretraining: the embedding is frozen and its input is a leaf -> stop here.
         es = saved.get("embed")
         if es is not None:  # supervised training: LayerNorm backward, then the convolution's weight / bias gradient
