@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcs_${tag}_$c -o $c -- python3 $root/bench.py --no-graph --no-cpu-baseline --no-roofline --steps $STEPS --warmup $WARM "$@" > /tmp/pmcs_${tag}_$c.log 2>&1
 done
-python3 - "$tag" "$root" $STEPS $WARM <<'PY' | tee $root/gpurun_out/${1}_step_traffic.txt
+python3 - "$tag" "$root" $STEPS $WARM <<'PY' | tee $root/gpurun_out/${tag}_step_traffic.txt
 import csv, glob, sys, collections, re
 tag, root, steps, warm = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 def fam(n):
