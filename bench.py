@@ -621,7 +621,8 @@ def main():
                           "last_loss": round(last_loss, 4),
                           "parity": "this configuration (train mode, dropout / DropPath on) is covered by statistical and finite-difference tests; "
                                     "the same kernels with dropout off are pinned bit-for-tolerance against reference fixtures (tests/golden, DESIGN 1)"},
-               "model_flops_frac_of_bf16_mfma_peak": round(wps / world * flops_per_window(a.model, a.dataset) / (MFMA_BF16_PEAK_TF * 1e12), 5),
+               "model_flops_frac_of_bf16_mfma_peak": (round(wps / world * flops_per_window(a.model, a.dataset) / (MFMA_BF16_PEAK_TF * 1e12), 5)
+                                                       if flops_per_window(a.model, a.dataset) else None),
                "flops_per_window": flops_per_window(a.model, a.dataset),
                "roofline": rl, "cpu_baseline": cb}
         print(json.dumps(out))
