@@ -91,9 +91,10 @@ class SwinModEncoder:
         P = bb.param  # cold parameters (frozen patch embedding) are read where they live
         fuse_ln = os.environ.get("FOCAL_NO_LN_FUSE") != "1"
         fuse_mlp = os.environ.get("FOCAL_NO_MLP_FUSE") != "1"
-        # 128 / 256 channels: the LayerNorm epilogue exists (row-complete wave tiles on the LDS-DMA GEMM) but loses to GEMM + LayerNorm
-        # as two launches in the step (-1 %: at 256 channels the fused fc2 takes 55-61 us against 35 + 11, profiles/r3_ln_wide_ab.txt)
-        fuse_wide = os.environ.get("FOCAL_LN_FUSE_WIDE") == "1"
+        # The LayerNorm epilogue of the residual GEMMs beyond 64 channels (row-complete wave tiles on the LDS-DMA GEMM): on at 128 channels
+        # (+1.1 % on the step, same-box), off at 256, where one row fragment per wave makes the fused fc2 take 55-61 us against 35 + 11
+        # (-1 % with both on; profiles/r3_ln_wide_ab.txt).  FOCAL_LN_FUSE_WIDE = 0 | 128 | 1 (= 128 and 256).
+        fuse_wide_env = os.environ.get("FOCAL_LN_FUSE_WIDE", "128")
         pre_ln = None  # (a1, st1) of the next block when the kernel before it already produced them
         first = f"{self.pre}.0.blocks.0"
         embed_saved = None
@@ -149,6 +150,7 @@ class SwinModEncoder:
                 d_proj = ops.linear_desc(cc, M, Cc, Cc, cc, f32, ACT_NONE, EPI_RESIDUAL,
                                          out_drop=self._drop(rng, view, uid, 0, p_drop, p_path, L))
                 x_mid = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
+                fuse_wide = fuse_wide_env == "1" or fuse_wide_env == str(Cc)
                 if fuse_ln and (Cc == 64 or fuse_wide) and ops.resid_ln_supported(cc, Cc, Cc):
                     a2, st2 = ops.linear_resid_ln_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"),
                                                       x, x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
