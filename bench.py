@@ -292,7 +292,7 @@ class StepTracer:
                     kern = f"{lib.focal_last_kernel().decode()} ({name})"
                 return (kern, "all launches of the kernel", _tensor_bytes(args, kw), flops, "hbm", shp)
             return describe
-        GEMM_OPS = {"linear_fwd", "linear_bwd_data", "linear_resid_ln_fwd", "conv_fwd", "conv_bwd_data", "conv_bwd_weight"}
+        GEMM_OPS = {"linear_fwd", "linear_bwd_data", "linear_bwd_data_ln", "linear_resid_ln_fwd", "conv_fwd", "conv_bwd_data", "conv_bwd_weight"}
         special = {"linear_bwd_weight": dw, "linear_bwd_weight_group": dwg, "layernorm_bwd": lnb, "mlp_bwd": mlpb}
         for name in dir(ops):
             fn = getattr(ops, name)

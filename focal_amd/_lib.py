@@ -114,6 +114,8 @@ PROTOTYPES = {
     "focal_linear_resid_ln_fwd": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P, P, C.c_float, P, P, P]),
     "focal_linear_resid_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_linear_bwd_data": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
+    "focal_linear_bwd_data_ln": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P]),
+    "focal_linear_bwd_data_ln_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_linear_bwd_weight": (C.c_int, [C.POINTER(LinearDesc), P, P, P, P, P]),
     "focal_linear_bwd_weight_workgroups": (C.c_int, [C.POINTER(LinearDesc)]),
     "focal_linear_bwd_weight_kernel": (C.c_int, [C.POINTER(LinearDesc)]),

@@ -15,7 +15,9 @@
 
 enum GemmPro { PRO_NONE = 0, PRO_GELU = 1, PRO_MASK = 2, PRO_CONV = 3 };
 enum GemmEpi { EPI_STORE = 0, EPI_RESID = 1, EPI_MUL_AUX = 2, EPI_RELU = 3, EPI_RELU_BWD = 4, EPI_ATOMIC = 5, EPI_GELU_FWD = 6,
-               EPI_RESID_LN = 7 };  // EPI_RESID, then LayerNorm of the finished row (N == 64 == one wave's tile width): y_ln, statistics
+               EPI_RESID_LN = 7,    // EPI_RESID, then LayerNorm of the finished row (N == 64 == one wave's tile width): y_ln, statistics
+               EPI_LN_BWD = 8 };    // the product IS the gradient w.r.t. a LayerNorm's output: finish that LayerNorm's backward on the row
+                                    // (gemm_pipe.hpp, row-complete wave tiles): C (fp32) += dx, aux_out = dtype(C * mask), dgamma / dbeta
 
 struct MaskParams {
   const uint32_t* seed;  // device word (null -> seed 0)
@@ -42,6 +44,8 @@ struct GemmParams {
   float* colsumA;                 // f32 [M] (+=): sum_r proA(A)[m][r]; only with transposed A (bias gradient)
   // EPI_RESID_LN: the next LayerNorm, applied to the finished residual row (aux_out = its CT output [M][N], ldc)
   const float* ln_gamma; const float* ln_beta; float* ln_stats; float ln_eps;  // stats f32 [M][2] = {mean, rstd}
+  // EPI_LN_BWD: resid = the LayerNorm's input x (fp32 [M][N], ldr), ln_stats read, ln_gamma; column sums of dy * xhat / dy are added here
+  float* ln_dgamma; float* ln_dbeta;
 };
 
 struct MaskEval {

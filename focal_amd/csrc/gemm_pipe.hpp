@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
   constexpr int LPW = ROWS / (8 * NW);         // LDS-DMA pieces (8 rows each) per wave per stage
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "a piece index must be an A piece or a W piece for all waves");
   constexpr int WPITCH = WC + 4;
-  constexpr int EPI_BYTES = NW * 16 * WPITCH * 4;
+  constexpr int EPI_BYTES = NW * 16 * WPITCH * 4 + (EPI == EPI_LN_BWD ? NW * 2 * WC * 4 : 0);
   constexpr int LDS_BYTES = NST * STAGE_BYTES > EPI_BYTES ? NST * STAGE_BYTES : EPI_BYTES;
   extern __shared__ __attribute__((aligned(1024))) char pipe_lds[];
   static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit in LDS");
@@ -212,8 +212,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
   // ---- epilogue: transpose 16 rows at a time through a wave-private LDS region, then walk it row-major (16 B per lane)
   float* est = reinterpret_cast<float*>(pipe_lds) + wave * 16 * WPITCH;
   MaskEval meE;
-  if (EPI == EPI_RESID || EPI == EPI_GELU_FWD || EPI == EPI_RESID_LN) meE.init(p.epi);
-  static_assert(EPI != EPI_RESID_LN || (WGN == 1 && sizeof(TC) == 4), "the LayerNorm epilogue needs row-complete wave tiles and an fp32 residual stream");
+  if (EPI == EPI_RESID || EPI == EPI_GELU_FWD || EPI == EPI_RESID_LN || EPI == EPI_LN_BWD) meE.init(p.epi);
+  static_assert((EPI != EPI_RESID_LN && EPI != EPI_LN_BWD) || (WGN == 1 && sizeof(TC) == 4), "the LayerNorm epilogues need row-complete wave tiles and an fp32 residual stream");
+  float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};  // EPI_LN_BWD: this lane's column partials of dy * xhat, dy
+  float lng[4] = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == EPI_LN_BWD) loadN<4>(p.ln_gamma + (n0 + wn * WC + (lane % (WC / 4)) * 4), lng);
   constexpr int CPL = (sizeof(TC) == 2) ? 8 : 4;
   constexpr int LPR = WC / CPL, RPI = 64 / LPR;
   const int c = (lane % LPR) * CPL, n = n0 + wn * WC + c;
@@ -228,12 +231,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
     // LDS traffic between its iterations -- staging reads, cross-lane sums -- and hipcc will not move a global load above those: left
     // inside the loop each row exposed a full memory latency, 16 in a row at 256 channels).  Rows past M re-read the last row.
     constexpr int NIT = 16 / RPI;
-    float rpre[EPI == EPI_RESID_LN ? NIT : 1][CPL];
-    if (EPI == EPI_RESID_LN) {
+    float rpre[(EPI == EPI_RESID_LN || EPI == EPI_LN_BWD) ? NIT : 1][CPL];
+    float gpre[EPI == EPI_LN_BWD ? NIT : 1][CPL];
+    float2 spre[EPI == EPI_LN_BWD ? NIT : 1];
+    if (EPI == EPI_RESID_LN || EPI == EPI_LN_BWD) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int mm = min(mbase + it * RPI + lane / LPR, p.M - 1);
         loadN<CPL>(p.resid + (long)mm * p.ldr + n, rpre[it]);
+        if (EPI == EPI_LN_BWD) {  // the LayerNorm's input row (resid), the residual-stream gradient it is added to, the row's statistics
+          loadN<CPL>(reinterpret_cast<const float*>(C) + (long)mm * p.ldc + n, gpre[it]);
+          spre[it] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mm);
+        }
       }
     }
 #pragma unroll
@@ -288,6 +297,38 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
         for (int e = 0; e < CPL; ++e) yq[e] = (v[e] - mean) * rstd * gq[e] + bt[e];
         storeN<CPL>(reinterpret_cast<bf16_t*>(p.aux_out) + (long)m * p.ldc + n, yq);
         if ((lane % LPR) == 0) *reinterpret_cast<float2*>(p.ln_stats + 2 * (long)m) = make_float2(mean, rstd);
+      } else if (EPI == EPI_LN_BWD) {
+        // v = dy of the LayerNorm (this GEMM's product, fp32 -- never written): dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;
+        // the residual-stream gradient row gets += dx and leaves a second time as dtype(row * mask) for the next branch's GEMMs
+        constexpr int IT = (EPI == EPI_LN_BWD) ? 1 : 0;
+        const int it = IT * (rr / RPI);
+        const float mean = spre[it].x, rstd = spre[it].y;
+        float xh[CPL], gd[CPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+          xh[e] = (rpre[it][e] - mean) * rstd;
+          gd[e] = v[e] * lng[e];
+          s1 += gd[e];
+          s2 += gd[e] * xh[e];
+          pg[e] += v[e] * xh[e];
+          pb[e] += v[e];
+        }
+        s1 = row16_sum(s1); s2 = row16_sum(s2);
+        if (LPR >= 32) { s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); }
+        if (LPR >= 64) { s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); }
+        const float m1 = s1 * (1.0f / WC), m2 = s2 * (1.0f / WC);
+        float o[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) o[e] = gpre[it][e] + rstd * (gd[e] - m1 - xh[e] * m2);
+        storeN<CPL>(dst, o);
+        if (p.aux_out) {
+          const float rowm = meE.row_mult(m);
+          float om[CPL];
+#pragma unroll
+          for (int e = 0; e < CPL; ++e) om[e] = o[e] * rowm * meE.elem_mult(m, n + e);
+          storeN<CPL>(reinterpret_cast<bf16_t*>(p.aux_out) + (long)m * p.ldc + n, om);
+        }
       } else if (EPI == EPI_MUL_AUX) {
         float a[CPL];
         loadN<CPL>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n, a);
@@ -309,6 +350,29 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
         storeN<CPL>(dst, v);
         storeN<CPL>(reinterpret_cast<TC*>(p.aux_out) + (long)m * p.ldc + n, gq);
       }
+    }
+  }
+  if (EPI == EPI_LN_BWD) {
+    // dgamma / dbeta: the lanes of a wave that share columns fold by shuffles, one [2][WC] row per wave goes to LDS behind the staging
+    // regions, the waves are summed and every column leaves as ONE atomic per workgroup
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      for (int o = LPR; o < 64; o <<= 1) {
+        pg[e] += __shfl_xor(pg[e], o, 64);
+        pb[e] += __shfl_xor(pb[e], o, 64);
+      }
+    }
+    float* red = reinterpret_cast<float*>(pipe_lds) + NW * 16 * WPITCH;
+    if (lane < LPR) {
+      *reinterpret_cast<float4*>(red + wave * 2 * WC + c) = make_float4(pg[0], pg[1], pg[2], pg[3]);
+      *reinterpret_cast<float4*>(red + wave * 2 * WC + WC + c) = make_float4(pb[0], pb[1], pb[2], pb[3]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * WC; i += 64 * NW) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a += red[w * 2 * WC + i];
+      atomicAdd(i < WC ? p.ln_dgamma + n0 + i : p.ln_dbeta + n0 + (i - WC), a);
     }
   }
 }

@@ -131,6 +131,52 @@ extern "C" int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy,
   return focal_launch_gemm(s, p, (hipStream_t)stream);
 }
 
+extern "C" int focal_linear_bwd_data_ln_supported(int dtype, int N, int K) {
+  // K = the LayerNorm's width (the linear layer's input features), N = its output features (the contraction of the dX product)
+  return dtype == FOCAL_BF16 && (K == 64 || K == 128) && N % 64 == 0 && N >= 64;
+}
+
+// dx of a linear layer whose input came out of a LayerNorm, and that LayerNorm's backward, in one kernel: the [M, K] product dy . w never
+// reaches memory -- the GEMM's epilogue (row-complete wave tiles, gemm_pipe.hpp EPI_LN_BWD) turns each finished row into the LayerNorm's
+// input gradient, adds it to the residual-stream gradient g, writes dtype(g * mask) for the next branch and accumulates dgamma / dbeta.
+extern "C" int focal_linear_bwd_data_ln(const focal_linear_desc* d, const void* dy, const void* w, const float* ln_x, const float* ln_stats,
+                                        const float* ln_gamma, float* g, float* dgamma, float* dbeta, void* g_masked,
+                                        const focal_drop_desc* mask, void* stream) {
+  if (int rc = check_desc(d)) return rc;
+  FOCAL_CHECK_ARG(dy && w && ln_x && ln_stats && ln_gamma && g && dgamma && dbeta, "linear_bwd_data_ln: null tensor");
+  FOCAL_CHECK_ARG(focal_linear_bwd_data_ln_supported(d->dtype, d->N, d->K) && d->x_dtype == d->dtype && d->y_dtype == d->dtype &&
+                  d->epilogue != FOCAL_EPI_RESIDUAL && d->act_in == FOCAL_ACT_NONE,  // (a GELU epilogue's derivative is already in dy)
+                  "linear_bwd_data_ln: bf16 layers with 64 / 128 input features, plain `dtype` dy (N = %d, K = %d)", d->N, d->K);
+  FOCAL_CHECK_ARG(((uintptr_t)dy % 16 == 0) && ((uintptr_t)w % 16 == 0), "linear_bwd_data_ln: operands must be 16-byte aligned");
+  FOCAL_CHECK_ARG(!mask || g_masked, "linear_bwd_data_ln: mask without g_masked");
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->M; p.N = d->K; p.K = d->N;
+  p.A = dy; p.lda = d->N;
+  p.B = w; p.ldb = d->K;
+  p.C = g; p.ldc = d->K;
+  p.batch = 1; p.splits = 1; p.alpha = 1.f;
+  p.resid = ln_x; p.ldr = d->K;
+  p.ln_stats = const_cast<float*>(ln_stats);
+  p.ln_gamma = ln_gamma;
+  p.ln_dgamma = dgamma; p.ln_dbeta = dbeta;
+  p.aux_out = g_masked;
+  p.proA = no_mask();
+  p.proB = no_mask();
+  focal_drop_desc dd;
+  memset(&dd, 0, sizeof(dd));
+  if (mask) dd = *mask;
+  p.epi = to_mask(dd, d->K);
+  focal_note_kernel("focal_gemm_pipe_kernel<f32, epi=%d (LayerNorm backward), trB=1, 128x%d, 4x1 waves>", EPI_LN_BWD, d->K);
+  hipError_t e = d->K == 64 ? focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 128, 64, 2, 4, 1>(p, (hipStream_t)stream)
+                            : focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 128, 128, 2, 4, 1>(p, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    focal_set_error("linear_bwd_data_ln: launch failed: %s", hipGetErrorString(e));
+    return FOCAL_EHIP;
+  }
+  return FOCAL_OK;
+}
+
 extern "C" int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const void* x, float* dw, float* dbias,
                                        void* stream) {
   if (int rc = check_desc(d)) return rc;

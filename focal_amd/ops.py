@@ -295,6 +295,20 @@ def linear_bwd_data(d, dy, w, x, dx):
     check(_lib.load().focal_linear_bwd_data(C.byref(d), _p(dy), _p(w), _p(x), _p(dx), _stream()))
 
 
+def bwd_data_ln_supported(dtype_code, N, K):
+    return bool(_lib.load().focal_linear_bwd_data_ln_supported(dtype_code, N, K))
+
+
+def linear_bwd_data_ln(d, dy, w, ln_x, ln_stats, ln_gamma, g, dgamma, dbeta, g_masked=None, mask=None):
+    """dX of the linear layer `d` and the backward of the LayerNorm that produced its input, in one kernel: g += dLN(dy . w); dgamma / dbeta
+    accumulate; g_masked (dy.dtype) <- g * mask for the residual branch that consumes g next (mask=None: a plain cast)."""
+    _need_cuda(dy, w, ln_x, ln_stats, ln_gamma, g, dgamma, dbeta, g_masked)
+    if g_masked is not None:
+        mask = mask or NO_DROP
+    check(_lib.load().focal_linear_bwd_data_ln(C.byref(d), _p(dy), _p(w), _p(ln_x), _p(ln_stats), _p(ln_gamma), _p(g), _p(dgamma), _p(dbeta),
+                                               _p(g_masked), C.byref(mask) if mask is not None else None, _stream()))
+
+
 def linear_bwd_weight(d, dy, x, dw, dbias):
     check(_lib.load().focal_linear_bwd_weight(C.byref(d), _p(dy), _p(x), _p(dw), _p(dbias), _stream()))
 

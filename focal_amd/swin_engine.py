@@ -261,6 +261,8 @@ class SwinModEncoder:
         # next, written once by whichever kernel completes g (LayerNorm backward, or mask_cast for the first one); the
         # branch's dX / dW GEMMs then run as plain `ct` kernels instead of regenerating the mask per column tile.
         group_dw = os.environ.get("FOCAL_NO_DW_GROUP") != "1"
+        # LayerNorm backward as the epilogue of the dX GEMM in front of it (64 / 128 channels, bf16): focal_linear_bwd_data_ln
+        fuse_ln_bwd = os.environ.get("FOCAL_NO_LN_BWD_FUSE") != "1" and ct == torch.bfloat16
         # one pass per step over this encoder's weights (both views in one batch): a gradient tile has a single writer per launch
         exclusive_dw = bool(getattr(bb, "views_share_pass", False))
         # Nothing in the backward pass waits for a weight gradient (only the optimizer does), so a block's weight-gradient launches
@@ -305,6 +307,7 @@ class SwinModEncoder:
             # ---- MLP branch: x_out = x_mid + mask * (h W2^T + b2), h = drop(gelu(a2 W1^T + b1))
             dc = torch.empty_like(s["a2"])
             du = None
+            ln2_done = False
             if s.get("d_mlp") is not None:  # fused branch: h and h' recomputed from a2, all four parameter gradients from one pass
                 ops.mlp_bwd(s["d_mlp"], gm, s["a2"], ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
                             ar.operand(f"{pb}.mlp.fc2.weight"), dc, ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"),
@@ -315,11 +318,18 @@ class SwinModEncoder:
                 du = torch.empty_like(s["h"])
                 ops.linear_bwd_data(d_fc2_b, gm, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
                 weight_grad(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
-                ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
+                if fuse_ln_bwd and ops.bwd_data_ln_supported(cc, 4 * Cc, Cc):
+                    ln2_done = True  # dX of fc1 and norm2's backward in one kernel (below)
+                else:
+                    ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
             # (the MLP branch's gm is still an operand of a pending weight gradient unless the fused branch has consumed it)
             gm_attn = torch.empty_like(gm) if (s.get("d_mlp") is None and (grouped or dwq.enabled)) else gm
-            ops.layernorm_bwd(dc, s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g, True,
-                              ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), dx_masked=gm_attn, mask=s["d_proj"].out_drop)
+            if ln2_done:
+                ops.linear_bwd_data_ln(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g,
+                                       ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), g_masked=gm_attn, mask=s["d_proj"].out_drop)
+            else:
+                ops.layernorm_bwd(dc, s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g, True,
+                                  ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), dx_masked=gm_attn, mask=s["d_proj"].out_drop)
             # ---- attention branch: x_mid = x + mask * (o Wp^T + bp)
             d_proj_b = ops.linear_desc(cc, M, Cc, Cc, cc, cc)
             weight_grad(d_proj_b, gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
@@ -330,16 +340,23 @@ class SwinModEncoder:
                                 ar.g(f"{pb}.attn.relative_position_bias_table"))
             weight_grad(s["d_qkv"], dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias"))
             da = do
-            ops.linear_bwd_data(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), None, da)
+            ln1_fused = fuse_ln_bwd and ops.bwd_data_ln_supported(cc, 3 * Cc, Cc)
+            if not ln1_fused:
+                ops.linear_bwd_data(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), None, da)
             deferred = dwq.submit(cc, dw_items, dw_calls, exclusive_dw)
-            del dqkv, du
+            du = None
             # the next consumer of g: block k-1's MLP branch, unless a PatchMerging (handled above) or the embedding comes first
             nxt = blocks[k - 1]["d_fc2"].out_drop if (k > 0 and k not in merges) else None
             if deferred and nxt is not None:
                 gm = torch.empty_like(gm)  # the old buffers are operands of the weight gradients now running beside this stream
-            ops.layernorm_bwd(da, s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g, True,
-                              ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"),
-                              dx_masked=gm if nxt is not None else None, mask=nxt)
+            if ln1_fused:  # dX of qkv and norm1's backward in one kernel
+                ops.linear_bwd_data_ln(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g,
+                                       ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"), g_masked=gm if nxt is not None else None, mask=nxt)
+            else:
+                ops.layernorm_bwd(da, s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g, True,
+                                  ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"),
+                                  dx_masked=gm if nxt is not None else None, mask=nxt)
+            del dqkv
             blocks[k] = None  # free this block's activations as we go
             dw_items = dw_calls = weight_grad = None
         if dwq.enabled and not torch.cuda.is_current_stream_capturing():

@@ -157,6 +157,14 @@ int focal_linear_resid_ln_fwd(const focal_linear_desc* d, const void* x, const v
 int focal_linear_resid_ln_supported(int dtype, int N, int K);
 int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy, const void* w, const void* x, void* dx,
                           void* stream);
+/* focal_linear_bwd_data for a layer whose input x came out of a LayerNorm (qkv after norm1, fc1 after norm2: SwinModules.py:253,258)
+ * TOGETHER with that LayerNorm's backward (focal_layernorm_bwd with accumulate_dx = 1): g (fp32 [M, K], the residual-stream gradient) +=
+ * dLN(dy . w; ln_x, ln_stats, ln_gamma); dgamma / dbeta += ...; g_masked (optional, `dtype`) = dtype(g * mask).  The [M, K] product never
+ * reaches memory.  bf16, K = 64 or 128 (focal_linear_bwd_data_ln_supported); d describes the LINEAR layer (plain `dtype` x / y). */
+int focal_linear_bwd_data_ln(const focal_linear_desc* d, const void* dy, const void* w, const float* ln_x, const float* ln_stats,
+                             const float* ln_gamma, float* g, float* dgamma, float* dbeta, void* g_masked, const focal_drop_desc* mask,
+                             void* stream);
+int focal_linear_bwd_data_ln_supported(int dtype, int N, int K);
 int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const void* x, float* dw, float* dbias,
                             void* stream);
 /* Number of workgroups focal_linear_bwd_weight launches for this descriptor (output tiles x token splits): lets a caller match its

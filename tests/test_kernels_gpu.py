@@ -148,6 +148,50 @@ def test_linear_resid_ln_wide(ops, M, N, K):
     assert rel_err(y_ln.float(), F.layer_norm(t, (N,), gamma, beta, 1e-5)) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K,drop", [(2304, 192, 64, False), (2304, 384, 128, True), (1000, 512, 128, True), (64, 256, 64, False), (9216, 384, 128, False),
+                                         (4672, 192, 64, True)])
+def test_linear_bwd_data_ln(ops, M, N, K, drop):
+    """focal_linear_bwd_data_ln = focal_linear_bwd_data followed by focal_layernorm_bwd (accumulating into g, with the masked operand copy
+    for the next branch): the LayerNorm backward as the epilogue of the dX GEMM (row-complete wave tiles), ragged M, with / without a mask."""
+    ct = torch.bfloat16
+    c = ops.code(ct)
+    assert ops.bwd_data_ln_supported(c, N, K)
+    dy, w = rnd(M, N, seed=51, dtype=ct), rnd(N, K, scale=N ** -0.5, seed=52, dtype=ct)
+    x = rnd(M, K, seed=53) * 1.5 + 0.2
+    gamma, beta = rnd(K, seed=54) * 0.1 + 1.0, rnd(K, seed=55) * 0.1
+    g0 = rnd(M, K, seed=56)
+    _, stats = ops.layernorm_fwd(x, gamma, beta, ct)
+    rng = ops.new_rng_state(1234, DEV)
+    mask = ops.drop_desc(rng, 5, 0.2, 9, 0.1, 576) if drop else None
+    d = ops.linear_desc(c, M, N, K, c, c)
+    # reference: the two kernels
+    da = torch.empty(M, K, dtype=ct, device=DEV)
+    ops.linear_bwd_data(d, dy, w, None, da)
+    g_ref, gm_ref = g0.clone(), torch.empty(M, K, dtype=ct, device=DEV)
+    dg_ref, db_ref = torch.full((K,), 0.5, device=DEV), torch.full((K,), -0.5, device=DEV)
+    ops.layernorm_bwd(da, x, stats, gamma, g_ref, True, dg_ref, db_ref, dx_masked=gm_ref, mask=mask)
+    # fused
+    g, gm = g0.clone(), torch.empty(M, K, dtype=ct, device=DEV)
+    dg, db = torch.full((K,), 0.5, device=DEV), torch.full((K,), -0.5, device=DEV)
+    ops.linear_bwd_data_ln(d, dy, w, x, stats, gamma, g, dg, db, g_masked=gm, mask=mask)
+    # (the two-kernel path rounds dy . w to bf16 in between, the fused one does not: agreement to that rounding)
+    assert rel_err(g - g0, g_ref - g0) < 6e-3
+    assert rel_err(gm.float(), gm_ref.float()) < 6e-3
+    assert rel_err(dg - 0.5, dg_ref - 0.5) < 6e-3 and rel_err(db + 0.5, db_ref + 0.5) < 6e-3
+    # and against fp32 torch: LayerNorm backward of da = dy w
+    xt = x.clone().requires_grad_(True)
+    gt = gamma.clone().requires_grad_(True)
+    bt = beta.clone().requires_grad_(True)
+    y = F.layer_norm(xt, (K,), gt, bt, 1e-5)
+    y.backward(dy.float() @ w.float())
+    assert rel_err(g - g0, xt.grad) < 2e-5 + 1e-3 * 0  # fp32 accumulate over bf16 operands: the products are exact in fp32
+    assert rel_err(dg - 0.5, gt.grad) < 1e-4 and rel_err(db + 0.5, bt.grad) < 1e-4
+    # no masked copy requested
+    g2 = g0.clone()
+    ops.linear_bwd_data_ln(d, dy, w, x, stats, gamma, g2, torch.zeros(K, device=DEV), torch.zeros(K, device=DEV))
+    assert rel_err(g2, g) < 1e-6
+
+
 @pytest.mark.parametrize("rows,C,exclusive", [(2304, 128, True), (2304, 128, False), (64, 128, True), (1152, 256, True), (4672, 256, False),
                                               (36864, 128, True), (576, 256, True)])
 def test_weight_gradient_group_kernel(ops, rows, C, exclusive):
