@@ -77,6 +77,140 @@ template <int I, int N, typename F> __device__ __forceinline__ void pipe_static_
   }
 }
 
+// LayerNorm epilogues when TWO waves side by side cover a row (256 channels: 4 x 2 waves of 16 x 128 outputs on a 64 x 256 tile -- a
+// single wave per row means 16 rows x 256 columns of serial epilogue per wave at 8 waves per CU, which lost to GEMM + LayerNorm as two
+// launches).  Each wave reduces its half row, the halves meet through one LDS exchange per pass:
+//   forward  (EPI_RESID_LN): half-row mean and centred sum of squares, merged as  mean = (ma + mb) / 2,  M2 = M2a + M2b + (n/2)(ma - mb)^2 / 2 * 2
+//   backward (EPI_LN_BWD):   the two row sums of  g = dy gamma  and  g xhat  are linear: the halves' partial sums are added.
+template <int EPI, int BM, int BN, int WGM, int TM, int TN>
+__device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, f32x4 (&acc)[TM][TN], float* lds, int m0, int n0, int wm, int wn,
+                                                           int wave, int lane, int tid, float* Cf) {
+  constexpr int NW = WGM * 2, WC = BN / 2, WR = BM / WGM, WPITCH = WC + 4;
+  constexpr int LPR = WC / 4, RPI = 64 / LPR, NIT = 16 / RPI;
+  static_assert(LPR == 32, "two waves per row: 128 columns per wave");
+  float* est = lds + wave * 16 * WPITCH;
+  float2* xch = reinterpret_cast<float2*>(lds + NW * 16 * WPITCH);   // [BM rows][2 halves]
+  float* red = lds + NW * 16 * WPITCH + BM * 4;                       // [NW][2][WC] (EPI_LN_BWD)
+  MaskEval meE;
+  meE.init(p.epi);
+  const int c = (lane % LPR) * 4, n = n0 + wn * WC + c;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f}, lng[4], lnb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == EPI_RESID_LN && p.bias) loadN<4>(p.bias + n, bias);
+  loadN<4>(p.ln_gamma + n, lng);
+  if (EPI == EPI_RESID_LN) loadN<4>(p.ln_beta + n, lnb);
+  float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int lrow0 = wm * WR + i * 16, mbase = m0 + lrow0;
+    float rpre[NIT][4], gpre[EPI == EPI_LN_BWD ? NIT : 1][4];
+    float2 spre[EPI == EPI_LN_BWD ? NIT : 1];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {  // every global read of the pass is requested before the accumulators are staged
+      const int mm = min(mbase + it * RPI + lane / LPR, p.M - 1);
+      loadN<4>(p.resid + (long)mm * p.ldr + n, rpre[it]);
+      if (EPI == EPI_LN_BWD) {
+        loadN<4>(Cf + (long)mm * p.ldc + n, gpre[it]);
+        spre[it] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mm);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const f32x4 v = acc[i][j] * p.alpha;
+      *reinterpret_cast<float4*>(est + (lane & 15) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    float a[NIT][4], b[NIT][4];  // forward: the finished residual row (a); backward: g = dy gamma (a) and xhat (b)
+    float h1[NIT], h2[NIT];      // this half row's two reduced quantities
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + lane / LPR, m = mbase + row;
+      float v[4];
+      loadN<4>(est + row * WPITCH + c, v);
+      if (EPI == EPI_RESID_LN) {
+        const float rowm = meE.row_mult(min(m, p.M - 1));
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[it][e] = rpre[it][e] + (v[e] + bias[e]) * rowm * meE.elem_mult(min(m, p.M - 1), n + e);
+          s1 += a[it][e];
+        }
+        if (m < p.M) storeN<4>(Cf + (long)m * p.ldc + n, a[it]);
+        s1 = row16_sum(s1);
+        s1 += __shfl_xor(s1, 16, 64);
+        const float mh = s1 * (1.0f / WC);
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s2 += (a[it][e] - mh) * (a[it][e] - mh);
+        s2 = row16_sum(s2);
+        s2 += __shfl_xor(s2, 16, 64);
+        h1[it] = mh; h2[it] = s2;
+      } else {
+        const float mean = spre[it].x, rstd = spre[it].y;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          b[it][e] = (rpre[it][e] - mean) * rstd;
+          a[it][e] = v[e] * lng[e];
+          s1 += a[it][e];
+          s2 += a[it][e] * b[it][e];
+          if (m < p.M) { pg[e] += v[e] * b[it][e]; pb[e] += v[e]; }
+        }
+        s1 = row16_sum(s1); s2 = row16_sum(s2);
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        h1[it] = s1; h2[it] = s2;
+      }
+      if ((lane % LPR) == 0) xch[(lrow0 + row) * 2 + wn] = make_float2(h1[it], h2[it]);
+    }
+    __syncthreads();  // (every wave runs the same TM passes: the halves of a row meet here)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + lane / LPR, m = mbase + row;
+      const float2 o = xch[(lrow0 + row) * 2 + (wn ^ 1)];
+      if (m >= p.M) continue;
+      if (EPI == EPI_RESID_LN) {
+        const float mean = 0.5f * (h1[it] + o.x), dm = h1[it] - o.x;
+        const float rstd = rsqrtf((h2[it] + o.y + 0.5f * WC * dm * dm) * (1.0f / BN) + p.ln_eps);
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (a[it][e] - mean) * rstd * lng[e] + lnb[e];
+        storeN<4>(reinterpret_cast<bf16_t*>(p.aux_out) + (long)m * p.ldc + n, y);
+        if (wn == 0 && (lane % LPR) == 0) *reinterpret_cast<float2*>(p.ln_stats + 2 * (long)m) = make_float2(mean, rstd);
+      } else {
+        const float rstd = spre[it].y, m1 = (h1[it] + o.x) * (1.0f / BN), m2 = (h2[it] + o.y) * (1.0f / BN);
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = gpre[it][e] + rstd * (a[it][e] - m1 - b[it][e] * m2);
+        storeN<4>(Cf + (long)m * p.ldc + n, g);
+        if (p.aux_out) {
+          const float rowm = meE.row_mult(m);
+          float gq[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gq[e] = g[e] * rowm * meE.elem_mult(m, n + e);
+          storeN<4>(reinterpret_cast<bf16_t*>(p.aux_out) + (long)m * p.ldc + n, gq);
+        }
+      }
+    }
+  }
+  if (EPI == EPI_LN_BWD) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pg[e] += __shfl_xor(pg[e], 32, 64);
+      pb[e] += __shfl_xor(pb[e], 32, 64);
+    }
+    if (lane < LPR) {
+      *reinterpret_cast<float4*>(red + wave * 2 * WC + c) = make_float4(pg[0], pg[1], pg[2], pg[3]);
+      *reinterpret_cast<float4*>(red + wave * 2 * WC + WC + c) = make_float4(pb[0], pb[1], pb[2], pb[3]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 64 * NW) {  // i -> (which sum, column of the full row): the WGM waves of that column half
+      const int which = i / BN, col = i % BN, half = col / WC, cc = col % WC;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGM; ++w) s += red[(w * 2 + half) * 2 * WC + which * WC + cc];
+      atomicAdd((which ? p.ln_dbeta : p.ln_dgamma) + n0 + col, s);
+    }
+  }
+}
+
 template <typename TC, int EPI, bool TRB, int BM, int BN, int NST, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const GemmParams p) {
   constexpr int NW = WGM * WGN;
@@ -88,7 +222,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
   constexpr int LPW = ROWS / (8 * NW);         // LDS-DMA pieces (8 rows each) per wave per stage
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "a piece index must be an A piece or a W piece for all waves");
   constexpr int WPITCH = WC + 4;
-  constexpr int EPI_BYTES = NW * 16 * WPITCH * 4 + (EPI == EPI_LN_BWD ? NW * 2 * WC * 4 : 0);
+  constexpr int EPI_BYTES = NW * 16 * WPITCH * 4 + (EPI == EPI_LN_BWD ? NW * 2 * WC * 4 : 0) +
+                            (((EPI == EPI_RESID_LN || EPI == EPI_LN_BWD) && WGN == 2) ? BM * 16 : 0);
   constexpr int LDS_BYTES = NST * STAGE_BYTES > EPI_BYTES ? NST * STAGE_BYTES : EPI_BYTES;
   extern __shared__ __attribute__((aligned(1024))) char pipe_lds[];
   static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit in LDS");
@@ -213,7 +348,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
   float* est = reinterpret_cast<float*>(pipe_lds) + wave * 16 * WPITCH;
   MaskEval meE;
   if (EPI == EPI_RESID || EPI == EPI_GELU_FWD || EPI == EPI_RESID_LN || EPI == EPI_LN_BWD) meE.init(p.epi);
-  static_assert((EPI != EPI_RESID_LN && EPI != EPI_LN_BWD) || (WGN == 1 && sizeof(TC) == 4), "the LayerNorm epilogues need row-complete wave tiles and an fp32 residual stream");
+  static_assert((EPI != EPI_RESID_LN && EPI != EPI_LN_BWD) || ((WGN == 1 || WGN == 2) && sizeof(TC) == 4 && BN == WGN * WC),
+                "the LayerNorm epilogues need wave tiles that cover a row (one wave, or two side by side) and an fp32 residual stream");
+  if constexpr ((EPI == EPI_RESID_LN || EPI == EPI_LN_BWD) && WGN == 2) {
+    pipe_ln_epilogue_two_waves<EPI, BM, BN, WGM, TM, TN>(p, acc, reinterpret_cast<float*>(pipe_lds), m0, n0, wm, wn, wave, lane, tid,
+                                                          reinterpret_cast<float*>(C));
+    return;
+  }
   float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};  // EPI_LN_BWD: this lane's column partials of dy * xhat, dy
   float lng[4] = {0.f, 0.f, 0.f, 0.f};
   if (EPI == EPI_LN_BWD) loadN<4>(p.ln_gamma + (n0 + wn * WC + (lane % (WC / 4)) * 4), lng);

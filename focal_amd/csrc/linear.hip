@@ -133,7 +133,7 @@ extern "C" int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy,
 
 extern "C" int focal_linear_bwd_data_ln_supported(int dtype, int N, int K) {
   // K = the LayerNorm's width (the linear layer's input features), N = its output features (the contraction of the dX product)
-  return dtype == FOCAL_BF16 && (K == 64 || K == 128) && N % 64 == 0 && N >= 64;
+  return dtype == FOCAL_BF16 && (K == 64 || K == 128 || K == 256) && N % 64 == 0 && N >= 64;
 }
 
 // dx of a linear layer whose input came out of a LayerNorm, and that LayerNorm's backward, in one kernel: the [M, K] product dy . w never
@@ -146,7 +146,7 @@ extern "C" int focal_linear_bwd_data_ln(const focal_linear_desc* d, const void* 
   FOCAL_CHECK_ARG(dy && w && ln_x && ln_stats && ln_gamma && g && dgamma && dbeta, "linear_bwd_data_ln: null tensor");
   FOCAL_CHECK_ARG(focal_linear_bwd_data_ln_supported(d->dtype, d->N, d->K) && d->x_dtype == d->dtype && d->y_dtype == d->dtype &&
                   d->epilogue != FOCAL_EPI_RESIDUAL && d->act_in == FOCAL_ACT_NONE,  // (a GELU epilogue's derivative is already in dy)
-                  "linear_bwd_data_ln: bf16 layers with 64 / 128 input features, plain `dtype` dy (N = %d, K = %d)", d->N, d->K);
+                  "linear_bwd_data_ln: bf16 layers with 64 / 128 / 256 input features, plain `dtype` dy (N = %d, K = %d)", d->N, d->K);
   FOCAL_CHECK_ARG(((uintptr_t)dy % 16 == 0) && ((uintptr_t)w % 16 == 0), "linear_bwd_data_ln: operands must be 16-byte aligned");
   FOCAL_CHECK_ARG(!mask || g_masked, "linear_bwd_data_ln: mask without g_masked");
   GemmParams p;
@@ -167,9 +167,11 @@ extern "C" int focal_linear_bwd_data_ln(const focal_linear_desc* d, const void* 
   memset(&dd, 0, sizeof(dd));
   if (mask) dd = *mask;
   p.epi = to_mask(dd, d->K);
-  focal_note_kernel("focal_gemm_pipe_kernel<f32, epi=%d (LayerNorm backward), trB=1, 128x%d, 4x1 waves>", EPI_LN_BWD, d->K);
-  hipError_t e = d->K == 64 ? focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 128, 64, 2, 4, 1>(p, (hipStream_t)stream)
-                            : focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 128, 128, 2, 4, 1>(p, (hipStream_t)stream);
+  focal_note_kernel("focal_gemm_pipe_kernel<f32, epi=%d (LayerNorm backward), trB=1, %dx%d, 4x%d waves>", EPI_LN_BWD, d->K == 256 ? 64 : 128,
+                    d->K, d->K == 256 ? 2 : 1);
+  hipError_t e = d->K == 64    ? focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 128, 64, 2, 4, 1>(p, (hipStream_t)stream)
+                 : d->K == 128 ? focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 128, 128, 2, 4, 1>(p, (hipStream_t)stream)
+                               : focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 64, 256, 2, 4, 2>(p, (hipStream_t)stream);
   if (e != hipSuccess) {
     focal_set_error("linear_bwd_data_ln: launch failed: %s", hipGetErrorString(e));
     return FOCAL_EHIP;

@@ -263,6 +263,7 @@ class SwinModEncoder:
         group_dw = os.environ.get("FOCAL_NO_DW_GROUP") != "1"
         # LayerNorm backward as the epilogue of the dX GEMM in front of it (64 / 128 channels, bf16): focal_linear_bwd_data_ln
         fuse_ln_bwd = os.environ.get("FOCAL_NO_LN_BWD_FUSE") != "1" and ct == torch.bfloat16
+        ln_bwd_max_c = int(os.environ.get("FOCAL_LN_BWD_FUSE_MAXC", "128"))
         # one pass per step over this encoder's weights (both views in one batch): a gradient tile has a single writer per launch
         exclusive_dw = bool(getattr(bb, "views_share_pass", False))
         # Nothing in the backward pass waits for a weight gradient (only the optimizer does), so a block's weight-gradient launches
@@ -318,7 +319,7 @@ class SwinModEncoder:
                 du = torch.empty_like(s["h"])
                 ops.linear_bwd_data(d_fc2_b, gm, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
                 weight_grad(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
-                if fuse_ln_bwd and ops.bwd_data_ln_supported(cc, 4 * Cc, Cc):
+                if fuse_ln_bwd and Cc <= ln_bwd_max_c and ops.bwd_data_ln_supported(cc, 4 * Cc, Cc):
                     ln2_done = True  # dX of fc1 and norm2's backward in one kernel (below)
                 else:
                     ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
@@ -340,7 +341,7 @@ class SwinModEncoder:
                                 ar.g(f"{pb}.attn.relative_position_bias_table"))
             weight_grad(s["d_qkv"], dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias"))
             da = do
-            ln1_fused = fuse_ln_bwd and ops.bwd_data_ln_supported(cc, 3 * Cc, Cc)
+            ln1_fused = fuse_ln_bwd and Cc <= ln_bwd_max_c and ops.bwd_data_ln_supported(cc, 3 * Cc, Cc)
             if not ln1_fused:
                 ops.linear_bwd_data(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), None, da)
             deferred = dwq.submit(cc, dw_items, dw_calls, exclusive_dw)

@@ -149,7 +149,7 @@ def test_linear_resid_ln_wide(ops, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,drop", [(2304, 192, 64, False), (2304, 384, 128, True), (1000, 512, 128, True), (64, 256, 64, False), (9216, 384, 128, False),
-                                         (4672, 192, 64, True)])
+                                         (4672, 192, 64, True), (1152, 768, 256, True), (1000, 1024, 256, False), (64, 768, 256, True), (9216, 1024, 256, True)])
 def test_linear_bwd_data_ln(ops, M, N, K, drop):
     """focal_linear_bwd_data_ln = focal_linear_bwd_data followed by focal_layernorm_bwd (accumulating into g, with the masked operand copy
     for the next branch): the LayerNorm backward as the epilogue of the dX GEMM (row-complete wave tiles), ragged M, with / without a mask."""
