@@ -1,6 +1,6 @@
 """The pretraining step as replayed hipGraphs -- one implementation for `bench.py` and for `train.py`.
 
-`train_utils/pretrain.py` launches ~350 kernels per SW_Transformer step through ctypes; eagerly that is host-bound (~10 ms per step
+`train_utils/pretrain.py` launches ~280 kernels per SW_Transformer step through ctypes; eagerly that is host-bound (~10 ms per step
 against 6 ms of GPU work).  `StepSegments` is the step body [zero_grad -> views -> FOCAL(view 1, view 2) -> loss head -> backward ->
 AdamW] cut where the data-parallel collectives sit:
 
