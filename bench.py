@@ -212,7 +212,7 @@ def _dw_bytes_flops(d):
 # ops of focal_amd.ops that launch nothing (descriptors, queries, allocation helpers): never traced
 _NOT_LAUNCHES = {"code", "torch_dtype", "zero_pool_reset", "pool_zeros", "zeros", "drop_desc", "new_rng_state", "linear_desc", "ln_desc",
                  "mlp_desc", "attn_desc", "conv_desc", "conv_in_desc", "bn_desc", "mlp_supported", "dw_group_supported", "resid_ln_supported",
-                 "check", "linear_bwd_weight_group_workgroups", "linear", "gru_desc"}
+                 "bwd_data_ln_supported", "check", "linear_bwd_weight_group_workgroups", "linear", "gru_desc"}
 
 
 def _tensor_bytes(args, kw):
