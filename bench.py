@@ -211,7 +211,7 @@ def _dw_bytes_flops(d):
 
 # ops of focal_amd.ops that launch nothing (descriptors, queries, allocation helpers): never traced
 _NOT_LAUNCHES = {"code", "torch_dtype", "zero_pool_reset", "pool_zeros", "zeros", "drop_desc", "new_rng_state", "linear_desc", "ln_desc",
-                 "mlp_desc", "attn_desc", "conv_desc", "conv_in_desc", "bn_desc", "mlp_supported", "dw_group_supported", "resid_ln_supported",
+                 "mlp_desc", "attn_desc", "conv_desc", "conv_in_desc", "bn_desc", "mlp_supported", "dw_group_supported", "dw_group_kind", "resid_ln_supported",
                  "bwd_data_ln_supported", "check", "linear_bwd_weight_group_workgroups", "linear", "gru_desc"}
 
 
@@ -264,6 +264,9 @@ class StepTracer:
             b = sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + w.numel() * 4 for dy, x, w, _ in items)
             f = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)
             rows, C = items[0][0].shape[0], min(min(dy.shape[1], x.shape[1]) for dy, x, _, _ in items)
+            if C % 128 != 0:
+                return ("focal_dw_ring_group_kernel<the dW of a 64-channel block's linears in one launch, 64x64 tiles, LDS-DMA ring>", f"{wgs} workgroups x 512",
+                        b, f, "hbm", f"{len(items)} dW of a C={C} block over {rows} rows")
             return ("focal_dw_group_kernel<the dW of a block's linears in one launch, 128x128 tiles, LDS-DMA ring>", f"{wgs} workgroups x 512", b, f, "hbm",
                     f"{len(items)} dW of a C={C} block over {rows} rows")
 

@@ -14,7 +14,7 @@ ACT_NONE, ACT_GELU, ACT_RELU_OUT = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class DropDesc(C.Structure):
@@ -122,6 +122,7 @@ PROTOTYPES = {
     "focal_linear_bwd_weight_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(DwProblem), P]),
     "focal_linear_bwd_weight_group_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "focal_linear_bwd_weight_group_workgroups": (C.c_int, [C.c_int, C.c_int, C.POINTER(DwProblem)]),
+    "focal_linear_bwd_weight_group_kind": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "focal_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P]),
     "focal_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P]),
@@ -139,6 +140,8 @@ PROTOTYPES = {
     "focal_loss_head_shard_b": (C.c_int, [C.POINTER(LossDesc), C.c_int, C.c_int, C.POINTER(P), P, C.POINTER(P), P, P, C.c_size_t, P]),
     "focal_adamw_multi": (C.c_int, [C.POINTER(AdamWDesc), C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P),
                                     C.POINTER(P), C.POINTER(P), C.POINTER(C.c_long), P, P, P]),
+    "focal_adamw_multi_advance": (C.c_int, [C.POINTER(AdamWDesc), C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P),
+                                            C.POINTER(P), C.POINTER(P), C.POINTER(C.c_long), P, P, P, P]),
     "focal_cast_bf16": (C.c_int, [P, P, C.c_long, P]),
     "focal_conv_in_fwd": (C.c_int, [C.POINTER(ConvInDesc), P, P, P, P, P]),
     "focal_conv_in_bwd_weight": (C.c_int, [C.POINTER(ConvInDesc), P, P, C.c_int, P, P, P]),

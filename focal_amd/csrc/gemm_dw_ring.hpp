@@ -26,8 +26,10 @@
 #pragma once
 #include "gemm_pipe.hpp"
 
+// (the kernel body is a device function of (problem, workgroup index, workgroups of the problem): focal_dw_ring_kernel runs it for its one
+// problem, focal_dw_ring_group_kernel for the problem its blockIdx falls into)
 template <int RPS, int NST, bool WITH_BIAS, int HALVES>
-__global__ __launch_bounds__(256 * HALVES) void focal_dw_ring_kernel(const GemmParams p) {
+__device__ __forceinline__ void focal_dw_ring_body(const GemmParams& p, const int block, const int nblocks) {
   // HALVES = 2: two groups of four waves, each with its own ring and its own slice of the token range, work on the SAME output tile and
   // add their accumulators through LDS before the one atomic pass -- the 8 waves a CU held as two workgroups, with half the atomic
   // volume (the epilogue's fp32 atomics retire at ~1.3 TB/s at the memory side: 2-5 us per launch, profiles/r2_dw_fixed_cost.txt).
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256 * HALVES) void focal_dw_ring_kernel(const GemmP
   char* dww_lds = dww_lds_all + half * (NST * STAGE_BYTES);  // this half's ring
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = p.N / TILE, ntiles = (p.M / TILE) * tiles_n;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int logical = xcd_remap(block, nblocks);
   const int tile = logical % ntiles, sp = logical / ntiles;
   const int m0 = (tile / tiles_n) * TILE, n0 = (tile % tiles_n) * TILE;
   const int KT = p.K / RPS;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256 * HALVES) void focal_dw_ring_kernel(const GemmP
 #pragma unroll
     for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bool do_bias = WITH_BIAS && (n0 == 0) && (wn == 0);
+  const bool do_bias = WITH_BIAS && p.colsumA != nullptr && (n0 == 0) && (wn == 0);
   // the column-sum MFMAs are issued by every wave (against a zero operand where the sums are not wanted): a branch here would split
   // the k-step into basic blocks and stop the scheduler from moving the next fragment reads above this step's MFMAs
   bf16x8 ones;
@@ -217,6 +219,65 @@ __global__ __launch_bounds__(256 * HALVES) void focal_dw_ring_kernel(const GemmP
     for (int r = 0; r < 16; r += RPI) atomicAdd(crow + (long)r * p.ldc, est[(r + erow) * WPITCH + ecol] + badd);
     if (do_bias && g == 0) atomicAdd(p.colsumA + m0 + WT * wm + 16 * i + l15, accb[i][0]);
   }
+}
+
+template <int RPS, int NST, bool WITH_BIAS, int HALVES>
+__global__ __launch_bounds__(256 * HALVES) void focal_dw_ring_kernel(const GemmParams p) {
+  focal_dw_ring_body<RPS, NST, WITH_BIAS, HALVES>(p, blockIdx.x, gridDim.x);
+}
+
+// Several weight gradients of 64-tile shapes as ONE launch (the qkv and proj gradients of a 64-channel Swin block: [192, 64] and
+// [64, 64] outputs -- too narrow for the 128 x 128 tiles of gemm_dw_group.hpp): every problem keeps the tiles, ring and atomic epilogue
+// of focal_dw_ring_kernel; a prefix table in the kernel arguments maps blockIdx to (problem, workgroup of the problem).
+constexpr int DWR_MAX_PROBLEMS = 4;
+struct DwRingGroupParams {
+  int nprob;
+  int wg_end[DWR_MAX_PROBLEMS];  // exclusive prefix ends of the problems' workgroup ranges
+  GemmParams prob[DWR_MAX_PROBLEMS];
+};
+template <int RPS, int NST, int HALVES>
+__global__ __launch_bounds__(256 * HALVES) void focal_dw_ring_group_kernel(const DwRingGroupParams gp) {
+  const int b = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int q = 0; q < DWR_MAX_PROBLEMS - 1; ++q) pi += (q < gp.nprob - 1 && b >= gp.wg_end[q]) ? 1 : 0;
+  const int start = pi > 0 ? gp.wg_end[pi - 1] : 0;
+  focal_dw_ring_body<RPS, NST, true, HALVES>(gp.prob[pi], b - start, gp.wg_end[pi] - start);
+}
+
+// splits (workgroups per tile, each taking HALVES token slices) such that the whole group is one round of 256 one-per-CU workgroups
+template <int HALVES> static inline int focal_dw_ring_group_plan(DwRingGroupParams& gp) {
+  int tiles = 0;
+  long rows_min = 1L << 40;
+  for (int i = 0; i < gp.nprob; ++i) {
+    tiles += (gp.prob[i].M / 64) * (gp.prob[i].N / 64);
+    if (gp.prob[i].K < rows_min) rows_min = gp.prob[i].K;
+  }
+  int per = 256 / (tiles > 0 ? tiles : 1);
+  const long max_per = (rows_min + 256L * HALVES - 1) / (256L * HALVES);  // at least 256 reduction rows per token slice
+  if (per > max_per) per = (int)max_per;
+  if (per < 1) per = 1;
+  int end = 0;
+  for (int i = 0; i < gp.nprob; ++i) {
+    gp.prob[i].splits = per;
+    end += (gp.prob[i].M / 64) * (gp.prob[i].N / 64) * per;
+    gp.wg_end[i] = end;
+  }
+  return end;
+}
+
+template <int RPS, int NST, int HALVES>
+static inline hipError_t focal_launch_dw_ring_group(const DwRingGroupParams& gp, int wgs, hipStream_t stream) {
+  constexpr int LDS_BYTES = HALVES * NST * RPS * 64 * 4;
+  auto kern = focal_dw_ring_group_kernel<RPS, NST, HALVES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256 * HALVES), LDS_BYTES, stream, gp);
+  return hipGetLastError();
 }
 
 template <int RPS, int NST, int HALVES>

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include "gemm.hpp"
 #include "gemm_dw_group.hpp"
+#include "gemm_dw_ring.hpp"
 
 static MaskParams to_mask(const focal_drop_desc& d, int ncols) {
   MaskParams m;
@@ -266,7 +267,56 @@ static int dw_group_build(int dtype, int n, const focal_dw_problem* probs, DwGro
   return FOCAL_OK;
 }
 
+// 64-tile problems (a 64-channel block's qkv / proj gradients): the ring kernel's tiles behind a problem table (gemm_dw_ring.hpp)
+static bool dw_ring_group_fits(const focal_dw_problem& q) {
+  return q.M >= 64 && q.M % 64 == 0 && q.N > 0 && q.N % 64 == 0 && q.K > 0 && q.K % 64 == 0 && q.dy && q.x && q.dw &&
+         ((uintptr_t)q.dy % 16 == 0) && ((uintptr_t)q.x % 16 == 0);
+}
+static bool dw_group_uses_ring(int n, const focal_dw_problem* probs) {
+  if (!probs || n < 1 || n > DWR_MAX_PROBLEMS) return false;
+  bool all128 = true, all64 = true;
+  for (int i = 0; i < n; ++i) { all128 = all128 && dw_group_fits(probs[i]); all64 = all64 && dw_ring_group_fits(probs[i]); }
+  return !all128 && all64;
+}
+static int dw_ring_group_build(int dtype, int n, const focal_dw_problem* probs, DwRingGroupParams* gp, int* wgs) {
+  FOCAL_CHECK_ARG(dtype == FOCAL_BF16, "linear_bwd_weight_group: bf16 operands only (dtype %d)", dtype);
+  memset(gp, 0, sizeof(*gp));
+  gp->nprob = n;
+  for (int i = 0; i < n; ++i) {
+    const focal_dw_problem& q = probs[i];
+    GemmParams& p = gp->prob[i];
+    p.M = q.N; p.N = q.K; p.K = q.M;
+    p.A = q.dy; p.lda = q.N;
+    p.B = q.x; p.ldb = q.K;
+    p.C = q.dw; p.ldc = q.K;
+    p.batch = 1; p.alpha = 1.f; p.splits = 1;
+    p.colsumA = q.dbias;
+  }
+  *wgs = focal_dw_ring_group_plan<2>(*gp);
+  return FOCAL_OK;
+}
+
+extern "C" int focal_linear_bwd_weight_group_kind(int dtype, int M, int N, int K) {
+  static const bool off = getenv("FOCAL_DW_NOGROUP") != nullptr;
+  if (off || dtype != FOCAL_BF16 || M <= 0 || M % 64 != 0) return 0;
+  if (N % 128 == 0 && K % 128 == 0) return 2;
+  static const bool off64 = getenv("FOCAL_DW_NORINGGROUP") != nullptr;
+  return (!off64 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0) ? 1 : 0;
+}
+
 extern "C" int focal_linear_bwd_weight_group(int dtype, int n, const focal_dw_problem* probs, void* stream) {
+  if (dw_group_uses_ring(n, probs)) {
+    DwRingGroupParams rp;
+    int rw = 0;
+    if (int rc = dw_ring_group_build(dtype, n, probs, &rp, &rw)) return rc;
+    focal_note_kernel("focal_dw_ring_group_kernel<64, 4, 2>");
+    hipError_t e = focal_launch_dw_ring_group<64, 4, 2>(rp, rw, (hipStream_t)stream);
+    if (e != hipSuccess) {
+      focal_set_error("linear_bwd_weight_group (64-tile ring): launch failed: %s", hipGetErrorString(e));
+      return FOCAL_EHIP;
+    }
+    return FOCAL_OK;
+  }
   DwGroupParams gp;
   int wgs = 0;
   if (int rc = dw_group_build(dtype, n, probs, &gp, &wgs)) return rc;
@@ -279,6 +329,11 @@ extern "C" int focal_linear_bwd_weight_group(int dtype, int n, const focal_dw_pr
 }
 
 extern "C" int focal_linear_bwd_weight_group_workgroups(int dtype, int n, const focal_dw_problem* probs) {
+  if (dw_group_uses_ring(n, probs)) {
+    DwRingGroupParams rp;
+    int rw = 0;
+    return dw_ring_group_build(dtype, n, probs, &rp, &rw) == FOCAL_OK ? rw : 0;
+  }
   DwGroupParams gp;
   int wgs = 0;
   return dw_group_build(dtype, n, probs, &gp, &wgs) == FOCAL_OK ? wgs : 0;

@@ -16,12 +16,15 @@ extern "C" int focal_rng_advance(uint32_t* state, void* stream) {
 
 // torch.optim.AdamW: p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// advance != 0 (focal_adamw_multi_advance): the update uses step count step_state[1] + 1, and the workgroup that finishes LAST -- by
+// then every workgroup has read the count -- advances step_state and seed_state the way focal_rng_advance would (ticket in
+// step_state[2]): the step's two one-thread bookkeeping launches ride on the optimizer kernel.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, long n,
-                                                    const float* __restrict__ lr_dev, const uint32_t* __restrict__ rng_state,
-                                                    focal_adamw_desc d) {
+                                                    const float* __restrict__ lr_dev, uint32_t* rng_state, uint32_t* seed_state,
+                                                    int advance, focal_adamw_desc d) {
   const float lr = lr_dev[0];
-  const float t = (float)rng_state[1];
+  const float t = (float)(rng_state[1] + (advance ? 1u : 0u));
   const float bc1 = 1.0f - powf(d.beta1, t), bc2 = 1.0f - powf(d.beta2, t);
   // weight decay: decoupled (AdamW: p *= 1 - lr * wd) or, with d.l2_decay, torch.optim.Adam's L2 form (g += wd * p)
   const float step = lr / bc1, isq = rsqrtf(bc2), decay = d.l2_decay ? 1.0f : 1.0f - lr * d.weight_decay;
@@ -48,22 +51,55 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       reinterpret_cast<bf16x4*>(shadow)[i] = s;
     }
   }
+  if (advance == 2) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(rng_state + 2, 1u) == gridDim.x - 1) {
+        rng_state[2] = 0u;
+        rng_state[0] = focal_mix32(rng_state[0] + 0x9E3779B9U);
+        rng_state[1] += 1u;
+        if (seed_state != nullptr) {
+          seed_state[0] = focal_mix32(seed_state[0] + 0x9E3779B9U);
+          seed_state[1] += 1u;
+        }
+      }
+    }
+  }
+}
+
+static int adamw_launch(const focal_adamw_desc* d, int nseg, float* const* p, const float* const* g, float* const* m, float* const* v,
+                        void* const* shadow_bf16, const long* n, const float* lr_dev, uint32_t* step_state, uint32_t* seed_state,
+                        bool advance, hipStream_t st) {
+  FOCAL_CHECK_ARG(d && p && g && m && v && n && lr_dev && step_state, "adamw_multi: null argument");
+  int last = -1;
+  for (int s = 0; s < nseg; ++s) {
+    FOCAL_CHECK_ARG(n[s] % 4 == 0, "adamw_multi: segment %d length %ld is not a multiple of 4 (arena segments are padded)", s, n[s]);
+    if (n[s] > 0) last = s;
+  }
+  FOCAL_CHECK_ARG(!advance || last >= 0, "adamw_multi_advance: no non-empty segment to carry the step-count advance");
+  for (int s = 0; s < nseg; ++s) {
+    if (n[s] == 0) continue;
+    int blocks = ceil_div(n[s] / 4, 256);
+    if (blocks > 2048) blocks = 2048;
+    // segments run in stream order: every one of them reads the same step count, the last one advances it
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, p[s], g[s], m[s], v[s], shadow_bf16 ? (bf16_t*)shadow_bf16[s] : nullptr,
+                       n[s], lr_dev, step_state, (advance && s == last) ? seed_state : nullptr, advance ? (s == last ? 2 : 1) : 0, *d);
+  }
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
 }
 
 extern "C" int focal_adamw_multi(const focal_adamw_desc* d, int nseg, float* const* p, const float* const* g, float* const* m,
                                  float* const* v, void* const* shadow_bf16, const long* n, const float* lr_dev,
                                  const uint32_t* rng_state, void* stream) {
-  FOCAL_CHECK_ARG(d && p && g && m && v && n && lr_dev && rng_state, "adamw_multi: null argument");
-  for (int s = 0; s < nseg; ++s) {
-    FOCAL_CHECK_ARG(n[s] % 4 == 0, "adamw_multi: segment %d length %ld is not a multiple of 4 (arena segments are padded)", s, n[s]);
-    if (n[s] == 0) continue;
-    int blocks = ceil_div(n[s] / 4, 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p[s], g[s], m[s], v[s],
-                       shadow_bf16 ? (bf16_t*)shadow_bf16[s] : nullptr, n[s], lr_dev, rng_state, *d);
-  }
-  FOCAL_LAUNCH_CHECK();
-  return FOCAL_OK;
+  return adamw_launch(d, nseg, p, g, m, v, shadow_bf16, n, lr_dev, const_cast<uint32_t*>(rng_state), nullptr, false, (hipStream_t)stream);
+}
+
+extern "C" int focal_adamw_multi_advance(const focal_adamw_desc* d, int nseg, float* const* p, const float* const* g, float* const* m,
+                                         float* const* v, void* const* shadow_bf16, const long* n, const float* lr_dev,
+                                         uint32_t* step_state, uint32_t* seed_state, void* stream) {
+  return adamw_launch(d, nseg, p, g, m, v, shadow_bf16, n, lr_dev, step_state, seed_state, true, (hipStream_t)stream);
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {

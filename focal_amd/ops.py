@@ -113,13 +113,19 @@ def cast_bf16(src, dst):
     check(_lib.load().focal_cast_bf16(_p(src), _p(dst), src.numel(), _stream()))
 
 
-def adamw_multi(segments, lr_dev, rng_state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, l2_decay=False):
-    """segments: list of (p, g, m, v, shadow_or_None) flat tensors (lengths multiples of 4)."""
+def adamw_multi(segments, lr_dev, rng_state, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, l2_decay=False, advance=False, seed_state=None):
+    """segments: list of (p, g, m, v, shadow_or_None) flat tensors (lengths multiples of 4).  rng_state[1] is the step count the update
+    uses; advance=True: the count used is rng_state[1] + 1 and the kernel itself then advances rng_state and (if given) seed_state
+    (focal_adamw_multi_advance: what two focal_rng_advance launches in front of the call would have done)."""
     n = len(segments)
     arr = lambda i: (C.c_void_p * n)(*[_p(s[i]) for s in segments])
     has_shadow = any(s[4] is not None for s in segments)
     lens = (C.c_long * n)(*[s[0].numel() for s in segments])
     d = AdamWDesc(beta1, beta2, eps, weight_decay, int(l2_decay))
+    if advance:
+        check(_lib.load().focal_adamw_multi_advance(C.byref(d), n, arr(0), arr(1), arr(2), arr(3), arr(4) if has_shadow else None,
+                                                    lens, _p(lr_dev), _p(rng_state), _p(seed_state), _stream()))
+        return
     check(_lib.load().focal_adamw_multi(C.byref(d), n, arr(0), arr(1), arr(2), arr(3), arr(4) if has_shadow else None,
                                         lens, _p(lr_dev), _p(rng_state), _stream()))
 
@@ -315,6 +321,11 @@ def linear_bwd_weight(d, dy, x, dw, dbias):
 
 def dw_group_supported(dtype_code, M, N, K):
     return bool(_lib.load().focal_linear_bwd_weight_group_supported(dtype_code, M, N, K))
+
+
+def dw_group_kind(dtype_code, M, N, K):
+    """2: a shape for the 128 x 128 grouped weight-gradient launch, 1: for the 64-tile group only (at most 4 problems), 0: neither."""
+    return int(_lib.load().focal_linear_bwd_weight_group_kind(dtype_code, M, N, K))
 
 
 def _dw_problems(items, exclusive):

@@ -115,15 +115,15 @@ class FocalAdamW(torch.optim.Optimizer):
         dev = arenas[0].device
         if self._step_state is None:
             self._step_state = ops.new_rng_state(0, dev)
-        ops.rng_advance(self._step_state)  # this optimizer's step count, on the device (graph-replay safe)
-        runtime.advance_step(dev)          # fresh dropout seed for the next forward
+        # this optimizer's step count (on the device: graph-replay safe) and the dropout seed of the next forward pass are advanced
+        # by the AdamW kernel itself -- its last workgroup -- instead of two one-thread launches on the serial tail of the step
         segs = []
         for ar in arenas:
             m, v = ar.moments()
             lo, hi = self._span(ar)
             segs.append((ar.flat[lo:hi], ar.grad[lo:hi], m[lo:hi], v[lo:hi], ar.shadow[lo:hi] if ar.shadow is not None else None))
         ops.adamw_multi(segs, self._lr_dev, self._step_state, g0["betas"][0], g0["betas"][1], g0["eps"],
-                        g0["weight_decay"], self._l2)
+                        g0["weight_decay"], self._l2, advance=True, seed_state=runtime.rng_state(dev))
         for ar in arenas:
             ar.mark_shadow_fresh()
 

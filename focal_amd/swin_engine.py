@@ -280,9 +280,13 @@ class SwinModEncoder:
             if (k + 1) in merges:  # a PatchMerging sits between block k and block k+1
                 mg = merges[k + 1]
                 pm, d_red = mg["pm"], mg["d_red"]
-                ops.linear_bwd_weight(d_red, g, mg["a4"], ar.g(f"{pm}.reduction.weight"), None)
                 da4 = torch.empty_like(mg["a4"])
-                ops.linear_bwd_data(d_red, g, ar.operand(f"{pm}.reduction.weight"), None, da4)
+                if mg.get("dw_done"):  # the reduction's dW went out with block k+1's group; gm is the plain `ct` copy of g
+                    d_red_b = ops.linear_desc(cc, d_red.M, d_red.N, d_red.K, cc, cc)
+                    ops.linear_bwd_data(d_red_b, gm.view(d_red.M, d_red.N), ar.operand(f"{pm}.reduction.weight"), None, da4)
+                else:
+                    ops.linear_bwd_weight(d_red, g, mg["a4"], ar.g(f"{pm}.reduction.weight"), None)
+                    ops.linear_bwd_data(d_red, g, ar.operand(f"{pm}.reduction.weight"), None, da4)
                 g = torch.empty_like(mg["x"])
                 gm = torch.empty(mg["x"].shape, dtype=ct, device=dev)
                 ops.layernorm_bwd(da4, mg["x"], mg["st4"], ar.master(f"{pm}.norm.weight"), g, False,
@@ -295,7 +299,15 @@ class SwinModEncoder:
             # exist (ops.linear_bwd_weight_group; stages 1-2: C >= 128): one ramp and one atomic epilogue instead of four, half the
             # L2 -> LDS bytes per MAC.  Their operands stay alive until then, so the attention branch's masked gradient gets a buffer
             # of its own instead of overwriting the MLP branch's.
-            grouped = group_dw and s.get("d_mlp") is None and ops.dw_group_supported(cc, M, Cc, 4 * Cc) and ops.dw_group_supported(cc, M, 3 * Cc, Cc)
+            # 64-channel blocks (stage 0) are too narrow for those tiles: their launches -- qkv and proj beside the fused MLP kernel, all four
+            # otherwise -- go out as one launch of the 64 x 64 ring tiles behind a problem table (dw_group_kind 1).
+            fused_mlp = s.get("d_mlp") is not None
+            shapes = [(Cc, Cc), (3 * Cc, Cc)] + ([] if fused_mlp else [(Cc, 4 * Cc), (4 * Cc, Cc)])
+            kinds = [ops.dw_group_kind(cc, M, n_, k_) for n_, k_ in shapes] if group_dw else [0]
+            if os.environ.get("FOCAL_NO_DW_RING_GROUP") == "1":
+                kinds = [k if k == 2 else 0 for k in kinds]
+            grouped = min(kinds) >= 1
+            grouped128 = min(kinds) == 2
             dw_items, dw_calls = [], []  # grouped problems / single launches (descriptor, dy, x, dw, dbias) of this block
 
             def weight_grad(desc, dy, x, dw, db):
@@ -309,7 +321,7 @@ class SwinModEncoder:
             dc = torch.empty_like(s["a2"])
             du = None
             ln2_done = False
-            if s.get("d_mlp") is not None:  # fused branch: h and h' recomputed from a2, all four parameter gradients from one pass
+            if fused_mlp:  # fused branch: h and h' recomputed from a2, all four parameter gradients from one pass
                 ops.mlp_bwd(s["d_mlp"], gm, s["a2"], ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
                             ar.operand(f"{pb}.mlp.fc2.weight"), dc, ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"),
                             ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
@@ -324,7 +336,7 @@ class SwinModEncoder:
                 else:
                     ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
             # (the MLP branch's gm is still an operand of a pending weight gradient unless the fused branch has consumed it)
-            gm_attn = torch.empty_like(gm) if (s.get("d_mlp") is None and (grouped or dwq.enabled)) else gm
+            gm_attn = torch.empty_like(gm) if (not fused_mlp and (grouped or dwq.enabled)) else gm
             if ln2_done:
                 ops.linear_bwd_data_ln(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g,
                                        ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), g_masked=gm_attn, mask=s["d_proj"].out_drop)
@@ -344,19 +356,32 @@ class SwinModEncoder:
             ln1_fused = fuse_ln_bwd and Cc <= ln_bwd_max_c and ops.bwd_data_ln_supported(cc, 3 * Cc, Cc)
             if not ln1_fused:
                 ops.linear_bwd_data(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), None, da)
-            deferred = dwq.submit(cc, dw_items, dw_calls, exclusive_dw)
+            # First block of a stage behind a PatchMerging: the merge's reduction linear takes this block's finished g as its dy.  With
+            # a plain `ct` copy of g written by the LayerNorm backward below (as every other linear gets its dy), the reduction's weight
+            # gradient joins this block's group launch and its dX reads 2-byte operands.
+            mg_dw = merges.get(k) if (grouped128 and not dwq.enabled and os.environ.get("FOCAL_NO_MERGE_DW_GROUP") != "1") else None
+            if mg_dw is not None and ops.dw_group_kind(cc, mg_dw["d_red"].M, mg_dw["d_red"].N, mg_dw["d_red"].K) != 2:
+                mg_dw = None
+            deferred = False
+            if mg_dw is None:
+                deferred = dwq.submit(cc, dw_items, dw_calls, exclusive_dw)
             du = None
             # the next consumer of g: block k-1's MLP branch, unless a PatchMerging (handled above) or the embedding comes first
             nxt = blocks[k - 1]["d_fc2"].out_drop if (k > 0 and k not in merges) else None
-            if deferred and nxt is not None:
-                gm = torch.empty_like(gm)  # the old buffers are operands of the weight gradients now running beside this stream
+            want_gm = nxt is not None or mg_dw is not None
+            if want_gm and (deferred or mg_dw is not None):
+                gm = torch.empty_like(gm)  # the old buffers are operands of weight gradients that have not run yet / run beside this stream
             if ln1_fused:  # dX of qkv and norm1's backward in one kernel
                 ops.linear_bwd_data_ln(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g,
-                                       ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"), g_masked=gm if nxt is not None else None, mask=nxt)
+                                       ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"), g_masked=gm if want_gm else None, mask=nxt)
             else:
                 ops.layernorm_bwd(da, s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g, True,
                                   ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"),
-                                  dx_masked=gm if nxt is not None else None, mask=nxt)
+                                  dx_masked=gm if want_gm else None, mask=nxt)
+            if mg_dw is not None:
+                dw_items.append((gm.view(mg_dw["d_red"].M, mg_dw["d_red"].N), mg_dw["a4"], ar.g(f"{mg_dw['pm']}.reduction.weight"), None))
+                dwq.submit(cc, dw_items, dw_calls, exclusive_dw)
+                mg_dw["dw_done"] = True
             del dqkv
             blocks[k] = None  # free this block's activations as we go
             dw_items = dw_calls = weight_grad = None

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* 2: BatchNorm scratch of 2C + 1 floats; 3: fused MLP, warps, Mixup; 4: row-sharded loss head, weight-gradient launch queries */
-#define FOCAL_ABI_VERSION 5
+#define FOCAL_ABI_VERSION 6
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -187,6 +187,10 @@ typedef struct {
 } focal_dw_problem;
 int focal_linear_bwd_weight_group(int dtype, int n, const focal_dw_problem* problems, void* stream);
 int focal_linear_bwd_weight_group_supported(int dtype, int M, int N, int K);
+/* Narrower problems -- M % 64 == 0 and N, K % 64 == 0 for EVERY problem, at most 4 of them (the qkv [192, 64] and proj [64, 64]
+ * gradients of a 64-channel block) -- run as one launch of the 64 x 64 ring tiles behind a problem table (csrc/gemm_dw_ring.hpp,
+ * always atomics).  focal_linear_bwd_weight_group_kind: 2 = a shape for the 128 x 128 group, 1 = for the 64-tile group only, 0 = neither. */
+int focal_linear_bwd_weight_group_kind(int dtype, int M, int N, int K);
 /* workgroups that launch consists of (profiler-trace matching, as focal_linear_bwd_weight_workgroups); 0 = invalid */
 int focal_linear_bwd_weight_group_workgroups(int dtype, int n, const focal_dw_problem* problems);
 
@@ -376,6 +380,13 @@ typedef struct { float beta1, beta2, eps, weight_decay; int l2_decay; /* 0: deco
 int focal_adamw_multi(const focal_adamw_desc* d, int nseg, float* const* p, const float* const* g, float* const* m,
                       float* const* v, void* const* shadow_bf16, const long* n, const float* lr_dev,
                       const uint32_t* rng_state, void* stream);
+/* The same update with the step's bookkeeping folded in: the step count used is step_state[1] + 1, and the workgroup that finishes last
+ * advances step_state (as focal_rng_advance would have before the call) and, when non-NULL, seed_state (the dropout seed words of the
+ * next forward pass) -- two one-thread launches less on the serial tail of every step.  step_state[2] is the kernel's ticket word
+ * (zero between calls); 4 words as made by the binding's new_rng_state. */
+int focal_adamw_multi_advance(const focal_adamw_desc* d, int nseg, float* const* p, const float* const* g, float* const* m,
+                              float* const* v, void* const* shadow_bf16, const long* n, const float* lr_dev,
+                              uint32_t* step_state, uint32_t* seed_state, void* stream);
 /* fp32 -> bf16 cast of a weight segment (refreshing the shadow after load_state_dict) */
 int focal_cast_bf16(const float* src, void* dst, long n, void* stream);
 

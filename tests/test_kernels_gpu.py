@@ -220,8 +220,41 @@ def test_weight_gradient_group_kernel(ops, rows, C, exclusive):
     for i, ((dy, x, dw, db), (rw, rb)) in enumerate(zip(items, refs)):
         assert rel_err(dw - 0.25 * (i + 1), 2 * rw) < 2e-4, i
     assert not ops.dw_group_supported(c, rows, 64, 128) and not ops.dw_group_supported(c, rows + 8, 128, 128)
-    with pytest.raises(Exception):
-        ops.linear_bwd_weight_group(c, [(rnd(rows, 64, dtype=ct), rnd(rows, 128, dtype=ct), torch.zeros(64, 128, device=DEV), None)])
+    with pytest.raises(Exception):  # (a [64, 128] problem is legal: it runs on the 64-tile group, test_weight_gradient_ring_group_kernel)
+        ops.linear_bwd_weight_group(c, [(rnd(rows, 96, dtype=ct), rnd(rows, 128, dtype=ct), torch.zeros(96, 128, device=DEV), None)])
+
+
+@pytest.mark.parametrize("rows,C,nprob", [(147456, 64, 2), (4608, 64, 2), (2304, 64, 4), (64, 64, 2), (1152, 192, 3)])
+def test_weight_gradient_ring_group_kernel(ops, rows, C, nprob):
+    """focal_linear_bwd_weight_group on shapes the 128 x 128 tiles do not take (a 64-channel block: proj [C, C] and qkv [3C, C], plus fc2
+    [C, 4C] / fc1 [4C, C] where the MLP branch is not fused): one launch of the 64 x 64 ring tiles behind a problem table =
+    the single launches; accumulation into non-zero buffers, with and without bias, token ranges of one stage and of thousands."""
+    ct = torch.bfloat16
+    c = ops.code(ct)
+    shapes = [(C, C), (3 * C, C), (C, 4 * C), (4 * C, C)][:nprob]
+    items, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        assert ops.dw_group_kind(c, rows, N, K) >= 1
+        dy, x = rnd(rows, N, seed=400 + i, dtype=ct), rnd(rows, K, seed=410 + i, dtype=ct)
+        dw = torch.full((N, K), 0.5 * (i + 1), device=DEV)
+        db = torch.full((N,), -1.0, device=DEV) if i != 0 else None
+        items.append((dy, x, dw, db))
+        refs.append((dy.float().t() @ x.float(), dy.float().sum(0)))
+    assert any(ops.dw_group_kind(c, rows, N, K) == 1 for N, K in shapes)
+    wgs = ops.linear_bwd_weight_group_workgroups(c, items)
+    tiles = sum((N // 64) * (K // 64) for N, K in shapes)
+    assert tiles <= wgs <= max(256, tiles)
+    ops.linear_bwd_weight_group(c, items)
+    for i, ((dy, x, dw, db), (rw, rb)) in enumerate(zip(items, refs)):
+        assert rel_err(dw - 0.5 * (i + 1), rw) < 2e-4, i
+        if db is not None:
+            assert rel_err(db + 1.0, rb) < 1e-4, i
+    ops.linear_bwd_weight_group(c, items)  # accumulates
+    for i, ((dy, x, dw, db), (rw, rb)) in enumerate(zip(items, refs)):
+        assert rel_err(dw - 0.5 * (i + 1), 2 * rw) < 2e-4, i
+    assert ops.dw_group_kind(c, rows, 128, 256) == 2 and ops.dw_group_kind(c, rows, 96, 64) == 0 and ops.dw_group_kind(c, rows + 8, 64, 64) == 0
+    with pytest.raises(Exception):  # five 64-tile problems: more than the table holds
+        ops.linear_bwd_weight_group(c, [items[0]] * 5)
 
 
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
@@ -467,6 +500,50 @@ def test_adamw_matches_torch(ops):
     assert (p - pt.detach()).abs().max().item() < 1e-6
     assert torch.equal(shadow, p.bfloat16())
     assert int(state[1]) == 3
+
+
+def test_adamw_advances_its_own_step_count(ops):
+    """focal_adamw_multi_advance: the update with step count state[1] + 1, then the last workgroup advances the step state and the dropout
+    seed state exactly as focal_rng_advance would have -- several segments (the last one carries the advance), a large one (2048
+    workgroups racing for the ticket) and a replayed hipGraph."""
+    n0, n1 = 2048 * 1024 + 64, 4096
+    p0, g0, p1, g1 = rnd(n0, seed=62), rnd(n0, seed=63), rnd(n1, seed=64), rnd(n1, seed=65)
+    lr = torch.full((1,), 1e-3, device=DEV)
+
+    def run(advance, steps=3, graph=False):
+        segs = [(p0.clone(), g0, torch.zeros(n0, device=DEV), torch.zeros(n0, device=DEV), torch.zeros(n0, dtype=torch.bfloat16, device=DEV)),
+                (p1.clone(), g1, torch.zeros(n1, device=DEV), torch.zeros(n1, device=DEV), torch.zeros(n1, dtype=torch.bfloat16, device=DEV))]
+        step, seed = ops.new_rng_state(0, DEV), ops.new_rng_state(99, DEV)
+
+        def one():
+            if advance:
+                ops.adamw_multi(segs, lr, step, advance=True, seed_state=seed)
+            else:
+                ops.rng_advance(step)
+                ops.rng_advance(seed)
+                ops.adamw_multi(segs, lr, step)
+        if graph:
+            one()
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=st):
+                    one()
+            for _ in range(steps - 1):  # (the capture itself runs nothing)
+                gr.replay()
+        else:
+            for _ in range(steps):
+                one()
+        torch.cuda.synchronize()
+        return segs, step, seed
+    ref, rstep, rseed = run(False)
+    for graph in (False, True):
+        got, step, seed = run(True, graph=graph)
+        assert torch.equal(step.cpu()[:2], rstep.cpu()[:2]) and int(step[1]) == 3 and int(step[2]) == 0
+        assert torch.equal(seed.cpu(), rseed.cpu())
+        for a, b in zip(got, ref):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
 
 
 def test_dropout_statistics_and_replay(ops):

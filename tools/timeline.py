@@ -18,7 +18,7 @@ import bench  # noqa: E402
 from focal_amd import ops  # noqa: E402
 
 SKIP = {"code", "torch_dtype", "zero_pool_reset", "pool_zeros", "zeros", "drop_desc", "new_rng_state", "linear_desc", "ln_desc", "mlp_desc",
-        "attn_desc", "conv_desc", "conv_in_desc", "bn_desc", "mlp_supported", "dw_group_supported", "resid_ln_supported", "bwd_data_ln_supported", "check",
+        "attn_desc", "conv_desc", "conv_in_desc", "bn_desc", "mlp_supported", "dw_group_supported", "dw_group_kind", "resid_ln_supported", "bwd_data_ln_supported", "check",
         "linear_bwd_weight_group_workgroups", "linear"}
 rec = []
 
