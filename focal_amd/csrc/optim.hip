@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   if (advance == 2) {
     __syncthreads();
     if (threadIdx.x == 0) {
-      __threadfence();
+      // (no fence: a workgroup's read of the step count has returned -- its value went into every store above -- before it takes a
+      // ticket, and the words written below are read by later kernels only.  __threadfence() here is an L2 write-back per workgroup:
+      // it tripled the kernel's duration)
       if (atomicAdd(rng_state + 2, 1u) == gridDim.x - 1) {
         rng_state[2] = 0u;
         rng_state[0] = focal_mix32(rng_state[0] + 0x9E3779B9U);
