@@ -22,9 +22,9 @@ struct Shard {
 };
 #include "gemm.hpp"
 
-#define LOSS_MAXP 32   // InfoNCE problems  (2 views x mod pairs + mods)
+#define LOSS_MAXP 20   // InfoNCE problems (2 views x mod pairs + mods = M^2 <= 16) and orthogonality problems (M (M + 1) <= 20) share the table type
 #define LOSS_MAXQ 8    // ranking problems  (2 views x mods)
-#define LOSS_MAXO 32   // orthogonality problems
+#define LOSS_MAXO 20   // orthogonality problems
 
 struct PairProb { const float* e1; const float* e2; float* d1; float* d2; int off1, off2, kind; };
 struct PairTable { PairProb p[LOSS_MAXP]; };
@@ -55,11 +55,11 @@ static inline int loss_row_blocks(long rows) {
 // Every (problem, step) block holds n2p = round_up(2b, 4) rows: the fp32 GEMM moves 16-byte chunks along its reduction index, so
 // the logical 2b (any b >= 2: the last batch of an epoch may hold an odd number of subsequences) is padded with zero rows /
 // columns that every row kernel skips.
-__global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, int dim, int width,
+__device__ __forceinline__ void nce_pack_body(const int bid, const int nb, const PairTable& tab, int p0, int nprob, int seq, int b, int n2p, int dim, int width,
                                                        float* __restrict__ Zn, float* __restrict__ nrm, float* __restrict__ zero5) {
   const int lane = threadIdx.x & 63;
-  if (zero5 != nullptr && blockIdx.x == 0 && threadIdx.x < 5) zero5[threadIdx.x] = 0.f;  // this rank's partial loss terms (first launch of the head)
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (zero5 != nullptr && bid == 0 && threadIdx.x < 5) zero5[threadIdx.x] = 0.f;  // this rank's partial loss terms (first launch of the head)
+  const long row = (long)bid * 4 + (threadIdx.x >> 6);
   const long rows = (long)nprob * seq * n2p;
   if (row >= rows) return;
   const int r = row % n2p, t = (row / n2p) % seq, p = row / ((long)n2p * seq);
@@ -80,14 +80,14 @@ __global__ __launch_bounds__(256) void nce_pack_kernel(PairTable tab, int p0, in
 
 // one wave per OWN row i of S[p,t]: lse over j != i, loss_i = lse_i - S[i][pos(i)].  Own row w of block blk (w = h * bl + k: view half
 // h, own subsequence k) is row i = h * b + r0 + k of the block; its lse goes to slot (gb0 + blk) * 2 bl + w of this rank's chunk.
-__global__ __launch_bounds__(256) void nce_rows_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, Shard sh, int gb0,
+__device__ __forceinline__ void nce_rows_body(const int bid, const int nb, const PairTable& tab, int p0, int nprob, int seq, int b, int n2p, Shard sh, int gb0,
                                                        const float* __restrict__ S, float* __restrict__ lse_own, float* __restrict__ lse_full,
                                                        float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
   const int n2 = 2 * b, own = 2 * sh.bl;
   const long rows = (long)nprob * seq * own;
   float acc0 = 0.f, acc1 = 0.f;  // contributions to terms[0] (shared family) / terms[1] (private family)
-  for (long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6); idx < rows; idx += (long)gridDim.x * 4) {
+  for (long idx = (long)bid * 4 + (threadIdx.x >> 6); idx < rows; idx += (long)nb * 4) {
     const long blk = idx / own;
     const int w = idx % own, i = (w / sh.bl) * b + sh.r0 + (w % sh.bl);
     const int p = blk / seq;
@@ -131,11 +131,11 @@ __global__ __launch_bounds__(256) void xchg_unpack_kernel(Shard sh, int nblk, in
 }
 
 // in place, OWN rows of S -> W (times the family weight): W_ij = [j != i](e^{S_ij - lse_i} + e^{S_ij - lse_j}) - 2 [j == pos(i)]
-__global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, Shard sh,
+__device__ __forceinline__ void nce_weights_body(const int bid, const int nb, const PairTable& tab, int p0, int nprob, int seq, int b, int n2p, Shard sh,
                                                           float* __restrict__ S, const float* __restrict__ lse, float w_shared, float w_private) {
   const int n2 = 2 * b, own = 2 * sh.bl;
   const long total = (long)nprob * seq * own * n2p;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+  for (long e = (long)bid * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
     const int j = e % n2p;
     const long idx = e / n2p, blk = idx / own;
     const int w = idx % own, i = (w / sh.bl) * b + sh.r0 + (w % sh.bl);
@@ -153,11 +153,11 @@ __global__ __launch_bounds__(256) void nce_weights_kernel(PairTable tab, int p0,
 }
 
 // dz = (dzn - zn (zn . dzn)) / ||z||, scattered (+=) to the right sample / half of the source embeddings; own rows only
-__global__ __launch_bounds__(256) void nce_unpack_kernel(PairTable tab, int p0, int nprob, int seq, int b, int n2p, int dim, int width, Shard sh,
+__device__ __forceinline__ void nce_unpack_body(const int bid, const int nb, const PairTable& tab, int p0, int nprob, int seq, int b, int n2p, int dim, int width, Shard sh,
                                                          const float* __restrict__ Zn, const float* __restrict__ nrm,
                                                          const float* __restrict__ dZn) {
   const int lane = threadIdx.x & 63, own = 2 * sh.bl;
-  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long idx = (long)bid * 4 + (threadIdx.x >> 6);
   if (idx >= (long)nprob * seq * own) return;
   const long blk = idx / own;
   const int w = idx % own, h = w / sh.bl, sq_ = sh.r0 + (w % sh.bl);  // view half, subsequence
@@ -174,10 +174,10 @@ __global__ __launch_bounds__(256) void nce_unpack_kernel(PairTable tab, int p0, 
 
 // ------------------------------------------------------------------------------------------------ ranking
 // (Bp = round_up(B, 4) rows per problem, zero padding: same reason as n2p above)
-__global__ __launch_bounds__(256) void rank_pack_kernel(RankTable tab, int nq, int B, int Bp, int dim, float* __restrict__ X,
+__device__ __forceinline__ void rank_pack_body(const int bid, const int nb, const RankTable& tab, int nq, int B, int Bp, int dim, float* __restrict__ X,
                                                         float* __restrict__ sq) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long row = (long)bid * 4 + (threadIdx.x >> 6);
   if (row >= (long)nq * Bp) return;
   const int q = row / Bp, s = row % Bp;
   if (s >= B) {
@@ -193,9 +193,9 @@ __global__ __launch_bounds__(256) void rank_pack_kernel(RankTable tab, int nq, i
 }
 
 // in place, own rows [rs0, rs0 + nr) of G -> D = sqrt(max(0, |x_p|^2 + |x_q|^2 - 2 G_pq)), D_pp = 0   (torch.cdist mm path, loss.py:117)
-__global__ __launch_bounds__(256) void rank_dist_kernel(int nq, int B, int Bp, int rs0, int nr, float* __restrict__ G, const float* __restrict__ sq) {
+__device__ __forceinline__ void rank_dist_body(const int bid, const int nb, int nq, int B, int Bp, int rs0, int nr, float* __restrict__ G, const float* __restrict__ sq) {
   const long total = (long)nq * nr * Bp;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+  for (long e = (long)bid * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
     const int c = e % Bp;
     const int r = rs0 + (int)((e / Bp) % nr);
     const long qb = (e / ((long)Bp * nr)) * Bp;
@@ -206,9 +206,9 @@ __global__ __launch_bounds__(256) void rank_dist_kernel(int nq, int B, int Bp, i
 }
 
 // Dbar[q][I][J] = mean of the seq x seq block (self pairs excluded), loss.py:118-124; own subsequences I, all J
-__global__ __launch_bounds__(256) void rank_blockmean_kernel(int nq, int b, int seq, int Bp, Shard sh, const float* __restrict__ D, float* __restrict__ Dbar) {
+__device__ __forceinline__ void rank_blockmean_body(const int bid, const int nb, int nq, int b, int seq, int Bp, Shard sh, const float* __restrict__ D, float* __restrict__ Dbar) {
   const long total = (long)nq * sh.bl * b;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+  for (long e = (long)bid * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
     const int J = e % b, I = sh.r0 + (int)((e / b) % sh.bl), q = e / ((long)b * sh.bl);
     const float* base = D + ((long)q * Bp + (long)I * seq) * Bp + (long)J * seq;
     float s = 0.f;
@@ -220,13 +220,13 @@ __global__ __launch_bounds__(256) void rank_blockmean_kernel(int nq, int b, int 
 
 // one wave per (q, own I): hinge over J != I (MarginRankingLoss(margin, y = -1), loss.py:127-135) and dL/dDbar of that row; the
 // row's diagonal mean goes to the exchange chunk (other ranks need it for the transposed hinge of their coefficient rows)
-__global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float margin, Shard sh, const float* __restrict__ Dbar,
+__device__ __forceinline__ void rank_hinge_body(const int bid, const int nb, int nq, int b, float margin, Shard sh, const float* __restrict__ Dbar,
                                                          float* __restrict__ dDbar, float* __restrict__ diag_own, float* __restrict__ diag_full,
                                                          float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
   const float inv = 1.0f / ((float)b * (float)(b - 1));
   float acc = 0.f;
-  for (long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6); idx < (long)nq * sh.bl; idx += (long)gridDim.x * 4) {
+  for (long idx = (long)bid * 4 + (threadIdx.x >> 6); idx < (long)nq * sh.bl; idx += (long)nb * 4) {
     const int I = sh.r0 + (int)(idx % sh.bl);
     const long row = (idx / sh.bl) * b + I;
     const float* d = Dbar + row * b;
@@ -255,13 +255,13 @@ __global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float ma
 // in place, own rows of D -> E = w_rank * (A_pq + A_qp) / D_pq, A_pq = dDbar[I(p)][J(q)] / count(I, J); rowsum[p] = sum_q E_pq.
 // dDbar[J][I] of a column's subsequence J is re-derived from its diagonal mean (gathered: diag[q][J]) and Dbar[I][J] (block means are symmetric
 // up to the summation order of the 16 distances): -inv where the hinge of row J is active against I.
-__global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq, int Bp, float w_rank, float margin, Shard sh, float* __restrict__ D,
+__device__ __forceinline__ void rank_coeff_body(const int bid, const int nb, int nq, int b, int seq, int Bp, float w_rank, float margin, Shard sh, float* __restrict__ D,
                                                          const float* __restrict__ Dbar, const float* __restrict__ dDbar,
                                                          const float* __restrict__ diag, float* __restrict__ rowsum) {
   const int lane = threadIdx.x & 63;
   const int B = b * seq, nr = sh.bl * seq;
   const float inv = 1.0f / ((float)b * (float)(b - 1));
-  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long idx = (long)bid * 4 + (threadIdx.x >> 6);
   if (idx >= (long)nq * nr) return;
   const int q = idx / nr, p = sh.r0 * seq + (int)(idx % nr), I = p / seq;
   const long row = (long)q * Bp + p;
@@ -289,10 +289,10 @@ __global__ __launch_bounds__(256) void rank_coeff_kernel(int nq, int b, int seq,
   if (lane == 0) rowsum[row] = rs;
 }
 
-__global__ __launch_bounds__(256) void rank_grad_kernel(RankTable tab, int nq, int Bp, int dim, int rs0, int nr, const float* __restrict__ X,
+__device__ __forceinline__ void rank_grad_body(const int bid, const int nb, const RankTable& tab, int nq, int Bp, int dim, int rs0, int nr, const float* __restrict__ X,
                                                         const float* __restrict__ rowsum, const float* __restrict__ EX) {
   const long total = (long)nq * nr * dim;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+  for (long e = (long)bid * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
     const int c = e % dim, s = rs0 + (int)((e / dim) % nr), q = e / ((long)dim * nr);
     const long at = ((long)q * Bp + s) * dim + c;
     atomicAdd(tab.d[q] + (long)s * dim + c, rowsum[(long)q * Bp + s] * X[at] - EX[at]);
@@ -301,11 +301,11 @@ __global__ __launch_bounds__(256) void rank_grad_kernel(RankTable tab, int nq, i
 
 // ------------------------------------------------------------------------------------------------ orthogonality
 // CosineEmbeddingLoss(target = -1, margin 0, mean) = mean(max(0, cos)), loss.py:89-106; one wave per sample.
-__global__ __launch_bounds__(256) void orth_kernel(PairTable tab, int nprob, int B, int dim, int width, float w_orth, int rs0, int nr,
+__device__ __forceinline__ void orth_body(const int bid, const int nb, const PairTable& tab, int nprob, int B, int dim, int width, float w_orth, int rs0, int nr,
                                                    float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
   float acc = 0.f;
-  for (long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6); idx < (long)nprob * nr; idx += (long)gridDim.x * 4) {
+  for (long idx = (long)bid * 4 + (threadIdx.x >> 6); idx < (long)nprob * nr; idx += (long)nb * 4) {
     const int p = idx / nr, s = rs0 + (int)(idx % nr);
     const PairProb pr = tab.p[p];
     const float* x1 = pr.e1 + (long)s * dim + pr.off1;
@@ -330,8 +330,146 @@ __global__ __launch_bounds__(256) void orth_kernel(PairTable tab, int nprob, int
   block_term_add(acc, terms + 2);
 }
 
-// terms[0..3] = sum over ranks of the partial terms in the gathered chunks, terms[4] = their weighted sum
-__global__ void loss_total_kernel(float* terms, const float* __restrict__ xall, Shard sh, float ws, float wp, float wo, float wr) {
+// rank_dist + rank_blockmean + rank_hinge of one (problem q, own subsequence I) in ONE pass, one wave per row: lane J turns the seq x seq
+// block (I, J) of the Gram matrix into distances (written back in place: phase B reads them), keeps the block mean, and the hinge over
+// the row's b means follows through a wave-private LDS row (b <= RANK_ROW_MAX_B; longer rows use the three separate passes).
+#define RANK_ROW_MAX_B 1024
+__device__ __forceinline__ void rank_rows_body(const int bid, const int nb, int nq, int b, int seq, int B, int Bp, float margin, Shard sh,
+                                               float* __restrict__ G, const float* __restrict__ sq, float* __restrict__ Dbar,
+                                               float* __restrict__ dDbar, float* __restrict__ diag_own, float* __restrict__ diag_full,
+                                               float* __restrict__ terms) {
+  __shared__ float means[4][RANK_ROW_MAX_B];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* mrow = means[wave];
+  const float inv = 1.0f / ((float)b * (float)(b - 1));
+  float acc = 0.f;
+  for (long idx = (long)bid * 4 + wave; idx < (long)nq * sh.bl; idx += (long)nb * 4) {
+    const int I = sh.r0 + (int)(idx % sh.bl), q = (int)(idx / sh.bl);
+    const long qb = (long)q * Bp, row = (long)q * b + I;
+    for (int J = lane; J < b; J += 64) {
+      float s = 0.f;
+      for (int a = 0; a < seq; ++a) {
+        const int p = I * seq + a;
+        const float sp = sq[qb + p];
+        float* g = G + (qb + p) * Bp + (long)J * seq;
+        for (int c = 0; c < seq; ++c) {
+          const int col = J * seq + c;
+          const float d2 = sp + sq[qb + col] - 2.0f * g[c];
+          const float dist = (p == col) ? 0.f : sqrtf(fmaxf(d2, 0.f));
+          g[c] = dist;
+          s += dist;  // (the self pairs hold exact zeros; summation order = rank_blockmean's: a outer, c inner)
+        }
+      }
+      const float mean = s / (float)(seq * seq - (I == J ? seq : 0));
+      Dbar[row * b + J] = mean;
+      mrow[J] = mean;
+    }
+    for (int c = B + lane; c < Bp; c += 64)  // padding columns of the own rows
+      for (int a = 0; a < seq; ++a) G[(qb + I * seq + a) * Bp + c] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float dii = mrow[I];
+    float loss = 0.f, cnt = 0.f;
+    for (int J = lane; J < b; J += 64) {
+      if (J == I) continue;
+      const float h = dii - mrow[J] + margin;
+      const bool on = h > 0.f;
+      loss += on ? h : 0.f;
+      cnt += on ? 1.f : 0.f;
+      dDbar[row * b + J] = on ? -inv : 0.f;
+    }
+    loss = wave_sum(loss);
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+      dDbar[row * b + I] = cnt * inv;
+      diag_own[idx] = dii;
+      diag_full[row] = dii;
+      acc += loss * inv;
+    }
+    __builtin_amdgcn_wave_barrier();  // the LDS row is rewritten by the wave's next item
+  }
+  block_term_add(acc, terms + 3);
+}
+
+// ------------------------------------------------------------------------------------------------ launches
+// The head is ~20 small dependent kernels on the step's serial path (both encoder streams wait for it): what it costs is launches,
+// not bytes.  Kernels that do not depend on each other run as ONE launch -- a workgroup picks its part from blockIdx ranges --
+// which leaves memset, pack, 3 products, rows | coefficients, 3 products, gradients: 11 launches instead of 22 (one rank).
+struct NceGroup { int p0, nprob, width, gb0; float* Zn; float* dZn; float* nrm; float* S; float* lse; int blocks; };
+struct HeadArgs {
+  PairTable nce, orth;
+  RankTable rk;
+  NceGroup g[2];
+  Shard sh;
+  int seq, b, n2p, dim, B, Bp, Q, O, half;
+  float margin, w_orth, w_rank, w_shared, w_private;
+  float* X; float* sq; float* D; float* Dbar; float* dDbar; float* diag; float* rowsum; float* EX;
+  float* chunk; float* pterms;   // this rank's exchange chunk / its partial-term slots
+  const float* xall; float* terms;
+  int blocks_rank, blocks_orth, blocks_total;  // parts three, four, five of the launch
+  int fused_rank_rows;
+};
+
+__global__ __launch_bounds__(256) void head_pack_kernel(const HeadArgs a) {
+  int bid = blockIdx.x;
+  if (bid == 0 && threadIdx.x < 5) a.pterms[threadIdx.x] = 0.f;  // this rank's partial loss terms (nothing in this launch adds to them)
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (bid < a.g[k].blocks) {
+      nce_pack_body(bid, a.g[k].blocks, a.nce, a.g[k].p0, a.g[k].nprob, a.seq, a.b, a.n2p, a.dim, a.g[k].width, a.g[k].Zn, a.g[k].nrm, nullptr);
+      return;
+    }
+    bid -= a.g[k].blocks;
+  }
+  rank_pack_body(bid, a.blocks_rank, a.rk, a.Q, a.B, a.Bp, a.dim, a.X, a.sq);
+}
+
+__global__ __launch_bounds__(256) void head_rows_kernel(const HeadArgs a) {
+  int bid = blockIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (bid < a.g[k].blocks) {
+      nce_rows_body(bid, a.g[k].blocks, a.nce, a.g[k].p0, a.g[k].nprob, a.seq, a.b, a.n2p, a.sh, a.g[k].gb0, a.g[k].S, a.chunk, a.g[k].lse, a.pterms);
+      return;
+    }
+    bid -= a.g[k].blocks;
+  }
+  if (bid < a.blocks_rank) {
+    rank_rows_body(bid, a.blocks_rank, a.Q, a.b, a.seq, a.B, a.Bp, a.margin, a.sh, a.D, a.sq, a.Dbar, a.dDbar, a.chunk + a.sh.o_diag, a.diag, a.pterms);
+    return;
+  }
+  bid -= a.blocks_rank;
+  orth_body(bid, a.blocks_orth, a.orth, a.O, a.B, a.dim, a.half, a.w_orth, a.sh.r0 * a.seq, a.sh.bl * a.seq, a.pterms);
+}
+
+// rows pass when the ranking rows are too long for rank_rows_body: InfoNCE rows + distances + orthogonality (block means and hinge follow)
+__global__ __launch_bounds__(256) void head_rows_split_kernel(const HeadArgs a) {
+  int bid = blockIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (bid < a.g[k].blocks) {
+      nce_rows_body(bid, a.g[k].blocks, a.nce, a.g[k].p0, a.g[k].nprob, a.seq, a.b, a.n2p, a.sh, a.g[k].gb0, a.g[k].S, a.chunk, a.g[k].lse, a.pterms);
+      return;
+    }
+    bid -= a.g[k].blocks;
+  }
+  if (bid < a.blocks_rank) {
+    rank_dist_body(bid, a.blocks_rank, a.Q, a.B, a.Bp, a.sh.r0 * a.seq, a.sh.bl * a.seq, a.D, a.sq);
+    return;
+  }
+  bid -= a.blocks_rank;
+  orth_body(bid, a.blocks_orth, a.orth, a.O, a.B, a.dim, a.half, a.w_orth, a.sh.r0 * a.seq, a.sh.bl * a.seq, a.pterms);
+}
+__global__ __launch_bounds__(256) void rank_blockmean_kernel(int nq, int b, int seq, int Bp, Shard sh, const float* __restrict__ D, float* __restrict__ Dbar) {
+  rank_blockmean_body(blockIdx.x, gridDim.x, nq, b, seq, Bp, sh, D, Dbar);
+}
+__global__ __launch_bounds__(256) void rank_hinge_kernel(int nq, int b, float margin, Shard sh, const float* __restrict__ Dbar, float* __restrict__ dDbar,
+                                                         float* __restrict__ diag_own, float* __restrict__ diag_full, float* __restrict__ terms) {
+  rank_hinge_body(blockIdx.x, gridDim.x, nq, b, margin, sh, Dbar, dDbar, diag_own, diag_full, terms);
+}
+
+__device__ __forceinline__ void loss_total_body(float* terms, const float* __restrict__ xall, const Shard& sh, float ws, float wp, float wo, float wr) {
   float t[4];
   for (int k = 0; k < 4; ++k) {
     t[k] = 0.f;
@@ -339,6 +477,38 @@ __global__ void loss_total_kernel(float* terms, const float* __restrict__ xall, 
     terms[k] = t[k];
   }
   terms[4] = ws * t[0] + wp * t[1] + wo * t[2] + wr * t[3];
+}
+
+// coefficient pass: softmax weights of both InfoNCE groups, ranking coefficients, and (one thread of an extra workgroup) the loss terms
+__global__ __launch_bounds__(256) void head_coeff_kernel(const HeadArgs a) {
+  int bid = blockIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (bid < a.g[k].blocks) {
+      nce_weights_body(bid, a.g[k].blocks, a.nce, a.g[k].p0, a.g[k].nprob, a.seq, a.b, a.n2p, a.sh, a.g[k].S, a.g[k].lse, a.w_shared, a.w_private);
+      return;
+    }
+    bid -= a.g[k].blocks;
+  }
+  if (bid < a.blocks_rank) {
+    rank_coeff_body(bid, a.blocks_rank, a.Q, a.b, a.seq, a.Bp, a.w_rank, a.margin, a.sh, a.D, a.Dbar, a.dDbar, a.diag, a.rowsum);
+    return;
+  }
+  if (threadIdx.x == 0) loss_total_body(a.terms, a.xall, a.sh, a.w_shared, a.w_private, a.w_orth, a.w_rank);
+}
+
+// gradient pass: dL/dz of both InfoNCE groups (normalisation backward, scatter) and the ranking gradient
+__global__ __launch_bounds__(256) void head_grad_kernel(const HeadArgs a) {
+  int bid = blockIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (bid < a.g[k].blocks) {
+      nce_unpack_body(bid, a.g[k].blocks, a.nce, a.g[k].p0, a.g[k].nprob, a.seq, a.b, a.n2p, a.dim, a.g[k].width, a.sh, a.g[k].Zn, a.g[k].nrm, a.g[k].dZn);
+      return;
+    }
+    bid -= a.g[k].blocks;
+  }
+  rank_grad_body(bid, a.blocks_rank, a.rk, a.Q, a.Bp, a.dim, a.sh.r0 * a.seq, a.sh.bl * a.seq, a.X, a.rowsum, a.EX);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -457,11 +627,43 @@ template <typename F> static int over_own_halves(const LossPlan& pl, F&& f) {
   return FOCAL_OK;
 }
 
+// the argument block of the fused launches (block counts are filled in per launch)
+static void head_args(const focal_loss_desc* d, const LossPlan& pl, const float* const* feats, float* const* dfeats, float* chunk,
+                      const float* xall, float* terms, float* ws, HeadArgs* a) {
+  LossTables tb;
+  loss_tables(d, feats, dfeats, &tb);
+  memset(a, 0, sizeof(*a));
+  a->nce = tb.nce; a->orth = tb.orth; a->rk = tb.rk;
+  a->sh = pl.sh;
+  a->seq = d->seq; a->b = pl.b; a->n2p = pl.n2p; a->dim = d->dim; a->B = d->B; a->Bp = pl.Bp; a->Q = pl.Q; a->O = pl.O; a->half = d->dim / 2;
+  a->margin = d->margin; a->w_orth = d->w_orth; a->w_rank = d->w_rank; a->w_shared = d->w_shared; a->w_private = d->w_private;
+  a->X = ws + pl.off_X; a->sq = ws + pl.off_sq; a->D = ws + pl.off_D; a->Dbar = ws + pl.off_dbar; a->dDbar = ws + pl.off_ddbar;
+  a->diag = ws + pl.off_diag; a->rowsum = ws + pl.off_rs; a->EX = ws + pl.off_ex;
+  a->chunk = chunk; a->pterms = chunk ? chunk + pl.sh.o_terms : nullptr;
+  a->xall = xall; a->terms = terms;
+  // the two InfoNCE families may have different widths (tag == "noPrivate"), so they are two groups of problems
+  size_t zoff = 0, roff = 0;
+  int gb0 = 0;
+  for (int grp = 0; grp < 2; ++grp) {
+    NceGroup& g = a->g[grp];
+    g.p0 = grp == 0 ? 0 : pl.P_sh; g.nprob = grp == 0 ? pl.P_sh : pl.P_pr; g.width = grp == 0 ? pl.w_sh : pl.w_pr;
+    const long rows = (long)g.nprob * d->seq * pl.n2p;
+    g.gb0 = gb0;
+    g.Zn = ws + pl.off_zn + zoff; g.dZn = ws + pl.off_dzn + zoff; g.nrm = ws + pl.off_nrm + roff;
+    g.S = ws + pl.off_S + roff * pl.n2p; g.lse = ws + pl.off_lse + roff;
+    zoff += (size_t)rows * g.width;
+    roff += rows;
+    gb0 += g.nprob * d->seq;
+  }
+  a->fused_rank_rows = pl.b <= RANK_ROW_MAX_B;
+}
+static inline int capped(long blocks, int cap) { return (int)(blocks > cap ? cap : (blocks < 1 ? 1 : blocks)); }
+
 // Phase A: everything up to the quantities other ranks need -- zero the gradients, InfoNCE similarity rows + lse, the ranking
 // distances, block means and hinge rows, the orthogonality term; this rank's lse / diagonal means / partial terms -> `chunk`.
 static int loss_phase_a(const focal_loss_desc* d, const LossPlan& pl, const float* const* feats, float* terms, float* const* dfeats,
                         float* chunk, float* ws, hipStream_t st) {
-  const int M = d->n_mod, B = d->B, dim = d->dim, seq = d->seq, b = pl.b, n2p = pl.n2p, Bp = pl.Bp, half = d->dim / 2;
+  const int M = d->n_mod, B = d->B, dim = d->dim, seq = d->seq, n2p = pl.n2p, Bp = pl.Bp;
   const Shard sh = pl.sh;
   // the binding hands over ONE allocation [2M gradients | terms]: a single memset node instead of 2M + 1
   const size_t gbytes = (size_t)B * dim * sizeof(float);
@@ -482,54 +684,40 @@ static int loss_phase_a(const focal_loss_desc* d, const LossPlan& pl, const floa
     (void)hipMemsetAsync(terms, 0, 5 * sizeof(float), st);
     for (int i = 0; i < 2 * M; ++i) (void)hipMemsetAsync(dfeats[i], 0, gbytes, st);
   }
-  float* pterms = chunk + sh.o_terms;  // partial terms of this rank (zeroed by the first pack launch)
-  bool zeroed = false;
-  LossTables tb;
-  loss_tables(d, feats, dfeats, &tb);
+  HeadArgs a;
+  head_args(d, pl, feats, dfeats, chunk, nullptr, terms, ws, &a);
+  const int Q = pl.Q, rs0 = sh.r0 * seq, nr = sh.bl * seq;
 
-  // ---- InfoNCE: the two families may have different widths (tag == "noPrivate"), so they run as two groups
-  size_t zoff = 0, roff = 0;
-  int gb0 = 0;
-  for (int grp = 0; grp < 2; ++grp) {
-    const int p0 = grp == 0 ? 0 : pl.P_sh, nprob = grp == 0 ? pl.P_sh : pl.P_pr, width = grp == 0 ? pl.w_sh : pl.w_pr;
-    if (nprob == 0) continue;
-    const long rows = (long)nprob * seq * n2p, own_rows = (long)nprob * seq * 2 * sh.bl;
-    float* Zn = ws + pl.off_zn + zoff;
-    float* nrm = ws + pl.off_nrm + roff;
-    float* S = ws + pl.off_S + roff * n2p;
-    hipLaunchKernelGGL(nce_pack_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, dim, width, Zn, nrm,
-                       zeroed ? nullptr : pterms);
-    zeroed = true;
+  // ---- launch 1: normalised InfoNCE rows of both groups, ranking rows + squared norms (this rank's partial terms zeroed)
+  for (int k = 0; k < 2; ++k) a.g[k].blocks = a.g[k].nprob ? ceil_div((long)a.g[k].nprob * seq * n2p, 4) : 0;
+  a.blocks_rank = ceil_div((long)Q * Bp, 4);
+  hipLaunchKernelGGL(head_pack_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank), dim3(256), 0, st, a);
+
+  // ---- products: similarity rows S = Zn Zn^T / T per group, Gram rows G = X X^T (exact-fp32 MFMA)
+  for (int k = 0; k < 2; ++k) {
+    const NceGroup& g = a.g[k];
+    if (g.nprob == 0) continue;
     if (int rc = over_own_halves(pl, [&](int row0, int nrow) {
-          return f32_gemm(false, nrow, n2p, width, Zn + (long)row0 * width, width, (long)n2p * width, Zn, width, (long)n2p * width,
-                          S + (long)row0 * n2p, n2p, (long)n2p * n2p, nprob * seq, 1.0f / d->temperature, st);
+          return f32_gemm(false, nrow, n2p, g.width, g.Zn + (long)row0 * g.width, g.width, (long)n2p * g.width, g.Zn, g.width, (long)n2p * g.width,
+                          g.S + (long)row0 * n2p, n2p, (long)n2p * n2p, g.nprob * seq, 1.0f / d->temperature, st);
         })) return rc;
-    hipLaunchKernelGGL(nce_rows_kernel, dim3(loss_row_blocks(own_rows)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, sh, gb0, S, chunk,
-                       ws + pl.off_lse + roff, pterms);
-    zoff += (size_t)rows * width;
-    roff += rows;
-    gb0 += nprob * seq;
   }
+  const int mrows = sh.world == 1 ? Bp : nr;
+  if (int rc = f32_gemm(false, mrows, Bp, dim, a.X + (long)rs0 * dim, dim, (long)Bp * dim, a.X, dim, (long)Bp * dim, a.D + (long)rs0 * Bp, Bp,
+                        (long)Bp * Bp, Q, 1.0f, st)) return rc;
 
-  // ---- temporal ranking, loss.py:189-192: distances, block means and hinges of the own rows
-  {
-    const int Q = pl.Q, rs0 = sh.r0 * seq, nr = sh.bl * seq;
-    float* X = ws + pl.off_X; float* sq = ws + pl.off_sq;
-    float* D = ws + pl.off_D; float* Dbar = ws + pl.off_dbar; float* dDbar = ws + pl.off_ddbar;
-    hipLaunchKernelGGL(rank_pack_kernel, dim3(ceil_div((long)Q * Bp, 4)), dim3(256), 0, st, tb.rk, Q, B, Bp, dim, X, sq);
-    const int mrows = sh.world == 1 ? Bp : nr;
-    if (int rc = f32_gemm(false, mrows, Bp, dim, X + (long)rs0 * dim, dim, (long)Bp * dim, X, dim, (long)Bp * dim, D + (long)rs0 * Bp, Bp,
-                          (long)Bp * Bp, Q, 1.0f, st)) return rc;
-    int eb = ceil_div((long)Q * nr * Bp, 256);
-    if (eb > 8192) eb = 8192;
-    hipLaunchKernelGGL(rank_dist_kernel, dim3(eb), dim3(256), 0, st, Q, B, Bp, rs0, nr, D, sq);
-    int bb = ceil_div((long)Q * sh.bl * b, 256);
-    if (bb > 4096) bb = 4096;
-    hipLaunchKernelGGL(rank_blockmean_kernel, dim3(bb), dim3(256), 0, st, Q, b, seq, Bp, sh, D, Dbar);
-    hipLaunchKernelGGL(rank_hinge_kernel, dim3(loss_row_blocks((long)Q * sh.bl)), dim3(256), 0, st, Q, b, d->margin, sh, Dbar, dDbar,
-                       chunk + sh.o_diag, ws + pl.off_diag, pterms);
-    // ---- orthogonality (row-local)
-    hipLaunchKernelGGL(orth_kernel, dim3(loss_row_blocks((long)pl.O * nr)), dim3(256), 0, st, tb.orth, pl.O, B, dim, half, d->w_orth, rs0, nr, pterms);
+  // ---- launch 2: lse rows + InfoNCE terms, ranking distances / block means / hinges (loss.py:189-192), orthogonality (row-local)
+  for (int k = 0; k < 2; ++k) a.g[k].blocks = a.g[k].nprob ? loss_row_blocks((long)a.g[k].nprob * seq * 2 * sh.bl) : 0;
+  a.blocks_orth = loss_row_blocks((long)pl.O * nr);
+  if (a.fused_rank_rows) {
+    a.blocks_rank = loss_row_blocks((long)Q * sh.bl);
+    hipLaunchKernelGGL(head_rows_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank + a.blocks_orth), dim3(256), 0, st, a);
+  } else {
+    a.blocks_rank = capped(ceil_div((long)Q * nr * Bp, 256), 8192);
+    hipLaunchKernelGGL(head_rows_split_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank + a.blocks_orth), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(rank_blockmean_kernel, dim3(capped(ceil_div((long)Q * sh.bl * pl.b, 256), 4096)), dim3(256), 0, st, Q, pl.b, seq, Bp, sh, a.D, a.Dbar);
+    hipLaunchKernelGGL(rank_hinge_kernel, dim3(loss_row_blocks((long)Q * sh.bl)), dim3(256), 0, st, Q, pl.b, d->margin, sh, a.Dbar, a.dDbar,
+                       chunk + sh.o_diag, a.diag, a.pterms);
   }
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
@@ -541,48 +729,33 @@ static int loss_phase_b(const focal_loss_desc* d, const LossPlan& pl, const floa
                         const float* xall, float* ws, hipStream_t st) {
   const int dim = d->dim, seq = d->seq, b = pl.b, n2 = pl.n2, n2p = pl.n2p, Bp = pl.Bp;
   const Shard sh = pl.sh;
-  LossTables tb;
-  loss_tables(d, feats, dfeats, &tb);
+  HeadArgs a;
+  head_args(d, pl, feats, dfeats, nullptr, xall, terms, ws, &a);
   if (sh.world > 1) {  // (one rank: phase A has written every row's lse / diagonal mean in place already)
     const int nblk = (pl.P_sh + pl.P_pr) * seq;
-    int ub = ceil_div((long)nblk * n2 + (long)pl.Q * b, 256);
-    if (ub > 1024) ub = 1024;
-    hipLaunchKernelGGL(xchg_unpack_kernel, dim3(ub), dim3(256), 0, st, sh, nblk, b, n2p, pl.Q, xall, ws + pl.off_lse, ws + pl.off_diag);
+    hipLaunchKernelGGL(xchg_unpack_kernel, dim3(capped(ceil_div((long)nblk * n2 + (long)pl.Q * b, 256), 1024)), dim3(256), 0, st, sh, nblk, b, n2p, pl.Q,
+                       xall, ws + pl.off_lse, ws + pl.off_diag);
   }
-  size_t zoff = 0, roff = 0;
-  for (int grp = 0; grp < 2; ++grp) {
-    const int p0 = grp == 0 ? 0 : pl.P_sh, nprob = grp == 0 ? pl.P_sh : pl.P_pr, width = grp == 0 ? pl.w_sh : pl.w_pr;
-    if (nprob == 0) continue;
-    const long rows = (long)nprob * seq * n2p, own_rows = (long)nprob * seq * 2 * sh.bl;
-    float* Zn = ws + pl.off_zn + zoff;
-    float* dZn = ws + pl.off_dzn + zoff;
-    float* nrm = ws + pl.off_nrm + roff;
-    float* S = ws + pl.off_S + roff * n2p;
-    int eb = ceil_div(own_rows * n2p, 256);
-    if (eb > 8192) eb = 8192;
-    hipLaunchKernelGGL(nce_weights_kernel, dim3(eb), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, sh, S, ws + pl.off_lse + roff, d->w_shared,
-                       d->w_private);
+  const int Q = pl.Q, rs0 = sh.r0 * seq, nr = sh.bl * seq;
+  // ---- launch 3: softmax coefficients of both groups (in place of S), ranking coefficients (in place of D) + their row sums, loss terms
+  for (int k = 0; k < 2; ++k) a.g[k].blocks = a.g[k].nprob ? capped(ceil_div((long)a.g[k].nprob * seq * 2 * sh.bl * n2p, 256), 8192) : 0;
+  a.blocks_rank = ceil_div((long)Q * nr, 4);
+  hipLaunchKernelGGL(head_coeff_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank + 1), dim3(256), 0, st, a);
+  // ---- products: dZn = W Zn per group, EX = E X
+  for (int k = 0; k < 2; ++k) {
+    const NceGroup& g = a.g[k];
+    if (g.nprob == 0) continue;
     if (int rc = over_own_halves(pl, [&](int row0, int nrow) {
-          return f32_gemm(true, nrow, width, n2p, S + (long)row0 * n2p, n2p, (long)n2p * n2p, Zn, width, (long)n2p * width,
-                          dZn + (long)row0 * width, width, (long)n2p * width, nprob * seq, 1.0f / ((float)seq * n2 * d->temperature), st);
+          return f32_gemm(true, nrow, g.width, n2p, g.S + (long)row0 * n2p, n2p, (long)n2p * n2p, g.Zn, g.width, (long)n2p * g.width,
+                          g.dZn + (long)row0 * g.width, g.width, (long)n2p * g.width, g.nprob * seq, 1.0f / ((float)seq * n2 * d->temperature), st);
         })) return rc;
-    hipLaunchKernelGGL(nce_unpack_kernel, dim3(ceil_div(own_rows, 4)), dim3(256), 0, st, tb.nce, p0, nprob, seq, b, n2p, dim, width, sh, Zn, nrm, dZn);
-    zoff += (size_t)rows * width;
-    roff += rows;
   }
-  {
-    const int Q = pl.Q, rs0 = sh.r0 * seq, nr = sh.bl * seq;
-    float* X = ws + pl.off_X; float* EX = ws + pl.off_ex; float* rs = ws + pl.off_rs;
-    float* D = ws + pl.off_D; float* Dbar = ws + pl.off_dbar; float* dDbar = ws + pl.off_ddbar;
-    hipLaunchKernelGGL(rank_coeff_kernel, dim3(ceil_div((long)Q * nr, 4)), dim3(256), 0, st, Q, b, seq, Bp, d->w_rank, d->margin, sh, D, Dbar, dDbar,
-                       ws + pl.off_diag, rs);
-    if (int rc = f32_gemm(true, nr, dim, Bp, D + (long)rs0 * Bp, Bp, (long)Bp * Bp, X, dim, (long)Bp * dim, EX + (long)rs0 * dim, dim,
-                          (long)Bp * dim, Q, 1.0f, st)) return rc;
-    int gb = ceil_div((long)Q * nr * dim, 256);
-    if (gb > 8192) gb = 8192;
-    hipLaunchKernelGGL(rank_grad_kernel, dim3(gb), dim3(256), 0, st, tb.rk, Q, Bp, dim, rs0, nr, X, rs, EX);
-  }
-  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, st, terms, xall, sh, d->w_shared, d->w_private, d->w_orth, d->w_rank);
+  if (int rc = f32_gemm(true, nr, dim, Bp, a.D + (long)rs0 * Bp, Bp, (long)Bp * Bp, a.X, dim, (long)Bp * dim, a.EX + (long)rs0 * dim, dim,
+                        (long)Bp * dim, Q, 1.0f, st)) return rc;
+  // ---- launch 4: gradients back onto the embeddings
+  for (int k = 0; k < 2; ++k) a.g[k].blocks = a.g[k].nprob ? ceil_div((long)a.g[k].nprob * seq * 2 * sh.bl, 4) : 0;
+  a.blocks_rank = capped(ceil_div((long)Q * nr * dim, 256), 8192);
+  hipLaunchKernelGGL(head_grad_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank), dim3(256), 0, st, a);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
