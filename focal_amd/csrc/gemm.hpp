@@ -316,8 +316,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // BKM: reduction-tile multiplier.  The weight-gradient GEMMs (reduction over 1e4-1e5 tokens, tiny output) use 2: twice
 // the bytes in flight per workgroup and half the barriers in a loop that is bound by memory latency.
+// (the kernel is a device function of (problem, workgroup index, workgroups of the problem): focal_gemm_kernel runs it for its one problem,
+// the loss head's grouped launch -- loss.hip -- for the problem its blockIdx falls into)
 template <typename CT, typename TA, typename TB, typename TC, bool TRA, bool TRB, int PROA, int PROB, int EPI, int BM, int BN, int BKM = 1>
-__global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void focal_gemm_body(const GemmParams& p, const int block, const int nblocks) {
   using Cfg = GemmCfg<CT>;
   constexpr int BK = Cfg::BK * BKM, KI = Cfg::KI;
   using StA = OperandStage<CT, TA, TRA, PROA, BM, BKM>;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
   // weight-gradient GEMMs, all output tiles of one reduction chunk -- then share an L2 instead of re-fetching.
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int ntiles = tiles_m * tiles_n;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int logical = xcd_remap(block, nblocks);
   const int tile = logical % ntiles, z = logical / ntiles;
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int bz = z / p.splits, sp = z % p.splits;
@@ -573,6 +575,11 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
       }
     }
   }
+}
+
+template <typename CT, typename TA, typename TB, typename TC, bool TRA, bool TRB, int PROA, int PROB, int EPI, int BM, int BN, int BKM = 1>
+__global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
+  focal_gemm_body<CT, TA, TB, TC, TRA, TRB, PROA, PROB, EPI, BM, BN, BKM>(p, blockIdx.x, gridDim.x);
 }
 
 // Launch plan of a weight-gradient GEMM (output [M][N], reduction over `rows` tokens split across workgroups): tile shape and split

@@ -595,6 +595,41 @@ static int f32_gemm(bool trb, int M, int N, int K, const float* A, long lda, lon
   return focal_launch_gemm(s, p, st);
 }
 
+// The head's exact-fp32 products of one phase (similarity rows of both InfoNCE groups + Gram rows; coefficient rows x embeddings) do not
+// depend on each other: ONE launch of the 64 x 64 tiles of focal_gemm_kernel behind a problem table instead of three (five when a
+// rank's own rows are two runs per block).
+#define LOSS_GEMM_MAX 6
+struct GemmGroup { int n; int wg_end[LOSS_GEMM_MAX]; GemmParams p[LOSS_GEMM_MAX]; };
+template <bool TRB> __global__ __launch_bounds__(256) void loss_gemm_group_kernel(const GemmGroup g) {
+  const int b = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int q = 0; q < LOSS_GEMM_MAX - 1; ++q) pi += (q < g.n - 1 && b >= g.wg_end[q]) ? 1 : 0;
+  const int start = pi > 0 ? g.wg_end[pi - 1] : 0;
+  focal_gemm_body<float, float, float, float, false, TRB, PRO_NONE, PRO_NONE, EPI_STORE, 64, 64, 1>(g.p[pi], b - start, g.wg_end[pi] - start);
+}
+static void gemm_group_add(GemmGroup* g, int M, int N, int K, const float* A, long lda, long sA, const float* B, long ldb, long sB, float* C, long ldc,
+                           long sC, int batch, float alpha) {
+  GemmParams& p = g->p[g->n];
+  memset(&p, 0, sizeof(p));
+  p.M = M; p.N = N; p.K = K;
+  p.A = A; p.lda = lda; p.strideA = sA;
+  p.B = B; p.ldb = ldb; p.strideB = sB;
+  p.C = C; p.ldc = ldc; p.strideC = sC;
+  p.batch = batch; p.splits = 1; p.alpha = alpha;
+  const int wgs = ceil_div(M, 64) * ceil_div(N, 64) * batch;
+  g->wg_end[g->n] = (g->n ? g->wg_end[g->n - 1] : 0) + wgs;
+  ++g->n;
+}
+static int gemm_group_launch(const GemmGroup& g, bool trb, hipStream_t st) {
+  if (g.n == 0) return FOCAL_OK;
+  const int wgs = g.wg_end[g.n - 1];
+  if (trb) hipLaunchKernelGGL(loss_gemm_group_kernel<true>, dim3(wgs), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL(loss_gemm_group_kernel<false>, dim3(wgs), dim3(256), 0, st, g);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
 struct LossTables { PairTable nce, orth; RankTable rk; };
 
 static void loss_tables(const focal_loss_desc* d, const float* const* feats, float* const* dfeats, LossTables* t) {
@@ -694,17 +729,28 @@ static int loss_phase_a(const focal_loss_desc* d, const LossPlan& pl, const floa
   hipLaunchKernelGGL(head_pack_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank), dim3(256), 0, st, a);
 
   // ---- products: similarity rows S = Zn Zn^T / T per group, Gram rows G = X X^T (exact-fp32 MFMA)
+  static const bool one_gemm_launch = getenv("FOCAL_LOSS_GEMM_SEPARATE") == nullptr;
+  GemmGroup gg;
+  gg.n = 0;
   for (int k = 0; k < 2; ++k) {
     const NceGroup& g = a.g[k];
     if (g.nprob == 0) continue;
     if (int rc = over_own_halves(pl, [&](int row0, int nrow) {
+          if (one_gemm_launch) {
+            gemm_group_add(&gg, nrow, n2p, g.width, g.Zn + (long)row0 * g.width, g.width, (long)n2p * g.width, g.Zn, g.width, (long)n2p * g.width,
+                           g.S + (long)row0 * n2p, n2p, (long)n2p * n2p, g.nprob * seq, 1.0f / d->temperature);
+            return (int)FOCAL_OK;
+          }
           return f32_gemm(false, nrow, n2p, g.width, g.Zn + (long)row0 * g.width, g.width, (long)n2p * g.width, g.Zn, g.width, (long)n2p * g.width,
                           g.S + (long)row0 * n2p, n2p, (long)n2p * n2p, g.nprob * seq, 1.0f / d->temperature, st);
         })) return rc;
   }
   const int mrows = sh.world == 1 ? Bp : nr;
-  if (int rc = f32_gemm(false, mrows, Bp, dim, a.X + (long)rs0 * dim, dim, (long)Bp * dim, a.X, dim, (long)Bp * dim, a.D + (long)rs0 * Bp, Bp,
-                        (long)Bp * Bp, Q, 1.0f, st)) return rc;
+  if (one_gemm_launch) {
+    gemm_group_add(&gg, mrows, Bp, dim, a.X + (long)rs0 * dim, dim, (long)Bp * dim, a.X, dim, (long)Bp * dim, a.D + (long)rs0 * Bp, Bp, (long)Bp * Bp, Q, 1.0f);
+    if (int rc = gemm_group_launch(gg, false, st)) return rc;
+  } else if (int rc = f32_gemm(false, mrows, Bp, dim, a.X + (long)rs0 * dim, dim, (long)Bp * dim, a.X, dim, (long)Bp * dim, a.D + (long)rs0 * Bp, Bp,
+                               (long)Bp * Bp, Q, 1.0f, st)) return rc;
 
   // ---- launch 2: lse rows + InfoNCE terms, ranking distances / block means / hinges (loss.py:189-192), orthogonality (row-local)
   for (int k = 0; k < 2; ++k) a.g[k].blocks = a.g[k].nprob ? loss_row_blocks((long)a.g[k].nprob * seq * 2 * sh.bl) : 0;
@@ -742,16 +788,27 @@ static int loss_phase_b(const focal_loss_desc* d, const LossPlan& pl, const floa
   a.blocks_rank = ceil_div((long)Q * nr, 4);
   hipLaunchKernelGGL(head_coeff_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank + 1), dim3(256), 0, st, a);
   // ---- products: dZn = W Zn per group, EX = E X
+  static const bool one_gemm_launch = getenv("FOCAL_LOSS_GEMM_SEPARATE") == nullptr;
+  GemmGroup gg;
+  gg.n = 0;
   for (int k = 0; k < 2; ++k) {
     const NceGroup& g = a.g[k];
     if (g.nprob == 0) continue;
     if (int rc = over_own_halves(pl, [&](int row0, int nrow) {
+          if (one_gemm_launch) {
+            gemm_group_add(&gg, nrow, g.width, n2p, g.S + (long)row0 * n2p, n2p, (long)n2p * n2p, g.Zn, g.width, (long)n2p * g.width,
+                           g.dZn + (long)row0 * g.width, g.width, (long)n2p * g.width, g.nprob * seq, 1.0f / ((float)seq * n2 * d->temperature));
+            return (int)FOCAL_OK;
+          }
           return f32_gemm(true, nrow, g.width, n2p, g.S + (long)row0 * n2p, n2p, (long)n2p * n2p, g.Zn, g.width, (long)n2p * g.width,
                           g.dZn + (long)row0 * g.width, g.width, (long)n2p * g.width, g.nprob * seq, 1.0f / ((float)seq * n2 * d->temperature), st);
         })) return rc;
   }
-  if (int rc = f32_gemm(true, nr, dim, Bp, a.D + (long)rs0 * Bp, Bp, (long)Bp * Bp, a.X, dim, (long)Bp * dim, a.EX + (long)rs0 * dim, dim,
-                        (long)Bp * dim, Q, 1.0f, st)) return rc;
+  if (one_gemm_launch) {
+    gemm_group_add(&gg, nr, dim, Bp, a.D + (long)rs0 * Bp, Bp, (long)Bp * Bp, a.X, dim, (long)Bp * dim, a.EX + (long)rs0 * dim, dim, (long)Bp * dim, Q, 1.0f);
+    if (int rc = gemm_group_launch(gg, true, st)) return rc;
+  } else if (int rc = f32_gemm(true, nr, dim, Bp, a.D + (long)rs0 * Bp, Bp, (long)Bp * Bp, a.X, dim, (long)Bp * dim, a.EX + (long)rs0 * dim, dim,
+                               (long)Bp * dim, Q, 1.0f, st)) return rc;
   // ---- launch 4: gradients back onto the embeddings
   for (int k = 0; k < 2; ++k) a.g[k].blocks = a.g[k].nprob ? ceil_div((long)a.g[k].nprob * seq * 2 * sh.bl, 4) : 0;
   a.blocks_rank = capped(ceil_div((long)Q * nr * dim, 256), 8192);
