@@ -45,6 +45,9 @@ def side_stream(device, index):
     """index 0 = the caller's current stream; index >= 1 = a dedicated side stream of this device."""
     if index == 0 or os.environ.get("FOCAL_NO_STREAMS") == "1":
         return torch.cuda.current_stream(device)
+    cap = int(os.environ.get("FOCAL_SIDE_STREAMS", "0"))  # experiment / tuning: at most this many side streams (encoders share them round-robin)
+    if cap > 0:
+        index = (index - 1) % cap + 1
     key = (torch.device(device), index)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
