@@ -127,7 +127,12 @@ class SW_Transformer(HipBackbone):
         out = {}
         point = runtime.fork_point(dev)  # every encoder starts from here: none waits for the one launched before it
         for mi, mod in enumerate(self.modalities):
-            st = runtime.fork_from(dev, (view % 2) * len(self.modalities) + mi, point)
+            # stream per modality; with one backbone pass per view the two passes of a step alternate between two sets of streams so
+            # that they overlap.  One pass per step (views_share_pass) always uses the same set -- the first modality stays on the
+            # caller's stream: alternating there only doubled the streams every join has to wait for (-1.6 % on the step,
+            # profiles/r3_encoder_streams_ab.txt)
+            slot = 0 if self.views_share_pass else view % 2
+            st = runtime.fork_from(dev, slot * len(self.modalities) + mi, point)
             with torch.cuda.stream(st):
                 f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
                 out[mod] = run_stage(self, self._heads[mod], f) if proj_head else f
