@@ -1,6 +1,7 @@
 // LayerNorm forward / backward for the SW_Transformer residual stream (nn.LayerNorm, eps 1e-5, biased variance),
 // optionally fused with PatchMerging's 2x2 gather (models/SwinModules.py:388-399).  HBM-bound streaming kernels:
 // one float4 per lane, LPR = C/4 lanes per row (up to a full wave), wave-shuffle reductions, no LDS in forward.
+#include <stdlib.h>
 #include "common.hpp"
 
 // Row addressing.  Plain: row r -> x + r*C.  Gather: row r = (b, y2, x2) of the merged grid; segment s = c / Cin
@@ -248,7 +249,10 @@ extern "C" int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const
   if (int rc = ln_geometry(d, &lpr, &nv, &map)) return rc;
   FOCAL_CHECK_ARG(dy && x && stats && gamma && dx && dgamma && dbeta, "layernorm_bwd: null tensor");
   const int rpw = 64 / lpr;
-  const int tpb = d->C >= 512 ? 256 : 1024, maxb = 256;
+  // 16 waves per workgroup up to 512 channels (the PatchMerging norms: 4 waves per CU left every row's memory latency exposed -- rows
+  // 18 432 x 512: 66 -> 39 us cold, step +0.9 %, profiles/r3_ln_bwd_wide_tpb.txt); 1024 channels (4 float4 per lane and array) stay at 4
+  static const int wide_tpb = getenv("FOCAL_LN_BWD_WIDE_TPB") ? atoi(getenv("FOCAL_LN_BWD_WIDE_TPB")) : 1024;
+  const int tpb = d->C >= 1024 ? 256 : (d->C >= 512 ? wide_tpb : 1024), maxb = 256;
   focal_drop_desc dd;
   memset(&dd, 0, sizeof(dd));
   if (mask) dd = *mask;

@@ -123,6 +123,18 @@ for tag, M, C in STAGES:
     dg, dbt = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     report(f"{tag} ln_bwd [{M}x{C}]", timeit(lambda: ops.layernorm_bwd(dy, x, st, gam, dx, True, dg, dbt)), M * C * (ES + 4 + 8))
 
+if not ONLY or ONLY == "lnmerge":  # PatchMerging LayerNorm backward (gather: rows of 4 C_in channels from the 2 x 2 token neighbourhood)
+    for tag, Bq, H, W, Cin in (("m01a", B, 12, 48, 64), ("m12a", B, 6, 24, 128), ("m01s", B, 12, 24, 64), ("m12s", B, 6, 12, 128)):
+        rows, C4 = Bq * (H // 2) * (W // 2), 4 * Cin
+        x = rnd(Bq * H * W, Cin)
+        gam, bet = rnd(C4), rnd(C4)
+        y, st = ops.layernorm_fwd(x, gam, bet, CT, gather=(Bq, H, W, Cin))
+        dy, dx = rnd(rows, C4, dtype=CT), torch.empty_like(x)
+        dxm = torch.empty(x.shape, dtype=CT, device=DEV)
+        dg, dbt = torch.zeros(C4, device=DEV), torch.zeros(C4, device=DEV)
+        report(f"{tag} ln_bwd gather [{rows}x{C4}]", timeit(lambda: ops.layernorm_bwd(dy, x, st, gam, dx, False, dg, dbt, gather=(Bq, H, W, Cin), dx_masked=dxm)),
+               rows * C4 * (ES + 4 + 4 + ES))
+
 GEO = [("s0a", 12, 48, 64), ("s0s", 12, 24, 64), ("s1a", 6, 24, 128), ("s1s", 6, 12, 128), ("s2a", 3, 12, 256), ("s2s", 3, 6, 256)]
 for tag, H, W, C in GEO:
     if ONLY and ONLY not in ("attn", tag):
