@@ -232,6 +232,32 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
   }
 }
 
+// Token of window slot t for the lanes that load it, once per item: the four tiles of an item (Q, K, V, dO) share their source rows.
+template <int HD> struct TileRows { int tok[HD / 16]; };
+template <int HD> __device__ __forceinline__ TileRows<HD> tile_rows(int tok_own, int lane) {
+  constexpr int CPR = HD / 4;
+  TileRows<HD> r;
+#pragma unroll
+  for (int q = 0; q < HD / 16; ++q) r.tok[q] = __shfl(tok_own, (lane + 64 * q) / CPR, 64);
+  return r;
+}
+template <int HD>
+__device__ __forceinline__ void tile_fetch_rows(TileRegs<HD>& r, const bf16_t* base, long row_stride, const TileRows<HD>& rows, int N, int lane) {
+  constexpr int CPR = HD / 4;
+#pragma unroll
+  for (int q = 0; q < HD / 16; ++q) {
+    const int c = lane + 64 * q, t = c / CPR, dc = c % CPR;
+    r.v[q] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (t < N) r.v[q] = *reinterpret_cast<const bf16x4*>(base + (long)rows.tok[q] * row_stride + dc * 4);
+  }
+}
+
+// The backward works in the S^T orientation (rows j = keys, column i = query -- the forward kernel's): a lane holds four keys of ONE query,
+// so the three reductions over keys (softmax maximum and sum, the dS row dot) are three in-lane operations and two cross-row exchanges
+// each.  In the S orientation they were 12 sixteen-lane DPP reductions of 8 VALU instructions -- a quarter of an instruction stream that
+// is what bounds this kernel (4 waves per SIMD, ~400 VALU instructions per (window, head) item: profiles/r3_attn_bwd_depth_ab.txt).
+// dS^T is directly the B operand of dQ; dS and Pd in the other orientation (B operands of dK, dV) come from two bf16 tiles written
+// [i][j] into wave-private LDS and read back with the hardware transpose read.
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_table,
                                                                    const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
@@ -239,7 +265,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
                                                                    int iters, const uint32_t* rng, uint32_t stream, float p_attn) {
   constexpr int P = HD + 4, TILE = 16 * P;
   __shared__ __attribute__((aligned(16))) bf16_t tiles[NW][4][TILE];
-  __shared__ __attribute__((aligned(16))) bf16_t trt[NW][16 * 20];  // dS tile, written [j][i], read back transposed (see below)
+  __shared__ __attribute__((aligned(16))) bf16_t trt[NW][2][16 * 20];  // dS^T / Pd^T tiles, written [i][j], read back transposed
   __shared__ float dbacc[256];  // (2wh-1)(2ww-1) x heads <= 256 entries
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: item, window and head arithmetic then runs on the SALU
   bf16_t* Qt = tiles[wave][0];
@@ -252,22 +278,23 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
   const DropCtx dc = make_drop(rng, stream, p_attn);
   const bool drop_on = p_attn > 0.f;
   const int C = g.C, grp = lane >> 4, col = lane & 15;
-  const TileIdx tB = make_tile_idx<false>(g, lane);
+  const TileIdx tA = make_tile_idx<true>(g, lane);  // rows j = 4 grp + r, column i = col
   const int slot = lane & 15, sy = slot / g.ww, sx = slot - sy * g.ww;
   // Relative-position-bias gradient: a lane owns the same (i, j) -- hence the same table row -- in every window, so it
-  // accumulates in registers and touches LDS only when the head it works on changes (never, when 4 * gridDim is a
-  // multiple of heads).  LDS float atomics serialise per lane; issuing 4 per (window, head) was ~half of this kernel.
+  // accumulates in registers and touches LDS only when the head it works on changes (never, when NW is a multiple of heads).
   float dbreg[4] = {0.f, 0.f, 0.f, 0.f};
   int h_acc = -1;
   auto flush_dbias = [&]() {
     if (h_acc < 0) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if ((4 * grp + r) < g.N && col < g.N) atomicAdd(&dbacc[tB.rel[r] + h_acc], dbreg[r]);
+      if (tA.ok[r]) atomicAdd(&dbacc[tA.rel[r] + h_acc], dbreg[r]);
       dbreg[r] = 0.f;
     }
   };
-  float biasB[4] = {0.f, 0.f, 0.f, 0.f};
+  // bias + validity of this lane's four (i, j) as ONE additive constant per head: score = s * scale + badd with badd = the relative-
+  // position bias inside the window, 0 on a padded query row (kept finite), -1e30 on a padded key (the tiles are zero-filled there, so s = 0)
+  float badd[4] = {0.f, 0.f, 0.f, 0.f};
   int h_cur = -1;
   auto item_of = [&](int it, bool& live, int& win, int& h) {
     const int item = (it * gridDim.x + blockIdx.x) * NW + wave;
@@ -279,14 +306,16 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
   bool live_n; int win_n, h_n, reg_n = 0, tok_n = 0;
   item_of(0, live_n, win_n, h_n);
   tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
-  tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
-  tile_fetch<HD>(rk, qkv + C + h_n * HD, 3 * C, tok_n, g.N, lane);
-  tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
-  tile_fetch<HD>(rg, dout + h_n * HD, C, tok_n, g.N, lane);
+  {
+    const TileRows<HD> rows = tile_rows<HD>(tok_n, lane);
+    tile_fetch_rows<HD>(rq, qkv + h_n * HD, 3 * C, rows, g.N, lane);
+    tile_fetch_rows<HD>(rk, qkv + C + h_n * HD, 3 * C, rows, g.N, lane);
+    tile_fetch_rows<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, rows, g.N, lane);
+    tile_fetch_rows<HD>(rg, dout + h_n * HD, C, rows, g.N, lane);
+  }
   for (int it = 0; it < iters; ++it) {
     const bool live = live_n;
     const int win = win_n, h = h_n, reg_own = reg_n, tok_own = tok_n;
-    const bool edge = g.shifted;  // (restricting this to the windows that really mix mask regions costs more in index arithmetic than it saves)
     if (live && h != h_acc) {
       flush_dbias();
       h_acc = h;
@@ -301,58 +330,78 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       item_of(it + 1, live_n, win_n, h_n);
       reg_n = 0;
       tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
-      tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
-      tile_fetch<HD>(rk, qkv + C + h_n * HD, 3 * C, tok_n, g.N, lane);
-      tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
-      tile_fetch<HD>(rg, dout + h_n * HD, C, tok_n, g.N, lane);
+      const TileRows<HD> rows = tile_rows<HD>(tok_n, lane);
+      tile_fetch_rows<HD>(rq, qkv + h_n * HD, 3 * C, rows, g.N, lane);
+      tile_fetch_rows<HD>(rk, qkv + C + h_n * HD, 3 * C, rows, g.N, lane);
+      tile_fetch_rows<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, rows, g.N, lane);
+      tile_fetch_rows<HD>(rg, dout + h_n * HD, C, rows, g.N, lane);
     }
-    // Only the (rows i, col j) orientation of the score tile is evaluated here (the forward kernel needs the other one): S, the
-    // softmax, dPd and dS once.  dQ needs dS^T as its B operand; instead of a second pair of MFMAs, a second softmax and a second
-    // set of dropout hashes (~130 of this loop's ~500 instructions), the bf16 dS tile goes through 640 bytes of wave-private
-    // LDS: written [j][i] (8 bytes per lane), read back with the hardware transpose read.
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, d1 = s1;
+    f32x4 st = {0.f, 0.f, 0.f, 0.f}, dt = st;
 #pragma unroll
     for (int kk = 0; kk < HD / 16; ++kk) {
       const bf16x4 fq = frag_rows(Qt, P, kk, lane), fk = frag_rows(Kt, P, kk, lane);
       const bf16x4 fv = frag_rows(Vt, P, kk, lane), fg = frag_rows(Gt, P, kk, lane);
-      s1 = mma16x16(fq, fk, s1);  // S   : rows i, col j
-      d1 = mma16x16(fg, fv, d1);  // dPd : rows i, col j
+      st = mma16x16(fk, fq, st);  // S^T  : rows j, col i
+      dt = mma16x16(fv, fg, dt);  // dPd^T: rows j, col i   (sum_d V[j][d] dO[i][d])
     }
-    float p1[4] = {s1[0], s1[1], s1[2], s1[3]};
     if (h != h_cur) {
       h_cur = h;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) biasB[r] = tB.ok[r] ? bias_table[tB.rel[r] + h] : 0.f;
+      for (int r = 0; r < 4; ++r) badd[r] = tA.ok[r] ? bias_table[tA.rel[r] + h] : (tA.qpad[r] ? 0.f : -1.0e30f);
     }
-    tile_softmax<false>(g, tB, p1, biasB, reg_own, edge);
-    const uint32_t wbase = ((uint32_t)win * g.heads + h) * g.N;
-    // ---- layout 1: rows i = 4*grp + r, col j
-    float ds1[4], pd1[4];
+    // ---- softmax over the keys of query i = col: in-lane over r, then across the four row groups
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = fmaf(st[r], g.scale, badd[r]);
+    if (g.shifted) {  // (wave-uniform) SwinModules.py:287: -100 between tokens of different mask regions; the query's region is the lane's own
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int reg_j = __shfl(reg_own, 4 * grp + r, 64);
+        p[r] += (tA.ok[r] && reg_j != reg_own) ? -100.0f : 0.f;
+      }
+    }
+    float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p[r] = __expf(p[r] - m); sum += p[r]; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    // ---- dP (through the dropout mask), the row dot, dS^T and Pd^T
+    const uint32_t ebase = (((uint32_t)win * g.heads + h) * g.N + col) * g.N + 4 * grp;  // element (i = col, j = 4 grp + r)
+    float dsT[4], pdT[4], dot = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = 4 * grp + r, j = col;
-      const bool ok = i < g.N && j < g.N;
-      const float m = (drop_on && ok) ? drop_mult(dc, (wbase + i) * g.N + j) : 1.f;
-      const float dp = d1[r] * m;
-      float dot = ok ? p1[r] * dp : 0.f;
-      dot = row16_sum(dot);
-      ds1[r] = ok ? p1[r] * (dp - dot) : 0.f;
-      pd1[r] = ok ? p1[r] * m : 0.f;
-      if (live) dbreg[r] += ds1[r];  // ds1 is 0 outside the window
+      p[r] *= inv;
+      const float mlt = (drop_on && tA.ok[r]) ? drop_mult(dc, ebase + r) : 1.f;
+      pdT[r] = p[r] * mlt;
+      dsT[r] = dt[r] * mlt;      // dP
+      dot += p[r] * dsT[r];
     }
-    const bf16x4 bds1 = pack4(ds1), bpd1 = pack4(pd1);
-    bf16_t* tw = trt[wave];
-    *reinterpret_cast<bf16x4*>(tw + col * 20 + 4 * grp) = bds1;  // tile_T[j = col][i = 4 grp .. 4 grp + 3]
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dsT[r] = p[r] * (dsT[r] - dot);  // 0 on padded keys (p = 0); padded query columns meet zero rows of Q / dO below and are not stored
+      if (live) dbreg[r] += dsT[r];
+    }
+    const bf16x4 bdsT = pack4(dsT), bpdT = pack4(pdT);
+    bf16_t* tw = trt[wave][0];
+    *reinterpret_cast<bf16x4*>(tw + col * 20 + 4 * grp) = bdsT;              // tile[i = col][j = 4 grp .. + 3]
+    *reinterpret_cast<bf16x4*>(tw + 16 * 20 + col * 20 + 4 * grp) = bpdT;
     wave_lds_fence();
-    const bf16x4 bds2 = frag_cols(tw, 20, 0, lane);              // lane (col i) <- rows j = 4 grp .. 4 grp + 3 : dS^T
+    const bf16x4 bds = frag_cols(tw, 20, 0, lane);             // lane (col j) <- rows i = 4 grp .. + 3 : dS
+    const bf16x4 bpd = frag_cols(tw + 16 * 20, 20, 0, lane);   // Pd
     const bool st_ok = live && col < g.N;
     bf16_t* dst = dqkv + (long)tok_own * 3 * C + h * HD + 4 * grp;
 #pragma unroll
     for (int db = 0; db < HD / 16; ++db) {
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 dq = mma16x16(frag_cols(Kt, P, db, lane), bds2, z);  // dQ^T[d][i] = sum_j K[j][d] dS[i][j]
-      const f32x4 dk = mma16x16(frag_cols(Qt, P, db, lane), bds1, z);  // dK^T[d][j] = sum_i Q[i][d] dS[i][j]
-      const f32x4 dv = mma16x16(frag_cols(Gt, P, db, lane), bpd1, z);  // dV^T[d][j] = sum_i dO[i][d] Pd[i][j]
+      const f32x4 dq = mma16x16(frag_cols(Kt, P, db, lane), bdsT, z);  // dQ^T[d][i] = sum_j K[j][d] dS[i][j]
+      const f32x4 dk = mma16x16(frag_cols(Qt, P, db, lane), bds, z);   // dK^T[d][j] = sum_i Q[i][d] dS[i][j]
+      const f32x4 dv = mma16x16(frag_cols(Gt, P, db, lane), bpd, z);   // dV^T[d][j] = sum_i dO[i][d] Pd[i][j]
       if (st_ok) {
         const float a[4] = {dq[0] * g.scale, dq[1] * g.scale, dq[2] * g.scale, dq[3] * g.scale};
         const float b[4] = {dk[0] * g.scale, dk[1] * g.scale, dk[2] * g.scale, dk[3] * g.scale};
