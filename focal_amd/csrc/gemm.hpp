@@ -320,266 +320,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // the loss head's grouped launch -- loss.hip -- for the problem its blockIdx falls into)
 template <typename CT, typename TA, typename TB, typename TC, bool TRA, bool TRB, int PROA, int PROB, int EPI, int BM, int BN, int BKM = 1>
 __device__ __forceinline__ void focal_gemm_body(const GemmParams& p, const int block, const int nblocks) {
-  using Cfg = GemmCfg<CT>;
-  constexpr int BK = Cfg::BK * BKM, KI = Cfg::KI;
-  using StA = OperandStage<CT, TA, TRA, PROA, BM, BKM>;
-  using StB = OperandStage<CT, TB, TRB, PROB, BN, BKM>;
-  using FA = FragLoad<CT, TRA, StA::PITCH>;
-  using FB = FragLoad<CT, TRB, StB::PITCH>;
-  // wave grid: 64-column tiles put the 4 waves 4 x 1 so that one wave spans the full tile width -- its epilogue then
-  // writes whole 128-B (bf16) / 256-B (fp32) row segments instead of half lines; wider tiles use 2 x 2
-  constexpr int WGN = (BN <= 64) ? 1 : 2, WGM = 4 / WGN;
-  constexpr int WR = BM / WGM, WC = BN / WGN;  // rows / columns of the output tile owned by one wave
-  constexpr int TM = WR / 16, TN = WC / 16;
-
-  constexpr int OPER_BYTES = (StA::LDS_ELEMS + StB::LDS_ELEMS) * (int)sizeof(CT);
-  constexpr int EPI_RP = (WC > 64 || WR < 32) ? 16 : 32;  // rows per epilogue pass
-  constexpr int STAGE_BYTES = 4 * EPI_RP * (WC + 4) * 4;  // epilogue staging: 4 waves x RP rows x (WC + 4) floats
-  constexpr int LDS_BYTES = OPER_BYTES > STAGE_BYTES ? OPER_BYTES : STAGE_BYTES;
-  __shared__ __attribute__((aligned(16))) char lds_raw[LDS_BYTES];
-  CT* lds = reinterpret_cast<CT*>(lds_raw);
-  CT* ldsA = lds;
-  CT* ldsB = lds + StA::LDS_ELEMS;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WGN, wn = wave % WGN;
-  // 1-D grid over (batch x split) x tiles, re-ordered so that each XCD (private L2) owns a contiguous run of
-  // logical ids with the tile index fastest: the column tiles that re-read the same activation rows -- and, in the
-  // weight-gradient GEMMs, all output tiles of one reduction chunk -- then share an L2 instead of re-fetching.
-  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  const int ntiles = tiles_m * tiles_n;
-  const int logical = xcd_remap(block, nblocks);
-  const int tile = logical % ntiles, z = logical / ntiles;
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int bz = z / p.splits, sp = z % p.splits;
-
-  const TA* A = reinterpret_cast<const TA*>(p.A) + (long)bz * p.strideA;
-  const TB* B = reinterpret_cast<const TB*>(p.B) + (long)bz * p.strideB;
-  TC* C = reinterpret_cast<TC*>(p.C) + (long)bz * p.strideC;
-
-  const int KT = (p.K + BK - 1) / BK;
-  const int kt_per = (KT + p.splits - 1) / p.splits;
-  const int kt0 = sp * kt_per;
-  const int kt1 = min(KT, kt0 + kt_per);
-  const int k_end = min(p.K, kt1 * BK);
-
-  MaskEval meA, meB, meE;
-  if (PROA != PRO_NONE) meA.init(p.proA);
-  if (PROB != PRO_NONE) meB.init(p.proB);
-  if (EPI == EPI_RESID || EPI == EPI_GELU_FWD || EPI == EPI_RESID_LN) meE.init(p.epi);
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = TRA && (p.colsumA != nullptr) && (n0 == 0);
-
-  // Main loop: single LDS buffer; the global loads of the NEXT tile sit in registers while the current tile is
-  // multiplied.  Keeping TWO tiles in flight (PF2) was measured and rejected: +40 VGPRs drop the 64x64 kernels from
-  // 5-6 to 3-4 waves/SIMD and the step got 8 % slower -- occupancy, not prefetch depth, hides the latency here.
-  constexpr bool PF2 = false;
-  StA sa0, sa1;
-  StB sb0, sb1;
-  auto step = [&](StA& sa, StB& sb, int kt, int kt_next) {
-    if (TRA && do_colsum) sa.template store<true>(ldsA, m0, kt * BK, tid, meA, csum);
-    else sa.template store<false>(ldsA, m0, kt * BK, tid, meA, csum);
-    sb.template store<false>(ldsB, n0, kt * BK, tid, meB, csum);
-    __syncthreads();
-    if (kt_next < kt1) {
-      sa.load(A, p.lda, m0, kt_next * BK, p.M, k_end, tid, meA);
-      sb.load(B, p.ldb, n0, kt_next * BK, p.N, k_end, tid, meB);
-    }
-#pragma unroll
-    for (int kk = 0; kk < BK / KI; ++kk) {
-      typename FA::Frag xa[TM];
-      typename FB::Frag wb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) xa[i] = FA::load(ldsA, wm * WR + i * 16, kk, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) wb[j] = FB::load(ldsB, wn * WC + j * 16, kk, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mma16(wb[j], xa[i], acc[i][j]);
-    }
-    __syncthreads();
-  };
-  sa0.init(p.lda, m0, tid);
-  sb0.init(p.ldb, n0, tid);
-  if (PF2) {
-    sa1.init(p.lda, m0, tid);
-    sb1.init(p.ldb, n0, tid);
-  }
-  if (kt0 < kt1) {
-    sa0.load(A, p.lda, m0, kt0 * BK, p.M, k_end, tid, meA);
-    sb0.load(B, p.ldb, n0, kt0 * BK, p.N, k_end, tid, meB);
-  }
-  if (PF2) {
-    if (kt0 + 1 < kt1) {
-      sa1.load(A, p.lda, m0, (kt0 + 1) * BK, p.M, k_end, tid, meA);
-      sb1.load(B, p.ldb, n0, (kt0 + 1) * BK, p.N, k_end, tid, meB);
-    }
-    for (int kt = kt0; kt < kt1; kt += 2) {
-      step(sa0, sb0, kt, kt + 2);
-      if (kt + 1 < kt1) step(sa1, sb1, kt + 1, kt + 3);
-    }
-  } else {
-    for (int kt = kt0; kt < kt1; ++kt) step(sa0, sb0, kt, kt + 1);
-  }
-
-  if (TRA) {
-    if (do_colsum) {
-      // Combine the 256 / CPR threads that share a column group: xor-shuffles inside the wave, one LDS row per wave
-      // (LDS float atomics serialise per lane and cost microseconds here), then one global atomic per column.
-      float* red = reinterpret_cast<float*>(lds_raw);
-      constexpr int EC = Cfg::EC, CPR = StA::CPR;
-      static_assert((CPR & (CPR - 1)) == 0 && CPR <= 64, "column groups per row must be a power of two");
-#pragma unroll
-      for (int e = 0; e < EC; ++e)
-#pragma unroll
-        for (int o = CPR; o < 64; o <<= 1) csum[e] += __shfl_xor(csum[e], o, 64);
-      __syncthreads();
-      if (lane < CPR) {
-#pragma unroll
-        for (int e = 0; e < EC; ++e) red[wave * BM + lane * EC + e] = csum[e];
-      }
-      __syncthreads();
-      if (tid < BM && (m0 + tid) < p.M)
-        atomicAdd(p.colsumA + m0 + tid, red[tid] + red[BM + tid] + red[2 * BM + tid] + red[3 * BM + tid]);
-    }
-  }
-
-  // ---- epilogue.  The MFMA register layout gives a lane 4 consecutive n of ONE row per accumulator, i.e. a wave
-  // store would touch 16 rows x 32-64 B.  Each wave instead transposes its sub-tile through a private LDS region (32
-  // rows per pass) and walks it row-major: 128-256 B contiguous per row for stores, residual / aux loads and, for
-  // the atomic form, 256 contiguous bytes per wave-instruction (the only shape fp32 atomics run at full rate in).
-  constexpr int WN = WC, WPITCH = WN + 4, RP = EPI_RP, TPP = RP / 16;  // MFMA row-tiles per pass
-  float* stage = reinterpret_cast<float*>(lds_raw) + wave * RP * WPITCH;
-#pragma unroll
-  for (int pass = 0; pass < TM / TPP; ++pass) {
-    __syncthreads();
-#pragma unroll
-    for (int ii = 0; ii < TPP; ++ii) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const f32x4 v = acc[pass * TPP + ii][j] * p.alpha;
-        *reinterpret_cast<float4*>(stage + (ii * 16 + (lane & 15)) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-    __syncthreads();
-    const int mbase = m0 + wm * WR + pass * RP, nbase = n0 + wn * WN;
-    if (EPI == EPI_ATOMIC) {
-      float* Cf = reinterpret_cast<float*>(C);
-      const bool add_bias = p.bias && sp == 0;
-      constexpr int RPI = WN >= 64 ? 1 : 64 / WN;  // rows per wave-instruction
-      constexpr int CPI = WN >= 64 ? WN / 64 : 1;  // 64-column pieces per row
-#pragma unroll 4
-      for (int rr = 0; rr < RP; rr += RPI) {
-#pragma unroll
-        for (int cp = 0; cp < CPI; ++cp) {
-          const int row = rr + (WN >= 64 ? 0 : lane / WN), col = (WN >= 64 ? cp * 64 + lane : lane % WN);
-          const int m = mbase + row, n = nbase + col;
-          if (m < p.M && n < p.N) {
-            float v = stage[row * WPITCH + col];
-            if (add_bias) v += p.bias[n];
-            atomicAdd(Cf + (long)m * p.ldc + n, v);
-          }
-        }
-      }
-    } else {
-      // 16 bytes per lane on the way out: 8 columns for bf16 outputs, 4 for fp32 (the store tail is issue-bound:
-      // half the store instructions at equal bytes)
-      constexpr int CPL = (sizeof(TC) == 2) ? 8 : 4;
-      constexpr int LPR = WN / CPL, RPI = 64 / LPR;  // lanes per row, rows per wave-instruction
-      const int c = (lane % LPR) * CPL, n = nbase + c;
-      float bias[CPL];
-#pragma unroll
-      for (int e = 0; e < CPL; ++e) bias[e] = 0.f;
-      if (p.bias && n < p.N) loadN<CPL>(p.bias + n, bias);
-#pragma unroll
-      for (int rr = 0; rr < RP; rr += RPI) {
-        const int row = rr + lane / LPR;
-        const int m = mbase + row;
-        if (m >= p.M || n >= p.N) continue;
-        float v[CPL];
-        loadN<CPL>(stage + row * WPITCH + c, v);
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) v[e] += bias[e];
-        TC* dst = C + (long)m * p.ldc + n;
-        if (EPI == EPI_STORE) {
-          storeN<CPL>(dst, v);
-        } else if (EPI == EPI_RESID) {
-          float r[CPL];
-          loadN<CPL>(p.resid + (long)m * p.ldr + n, r);
-          const float rowm = meE.row_mult(m);
-#pragma unroll
-          for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
-          storeN<CPL>(dst, v);
-        } else if (EPI == EPI_RESID_LN) {
-          // (launcher guarantees N == BN == 64, fp32 C: CPL = 4, the 16 lanes of a DPP row hold one whole output row)
-          float r[CPL];
-          loadN<CPL>(p.resid + (long)m * p.ldr + n, r);
-          const float rowm = meE.row_mult(m);
-#pragma unroll
-          for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
-          storeN<CPL>(dst, v);
-          float s1 = 0.f;
-#pragma unroll
-          for (int e = 0; e < CPL; ++e) s1 += v[e];
-          const float mean = row16_sum(s1) * (1.0f / 64.0f);
-          float s2 = 0.f;
-#pragma unroll
-          for (int e = 0; e < CPL; ++e) s2 += (v[e] - mean) * (v[e] - mean);
-          const float rstd = rsqrtf(row16_sum(s2) * (1.0f / 64.0f) + p.ln_eps);
-          float g[CPL], bt[CPL], y[CPL];
-          loadN<CPL>(p.ln_gamma + n, g);
-          loadN<CPL>(p.ln_beta + n, bt);
-#pragma unroll
-          for (int e = 0; e < CPL; ++e) y[e] = (v[e] - mean) * rstd * g[e] + bt[e];
-          storeN<CPL>(reinterpret_cast<CT*>(p.aux_out) + (long)m * p.ldc + n, y);
-          if ((lane % LPR) == 0) *reinterpret_cast<float2*>(p.ln_stats + 2 * (long)m) = make_float2(mean, rstd);
-        } else if (EPI == EPI_MUL_AUX) {
-          float a[CPL];
-          loadN<CPL>(reinterpret_cast<const CT*>(p.aux) + (long)m * p.ldaux + n, a);
-#pragma unroll
-          for (int e = 0; e < CPL; ++e) v[e] *= a[e];
-          storeN<CPL>(dst, v);
-        } else if (EPI == EPI_GELU_FWD) {
-          float g[CPL];
-#pragma unroll
-          for (int e = 0; e < CPL; e += 2) {
-            const gelu_f2 x = {v[e], v[e + 1]};
-            gelu_f2 cdf, pdf;
-            gelu_parts2(x, cdf, pdf);
-            const gelu_f2 mult = meE.elem_mult_pair(m, n + e);
-            const gelu_f2 gg = (x * pdf + cdf) * mult, hh = x * cdf * mult;
-            g[e] = gg.x; g[e + 1] = gg.y;
-            v[e] = hh.x; v[e + 1] = hh.y;
-          }
-          storeN<CPL>(dst, v);
-          storeN<CPL>(reinterpret_cast<TC*>(p.aux_out) + (long)m * p.ldc + n, g);
-        } else if (EPI == EPI_RELU) {
-#pragma unroll
-          for (int e = 0; e < CPL; ++e) v[e] = fmaxf(v[e], 0.f);
-          storeN<CPL>(dst, v);
-        } else if (EPI == EPI_RELU_BWD) {
-          float y[CPL];
-          loadN<CPL>(reinterpret_cast<const TC*>(p.aux) + (long)m * p.ldaux + n, y);
-#pragma unroll
-          for (int e = 0; e < CPL; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
-          storeN<CPL>(dst, v);
-        }
-      }
-    }
-  }
+#include "gemm_body.inc"
 }
 
 template <typename CT, typename TA, typename TB, typename TC, bool TRA, bool TRB, int PROA, int PROB, int EPI, int BM, int BN, int BKM = 1>
 __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
-  focal_gemm_body<CT, TA, TB, TC, TRA, TRB, PROA, PROB, EPI, BM, BN, BKM>(p, blockIdx.x, gridDim.x);
+  const int block = blockIdx.x, nblocks = gridDim.x;
+#include "gemm_body.inc"
 }
 
 // Launch plan of a weight-gradient GEMM (output [M][N], reduction over `rows` tokens split across workgroups): tile shape and split

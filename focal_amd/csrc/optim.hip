@@ -17,8 +17,8 @@ extern "C" int focal_rng_advance(uint32_t* state, void* stream) {
 // torch.optim.AdamW: p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // advance != 0 (focal_adamw_multi_advance): the update uses step count step_state[1] + 1, and the workgroup that finishes LAST -- by
-// then every workgroup has read the count -- advances step_state and seed_state the way focal_rng_advance would (ticket in
-// step_state[2]): the step's two one-thread bookkeeping launches ride on the optimizer kernel.
+// then every workgroup has read the count -- advances step_state and seed_state the way focal_rng_advance would (tickets in
+// step_state[2] and step_state[8 .. 39]: FOCAL_STEP_STATE_WORDS = 40 zero-initialised words): the step's two one-thread bookkeeping launches ride on the optimizer kernel.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ shadow, long n,
                                                     const float* __restrict__ lr_dev, uint32_t* rng_state, uint32_t* seed_state,
@@ -56,14 +56,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (threadIdx.x == 0) {
       // (no fence: a workgroup's read of the step count has returned -- its value went into every store above -- before it takes a
       // ticket, and the words written below are read by later kernels only.  __threadfence() here is an L2 write-back per workgroup:
-      // it tripled the kernel's duration)
-      if (atomicAdd(rng_state + 2, 1u) == gridDim.x - 1) {
-        rng_state[2] = 0u;
-        rng_state[0] = focal_mix32(rng_state[0] + 0x9E3779B9U);
-        rng_state[1] += 1u;
-        if (seed_state != nullptr) {
-          seed_state[0] = focal_mix32(seed_state[0] + 0x9E3779B9U);
-          seed_state[1] += 1u;
+      // it tripled the kernel's duration.)  Two ticket levels -- 32 groups of workgroups, then the groups -- because atomics onto ONE
+      // word are a serial chain of ~10 ns links: 2048 workgroups on one ticket added 12 us to DeepSense's 26 us launch.
+      const uint32_t grp = blockIdx.x & 31u, ngrp = gridDim.x < 32u ? gridDim.x : 32u;
+      const uint32_t gsize = (gridDim.x - grp + 31u) >> 5;
+      if (atomicAdd(rng_state + 8 + grp, 1u) == gsize - 1u) {
+        rng_state[8 + grp] = 0u;
+        if (atomicAdd(rng_state + 2, 1u) == ngrp - 1u) {
+          rng_state[2] = 0u;
+          rng_state[0] = focal_mix32(rng_state[0] + 0x9E3779B9U);
+          rng_state[1] += 1u;
+          if (seed_state != nullptr) {
+            seed_state[0] = focal_mix32(seed_state[0] + 0x9E3779B9U);
+            seed_state[1] += 1u;
+          }
         }
       }
     }

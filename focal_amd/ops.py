@@ -104,6 +104,14 @@ def new_rng_state(seed, device):
     return torch.tensor([seed & 0xFFFFFFFF, 0, 0, 0], dtype=torch.int64, device=device).to(torch.int32)
 
 
+def new_step_state(device, count=0):
+    """The optimizer's device-side step state for adamw_multi(advance=True): {seed, step count, tickets ...} (FOCAL_STEP_STATE_WORDS)."""
+    st = torch.zeros(40, dtype=torch.int32, device=device)
+    if count:
+        st[1] = int(count)
+    return st
+
+
 def rng_advance(state):
     check(_lib.load().focal_rng_advance(_p(state), _stream()))
 

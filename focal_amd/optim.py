@@ -114,7 +114,7 @@ class FocalAdamW(torch.optim.Optimizer):
         g0 = self.param_groups[0]
         dev = arenas[0].device
         if self._step_state is None:
-            self._step_state = ops.new_rng_state(0, dev)
+            self._step_state = ops.new_step_state(dev)
         # this optimizer's step count (on the device: graph-replay safe) and the dropout seed of the next forward pass are advanced
         # by the AdamW kernel itself -- its last workgroup -- instead of two one-thread launches on the serial tail of the step
         segs = []
@@ -148,5 +148,5 @@ class FocalAdamW(torch.optim.Optimizer):
             av.copy_(v.to(av.device))
         dev = arenas[0].device
         if self._step_state is None:
-            self._step_state = ops.new_rng_state(0, dev)
+            self._step_state = ops.new_step_state(dev)
         self._step_state[1] = int(state["step"])

@@ -382,8 +382,10 @@ int focal_adamw_multi(const focal_adamw_desc* d, int nseg, float* const* p, cons
                       const uint32_t* rng_state, void* stream);
 /* The same update with the step's bookkeeping folded in: the step count used is step_state[1] + 1, and the workgroup that finishes last
  * advances step_state (as focal_rng_advance would have before the call) and, when non-NULL, seed_state (the dropout seed words of the
- * next forward pass) -- two one-thread launches less on the serial tail of every step.  step_state[2] is the kernel's ticket word
- * (zero between calls); 4 words as made by the binding's new_rng_state. */
+ * next forward pass) -- two one-thread launches less on the serial tail of every step.  step_state holds FOCAL_STEP_STATE_WORDS
+ * 32-bit words: {seed, step count, ticket, -, -, -, -, -, 32 group tickets}; the tickets are zero between calls.  seed_state: the 4
+ * words of focal_rng_advance. */
+#define FOCAL_STEP_STATE_WORDS 40
 int focal_adamw_multi_advance(const focal_adamw_desc* d, int nseg, float* const* p, const float* const* g, float* const* m,
                               float* const* v, void* const* shadow_bf16, const long* n, const float* lr_dev,
                               uint32_t* step_state, uint32_t* seed_state, void* stream);
