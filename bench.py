@@ -164,9 +164,13 @@ class Step:
         # back-to-back draws): SW_Transformer runs them as one batch without a concatenation
         both = {l: {m: torch.empty(2 * x.shape[0], 2 * x.shape[1], x.shape[2], x.shape[3], device=x.device) for m, x in mm.items()}
                 for l, mm in self.x.items()}
-        v1 = {l: {m: self.ops.fft_realpack(x, out=both[l][m][:x.shape[0]]) for m, x in mm.items()} for l, mm in self.x.items()}
-        v2 = {l: {m: self.ops.fft_realpack(x, scale=-1.1, out=both[l][m][x.shape[0]:]) for m, x in mm.items()}
-              for l, mm in self.x.items()}  # negation + scaling, folded into the DFT
+        # (negation + scaling of view 2 folded into the DFT; all (view, modality) transforms in one call: the short-row modalities share a launch)
+        flat = [(l, m) for l, mm in self.x.items() for m in mm]
+        outs = self.ops.fft_realpack_multi([dict(x=self.x[l][m], out=both[l][m][:self.x[l][m].shape[0]]) for l, m in flat] +
+                                           [dict(x=self.x[l][m], scale=-1.1, out=both[l][m][self.x[l][m].shape[0]:]) for l, m in flat])
+        v1, v2 = {l: {} for l in self.x}, {l: {} for l in self.x}
+        for i, (l, m) in enumerate(flat):
+            v1[l][m], v2[l][m] = outs[i], outs[len(flat) + i]
         return v1, v2
 
     # The step itself -- capturable segments with the data-parallel collectives between them -- is the product's
@@ -296,7 +300,12 @@ class StepTracer:
                 return (kern, "all launches of the kernel", _tensor_bytes(args, kw), flops, "hbm", shp)
             return describe
         GEMM_OPS = {"linear_fwd", "linear_bwd_data", "linear_bwd_data_ln", "linear_resid_ln_fwd", "conv_fwd", "conv_bwd_data", "conv_bwd_weight"}
-        special = {"linear_bwd_weight": dw, "linear_bwd_weight_group": dwg, "layernorm_bwd": lnb, "mlp_bwd": mlpb}
+        def fftm(items):
+            small = sum(1 for it in items if it["x"].shape[-1] <= 64)
+            nl = (small + 7) // 8 + (len(items) - small)  # kernel launches of the call: the short-row transforms share launches of 8
+            b = sum(3 * it["x"].numel() * 4 for it in items)
+            return ("fft_realpack_multi", f"{len(items)} transforms in {nl} launches", b, 0.0, "hbm", f"{len(items)} transforms", nl)
+        special = {"linear_bwd_weight": dw, "linear_bwd_weight_group": dwg, "layernorm_bwd": lnb, "mlp_bwd": mlpb, "fft_realpack_multi": fftm}
         for name in dir(ops):
             fn = getattr(ops, name)
             if (callable(fn) and not name.startswith("_") and name not in _NOT_LAUNCHES and not isinstance(fn, type)
@@ -310,9 +319,11 @@ class StepTracer:
     def summary(self, steps):
         torch.cuda.synchronize()
         groups = {}
-        for (kern, shape, b, f, bound, inst), e0, e1 in self.rec:
-            g = groups.setdefault((kern, shape, bound), [0, 0.0, 0.0, 0.0, {}])
+        for desc, e0, e1 in self.rec:
+            kern, shape, b, f, bound, inst = desc[:6]
+            g = groups.setdefault((kern, shape, bound), [0, 0.0, 0.0, 0.0, {}, 0])
             us = e0.elapsed_time(e1) * 1e3
+            g[5] += desc[6] if len(desc) > 6 else 1  # kernel launches behind the call (1 unless the op says otherwise)
             g[0] += 1
             g[1] += us
             g[2] += b
@@ -324,7 +335,7 @@ class StepTracer:
         for k, v in groups.items():
             inst = sorted(({"instance": n, "calls_per_step": round(c / steps, 2), "avg_us": round(t / c, 2), "GBps": round(b / (t / c * 1e-6) / 1e9, 1)}
                            for n, (c, t, b) in v[4].items()), key=lambda r: -r["calls_per_step"] * r["avg_us"])
-            out.append(dict(kernel=k[0], launch_shape=k[1], bound=k[2], calls_per_step=v[0] / steps, us_per_step=v[1] / steps,
+            out.append(dict(kernel=k[0], launch_shape=k[1], bound=k[2], calls_per_step=v[0] / steps, launches_per_step=v[5] / steps, us_per_step=v[1] / steps,
                             avg_us=v[1] / v[0], bytes_per_launch=v[2] / v[0], flops_per_launch=v[3] / v[0], instances=inst[:12]))
         return out
 
@@ -403,7 +414,7 @@ def roofline(a, step, device):
            "measured": "in the step: HIP events around each launch of eager steps (one stream, as rocprofv3 sees them); algorithmic bytes of all the "
                        "kernel's launches / their total time",
            "calls_per_step": round(calls, 2), "avg_us": round(us / calls, 2), "ms_per_step": round(us / 1e3, 4),
-           "launches_per_step": round(sum(g["calls_per_step"] for g in groups), 1),
+           "launches_per_step": round(sum(g["launches_per_step"] for g in groups), 1),
            "kernel_ms_per_step": round(sum(g["us_per_step"] for g in groups) / 1e3, 3),
            "algorithmic_bytes_per_launch": round(nbytes / calls), "flops_per_launch": round(nflops / calls),
            "launch_shapes": [grp(g) for g in kg],

@@ -31,6 +31,10 @@ class AugDesc(C.Structure):
                 ("phase_sin", C.c_float)]
 
 
+class FftProblem(C.Structure):
+    _fields_ = [("d", FFTDesc), ("has_aug", C.c_int), ("aug", AugDesc), ("x", C.c_void_p), ("twiddle", C.c_void_p), ("out", C.c_void_p)]
+
+
 class EmbedDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "cin", "I", "S", "Hp", "Wp", "pw", "C0")] + [("eps", C.c_float)]
 
@@ -103,6 +107,7 @@ PROTOTYPES = {
     "focal_rng_advance": (C.c_int, [P, P]),
     "focal_fft_realpack_fwd": (C.c_int, [C.POINTER(FFTDesc), P, P, P, P]),
     "focal_augment_fft_fwd": (C.c_int, [C.POINTER(FFTDesc), C.POINTER(AugDesc), P, P, P, P]),
+    "focal_fft_realpack_multi": (C.c_int, [C.c_int, C.POINTER(FftProblem), P]),
     "focal_warp_fwd": (C.c_int, [C.c_int, C.c_int, P, P, P, P, C.c_int, P, P]),
     "focal_mixup_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "focal_pad_patch_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P]),

@@ -285,6 +285,102 @@ static int fft_launch(const focal_fft_desc* d, const AugParams& aug, const float
   return FOCAL_OK;
 }
 
+// ---- several short transforms in one launch.  The sensor modalities' rows are 20 samples long (100 Hz x 0.2 s): a direct DFT of 400
+// MACs per row, for which fft_realpack_kernel's one-workgroup-per-row form keeps 20 of 256 lanes busy, and of which a step has one
+// launch per (view, modality) on its serial head -- 8 launches of ~20 us + gaps for the four-modality config.  Here a thread owns one
+// output bin of one row (256 / n rows per workgroup pass), and a table in the kernel arguments maps blockIdx ranges to problems.
+#define FFT_MULTI_MAX 8
+struct FftSmallProblem { const float* x; const float* tw; float* out; int rows, I, n, rpb; AugParams aug; };
+struct FftSmallTable { int nprob; int wg_end[FFT_MULTI_MAX]; FftSmallProblem p[FFT_MULTI_MAX]; };
+
+__global__ __launch_bounds__(256) void fft_small_multi_kernel(const FftSmallTable t) {
+  __shared__ float xs[256], twc[64], tws[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int q = 0; q < FFT_MULTI_MAX - 1; ++q) pi += (q < t.nprob - 1 && b >= t.wg_end[q]) ? 1 : 0;
+  const FftSmallProblem& P = t.p[pi];
+  const int start = pi > 0 ? t.wg_end[pi - 1] : 0, nb = t.wg_end[pi] - start;
+  const int n = P.n, rpb = P.rpb;
+  if (tid < n) { twc[tid] = P.tw[2 * tid]; tws[tid] = P.tw[2 * tid + 1]; }
+  const int r = tid / n, k = tid - r * n;
+  const bool active = r < rpb;
+  for (int row0 = (b - start) * rpb; row0 < P.rows; row0 += nb * rpb) {
+    const int row = row0 + r;
+    const bool ok = active && row < P.rows;
+    __syncthreads();
+    if (ok) xs[tid] = P.aug.scale * P.x[(long)aug_src_row(P.aug, row, P.I) * n + (P.aug.flip ? n - 1 - k : k)];
+    __syncthreads();
+    if (!ok) continue;
+    const float* xr = xs + r * n;
+    float re = 0.f, im = 0.f;
+    int ph = 0;  // m * k mod n
+    for (int m = 0; m < n; ++m) {
+      const float v = xr[m];
+      re += v * twc[ph];
+      im += v * tws[ph];
+      ph += k;
+      if (ph >= n) ph -= n;
+    }
+    const int ci = row % P.I, bc = row / P.I;  // row = (b*C + c)*I + i
+    P.out[((long)(2 * bc) * P.I + ci) * n + k] = re * P.aug.pc - im * P.aug.ps;
+    P.out[((long)(2 * bc + 1) * P.I + ci) * n + k] = re * P.aug.ps + im * P.aug.pc;
+  }
+}
+
+static int aug_params(const focal_fft_desc* d, const focal_aug_desc* a, AugParams* p) {
+  *p = aug_identity();
+  if (a == nullptr) return FOCAL_OK;
+  p->scale = a->scale;
+  p->flip = a->flip != 0;
+  p->use_perm = a->use_perm != 0;
+  p->pc = a->phase_cos;
+  p->ps = a->phase_sin;
+  if (p->use_perm) {
+    FOCAL_CHECK_ARG(d->I <= FOCAL_AUG_MAX_INTERVALS, "augment_fft: %d intervals exceed the permutation table (%d)", d->I, FOCAL_AUG_MAX_INTERVALS);
+    for (int i = 0; i < d->I; ++i) {
+      FOCAL_CHECK_ARG(a->perm[i] >= 0 && a->perm[i] < d->I, "augment_fft: permutation entry %d out of range", a->perm[i]);
+      p->perm[i] = a->perm[i];
+    }
+  }
+  return FOCAL_OK;
+}
+
+extern "C" int focal_fft_realpack_multi(int n, const focal_fft_problem* probs, void* stream) {
+  FOCAL_CHECK_ARG(n >= 1 && probs, "fft_realpack_multi: no problems");
+  static const bool no_multi = getenv("FOCAL_FFT_NO_MULTI") != nullptr;
+  FftSmallTable t;
+  memset(&t, 0, sizeof(t));
+  auto flush = [&]() -> int {
+    if (t.nprob == 0) return FOCAL_OK;
+    hipLaunchKernelGGL(fft_small_multi_kernel, dim3(t.wg_end[t.nprob - 1]), dim3(256), 0, (hipStream_t)stream, t);
+    FOCAL_LAUNCH_CHECK();
+    memset(&t, 0, sizeof(t));
+    return FOCAL_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const focal_fft_problem& q = probs[i];
+    FOCAL_CHECK_ARG(q.x && q.twiddle && q.out, "fft_realpack_multi: null tensor in problem %d", i);
+    FOCAL_CHECK_ARG(q.d.B > 0 && q.d.C > 0 && q.d.I > 0 && q.d.n > 0, "fft_realpack: bad shape");
+    AugParams ap;
+    if (int rc = aug_params(&q.d, q.has_aug ? &q.aug : nullptr, &ap)) return rc;
+    if (!no_multi && q.d.n <= 64 && q.d.n2 == 1 && q.d.n1 == q.d.n) {  // short rows: the shared launch
+      FftSmallProblem& P = t.p[t.nprob];
+      P.x = q.x; P.tw = q.twiddle; P.out = q.out;
+      P.rows = q.d.B * q.d.C * q.d.I; P.I = q.d.I; P.n = q.d.n; P.rpb = 256 / q.d.n;
+      P.aug = ap;
+      int blocks = ceil_div(P.rows, P.rpb);
+      if (blocks > 1024) blocks = 1024;
+      t.wg_end[t.nprob] = (t.nprob ? t.wg_end[t.nprob - 1] : 0) + blocks;
+      if (++t.nprob == FFT_MULTI_MAX)
+        if (int rc = flush()) return rc;
+    } else if (int rc = fft_launch(&q.d, ap, q.x, q.twiddle, q.out, stream)) {
+      return rc;
+    }
+  }
+  return flush();
+}
+
 extern "C" int focal_fft_realpack_fwd(const focal_fft_desc* d, const float* x, const float* twiddle, float* out, void* stream) {
   return fft_launch(d, aug_identity(), x, twiddle, out, stream);
 }

@@ -153,12 +153,8 @@ def _factor(n):
     return n // best, best
 
 
-def fft_realpack(x, scale=1.0, flip=False, perm=None, phase=0.0, out=None):
-    """[B, C, I, n] real fp32 -> [B, 2C, I, n] (Re/Im channel pairs of the full two-sided spectrum).
-
-    Optional view augmentation folded into the transform (focal_augment_fft_fwd): x * scale, horizontal flip (intervals and
-    samples reversed), interval order `perm` (sequence of I ints), and a rotation of every bin by `phase` radians.
-    `out`: write into this contiguous [B, 2C, I, n] fp32 tensor (e.g. one half of a two-view batch) instead of allocating."""
+def _fft_problem(x, scale=1.0, flip=False, perm=None, phase=0.0, out=None):
+    """(descriptor, augmentation descriptor | None, x, twiddle table, out) of one transform."""
     _need_cuda(x)
     B, Cc, I, n = x.shape
     key = (n, x.device)
@@ -173,8 +169,7 @@ def fft_realpack(x, scale=1.0, flip=False, perm=None, phase=0.0, out=None):
         raise ValueError("fft_realpack: `out` must be a contiguous fp32 [B, 2C, I, n] tensor on x's device")
     d = FFTDesc(B, Cc, I, n, n1, n2)
     if scale == 1.0 and not flip and perm is None and phase == 0.0:
-        check(_lib.load().focal_fft_realpack_fwd(C.byref(d), _p(x), _p(_TWIDDLES[key]), _p(out), _stream()))
-        return out
+        return d, None, x, _TWIDDLES[key], out
     a = _lib.AugDesc()
     a.scale, a.flip, a.use_perm = float(scale), int(bool(flip)), int(perm is not None)
     a.phase_cos, a.phase_sin = math.cos(phase), math.sin(phase)
@@ -184,8 +179,37 @@ def fft_realpack(x, scale=1.0, flip=False, perm=None, phase=0.0, out=None):
             raise ValueError(f"perm must be a permutation of range({I})")
         for i, v in enumerate(perm):
             a.perm[i] = v
-    check(_lib.load().focal_augment_fft_fwd(C.byref(d), C.byref(a), _p(x), _p(_TWIDDLES[key]), _p(out), _stream()))
+    return d, a, x, _TWIDDLES[key], out
+
+
+def fft_realpack(x, scale=1.0, flip=False, perm=None, phase=0.0, out=None):
+    """[B, C, I, n] real fp32 -> [B, 2C, I, n] (Re/Im channel pairs of the full two-sided spectrum).
+
+    Optional view augmentation folded into the transform (focal_augment_fft_fwd): x * scale, horizontal flip (intervals and
+    samples reversed), interval order `perm` (sequence of I ints), and a rotation of every bin by `phase` radians.
+    `out`: write into this contiguous [B, 2C, I, n] fp32 tensor (e.g. one half of a two-view batch) instead of allocating."""
+    d, a, x, tw, out = _fft_problem(x, scale, flip, perm, phase, out)
+    if a is None:
+        check(_lib.load().focal_fft_realpack_fwd(C.byref(d), _p(x), _p(tw), _p(out), _stream()))
+    else:
+        check(_lib.load().focal_augment_fft_fwd(C.byref(d), C.byref(a), _p(x), _p(tw), _p(out), _stream()))
     return out
+
+
+def fft_realpack_multi(items):
+    """items: [dict(x=..., scale=, flip=, perm=, phase=, out=)] -- the keyword arguments of fft_realpack, one dict per transform (the
+    modalities of a view, or of both views) -> list of outputs.  One call (focal_fft_realpack_multi): the short-row transforms (the
+    20-sample sensor modalities) share one launch, the others are launched as fft_realpack would."""
+    probs = [_fft_problem(**it) for it in items]
+    arr = (_lib.FftProblem * len(probs))()
+    for i, (d, a, x, tw, out) in enumerate(probs):
+        arr[i].d = d
+        arr[i].has_aug = int(a is not None)
+        if a is not None:
+            arr[i].aug = a
+        arr[i].x, arr[i].twiddle, arr[i].out = _p(x), _p(tw), _p(out)
+    check(_lib.load().focal_fft_realpack_multi(len(probs), arr, _stream()))
+    return [p[4] for p in probs]
 
 
 def mag_warp(x, mult):

@@ -107,6 +107,17 @@ TIME_AUGMENTERS = {"no": None, "mixup": _mixup_in_random_pool, "negation": _nega
 FREQ_AUGMENTERS = {"no": None, "phase_shift": _phase_shift}
 
 
+def _transform_all(items):
+    """{loc: {mod: fft_realpack keyword arguments}} -> {loc: {mod: spectrum}}: every (location, modality) of a view in ONE call
+    (ops.fft_realpack_multi: the short-row sensor modalities share a launch instead of one launch each)."""
+    flat = [(loc, mod) for loc, mods in items.items() for mod in mods]
+    outs = ops.fft_realpack_multi([items[loc][mod] for loc, mod in flat])
+    res = {loc: {} for loc in items}
+    for (loc, mod), o in zip(flat, outs):
+        res[loc][mod] = o
+    return res
+
+
 class Augmenter:
     def __init__(self, args) -> None:
         self.args = args
@@ -178,7 +189,7 @@ class Augmenter:
             for loc in d:
                 for mod in d[loc]:
                     kw[loc][mod].update(d[loc][mod])
-        return {loc: {mod: ops.fft_realpack(t.contiguous(), **kw[loc][mod]) for mod, t in mods.items()} for loc, mods in x.items()}
+        return _transform_all({loc: {mod: dict(x=t.contiguous(), **kw[loc][mod]) for mod, t in mods.items()} for loc, mods in x.items()})
 
     def forward_random(self, time_loc_inputs):
         """ONE augmenter from the (time + freq) pool per call (reference :76-113); its arithmetic runs inside the DFT kernel."""
@@ -186,15 +197,15 @@ class Augmenter:
         name = self.aug_names[k]
         fn = TIME_AUGMENTERS[name] if k < len(self.time_aug_names) else FREQ_AUGMENTERS[name]
         kw = self._draw(fn, name, time_loc_inputs)
-        out = {}
+        items = {}
         for loc, mods in time_loc_inputs.items():
-            out[loc] = {}
+            items[loc] = {}
             for mod, x in mods.items():
                 k = dict(kw[loc][mod])
                 pre = k.pop("pre", None)  # the spline warps are a pass of their own in front of the transform
                 src = pre(x.contiguous()) if pre is not None else x.contiguous()
-                out[loc][mod] = ops.fft_realpack(src, out=self._view_slot(loc, mod, x), **k)
-        return out
+                items[loc][mod] = dict(x=src, out=self._view_slot(loc, mod, x), **k)
+        return _transform_all(items)
 
     def _view_slot(self, loc, mod, x):
         """Where this view's spectrum goes: the pretraining loop draws two views of the same windows back to back
@@ -231,5 +242,4 @@ class Augmenter:
 
     def fft_preprocess(self, time_loc_inputs):
         """[b, c, i, s] real -> [b, 2c, i, s] packed spectrum (reference :141-158), on the HIP DFT kernel."""
-        return {loc: {mod: ops.fft_realpack(x.contiguous()) for mod, x in mods.items()}
-                for loc, mods in time_loc_inputs.items()}
+        return _transform_all({loc: {mod: dict(x=x.contiguous()) for mod, x in mods.items()} for loc, mods in time_loc_inputs.items()})

@@ -72,6 +72,12 @@ int focal_fft_realpack_fwd(const focal_fft_desc* d, const float* x, const float*
 typedef struct { float scale; int flip; int use_perm; int perm[FOCAL_AUG_MAX_INTERVALS]; float phase_cos, phase_sin; } focal_aug_desc;
 int focal_augment_fft_fwd(const focal_fft_desc* d, const focal_aug_desc* a, const float* x, const float* twiddle, float* out,
                           void* stream);
+/* n transforms (each with or without an augmentation: the two views x the modalities of a step) in ONE call: problems with short rows
+ * (n <= 64 samples as a direct DFT, n2 == 1: the 20-sample sensor modalities) share one launch -- a thread per output bin, 256 / n
+ * rows per workgroup pass, a problem table in the kernel arguments, up to 8 problems per launch -- the others are launched as by
+ * focal_fft_realpack_fwd / focal_augment_fft_fwd.  Results are those of the single calls. */
+typedef struct { focal_fft_desc d; int has_aug; focal_aug_desc aug; const float* x; const float* twiddle; float* out; } focal_fft_problem;
+int focal_fft_realpack_multi(int n, const focal_fft_problem* problems, void* stream);
 
 /* TimeWarp / MagWarp (data_augmenter/TimeWarpAugmenter.py:18,44, MagWarpAugmenter.py:18,44 -> tsai 0.3.7 TSTimeWarp / TSMagWarp;
  * SURVEY 8f rank 1): one smooth random curve per call over the flattened (I*S) axis of [B, C, I, S], shared by batch and channels;

@@ -482,6 +482,28 @@ def test_fft_realpack(ops, n):
     assert (out.double() - ref).abs().max().item() < 2e-4 * math.sqrt(n)
 
 
+def test_fft_realpack_multi_equals_single_calls(ops):
+    """focal_fft_realpack_multi: the transforms of a step's (view, modality) pairs in one call -- short rows (n <= 64, direct DFT) share
+    launches of up to 8 problems, long rows go the usual way -- give exactly what the single calls give, augmentations included."""
+    g = torch.Generator().manual_seed(70)
+    xs = [torch.randn(5, 3, 10, 20, generator=g).to(DEV), torch.randn(5, 1, 10, 20, generator=g).to(DEV), torch.randn(4, 1, 10, 1600, generator=g).to(DEV),
+          torch.randn(3, 2, 7, 48, generator=g).to(DEV), torch.randn(2, 1, 10, 64, generator=g).to(DEV)]
+    kws = [dict(), dict(scale=-1.1), dict(flip=True), dict(perm=[3, 1, 0, 2, 6, 5, 4]), dict(phase=0.7)]
+    items = [dict(x=x, **kw) for x, kw in zip(xs, kws)]
+    items += [dict(x=xs[0], scale=0.9, perm=list(range(9, -1, -1))), dict(x=xs[1], flip=True, phase=-1.3)] + [dict(x=xs[0], scale=float(i)) for i in range(2, 9)]
+    both = torch.empty(10, 6, 10, 20, device=DEV)
+    items += [dict(x=xs[0], out=both[:5]), dict(x=xs[0], scale=-1.1, out=both[5:])]
+    outs = ops.fft_realpack_multi(items)
+    assert len(outs) == len(items) and outs[-1].data_ptr() == both[5:].data_ptr()
+    for it, o in zip(items, outs):
+        ref = ops.fft_realpack(**{k: v for k, v in it.items() if k != "out"})
+        assert o.shape == ref.shape
+        tol = 1e-5 * ref.abs().max().item()
+        assert (o - ref).abs().max().item() <= tol, (it["x"].shape, {k: v for k, v in it.items() if k not in ("x", "out")})
+    f = torch.view_as_real(torch.fft.fft(xs[0].double(), dim=-1)).permute(0, 1, 4, 2, 3).reshape(5, 6, 10, 20)
+    assert (outs[0].double() - f).abs().max().item() < 2e-4 * math.sqrt(20)
+
+
 # ---------------------------------------------------------------------------------------------- optimizer / rng
 def test_adamw_matches_torch(ops):
     n = 4096 + 8
