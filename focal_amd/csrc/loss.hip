@@ -20,6 +20,7 @@ struct Shard {
   int world, ch;     // ranks, floats per exchange chunk
   int o_diag, o_terms;  // offsets inside a chunk: [lse of own rows: nblk_total * 2 bl | diag means: Q * bl | partial terms: 5 | pad]
 };
+#include <stdlib.h>
 #include "gemm.hpp"
 
 #define LOSS_MAXP 20   // InfoNCE problems (2 views x mod pairs + mods = M^2 <= 16) and orthogonality problems (M (M + 1) <= 20) share the table type
@@ -690,7 +691,8 @@ static void head_args(const focal_loss_desc* d, const LossPlan& pl, const float*
     roff += rows;
     gb0 += g.nprob * d->seq;
   }
-  a->fused_rank_rows = pl.b <= RANK_ROW_MAX_B;
+  static const bool split_rows = getenv("FOCAL_LOSS_RANK_SPLIT") != nullptr;  // (tests: the three-pass form of longer rows on small inputs)
+  a->fused_rank_rows = pl.b <= RANK_ROW_MAX_B && !split_rows;
 }
 static inline int capped(long blocks, int cap) { return (int)(blocks > cap ? cap : (blocks < 1 ? 1 : blocks)); }
 

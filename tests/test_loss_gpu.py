@@ -201,3 +201,17 @@ def test_sharded_loss_head_equals_one_rank_head(cfg, M, B, world, no_private, se
     assert torch.allclose(ts, t1.cpu(), rtol=2e-5, atol=1e-6), (ts, t1)
     for got, ref in zip(s1 + s2, g1 + g2):
         assert ((got - ref.cpu()).norm() / ref.norm()).item() < 2e-5
+
+
+def test_loss_head_fallback_forms_give_the_same_results():
+    """The launch-fused head has two fallbacks that the sizes in this suite never reach: the three-pass ranking rows (subsequence counts
+    above RANK_ROW_MAX_B = 1024) and one launch per product (FOCAL_LOSS_GEMM_SEPARATE).  Both are forced through their environment
+    switches in a child process (they are read once per process) on the oracle / sharding tests above."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, FOCAL_LOSS_RANK_SPLIT="1", FOCAL_LOSS_GEMM_SEPARATE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_loss_head_matches_oracle or test_sharded_loss_head_equals_one_rank_head"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
