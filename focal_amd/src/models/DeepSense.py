@@ -133,7 +133,11 @@ class DeepSense(HipBackbone):
                     enc._packs = None
         point = runtime.fork_point(dev)  # every encoder starts from here: none waits for the one launched before it
         late = os.environ.get("FOCAL_FORK_LATE") == "1"
-        for mi, mod in enumerate(self.modalities):
+        order = list(range(len(self.modalities)))
+        if os.environ.get("FOCAL_HEAVY_FIRST", "1") != "0":  # the heaviest encoder is enqueued first (see SW_Transformer.forward_encoder)
+            order.sort(key=lambda i: -freq_x[loc][self.modalities[i]].numel())
+        for mi in order:
+            mod = self.modalities[mi]
             # with one stream per (view, modality) no encoder runs on the caller's stream (index 0): view 2's forks would otherwise
             # wait for the view-1 pass that was enqueued there
             st = runtime.fork_from(dev, (view_index * len(self.modalities) + (0 if late else 1) if view_streams else 0) + mi, point)
@@ -144,7 +148,7 @@ class DeepSense(HipBackbone):
                 out[mod].record_stream(cur)
         if not defer_join:  # FOCAL.forward joins once after both views so that their encoders overlap
             runtime.join_all(dev)
-        return out
+        return {mod: out[mod] for mod in self.modalities}
 
     def finish_views(self):
         """After both views' passes of a step (FOCAL.forward): the BatchNorm running-buffer updates the passes recorded (see

@@ -277,9 +277,14 @@ def test_full_batch_equals_small_batches(cfg, ct):
     sub = lambda lo, hi: {"shake": {m: v[lo:hi] for m, v in x["shake"].items()}}
     r = {m: torch.randn(B, 256, generator=g).cuda() for m in cfg["modality_names"]}
 
+    # bf16: the un-projected features are differentiated.  The projector's ReLU makes the gradient discontinuous where a hidden unit sits
+    # within summation noise of zero (mod_in is a split-K GEMM: its fp32 atomics arrive in any order, and bf16 rounding amplifies that
+    # into a flipped gate once in a while -- the mechanism found on HAR4, profiles/r3_fd_outlier.txt); fp32 keeps the projector in.
+    proj = ct == "fp32"
+
     def grads(lo, hi):
         net.arena().zero_grad()
-        out = net(sub(lo, hi), class_head=False, proj_head=True)
+        out = net(sub(lo, hi), class_head=False, proj_head=proj)
         sum((out[m] * r[m][lo:hi]).sum() for m in out).backward()
         torch.cuda.synchronize()
         return {m: out[m].detach().clone() for m in out}, net.arena().grad.clone()
