@@ -869,12 +869,12 @@ def test_product_augmenter_random_views_follow_the_oracle(ops, cfg, monkeypatch)
     args = make_args(cfg, "SW_Transformer", torch.device(DEV), "bf16")
     aug = A.Augmenter(args)
     calls = []
-    real = A.ops.fft_realpack
+    real = A.ops.fft_realpack_multi
 
-    def spy(x, **kw):
-        calls.append((x, kw))
-        return real(x, **kw)
-    monkeypatch.setattr(A.ops, "fft_realpack", spy)
+    def spy(items):  # the augmenter hands all (location, modality) transforms of a view to ONE call
+        calls.extend((it["x"], {k: v for k, v in it.items() if k not in ("x", "out")}) for it in items)
+        return real(items)
+    monkeypatch.setattr(A.ops, "fft_realpack_multi", spy)
     import random
     import numpy as np
     random.seed(12)  # the augmenter draws from `random`, numpy and torch: fix all three so the coverage check below is deterministic
