@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--dtype", default="bf16")
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true", help="skip the DeepSense / HAR4 lines appended to the default single-GPU run")
     p.add_argument("--sync-bn", action="store_true", help="DeepSense under DP: cross-rank BatchNorm statistics (exact global-batch parity)")
     p.add_argument("--no-dropout", action="store_true", help="diagnostic: all dropout rates 0 (flagged in the JSON line)")
     p.add_argument("--cpu-steps", type=int, default=4)
@@ -58,6 +59,7 @@ def parse():
                    help="fixed: identity / x * -1.1 folded into the DFT inside the captured step (the default, what `value` is quoted on); random: the "
                         "product Augmenter's draws (data_augmenter/Augmenter.py: coin flips, permutation / flip / phase / warp tables on the host, one "
                         "DFT launch per modality and view plus a warp pass when drawn) made eagerly before every replay, inside the timed region")
+    p.add_argument("--trace-dump", default=None, help="write the library's launch trace of 5 eager steps (per-instance medians, both trace modes) to this JSON file and exit")
     p.add_argument("--no-roofline", action="store_true", help="profiling runs: skip the dominant-kernel timing loop (the JSON line then has roofline null)")
     return p.parse_args()
 
@@ -202,10 +204,20 @@ def time_kernel(fn, iters=20):
 
 # ---------------------------------------------------------------------------------------------------------------- roofline
 # The dominant kernel is chosen and timed INSIDE the step (a warm back-to-back replay of one launch sits in the 256 MiB
-# Infinity Cache and flattered the number by 2.6x).  One eager step is run with a HIP-event pair around every launch of the
-# traced kernel families, recorded on the stream the launch goes to (each modality encoder has its own stream); launches are
-# grouped the way the committed rocprofv3 trace groups them (profiles/r2_*_instances.csv: kernel template x launch grid), so
-# `calls_per_step` / `avg_us` of the reported group can be checked against that file row by row.
+# Infinity Cache and flattered the number by 2.6x), and timed by the library itself (event pairs recorded from Python
+# bracketed allocator misses on a fresh box): while a launch trace is open (include/focal_hip.h: focal_trace_*), every kernel launch
+# of libfocal_hip carries a start / stop event pair on the dispatch, so a record is the kernel's own begin -> end time -- what
+# `rocprofv3 --kernel-trace` reports -- labelled with the launched kernel's symbol.  Groups are therefore rocprofv3's rows (one per
+# kernel instantiation; an op that launches two kernels is two groups) and are checked against the committed trace of the same
+# workload (profiles/r4_reference_<model>_<dataset>.json, made by tools/profile_round.sh from `rocprofv3 --kernel-trace --stats -M`).
+# The Python side only attributes ALGORITHMIC bytes / flops: every public op of focal_amd.ops is wrapped, notes which trace records its
+# call produced, and describes what the call has to move.
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from kernel_names import short_kernel_name  # noqa: E402
+
+ROUND = "r4"
+
+
 def _dw_bytes_flops(d):
     es = 2 if d.dtype == 1 else 4
     ey = 4 if d.y_dtype == 0 else es
@@ -214,7 +226,7 @@ def _dw_bytes_flops(d):
 
 
 # ops of focal_amd.ops that launch nothing (descriptors, queries, allocation helpers): never traced
-_NOT_LAUNCHES = {"code", "torch_dtype", "zero_pool_reset", "pool_zeros", "zeros", "drop_desc", "new_rng_state", "linear_desc", "ln_desc",
+_NOT_LAUNCHES = {"code", "torch_dtype", "zero_pool_reset", "pool_zeros", "zeros", "drop_desc", "new_rng_state", "new_step_state", "linear_desc", "ln_desc",
                  "mlp_desc", "attn_desc", "conv_desc", "conv_in_desc", "bn_desc", "mlp_supported", "dw_group_supported", "dw_group_kind", "resid_ln_supported",
                  "bwd_data_ln_supported", "check", "linear_bwd_weight_group_workgroups", "linear", "gru_desc"}
 
@@ -230,61 +242,67 @@ def _tensor_bytes(args, kw):
 
 
 class StepTracer:
-    """HIP events around every libfocal_hip launch of eager steps (every public op of focal_amd.ops), recorded on the stream the launch
-    goes to.  Algorithmic bytes of a launch: the op's own formula where one is given below (weight gradients, LayerNorm backward, fused
-    MLP), otherwise every tensor argument once (inputs read once, outputs written once -- what a streaming or GEMM kernel has to move)."""
+    """Attributes algorithmic bytes / flops to the records of the library's launch trace.  Every public op of focal_amd.ops is wrapped; a
+    call notes the range of trace records it produced and a description (bytes, flops, bound, instance label).  Algorithmic bytes of a call:
+    the op's own formula where one is given below (weight gradients, LayerNorm backward, fused MLP, BatchNorm backward), otherwise every
+    tensor argument and result once (inputs read once, outputs written once -- what a streaming or GEMM kernel has to move).  A call that
+    launches several kernels without a formula of its own splits its bytes over them by launch size (threads)."""
 
     def __init__(self, ops):
-        self.ops, self.rec, self.saved = ops, [], {}
+        self.ops, self.calls, self.saved = ops, [], {}
+        self.lib = __import__("focal_amd._lib", fromlist=["load"]).load()
 
     def _wrap(self, name, describe):
         orig = getattr(self.ops, name)
         self.saved[name] = orig
+        lib = self.lib
 
         def traced(*args, **kw):
-            st = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(st)
+            n0 = lib.focal_trace_count()
             out = orig(*args, **kw)
-            e1.record(st)
-            self.rec.append((describe(*args, **kw), e0, e1))
+            n1 = lib.focal_trace_count()
+            if n1 > n0:
+                self.calls.append((describe(out, *args, **kw), n0, n1))
             return out
         setattr(self.ops, name, traced)
 
     def install(self):
         ops = self.ops
-        lib = __import__("focal_amd._lib", fromlist=["load"]).load()
-        import ctypes
 
-        def dw(d, dy, x, dw_, db):
-            wgs = lib.focal_linear_bwd_weight_workgroups(ctypes.byref(d))
+        def out_bytes(out):
+            return _tensor_bytes([out] if isinstance(out, torch.Tensor) else (out or ()), {})
+
+        def dw(out, d, dy, x, dw_, db):
             b, f = _dw_bytes_flops(d)
-            kern = ("focal_dw_ring_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles, LDS-DMA ring>" if lib.focal_linear_bwd_weight_kernel(ctypes.byref(d)) == 2
-                    else "focal_gemm_kernel<dW: dy^T x, fp32 atomics, 64x64 tiles>")
-            return (kern, f"{wgs} workgroups x {512 if kern.startswith('focal_dw_ring') else 256}", b, f, "hbm", f"dW[{d.N},{d.K}] over {d.M} rows")
+            return dict(bytes=b, flops=f, bound="hbm", inst=f"dW[{d.N},{d.K}] over {d.M} rows")
 
-        def dwg(dtype_code, items, exclusive=True):
-            wgs = ops.linear_bwd_weight_group_workgroups(dtype_code, items, exclusive)
+        def dwg(out, dtype_code, items, exclusive=True):
             b = sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + w.numel() * 4 for dy, x, w, _ in items)
             f = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)
             rows, C = items[0][0].shape[0], min(min(dy.shape[1], x.shape[1]) for dy, x, _, _ in items)
-            if C % 128 != 0:
-                return ("focal_dw_ring_group_kernel<the dW of a 64-channel block's linears in one launch, 64x64 tiles, LDS-DMA ring>", f"{wgs} workgroups x 512",
-                        b, f, "hbm", f"{len(items)} dW of a C={C} block over {rows} rows")
-            return ("focal_dw_group_kernel<the dW of a block's linears in one launch, 128x128 tiles, LDS-DMA ring>", f"{wgs} workgroups x 512", b, f, "hbm",
-                    f"{len(items)} dW of a C={C} block over {rows} rows")
+            return dict(bytes=b, flops=f, bound="hbm", inst=f"{len(items)} dW of a C={C} block over {rows} rows")
 
-        def lnb(dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None, dx_masked=None, mask=None):
+        def lnb(out, dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None, dx_masked=None, mask=None):
             rows, C = dy.shape
             es = dy.element_size()
             b = rows * C * (es + 4 + (8 if accumulate else 4) + (es if dx_masked is not None else 0)) + rows * 8
-            return ("ln_bwd_kernel", "persistent grid (all LayerNorm backward launches)", b, 8.0 * rows * C, "hbm", f"rows {rows} x C {C}")
+            return dict(bytes=b, flops=8.0 * rows * C, bound="hbm", inst=f"rows {rows} x C {C}")
 
-        def mlpb(d, gm, a, *rest, **kw):
-            return ("mlp_bwd_kernel", "256 workgroups x 1024 (persistent)", d.M * d.C * 6, 10.0 * d.M * d.C * d.hidden, "mfma", f"M {d.M}")
+        def mlpb(out, d, gm, a, *rest, **kw):
+            # recompute fc1 + dH + dX + dW1 + dW2 = 5 products of 2 M C H flops; bytes: gm, a in, da out (DESIGN 3)
+            return dict(bytes=d.M * d.C * 6, flops=10.0 * d.M * d.C * d.hidden, bound="mfma", inst=f"M {d.M}")
+
+        def mlpf(out, d, a, resid, *rest, **kw):
+            return dict(bytes=_tensor_bytes((a, resid) + rest, kw) + out_bytes(out), flops=4.0 * d.M * d.C * d.hidden, bound="hbm", inst=f"M {d.M}")
+
+        def bnb(out, d, z, g, *rest, **kw):
+            es_o = out.element_size() if isinstance(out, torch.Tensor) else 4
+            n = d.rows * d.C
+            return dict(bytes=n * (8 + 8 + es_o), flops=0.0, bound="hbm", inst=f"rows {d.rows} x C {d.C}",
+                        parts={"bn_bwd_reduce": n * 8, "bn_bwd_apply": n * (8 + es_o)})
 
         def generic(name):
-            def describe(*args, **kw):
+            def describe(out, *args, **kw):
                 d = args[0] if args and hasattr(args[0], "_fields_") else None
                 flops = 0.0
                 if d is not None and all(hasattr(d, k) for k in ("M", "N", "K")):
@@ -294,18 +312,13 @@ class StepTracer:
                 elif d is not None and all(hasattr(d, k) for k in ("B", "T", "H")):
                     flops = 2.0 * d.B * d.T * 2 * 3 * d.H * d.H * (2 if name.endswith("bwd") else 1)
                 shp = " x ".join(str(tuple(t.shape)) for t in args if isinstance(t, torch.Tensor))[:70]
-                kern = name
-                if name in GEMM_OPS:  # one op, several kernel templates: group by what the dispatcher launched (rocprofv3 --stats rows)
-                    kern = f"{lib.focal_last_kernel().decode()} ({name})"
-                return (kern, "all launches of the kernel", _tensor_bytes(args, kw), flops, "hbm", shp)
+                return dict(bytes=_tensor_bytes(args, kw) + out_bytes(out), flops=flops, bound="hbm", inst=f"{name} {shp}")
             return describe
-        GEMM_OPS = {"linear_fwd", "linear_bwd_data", "linear_bwd_data_ln", "linear_resid_ln_fwd", "conv_fwd", "conv_bwd_data", "conv_bwd_weight"}
-        def fftm(items):
-            small = sum(1 for it in items if it["x"].shape[-1] <= 64)
-            nl = (small + 7) // 8 + (len(items) - small)  # kernel launches of the call: the short-row transforms share launches of 8
-            b = sum(3 * it["x"].numel() * 4 for it in items)
-            return ("fft_realpack_multi", f"{len(items)} transforms in {nl} launches", b, 0.0, "hbm", f"{len(items)} transforms", nl)
-        special = {"linear_bwd_weight": dw, "linear_bwd_weight_group": dwg, "layernorm_bwd": lnb, "mlp_bwd": mlpb, "fft_realpack_multi": fftm}
+
+        def fftm(out, items):
+            return dict(bytes=sum(3 * it["x"].numel() * 4 for it in items), flops=0.0, bound="hbm", inst=f"{len(items)} transforms")
+        special = {"linear_bwd_weight": dw, "linear_bwd_weight_group": dwg, "layernorm_bwd": lnb, "mlp_bwd": mlpb, "mlp_fwd": mlpf,
+                   "fft_realpack_multi": fftm, "bn_act_bwd": bnb}
         for name in dir(ops):
             fn = getattr(ops, name)
             if (callable(fn) and not name.startswith("_") and name not in _NOT_LAUNCHES and not isinstance(fn, type)
@@ -316,113 +329,201 @@ class StepTracer:
         for k, v in self.saved.items():
             setattr(self.ops, k, v)
 
-    def summary(self, steps):
-        torch.cuda.synchronize()
-        groups = {}
-        for desc, e0, e1 in self.rec:
-            kern, shape, b, f, bound, inst = desc[:6]
-            g = groups.setdefault((kern, shape, bound), [0, 0.0, 0.0, 0.0, {}, 0])
-            us = e0.elapsed_time(e1) * 1e3
-            g[5] += desc[6] if len(desc) > 6 else 1  # kernel launches behind the call (1 unless the op says otherwise)
-            g[0] += 1
-            g[1] += us
-            g[2] += b
-            g[3] += f
-            i = g[4].setdefault(inst, [0, 0.0, b])
-            i[0] += 1
-            i[1] += us
-        out = []
-        for k, v in groups.items():
-            inst = sorted(({"instance": n, "calls_per_step": round(c / steps, 2), "avg_us": round(t / c, 2), "GBps": round(b / (t / c * 1e-6) / 1e9, 1)}
-                           for n, (c, t, b) in v[4].items()), key=lambda r: -r["calls_per_step"] * r["avg_us"])
-            out.append(dict(kernel=k[0], launch_shape=k[1], bound=k[2], calls_per_step=v[0] / steps, launches_per_step=v[5] / steps, us_per_step=v[1] / steps,
-                            avg_us=v[1] / v[0], bytes_per_launch=v[2] / v[0], flops_per_launch=v[3] / v[0], instances=inst[:12]))
+    def launches(self):
+        """One dict per recorded launch, in launch order: kernel (short name), us, grid, bytes, flops, bound, inst, op."""
+        from focal_amd._lib import TraceRecord
+        n = self.lib.focal_trace_count()
+        recs = (TraceRecord * max(n, 1))()
+        if n:
+            from focal_amd._lib import check
+            check(self.lib.focal_trace_read(0, n, recs))
+        out = [dict(kernel=short_kernel_name(recs[i].kernel.decode()), us=float(recs[i].us), wgs=recs[i].grid[0] * recs[i].grid[1] * recs[i].grid[2],
+                    threads=recs[i].block[0] * recs[i].block[1] * recs[i].block[2], bytes=0.0, flops=0.0, bound="hbm", inst="(no op description)")
+               for i in range(n)]
+        for desc, n0, n1 in self.calls:
+            mine = out[n0:n1]
+            parts = desc.get("parts")
+            size = [r["wgs"] * r["threads"] for r in mine]
+            for r, sz in zip(mine, size):
+                share = 1.0 if len(mine) == 1 else sz / max(sum(size), 1)
+                if parts:
+                    hit = [v for k, v in parts.items() if k in r["kernel"]]
+                    r["bytes"] = float(hit[0]) if hit else 0.0
+                    r["flops"] = 0.0
+                else:
+                    r["bytes"], r["flops"] = desc["bytes"] * share, desc["flops"] * share
+                r["bound"], r["inst"] = desc["bound"], desc["inst"]
         return out
 
 
-def _pmc_traffic(a, kern):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes over the same eager step (tools/pmc_step_traffic.sh:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections) -- or (None, why) when the committed file was not
-    taken from this bench.py / library (a stale byte count must not sit next to a live time)."""
-    tf = os.path.join(ROOT, "profiles", f"r3_pmc_groups_{a.model}_{a.dataset}.json")
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def trace_groups(per_step):
+    """per_step: the launch lists of n traced steps (StepTracer.launches() cut per step).  Every launch position of the step is one
+    instance; its duration is the MEDIAN over the steps (the steps launch the same sequence; when they do not -- never observed --
+    the mean over all launches is used).  Returns the groups, one per kernel instantiation."""
+    n = len(per_step)
+    same = all(len(s) == len(per_step[0]) and all(a["kernel"] == b["kernel"] for a, b in zip(s, per_step[0])) for s in per_step)
+    if same:
+        inst = [dict(per_step[0][j], us=_median([s[j]["us"] for s in per_step])) for j in range(len(per_step[0]))]
+        scale = 1.0
+    else:
+        inst = [r for s in per_step for r in s]
+        scale = 1.0 / n
+    groups = {}
+    for r in inst:
+        g = groups.setdefault(r["kernel"], dict(kernel=r["kernel"], bound=r["bound"], calls=0.0, us=0.0, bytes=0.0, flops=0.0, inst={}))
+        g["calls"] += scale
+        g["us"] += r["us"] * scale
+        g["bytes"] += r["bytes"] * scale
+        g["flops"] += r["flops"] * scale
+        if r["bound"] == "mfma":
+            g["bound"] = "mfma"
+        i = g["inst"].setdefault((r["inst"], r["wgs"], r["threads"]), [0.0, 0.0, r["bytes"]])
+        i[0] += scale
+        i[1] += r["us"] * scale
+    out = []
+    for g in groups.values():
+        inst_rows = sorted(({"instance": f"{k[0]} [{k[1]} workgroups x {k[2]}]", "calls_per_step": round(c, 2), "avg_us": round(t / c, 2),
+                             "GBps": round(b / (t / c * 1e-6) / 1e9, 1)} for k, (c, t, b) in g["inst"].items()), key=lambda r: -r["calls_per_step"] * r["avg_us"])
+        out.append(dict(kernel=g["kernel"], bound=g["bound"], calls_per_step=g["calls"], us_per_step=g["us"], avg_us=g["us"] / g["calls"],
+                        bytes_per_launch=g["bytes"] / g["calls"], flops_per_launch=g["flops"] / g["calls"], instances=inst_rows[:12]))
+    out.sort(key=lambda g: -g["us_per_step"])
+    return out, same
+
+
+def _reference(a):
+    """The committed rocprofv3 figures of this workload (tools/profile_round.sh): per kernel instantiation calls per step, average
+    duration and PMC fabric bytes per launch; the serialized kernel time and the PMC bytes of a whole step."""
+    tf = os.path.join(ROOT, "profiles", f"{ROUND}_reference_{a.model}_{a.dataset}.json")
     if not os.path.exists(tf):
-        return None, "no PMC pass committed for this workload"
-    pg = json.load(open(tf))
-    key = kern.split("<")[0].split(" ")[0]
-    hit = pg.get("groups", {}).get(key)
-    if not hit:
-        return None, f"{os.path.basename(tf)} has no group {key!r}"
-    return round(hit["hbm_bytes_per_launch"]), f"profiles/{os.path.basename(tf)} (launch-weighted over the kernel's {hit['launches']} profiled launches; taken at library build {pg.get('lib_sha16')})"
+        return None, tf
+    return json.load(open(tf)), tf
 
 
-def roofline(a, step, device):
-    """`roofline` of the JSON line: the kernel with the largest time per step, measured in the step.  HBM-bound kernels: achieved =
-    algorithmic bytes per launch / average launch duration against the 8 TB/s peak; the fused MLP backward is compute-bound (its bytes
-    are 6 B per token-channel): TFLOP/s against the dense bf16 MFMA peak.  `isolated` (SW_Transformer on MOD) repeats the round-1
-    measurement (one instance, back-to-back launches) warm and cold for comparison."""
+def run_traced_steps(step, n_steps, mode):
+    """n_steps eager steps under an open launch trace -> (groups, launches per step, same_sequence).  One stream for the traced steps: the
+    modality encoders normally run on their own streams, where a kernel's duration also holds the slow-down from the other streams'
+    kernels (observed +20-45 %); rocprofv3 serialises the streams, and the committed trace this is checked against was taken that way.
+    The step's `value` is measured with all streams, of course."""
     ops = step.ops
-    tr = StepTracer(ops)
-    tr.install()
-    n_steps = 3
-    # One stream for the traced steps: the modality encoders normally run on their own streams, where a launch's event pair also spans
-    # the slow-down from the other streams' kernels (observed +20-45 %); rocprofv3 serialises the streams, and the committed trace
-    # this number must be checkable against was taken that way.  The step's `value` is measured with all streams, of course.
+    lib = __import__("focal_amd._lib", fromlist=["load"]).load()
+    from focal_amd._lib import check
     os.environ["FOCAL_NO_STREAMS"] = "1"
+    tr = StepTracer(ops)
     try:
-        # keep the GPU behind the host: ~20 ms of fills are queued first, so the step's launches (and their events) are consumed
-        # back to back and an event pair brackets kernel time, not host launch gaps
-        pad = torch.empty(256 << 20, dtype=torch.float32, device=device)
-        for _ in range(6):
-            pad.fill_(1.0)
         # (only rank 0 gets here: its traced steps are local -- no collective that the other ranks are not in)
         with step.dist.local_only():
-            for _ in range(n_steps):
-                for _ in range(40):
-                    pad.fill_(1.0)
+            for _ in range(2):  # untraced: every allocator pool of the one-stream eager form is warm before a record is taken
                 step.run()
-        groups = tr.summary(n_steps)
+            torch.cuda.synchronize()
+            tr.install()
+            per_step = []
+            for _ in range(n_steps):
+                check(lib.focal_trace_begin(4096, mode))
+                tr.calls = []
+                step.run()
+                torch.cuda.synchronize()
+                lib.focal_trace_end()
+                per_step.append(tr.launches())
     finally:
+        lib.focal_trace_end()
         tr.remove()
         os.environ.pop("FOCAL_NO_STREAMS", None)
-    del pad
-    groups.sort(key=lambda g: -g["us_per_step"])
-    # The dominant kernel = the KERNEL (as `rocprofv3 --stats` lists it: by name, over all its launch shapes) with the largest time in
-    # the step; its launch-shape groups and the other groups are listed below it.
-    by_kernel = {}
-    for g in groups:
-        by_kernel.setdefault(g["kernel"], []).append(g)
-    kern, kg = max(by_kernel.items(), key=lambda kv: sum(g["us_per_step"] for g in kv[1]))
-    calls = sum(g["calls_per_step"] for g in kg)
-    us = sum(g["us_per_step"] for g in kg)
-    nbytes = sum(g["bytes_per_launch"] * g["calls_per_step"] for g in kg)
-    nflops = sum(g["flops_per_launch"] * g["calls_per_step"] for g in kg)
-    bound = kg[0]["bound"]
+    groups, same = trace_groups(per_step)
+    return groups, per_step, same
+
+
+def roofline(a, step, device, ms_per_step=None):
+    """`roofline` of the JSON line: the kernel (instantiation = row of `rocprofv3 --stats`) with the largest time per step, measured in the
+    step.  HBM-bound kernels: achieved = algorithmic bytes per launch / average launch duration against the 8 TB/s peak; the fused MLP
+    backward is compute-bound (its bytes are 6 B per token-channel): TFLOP/s against the dense bf16 MFMA peak.  `isolated`
+    (SW_Transformer on MOD) repeats the round-1 measurement (one instance, back-to-back launches) warm and cold for comparison."""
+    from focal_amd._lib import TRACE_DISPATCH, TRACE_EVENTS
+    mode = TRACE_EVENTS if os.environ.get("FOCAL_BENCH_TRACE_MODE") == "events" else TRACE_DISPATCH
+    n_steps = 5
+    groups, per_step, same = run_traced_steps(step, n_steps, mode)
+    g0 = groups[0]
+    kern = g0["kernel"]
+    bound = g0["bound"]
     if bound == "hbm":
-        ach = nbytes / (us * 1e-6) / 1e9
+        ach = g0["bytes_per_launch"] / (g0["avg_us"] * 1e-6) / 1e9
         peak, unit = HBM_PEAK_GBS, "GB/s"
     else:
-        ach = nflops / (us * 1e-6) / 1e12
+        ach = g0["flops_per_launch"] / (g0["avg_us"] * 1e-6) / 1e12
         peak, unit = (MFMA_BF16_PEAK_TF if a.dtype == "bf16" else MFMA_F32_PEAK_TF), "TFLOP/s"
-    traffic, traffic_src = _pmc_traffic(a, kern)
+    kernel_ms = sum(g["us_per_step"] for g in groups) / 1e3
+    ref, ref_file = _reference(a)
+    ref_name = "profiles/" + os.path.basename(ref_file)
+    traffic, traffic_src, check_, suspect, why = None, f"{ref_name} missing: no PMC pass committed for this workload", None, False, []
+    if ref is not None:
+        row = ref["kernels"].get(kern)
+        prov = f"{ref_name} (rocprofv3 of the same workload at library build {ref.get('lib_sha16')}; this run's library {_lib_sha16()})"
+        if row and row.get("hbm_bytes_per_launch") is not None:
+            traffic, traffic_src = round(row["hbm_bytes_per_launch"]), prov + ": 2 x FETCH_SIZE + WRITE_SIZE per launch, launch-weighted over the kernel's launch shapes"
+        else:
+            traffic_src = f"{ref_name} has no PMC row for {kern}"
+        if row:
+            check_ = {"rocprof_avg_us": round(row["avg_us"], 2), "rocprof_calls_per_step": round(row["calls_per_step"], 2),
+                      "avg_us_over_rocprof": round(g0["avg_us"] / row["avg_us"], 3), "rocprof_kernel_ms_per_step": round(ref["serialized_ms_per_step"], 3),
+                      "kernel_ms_over_rocprof": round(kernel_ms / ref["serialized_ms_per_step"], 3), "source": prov}
+            if abs(g0["avg_us"] / row["avg_us"] - 1.0) > 0.15:
+                suspect = True
+                why.append(f"avg_us {g0['avg_us']:.1f} vs rocprofv3 {row['avg_us']:.1f} for the same kernel: off by more than 15 %")
+        else:
+            suspect = True
+            why.append(f"{ref_name} has no row for {kern}")
+        if kernel_ms > 1.25 * ref["serialized_ms_per_step"]:
+            suspect = True
+            why.append(f"kernel_ms_per_step {kernel_ms:.2f} > 1.25 x the committed rocprofv3 serialized total {ref['serialized_ms_per_step']:.2f}")
+    if not same:
+        why.append("the traced steps did not launch identical sequences: means over all launches instead of per-instance medians")
 
     def grp(g):
-        return {"kernel": f"{g['kernel']} [{g['launch_shape']}]", "calls_per_step": round(g["calls_per_step"], 2), "avg_us": round(g["avg_us"], 2),
+        return {"kernel": g["kernel"], "calls_per_step": round(g["calls_per_step"], 2), "avg_us": round(g["avg_us"], 2),
                 "ms_per_step": round(g["us_per_step"] / 1e3, 4), "GBps": round(g["bytes_per_launch"] / (g["avg_us"] * 1e-6) / 1e9, 1),
-                "TFLOPps": round(g["flops_per_launch"] / (g["avg_us"] * 1e-6) / 1e12, 1)}
-    out = {"bound": bound, "kernel": kern + " [all %d launch shapes]" % len(kg), "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                "TFLOPps": round(g["flops_per_launch"] / (g["avg_us"] * 1e-6) / 1e12, 1),
+                **({"rocprof_avg_us": round(ref["kernels"][g["kernel"]]["avg_us"], 2)} if ref and g["kernel"] in ref["kernels"] else {})}
+    step_bytes = ref.get("hbm_bytes_per_step") if ref else None
+    compulsory = _compulsory_bytes(a, step)
+    out = {"bound": bound, "kernel": kern, "achieved": round(ach, 1), "peak": peak, "unit": unit,
            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-           "measured": "in the step: HIP events around each launch of eager steps (one stream, as rocprofv3 sees them); algorithmic bytes of all the "
-                       "kernel's launches / their total time",
-           "calls_per_step": round(calls, 2), "avg_us": round(us / calls, 2), "ms_per_step": round(us / 1e3, 4),
-           "launches_per_step": round(sum(g["launches_per_step"] for g in groups), 1),
-           "kernel_ms_per_step": round(sum(g["us_per_step"] for g in groups) / 1e3, 3),
-           "algorithmic_bytes_per_launch": round(nbytes / calls), "flops_per_launch": round(nflops / calls),
-           "launch_shapes": [grp(g) for g in kg],
-           "instances": kg[0]["instances"],
-           "other_groups": [grp(g) for g in groups if g["kernel"] != kern][:8],
+           "measured": ("in the step: the library's launch trace (start / stop events on each dispatch of %d eager one-stream steps after 2 untraced ones; "
+                        "per-launch-position median over the steps); algorithmic bytes (flops) of all the kernel's launches / their total time" % n_steps)
+                       if mode == TRACE_DISPATCH else "in the step: hipEventRecord pairs around each launch inside the library (cross-check mode)",
+           "suspect": suspect, "suspect_reason": "; ".join(why) or None, "check_against_profile": check_,
+           "calls_per_step": round(g0["calls_per_step"], 2), "avg_us": round(g0["avg_us"], 2), "ms_per_step": round(g0["us_per_step"] / 1e3, 4),
+           "launches_per_step": round(sum(g["calls_per_step"] for g in groups), 1),
+           "kernel_ms_per_step": round(kernel_ms, 3),
+           "algorithmic_bytes_per_launch": round(g0["bytes_per_launch"]), "flops_per_launch": round(g0["flops_per_launch"]),
+           "instances": g0["instances"],
+           "other_groups": [grp(g) for g in groups[1:13]],
            "families": _families(groups),
+           "step": {"hbm_bytes_per_step_pmc": step_bytes,
+                    "hbm_frac_step": (round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (step_bytes and ms_per_step) else None),
+                    "compulsory_bytes_per_step": compulsory,
+                    "traffic_over_compulsory": (round(step_bytes / compulsory, 1) if (step_bytes and compulsory) else None),
+                    "note": "PMC bytes of one eager step at the L2 <-> fabric boundary (Infinity-Cache hits included) / the graph-replayed step time / 8 TB/s; "
+                            "compulsory = the windows read once + 40 B per trained parameter (SURVEY 8d)"},
            "isolated": roofline_isolated(a, step, device) if (a.model == "SW_Transformer" and a.dataset == "MOD") else None}
     return out
+
+
+def _lib_sha16():
+    import hashlib
+    from focal_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+def _compulsory_bytes(a, step):
+    """every window read once per view (time domain, fp32) + 40 B per trained parameter (weights read three times,
+    gradient, AdamW state)."""
+    x = sum(t.numel() * 4 for mm in step.x.values() for t in mm.values())
+    n_par = sum(p.numel() for p in step.model.parameters() if p.requires_grad)
+    return int(2 * x + 40 * n_par)
 
 
 def _families(groups):
@@ -431,7 +532,8 @@ def _families(groups):
     fam = {}
     for g in groups:
         k = g["kernel"]
-        name = ("weight gradients (all dW launches)" if k.startswith(("focal_gemm_kernel<dW", "focal_dw_ring_kernel", "focal_dw_group_kernel")) else k.split("<")[0].split(" ")[0])
+        name = ("weight gradients (all dW launches)" if (k.startswith(("focal_dw_ring", "focal_dw_group")) or (k.startswith("focal_gemm_kernel<") and ", true, true," in k))
+                else k.split("<")[0].split(" ")[0])
         f = fam.setdefault(name, [0.0, 0.0, 0.0, 0.0])
         f[0] += g["calls_per_step"]
         f[1] += g["us_per_step"]
@@ -473,6 +575,21 @@ def roofline_isolated(a, step, device):
     return {"kernel": "dW[%d,%d] += dy[%d,%d]^T x[%d,%d] (%s)" % (N, K, M, N, M, K, a.dtype), "algorithmic_bytes": bytes_alg,
             "warm_us": round(ms_w * 1e3, 2), "warm_frac": round(bytes_alg / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "cold_us": round(ms_c * 1e3, 2), "cold_frac": round(bytes_alg / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def dump_trace(a, step):
+    """tools/profile_round.sh: the launch trace in both modes next to the rocprofv3 pass of the same box (profiles/r4_trace_vs_rocprof_*.txt)."""
+    from focal_amd._lib import TRACE_DISPATCH, TRACE_EVENTS
+    for _ in range(2):
+        step.run()
+    torch.cuda.synchronize()
+    out = {}
+    for tag, mode in (("dispatch", TRACE_DISPATCH), ("events", TRACE_EVENTS)):
+        groups, per_step, same = run_traced_steps(step, 5, mode)
+        out[tag] = {"same_sequence": same, "kernel_ms_per_step": sum(g["us_per_step"] for g in groups) / 1e3,
+                    "kernels": {g["kernel"]: {"calls_per_step": g["calls_per_step"], "avg_us": g["avg_us"], "bytes_per_launch": g["bytes_per_launch"],
+                                              "flops_per_launch": g["flops_per_launch"], "bound": g["bound"]} for g in groups}}
+    json.dump(out, open(a.trace_dump, "w"), indent=1)
 
 
 def cpu_baseline(a, cfg):
@@ -526,32 +643,9 @@ def cpu_baseline(a, cfg):
     return out
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hook (tests/ and single-GPU boxes only): FOCAL_BENCH_TEST_BACKEND=gloo runs every rank on cuda:0 over gloo so
-    # that the N>1 control flow can be exercised on a 1-GPU box; the driver's multi-GPU runs use RCCL, one GPU per rank.
-    test_backend = os.environ.get("FOCAL_BENCH_TEST_BACKEND")
-    if test_backend:
-        local = 0
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if world > 1:
-        if test_backend:
-            dist.init_process_group(test_backend)
-        else:
-            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=30))
-    rank = dist.get_rank() if world > 1 else 0
-    if os.environ.get("FOCAL_ABLATE"):  # timing diagnostic (tools/ablate_shim.py): the JSON line is marked invalid below
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import ablate_shim
-        ablate_shim.install()
-    step = Step(a, device)
-    if a.roofline_only:
-        print(json.dumps(roofline(a, step, device)))
-        return
-
+def timed_steps(a, step, world, rank, device, steps, warmup):
+    """Capture (unless --no-graph), `warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides.
+    Returns (seconds of this rank, whether graphs were replayed, the stream everything ran on)."""
     graphed = False
     run = step.run
     side = torch.cuda.Stream()
@@ -588,7 +682,7 @@ def main():
             def run():
                 step.feed_step_inputs()
                 inner()
-        for _ in range(a.warmup):
+        for _ in range(warmup):
             run()
             step.loss.item()
         torch.cuda.synchronize()
@@ -598,7 +692,7 @@ def main():
         t0 = time.perf_counter()
         lag = os.environ.get("FOCAL_BENCH_LAGGED_LOSS") == "1"  # diagnostic: read step k-1's loss after launching step k
         prev = None
-        for _ in range(a.steps):
+        for _ in range(steps):
             run()
             if lag:
                 if prev is not None:
@@ -611,12 +705,72 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    return dt, graphed, side
+
+
+def secondary_workloads(a, device):
+    """BASELINE configs[1] (DeepSense, MOD) and the per-GPU workload of configs[4] (SW_Transformer, 4-modality HAR4) timed by the same
+    process right after the headline, the same way (captured step, 10 warm-up + 20 timed steps, loss read every step): so that the
+    driver's own run carries them.  The headline keys of the JSON line are untouched."""
+    out = {}
+    for model, dataset in (("DeepSense", "MOD"), ("SW_Transformer", "HAR4")):
+        if (model, dataset) == (a.model, a.dataset):
+            continue
+        b = copy.copy(a)
+        b.model, b.dataset, b.views, b.from_host = model, dataset, "fixed", False
+        try:
+            st = Step(b, device)
+            dt, graphed, _ = timed_steps(b, st, 1, 0, device, 20, 10)
+            out[f"{model}/{dataset}"] = {"value": round(b.batch * 20 / dt, 1), "unit": "windows/s", "ms_per_step": round(dt / 20 * 1e3, 3), "steps": 20, "warmup": 10,
+                                         "hip_graph": graphed, "dtype": b.dtype, "batch": b.batch, "last_loss": round(st.loss.item(), 4)}
+            del st
+        except Exception as e:  # noqa: BLE001  (a secondary workload must never take the headline line down with it)
+            out[f"{model}/{dataset}"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/ and single-GPU boxes only): FOCAL_BENCH_TEST_BACKEND=gloo runs every rank on cuda:0 over gloo so
+    # that the N>1 control flow can be exercised on a 1-GPU box; the driver's multi-GPU runs use RCCL, one GPU per rank.
+    test_backend = os.environ.get("FOCAL_BENCH_TEST_BACKEND")
+    if test_backend:
+        local = 0
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        if test_backend:
+            dist.init_process_group(test_backend)
+        else:
+            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=30))
+    rank = dist.get_rank() if world > 1 else 0
+    if os.environ.get("FOCAL_ABLATE"):  # timing diagnostic (tools/ablate_shim.py): the JSON line is marked invalid below
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import ablate_shim
+        ablate_shim.install()
+    step = Step(a, device)
+    if a.roofline_only:
+        print(json.dumps(roofline(a, step, device)))
+        return
+    if a.trace_dump:
+        dump_trace(a, step)
+        return
+
+    dt, graphed, side = timed_steps(a, step, world, rank, device, a.steps, a.warmup)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     last_loss = step.loss.item()
-    rl = roofline(a, step, device) if (rank == 0 and not a.no_roofline) else None
+    with torch.cuda.stream(side):  # the stream the warm-up and the timed steps ran on: its allocator pools are the warm ones
+        rl = roofline(a, step, device, dt / a.steps * 1e3) if (rank == 0 and not a.no_roofline) else None
+    # (the plain single-GPU run only: profiling / diagnostic invocations -- --no-graph, --no-roofline, --no-cpu-baseline -- measure one workload)
+    plain = not (a.no_secondary or a.no_graph or a.no_roofline or a.no_cpu_baseline or a.no_dropout or a.from_host or a.views != "fixed" or a.batch != 256)
+    sec = secondary_workloads(a, device) if (rank == 0 and world == 1 and plain and a.model == "SW_Transformer" and a.dataset == "MOD") else None
     cb = cpu_baseline(a, step.cfg) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
     if world > 1:
         dist.barrier()  # the other ranks wait here while rank 0 measures its roofline: all leave the process group together
@@ -638,7 +792,7 @@ def main():
                "model_flops_frac_of_bf16_mfma_peak": (round(wps / world * flops_per_window(a.model, a.dataset) / (MFMA_BF16_PEAK_TF * 1e12), 5)
                                                        if flops_per_window(a.model, a.dataset) else None),
                "flops_per_window": flops_per_window(a.model, a.dataset),
-               "roofline": rl, "cpu_baseline": cb}
+               "roofline": rl, "cpu_baseline": cb, "secondary": sec}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -14,7 +14,7 @@ ACT_NONE, ACT_GELU, ACT_RELU_OUT = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class DropDesc(C.Structure):
@@ -98,12 +98,21 @@ class AdamWDesc(C.Structure):
     _fields_ = [("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("l2_decay", C.c_int)]
 
 
+class TraceRecord(C.Structure):
+    _fields_ = [("kernel", C.c_char * 384), ("grid", C.c_uint * 3), ("block", C.c_uint * 3), ("stream", C.c_void_p), ("us", C.c_float)]
+
+
+TRACE_DISPATCH, TRACE_EVENTS = 1, 2
 P = C.c_void_p
 # name -> (restype, argtypes); every symbol include/focal_hip.h declares
 PROTOTYPES = {
     "focal_abi_version": (C.c_int, []),
     "focal_last_error": (C.c_char_p, []),
     "focal_last_kernel": (C.c_char_p, []),
+    "focal_trace_begin": (C.c_int, [C.c_int, C.c_int]),
+    "focal_trace_end": (C.c_int, []),
+    "focal_trace_count": (C.c_int, []),
+    "focal_trace_read": (C.c_int, [C.c_int, C.c_int, C.POINTER(TraceRecord)]),
     "focal_rng_advance": (C.c_int, [P, P]),
     "focal_fft_realpack_fwd": (C.c_int, [C.POINTER(FFTDesc), P, P, P, P]),
     "focal_augment_fft_fwd": (C.c_int, [C.POINTER(FFTDesc), C.POINTER(AugDesc), P, P, P, P]),

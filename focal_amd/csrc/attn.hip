@@ -302,7 +302,7 @@ extern "C" int focal_window_attn_fwd(const focal_attn_desc* d, const void* qkv, 
   if (blocks > 4096) blocks = 4096;
   const size_t sm = wpb * per_win;
   hipStream_t st = (hipStream_t)stream;
-#define ATT_FWD_(T, HD, NT) hipLaunchKernelGGL((window_attn_fwd_kernel<T, HD, NT>), dim3(blocks), dim3(threads), sm, st, (const T*)qkv, bias_table, (T*)out, g, wpb, total, d->rng, d->stream, d->p_attn)
+#define ATT_FWD_(T, HD, NT) FOCAL_LAUNCH((window_attn_fwd_kernel<T, HD, NT>), dim3(blocks), dim3(threads), sm, st, (const T*)qkv, bias_table, (T*)out, g, wpb, total, d->rng, d->stream, d->p_attn)
 #define ATT_FWD(T, HD) do { if (g.N == 9) ATT_FWD_(T, HD, 9); else ATT_FWD_(T, HD, ATT_NMAX); } while (0)
   if (d->dtype == FOCAL_F32) { if (g.hd == 16) ATT_FWD(float, 16); else if (g.hd == 32) ATT_FWD(float, 32); else ATT_FWD(float, 64); }
   else { if (g.hd == 16) ATT_FWD(bf16_t, 16); else if (g.hd == 32) ATT_FWD(bf16_t, 32); else ATT_FWD(bf16_t, 64); }
@@ -335,7 +335,7 @@ extern "C" int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, 
   if (blocks > 1024) blocks = 1024;  // bounds the atomic fan-in on the 25 x heads bias-table gradient
   const size_t sm = wpb * per_win + fixed;
   hipStream_t st = (hipStream_t)stream;
-#define ATT_BWD_(T, HD, NT) hipLaunchKernelGGL((window_attn_bwd_kernel<T, HD, NT>), dim3(blocks), dim3(threads), sm, st, (const T*)qkv, bias_table, (const T*)dout, (T*)dqkv, dbias_table, g, wpb, total, d->rng, d->stream, d->p_attn)
+#define ATT_BWD_(T, HD, NT) FOCAL_LAUNCH((window_attn_bwd_kernel<T, HD, NT>), dim3(blocks), dim3(threads), sm, st, (const T*)qkv, bias_table, (const T*)dout, (T*)dqkv, dbias_table, g, wpb, total, d->rng, d->stream, d->p_attn)
 #define ATT_BWD(T, HD) do { if (g.N == 9) ATT_BWD_(T, HD, 9); else ATT_BWD_(T, HD, ATT_NMAX); } while (0)
   if (d->dtype == FOCAL_F32) { if (g.hd == 16) ATT_BWD(float, 16); else if (g.hd == 32) ATT_BWD(float, 32); else ATT_BWD(float, 64); }
   else { if (g.hd == 16) ATT_BWD(bf16_t, 16); else if (g.hd == 32) ATT_BWD(bf16_t, 32); else ATT_BWD(bf16_t, 64); }

@@ -423,7 +423,7 @@ int focal_attn_mfma_fwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
   int blocks = ceil_div(items, 4);
   if (blocks > 4096) blocks = 4096;
   const int iters = ceil_div(items, blocks * 4);
-#define LAUNCH(HD) hipLaunchKernelGGL((window_attn_fwd_mfma_kernel<HD>), dim3(blocks), dim3(256), 0, st, qkv, bias_table, out, g, items, iters, rng, stream_id, p_attn)
+#define LAUNCH(HD) FOCAL_LAUNCH((window_attn_fwd_mfma_kernel<HD>), dim3(blocks), dim3(256), 0, st, qkv, bias_table, out, g, items, iters, rng, stream_id, p_attn)
   if (g.hd == 16) LAUNCH(16); else if (g.hd == 32) LAUNCH(32); else LAUNCH(64);
 #undef LAUNCH
   FOCAL_LAUNCH_CHECK();
@@ -443,7 +443,7 @@ int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
   int blocks = ceil_div(items, nw);
   if (blocks > maxb) blocks = maxb;
   const int iters = ceil_div(items, blocks * nw);
-#define LAUNCH2(HD, NW) hipLaunchKernelGGL((window_attn_bwd_mfma_kernel<HD, NW>), dim3(blocks), dim3(NW * 64), 0, st, qkv, bias_table, dout, dqkv, dbias_table, g, items, iters, rng, stream_id, p_attn)
+#define LAUNCH2(HD, NW) FOCAL_LAUNCH((window_attn_bwd_mfma_kernel<HD, NW>), dim3(blocks), dim3(NW * 64), 0, st, qkv, bias_table, dout, dqkv, dbias_table, g, items, iters, rng, stream_id, p_attn)
 #define LAUNCH(HD) do { if (nw == 16) LAUNCH2(HD, 16); else if (nw == 8) LAUNCH2(HD, 8); else LAUNCH2(HD, 4); } while (0)
   if (g.hd == 16) LAUNCH(16); else if (g.hd == 32) LAUNCH(32); else LAUNCH(64);
 #undef LAUNCH2

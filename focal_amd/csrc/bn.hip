@@ -249,7 +249,7 @@ extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scr
   const int C = d->C;
   if (training == FOCAL_BN_EVAL) {
     FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
-    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, running_mean, running_var, mean_rstd, C, d->eps);
+    FOCAL_LAUNCH(bn_eval_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, running_mean, running_var, mean_rstd, C, d->eps);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
@@ -266,11 +266,11 @@ extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scr
       FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
       fin.mean_rstd = mean_rstd; fin.run_mean = running_mean; fin.run_var = running_var;
     }
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(1024), 32 * C * sizeof(float), st, z, scratch, (long)d->rows, C, fin);
+    FOCAL_LAUNCH(bn_partial_kernel, dim3(blocks), dim3(1024), 32 * C * sizeof(float), st, z, scratch, (long)d->rows, C, fin);
   }
   if (training == FOCAL_BN_FINALIZE || (training == FOCAL_BN_TRAIN && getenv("FOCAL_BN_NOFUSE"))) {
     FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, mean_rstd, running_mean, running_var, n_stat, C,
+    FOCAL_LAUNCH(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, mean_rstd, running_mean, running_var, n_stat, C,
                        d->eps, d->momentum);
   }
   FOCAL_LAUNCH_CHECK();
@@ -284,10 +284,10 @@ extern "C" int focal_bn_act_fwd(const focal_bn_desc* d, const float* z, const fl
   hipStream_t st = (hipStream_t)stream;
   const int blocks = stream_blocks(d->rows, d->C);
   if (d->dtype == FOCAL_F32)
-    hipLaunchKernelGGL((bn_act_fwd_kernel<float>), dim3(blocks), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (float*)y_cast,
+    FOCAL_LAUNCH((bn_act_fwd_kernel<float>), dim3(blocks), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (float*)y_cast,
                        (long)d->rows, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
   else
-    hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (bf16_t*)y_cast,
+    FOCAL_LAUNCH((bn_act_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (bf16_t*)y_cast,
                        (long)d->rows, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
@@ -306,22 +306,22 @@ extern "C" int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const fl
     if (!prezeroed) (void)hipMemsetAsync(scratch, 0, (2 * C + 1) * sizeof(float), st);
     int rb = ceil_div((long)d->rows * C / 4, 1024 * 2);
     if (rb > 256) rb = 256;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(1024), 32 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
+    FOCAL_LAUNCH(bn_bwd_reduce_kernel, dim3(rb), dim3(1024), 32 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
                        (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
   }
   if (phase == FOCAL_BN_PARTIAL) {  // the parameter gradients are the LOCAL sums (the gradient all-reduce adds the other ranks')
     FOCAL_CHECK_ARG(dgamma && dbeta, "bn_act_bwd: null tensor");
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, dgamma, dbeta, C);
+    FOCAL_LAUNCH(bn_param_grad_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, dgamma, dbeta, C);
   } else {
     FOCAL_CHECK_ARG(dz && (phase == FOCAL_BN_FINALIZE || (dgamma && dbeta)), "bn_act_bwd: null tensor");
     float* dgm = phase == FOCAL_BN_FINALIZE ? nullptr : dgamma;
     const long stat_rows = (phase == FOCAL_BN_FINALIZE && d->stat_rows > 0) ? d->stat_rows : d->rows;
     const int blocks = stream_blocks(d->rows, C);
     if (d->dtype == FOCAL_F32)
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (float*)dz,
+      FOCAL_LAUNCH((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (float*)dz,
                          dgm, dbeta, (long)d->rows, stat_rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
     else
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (bf16_t*)dz,
+      FOCAL_LAUNCH((bn_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (bf16_t*)dz,
                          dgm, dbeta, (long)d->rows, stat_rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
   }
   FOCAL_LAUNCH_CHECK();
@@ -351,7 +351,7 @@ extern "C" int focal_bn_running_combine(int n, float* const* running, const floa
     FOCAL_CHECK_ARG(running[i] && view1[i] && view2[i], "bn_running_combine: null buffer %d", i);
     t.run[i] = running[i]; t.s1[i] = view1[i]; t.s2[i] = view2[i];
   }
-  hipLaunchKernelGGL(bn_running_combine_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, t, C, momentum);
+  FOCAL_LAUNCH(bn_running_combine_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, t, C, momentum);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

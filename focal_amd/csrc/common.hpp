@@ -1,6 +1,7 @@
 // Shared device/host helpers for libfocal_hip (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -33,6 +34,26 @@ void focal_note_kernel(const char* fmt, ...);
       focal_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
       return FOCAL_EHIP;                                                           \
     }                                                                              \
+  } while (0)
+
+// ----------------------------------------------------------------------------------------------- launches
+// Every kernel of the library goes out through FOCAL_LAUNCH: the plain launch, or -- while a launch trace is open (trace.cpp,
+// focal_trace_begin: bench.py's in-step roofline) -- the same launch with a start / stop event pair on the dispatch itself.
+extern int g_focal_trace_on;
+int focal_trace_slot(const void* kernel, dim3 grid, dim3 block, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);
+#define FOCAL_LAUNCH(kern, grid, block, sm, st, ...)                                                  \
+  do {                                                                                                 \
+    auto k__ = (kern);                                                                                 \
+    hipStream_t st__ = (st);                                                                           \
+    hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                         \
+    const int tm__ = __builtin_expect(g_focal_trace_on, 0) ? focal_trace_slot((const void*)k__, (grid), (block), st__, &e0__, &e1__) : 0; \
+    if (tm__ == FOCAL_TRACE_DISPATCH) {                                                                \
+      hipExtLaunchKernelGGL(k__, (grid), (block), (sm), st__, e0__, e1__, 0, __VA_ARGS__);             \
+    } else {                                                                                           \
+      if (tm__ == FOCAL_TRACE_EVENTS) (void)hipEventRecord(e0__, st__);                                \
+      hipLaunchKernelGGL(k__, (grid), (block), (sm), st__, __VA_ARGS__);                               \
+      if (tm__ == FOCAL_TRACE_EVENTS) (void)hipEventRecord(e1__, st__);                                \
+    }                                                                                                  \
   } while (0)
 
 // ----------------------------------------------------------------------------------------------- scalar conversions

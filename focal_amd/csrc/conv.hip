@@ -374,14 +374,14 @@ extern "C" int focal_conv_in_fwd(const focal_conv_in_desc* d, const float* x, co
     static const int cap = getenv("FOCAL_CONVIN_BLOCKS") ? atoi(getenv("FOCAL_CONVIN_BLOCKS")) : 256;
     if (blocks > cap) blocks = cap;
     const PatchGeom pg = make_patch_geom(d->S_out, d->I, d->I, d->S_in, d->k, d->cin);
-    hipLaunchKernelGGL((conv_in_fwd_mfma_kernel<160>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, z, *d, total, pg);
+    FOCAL_LAUNCH((conv_in_fwd_mfma_kernel<160>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, z, *d, total, pg);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
   const size_t sm = ((size_t)K * d->C + (size_t)CIN_TOK * (K + 1)) * sizeof(float);
   int blocks = ceil_div(total, CIN_TOK);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL((conv_in_fwd_kernel<64>), dim3(blocks), dim3(256), sm, (hipStream_t)stream, x, w, bias, z, *d, K, total);
+  FOCAL_LAUNCH((conv_in_fwd_kernel<64>), dim3(blocks), dim3(256), sm, (hipStream_t)stream, x, w, bias, z, *d, K, total);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -400,9 +400,9 @@ extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float
     hipStream_t st = (hipStream_t)stream;
     const PatchGeom pg = make_patch_geom(d->S_out, d->I, d->I, d->S_in, d->k, d->cin);
     if (dz_dtype == FOCAL_F32)
-      hipLaunchKernelGGL((conv_in_bwd_weight_mfma_kernel<float, 160>), dim3(blocks), dim3(256), smm, st, x, (const float*)dz, dw, dbias, *d, total, cpw, pg);
+      FOCAL_LAUNCH((conv_in_bwd_weight_mfma_kernel<float, 160>), dim3(blocks), dim3(256), smm, st, x, (const float*)dz, dw, dbias, *d, total, cpw, pg);
     else
-      hipLaunchKernelGGL((conv_in_bwd_weight_mfma_kernel<bf16_t, 160>), dim3(blocks), dim3(256), smm, st, x, (const bf16_t*)dz, dw, dbias, *d, total, cpw, pg);
+      FOCAL_LAUNCH((conv_in_bwd_weight_mfma_kernel<bf16_t, 160>), dim3(blocks), dim3(256), smm, st, x, (const bf16_t*)dz, dw, dbias, *d, total, cpw, pg);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
@@ -413,9 +413,9 @@ extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float
     const int blocks = ceil_div(ceil_div(total, tpw), 16);
     hipStream_t st = (hipStream_t)stream;
     if (dz_dtype == FOCAL_F32)
-      hipLaunchKernelGGL((conv_in_bwd_weight_tiny_kernel<float>), dim3(blocks), dim3(1024), 0, st, x, (const float*)dz, dw, dbias, *d, K, total, tpw);
+      FOCAL_LAUNCH((conv_in_bwd_weight_tiny_kernel<float>), dim3(blocks), dim3(1024), 0, st, x, (const float*)dz, dw, dbias, *d, K, total, tpw);
     else
-      hipLaunchKernelGGL((conv_in_bwd_weight_tiny_kernel<bf16_t>), dim3(blocks), dim3(1024), 0, st, x, (const bf16_t*)dz, dw, dbias, *d, K, total, tpw);
+      FOCAL_LAUNCH((conv_in_bwd_weight_tiny_kernel<bf16_t>), dim3(blocks), dim3(1024), 0, st, x, (const bf16_t*)dz, dw, dbias, *d, K, total, tpw);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
@@ -428,9 +428,9 @@ extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float
     const int blocks = ceil_div(chunks, cpw);
     hipStream_t st = (hipStream_t)stream;
     if (dz_dtype == FOCAL_F32)
-      hipLaunchKernelGGL((conv_in_bwd_weight_smallk_kernel<float, 64>), dim3(blocks), dim3(256), sms, st, x, (const float*)dz, dw, dbias, *d, K, total, cpw);
+      FOCAL_LAUNCH((conv_in_bwd_weight_smallk_kernel<float, 64>), dim3(blocks), dim3(256), sms, st, x, (const float*)dz, dw, dbias, *d, K, total, cpw);
     else
-      hipLaunchKernelGGL((conv_in_bwd_weight_smallk_kernel<bf16_t, 64>), dim3(blocks), dim3(256), sms, st, x, (const bf16_t*)dz, dw, dbias, *d, K, total, cpw);
+      FOCAL_LAUNCH((conv_in_bwd_weight_smallk_kernel<bf16_t, 64>), dim3(blocks), dim3(256), sms, st, x, (const bf16_t*)dz, dw, dbias, *d, K, total, cpw);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
@@ -442,9 +442,9 @@ extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float
   const int blocks = ceil_div(chunks, cpw);
   hipStream_t st = (hipStream_t)stream;
   if (dz_dtype == FOCAL_F32)
-    hipLaunchKernelGGL((conv_in_bwd_weight_kernel<float, 64>), dim3(blocks), dim3(256), sm, st, x, (const float*)dz, dw, dbias, *d, K, total, cpw);
+    FOCAL_LAUNCH((conv_in_bwd_weight_kernel<float, 64>), dim3(blocks), dim3(256), sm, st, x, (const float*)dz, dw, dbias, *d, K, total, cpw);
   else
-    hipLaunchKernelGGL((conv_in_bwd_weight_kernel<bf16_t, 64>), dim3(blocks), dim3(256), sm, st, x, (const bf16_t*)dz, dw, dbias, *d, K, total, cpw);
+    FOCAL_LAUNCH((conv_in_bwd_weight_kernel<bf16_t, 64>), dim3(blocks), dim3(256), sm, st, x, (const bf16_t*)dz, dw, dbias, *d, K, total, cpw);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -476,23 +476,23 @@ template <typename TD> __global__ void conv_pack_bwd_kernel(const float* __restr
 extern "C" int focal_permute_pack(int A, int Bd, int Cd, const float* src, void* dst, int dtype, void* stream) {
   FOCAL_CHECK_ARG(src && dst && A > 0 && Bd > 0 && Cd > 0, "permute_pack: bad argument");
   const int blocks = min(1024, ceil_div((long)A * Bd * Cd, 256));
-  if (dtype == FOCAL_F32) hipLaunchKernelGGL((permute_pack_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, A, Bd, Cd);
-  else hipLaunchKernelGGL((permute_pack_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, A, Bd, Cd);
+  if (dtype == FOCAL_F32) FOCAL_LAUNCH((permute_pack_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, A, Bd, Cd);
+  else FOCAL_LAUNCH((permute_pack_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, A, Bd, Cd);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
 extern "C" int focal_permute_unpack_add(int A, int Bd, int Cd, const float* src, float* dst, void* stream) {
   FOCAL_CHECK_ARG(src && dst && A > 0 && Bd > 0 && Cd > 0, "permute_unpack_add: bad argument");
   const int blocks = min(1024, ceil_div((long)A * Bd * Cd, 256));
-  hipLaunchKernelGGL(permute_unpack_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, A, Bd, Cd);
+  FOCAL_LAUNCH(permute_unpack_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, A, Bd, Cd);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
 extern "C" int focal_conv_pack_bwd(const focal_conv_desc* d, const float* w, void* w_bwd, void* stream) {
   FOCAL_CHECK_ARG(d && w && w_bwd, "conv_pack_bwd: null argument");
   const int blocks = min(1024, ceil_div((long)d->C_out * d->C_in * d->k, 256));
-  if (d->dtype == FOCAL_F32) hipLaunchKernelGGL((conv_pack_bwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)w_bwd, d->C_out, d->C_in, d->k);
-  else hipLaunchKernelGGL((conv_pack_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)w_bwd, d->C_out, d->C_in, d->k);
+  if (d->dtype == FOCAL_F32) FOCAL_LAUNCH((conv_pack_bwd_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)w_bwd, d->C_out, d->C_in, d->k);
+  else FOCAL_LAUNCH((conv_pack_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)w_bwd, d->C_out, d->C_in, d->k);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -544,8 +544,8 @@ extern "C" int focal_pack_multi(int dtype, int n, const focal_pack_entry* entrie
   long most;
   if (int rc = pack_table(n, entries, &t, &most)) return rc;
   const dim3 grid(min(64, ceil_div(most, 256)), n);
-  if (dtype == FOCAL_F32) hipLaunchKernelGGL((pack_multi_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, t);
-  else hipLaunchKernelGGL((pack_multi_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, t);
+  if (dtype == FOCAL_F32) FOCAL_LAUNCH((pack_multi_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, t);
+  else FOCAL_LAUNCH((pack_multi_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, t);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -554,7 +554,7 @@ extern "C" int focal_unpack_add_multi(int n, const focal_pack_entry* entries, vo
   long most;
   if (int rc = pack_table(n, entries, &t, &most)) return rc;
   for (int i = 0; i < n; ++i) FOCAL_CHECK_ARG(entries[i].kind == FOCAL_PACK_PERMUTE, "unpack_add_multi: entry %d is not a permutation", i);
-  hipLaunchKernelGGL(unpack_add_multi_kernel, dim3(min(64, ceil_div(most, 256)), n), dim3(256), 0, (hipStream_t)stream, t);
+  FOCAL_LAUNCH(unpack_add_multi_kernel, dim3(min(64, ceil_div(most, 256)), n), dim3(256), 0, (hipStream_t)stream, t);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -235,14 +235,14 @@ static int embed_launch(const focal_embed_desc* d, const float* x, const float* 
     static const int mb_cap = getenv("FOCAL_EMBED_BLOCKS") ? atoi(getenv("FOCAL_EMBED_BLOCKS")) : 512;
     if (mb > mb_cap) mb = mb_cap;
     const PatchGeom pg = make_patch_geom(d->Wp, d->Hp, d->I, d->S, d->pw, d->cin);
-    hipLaunchKernelGGL((patch_embed_ln_mfma_kernel<80>), dim3(mb), dim3(256), 0, st, x, w, b, gamma, beta, tokens, *d, total, pg, l2);
+    FOCAL_LAUNCH((patch_embed_ln_mfma_kernel<80>), dim3(mb), dim3(256), 0, st, x, w, b, gamma, beta, tokens, *d, total, pg, l2);
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
   int blocks = ceil_div(total, EMB_TOK);
   if (blocks > 2048) blocks = 2048;
-  if (d->C0 == 64) hipLaunchKernelGGL((patch_embed_ln_kernel<64>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total, l2);
-  else hipLaunchKernelGGL((patch_embed_ln_kernel<128>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total, l2);
+  if (d->C0 == 64) FOCAL_LAUNCH((patch_embed_ln_kernel<64>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total, l2);
+  else FOCAL_LAUNCH((patch_embed_ln_kernel<128>), dim3(blocks), dim3(256), sm, st, x, w, b, gamma, beta, tokens, *d, K, total, l2);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -273,14 +273,14 @@ static int fft_launch(const focal_fft_desc* d, const AugParams& aug, const float
     }
     static const int maxb = getenv("FOCAL_FFT_BLOCKS") ? atoi(getenv("FOCAL_FFT_BLOCKS")) : 1024;
     int blocks = rows / 2 < maxb ? rows / 2 : maxb;
-#define FFT_GO(N_) case N_: hipLaunchKernelGGL((fft_realpack_mfma_kernel<N_, N_>), dim3(blocks), dim3(256), smm, (hipStream_t)stream, x, twiddle, out, *d, rows, aug); break
+#define FFT_GO(N_) case N_: FOCAL_LAUNCH((fft_realpack_mfma_kernel<N_, N_>), dim3(blocks), dim3(256), smm, (hipStream_t)stream, x, twiddle, out, *d, rows, aug); break
     switch (d->n1) { FFT_GO(8); FFT_GO(16); FFT_GO(24); FFT_GO(32); FFT_GO(40); default: FFT_GO(48); }
 #undef FFT_GO
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
   int blocks = rows < 4096 ? rows : 4096;
-  hipLaunchKernelGGL(fft_realpack_kernel, dim3(blocks), dim3(256), sm, (hipStream_t)stream, x, twiddle, out, *d, rows, aug);
+  FOCAL_LAUNCH(fft_realpack_kernel, dim3(blocks), dim3(256), sm, (hipStream_t)stream, x, twiddle, out, *d, rows, aug);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -353,7 +353,7 @@ extern "C" int focal_fft_realpack_multi(int n, const focal_fft_problem* probs, v
   memset(&t, 0, sizeof(t));
   auto flush = [&]() -> int {
     if (t.nprob == 0) return FOCAL_OK;
-    hipLaunchKernelGGL(fft_small_multi_kernel, dim3(t.wg_end[t.nprob - 1]), dim3(256), 0, (hipStream_t)stream, t);
+    FOCAL_LAUNCH(fft_small_multi_kernel, dim3(t.wg_end[t.nprob - 1]), dim3(256), 0, (hipStream_t)stream, t);
     FOCAL_LAUNCH_CHECK();
     memset(&t, 0, sizeof(t));
     return FOCAL_OK;

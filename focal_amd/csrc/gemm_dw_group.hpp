@@ -246,6 +246,6 @@ static inline hipError_t focal_launch_dw_group(const DwGroupParams& gp, int wgs,
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), LDS_BYTES, stream, gp);
+  FOCAL_LAUNCH(kern, dim3(wgs), dim3(512), LDS_BYTES, stream, gp);
   return hipGetLastError();
 }

@@ -276,7 +276,7 @@ static inline hipError_t focal_launch_dw_ring_group(const DwRingGroupParams& gp,
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256 * HALVES), LDS_BYTES, stream, gp);
+  FOCAL_LAUNCH(kern, dim3(wgs), dim3(256 * HALVES), LDS_BYTES, stream, gp);
   return hipGetLastError();
 }
 
@@ -294,7 +294,7 @@ static inline hipError_t focal_launch_dw_ring(const GemmParams& p, hipStream_t s
     attr_set = true;
   }
   dim3 grid((p.M / TILE) * (p.N / TILE) * p.splits);
-  if (p.colsumA) hipLaunchKernelGGL(kern, grid, dim3(256 * HALVES), LDS_BYTES, stream, p);
-  else hipLaunchKernelGGL(kern0, grid, dim3(256 * HALVES), LDS_BYTES, stream, p);
+  if (p.colsumA) FOCAL_LAUNCH(kern, grid, dim3(256 * HALVES), LDS_BYTES, stream, p);
+  else FOCAL_LAUNCH(kern0, grid, dim3(256 * HALVES), LDS_BYTES, stream, p);
   return hipGetLastError();
 }

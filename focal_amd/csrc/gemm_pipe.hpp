@@ -529,6 +529,6 @@ static inline hipError_t focal_launch_gemm_pipe(const GemmParams& p, hipStream_t
     attr_set = true;
   }
   dim3 grid(((p.M + BM - 1) / BM) * (p.N / BN) * p.batch);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), LDS_BYTES, stream, p);
+  FOCAL_LAUNCH(kern, grid, dim3(64 * WGM * WGN), LDS_BYTES, stream, p);
   return hipGetLastError();
 }

@@ -316,7 +316,7 @@ static int gblocks(long n) { long b = (n + 255) / 256; return (int)(b > 2048 ? 2
 extern "C" int focal_gru_gate_fwd(const focal_gru_desc* d, int t, int dir_offset, const float* gi, const float* gh, const float* h_prev,
                                   float* h_new, float* out, float* save, void* stream) {
   FOCAL_CHECK_ARG(d && gi && gh && h_new && out && save && t >= 0 && t < d->T, "gru_gate_fwd: bad argument");
-  hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(gblocks((long)d->B * d->H)), dim3(256), 0, (hipStream_t)stream, *d, t, dir_offset, gi, gh,
+  FOCAL_LAUNCH(gru_gate_fwd_kernel, dim3(gblocks((long)d->B * d->H)), dim3(256), 0, (hipStream_t)stream, *d, t, dir_offset, gi, gh,
                      h_prev, h_new, out, save);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
@@ -326,7 +326,7 @@ extern "C" int focal_gru_gate_bwd(const focal_gru_desc* d, int t, int dir_offset
                                   const float* dh_rec, const float* dhz_in, const float* save, const float* h_prev, float* dgi,
                                   float* dgh, float* dhz_out, void* stream) {
   FOCAL_CHECK_ARG(d && dout && save && dgi && dgh && dhz_out && t >= 0 && t < d->T, "gru_gate_bwd: bad argument");
-  hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(gblocks((long)d->B * d->H)), dim3(256), 0, (hipStream_t)stream, *d, t, dir_offset, dout,
+  FOCAL_LAUNCH(gru_gate_bwd_kernel, dim3(gblocks((long)d->B * d->H)), dim3(256), 0, (hipStream_t)stream, *d, t, dir_offset, dout,
                      ld_b, ld_t, scale, dh_rec, dhz_in, save, h_prev, dgi, dgh, dhz_out);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
@@ -334,14 +334,14 @@ extern "C" int focal_gru_gate_bwd(const focal_gru_desc* d, int t, int dir_offset
 
 extern "C" int focal_mean_time(int B, int T, int D, const float* x, float* y, void* stream) {
   FOCAL_CHECK_ARG(x && y && B > 0 && T > 0 && D > 0, "mean_time: bad argument");
-  hipLaunchKernelGGL(mean_time_kernel, dim3(gblocks((long)B * D)), dim3(256), 0, (hipStream_t)stream, B, T, D, x, y);
+  FOCAL_LAUNCH(mean_time_kernel, dim3(gblocks((long)B * D)), dim3(256), 0, (hipStream_t)stream, B, T, D, x, y);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
 
 extern "C" int focal_dropout(long n, const float* x, float* y, const uint32_t* rng, uint32_t stream_id, float p, void* stream) {
   FOCAL_CHECK_ARG(x && y && n >= 0 && p >= 0.f && p < 1.f, "dropout: bad argument");
-  hipLaunchKernelGGL(dropout_kernel, dim3(gblocks(n)), dim3(256), 0, (hipStream_t)stream, n, x, y, rng, stream_id, p);
+  FOCAL_LAUNCH(dropout_kernel, dim3(gblocks(n)), dim3(256), 0, (hipStream_t)stream, n, x, y, rng, stream_id, p);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -351,14 +351,14 @@ __global__ __launch_bounds__(256) void mul_kernel(long n, const float* __restric
 }
 extern "C" int focal_mul(long n, const float* a, float* y, void* stream) {
   FOCAL_CHECK_ARG(a && y && n >= 0, "mul: bad argument");
-  hipLaunchKernelGGL(mul_kernel, dim3(gblocks(n)), dim3(256), 0, (hipStream_t)stream, n, a, y);
+  FOCAL_LAUNCH(mul_kernel, dim3(gblocks(n)), dim3(256), 0, (hipStream_t)stream, n, a, y);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
 
 extern "C" int focal_axpy(long n, float a, const float* x, float* y, void* stream) {
   FOCAL_CHECK_ARG(x && y && n >= 0, "axpy: bad argument");
-  hipLaunchKernelGGL(axpy_kernel, dim3(gblocks(n)), dim3(256), 0, (hipStream_t)stream, n, a, x, y);
+  FOCAL_LAUNCH(axpy_kernel, dim3(gblocks(n)), dim3(256), 0, (hipStream_t)stream, n, a, x, y);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -386,8 +386,8 @@ extern "C" int focal_gru_seq_fwd(const focal_gru_desc* d, int n_dir, const float
     if (e != hipSuccess) { focal_set_error("gru_seq_fwd: cannot reserve LDS: %s", hipGetErrorString(e)); return FOCAL_EHIP; }
     granted = true;
   }
-  if (H == 256) hipLaunchKernelGGL((gru_seq_fwd_kernel<256, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, out);
-  else hipLaunchKernelGGL((gru_seq_fwd_kernel<128, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, out);
+  if (H == 256) FOCAL_LAUNCH((gru_seq_fwd_kernel<256, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, out);
+  else FOCAL_LAUNCH((gru_seq_fwd_kernel<128, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, out);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -417,8 +417,8 @@ extern "C" int focal_gru_seq_bwd(const focal_gru_desc* d, int n_dir, const float
     if (e != hipSuccess) { focal_set_error("gru_seq_bwd: cannot reserve LDS: %s", hipGetErrorString(e)); return FOCAL_EHIP; }
     granted = true;
   }
-  if (H == 256) hipLaunchKernelGGL((gru_seq_bwd_kernel<256, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
-  else hipLaunchKernelGGL((gru_seq_bwd_kernel<128, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
+  if (H == 256) FOCAL_LAUNCH((gru_seq_bwd_kernel<256, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
+  else FOCAL_LAUNCH((gru_seq_bwd_kernel<128, GRU_NW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

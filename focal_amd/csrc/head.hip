@@ -64,7 +64,7 @@ extern "C" int focal_fusion_attn_fwd(int B, int M, int E, int heads, const float
   FOCAL_CHECK_ARG(q && kv && out && probs && weights, "fusion_attn_fwd: null tensor");
   FOCAL_CHECK_ARG(B > 0 && M >= 1 && M <= FUSE_MAX_M && heads >= 1 && E == heads * 64 && E <= 256,
                   "fusion_attn: need head_dim 64, E <= 256, M <= %d (got M=%d E=%d heads=%d)", FUSE_MAX_M, M, E, heads);
-  hipLaunchKernelGGL(fusion_attn_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, kv, out, probs, weights, M, E, heads,
+  FOCAL_LAUNCH(fusion_attn_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, kv, out, probs, weights, M, E, heads,
                      0.125f, rng, stream_id, p_drop);  // 1 / sqrt(64)
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
@@ -74,7 +74,7 @@ extern "C" int focal_fusion_attn_bwd(int B, int M, int E, int heads, const float
                                      const float* weights, const float* dout, float* dq, float* dkv, void* stream) {
   FOCAL_CHECK_ARG(q && kv && probs && weights && dout && dq && dkv, "fusion_attn_bwd: null tensor");
   FOCAL_CHECK_ARG(B > 0 && M >= 1 && M <= FUSE_MAX_M && heads >= 1 && E == heads * 64 && E <= 256, "fusion_attn_bwd: bad geometry");
-  hipLaunchKernelGGL(fusion_attn_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, kv, probs, weights, dout, dq, dkv, M, E,
+  FOCAL_LAUNCH(fusion_attn_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, q, kv, probs, weights, dout, dq, dkv, M, E,
                      heads, 0.125f);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
 
 extern "C" int focal_cross_entropy(int B, int C, const float* logits, const long* labels, float* loss, float* dlogits, void* stream) {
   FOCAL_CHECK_ARG(B > 0 && C > 0 && logits && labels && loss && dlogits, "cross_entropy: bad argument");
-  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, loss, dlogits, B, C);
+  FOCAL_LAUNCH(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels, loss, dlogits, B, C);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void small_linear_bwd_data_kernel(const float*
 
 extern "C" int focal_small_linear_fwd(int B, int N, int K, const float* x, const float* w, const float* bias, float* y, void* stream) {
   FOCAL_CHECK_ARG(B > 0 && N > 0 && K > 0 && x && w && y, "small_linear_fwd: bad argument");
-  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(ceil_div((long)B * N, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, N, K);
+  FOCAL_LAUNCH(small_linear_fwd_kernel, dim3(ceil_div((long)B * N, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, N, K);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -160,8 +160,8 @@ extern "C" int focal_small_linear_bwd(int B, int N, int K, const float* dy, cons
                                       float* dx, void* stream) {
   FOCAL_CHECK_ARG(B > 0 && N > 0 && K > 0 && dy && x && w && dw, "small_linear_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(small_linear_bwd_weight_kernel, dim3(ceil_div((long)N * K, 256)), dim3(256), 0, st, dy, x, dw, dbias, B, N, K);
-  if (dx) hipLaunchKernelGGL(small_linear_bwd_data_kernel, dim3(ceil_div((long)B * K, 256)), dim3(256), 0, st, dy, w, dx, B, N, K);
+  FOCAL_LAUNCH(small_linear_bwd_weight_kernel, dim3(ceil_div((long)N * K, 256)), dim3(256), 0, st, dy, x, dw, dbias, B, N, K);
+  if (dx) FOCAL_LAUNCH(small_linear_bwd_data_kernel, dim3(ceil_div((long)B * K, 256)), dim3(256), 0, st, dy, w, dx, B, N, K);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -625,8 +625,8 @@ static void gemm_group_add(GemmGroup* g, int M, int N, int K, const float* A, lo
 static int gemm_group_launch(const GemmGroup& g, bool trb, hipStream_t st) {
   if (g.n == 0) return FOCAL_OK;
   const int wgs = g.wg_end[g.n - 1];
-  if (trb) hipLaunchKernelGGL(loss_gemm_group_kernel<true>, dim3(wgs), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL(loss_gemm_group_kernel<false>, dim3(wgs), dim3(256), 0, st, g);
+  if (trb) FOCAL_LAUNCH(loss_gemm_group_kernel<true>, dim3(wgs), dim3(256), 0, st, g);
+  else FOCAL_LAUNCH(loss_gemm_group_kernel<false>, dim3(wgs), dim3(256), 0, st, g);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -728,7 +728,7 @@ static int loss_phase_a(const focal_loss_desc* d, const LossPlan& pl, const floa
   // ---- launch 1: normalised InfoNCE rows of both groups, ranking rows + squared norms (this rank's partial terms zeroed)
   for (int k = 0; k < 2; ++k) a.g[k].blocks = a.g[k].nprob ? ceil_div((long)a.g[k].nprob * seq * n2p, 4) : 0;
   a.blocks_rank = ceil_div((long)Q * Bp, 4);
-  hipLaunchKernelGGL(head_pack_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank), dim3(256), 0, st, a);
+  FOCAL_LAUNCH(head_pack_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank), dim3(256), 0, st, a);
 
   // ---- products: similarity rows S = Zn Zn^T / T per group, Gram rows G = X X^T (exact-fp32 MFMA)
   static const bool one_gemm_launch = getenv("FOCAL_LOSS_GEMM_SEPARATE") == nullptr;
@@ -759,12 +759,12 @@ static int loss_phase_a(const focal_loss_desc* d, const LossPlan& pl, const floa
   a.blocks_orth = loss_row_blocks((long)pl.O * nr);
   if (a.fused_rank_rows) {
     a.blocks_rank = loss_row_blocks((long)Q * sh.bl);
-    hipLaunchKernelGGL(head_rows_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank + a.blocks_orth), dim3(256), 0, st, a);
+    FOCAL_LAUNCH(head_rows_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank + a.blocks_orth), dim3(256), 0, st, a);
   } else {
     a.blocks_rank = capped(ceil_div((long)Q * nr * Bp, 256), 8192);
-    hipLaunchKernelGGL(head_rows_split_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank + a.blocks_orth), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(rank_blockmean_kernel, dim3(capped(ceil_div((long)Q * sh.bl * pl.b, 256), 4096)), dim3(256), 0, st, Q, pl.b, seq, Bp, sh, a.D, a.Dbar);
-    hipLaunchKernelGGL(rank_hinge_kernel, dim3(loss_row_blocks((long)Q * sh.bl)), dim3(256), 0, st, Q, pl.b, d->margin, sh, a.Dbar, a.dDbar,
+    FOCAL_LAUNCH(head_rows_split_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank + a.blocks_orth), dim3(256), 0, st, a);
+    FOCAL_LAUNCH(rank_blockmean_kernel, dim3(capped(ceil_div((long)Q * sh.bl * pl.b, 256), 4096)), dim3(256), 0, st, Q, pl.b, seq, Bp, sh, a.D, a.Dbar);
+    FOCAL_LAUNCH(rank_hinge_kernel, dim3(loss_row_blocks((long)Q * sh.bl)), dim3(256), 0, st, Q, pl.b, d->margin, sh, a.Dbar, a.dDbar,
                        chunk + sh.o_diag, a.diag, a.pterms);
   }
   FOCAL_LAUNCH_CHECK();
@@ -781,14 +781,14 @@ static int loss_phase_b(const focal_loss_desc* d, const LossPlan& pl, const floa
   head_args(d, pl, feats, dfeats, nullptr, xall, terms, ws, &a);
   if (sh.world > 1) {  // (one rank: phase A has written every row's lse / diagonal mean in place already)
     const int nblk = (pl.P_sh + pl.P_pr) * seq;
-    hipLaunchKernelGGL(xchg_unpack_kernel, dim3(capped(ceil_div((long)nblk * n2 + (long)pl.Q * b, 256), 1024)), dim3(256), 0, st, sh, nblk, b, n2p, pl.Q,
+    FOCAL_LAUNCH(xchg_unpack_kernel, dim3(capped(ceil_div((long)nblk * n2 + (long)pl.Q * b, 256), 1024)), dim3(256), 0, st, sh, nblk, b, n2p, pl.Q,
                        xall, ws + pl.off_lse, ws + pl.off_diag);
   }
   const int Q = pl.Q, rs0 = sh.r0 * seq, nr = sh.bl * seq;
   // ---- launch 3: softmax coefficients of both groups (in place of S), ranking coefficients (in place of D) + their row sums, loss terms
   for (int k = 0; k < 2; ++k) a.g[k].blocks = a.g[k].nprob ? capped(ceil_div((long)a.g[k].nprob * seq * 2 * sh.bl * n2p, 256), 8192) : 0;
   a.blocks_rank = ceil_div((long)Q * nr, 4);
-  hipLaunchKernelGGL(head_coeff_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank + 1), dim3(256), 0, st, a);
+  FOCAL_LAUNCH(head_coeff_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank + 1), dim3(256), 0, st, a);
   // ---- products: dZn = W Zn per group, EX = E X
   static const bool one_gemm_launch = getenv("FOCAL_LOSS_GEMM_SEPARATE") == nullptr;
   GemmGroup gg;
@@ -814,7 +814,7 @@ static int loss_phase_b(const focal_loss_desc* d, const LossPlan& pl, const floa
   // ---- launch 4: gradients back onto the embeddings
   for (int k = 0; k < 2; ++k) a.g[k].blocks = a.g[k].nprob ? ceil_div((long)a.g[k].nprob * seq * 2 * sh.bl, 4) : 0;
   a.blocks_rank = capped(ceil_div((long)Q * nr * dim, 256), 8192);
-  hipLaunchKernelGGL(head_grad_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank), dim3(256), 0, st, a);
+  FOCAL_LAUNCH(head_grad_kernel, dim3(a.g[0].blocks + a.g[1].blocks + a.blocks_rank), dim3(256), 0, st, a);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -14,7 +14,7 @@
 #include "gemm.hpp"
 #include "mlp.hpp"
 
-namespace {
+namespace focal_mlp_kernels {
 
 constexpr int C = MLP_C, H = MLP_H;
 constexpr int LDS_W1 = 0, LDS_W2 = 32768, LDS_B1 = 65536, LDS_B2 = LDS_B1 + 1024, LDS_G = LDS_B2 + 256, LDS_BT = LDS_G + 256,
@@ -158,7 +158,8 @@ __global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpFwdParams p) {
   }
 }
 
-}  // namespace
+}  // namespace focal_mlp_kernels
+using namespace focal_mlp_kernels;
 
 static MaskParams mlp_mask(const focal_drop_desc& d, int ncols) {
   MaskParams m;
@@ -215,7 +216,7 @@ extern "C" int focal_mlp_fwd(const focal_mlp_desc* d, const void* a, const float
   }
   const int nwg = (d->M + 127) / 128;
   const int grid = nwg < 512 ? nwg : 512;  // two 8-wave workgroups per CU, persistent over 16-row wave tiles
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_FWD_BYTES, (hipStream_t)stream, p);
+  FOCAL_LAUNCH(kern, dim3(grid), dim3(512), LDS_FWD_BYTES, (hipStream_t)stream, p);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -20,7 +20,7 @@
 #include "gemm.hpp"
 #include "mlp.hpp"
 
-namespace {
+namespace focal_mlp_kernels {
 
 constexpr int C = MLP_C, H = MLP_H, BM = 128;
 // LDS map (bytes).  Every image is laid out so that (a) its fragment reads -- direct ds_read_b128 and / or transposed
@@ -268,7 +268,8 @@ __global__ __launch_bounds__(1024, 4) void mlp_bwd_kernel(const MlpBwdParams p) 
   }
 }
 
-}  // namespace
+}  // namespace focal_mlp_kernels
+using namespace focal_mlp_kernels;
 
 static MaskParams mlp_bwd_mask(const focal_drop_desc& d, int ncols) {
   MaskParams m;
@@ -317,7 +318,7 @@ extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void
   }
   const int ntiles = (d->M + BM - 1) / BM;
   const int grid = ntiles < 256 ? ntiles : 256;  // one persistent 16-wave workgroup per CU
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), LDS_BWD_BYTES, (hipStream_t)stream, p);
+  FOCAL_LAUNCH(kern, dim3(grid), dim3(1024), LDS_BWD_BYTES, (hipStream_t)stream, p);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

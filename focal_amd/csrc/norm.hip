@@ -233,7 +233,7 @@ extern "C" int focal_layernorm_fwd(const focal_ln_desc* d, const float* x, const
   int blocks = ceil_div(d->rows, rpw * 4);
   if (blocks > 2048) blocks = 2048;
   hipStream_t st = (hipStream_t)stream;
-#define LN_FWD(TY, NV) hipLaunchKernelGGL((ln_fwd_kernel<TY, NV>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, (TY*)y, stats, d->rows, d->C, lpr, d->eps, map)
+#define LN_FWD(TY, NV) FOCAL_LAUNCH((ln_fwd_kernel<TY, NV>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, (TY*)y, stats, d->rows, d->C, lpr, d->eps, map)
   if (d->dtype == FOCAL_F32) { if (nv == 1) LN_FWD(float, 1); else if (nv == 2) LN_FWD(float, 2); else LN_FWD(float, 4); }
   else { if (nv == 1) LN_FWD(bf16_t, 1); else if (nv == 2) LN_FWD(bf16_t, 2); else LN_FWD(bf16_t, 4); }
 #undef LN_FWD
@@ -262,7 +262,7 @@ extern "C" int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const
   if (blocks > maxb) blocks = maxb;
   hipStream_t st = (hipStream_t)stream;
   const size_t sm = (size_t)(tpb / 64) * 2 * d->C * sizeof(float);
-#define LN_BWD(TY, NV) hipLaunchKernelGGL((ln_bwd_kernel<TY, NV>), dim3(blocks), dim3(tpb), sm, st, (const TY*)dy, x, stats, gamma, dx, accumulate_dx, dgamma, dbeta, d->rows, d->C, lpr, map, (TY*)dx_masked, dd, mcols)
+#define LN_BWD(TY, NV) FOCAL_LAUNCH((ln_bwd_kernel<TY, NV>), dim3(blocks), dim3(tpb), sm, st, (const TY*)dy, x, stats, gamma, dx, accumulate_dx, dgamma, dbeta, d->rows, d->C, lpr, map, (TY*)dx_masked, dd, mcols)
   if (d->dtype == FOCAL_F32) { if (nv == 1) LN_BWD(float, 1); else if (nv == 2) LN_BWD(float, 2); else LN_BWD(float, 4); }
   else { if (nv == 1) LN_BWD(bf16_t, 1); else if (nv == 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
 #undef LN_BWD
@@ -289,8 +289,8 @@ extern "C" int focal_mask_cast(int dtype, int rows, int C, const float* g, const
   long blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FOCAL_F32) hipLaunchKernelGGL((mask_cast_kernel<float>), dim3(blocks), dim3(256), 0, st, g, (float*)out, n4, dd, C);
-  else hipLaunchKernelGGL((mask_cast_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, g, (bf16_t*)out, n4, dd, C);
+  if (dtype == FOCAL_F32) FOCAL_LAUNCH((mask_cast_kernel<float>), dim3(blocks), dim3(256), 0, st, g, (float*)out, n4, dd, C);
+  else FOCAL_LAUNCH((mask_cast_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, g, (bf16_t*)out, n4, dd, C);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -9,7 +9,7 @@ __global__ void rng_advance_kernel(uint32_t* state) {
 
 extern "C" int focal_rng_advance(uint32_t* state, void* stream) {
   FOCAL_CHECK_ARG(state != nullptr, "rng_advance: null state");
-  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  FOCAL_LAUNCH(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -91,7 +91,7 @@ static int adamw_launch(const focal_adamw_desc* d, int nseg, float* const* p, co
     int blocks = ceil_div(n[s] / 4, 256);
     if (blocks > 2048) blocks = 2048;
     // segments run in stream order: every one of them reads the same step count, the last one advances it
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, st, p[s], g[s], m[s], v[s], shadow_bf16 ? (bf16_t*)shadow_bf16[s] : nullptr,
+    FOCAL_LAUNCH(adamw_kernel, dim3(blocks), dim3(256), 0, st, p[s], g[s], m[s], v[s], shadow_bf16 ? (bf16_t*)shadow_bf16[s] : nullptr,
                        n[s], lr_dev, step_state, (advance && s == last) ? seed_state : nullptr, advance ? (s == last ? 2 : 1) : 0, *d);
   }
   FOCAL_LAUNCH_CHECK();
@@ -126,7 +126,7 @@ extern "C" int focal_cast_bf16(const float* src, void* dst, long n, void* stream
   if (n == 0) return FOCAL_OK;
   int blocks = ceil_div((n + 3) / 4, 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+  FOCAL_LAUNCH(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

@@ -55,11 +55,11 @@ extern "C" int focal_warp_fwd(int rows, int L, const float* x, const float* mult
     FOCAL_CHECK_ARG(L % 4 == 0, "warp: row length %d must be a multiple of 4", L);
     long blocks = ((long)rows * L / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(mag_warp_kernel, dim3((int)blocks), dim3(256), 0, st, rows, L, x, mult, y);
+    FOCAL_LAUNCH(mag_warp_kernel, dim3((int)blocks), dim3(256), 0, st, rows, L, x, mult, y);
   } else {
     FOCAL_CHECK_ARG(taps == 24, "warp: built for 24 taps (got %d)", taps);
     constexpr int RPT = 16;
-    hipLaunchKernelGGL((time_warp_kernel<24, RPT>), dim3((L + 255) / 256, (rows + RPT - 1) / RPT), dim3(256), 0, st, rows, L, x, k0, w, y);
+    FOCAL_LAUNCH((time_warp_kernel<24, RPT>), dim3((L + 255) / 256, (rows + RPT - 1) / RPT), dim3(256), 0, st, rows, L, x, k0, w, y);
   }
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
@@ -91,7 +91,7 @@ extern "C" int focal_mixup_fwd(int B, int C_, int I, int S, const float* x, cons
   const long per = (long)C_ * I * S;
   long blocks = ((long)B * per + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(mixup_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, B, per, I, S, x, perm, lam, cut, yl, yh, xl, xh, y);
+  FOCAL_LAUNCH(mixup_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, B, per, I, S, x, perm, lam, cut, yl, yh, xl, xh, y);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

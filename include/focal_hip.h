@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-/* 2: BatchNorm scratch of 2C + 1 floats; 3: fused MLP, warps, Mixup; 4: row-sharded loss head, weight-gradient launch queries */
-#define FOCAL_ABI_VERSION 6
+/* 7: launch trace (focal_trace_*), focal_adamw_multi_advance takes the step-state length; 2: BatchNorm scratch of 2C + 1 floats; 3: fused MLP, warps, Mixup; 4: row-sharded loss head, weight-gradient launch queries */
+#define FOCAL_ABI_VERSION 7
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -37,6 +37,25 @@ int focal_abi_version(void);
 /* diagnostics: the kernel template the GEMM-family entry points launched last on this thread ("" before the first one) */
 const char* focal_last_kernel(void);
 const char* focal_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ launch trace (measurement only)
+ * Per-kernel durations of eager steps for bench.py's in-step roofline.  Between focal_trace_begin and focal_trace_end
+ * every kernel launch of the library is recorded: FOCAL_TRACE_DISPATCH attaches a start / stop event pair to the dispatch itself
+ * (hipExtLaunchKernel: the duration is the dispatch's own begin -> end timestamps, as rocprofv3 --kernel-trace reports it),
+ * FOCAL_TRACE_EVENTS records one event directly before and one directly behind the launch.  Launches onto a stream that is being
+ * captured into a hipGraph are not recorded.  These calls own a pool of events and focal_trace_read synchronises on them: they are
+ * the one exception to "nothing allocates or synchronises", and no product path calls them. */
+enum { FOCAL_TRACE_DISPATCH = 1, FOCAL_TRACE_EVENTS = 2 };
+typedef struct {
+  char kernel[384];        /* symbol name of the launched kernel (mangled: one per template instantiation = one row of `rocprofv3 --stats -M`) */
+  unsigned grid[3], block[3];
+  void* stream;
+  float us;                /* duration in microseconds */
+} focal_trace_record;
+int focal_trace_begin(int capacity, int mode); /* drops the records of an earlier trace, records up to `capacity` launches */
+int focal_trace_end(void);
+int focal_trace_count(void);
+int focal_trace_read(int first, int n, focal_trace_record* out); /* waits for the launches; records stay until the next begin */
 
 /* ------------------------------------------------------------------------------------------------ RNG state
  * Device-resident {seed, step} pair (uint32[4], two words used).  Dropout masks are pure functions of
