@@ -138,8 +138,8 @@ PROTOTYPES = {
     "focal_linear_bwd_weight_group_workgroups": (C.c_int, [C.c_int, C.c_int, C.POINTER(DwProblem)]),
     "focal_linear_bwd_weight_group_kind": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "focal_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "focal_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P]),
-    "focal_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P]),
+    "focal_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "focal_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P, P]),
     "focal_window_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P]),
     "focal_window_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P]),
     "focal_fusion_attn_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint32, C.c_float, P]),

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpFwdParams p) {
     for (int j = 0; j < 4; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint32_t dst = DROP ? ds.start(ds_key, m, g) : 0u;
+    uint32_t mb0 = 0u, mb1 = 0u;  // keep bits of this lane's 64 hidden units {16 T + 4 g + e}: bit 4 T + e
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {  // 64 hidden units at a time
       f32x4 u[4];
@@ -94,12 +95,17 @@ __global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpFwdParams p) {
         }
       }
       bf16x8 hf[2];
+      uint32_t kb = 0u;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
           gelu_f2 hh = mlp_gelu_fwd(gelu_f2{u[t][e], u[t][e + 1]});
-          if (DROP) hh = mlp_mul2(hh, ds.next(dst));
+          if (DROP) {
+            const gelu_f2 mult = ds.next(dst);
+            kb |= MlpDropStream::keep_bits(mult) << (4 * t + e);
+            hh = mlp_mul2(hh, mult);
+          }
           hf[t >> 1][(t & 1) * 4 + e] = (bf16_t)hh.x;
           hf[t >> 1][(t & 1) * 4 + e + 1] = (bf16_t)hh.y;
         }
@@ -112,7 +118,12 @@ __global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpFwdParams p) {
           yacc[j] = mma16(w, hf[s], yacc[j]);
         }
       }
+      if (DROP) {  // hidden tiles T = 4 q .. 4 q + 3: 16 bits of word T / 8
+        const uint32_t sh = kb << ((q & 1) * 16);
+        if (q < 2) mb0 |= sh; else mb1 |= sh;
+      }
     }
+    if (DROP && mok && p.mask_bits) *reinterpret_cast<uint2*>(p.mask_bits + (long)m * 8 + 2 * g) = make_uint2(mb0, mb1);
 
     // ---- epilogue: bias, dropout x drop-path, residual; optionally the LayerNorm that reads x_out next
     f32x4 res[4];  // (requested here, not before the chunk loop: 16 registers less across it; three other waves per SIMD cover the latency)
@@ -185,7 +196,7 @@ extern "C" int focal_mlp_supported(int dtype, int C_, int hidden) { return dtype
 
 extern "C" int focal_mlp_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
                              const float* b2, float* y, const float* ln_gamma, const float* ln_beta, void* y_ln, float* ln_stats,
-                             void* stream) {
+                             uint32_t* mask_bits, void* stream) {
   if (int rc = mlp_check_desc(d, "mlp_fwd")) return rc;
   FOCAL_CHECK_ARG(a && resid && w1 && b1 && w2 && b2 && y, "mlp_fwd: null tensor");
   const bool ln = y_ln != nullptr;
@@ -202,6 +213,7 @@ extern "C" int focal_mlp_fwd(const focal_mlp_desc* d, const void* a, const float
   p.drop_h = mlp_mask(d->drop_hidden, MLP_H);
   p.drop_o = mlp_mask(d->drop_out, MLP_C);
   p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.y_ln = reinterpret_cast<bf16_t*>(y_ln); p.ln_stats = ln_stats; p.ln_eps = d->ln_eps;
+  p.mask_bits = mask_bits;
   const bool drop = d->drop_hidden.p_elem > 0.f;
   void (*kern)(const MlpFwdParams) = ln ? (drop ? mlp_fwd_kernel<true, true> : mlp_fwd_kernel<true, false>)
                                         : (drop ? mlp_fwd_kernel<false, true> : mlp_fwd_kernel<false, false>);

@@ -16,6 +16,7 @@ struct MlpFwdParams {
   MaskParams drop_h;    // Mlp.drop after the activation (pair hash over [M][H])
   MaskParams drop_o;    // Mlp.drop after fc2 x DropPath (over [M][C])
   const float* ln_gamma; const float* ln_beta; bf16_t* y_ln; float* ln_stats; float ln_eps;
+  uint32_t* mask_bits;  // [M][8] (DROP): the keep bits of drop_h -- bit 4 (T % 8) + e of word 2 g + T / 8 = hidden unit 16 T + 4 g + e
 };
 
 struct MlpBwdParams {
@@ -26,6 +27,7 @@ struct MlpBwdParams {
   bf16_t* da;           // [M][C]   dL/da (LN_BWD = false)
   float* dw1; float* db1; float* dw2; float* db2;   // fp32, accumulated (+=)
   MaskParams drop_h;
+  const uint32_t* mask_bits;  // [M][8]: the forward kernel's keep bits of drop_h (required when p_elem > 0)
   // LN_BWD: the norm2 backward fused behind dL/da -- completes the residual-stream gradient g (+= in place) and emits
   // gm_next = bf16(g x next_mask) for the attention branch
   const float* x; const float* stats; const float* ln_gamma; float* g; bf16_t* gm_next; float* dgamma; float* dbeta;
@@ -138,6 +140,10 @@ struct MlpDropStream {
     st ^= st >> 17;
     st ^= st << 5;
     return gelu_f2{(st & 0xffffu) < t16 ? 0.0f : scale, (st >> 16) < t16 ? 0.0f : scale};
+  }
+  // the two keep decisions of a pair as bits 0 / 1 (the forward kernel saves them for the backward kernel: mlp_bwd.hip)
+  static __device__ __forceinline__ uint32_t keep_bits(gelu_f2 mult) {
+    return (mult.x != 0.0f ? 1u : 0u) | (mult.y != 0.0f ? 2u : 0u);
   }
 };
 #endif

@@ -2,270 +2,264 @@
 //
 // One pass over gm = dL/dx_out (already x the branch's dropout / drop-path mask, bf16) and a2 (the saved LayerNorm output)
 // produces dL/da2 and all four parameter gradients; the hidden activation h and its derivative are RECOMPUTED per tile instead of
-// being read back from two [M, 256] tensors by four GEMM launches:
+// being read back from two [M, 256] tensors by four GEMM launches.
 //
-//   per 128-token tile, 32 hidden units at a time, two roles of 8 waves each:
-//     A waves   u = a2 W1c^T + b1c -> h = drop(gelu(u)), h' = drop(gelu'(u))        (recompute; mask regenerated from the hash)
-//     (16       dh = gm W2c -> du = dh . h'                                         (accumulator layouts match: no shuffles)
-//     tokens    da2 += du W1c                                                       (du re-enters the matrix core from registers)
-//     each)     h, du -> LDS (bf16, [token][32])
-//     B waves   dW2c += gm^T h, dW1c += du^T a2 over all 128 tokens of the PREVIOUS chunk: every B wave owns 2 of a chunk's 16 output
-//               tiles and keeps its 16 accumulators (64 VGPRs) for the WHOLE kernel -- the weight gradient leaves the CU once, as
-//               256-byte contiguous fp32 atomics staged through LDS.
-//   (double-buffered h / du tiles, one barrier per chunk).
+// Round 4 layout -- every wave owns a HIDDEN slice, not a token slice.  Wave w of the 16 keeps hidden units 16 w .. 16 w + 15 for the
+// whole kernel: its W1 rows and W2 columns are ready-made B operands in registers, and so are the accumulators of dW1^T[:, slice] and
+// dW2[:, slice] (8 tiles).  Per 128-token tile and 16-token block:
+//     u  = a2 W1s^T + b1s,  dh = gm W2s          D[token][hidden]: a lane holds 4 consecutive TOKENS of one hidden unit
+//     h  = drop(gelu(u)),   du = dh gelu'(u) drop
+// and two blocks' h / du (bf16) ARE the B operands of the weight-gradient products -- the token index moves from the accumulator's
+// register slots to the contraction slots of the next MFMA (k-slot (g, e) <-> token 16 (2p + e / 4) + 4 g + e % 4, the order in which
+// the transposed reads of gm^T / a2^T fetch their rows):
+//     dW2[:, slice] += gm^T h,   dW1^T[:, slice] += a2^T du
+// so the hidden activation makes NO LDS round trip for the weight gradients and nothing is exchanged between waves for them.  Only
+// dL/da2 = du W1 contracts over all 256 hidden units: du goes to LDS as a [hidden][token] image (one 8-byte store per lane and block)
+// and, behind the tile's single exchange barrier, every wave contracts two 16 x 16 output tiles over the full hidden axis.
+// Two workgroup barriers per 128 tokens (the first version had ten, and two wave roles that waited for each other 48 % of the
+// time: profiles/r2_mlp_pmc_split.txt); every wave runs the same instruction mix, so four of them per SIMD overlap their phases.
+// The dropout mask of the hidden activation comes from the forward kernel as one bit per element (mlp.hip: [M][8] words, 32 B per
+// token) -- 2 vector instructions per element instead of regenerating the xorshift stream (9, in a layout where a lane walks tokens).
 //
-// Operands that are contracted over their row index (W2 for dh, W1 for da2, gm / a2 / h / du for the weight gradients) are read
-// with ds_read_b64_tr_b16; all LDS images are XOR-swizzled so that both their direct and their transposed fragment reads are
-// bank-conflict free (derivations next to each swizzle function).
+// LDS images are XOR-swizzled so that every access pattern below is bank-conflict free (MI355X_MICROARCH.md, LDS table: ds_read_b128
+// in four 16-lane groups and ds_read_b64_tr_b16 in two halves on 64 banks; stores on 32 banks); derivations next to each swizzle.
 #include "gemm.hpp"
 #include "mlp.hpp"
 
 namespace focal_mlp_kernels {
 
 constexpr int C = MLP_C, H = MLP_H, BM = 128;
-// LDS map (bytes).  Every image is laid out so that (a) its fragment reads -- direct ds_read_b128 and / or transposed
-// ds_read_b64_tr_b16 -- are bank-conflict free and (b) an address is (per-lane base) + (compile-time constant): the swizzles only mix
-// LANE-dependent bits, loop indices select sub-images.  (The first version XOR-ed loop constants into the chunk index: half of the
-// kernel's 4 700 vector instructions per tile were address arithmetic, and the kernel ran VALU-bound at 1/13 of the MFMA rate.)
-constexpr int L_W1 = 0;                  // 2 half images (c < 32 | c >= 32) of [256 h][32 c] bf16: 64-B rows, chunk ^ P[(h >> 2) & 3]
-constexpr int L_W2 = 32768;              // 16 sub-images (16 hidden units each) of [64 c][16 h] bf16: 32-B rows at row' = c ^ ((c >> 3 & 1) << 2)
-constexpr int L_GM = 65536;              // [128 m][64 c] bf16: 128-B rows, chunk ^ sw_tile(m)
-constexpr int L_A2 = L_GM + 16384;
-constexpr int L_HB = L_A2 + 16384;       // 2 buffers x { h, du } x 2 sub-tiles (16 hidden units) of [128 m][16] bf16: 32-B rows at row'(m)
-constexpr int L_B1 = L_HB + 32768;       // [256] f32
-constexpr int L_END = L_B1 + 1024;
-constexpr int LDS_BWD_BYTES = L_END;     // 129 KB: one workgroup per CU
+constexpr int L_GM = 0;                  // [128 tok][64 c] bf16: 128-B rows, 16-B chunk ^ sw_tok(row)
+constexpr int L_A2 = 16384;
+constexpr int L_DU = 32768;              // du^T [256 hid][128 tok] bf16: 256-B rows, 8-B slot (4 tokens) ^ du_sw(hid)
+constexpr int L_W1T = L_DU + 65536;      // W1^T [64 c][256 hid] bf16: 512-B rows, 16-B chunk ^ (c & 15)
+constexpr int MB_LD = 132;               // mask words [8 columns][128 tok (+ 4 pad)]: the pad spreads the 8 columns over the banks
+constexpr int L_MB = L_W1T + 32768;
+constexpr int L_DB2 = L_MB + 8 * MB_LD * 4;  // db2 [64] f32: per-tile column sums of gm, added up in LDS
+constexpr int L_END = L_DB2 + 256;
+constexpr int LDS_BWD_BYTES = L_END;     // 132 KB: one workgroup per CU; the final flush reuses [0, 128 KB) as two fp32 images
 
 typedef __attribute__((address_space(3))) bf16x4* lds_tr_ptr;
 
-// chunk swizzle of the W1 half images: conflict-free for the direct reads of 16 consecutive rows (ds_read_b128 serves lanes
-// {0-3, 12-15, 20-27} etc. together: the four 4-row blocks of a tile must land on different 16-byte columns for both chunk parities)
-// and for the transposed reads over rows 32 q + 4 g + {0..3}
-__device__ __forceinline__ int sw_p(int blk) { return (0x1230 >> (4 * (blk & 3))) & 3; }  // {0, 3, 2, 1}
-// token tiles (gm, a2): direct reads of 16 consecutive rows, transposed reads over rows 32 ks + 8 g + {0..3} (+4): bits 1 and 3 of the row
-__device__ __forceinline__ int sw_tile(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }
-// 32-byte-row images: rows r and r + 8 would share banks; swapping the two 4-row halves of every second 8-row block separates them
-__device__ __forceinline__ int rowp(int r) { return r ^ (((r >> 3) & 1) << 2); }
+// Token tiles.  Direct fragment reads (ds_read_b128, lane = token l15, chunk 4 kk + g): a 16-lane group holds rows {0-3, 12-15} with one
+// g and rows {4-11} with the next: sw = 2 * bits(1..2) of the row gives the first set even and the second odd chunk columns in both
+// 128-byte halves of the bank row -> 16 distinct 16-byte slots.  Transposed reads (lanes (g, tq) address rows 4 g + tq, chunk
+// 2 ct + tp / 2): a half-wave holds rows 0..7 (8..15), two chunks each -> rows of equal parity need four distinct even offsets: the same sw.
+__device__ __forceinline__ int sw_tok(int row) { return ((row >> 1) & 3) << 1; }
+// du^T image.  Stores (ds_write_b64, 16 consecutive lanes = 16 hidden rows, one slot): the slot offsets must differ modulo 16 (32 banks
+// = 128 bytes) -> bits 0-3 of du_sw are a permutation of the row's low 4 bits.  Transposed reads (lanes (g, tq) address rows 8 g + tq
+// (+ 4), slots 4 tb + tp): the 8 rows of a half-wave must differ in bits 2-4 of the offset (64 banks = all 32 slots of a row) -> bits
+// 2-3 = tq, bit 4 = g.
+__device__ __forceinline__ int du_sw(int h) { return ((h & 3) << 2) | ((h >> 2) & 3) | (((h >> 3) & 1) << 4); }
 
-__device__ __forceinline__ int a_w1(int h, int c) { return L_W1 + (c >> 5) * 16384 + h * 64 + (((((c & 31) >> 3)) ^ sw_p(h >> 2)) << 4) + (c & 7) * 2; }
-__device__ __forceinline__ int a_w2(int c, int h) { return L_W2 + (h >> 4) * 2048 + rowp(c) * 32 + (h & 15) * 2; }
-
-// (an element-wise bf16x8{lo[0], .., hi[3]} makes hipcc unpack and re-pack every 16-bit element: ~700 vector instructions per tile)
 __device__ __forceinline__ bf16x8 join(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 __device__ __forceinline__ bf16x4 tr_read(const char* lds, int addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr_ptr)(lds + addr)); }
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would expose the full HBM latency of the
 // next tile's prefetch at the first barrier behind it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ float sum8(bf16x8 v) {
-  float s = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s += (float)v[e];
-  return s;
-}
 
-// The two halves of a barrier interval run on DIFFERENT waves: waves 0-7 ("A") recompute h / h' and produce du and dL/da2 for their
-// 16 tokens, waves 8-15 ("B") contract the previous chunk's h / du sub-tiles into the weight gradients.  The first version ran A then
-// B in every one of 8 waves and was latency-bound (39 % of its wave-cycles waiting, vector ALU 31 % / matrix pipe 9.5 % busy:
-// profiles/r2_mlp_pmc.txt); with the roles on separate waves an interval lasts max(A, B) instead of A + B and every SIMD holds four
-// waves instead of two: 186 -> 165 us at the stage-0 audio shape, +0.9 % on the step (same-box A/B, profiles/r2_mlp_ab.txt (3)).  Each
-// role is its own loop -- its own register budget: the B waves' 64 accumulator registers and the A waves' GELU temporaries never live
-// in the same wave (128 VGPRs, no spills) -- and both execute the same ten workgroup barriers per tile.
 template <bool DROP>
-__global__ __launch_bounds__(1024, 4) void mlp_bwd_kernel(const MlpBwdParams p) {
+__global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool role_a = wave < 8;
-  const int wa = wave & 7;
-  const bool c_side_first = wa < 4;   // B waves 8-11 own dW2 tiles (c-tile cw, all hidden tiles), 12-15 dW1 tiles (all hidden tiles, c-tile cw)
-  const int cw = wa & 3;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // ---- weights -> LDS
-  {
-    uint4 v1[2], v2[2];
+  // ---- W1^T image (once): thread -> 8 channels of one hidden row, scattered as 2-byte stores
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      v1[i] = reinterpret_cast<const uint4*>(p.w1)[tid + 1024 * i];
-      v2[i] = reinterpret_cast<const uint4*>(p.w2)[tid + 1024 * i];
-    }
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + 1024 * i, h = q >> 3, c0 = (q & 7) * 8;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.w1 + h * C + c0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = tid + 1024 * i;
-      *reinterpret_cast<uint4*>(lds + a_w1(q >> 3, (q & 7) * 8)) = v1[i];
-      *reinterpret_cast<uint4*>(lds + a_w2(q >> 5, (q & 31) * 8)) = v2[i];
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      *reinterpret_cast<bf16_t*>(lds + L_W1T + c * 512 + ((((h >> 3)) ^ (c & 15)) << 4) + (h & 7) * 2) = v[e];
     }
-    if (tid < H) reinterpret_cast<float*>(lds + L_B1)[tid] = p.b1[tid];
   }
+  // ---- this wave's hidden slice as B operands (k = channel 32 kk + 8 g + e, n = hidden 16 w + l15)
+  const int hid = 16 * w + l15;
+  bf16x8 w1f[2], w2f[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    w1f[kk] = *reinterpret_cast<const bf16x8*>(p.w1 + hid * C + 32 * kk + 8 * g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w2f[kk][e] = p.w2[(32 * kk + 8 * g + e) * H + hid];
+  }
+  const float b1v = p.b1[hid];
+  uint32_t scale_bits = 0;
+  int mask_shift = 0;
+  if (tid < C) reinterpret_cast<float*>(lds + L_DB2)[tid] = 0.f;
+  if (DROP) {
+    scale_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / (1.0f - p.drop_h.p_elem)));
+    mask_shift = (w & 7) * 4 + (l15 & 3);  // the forward kernel's bit of (token, hidden 16 T + 4 G + e): word 2 G + T / 8, bit 4 (T % 8) + e
+  }
+
   const int ntiles = (p.M + BM - 1) / BM;
-  // every thread stages one 16-byte chunk of gm and one of a2 per tile: chunk id = tid -> row tid >> 3, column chunk tid & 7
-  const int b_st = L_GM + (tid >> 3) * 128 + (((tid & 7) ^ sw_tile(tid >> 3)) << 4);
+  // staging: thread -> one 16-byte chunk of gm and of a2 (row tid / 8, chunk tid % 8) and one mask word (token tid / 8, column tid % 8)
+  const int b_st = L_GM + (tid >> 3) * 128 + (((tid & 7) ^ sw_tok(tid >> 3)) << 4);
+  const int b_stm = L_MB + ((tid & 7) * MB_LD + (tid >> 3)) * 4;
   uint4 pg, pa;
+  uint32_t pm = 0;
+  // (32-bit offsets from the uniform base pointers: the addresses stay in scalar registers + one vector offset; 64-bit per-thread
+  // pointers cost this kernel eight vector registers it does not have -- the first build spilled them)
+  const char* gm_base = reinterpret_cast<const char*>(p.gm);
+  const char* a_base = reinterpret_cast<const char*>(p.a);
+  const char* mb_base = reinterpret_cast<const char*>(p.mask_bits);
+  const uint32_t pf_off = (uint32_t)tid * 16u;  // the tile is 1024 contiguous 16-byte chunks of gm / a2 (and 1024 mask words)
   auto prefetch = [&](int tile) {
-    const long m = (long)tile * BM + (tid >> 3);
-    const bool ok = m < p.M;
-    pg = ok ? *reinterpret_cast<const uint4*>(p.gm + m * C + (tid & 7) * 8) : make_uint4(0, 0, 0, 0);
-    pa = ok ? *reinterpret_cast<const uint4*>(p.a + m * C + (tid & 7) * 8) : make_uint4(0, 0, 0, 0);
+    const bool ok = tile * BM + (tid >> 3) < p.M;
+    const uint32_t off = (uint32_t)tile * (BM * C * 2) + pf_off;
+    pg = ok ? *reinterpret_cast<const uint4*>(gm_base + off) : make_uint4(0, 0, 0, 0);
+    pa = ok ? *reinterpret_cast<const uint4*>(a_base + off) : make_uint4(0, 0, 0, 0);
+    if (DROP) pm = ok ? *reinterpret_cast<const uint32_t*>(mb_base + ((uint32_t)tile * (BM * 32) + (uint32_t)tid * 4u)) : 0u;
   };
   auto stage = [&]() {
     *reinterpret_cast<uint4*>(lds + b_st) = pg;
     *reinterpret_cast<uint4*>(lds + b_st + 16384) = pa;
+    if (DROP) *reinterpret_cast<uint32_t*>(lds + b_stm) = pm;
   };
   if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
-  const int rp_lo = rowp(8 * g + tq) * 32 + tp * 8, rp_hi = rowp(8 * g + tq + 4) * 32 + tp * 8;
 
-  if (role_a) {
-    // ================================================================================================= A: recompute, du, dL/da2
-    MlpDropStream ds;
-    ds.init(p.drop_h);
-    const uint32_t ds_key = ds.s;
-    const int mloc = wa * 16 + l15;
-    const int b_w1d = L_W1 + l15 * 64 + ((g ^ sw_p(l15 >> 2)) << 4);
-    int b_w1t[2];
+  // ---- per-lane LDS addresses: ONE register per image; what a loop index adds to a swizzled chunk index is an XOR constant (the
+  // swizzles only mix bits the address's other terms leave free), so no address is recomputed and none is kept per index value
+  const int b_dir = L_A2 + l15 * 128 + ((g ^ sw_tok(l15)) << 4);              // a2 fragment kk of token block tb: (b_dir ^ 64 kk) + 2048 tb; gm: - 16384
+  const int b_tr = L_GM + (4 * g + tq) * 128 + (((tp >> 1) ^ sw_tok(4 * g + tq)) << 4) + (tp & 1) * 8;  // gm^T of channel tile ct: (b_tr ^ 32 ct) + 4096 p (+ 2048)
+  const int b_duw = L_DU + hid * 256, du_xs = g ^ du_sw(l15);                 // store slot (4 tb + g) ^ du_sw = du_xs ^ 4 tb
+  const int tb2 = w >> 1, ctb = 2 * (w & 1);                                  // exchange phase: token block and the first of two channel tiles
+  const int h_lo = 8 * (g & 1) + tq;                                           // (row & 15) of this lane's transposed du reads (rows 32 ks + 8 g + tq, + 4)
+  const int a_dur_lo = L_DU + (8 * g + tq) * 256 + (((4 * tb2 + tp) ^ du_sw(h_lo)) << 3);       // + 8192 ks
+  const int a_dur_hi = L_DU + (8 * g + tq + 4) * 256 + (((4 * tb2 + tp) ^ du_sw(h_lo + 4)) << 3);
+  const int a_w1t = L_W1T + (16 * ctb + l15) * 512 + ((g ^ l15) << 4);        // chunk (4 ks + g) ^ l15: a_w1t ^ 64 ks; second tile + 8192
+  const int b_mb = L_MB + ((2 * (l15 >> 2) + (w >> 3)) * MB_LD + 4 * g) * 4;  // + 64 tb
+
+  f32x4 acc1[4], acc2[4];
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) b_w1t[jb] = L_W1 + (4 * g + tq) * 64 + ((((2 * jb + (tp >> 1))) ^ sw_p(g)) << 4) + (tp & 1) * 8;
-    const int b_w2_lo = L_W2 + rp_lo, b_w2_hi = L_W2 + rp_hi;
-    const int b_hw = L_HB + rowp(mloc) * 32 + 8 * g;
-    int b_td[2];
+  for (int i = 0; i < 4; ++i) acc1[i] = acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db1acc = 0.f;
+  __syncthreads();  // W1^T image complete
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    stage();
+    lds_barrier();  // the tile is in LDS; every wave has left the previous tile's exchange phase (the du image is free)
+    // ================================================================================ recompute + weight gradients, all waves alike
+#pragma unroll 1
+    for (int pr = 0; pr < 4; ++pr) {
+      bf16x4 h4[2], d4[2];
+      int dir0 = b_dir, tr0 = b_tr;
+      asm volatile("" : "+v"(dir0), "+v"(tr0));  // (the XOR variants of these addresses are recomputed per pair, not kept in 5 registers across the loop)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) b_td[kk] = L_GM + mloc * 128 + (((4 * kk + g) ^ sw_tile(mloc)) << 4);
-    const int b_b1 = L_B1 + 16 * g;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      stage();
-      lds_barrier();
-      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
-      const int m = tile * BM + mloc;
-      uint32_t dst = DROP ? ds.start(ds_key, m, g) : 0u;
-      bf16x8 xa[2], xg[2];
+      for (int hf = 0; hf < 2; ++hf) {
+        const int tb = 2 * pr + hf;
+        bf16x8 xa[2], xg[2];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        xg[kk] = *reinterpret_cast<const bf16x8*>(lds + b_td[kk]);
-        xa[kk] = *reinterpret_cast<const bf16x8*>(lds + b_td[kk] + 16384);
-      }
-      f32x4 dc[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      auto phase_a = [&](int q) {  // hidden units 32 q .. 32 q + 31: u, dh -> h, h', du -> LDS; da2 += du W1c
-        const int buf = (q & 1) * 16384;
-        bf16x4 dqs[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int ht = 2 * q + t;
-          f32x4 u = *reinterpret_cast<const f32x4*>(lds + b_b1 + ht * 64), dh = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8 w1f = *reinterpret_cast<const bf16x8*>(lds + b_w1d + kk * 16384 + ht * 1024);
-            u = mma16(w1f, xa[kk], u);
-            const bf16x8 w2f = join(tr_read(lds, b_w2_lo + ht * 2048 + kk * 1024), tr_read(lds, b_w2_hi + ht * 2048 + kk * 1024));
-            dh = mma16(w2f, xg[kk], dh);
-          }
-          bf16x4 hq, dq;
-#pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            gelu_f2 hh, gg;
-            mlp_gelu_bwd(gelu_f2{u[e], u[e + 1]}, hh, gg);
-            if (DROP) {
-              const gelu_f2 mult = ds.next(dst);
-              hh = mlp_mul2(hh, mult);
-              gg = mlp_mul2(gg, mult);
-            }
-            const gelu_f2 dd = mlp_mul2(gelu_f2{dh[e], dh[e + 1]}, gg);
-            hq[e] = (bf16_t)hh.x; hq[e + 1] = (bf16_t)hh.y;
-            dq[e] = (bf16_t)dd.x; dq[e + 1] = (bf16_t)dd.y;
-          }
-          *reinterpret_cast<bf16x4*>(lds + b_hw + buf + t * 4096) = hq;
-          *reinterpret_cast<bf16x4*>(lds + b_hw + buf + 8192 + t * 4096) = dq;
-          dqs[t] = dq;
+        for (int kk = 0; kk < 2; ++kk) {
+          xa[kk] = *reinterpret_cast<const bf16x8*>(lds + (dir0 ^ (64 * kk)) + tb * 2048);
+          xg[kk] = *reinterpret_cast<const bf16x8*>(lds + (dir0 ^ (64 * kk)) + tb * 2048 - 16384);
         }
-        const bf16x8 duf = join(dqs[0], dqs[1]);
+        f32x4 u = mma16(xa[0], w1f[0], f32x4{0.f, 0.f, 0.f, 0.f});
+        u = mma16(xa[1], w1f[1], u);
+        u += b1v;
+        f32x4 dh = mma16(xg[0], w2f[0], f32x4{0.f, 0.f, 0.f, 0.f});
+        dh = mma16(xg[1], w2f[1], dh);
+        uint4 mq = make_uint4(0, 0, 0, 0);
+        if (DROP) mq = *reinterpret_cast<const uint4*>(lds + b_mb + tb * 64);
+        const uint32_t mw[4] = {mq.x, mq.y, mq.z, mq.w};
+        bf16x4 hq, dq;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int a0 = b_w1t[j & 1] + (j >> 1) * 16384 + q * 2048;
-          const bf16x8 w1t = join(tr_read(lds, a0), tr_read(lds, a0 + 1024));
-          dc[j] = mma16(w1t, duf, dc[j]);
+        for (int e = 0; e < 4; e += 2) {
+          gelu_f2 hh, gg;
+          mlp_gelu_bwd(gelu_f2{u[e], u[e + 1]}, hh, gg);
+          if (DROP) {
+            // keep bit -> 0 / 1/(1-p): sign-extended one-bit field AND the multiplier's bits
+            const gelu_f2 mult = gelu_f2{__uint_as_float((uint32_t)__builtin_amdgcn_sbfe(mw[e], mask_shift, 1) & scale_bits),
+                                         __uint_as_float((uint32_t)__builtin_amdgcn_sbfe(mw[e + 1], mask_shift, 1) & scale_bits)};
+            hh = mlp_mul2(hh, mult);
+            gg = mlp_mul2(gg, mult);
+          }
+          const gelu_f2 dd = mlp_mul2(gelu_f2{dh[e], dh[e + 1]}, gg);
+          db1acc += dd.x + dd.y;
+          hq[e] = (bf16_t)hh.x; hq[e + 1] = (bf16_t)hh.y;
+          dq[e] = (bf16_t)dd.x; dq[e + 1] = (bf16_t)dd.y;
         }
-      };
-      phase_a(0);
-      lds_barrier();
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (q < 7) phase_a(q + 1);
-        lds_barrier();
+        *reinterpret_cast<bf16x4*>(lds + b_duw + ((du_xs ^ (4 * tb)) << 3)) = dq;
+        h4[hf] = hq;
+        d4[hf] = dq;
       }
+      const bf16x8 h8 = join(h4[0], h4[1]), du8 = join(d4[0], d4[1]);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int a0 = (tr0 ^ (32 * ct)) + pr * 4096;
+        const bf16x8 gt = join(tr_read(lds, a0), tr_read(lds, a0 + 2048));
+        const bf16x8 at = join(tr_read(lds, a0 + 16384), tr_read(lds, a0 + 16384 + 2048));
+        acc2[ct] = mma16(gt, h8, acc2[ct]);
+        acc1[ct] = mma16(at, du8, acc1[ct]);
+      }
+    }
+    if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);  // lands during the exchange phase; staged at the top of the loop
+    lds_barrier();  // the du image of all 256 hidden units is complete
+    // ================================================================================ dL/da2[tb2][ctb, ctb + 1] = W1^T du^T over all hidden units
+    {
+      f32x4 dc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      int w1t0 = a_w1t, tr0 = b_tr;
+      asm volatile("" : "+v"(w1t0), "+v"(tr0));
+      {  // db2[c] += sum over tokens of gm[.][c]: wave w takes block pair w / 4, channel tile w % 4 (gm^T fragment x ones), summed in LDS
+        const int a0 = (tr0 ^ (32 * (w & 3))) + (w >> 2) * 4096;
+        const bf16x8 gt = join(tr_read(lds, a0), tr_read(lds, a0 + 2048));
+        const bf16_t one_b = (bf16_t)1.0f;
+        const f32x4 cs = mma16(gt, bf16x8{one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b}, f32x4{0.f, 0.f, 0.f, 0.f});
+        if (l15 == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(reinterpret_cast<float*>(lds + L_DB2) + 16 * (w & 3) + 4 * g + r, cs[r]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 duf = join(tr_read(lds, a_dur_lo + ks * 8192), tr_read(lds, a_dur_hi + ks * 8192));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 wt = *reinterpret_cast<const bf16x8*>(lds + (w1t0 ^ (ks << 6)) + j * 8192);
+          dc[j] = mma16(wt, duf, dc[j]);
+        }
+      }
+      const int m = tile * BM + 16 * tb2 + l15;
       if (m < p.M) {
+        char* da_base = reinterpret_cast<char*>(p.da);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) store4(p.da + (long)m * C + 16 * j + 4 * g, dc[j]);
-      }
-    }
-    __syncthreads();  // B waves have put their tiles into LDS
-  } else {
-    // ================================================================================================= B: weight / bias gradients
-    const int hsel = c_side_first ? 0 : 8192;
-    const int b_hb_lo = L_HB + hsel + rp_lo, b_hb_hi = L_HB + hsel + rp_hi;
-    const int b_tr = (c_side_first ? L_GM : L_A2) + (8 * g + tq) * 128 + ((((2 * cw + (tp >> 1))) ^ sw_tile(8 * g + tq)) << 4) + (tp & 1) * 8;
-    f32x4 acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dbh[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dbh[i] = 0.f;
-    float dbc = 0.f;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      stage();
-      lds_barrier();
-      if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
-      lds_barrier();  // chunk 0 of this tile is in LDS
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int buf = (q & 1) * 16384;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 fc = join(tr_read(lds, b_tr + ks * 4096), tr_read(lds, b_tr + ks * 4096 + 512));
-          if (c_side_first && q == 0) dbc += sum8(fc);  // db2: column sums of gm, once per tile
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const bf16x8 fh = join(tr_read(lds, b_hb_lo + buf + t * 4096 + ks * 1024), tr_read(lds, b_hb_hi + buf + t * 4096 + ks * 1024));
-            acc[2 * q + t] = mma16(fc, fh, acc[2 * q + t]);
-            if (!c_side_first && ks == cw) dbh[2 * q + t] += sum8(fh);  // db1: wave 12 + cw takes the 32 tokens of k-step cw
-          }
+        for (int j = 0; j < 2; ++j) {
+          bf16x4 o;
+          o[0] = (bf16_t)dc[j][0]; o[1] = (bf16_t)dc[j][1]; o[2] = (bf16_t)dc[j][2]; o[3] = (bf16_t)dc[j][3];
+          *reinterpret_cast<bf16x4*>(da_base + ((uint32_t)m * (C * 2) + (uint32_t)(16 * (ctb + j) + 4 * g) * 2u)) = o;
         }
-        lds_barrier();
       }
     }
-    // ---- tiles -> LDS ([64][256] dW2 then [256][64] dW1, fp32)
-    float* F2 = reinterpret_cast<float*>(lds);
-    float* F1 = reinterpret_cast<float*>(lds + 65536);
-#pragma unroll
-    for (int ht = 0; ht < 16; ++ht) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (c_side_first) F2[(16 * cw + 4 * g + r) * H + 16 * ht + l15] = acc[ht][r];
-        else F1[(16 * ht + l15) * C + 16 * cw + 4 * g + r] = acc[ht][r];
-      }
-    }
-    if (c_side_first) {
-      dbc += __shfl_xor(dbc, 16, 64);
-      dbc += __shfl_xor(dbc, 32, 64);
-      if (g == 0 && p.db2) atomicAdd(p.db2 + 16 * cw + l15, dbc);
-    } else if (p.db1) {
-#pragma unroll
-      for (int ht = 0; ht < 16; ++ht) {
-        float v = dbh[ht];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (g == 0) atomicAdd(p.db1 + 16 * ht + l15, v);
-      }
-    }
-    __syncthreads();
   }
+  __syncthreads();  // every wave is out of the loop: the images are free
+  // ---- weight gradients -> two fp32 images ([64][256] dW2, [256][64] dW1), bias gradients
+  float* F2 = reinterpret_cast<float*>(lds);
+  float* F1 = reinterpret_cast<float*>(lds + 65536);
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) F2[(16 * ct + 4 * g + r) * H + hid] = acc2[ct][r];
+    *reinterpret_cast<f32x4*>(F1 + hid * C + 16 * ct + 4 * g) = acc1[ct];
+  }
+  if (p.db1) {
+    float v = db1acc;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (g == 0) atomicAdd(p.db1 + hid, v);
+  }
+  if (p.db2 && tid < C) atomicAdd(p.db2 + tid, reinterpret_cast<const float*>(lds + L_DB2)[tid]);
+  __syncthreads();
   // ---- 256-byte contiguous atomics of the two weight gradients, all 1024 threads
-  const float* F2 = reinterpret_cast<const float*>(lds);
-  const float* F1 = reinterpret_cast<const float*>(lds + 65536);
+  // (33.5 MB of fp32 atomics per launch -- 256 workgroups x 128 KB -- drain at the memory side in ~30 us (1.3 TB/s); the waves end as
+  // soon as they are issued, so the CUs are free for the other encoder stream's kernels meanwhile: profiles/r4_mlp_bwd.txt)
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
     const int idx = tid + 1024 * i;
     atomicAdd(p.dw2 + idx, F2[idx]);
     atomicAdd(p.dw1 + idx, F1[idx]);
   }
+
 }
 
 }  // namespace focal_mlp_kernels
@@ -286,7 +280,7 @@ static MaskParams mlp_bwd_mask(const focal_drop_desc& d, int ncols) {
 extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void* a, const void* w1, const float* b1, const void* w2,
                              void* da, float* dw1, float* db1, float* dw2, float* db2, const float* ln_x, const float* ln_stats,
                              const float* ln_gamma, float* g, void* gm_next, const focal_drop_desc* next_mask, float* dgamma,
-                             float* dbeta, void* stream) {
+                             float* dbeta, const uint32_t* mask_bits, void* stream) {
   if (int rc = mlp_check_desc(d, "mlp_bwd")) return rc;
   FOCAL_CHECK_ARG(gm && a && w1 && b1 && w2 && dw1 && dw2, "mlp_bwd: null tensor");
   if (ln_x != nullptr) {
@@ -307,6 +301,8 @@ extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void
   p.dw1 = dw1; p.db1 = db1; p.dw2 = dw2; p.db2 = db2;
   p.drop_h = mlp_bwd_mask(d->drop_hidden, MLP_H);
   const bool drop = d->drop_hidden.p_elem > 0.f;
+  FOCAL_CHECK_ARG(!drop || mask_bits != nullptr, "mlp_bwd: hidden dropout is on (p = %g) but mask_bits is NULL: pass the [M][8] words focal_mlp_fwd wrote", (double)d->drop_hidden.p_elem);
+  p.mask_bits = mask_bits;
   void (*kern)(const MlpBwdParams) = drop ? mlp_bwd_kernel<true> : mlp_bwd_kernel<false>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[drop]) {

@@ -401,33 +401,42 @@ def mlp_desc(dtype_code, M, Cc, hidden, drop_hidden=None, drop_out=None, ln_eps=
     return MlpDesc(dtype_code, M, Cc, hidden, drop_hidden or NO_DROP, drop_out or NO_DROP, ln_eps)
 
 
-def mlp_fwd(d, a, resid, w1, b1, w2, b2, y, next_ln=None):
+def mlp_mask_bits(d, device):
+    """The hidden-dropout keep bits of one fused-MLP call (int32 [M, 8]; None when the descriptor has no hidden dropout): filled by
+    mlp_fwd, read by mlp_bwd -- together with `a` the saved state of the branch."""
+    if d.drop_hidden.p_elem <= 0.0:
+        return None
+    return torch.empty(d.M, 8, dtype=torch.int32, device=device)
+
+
+def mlp_fwd(d, a, resid, w1, b1, w2, b2, y, next_ln=None, mask_bits=None):
     """y = resid + drop_out(drop_hidden(gelu(a w1^T + b1)) w2^T + b2) (focal_mlp_fwd); next_ln = (gamma, beta) also returns
-    (LayerNorm(y) in a's dtype, stats) of the LayerNorm that reads y next."""
-    _need_cuda(a, resid, w1, b1, w2, b2, y)
+    (LayerNorm(y) in a's dtype, stats) of the LayerNorm that reads y next.  mask_bits (ops.mlp_mask_bits) receives the hidden
+    dropout's keep bits for mlp_bwd."""
+    _need_cuda(a, resid, w1, b1, w2, b2, y, mask_bits)
     if next_ln is None:
         check(_lib.load().focal_mlp_fwd(C.byref(d), _p(a), _p(resid), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), None, None, None, None,
-                                            _stream()))
+                                            _p(mask_bits), _stream()))
         return None
     y_ln = torch.empty(d.M, d.C, dtype=a.dtype, device=a.device)
     stats = torch.empty(d.M, 2, dtype=torch.float32, device=a.device)
     check(_lib.load().focal_mlp_fwd(C.byref(d), _p(a), _p(resid), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(next_ln[0]),
-                                        _p(next_ln[1]), _p(y_ln), _p(stats), _stream()))
+                                        _p(next_ln[1]), _p(y_ln), _p(stats), _p(mask_bits), _stream()))
     return y_ln, stats
 
 
-def mlp_bwd(d, gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, ln=None):
-    """focal_mlp_bwd.  ln = dict(x=, stats=, gamma=, g=, gm_next=, next_mask=, dgamma=, dbeta=) fuses the norm2 backward behind it
-    (da is then not written)."""
-    _need_cuda(gm, a, w1, b1, w2, da, dw1, db1, dw2, db2)
+def mlp_bwd(d, gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, ln=None, mask_bits=None):
+    """focal_mlp_bwd.  mask_bits: what mlp_fwd filled (required when the descriptor has hidden dropout).  ln = dict(x=, stats=, gamma=,
+    g=, gm_next=, next_mask=, dgamma=, dbeta=) would fuse the norm2 backward behind it (not built: FOCAL_EUNSUPPORTED)."""
+    _need_cuda(gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, mask_bits)
     if ln is None:
         check(_lib.load().focal_mlp_bwd(C.byref(d), _p(gm), _p(a), _p(w1), _p(b1), _p(w2), _p(da), _p(dw1), _p(db1), _p(dw2), _p(db2),
-                                        None, None, None, None, None, None, None, None, _stream()))
+                                        None, None, None, None, None, None, None, None, _p(mask_bits), _stream()))
         return
     mask = ln.get("next_mask") or NO_DROP
     check(_lib.load().focal_mlp_bwd(C.byref(d), _p(gm), _p(a), _p(w1), _p(b1), _p(w2), _p(da), _p(dw1), _p(db1), _p(dw2), _p(db2),
                                     _p(ln["x"]), _p(ln["stats"]), _p(ln["gamma"]), _p(ln["g"]), _p(ln.get("gm_next")), C.byref(mask),
-                                    _p(ln["dgamma"]), _p(ln["dbeta"]), _stream()))
+                                    _p(ln["dgamma"]), _p(ln["dbeta"]), _p(mask_bits), _stream()))
 
 
 # ------------------------------------------------------------------------------------------------ row 10

@@ -170,9 +170,10 @@ class SwinModEncoder:
                     if fuse_ln and bi + 1 < st["depth"]:
                         nb = f"{self.pre}.{si}.blocks.{bi + 1}"
                         nxt_ln = (ar.master(f"{nb}.norm1.weight"), ar.master(f"{nb}.norm1.bias"))
+                    mlp_bits = ops.mlp_mask_bits(d_mlp, x.device)  # the hidden dropout's keep bits (32 B per token): all the branch saves beside a2
                     pre_ln = ops.mlp_fwd(d_mlp, a2, x_mid, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
-                                         ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_out, next_ln=nxt_ln)
-                    saved["blocks"].append(dict(pb=pb, x=x, st1=st1, a1=a1, qkv=qkv, o=o, x_mid=x_mid, st2=st2, a2=a2, h=None, hg=None,
+                                         ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_out, next_ln=nxt_ln, mask_bits=mlp_bits)
+                    saved["blocks"].append(dict(pb=pb, x=x, st1=st1, a1=a1, qkv=qkv, o=o, x_mid=x_mid, st2=st2, a2=a2, h=None, hg=None, mlp_bits=mlp_bits,
                                                 d_qkv=d_qkv, d_att=d_att, d_proj=d_proj, d_fc1=d_fc1, d_fc2=d_fc2, d_mlp=d_mlp, M=M, C=Cc))
                     x = x_out
                     uid += 1
@@ -324,7 +325,7 @@ class SwinModEncoder:
             if fused_mlp:  # fused branch: h and h' recomputed from a2, all four parameter gradients from one pass
                 ops.mlp_bwd(s["d_mlp"], gm, s["a2"], ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
                             ar.operand(f"{pb}.mlp.fc2.weight"), dc, ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"),
-                            ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
+                            ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"), mask_bits=s["mlp_bits"])
             else:
                 d_fc2_b = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, cc, ACT_GELU)  # dy = gm: operand dtype, already masked
                 weight_grad(d_fc2_b, gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))

@@ -227,19 +227,24 @@ int focal_linear_bwd_weight_group_workgroups(int dtype, int n, const focal_dw_pr
  *   bwd: gm = dtype(dL/dy x drop_out mask) (what focal_layernorm_bwd / focal_mask_cast emit as dx_masked); the hidden
  *        activation and its derivative are RECOMPUTED from `a` (dropout mask regenerated), da = dL/da (bf16), dw1 / db1 / dw2 /
  *        db2 accumulated (+=) in fp32 -- one pass over gm and a instead of four GEMMs over two saved [M, 4C] tensors.
+ *        (Round 4: every wave owns 16 hidden units for the whole launch; the recomputed h / du re-enter the matrix cores from
+ *        registers for the weight gradients and only du crosses LDS, for dL/da: focal_amd/csrc/mlp_bwd.hip.)
  *        With ln_x non-NULL the norm2 backward is fused behind it: da is not written; instead g (fp32 [M, C], the residual-
  *        stream gradient) += LayerNorm-backward(da; ln_x, ln_stats, ln_gamma), gm_next (bf16 [M, C], optional) = g x next_mask,
  *        dgamma / dbeta accumulated.
- * drop_hidden uses the pair hash of FOCAL_EPI_GELU (element index over [M, hidden]); drop_out the element / DropPath
- * convention of FOCAL_EPI_RESIDUAL (over [M, C]). */
+ * drop_hidden is a per-(row, lane group) xorshift stream seeded from (seed word, stream id, row); the forward kernel writes its keep
+ * decisions to mask_bits (uint32 [M][8], one bit per hidden unit: 32 bytes per token; required by both calls when drop_hidden.p_elem
+ * > 0, ignored otherwise) and the backward kernel reads them back: the saved state of the branch is `a` plus these words.
+ * drop_out follows the element / DropPath convention of FOCAL_EPI_RESIDUAL (over [M, C]). */
 typedef struct { int dtype; int M, C, hidden; focal_drop_desc drop_hidden, drop_out; float ln_eps; } focal_mlp_desc;
 int focal_mlp_supported(int dtype, int C, int hidden);
 int focal_mlp_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
-                  const float* b2, float* y, const float* ln_gamma, const float* ln_beta, void* y_ln, float* ln_stats, void* stream);
+                  const float* b2, float* y, const float* ln_gamma, const float* ln_beta, void* y_ln, float* ln_stats,
+                  uint32_t* mask_bits, void* stream);
 int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void* a, const void* w1, const float* b1, const void* w2,
                   void* da, float* dw1, float* db1, float* dw2, float* db2,
                   const float* ln_x, const float* ln_stats, const float* ln_gamma, float* g, void* gm_next,
-                  const focal_drop_desc* next_mask, float* dgamma, float* dbeta, void* stream);
+                  const focal_drop_desc* next_mask, float* dgamma, float* dbeta, const uint32_t* mask_bits, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 10: W-MSA
  * WindowAttention between its qkv and proj Linears (models/SwinModules.py:121-152) with the cyclic shift, window

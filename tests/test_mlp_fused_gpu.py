@@ -135,13 +135,15 @@ def test_fused_mlp_hidden_dropout_rate_scale_and_forward_backward_consistency(op
     d = ops.mlp_desc(cc, M, C, H, ops.drop_desc(rng, 21, p, 25, 0.0, 16), ops.drop_desc(rng, 22, 0.0, 26, 0.0, 16))
     d0 = ops.mlp_desc(cc, M, C, H)
     fwd_mask = torch.zeros(M, H, dtype=torch.bool, device=DEV)   # True = kept
+    bits = ops.mlp_mask_bits(d, DEV)                             # the keep bits the forward kernel saves for the backward kernel
+    assert ops.mlp_mask_bits(d0, DEV) is None
     ratio = []
     for quarter in range(4):
         w2 = torch.zeros(C, H, device=DEV)
         w2[torch.arange(C), quarter * C + torch.arange(C)] = 1.0
         w2 = w2.to(BF)
         y, y0 = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
-        ops.mlp_fwd(d, a, r, w1, b1, w2, b2, y)
+        ops.mlp_fwd(d, a, r, w1, b1, w2, b2, y, mask_bits=bits)
         ops.mlp_fwd(d0, a, r, w1, b1, w2, b2, y0)
         live = y0.abs() > 1e-3                                   # units whose un-dropped activation is clearly non-zero
         fwd_mask[:, quarter * C:(quarter + 1) * C] = (y != 0) | ~live
@@ -151,6 +153,14 @@ def test_fused_mlp_hidden_dropout_rate_scale_and_forward_backward_consistency(op
     assert (ratio - 1.0 / (1.0 - p)).abs().max().item() < 2e-2   # survivors scaled by 1.25 (bf16 rounding of h)
     rate = 1.0 - fwd_mask.float().mean().item()
     assert abs(rate - p) < 0.01, rate
+    # the saved words: hidden unit 16 T + 4 g + e of a row = bit 4 (T % 8) + e of word 2 g + T / 8 (include/focal_hip.h)
+    hid = torch.arange(H, device=DEV)
+    T, gq, e = hid // 16, (hid % 16) // 4, hid % 4
+    word = bits.to(torch.int64)[:, (2 * gq + T // 8)] & 0xFFFFFFFF
+    saved = ((word >> (4 * (T % 8) + e)) & 1).bool()
+    live_all = (a.float() @ w1.float().t() + b1).abs() > 0.05
+    assert torch.equal(saved[live_all], fwd_mask[live_all])
+    assert abs(1.0 - saved.float().mean().item() - p) < 0.01
     # backward: a one-hot gradient row by row
     w2 = rnd(C, H, scale=0.5, seed=61, dtype=BF).abs() + 0.1
     w2 = w2.to(BF)
@@ -162,10 +172,12 @@ def test_fused_mlp_hidden_dropout_rate_scale_and_forward_backward_consistency(op
         da = torch.empty(M, C, dtype=BF, device=DEV)
         dw1, db1 = torch.zeros(H, C, device=DEV), torch.zeros(H, device=DEV)
         dw2, db2 = torch.zeros(C, H, device=DEV), torch.zeros(C, device=DEV)
-        ops.mlp_bwd(d, gm, a, w1, b1, w2, da, dw1, db1, dw2, db2)
+        ops.mlp_bwd(d, gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, mask_bits=bits)
         bwd_kept[row] = db1 != 0
         sure = (u[row].abs() > 0.05) & (u[row] > -3)             # gelu'(u) clearly non-zero there
         assert torch.equal(bwd_kept[row][sure], fwd_mask[row][sure]), row
+    with pytest.raises(Exception, match="mask_bits"):          # hidden dropout on and no saved words: an error, never a silent default
+        ops.mlp_bwd(d, gm, a, w1, b1, w2, da, dw1, db1, dw2, db2)
     # a different seed word -> a different mask
     rng2 = ops.new_rng_state(78, DEV)
     d2 = ops.mlp_desc(cc, M, C, H, ops.drop_desc(rng2, 21, p, 25, 0.0, 16), ops.drop_desc(rng2, 22, 0.0, 26, 0.0, 16))

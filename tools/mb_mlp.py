@@ -24,7 +24,7 @@ def sets(M, n):
         g = torch.Generator(device=DEV).manual_seed(i)
         out.append(dict(a=torch.randn(M, 64, device=DEV, generator=g).to(BF), r=torch.randn(M, 64, device=DEV, generator=g),
                         gm=torch.randn(M, 64, device=DEV, generator=g).to(BF), y=torch.empty(M, 64, device=DEV),
-                        da=torch.empty(M, 64, device=DEV, dtype=BF)))
+                        da=torch.empty(M, 64, device=DEV, dtype=BF), bits=torch.empty(M, 8, device=DEV, dtype=torch.int32)))
     return out
 
 
@@ -54,13 +54,13 @@ def main():
         for mode, n in (("warm", 1), ("cold", max(2, (600 << 20) // per_set + 1))):
             S = sets(M, n)
             if ONLY in ("", "fwd"):
-                us = timed(lambda i: ops.mlp_fwd(d, S[i % n]["a"], S[i % n]["r"], w1, b1, w2, b2, S[i % n]["y"]), ITERS)
+                us = timed(lambda i: ops.mlp_fwd(d, S[i % n]["a"], S[i % n]["r"], w1, b1, w2, b2, S[i % n]["y"], mask_bits=S[i % n]["bits"] if P else None), ITERS)
                 byt = M * 64 * (2 + 4 + 4)
                 print(f"mlp_fwd      {name:8s} {mode}: {us:8.1f} us  {byt / us / 1e3:7.0f} GB/s  {2 * 2 * M * 64 * 256 / us / 1e6:6.0f} TFLOP/s")
-                us = timed(lambda i: ops.mlp_fwd(d, S[i % n]["a"], S[i % n]["r"], w1, b1, w2, b2, S[i % n]["y"], next_ln=(gamma, beta)), ITERS)
+                us = timed(lambda i: ops.mlp_fwd(d, S[i % n]["a"], S[i % n]["r"], w1, b1, w2, b2, S[i % n]["y"], next_ln=(gamma, beta), mask_bits=S[i % n]["bits"] if P else None), ITERS)
                 print(f"mlp_fwd + LN {name:8s} {mode}: {us:8.1f} us")
             if ONLY in ("", "bwd"):
-                us = timed(lambda i: ops.mlp_bwd(d, S[i % n]["gm"], S[i % n]["a"], w1, b1, w2, S[i % n]["da"], dw1, db1, dw2, db2), ITERS)
+                us = timed(lambda i: ops.mlp_bwd(d, S[i % n]["gm"], S[i % n]["a"], w1, b1, w2, S[i % n]["da"], dw1, db1, dw2, db2, mask_bits=S[i % n]["bits"] if P else None), ITERS)
                 byt = M * 64 * (2 + 2 + 2)
                 print(f"mlp_bwd      {name:8s} {mode}: {us:8.1f} us  {byt / us / 1e3:7.0f} GB/s  {5 * 2 * M * 64 * 256 / us / 1e6:6.0f} TFLOP/s")
             del S
