@@ -654,21 +654,13 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
             step.run()  # builds the arena / moments / workspaces outside capture
         torch.cuda.synchronize()
         if not a.no_graph:
-            # capture failures must not be rank-dependent (a rank falling back to eager while another replays would
-            # desynchronise the collectives): agree on the outcome before using the graphs
-            ok = 1
+            # capture failures are not rank-dependent: StepSegments.capture makes the ranks agree after every segment, before the
+            # collective that follows it, so either every rank gets its graphs or every rank raises here
             try:
-                replay = step.capture(side)
+                run, graphed = step.capture(side), True
             except Exception as e:  # noqa: BLE001
-                ok = 0
                 print(f"[bench] rank {rank}: hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 torch.cuda.synchronize()
-            if world > 1:
-                flag = torch.tensor([ok], device=device, dtype=torch.int32)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            if ok:
-                run, graphed = replay, True
         if a.views == "random":
             drawn = run
 
@@ -705,7 +697,26 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        step.last_run = run
     return dt, graphed, side
+
+
+def dp_diagnostics(a, step, world, device, graphed):
+    """N > 1: what the first RCCL runs are read with (every rank calls this; rank 0 reports): the backend and its version, the number of
+    ranks that really take part (an all-reduce of ones), and the medians of HIP events between the pieces of 5 more replayed steps --
+    the graph segments, the embedding all-gather, the gradient all-reduce and how much of it stays exposed behind the split backward."""
+    ones = torch.ones(1, device=device)
+    dist.all_reduce(ones)
+    out = {"backend": dist.get_backend(), "world": world, "ranks_seen": int(ones.item()),
+           "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None),
+           "loss_head_sharded": bool(step.dist.shard_loss_head()), "split_backward": step.seg.buckets() is not None}
+    if graphed:
+        pieces = step.seg.measure_pieces(step.last_run, 5)
+        out["us_segments"] = pieces
+        out["us_exchange"] = round(sum(v for k, v in pieces.items() if k.startswith("exchange")), 1)
+        out["us_allreduce_exposed"] = round(sum(v for k, v in pieces.items() if "exposed" in k), 1)
+        out["us_step_from_events"] = round(sum(pieces.values()), 1)
+    return out
 
 
 def secondary_workloads(a, device):
@@ -766,6 +777,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     last_loss = step.loss.item()
+    with torch.cuda.stream(side):
+        dp = dp_diagnostics(a, step, world, device, graphed) if world > 1 else None
     with torch.cuda.stream(side):  # the stream the warm-up and the timed steps ran on: its allocator pools are the warm ones
         rl = roofline(a, step, device, dt / a.steps * 1e3) if (rank == 0 and not a.no_roofline) else None
     # (the plain single-GPU run only: profiling / diagnostic invocations -- --no-graph, --no-roofline, --no-cpu-baseline -- measure one workload)
@@ -792,7 +805,7 @@ def main():
                "model_flops_frac_of_bf16_mfma_peak": (round(wps / world * flops_per_window(a.model, a.dataset) / (MFMA_BF16_PEAK_TF * 1e12), 5)
                                                        if flops_per_window(a.model, a.dataset) else None),
                "flops_per_window": flops_per_window(a.model, a.dataset),
-               "roofline": rl, "cpu_baseline": cb, "secondary": sec}
+               "roofline": rl, "cpu_baseline": cb, "secondary": sec, "dp": dp}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -28,6 +28,44 @@ import torch
 from . import distributed
 
 
+class CaptureAborted(RuntimeError):
+    """A segment failed to capture on SOME rank; every rank raises this at the same point, before the next collective is issued."""
+
+
+class SegmentTimer:
+    """HIP events between the pieces of a replayed data-parallel step (graph segments and the eager collectives between them): what the
+    first RCCL runs will be diagnosed with (bench.py `dp`).  mark(name) closes the piece `name` on the current stream."""
+
+    def __init__(self):
+        self.steps, self.cur = [], None
+
+    def begin(self):
+        self.cur = [("start", self._event())]
+
+    @staticmethod
+    def _event():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def mark(self, name):
+        self.cur.append((name, self._event()))
+
+    def end(self):
+        self.steps.append(self.cur)
+        self.cur = None
+
+    def medians_us(self):
+        """{piece: median microseconds over the timed steps}, in step order."""
+        torch.cuda.synchronize()
+        out = {}
+        for st in self.steps:
+            for (_, e0), (name, e1) in zip(st[:-1], st[1:]):
+                out.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
+        med = lambda v: sorted(v)[len(v) // 2]
+        return {k: round(med(v), 1) for k, v in out.items()}
+
+
 class StepSegments:
     def __init__(self, model, loss_fn, opt, views, device):
         """views(): -> (view1, view2) frequency-domain inputs; called inside segment A (bench.py: the DFT of the resident windows is
@@ -36,6 +74,8 @@ class StepSegments:
         self.dist = distributed
         self.loss = torch.zeros((), device=device)
         self.feats = None
+        self.device = device
+        self.timer = None      # a SegmentTimer while bench.py measures the pieces of the replayed step
         self._buckets = False  # decided at the first data-parallel step (the arena exists by then)
 
     def buckets(self):
@@ -128,6 +168,36 @@ class StepSegments:
         self.reduce()
         self.seg_c()
 
+    def _capture_segment(self, graph, fn, pool, stream, mode):
+        """One segment into one hipGraph.  Under data parallelism the ranks agree on the outcome BEFORE anybody issues the collective that
+        follows the segment: a rank whose capture failed (out of memory, a capture error on one rank) used to run into
+        agree()'s all-reduce while its peers sat in the all-gather / all-reduce between the segments -- mismatched collectives, a hang
+        until the process-group timeout.  Now every rank leaves at the same point with CaptureAborted and the step state is cleaned up."""
+        err = None
+        try:
+            with torch.cuda.graph(graph, pool=pool, stream=stream, **mode):
+                fn()
+        except Exception as e:  # noqa: BLE001
+            err = e
+            torch.cuda.synchronize()
+        if err is not None and not self.dist.is_dist():
+            self.abort_capture()
+            raise err
+        if not agree(err is None, self.device):
+            self.abort_capture()
+            raise CaptureAborted(f"{type(err).__name__}: {err}" if err is not None else "another rank failed to capture this segment")
+
+    def abort_capture(self):
+        """Leave nothing of a half-captured step behind: parked backward halves hold tensors of the aborted graph pool (an eager
+        backward_continue() would run them into the arena gradients), split_backward must not stay set, outstanding all-reduce handles
+        are waited for (every rank issued them: the ranks agreed on the segment before) and dropped."""
+        bb = getattr(self.model, "backbone", None)
+        if bb is not None:
+            bb.pending_backward = []
+            bb.split_backward = False
+        self.opt.wait_reductions()
+        self.feats = None
+
     def capture(self, stream):
         """Returns the replay callable: one hipGraph of the whole step on one rank; with N > 1 ranks, hipGraphs of the segments (one
         shared memory pool) with the collectives issued eagerly between their replays.
@@ -146,37 +216,31 @@ class StepSegments:
                 # one rank: no collectives to interleave -> one graph for the whole step (each extra graph launch costs
                 # ~0.1 ms of idle GPU per step)
                 whole = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(whole, pool=pool, stream=stream):
-                    self.run()
+                self._capture_segment(whole, self.run, pool, stream, {})
                 graphs = (whole,)
             else:
                 shard = self.dist.shard_loss_head()
                 ga, gb, gb2, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, pool=pool, stream=stream, **mode):
-                    self.seg_a()
+                # (every segment: capture, then the ranks agree, then -- and only then -- the collective that follows it)
+                self._capture_segment(ga, self.seg_a, pool, stream, mode)
                 self.exchange()  # eager, autograd-aware: links segment B's backward to segment A's forward
                 if shard:
-                    with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
-                        self.seg_b1()
+                    self._capture_segment(gb, self.seg_b1, ga.pool(), stream, mode)
                     head = self.head
                     self.exchange_head()
-                    with torch.cuda.graph(gb2, pool=ga.pool(), stream=stream, **mode):
-                        self.seg_b2()
+                    self._capture_segment(gb2, self.seg_b2, ga.pool(), stream, mode)
                 else:
                     head, gb2 = None, None
-                    with torch.cuda.graph(gb, pool=ga.pool(), stream=stream, **mode):
-                        self.seg_b()
+                    self._capture_segment(gb, self.seg_b, ga.pool(), stream, mode)
                 gr = None
                 if self.buckets() is None:
                     self.reduce()
                 else:
                     self.reduce_first()
                     gr = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gr, pool=ga.pool(), stream=stream, **mode):
-                        self.seg_rest()
+                    self._capture_segment(gr, self.seg_rest, ga.pool(), stream, mode)
                     self.reduce_second()
-                with torch.cuda.graph(gc, pool=ga.pool(), stream=stream, **mode):
-                    self.seg_c()
+                self._capture_segment(gc, self.seg_c, ga.pool(), stream, mode)
                 graphs = (ga, gb, gb2, gc, gr)
             pool = graphs[0].pool()
             if attempt == 0:
@@ -188,20 +252,46 @@ class StepSegments:
         packed = self.packed
 
         def replay():
+            t = self.timer
+            mark = t.mark if t is not None else (lambda name: None)
+            if t is not None:
+                t.begin()
             ga.replay()
+            mark("A: zero_grad, views, backbone passes, pack")
             self.dist.replay_exchange(packed)
+            mark("exchange: all-gather of the embeddings")
             gb.replay()
+            mark("B1: head rows" if gb2 is not None else "B: loss head, backward")
             if gb2 is not None:
                 self.dist.exchange_loss_chunks(head)  # the persistent send / chunks buffers of the sharded head
+                mark("exchange: all-gather of the head's chunks")
                 gb2.replay()
+                mark("B2: head coefficients, backward")
             if gr is None:
                 self.opt.reduce_gradients()
+                mark("all-reduce of the gradient arena (exposed)")
             else:
                 self.reduce_first()   # bucket 1 (last stage, mod_in, projectors) travels ...
+                mark("issue all-reduce of bucket 1")
                 gr.replay()           # ... while the earlier stages' backward runs
+                mark("R: rest of backward, beside bucket 1")
                 self.reduce_second()
+                mark("all-reduce: wait for bucket 1 + bucket 2 (exposed)")
             gc.replay()
+            mark("C: AdamW")
+            if t is not None:
+                t.end()
         return replay
+
+    def measure_pieces(self, run, steps=5):
+        """`steps` more replays with HIP events between the pieces -> {piece: median us}.  Collective: every rank calls it."""
+        self.timer = SegmentTimer()
+        try:
+            for _ in range(steps):
+                run()
+            return self.timer.medians_us()
+        finally:
+            self.timer = None
 
 
 def agree(ok, device):
@@ -252,14 +342,12 @@ class CapturedTrainStep:
         self.seen = self.seen + 1 if key == self.key else 1
         self.key = key
         if self.seen >= self.warm_steps:
-            ok = True
+            # (the ranks agree segment by segment inside capture(): a failure on any rank raises here on every rank, at the same point)
             try:
                 self._capture(v1, v2)
             except Exception as e:  # noqa: BLE001 -- capture is an optimisation: stay eager, say so once
-                ok = False
                 logging.warning(f"hipGraph capture of the training step unavailable ({type(e).__name__}: {e}); running eagerly")
                 torch.cuda.synchronize()
-            if not agree(ok, out.device):  # every rank replays, or none does
                 self.enabled, self.replay = False, None
         return out
 

@@ -34,7 +34,7 @@ def test_four_modality_step(ct):
     dev = lambda d: {l: {m: v.cuda() for m, v in mm.items()} for l, mm in d.items()}
     f1, f2 = focal(dev(synthetic_freq_input(cfg, 8, seed=303)), dev(synthetic_freq_input(cfg, 8, seed=404)), proj_head=True)
     assert list(f1.keys()) == ["acc", "gyr", "mag", "lig"]
-    tol = 1e-3 if ct == "fp32" else 1.2e-2  # observed 7.5e-3 - 9.6e-3 (tests/golden/OBSERVED_r3.json)
+    tol = 1e-3 if ct == "fp32" else 1e-2  # observed 7.5e-3 - 9.6e-3 (tests/golden/OBSERVED_r3.json)
     from conftest import record_observed
     for m in f1:
         ref = torch.from_numpy(fx[f"train.emb1.{m}"])

@@ -46,3 +46,13 @@ def test_bench_contract_with_two_ranks(model):
     assert out["value"] > 0 and abs(out["value"] - 32 / (out["ms_per_step"] * 1e-3)) < 0.02 * out["value"]
     assert out["vs_baseline"] is None and out["cpu_baseline"] is None  # the CPU baseline is timed at N = 1 only
     assert out["roofline"] is not None and out["roofline"]["frac"] > 0
+    # day-one diagnostics of the data-parallel step (what the first RCCL runs will be read with)
+    dp = out["dp"]
+    assert dp["backend"] == "gloo" and dp["world"] == 2 and dp["ranks_seen"] == 2 and dp["rccl_version"] is None
+    assert dp["loss_head_sharded"] is (model == "SW_Transformer") and dp["split_backward"] is (model == "SW_Transformer")
+    seg = dp["us_segments"]
+    assert any(k.startswith("A:") for k in seg) and any(k.startswith("C:") for k in seg) and all(v >= 0 for v in seg.values())
+    assert dp["us_exchange"] > 0 and dp["us_allreduce_exposed"] > 0
+    # (no bound against ms_per_step here: over gloo the collectives are host round trips of two processes sharing one GPU, and the 5
+    # diagnostic steps run after rank 0's peers have gone idle; over RCCL the sum is the step)
+    assert dp["us_step_from_events"] >= dp["us_exchange"] + dp["us_allreduce_exposed"]

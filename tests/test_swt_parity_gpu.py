@@ -59,12 +59,12 @@ def test_eval_embeddings(cfg, ct, tol):
         record_observed(f"swt.eval.feat.{m}.{ct}.max_err_over_max_ref", ef)
         # bf16: north_star's 1e-2 as a relative-to-scale bound; operand rounding ALONE (the oracle in fp32 arithmetic with bf16-rounded
         # operands, test_bf16_path_equals_operand_rounded_oracle) already costs 0.8e-2 - 1.0e-2 and a row cosine of 0.99996 here
-        assert e < (1e-3 if ct == "fp32" else 1.5e-2), (m, e)
+        assert e < (1e-3 if ct == "fp32" else 1e-2), (m, e)   # (observed 0.82e-2 / 0.96e-2: tests/golden/OBSERVED_r4.json)
         if ct == "fp32":
             assert (emb[m].cpu() - ref).abs().max().item() < tol
         else:
             assert cos > 0.9999, (m, cos)
-        assert ef < (1e-3 if ct == "fp32" else 1.5e-2)
+        assert ef < (1e-3 if ct == "fp32" else 1e-2)
 
 
 @pytest.mark.parametrize("ct", ["fp32", "bf16"])
@@ -78,7 +78,7 @@ def test_train_step_loss_and_gradients(cfg, ct):
         e1 = scale_err(f1[m].detach().cpu(), torch.from_numpy(fx[f"train.emb1.{m}"]))
         e2 = scale_err(f2[m].detach().cpu(), torch.from_numpy(fx[f"train.emb2.{m}"]))
         record_observed(f"swt.train.emb.{m}.{ct}.max_err_over_max_ref", max(e1, e2))
-        assert max(e1, e2) < (1e-3 if ct == "fp32" else 1.5e-2), (m, e1, e2)
+        assert max(e1, e2) < (1e-3 if ct == "fp32" else 1e-2), (m, e1, e2)
     net.arena().zero_grad()
     loss = loss_fn(f1, f2)
     loss.backward()
