@@ -275,21 +275,16 @@ static int attn_geometry(const focal_attn_desc* d, AttnGeom* g) {
   return FOCAL_OK;
 }
 
-#include <stdlib.h>
-// LDS budget per workgroup: small enough that several workgroups share a CU and overlap their gather / compute /
-// scatter phases (tunable for experiments with FOCAL_ATTN_LDS_KB).
-static size_t att_lds_budget(bool bwd) {
-  const char* e = getenv(bwd ? "FOCAL_ATTN_BWD_LDS_KB" : "FOCAL_ATTN_LDS_KB");
-  const long kb = e ? atol(e) : (bwd ? 40 : 32);
-  return (size_t)(kb < 8 ? 8 : (kb > 60 ? 60 : kb)) * 1024;
-}
+// LDS budget per workgroup of the exact-fp32 kernels: small enough that several workgroups share a CU and overlap their gather /
+// compute / scatter phases
+static size_t att_lds_budget(bool bwd) { return (size_t)(bwd ? 40 : 32) * 1024; }
 
 extern "C" int focal_window_attn_fwd(const focal_attn_desc* d, const void* qkv, const float* bias_table, void* out,
                                      void* stream) {
   AttnGeom g;
   if (int rc = attn_geometry(d, &g)) return rc;
   FOCAL_CHECK_ARG(qkv && bias_table && out, "window_attn_fwd: null tensor");
-  if (d->dtype == FOCAL_BF16 && !getenv("FOCAL_ATTN_VALU"))  // matrix-core path (attn_mfma.hip); fp32 stays on the exact VALU kernel
+  if (d->dtype == FOCAL_BF16)  // matrix-core path (attn_mfma.hip); fp32 stays on the exact VALU kernel
     return focal_attn_mfma_fwd(g, (const bf16_t*)qkv, bias_table, (bf16_t*)out, d->rng, d->stream, d->p_attn, (hipStream_t)stream);
   const size_t per_win = (size_t)g.N * (3 * g.C + 4) * 4 + 2 * g.N * 4;
   int wpb = 256 / (g.heads * g.N);
@@ -304,8 +299,7 @@ extern "C" int focal_window_attn_fwd(const focal_attn_desc* d, const void* qkv, 
   hipStream_t st = (hipStream_t)stream;
 #define ATT_FWD_(T, HD, NT) FOCAL_LAUNCH((window_attn_fwd_kernel<T, HD, NT>), dim3(blocks), dim3(threads), sm, st, (const T*)qkv, bias_table, (T*)out, g, wpb, total, d->rng, d->stream, d->p_attn)
 #define ATT_FWD(T, HD) do { if (g.N == 9) ATT_FWD_(T, HD, 9); else ATT_FWD_(T, HD, ATT_NMAX); } while (0)
-  if (d->dtype == FOCAL_F32) { if (g.hd == 16) ATT_FWD(float, 16); else if (g.hd == 32) ATT_FWD(float, 32); else ATT_FWD(float, 64); }
-  else { if (g.hd == 16) ATT_FWD(bf16_t, 16); else if (g.hd == 32) ATT_FWD(bf16_t, 32); else ATT_FWD(bf16_t, 64); }
+  if (g.hd == 16) ATT_FWD(float, 16); else if (g.hd == 32) ATT_FWD(float, 32); else ATT_FWD(float, 64);
 #undef ATT_FWD
 #undef ATT_FWD_
   FOCAL_LAUNCH_CHECK();
@@ -317,7 +311,7 @@ extern "C" int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, 
   AttnGeom g;
   if (int rc = attn_geometry(d, &g)) return rc;
   FOCAL_CHECK_ARG(qkv && bias_table && dout && dqkv && dbias_table, "window_attn_bwd: null tensor");
-  if (d->dtype == FOCAL_BF16 && !getenv("FOCAL_ATTN_VALU")) {
+  if (d->dtype == FOCAL_BF16) {
     FOCAL_CHECK_ARG((2 * g.wh - 1) * (2 * g.ww - 1) * g.heads <= 256, "window_attn_bwd: bias table too large");
     return focal_attn_mfma_bwd(g, (const bf16_t*)qkv, bias_table, (const bf16_t*)dout, (bf16_t*)dqkv, dbias_table, d->rng, d->stream,
                                d->p_attn, (hipStream_t)stream);
@@ -337,8 +331,7 @@ extern "C" int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, 
   hipStream_t st = (hipStream_t)stream;
 #define ATT_BWD_(T, HD, NT) FOCAL_LAUNCH((window_attn_bwd_kernel<T, HD, NT>), dim3(blocks), dim3(threads), sm, st, (const T*)qkv, bias_table, (const T*)dout, (T*)dqkv, dbias_table, g, wpb, total, d->rng, d->stream, d->p_attn)
 #define ATT_BWD(T, HD) do { if (g.N == 9) ATT_BWD_(T, HD, 9); else ATT_BWD_(T, HD, ATT_NMAX); } while (0)
-  if (d->dtype == FOCAL_F32) { if (g.hd == 16) ATT_BWD(float, 16); else if (g.hd == 32) ATT_BWD(float, 32); else ATT_BWD(float, 64); }
-  else { if (g.hd == 16) ATT_BWD(bf16_t, 16); else if (g.hd == 32) ATT_BWD(bf16_t, 32); else ATT_BWD(bf16_t, 64); }
+  if (g.hd == 16) ATT_BWD(float, 16); else if (g.hd == 32) ATT_BWD(float, 32); else ATT_BWD(float, 64);
 #undef ATT_BWD
 #undef ATT_BWD_
   FOCAL_LAUNCH_CHECK();

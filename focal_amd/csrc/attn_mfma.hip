@@ -438,13 +438,12 @@ int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
   // kernel's duration.
   // Measured (r1, B=256): 4-wave x 4096 blocks 125/83/69/59/36/21 us for the six stage geometries, 16-wave x 256
   // blocks 99/54/39/24/20/16 us.
-  static const int nw = getenv("FOCAL_ATTN_BWD_NW") ? atoi(getenv("FOCAL_ATTN_BWD_NW")) : 16;
-  static const int maxb = getenv("FOCAL_ATTN_BWD_BLOCKS") ? atoi(getenv("FOCAL_ATTN_BWD_BLOCKS")) : 256;
+  const int nw = 16, maxb = 256;  // 16-wave persistent workgroups, one per CU (8 waves / 512 workgroups: within +-0.6 %, profiles/r1_u_same_box_knob_sweep.log)
   int blocks = ceil_div(items, nw);
   if (blocks > maxb) blocks = maxb;
   const int iters = ceil_div(items, blocks * nw);
 #define LAUNCH2(HD, NW) FOCAL_LAUNCH((window_attn_bwd_mfma_kernel<HD, NW>), dim3(blocks), dim3(NW * 64), 0, st, qkv, bias_table, dout, dqkv, dbias_table, g, items, iters, rng, stream_id, p_attn)
-#define LAUNCH(HD) do { if (nw == 16) LAUNCH2(HD, 16); else if (nw == 8) LAUNCH2(HD, 8); else LAUNCH2(HD, 4); } while (0)
+#define LAUNCH(HD) LAUNCH2(HD, 16)
   if (g.hd == 16) LAUNCH(16); else if (g.hd == 32) LAUNCH(32); else LAUNCH(64);
 #undef LAUNCH2
 #undef LAUNCH

@@ -261,14 +261,13 @@ extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scr
     int blocks = ceil_div((long)d->rows * C / 4, 1024 * 2);
     if (blocks > 256) blocks = 256;
     BnFinalize fin = {nullptr, nullptr, nullptr, n_stat, d->eps, d->momentum};
-    static const bool no_fuse = getenv("FOCAL_BN_NOFUSE") != nullptr;
-    if (training == FOCAL_BN_TRAIN && !no_fuse) {
+    if (training == FOCAL_BN_TRAIN) {
       FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
       fin.mean_rstd = mean_rstd; fin.run_mean = running_mean; fin.run_var = running_var;
     }
     FOCAL_LAUNCH(bn_partial_kernel, dim3(blocks), dim3(1024), 32 * C * sizeof(float), st, z, scratch, (long)d->rows, C, fin);
   }
-  if (training == FOCAL_BN_FINALIZE || (training == FOCAL_BN_TRAIN && getenv("FOCAL_BN_NOFUSE"))) {
+  if (training == FOCAL_BN_FINALIZE) {
     FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
     FOCAL_LAUNCH(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, scratch, mean_rstd, running_mean, running_var, n_stat, C,
                        d->eps, d->momentum);

@@ -351,8 +351,7 @@ __global__ __launch_bounds__(256) void conv_in_bwd_weight_mfma_kernel(const floa
 }
 
 static bool conv_in_is_patchify(const focal_conv_in_desc* d) {
-  return d->stride == d->k && d->pad_left == 0 && d->S_in == d->S_out * d->k && d->k % 4 == 0 && d->cin * d->k == 160 && d->C == 64 &&
-         !getenv("FOCAL_CONV_IN_VALU");
+  return d->stride == d->k && d->pad_left == 0 && d->S_in == d->S_out * d->k && d->k % 4 == 0 && d->cin * d->k == 160 && d->C == 64;
 }
 
 static int conv_in_check(const focal_conv_in_desc* d) {
@@ -371,7 +370,7 @@ extern "C" int focal_conv_in_fwd(const focal_conv_in_desc* d, const float* x, co
     int blocks = ceil_div(total, CIN_TOK);
     // one workgroup per CU: every workgroup pays for the 40 KB filter bank once (measured at 800 tiles: 26 us at 200-256
     // workgroups, 29 at 512, 32.5 at 768)
-    static const int cap = getenv("FOCAL_CONVIN_BLOCKS") ? atoi(getenv("FOCAL_CONVIN_BLOCKS")) : 256;
+    const int cap = 256;
     if (blocks > cap) blocks = cap;
     const PatchGeom pg = make_patch_geom(d->S_out, d->I, d->I, d->S_in, d->k, d->cin);
     FOCAL_LAUNCH((conv_in_fwd_mfma_kernel<160>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, z, *d, total, pg);
@@ -406,8 +405,8 @@ extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float
     FOCAL_LAUNCH_CHECK();
     return FOCAL_OK;
   }
-  if (K <= 16 && d->C == 64 && !getenv("FOCAL_CONVIN_DW_LDS")) {
-    static const int tiny_wg = getenv("FOCAL_CONVIN_DW_BLOCKS") ? atoi(getenv("FOCAL_CONVIN_DW_BLOCKS")) : 64;
+  if (K <= 16 && d->C == 64) {
+    const int tiny_wg = 64;
     const int waves = tiny_wg * 16;
     const int tpw = ceil_div(total, waves);
     const int blocks = ceil_div(ceil_div(total, tpw), 16);
@@ -422,7 +421,7 @@ extern "C" int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float
   if (K <= 16) {
     const size_t sms = ((size_t)CIN_TOK * (K + 1) + (size_t)CIN_TOK * (d->C + 4)) * sizeof(float);
     const int chunks = ceil_div(total, CIN_TOK);
-    static const int wg_cap = getenv("FOCAL_CONVIN_DW_BLOCKS") ? atoi(getenv("FOCAL_CONVIN_DW_BLOCKS")) : 512;
+    const int wg_cap = 512;
     int cpw = ceil_div(chunks, wg_cap);
     if (cpw < 1) cpw = 1;
     const int blocks = ceil_div(chunks, cpw);

@@ -228,11 +228,11 @@ static int embed_launch(const focal_embed_desc* d, const float* x, const float* 
   FOCAL_CHECK_ARG(sm <= 64 * 1024, "pad_patch_embed_ln: patch of %d values does not fit in LDS", K);
   const int total = d->B * d->Hp * d->Wp;
   hipStream_t st = (hipStream_t)stream;
-  if (K == 80 && d->C0 == 64 && d->pw % 4 == 0 && d->S % 4 == 0 && !getenv("FOCAL_EMBED_VALU")) {
+  if (K == 80 && d->C0 == 64 && d->pw % 4 == 0 && d->S % 4 == 0) {
     int mb = ceil_div(total, EMB_TOK);
     // two resident workgroups per CU (208-230 VGPRs); more only repeats the filter-bank load (measured 61 / 74 / 102 / 178 us at
     // 512 / 1024 / 2048 / 4608 workgroups before the bank went through LDS)
-    static const int mb_cap = getenv("FOCAL_EMBED_BLOCKS") ? atoi(getenv("FOCAL_EMBED_BLOCKS")) : 512;
+    const int mb_cap = 512;
     if (mb > mb_cap) mb = mb_cap;
     const PatchGeom pg = make_patch_geom(d->Wp, d->Hp, d->I, d->S, d->pw, d->cin);
     FOCAL_LAUNCH((patch_embed_ln_mfma_kernel<80>), dim3(mb), dim3(256), 0, st, x, w, b, gamma, beta, tokens, *d, total, pg, l2);

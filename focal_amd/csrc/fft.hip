@@ -257,7 +257,7 @@ static int fft_launch(const focal_fft_desc* d, const AugParams& aug, const float
   FOCAL_CHECK_ARG(sm <= 64 * 1024, "fft_realpack: n=%d too long for the LDS-resident DFT", d->n);
   const int rows = d->B * d->C * d->I;
   const bool mfma_shape = (d->n1 == d->n2) && (d->n1 == 8 || d->n1 == 16 || d->n1 == 24 || d->n1 == 32 || d->n1 == 40 || d->n1 == 48);
-  if (mfma_shape && rows % 2 == 0 && !getenv("FOCAL_FFT_VALU")) {
+  if (mfma_shape && rows % 2 == 0) {
     const size_t smm = (size_t)(2 * d->n + 2 * 48 * d->n1 + (d->n1 == d->n2 ? 0 : 2 * 48 * d->n2) + 4 * 48 * d->n2 + 2 * d->n) * sizeof(float);
     static size_t lds_granted = 48 * 1024;
     if (smm > lds_granted) {  // above the default dynamic-LDS grant: raise it for this kernel (160 KB per CU on gfx950)
@@ -271,7 +271,7 @@ static int fft_launch(const focal_fft_desc* d, const AugParams& aug, const float
       }
       lds_granted = smm;
     }
-    static const int maxb = getenv("FOCAL_FFT_BLOCKS") ? atoi(getenv("FOCAL_FFT_BLOCKS")) : 1024;
+    const int maxb = 1024;
     int blocks = rows / 2 < maxb ? rows / 2 : maxb;
 #define FFT_GO(N_) case N_: FOCAL_LAUNCH((fft_realpack_mfma_kernel<N_, N_>), dim3(blocks), dim3(256), smm, (hipStream_t)stream, x, twiddle, out, *d, rows, aug); break
     switch (d->n1) { FFT_GO(8); FFT_GO(16); FFT_GO(24); FFT_GO(32); FFT_GO(40); default: FFT_GO(48); }
@@ -348,7 +348,7 @@ static int aug_params(const focal_fft_desc* d, const focal_aug_desc* a, AugParam
 
 extern "C" int focal_fft_realpack_multi(int n, const focal_fft_problem* probs, void* stream) {
   FOCAL_CHECK_ARG(n >= 1 && probs, "fft_realpack_multi: no problems");
-  static const bool no_multi = getenv("FOCAL_FFT_NO_MULTI") != nullptr;
+  const bool no_multi = false;
   FftSmallTable t;
   memset(&t, 0, sizeof(t));
   auto flush = [&]() -> int {

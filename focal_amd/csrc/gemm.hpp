@@ -333,16 +333,13 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
 // count.  Shared by the dispatcher (gemm_dispatch.inc: launch_dw) and by focal_linear_bwd_weight_workgroups, which tells a caller
 // how a launch will show up in a profiler trace.
 static inline void focal_dw_plan(int M, int N, long rows, int* bm_out, int* bn_out, int* splits_out) {
-  int bm = M >= 256 ? 256 : (M >= 128 ? 128 : 64);
-  int bn = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
-  while (bm * bn > 16384) { if (bm >= bn) bm >>= 1; else bn >>= 1; }
-  // wide tiles only for outputs of at least FOCAL_DW_WIDE_MIN elements (default: never -- see the note at launch_dw)
-  static const long wide_min = getenv("FOCAL_DW_WIDE_MIN") ? atol(getenv("FOCAL_DW_WIDE_MIN")) : (getenv("FOCAL_GEMM_DW_WIDE") ? 0 : (1L << 40));
-  if ((long)M * N < wide_min) bm = bn = 64;
+  // 64 x 64 tiles, ~512 workgroups, at least 256 reduction rows each: the wide register-staged shapes (256 x 64 ... 128 x 128) and other
+  // workgroup targets were swept in rounds 1-2 and lost everywhere (profiles/r1_i_dw_tile_sweep.txt, r2_dw_variants.txt); round 4 removed them
+  const int bm = 64, bn = 64;
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-  static const long target_wg = getenv("FOCAL_DW_WGS") ? atol(getenv("FOCAL_DW_WGS")) : 512;
+  const long target_wg = 512;
   long splits = (target_wg + tiles - 1) / tiles;
-  static const long min_rows = getenv("FOCAL_DW_MIN_ROWS") ? atol(getenv("FOCAL_DW_MIN_ROWS")) : 256;  // reduction rows per workgroup, at least
+  const long min_rows = 256;  // reduction rows per workgroup, at least
   const long max_splits = (rows + min_rows - 1) / min_rows;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -351,8 +348,7 @@ static inline void focal_dw_plan(int M, int N, long rows, int* bm_out, int* bn_o
 
 // Shapes the LDS-DMA ring weight-gradient kernel (gemm_dw_ring.hpp) takes, given bf16 operands without a loader prologue.
 static inline bool focal_dw_ring_shape(int M, int N, long rows) {
-  static const bool off = getenv("FOCAL_DW_NORING") != nullptr;
-  return !off && M % 64 == 0 && N % 64 == 0 && rows % 64 == 0 && rows >= 64;
+  return M % 64 == 0 && N % 64 == 0 && rows % 64 == 0 && rows >= 64;
 }
 
 // Workgroups per output tile of the ring kernel when every workgroup takes two token slices (8 waves, two rings = 128 KB of LDS: ONE

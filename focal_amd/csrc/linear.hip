@@ -241,8 +241,7 @@ static bool dw_group_fits(const focal_dw_problem& q) {
 }
 
 extern "C" int focal_linear_bwd_weight_group_supported(int dtype, int M, int N, int K) {
-  static const bool off = getenv("FOCAL_DW_NOGROUP") != nullptr;
-  return !off && dtype == FOCAL_BF16 && M > 0 && M % 64 == 0 && N % 128 == 0 && K % 128 == 0;
+  return dtype == FOCAL_BF16 && M > 0 && M % 64 == 0 && N % 128 == 0 && K % 128 == 0;
 }
 
 static int dw_group_build(int dtype, int n, const focal_dw_problem* probs, DwGroupParams* gp, int* wgs) {
@@ -261,8 +260,7 @@ static int dw_group_build(int dtype, int n, const focal_dw_problem* probs, DwGro
     p.M = q.N; p.N = q.K; p.rows = q.M;
     p.exclusive = q.exclusive ? 1 : 0;
   }
-  static const int target = getenv("FOCAL_DWG_WGS") ? atoi(getenv("FOCAL_DWG_WGS")) : 256;
-  static const int min_steps = getenv("FOCAL_DWG_MIN_STEPS") ? atoi(getenv("FOCAL_DWG_MIN_STEPS")) : 8;
+  const int target = 256, min_steps = 8;  // ~one workgroup per CU, at least 8 ring stages each (swept in round 3: profiles/r3_dw_group.txt)
   *wgs = focal_dw_group_plan<64>(*gp, target, min_steps);
   return FOCAL_OK;
 }
@@ -297,11 +295,9 @@ static int dw_ring_group_build(int dtype, int n, const focal_dw_problem* probs, 
 }
 
 extern "C" int focal_linear_bwd_weight_group_kind(int dtype, int M, int N, int K) {
-  static const bool off = getenv("FOCAL_DW_NOGROUP") != nullptr;
-  if (off || dtype != FOCAL_BF16 || M <= 0 || M % 64 != 0) return 0;
+  if (dtype != FOCAL_BF16 || M <= 0 || M % 64 != 0) return 0;
   if (N % 128 == 0 && K % 128 == 0) return 2;
-  static const bool off64 = getenv("FOCAL_DW_NORINGGROUP") != nullptr;
-  return (!off64 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0) ? 1 : 0;
+  return (N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0) ? 1 : 0;
 }
 
 extern "C" int focal_linear_bwd_weight_group(int dtype, int n, const focal_dw_problem* probs, void* stream) {

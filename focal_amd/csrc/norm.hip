@@ -251,7 +251,7 @@ extern "C" int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const
   const int rpw = 64 / lpr;
   // 16 waves per workgroup up to 512 channels (the PatchMerging norms: 4 waves per CU left every row's memory latency exposed -- rows
   // 18 432 x 512: 66 -> 39 us cold, step +0.9 %, profiles/r3_ln_bwd_wide_tpb.txt); 1024 channels (4 float4 per lane and array) stay at 4
-  static const int wide_tpb = getenv("FOCAL_LN_BWD_WIDE_TPB") ? atoi(getenv("FOCAL_LN_BWD_WIDE_TPB")) : 1024;
+  const int wide_tpb = 1024;  // (16 waves per workgroup at 512 channels: 66 -> 39 us, profiles/r3_ln_bwd_wide_tpb.txt)
   const int tpb = d->C >= 1024 ? 256 : (d->C >= 512 ? wide_tpb : 1024), maxb = 256;
   focal_drop_desc dd;
   memset(&dd, 0, sizeof(dd));

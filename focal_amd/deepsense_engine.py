@@ -107,7 +107,7 @@ class DeepSenseModEncoder:
         # (momentum 1: the "running" buffer it is given simply receives the statistic) and DeepSense.finish_views applies both updates
         # afterwards in one launch (ops.bn_running_combine) -- the same two updates, in the reference's order.
         order = getattr(self, "pass_order", None)
-        side_by_side = order is not None and training and os.environ.get("FOCAL_DS_ORDERED_VIEWS") != "1"
+        side_by_side = order is not None and training
         sink = self._sink(order, x_freq.device) if side_by_side else None
         if order == 1 and not side_by_side and getattr(self, "_bn_done", None) is not None:
             torch.cuda.current_stream(x_freq.device).wait_event(self._bn_done)

@@ -211,7 +211,7 @@ class StepSegments:
         # capture mode that would invalidate a capture in progress, "thread_local" restricts the checks to the capturing thread
         mode = {"capture_error_mode": "thread_local"} if multi else {}
         pool, self._warm_graphs = None, []
-        for attempt in range(1 if os.environ.get("FOCAL_BENCH_SINGLE_CAPTURE") == "1" else 2):
+        for attempt in range(2):
             if not multi:
                 # one rank: no collectives to interleave -> one graph for the whole step (each extra graph launch costs
                 # ~0.1 ms of idle GPU per step)

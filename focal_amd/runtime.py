@@ -45,9 +45,6 @@ def side_stream(device, index):
     """index 0 = the caller's current stream; index >= 1 = a dedicated side stream of this device."""
     if index == 0 or os.environ.get("FOCAL_NO_STREAMS") == "1":
         return torch.cuda.current_stream(device)
-    cap = int(os.environ.get("FOCAL_SIDE_STREAMS", "0"))  # experiment / tuning: at most this many side streams (encoders share them round-robin)
-    if cap > 0:
-        index = (index - 1) % cap + 1
     key = (torch.device(device), index)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
@@ -75,8 +72,6 @@ def fork_point(device):
 
 def fork_from(device, index, point):
     """Stream `index` (0 = the caller's), ordered after `point` (see fork_point) only."""
-    if os.environ.get("FOCAL_FORK_LATE") == "1":  # A/B switch: the old behaviour
-        return fork(device, index)
     st = side_stream(device, index)
     if st != torch.cuda.current_stream(device):
         st.wait_event(point)

@@ -119,28 +119,23 @@ class DeepSense(HipBackbone):
             raise FocalHipError("the FOCAL HIP path needs the model on a ROCm device (no CPU fallback)")
         cur = torch.cuda.current_stream(dev)
         out = {}
-        # The two views of a step also get their own streams (FOCAL_DS_VIEW_STREAMS=0: one stream per modality): the GRU sequence
+        # The two views of a step also get their own streams: the GRU sequence
         # kernels are latency-bound launches of 32 workgroups, and view 2's convolution stack fills the chip under view 1's GRU.
         # BatchNorm's running buffers must see view 1 before view 2: an encoder's pass starts after the previous pass of the same
         # encoder has left its convolution stack (the last BatchNorm), see deepsense_engine.forward.
         # (view_index: FOCAL.forward numbers its two backbone calls 0 / 1; any other caller runs one stream per modality)
-        view_streams = view_index is not None and os.environ.get("FOCAL_DS_VIEW_STREAMS", "1") != "0" and self.training
+        view_streams = view_index is not None and self.training
         if view_index in (None, 0):
             for enc in self._encoders.values():
-                if os.environ.get("FOCAL_DS_PACK_ONCE", "1") != "0":
-                    enc.prepare_packs()  # re-ordered weights for both views' passes: one launch per encoder, before the streams fork
-                else:
-                    enc._packs = None
+                enc.prepare_packs()  # re-ordered weights for both views' passes: one launch per encoder, before the streams fork
         point = runtime.fork_point(dev)  # every encoder starts from here: none waits for the one launched before it
-        late = os.environ.get("FOCAL_FORK_LATE") == "1"
         order = list(range(len(self.modalities)))
-        if os.environ.get("FOCAL_HEAVY_FIRST", "1") != "0":  # the heaviest encoder is enqueued first (see SW_Transformer.forward_encoder)
-            order.sort(key=lambda i: -freq_x[loc][self.modalities[i]].numel())
+        order.sort(key=lambda i: -freq_x[loc][self.modalities[i]].numel())  # the heaviest encoder is enqueued first (see SW_Transformer.forward_encoder)
         for mi in order:
             mod = self.modalities[mi]
             # with one stream per (view, modality) no encoder runs on the caller's stream (index 0): view 2's forks would otherwise
             # wait for the view-1 pass that was enqueued there
-            st = runtime.fork_from(dev, (view_index * len(self.modalities) + (0 if late else 1) if view_streams else 0) + mi, point)
+            st = runtime.fork_from(dev, (view_index * len(self.modalities) + 1 if view_streams else 0) + mi, point)
             with torch.cuda.stream(st):
                 self._encoders[(loc, mod)].pass_order = view_index if view_streams else None
                 f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)

@@ -39,7 +39,8 @@ class SW_Transformer(HipBackbone):
         # No batch statistics anywhere in this backbone: FOCAL may run both views as one batch of 2B
         # (FOCALModules.FOCAL.forward).  Measured r1: 9.48 ms (two passes on 4 streams) -> 9.12 ms (one pass, 2 streams);
         # cutting the heavier modality back into batch chunks to balance the streams was slower again (9.34 ms).
-        self.views_share_pass = os.environ.get("FOCAL_SPLIT_VIEWS", "0") != "1"
+        # (one pass per view on four streams -- halved kernels, doubled launches -- cost 14 %: DESIGN 4; the switch was removed in round 4)
+        self.views_share_pass = True
         self._init_hip(args)
         self.init_encoder()
 
@@ -129,11 +130,10 @@ class SW_Transformer(HipBackbone):
         # The heaviest modality is enqueued first: the order of enqueueing is the order of the nodes in the captured step, and what the
         # runtime dispatches first gets a head start on the stream that ends the step (audio has 2/3 of the MOD step's work).  Autograd
         # then reaches the heaviest encoder's backward pass last; that order was measured not to matter.  +1.4 % on the step
-        # (profiles/r3_heavy_first_ab.txt; FOCAL_HEAVY_FIRST=0: configuration order).
+        # (profiles/r3_heavy_first_ab.txt).
         order = list(range(len(self.modalities)))
-        if os.environ.get("FOCAL_HEAVY_FIRST", "1") != "0":
-            tokens = [self.geometry[loc][m]["stages"][0]["H"] * self.geometry[loc][m]["stages"][0]["W"] for m in self.modalities]
-            order.sort(key=lambda i: -tokens[i])  # (stable: equal modalities keep the configuration order)
+        tokens = [self.geometry[loc][m]["stages"][0]["H"] * self.geometry[loc][m]["stages"][0]["W"] for m in self.modalities]
+        order.sort(key=lambda i: -tokens[i])  # (stable: equal modalities keep the configuration order)
         for mi in order:
             mod = self.modalities[mi]
             # stream per modality; with one backbone pass per view the two passes of a step alternate between two sets of streams so

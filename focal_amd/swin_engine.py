@@ -18,47 +18,6 @@ from . import ops
 from ._lib import ACT_GELU, ACT_NONE, EPI_GELU, EPI_NONE, EPI_RESIDUAL
 
 
-class _DeferredWeightGrads:
-    """A block's weight-gradient launches on a side stream of the encoder.
-
-    submit(): the launches wait (event) for the operands the encoder's stream has just produced and run beside that stream's next
-    block.  The encoder's stream NEVER waits for them: under hipGraph capture a stream forked from a forked stream must be joined to
-    the capture's origin stream only -- joining it back into its parent segfaults hipStreamEndCapture (ROCm 7.2;
-    tools/scratch/graph_fork_nested.py: every flag set with the inner join 'i' dumps core, the same sets without it run) -- and the
-    origin joins every side stream before the optimizer anyway (runtime.join_all).  So the operands -- saved activations and gradient
-    temporaries the encoder would otherwise free or overwrite right away -- stay alive until the encoder's next forward pass, which is
-    ordered behind that join.  (Tensor.record_stream is no alternative: inside a capture it parks blocks until the capture ends for
-    every later allocation as well, which cost 15 % in r2.)"""
-
-    def __init__(self, device, index, enabled=True):
-        from . import runtime
-        self.enabled = enabled and os.environ.get("FOCAL_NO_STREAMS") != "1"
-        self.device, self.keep = device, []
-        self.stream = runtime.side_stream(device, 16 + index) if self.enabled else None
-
-    def submit(self, dtype_code, items, calls, exclusive):
-        """items: problems of one grouped launch; calls: single launches.  Returns True when they were deferred to the side stream."""
-        if not items and not calls:
-            return False
-        if not self.enabled:
-            if items:
-                ops.linear_bwd_weight_group(dtype_code, items, exclusive=exclusive)
-            for c in calls:
-                ops.linear_bwd_weight(*c)
-            return False
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(self.device))
-        self.stream.wait_event(ready)
-        with torch.cuda.stream(self.stream):
-            if items:
-                ops.linear_bwd_weight_group(dtype_code, items, exclusive=exclusive)
-            for c in calls:
-                ops.linear_bwd_weight(*c)
-        self.keep.extend(t for it in items for t in it[:2])
-        self.keep.extend(t for c in calls for t in c[1:3])
-        return True
-
-
 class SwinModEncoder:
     def __init__(self, backbone, loc, mod, mod_index):
         self.bb = backbone
@@ -74,12 +33,6 @@ class SwinModEncoder:
     def forward(self, x_freq, view, training):
         """x_freq: [B, c, i, s] fp32 -> (feat [B, loc_out] fp32, saved state for backward)."""
         bb, geo, ar = self.bb, self.geo, self.bb.arena()
-        if getattr(self, "_dw_keep", None):
-            # operands of the previous backward pass's deferred weight gradients (see _DeferredWeightGrads): a training step has joined
-            # every side stream since (optimizer / zero_grad); any other caller is made to wait here, outside captures
-            if not torch.cuda.is_current_stream_capturing():
-                torch.cuda.current_stream(x_freq.device).wait_stream(self._dw_stream)
-        self._dw_keep = None
         ct = bb.compute_dtype
         cc = ops.code(ct)
         f32 = ops.code(torch.float32)
@@ -89,12 +42,13 @@ class SwinModEncoder:
             x_freq = x_freq.float().contiguous()
         pe = f"patch_embed.{self.loc}.{self.mod}"
         P = bb.param  # cold parameters (frozen patch embedding) are read where they live
-        fuse_ln = os.environ.get("FOCAL_NO_LN_FUSE") != "1"
-        fuse_mlp = os.environ.get("FOCAL_NO_MLP_FUSE") != "1"
-        # The LayerNorm epilogue of the residual GEMMs beyond 64 channels (row-complete wave tiles on the LDS-DMA GEMM): on at 128 channels
-        # (+1.1 % on the step, same-box), off at 256, where one row fragment per wave makes the fused fc2 take 55-61 us against 35 + 11
-        # (-1 % with both on; profiles/r3_ln_wide_ab.txt).  FOCAL_LN_FUSE_WIDE = 0 | 128 | 1 (= 128 and 256).
-        fuse_wide_env = os.environ.get("FOCAL_LN_FUSE_WIDE", "128")
+        # LayerNorm forwards ride on their producers (fuse_ln) and the 64-channel MLP branch is one kernel (fuse_mlp) wherever the library
+        # has the kernel for the dtype / shape (ops.*_supported; the exact-fp32 mode runs the plain kernels).
+        # The LayerNorm epilogue of the residual GEMMs beyond 64 channels (row-complete wave tiles on the LDS-DMA GEMM): at 128 channels
+        # (+1.1 % on the step, same-box), not at 256, where one row fragment per wave makes the fused fc2 take 55-61 us against 35 + 11
+        # (-1 % with both on; profiles/r3_ln_wide_ab.txt).
+        fuse_ln = fuse_mlp = True
+        LN_FUSE_MAX_C = 128
         pre_ln = None  # (a1, st1) of the next block when the kernel before it already produced them
         first = f"{self.pre}.0.blocks.0"
         embed_saved = None
@@ -150,7 +104,7 @@ class SwinModEncoder:
                 d_proj = ops.linear_desc(cc, M, Cc, Cc, cc, f32, ACT_NONE, EPI_RESIDUAL,
                                          out_drop=self._drop(rng, view, uid, 0, p_drop, p_path, L))
                 x_mid = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
-                fuse_wide = fuse_wide_env == "1" or fuse_wide_env == str(Cc)
+                fuse_wide = Cc <= LN_FUSE_MAX_C
                 if fuse_ln and (Cc == 64 or fuse_wide) and ops.resid_ln_supported(cc, Cc, Cc):
                     a2, st2 = ops.linear_resid_ln_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"),
                                                       x, x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
@@ -261,22 +215,16 @@ class SwinModEncoder:
         # gm = ct(g * mask): the residual-stream gradient times the dropout x drop-path mask of the branch that consumes it
         # next, written once by whichever kernel completes g (LayerNorm backward, or mask_cast for the first one); the
         # branch's dX / dW GEMMs then run as plain `ct` kernels instead of regenerating the mask per column tile.
-        group_dw = os.environ.get("FOCAL_NO_DW_GROUP") != "1"
-        # LayerNorm backward as the epilogue of the dX GEMM in front of it (64 / 128 channels, bf16): focal_linear_bwd_data_ln
-        fuse_ln_bwd = os.environ.get("FOCAL_NO_LN_BWD_FUSE") != "1" and ct == torch.bfloat16
-        ln_bwd_max_c = int(os.environ.get("FOCAL_LN_BWD_FUSE_MAXC", "128"))
+        group_dw = True
+        # LayerNorm backward as the epilogue of the dX GEMM in front of it (64 / 128 channels, bf16): focal_linear_bwd_data_ln; at 256
+        # channels neither one nor two waves per row gained anything (profiles/r3_ln_bwd_fused_ab.txt)
+        fuse_ln_bwd = ct == torch.bfloat16
+        ln_bwd_max_c = 128
         # one pass per step over this encoder's weights (both views in one batch): a gradient tile has a single writer per launch
         exclusive_dw = bool(getattr(bb, "views_share_pass", False))
-        # Nothing in the backward pass waits for a weight gradient (only the optimizer does), so a block's weight-gradient launches
-        # could leave the encoder's critical path -- the chain LayerNorm backward -> dX -> attention backward -> dX -> LayerNorm backward
-        # that the step time is made of (tools/timeline.py) -- for a side stream.  Measured (FOCAL_DW_STREAM=1, one rank, same-box
-        # A/B, profiles/r3_dw_stream_ab.txt): SW_Transformer 42 200 -> 38 300 windows/s, HAR4 33 700 -> 27 000.  The launches do overlap;
-        # what costs more is that their operands must outlive the block (see _DeferredWeightGrads), so every later temporary lands on
-        # memory the Infinity Cache does not hold.  Off by default; kept as the record of the experiment.
-        dwq = _DeferredWeightGrads(dev, self.mod_index, enabled=os.environ.get("FOCAL_DW_STREAM", "0") == "1")
-        if dwq.enabled:
-            self._dw_keep, self._dw_stream = (getattr(self, "_dw_keep", None) or []) + dwq.keep, dwq.stream  # released by the next forward pass
-            dwq.keep = self._dw_keep
+        # (A block's weight gradients on a side stream -- nothing in the backward pass waits for them -- was measured in round 3 and lost
+        # 9 % / 20 %: their operands must then outlive the block, and every later temporary lands on memory the Infinity Cache does not
+        # hold; profiles/r3_dw_stream_ab.txt.  The code was removed in round 4.)
         for k in range(state["next"], stop - 1, -1):
             if (k + 1) in merges:  # a PatchMerging sits between block k and block k+1
                 mg = merges[k + 1]
@@ -305,8 +253,6 @@ class SwinModEncoder:
             fused_mlp = s.get("d_mlp") is not None
             shapes = [(Cc, Cc), (3 * Cc, Cc)] + ([] if fused_mlp else [(Cc, 4 * Cc), (4 * Cc, Cc)])
             kinds = [ops.dw_group_kind(cc, M, n_, k_) for n_, k_ in shapes] if group_dw else [0]
-            if os.environ.get("FOCAL_NO_DW_RING_GROUP") == "1":
-                kinds = [k if k == 2 else 0 for k in kinds]
             grouped = min(kinds) >= 1
             grouped128 = min(kinds) == 2
             dw_items, dw_calls = [], []  # grouped problems / single launches (descriptor, dy, x, dw, dbias) of this block
@@ -314,8 +260,6 @@ class SwinModEncoder:
             def weight_grad(desc, dy, x, dw, db):
                 if grouped:
                     dw_items.append((dy, x, dw, db))
-                elif dwq.enabled:
-                    dw_calls.append((desc, dy, x, dw, db))
                 else:
                     ops.linear_bwd_weight(desc, dy, x, dw, db)
             # ---- MLP branch: x_out = x_mid + mask * (h W2^T + b2), h = drop(gelu(a2 W1^T + b1))
@@ -337,7 +281,7 @@ class SwinModEncoder:
                 else:
                     ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
             # (the MLP branch's gm is still an operand of a pending weight gradient unless the fused branch has consumed it)
-            gm_attn = torch.empty_like(gm) if (not fused_mlp and (grouped or dwq.enabled)) else gm
+            gm_attn = torch.empty_like(gm) if (not fused_mlp and grouped) else gm
             if ln2_done:
                 ops.linear_bwd_data_ln(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g,
                                        ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), g_masked=gm_attn, mask=s["d_proj"].out_drop)
@@ -360,18 +304,17 @@ class SwinModEncoder:
             # First block of a stage behind a PatchMerging: the merge's reduction linear takes this block's finished g as its dy.  With
             # a plain `ct` copy of g written by the LayerNorm backward below (as every other linear gets its dy), the reduction's weight
             # gradient joins this block's group launch and its dX reads 2-byte operands.
-            mg_dw = merges.get(k) if (grouped128 and not dwq.enabled and os.environ.get("FOCAL_NO_MERGE_DW_GROUP") != "1") else None
+            mg_dw = merges.get(k) if grouped128 else None
             if mg_dw is not None and ops.dw_group_kind(cc, mg_dw["d_red"].M, mg_dw["d_red"].N, mg_dw["d_red"].K) != 2:
                 mg_dw = None
-            deferred = False
-            if mg_dw is None:
-                deferred = dwq.submit(cc, dw_items, dw_calls, exclusive_dw)
+            if mg_dw is None and dw_items:
+                ops.linear_bwd_weight_group(cc, dw_items, exclusive=exclusive_dw)
             du = None
             # the next consumer of g: block k-1's MLP branch, unless a PatchMerging (handled above) or the embedding comes first
             nxt = blocks[k - 1]["d_fc2"].out_drop if (k > 0 and k not in merges) else None
             want_gm = nxt is not None or mg_dw is not None
-            if want_gm and (deferred or mg_dw is not None):
-                gm = torch.empty_like(gm)  # the old buffers are operands of weight gradients that have not run yet / run beside this stream
+            if want_gm and mg_dw is not None:
+                gm = torch.empty_like(gm)  # the old buffer is an operand of the group launch that has not run yet
             if ln1_fused:  # dX of qkv and norm1's backward in one kernel
                 ops.linear_bwd_data_ln(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g,
                                        ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"), g_masked=gm if want_gm else None, mask=nxt)
@@ -381,15 +324,11 @@ class SwinModEncoder:
                                   dx_masked=gm if want_gm else None, mask=nxt)
             if mg_dw is not None:
                 dw_items.append((gm.view(mg_dw["d_red"].M, mg_dw["d_red"].N), mg_dw["a4"], ar.g(f"{mg_dw['pm']}.reduction.weight"), None))
-                dwq.submit(cc, dw_items, dw_calls, exclusive_dw)
+                ops.linear_bwd_weight_group(cc, dw_items, exclusive=exclusive_dw)
                 mg_dw["dw_done"] = True
             del dqkv
             blocks[k] = None  # free this block's activations as we go
             dw_items = dw_calls = weight_grad = None
-        if dwq.enabled and not torch.cuda.is_current_stream_capturing():
-            # eager callers may read the gradients once autograd has joined THIS stream: fold the side stream in (a captured step's
-            # origin stream joins it before the optimizer instead -- see _DeferredWeightGrads for why not here)
-            torch.cuda.current_stream(dev).wait_stream(dwq.stream)
         state.update(g=g, gm=gm, next=stop - 1)
 
     def _backward_tail(self, saved, state):

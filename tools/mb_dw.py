@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Weight-gradient GEMM instances of the SW_Transformer step (B = 256, both views in one pass), HIP-event timed, cold operands
-(rotated through > 600 MB).  python tools/mb_dw.py   (launch-plan knobs: FOCAL_DW_WIDE_MIN, FOCAL_DW_WGS, FOCAL_DW_MIN_ROWS)"""
+(rotated through > 600 MB).  python tools/mb_dw.py"""
 import os
 import sys
 
