@@ -156,6 +156,7 @@ class Step:
 
     def draw_views(self):
         """--views random: what train.py does before every replay (train_utils/pretrain.py): two draws of the product augmenter."""
+        self.aug.begin_step()
         self.v1 = self.aug.forward("random", self.x)
         self.v2 = self.aug.forward("random", self.x)
 

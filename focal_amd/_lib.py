@@ -155,7 +155,7 @@ PROTOTYPES = {
     "focal_adamw_multi": (C.c_int, [C.POINTER(AdamWDesc), C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P),
                                     C.POINTER(P), C.POINTER(P), C.POINTER(C.c_long), P, P, P]),
     "focal_adamw_multi_advance": (C.c_int, [C.POINTER(AdamWDesc), C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P),
-                                            C.POINTER(P), C.POINTER(P), C.POINTER(C.c_long), P, P, P, P]),
+                                            C.POINTER(P), C.POINTER(P), C.POINTER(C.c_long), P, P, C.c_int, P, P]),
     "focal_cast_bf16": (C.c_int, [P, P, C.c_long, P]),
     "focal_conv_in_fwd": (C.c_int, [C.POINTER(ConvInDesc), P, P, P, P, P]),
     "focal_conv_in_bwd_weight": (C.c_int, [C.POINTER(ConvInDesc), P, P, C.c_int, P, P, P]),

@@ -24,7 +24,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     const float* __restrict__ lr_dev, uint32_t* rng_state, uint32_t* seed_state,
                                                     int advance, focal_adamw_desc d) {
   const float lr = lr_dev[0];
-  const float t = (float)(rng_state[1] + (advance ? 1u : 0u));
+  // (an explicit relaxed atomic load: `count` feeds every store below and, through `ticket_base`, the ticket this workgroup takes -- a data
+  // dependence, so the read cannot be ordered behind the ticket whatever the compiler does with the loop)
+  const uint32_t count = __atomic_load_n(rng_state + 1, __ATOMIC_RELAXED);
+  const float t = (float)(count + (advance ? 1u : 0u));
   const float bc1 = 1.0f - powf(d.beta1, t), bc2 = 1.0f - powf(d.beta2, t);
   // weight decay: decoupled (AdamW: p *= 1 - lr * wd) or, with d.l2_decay, torch.optim.Adam's L2 form (g += wd * p)
   const float step = lr / bc1, isq = rsqrtf(bc2), decay = d.l2_decay ? 1.0f : 1.0f - lr * d.weight_decay;
@@ -60,7 +63,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       // word are a serial chain of ~10 ns links: 2048 workgroups on one ticket added 12 us to DeepSense's 26 us launch.
       const uint32_t grp = blockIdx.x & 31u, ngrp = gridDim.x < 32u ? gridDim.x : 32u;
       const uint32_t gsize = (gridDim.x - grp + 31u) >> 5;
-      if (atomicAdd(rng_state + 8 + grp, 1u) == gsize - 1u) {
+      const uint32_t ticket_one = 1u + (count & 0u);  // == 1, computed from the count that was read
+      if (atomicAdd(rng_state + 8 + grp, ticket_one) == gsize - 1u) {
         rng_state[8 + grp] = 0u;
         if (atomicAdd(rng_state + 2, 1u) == ngrp - 1u) {
           rng_state[2] = 0u;
@@ -106,7 +110,9 @@ extern "C" int focal_adamw_multi(const focal_adamw_desc* d, int nseg, float* con
 
 extern "C" int focal_adamw_multi_advance(const focal_adamw_desc* d, int nseg, float* const* p, const float* const* g, float* const* m,
                                          float* const* v, void* const* shadow_bf16, const long* n, const float* lr_dev,
-                                         uint32_t* step_state, uint32_t* seed_state, void* stream) {
+                                         uint32_t* step_state, int step_state_words, uint32_t* seed_state, void* stream) {
+  FOCAL_CHECK_ARG(step_state_words >= FOCAL_STEP_STATE_WORDS, "adamw_multi_advance: step_state holds %d words, the tickets need FOCAL_STEP_STATE_WORDS = %d "
+                  "(the 4-word state of focal_rng_advance / focal_adamw_multi is not enough)", step_state_words, FOCAL_STEP_STATE_WORDS);
   return adamw_launch(d, nseg, p, g, m, v, shadow_bf16, n, lr_dev, step_state, seed_state, true, (hipStream_t)stream);
 }
 

@@ -132,7 +132,7 @@ def adamw_multi(segments, lr_dev, rng_state, beta1=0.9, beta2=0.999, eps=1e-8, w
     d = AdamWDesc(beta1, beta2, eps, weight_decay, int(l2_decay))
     if advance:
         check(_lib.load().focal_adamw_multi_advance(C.byref(d), n, arr(0), arr(1), arr(2), arr(3), arr(4) if has_shadow else None,
-                                                    lens, _p(lr_dev), _p(rng_state), _p(seed_state), _stream()))
+                                                    lens, _p(lr_dev), _p(rng_state), rng_state.numel(), _p(seed_state), _stream()))
         return
     check(_lib.load().focal_adamw_multi(C.byref(d), n, arr(0), arr(1), arr(2), arr(3), arr(4) if has_shadow else None,
                                         lens, _p(lr_dev), _p(rng_state), _stream()))

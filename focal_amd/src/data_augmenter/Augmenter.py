@@ -207,6 +207,14 @@ class Augmenter:
                 items[loc][mod] = dict(x=src, out=self._view_slot(loc, mod, x), **k)
         return _transform_all(items)
 
+    def begin_step(self):
+        """Called by the training loop before the first of a step's two draws (static_views): the next draw of every tensor gets the FIRST
+        half again.  Without it an odd number of draws on a training-shaped batch -- an exception between the two draws, a caller that
+        draws one view, a resume in mid-pair -- slipped the parity for good: view 1 in the second half, the captured step never matched
+        again and the job silently ran eagerly."""
+        for ent in self.__dict__.get("_static_pairs", {}).values():
+            ent[1] = 0
+
     def _view_slot(self, loc, mod, x):
         """Where this view's spectrum goes: the pretraining loop draws two views of the same windows back to back
         (train_utils/pretrain.py), so the first call gets the first half of a fresh [2B, 2C, I, n] tensor and the second call (same

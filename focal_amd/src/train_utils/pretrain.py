@@ -79,6 +79,7 @@ def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, 
             # (the batch crosses to the device once; both draws then see the same device tensors, which is also what pairs the two
             # views of a modality into the halves of one tensor, data_augmenter/Augmenter.py::_view_slot)
             time_loc_inputs, _ = augmenter.move_to_target_device(time_loc_inputs, None)
+            augmenter.begin_step()  # view 1 -> first half, view 2 -> second half of the static two-view buffers, whatever came before
             view1 = augmenter.forward("random", time_loc_inputs)
             view2 = augmenter.forward("random", time_loc_inputs)
             if pending is not None:

@@ -374,7 +374,10 @@ int focal_small_linear_bwd(int B, int N, int K, const float* dy, const float* x,
  * FOCALLoss.forward (models/loss.py:139-218): 2 InfoNCE families on the shared / private halves, orthogonality,
  * temporal ranking.  feats / dfeats are HOST arrays of 2*n_mod device pointers, view-major
  * ([view0 mod0, view0 mod1, .., view1 mod0, ..]), each fp32 [B, dim]; B = b*seq whole subsequences.
- * terms (device fp32[5]) = {shared, private, orth, rank, weighted total}; dfeats receive d total / d feat. */
+ * terms (device fp32[5]) = {shared, private, orth, rank, weighted total}; dfeats receive d total / d feat.
+ * Limit: n_mod <= 4 (the problem tables of the head's grouped launches travel as kernel arguments: n_mod^2 <= 16 InfoNCE problems and
+ * n_mod (n_mod + 1) <= 20 orthogonality problems fit the 4 KB argument segment; a fifth modality is rejected with FOCAL_EINVAL
+ * "too many modality pairs" -- the reference's datasets have 2 (MOD) and the authored HAR4 config 4). */
 typedef struct {
   int n_mod, B, dim, seq;
   float temperature, margin;
@@ -413,12 +416,13 @@ int focal_adamw_multi(const focal_adamw_desc* d, int nseg, float* const* p, cons
 /* The same update with the step's bookkeeping folded in: the step count used is step_state[1] + 1, and the workgroup that finishes last
  * advances step_state (as focal_rng_advance would have before the call) and, when non-NULL, seed_state (the dropout seed words of the
  * next forward pass) -- two one-thread launches less on the serial tail of every step.  step_state holds FOCAL_STEP_STATE_WORDS
- * 32-bit words: {seed, step count, ticket, -, -, -, -, -, 32 group tickets}; the tickets are zero between calls.  seed_state: the 4
- * words of focal_rng_advance. */
+ * 32-bit words: {seed, step count, ticket, -, -, -, -, -, 32 group tickets}; the tickets are zero between calls; step_state_words = the
+ * length of the caller's buffer, checked against FOCAL_STEP_STATE_WORDS (the 4-word state of focal_rng_advance has the same pointer
+ * type and would be written out of bounds).  seed_state: the 4 words of focal_rng_advance. */
 #define FOCAL_STEP_STATE_WORDS 40
 int focal_adamw_multi_advance(const focal_adamw_desc* d, int nseg, float* const* p, const float* const* g, float* const* m,
                               float* const* v, void* const* shadow_bf16, const long* n, const float* lr_dev,
-                              uint32_t* step_state, uint32_t* seed_state, void* stream);
+                              uint32_t* step_state, int step_state_words, uint32_t* seed_state, void* stream);
 /* fp32 -> bf16 cast of a weight segment (refreshing the shadow after load_state_dict) */
 int focal_cast_bf16(const float* src, void* dst, long n, void* stream);
 

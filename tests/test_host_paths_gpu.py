@@ -155,3 +155,11 @@ def test_static_views_pair_host_sourced_batches():
         now = {m: v1[loc][m]._base.data_ptr() for m in cfg["modality_names"]}
         assert bases is None or bases == now
         bases = now
+    # a lone draw (an exception between the two draws, a caller that wants one view) must not slip the pairing for good:
+    # begin_step() -- what the training loop calls before a step's first draw -- puts view 1 back into the first half
+    aug.forward("random", host)
+    aug.begin_step()
+    v1, v2 = aug.forward("random", host), aug.forward("random", host)
+    for m in cfg["modality_names"]:
+        a, b = v1[loc][m], v2[loc][m]
+        assert a.data_ptr() == bases[m] and b.data_ptr() == bases[m] + a.numel() * 4, m
