@@ -306,6 +306,33 @@ extern "C" int focal_window_attn_fwd(const focal_attn_desc* d, const void* qkv, 
   return FOCAL_OK;
 }
 
+// ---- q / k / v projected inside the attention kernels (attn_mfma.hip: qkv_project)
+extern "C" int focal_window_attn_qkv_supported(int dtype, int C, int heads, int window_tokens) {
+  return dtype == FOCAL_BF16 && C == 64 && heads == 4 && window_tokens >= 1 && window_tokens <= ATT_NMAX;
+}
+
+extern "C" int focal_window_attn_qkv_fwd(const focal_attn_desc* d, const void* a1, const void* wqkv, const float* bqkv, const float* bias_table,
+                                         void* out, void* stream) {
+  AttnGeom g;
+  if (int rc = attn_geometry(d, &g)) return rc;
+  FOCAL_CHECK_ARG(a1 && wqkv && bqkv && bias_table && out, "window_attn_qkv_fwd: null tensor");
+  FOCAL_CHECK_ARG(focal_window_attn_qkv_supported(d->dtype, g.C, g.heads, g.N), "window_attn_qkv_fwd: built for bf16, C = 64, 4 heads (got dtype %d, C = %d, heads = %d)",
+                  d->dtype, g.C, g.heads);
+  return focal_attn_mfma_fwd(g, (const bf16_t*)a1, bias_table, (bf16_t*)out, d->rng, d->stream, d->p_attn, (hipStream_t)stream, (const bf16_t*)wqkv, bqkv);
+}
+
+extern "C" int focal_window_attn_qkv_bwd(const focal_attn_desc* d, const void* a1, const void* wqkv, const float* bqkv, const float* bias_table,
+                                         const void* dout, void* dqkv, float* dbias_table, void* stream) {
+  AttnGeom g;
+  if (int rc = attn_geometry(d, &g)) return rc;
+  FOCAL_CHECK_ARG(a1 && wqkv && bqkv && bias_table && dout && dqkv && dbias_table, "window_attn_qkv_bwd: null tensor");
+  FOCAL_CHECK_ARG(focal_window_attn_qkv_supported(d->dtype, g.C, g.heads, g.N), "window_attn_qkv_bwd: built for bf16, C = 64, 4 heads (got dtype %d, C = %d, heads = %d)",
+                  d->dtype, g.C, g.heads);
+  FOCAL_CHECK_ARG((2 * g.wh - 1) * (2 * g.ww - 1) * g.heads <= 256, "window_attn_qkv_bwd: bias table too large");
+  return focal_attn_mfma_bwd(g, (const bf16_t*)a1, bias_table, (const bf16_t*)dout, (bf16_t*)dqkv, dbias_table, d->rng, d->stream, d->p_attn,
+                             (hipStream_t)stream, (const bf16_t*)wqkv, bqkv);
+}
+
 extern "C" int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, const float* bias_table, const void* dout,
                                      void* dqkv, float* dbias_table, void* stream) {
   AttnGeom g;

@@ -38,7 +38,9 @@ __device__ __forceinline__ int att_token(const AttnGeom& g, int win, int i, int*
 }
 
 
+// wqkv / bqkv non-NULL: `qkv` is the LayerNorm output a1 [M][C] and the kernels project q / k / v themselves (C == 64, 4 heads of 16)
 int focal_attn_mfma_fwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, bf16_t* out, const uint32_t* rng, uint32_t stream_id,
-                        float p_attn, hipStream_t st);
+                        float p_attn, hipStream_t st, const bf16_t* wqkv = nullptr, const float* bqkv = nullptr);
 int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, const bf16_t* dout, bf16_t* dqkv, float* dbias_table,
-                        const uint32_t* rng, uint32_t stream_id, float p_attn, hipStream_t st);
+                        const uint32_t* rng, uint32_t stream_id, float p_attn, hipStream_t st, const bf16_t* wqkv = nullptr,
+                        const float* bqkv = nullptr);

@@ -139,6 +139,51 @@ __device__ __forceinline__ void tile_softmax(const AttnGeom& g, const TileIdx& t
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- q / k / v on the fly (round 4)
+// At 64 channels (Swin stage 0: head_dim 16, 4 heads) the attention kernels can make their own q, k, v: a wave's head is fixed
+// (item = workgroup slot x waves + wave, waves % heads == 0), so the 48 rows of Wqkv it needs are six loop-invariant A fragments, and an
+// item's operands are the window's 9 LayerNorm-output rows -- two 16-byte loads per lane instead of three tile fetches.
+//     T^T[d][slot] = W_T[h 16 + d][:] . a1[token(slot)][:] + b_T[h 16 + d]          (T = q, k, v; 2 MFMAs of 16 x 16 x 32 each)
+// lands as 4 consecutive d of one token per lane: exactly the [token][d] tile the item loop reads.  The [M, 3C] qkv tensor then never
+// exists in HBM: the forward pass saves a1 (the weight gradient needs it anyway) and the backward pass recomputes -- 1 KB of traffic per
+// token and step, and one GEMM launch per block, less.  Padded slots are written as zeros, as the tile fetch did.
+struct QkvFrags {
+  bf16x8 w[3][2];   // A fragments: row = this lane's d (l & 15) of q / k / v for the wave's head, k = channels 32 kk + 8 (l >> 4) ..
+  f32x4 bias[3];    // bias of d = 4 (l >> 4) + r
+};
+__device__ __forceinline__ QkvFrags qkv_frags(const bf16_t* wqkv, const float* bqkv, int C, int h, int lane) {
+  QkvFrags f;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) f.w[t][kk] = *reinterpret_cast<const bf16x8*>(wqkv + (long)(t * C + h * 16 + (lane & 15)) * C + 32 * kk + 8 * (lane >> 4));
+    f.bias[t] = *reinterpret_cast<const f32x4*>(bqkv + t * C + h * 16 + 4 * (lane >> 4));
+  }
+  return f;
+}
+struct RowRegs { bf16x8 v[2]; };  // this lane's slot: channels 8 (l >> 4) .. + 7 and 32 + 8 (l >> 4) .. of its token's a1 row
+__device__ __forceinline__ void row_fetch(RowRegs& r, const bf16_t* a1, int C, int tok_own, bool valid, int lane) {
+  const bf16_t z = (bf16_t)0.f;
+  r.v[0] = r.v[1] = bf16x8{z, z, z, z, z, z, z, z};
+  if (valid) {
+    r.v[0] = *reinterpret_cast<const bf16x8*>(a1 + (long)tok_own * C + 8 * (lane >> 4));
+    r.v[1] = *reinterpret_cast<const bf16x8*>(a1 + (long)tok_own * C + 32 + 8 * (lane >> 4));
+  }
+}
+template <int P> __device__ __forceinline__ void qkv_project(bf16_t* Qt, bf16_t* Kt, bf16_t* Vt, const QkvFrags& f, const RowRegs& x, bool valid, int lane) {
+  bf16_t* dst[3] = {Qt, Kt, Vt};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    // (products first, bias last: the order of the GEMM epilogue this replaces, so that q / k / v round to the same bf16 values)
+    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t][0], x.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t][1], x.v[1], acc, 0, 0, 0);
+    acc += f.bias[t];
+    float o[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
+    *reinterpret_cast<bf16x4*>(dst[t] + (lane & 15) * P + 4 * (lane >> 4)) = pack4(o);
+  }
+}
+
 // token index of this lane's window slot; slot coordinates (sy, sx) are loop-invariant, only the window decomposes
 __device__ __forceinline__ int slot_token(const AttnGeom& g, int win, int sy, int sx, int* region) {
   const int b = (int)att_div((uint32_t)win, g.m_nW, (uint32_t)g.nW), wl = win - b * g.nW;
@@ -155,10 +200,12 @@ __device__ __forceinline__ int slot_token(const AttnGeom& g, int win, int sy, in
   return (b * g.H + y) * g.W + x;
 }
 
-template <int HD>
+template <int HD, bool FUSE>
 __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_table,
                                                                    bf16_t* __restrict__ out, AttnGeom g, int total_items, int iters,
-                                                                   const uint32_t* rng, uint32_t stream, float p_attn) {
+                                                                   const uint32_t* rng, uint32_t stream, float p_attn,
+                                                                   const bf16_t* __restrict__ wqkv, const float* __restrict__ bqkv) {
+  // FUSE: `qkv` is the LayerNorm output a1 [M][C] and q / k / v of an item are projected here (HD == 16, C == 64: see qkv_project)
   constexpr int P = HD + 4, TILE = 16 * P;
   __shared__ __attribute__((aligned(16))) bf16_t tiles[4][3][TILE];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: item, window and head arithmetic then runs on the SALU
@@ -180,28 +227,43 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
     h = live ? item - win * g.heads : 0;
   };
   TileRegs<HD> rq, rk, rv;
+  RowRegs rx;
+  QkvFrags qf;
   bool live_n; int win_n, h_n, reg_n = 0, tok_n = 0;
   item_of(0, live_n, win_n, h_n);
   tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
-  tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
-  tile_fetch<HD>(rk, qkv + C + h_n * HD, 3 * C, tok_n, g.N, lane);
-  tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
+  if constexpr (FUSE) {
+    qf = qkv_frags(wqkv, bqkv, C, wave % g.heads, lane);  // item = (..) * 4 + wave and heads == 4: the wave's head never changes
+    row_fetch(rx, qkv, C, tok_n, slot < g.N, lane);
+  } else {
+    tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
+    tile_fetch<HD>(rk, qkv + C + h_n * HD, 3 * C, tok_n, g.N, lane);
+    tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
+  }
   for (int it = 0; it < iters; ++it) {
     const bool live = live_n;
     const int win = win_n, h = h_n, reg_own = reg_n, tok_own = tok_n;
     const bool edge = g.shifted;  // (restricting this to the windows that really mix mask regions costs more in index arithmetic than it saves)
     wave_lds_fence();  // previous iteration's fragment reads are issued before these tile writes
-    tile_commit<HD>(Qt, rq, lane);
-    tile_commit<HD>(Kt, rk, lane);
-    tile_commit<HD>(Vt, rv, lane);
+    if constexpr (FUSE) {
+      qkv_project<P>(Qt, Kt, Vt, qf, rx, slot < g.N, lane);
+    } else {
+      tile_commit<HD>(Qt, rq, lane);
+      tile_commit<HD>(Kt, rk, lane);
+      tile_commit<HD>(Vt, rv, lane);
+    }
     wave_lds_fence();
     if (it + 1 < iters) {
       item_of(it + 1, live_n, win_n, h_n);
       reg_n = 0;
       tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
-      tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
-      tile_fetch<HD>(rk, qkv + C + h_n * HD, 3 * C, tok_n, g.N, lane);
-      tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
+      if constexpr (FUSE) {
+        row_fetch(rx, qkv, C, tok_n, slot < g.N, lane);
+      } else {
+        tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
+        tile_fetch<HD>(rk, qkv + C + h_n * HD, 3 * C, tok_n, g.N, lane);
+        tile_fetch<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, tok_n, g.N, lane);
+      }
     }
     f32x4 st = {0.f, 0.f, 0.f, 0.f};  // S^T: rows j (keys), col i (query)
 #pragma unroll
@@ -258,11 +320,13 @@ __device__ __forceinline__ void tile_fetch_rows(TileRegs<HD>& r, const bf16_t* b
 // is what bounds this kernel (4 waves per SIMD, ~400 VALU instructions per (window, head) item: profiles/r3_attn_bwd_depth_ab.txt).
 // dS^T is directly the B operand of dQ; dS and Pd in the other orientation (B operands of dK, dV) come from two bf16 tiles written
 // [i][j] into wave-private LDS and read back with the hardware transpose read.
-template <int HD, int NW>
+template <int HD, int NW, bool FUSE>
 __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_table,
                                                                    const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                                    float* __restrict__ dbias_table, AttnGeom g, int total_items,
-                                                                   int iters, const uint32_t* rng, uint32_t stream, float p_attn) {
+                                                                   int iters, const uint32_t* rng, uint32_t stream, float p_attn,
+                                                                   const bf16_t* __restrict__ wqkv, const float* __restrict__ bqkv) {
+  // FUSE: `qkv` is the LayerNorm output a1 [M][C]; q / k / v are recomputed per item (qkv_project), nothing of them was saved
   constexpr int P = HD + 4, TILE = 16 * P;
   __shared__ __attribute__((aligned(16))) bf16_t tiles[NW][4][TILE];
   __shared__ __attribute__((aligned(16))) bf16_t trt[NW][2][16 * 20];  // dS^T / Pd^T tiles, written [i][j], read back transposed
@@ -303,14 +367,21 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
     h = live ? item - win * g.heads : 0;
   };
   TileRegs<HD> rq, rk, rv, rg;
+  RowRegs rx;
+  QkvFrags qf;
   bool live_n; int win_n, h_n, reg_n = 0, tok_n = 0;
   item_of(0, live_n, win_n, h_n);
   tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
   {
     const TileRows<HD> rows = tile_rows<HD>(tok_n, lane);
-    tile_fetch_rows<HD>(rq, qkv + h_n * HD, 3 * C, rows, g.N, lane);
-    tile_fetch_rows<HD>(rk, qkv + C + h_n * HD, 3 * C, rows, g.N, lane);
-    tile_fetch_rows<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, rows, g.N, lane);
+    if constexpr (FUSE) {
+      qf = qkv_frags(wqkv, bqkv, C, wave % g.heads, lane);  // NW % heads == 0: the wave's head never changes
+      row_fetch(rx, qkv, C, tok_n, slot < g.N, lane);
+    } else {
+      tile_fetch_rows<HD>(rq, qkv + h_n * HD, 3 * C, rows, g.N, lane);
+      tile_fetch_rows<HD>(rk, qkv + C + h_n * HD, 3 * C, rows, g.N, lane);
+      tile_fetch_rows<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, rows, g.N, lane);
+    }
     tile_fetch_rows<HD>(rg, dout + h_n * HD, C, rows, g.N, lane);
   }
   for (int it = 0; it < iters; ++it) {
@@ -321,9 +392,13 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       h_acc = h;
     }
     wave_lds_fence();
-    tile_commit<HD>(Qt, rq, lane);
-    tile_commit<HD>(Kt, rk, lane);
-    tile_commit<HD>(Vt, rv, lane);
+    if constexpr (FUSE) {
+      qkv_project<P>(Qt, Kt, Vt, qf, rx, slot < g.N, lane);
+    } else {
+      tile_commit<HD>(Qt, rq, lane);
+      tile_commit<HD>(Kt, rk, lane);
+      tile_commit<HD>(Vt, rv, lane);
+    }
     tile_commit<HD>(Gt, rg, lane);
     wave_lds_fence();
     if (it + 1 < iters) {  // the next item's tiles fly while this one is multiplied
@@ -331,9 +406,13 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       reg_n = 0;
       tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
       const TileRows<HD> rows = tile_rows<HD>(tok_n, lane);
-      tile_fetch_rows<HD>(rq, qkv + h_n * HD, 3 * C, rows, g.N, lane);
-      tile_fetch_rows<HD>(rk, qkv + C + h_n * HD, 3 * C, rows, g.N, lane);
-      tile_fetch_rows<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, rows, g.N, lane);
+      if constexpr (FUSE) {
+        row_fetch(rx, qkv, C, tok_n, slot < g.N, lane);
+      } else {
+        tile_fetch_rows<HD>(rq, qkv + h_n * HD, 3 * C, rows, g.N, lane);
+        tile_fetch_rows<HD>(rk, qkv + C + h_n * HD, 3 * C, rows, g.N, lane);
+        tile_fetch_rows<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, rows, g.N, lane);
+      }
       tile_fetch_rows<HD>(rg, dout + h_n * HD, C, rows, g.N, lane);
     }
     f32x4 st = {0.f, 0.f, 0.f, 0.f}, dt = st;
@@ -418,20 +497,21 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
 }
 
 int focal_attn_mfma_fwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, bf16_t* out, const uint32_t* rng, uint32_t stream_id,
-                        float p_attn, hipStream_t st) {
+                        float p_attn, hipStream_t st, const bf16_t* wqkv, const float* bqkv) {
   const int items = g.B * g.nW * g.heads;
   int blocks = ceil_div(items, 4);
   if (blocks > 4096) blocks = 4096;
   const int iters = ceil_div(items, blocks * 4);
-#define LAUNCH(HD) FOCAL_LAUNCH((window_attn_fwd_mfma_kernel<HD>), dim3(blocks), dim3(256), 0, st, qkv, bias_table, out, g, items, iters, rng, stream_id, p_attn)
-  if (g.hd == 16) LAUNCH(16); else if (g.hd == 32) LAUNCH(32); else LAUNCH(64);
+#define LAUNCH(HD, FUSE) FOCAL_LAUNCH((window_attn_fwd_mfma_kernel<HD, FUSE>), dim3(blocks), dim3(256), 0, st, qkv, bias_table, out, g, items, iters, rng, stream_id, p_attn, wqkv, bqkv)
+  if (wqkv != nullptr) LAUNCH(16, true);  // (q / k / v projected in the kernel: C == 64, heads == 4, checked by the caller)
+  else if (g.hd == 16) LAUNCH(16, false); else if (g.hd == 32) LAUNCH(32, false); else LAUNCH(64, false);
 #undef LAUNCH
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
 
 int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, const bf16_t* dout, bf16_t* dqkv, float* dbias_table,
-                        const uint32_t* rng, uint32_t stream_id, float p_attn, hipStream_t st) {
+                        const uint32_t* rng, uint32_t stream_id, float p_attn, hipStream_t st, const bf16_t* wqkv, const float* bqkv) {
   const int items = g.B * g.nW * g.heads;
   // Every workgroup ends with one atomic per bias-table entry, and atomics onto one address are a serial chain
   // (~10 ns a link): the grid is kept small (workgroups loop over items) so the chain, not the math, does not set the
@@ -442,10 +522,9 @@ int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
   int blocks = ceil_div(items, nw);
   if (blocks > maxb) blocks = maxb;
   const int iters = ceil_div(items, blocks * nw);
-#define LAUNCH2(HD, NW) FOCAL_LAUNCH((window_attn_bwd_mfma_kernel<HD, NW>), dim3(blocks), dim3(NW * 64), 0, st, qkv, bias_table, dout, dqkv, dbias_table, g, items, iters, rng, stream_id, p_attn)
-#define LAUNCH(HD) LAUNCH2(HD, 16)
-  if (g.hd == 16) LAUNCH(16); else if (g.hd == 32) LAUNCH(32); else LAUNCH(64);
-#undef LAUNCH2
+#define LAUNCH(HD, FUSE) FOCAL_LAUNCH((window_attn_bwd_mfma_kernel<HD, 16, FUSE>), dim3(blocks), dim3(16 * 64), 0, st, qkv, bias_table, dout, dqkv, dbias_table, g, items, iters, rng, stream_id, p_attn, wqkv, bqkv)
+  if (wqkv != nullptr) LAUNCH(16, true);
+  else if (g.hd == 16) LAUNCH(16, false); else if (g.hd == 32) LAUNCH(32, false); else LAUNCH(64, false);
 #undef LAUNCH
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;

@@ -453,6 +453,22 @@ def window_attn_bwd(d, qkv, bias_table, dout, dqkv, dbias_table):
                                             _stream()))
 
 
+def attn_qkv_supported(dtype_code, Cc, heads, window_tokens):
+    return bool(_lib.load().focal_window_attn_qkv_supported(dtype_code, Cc, heads, window_tokens))
+
+
+def window_attn_qkv_fwd(d, a1, wqkv, bqkv, bias_table, out):
+    """W-MSA with the qkv Linear folded in (64-channel blocks): a1 [M, C] -> out [M, C]; no [M, 3C] tensor."""
+    _need_cuda(a1, wqkv, bqkv, bias_table, out)
+    check(_lib.load().focal_window_attn_qkv_fwd(C.byref(d), _p(a1), _p(wqkv), _p(bqkv), _p(bias_table), _p(out), _stream()))
+
+
+def window_attn_qkv_bwd(d, a1, wqkv, bqkv, bias_table, dout, dqkv, dbias_table):
+    _need_cuda(a1, wqkv, bqkv, bias_table, dout, dqkv, dbias_table)
+    check(_lib.load().focal_window_attn_qkv_bwd(C.byref(d), _p(a1), _p(wqkv), _p(bqkv), _p(bias_table), _p(dout), _p(dqkv), _p(dbias_table),
+                                                _stream()))
+
+
 # ------------------------------------------------------------------------------------------------ rows 11-13
 _LOSS_WS = {}
 

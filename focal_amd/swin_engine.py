@@ -95,12 +95,19 @@ class SwinModEncoder:
                 else:
                     a1, st1 = ops.layernorm_fwd(x, ar.master(f"{pb}.norm1.weight"), ar.master(f"{pb}.norm1.bias"), ct)
                 d_qkv = ops.linear_desc(cc, M, 3 * Cc, Cc, cc, cc)
-                qkv = torch.empty(M, 3 * Cc, dtype=ct, device=x.device)
-                ops.linear_fwd(d_qkv, a1, ar.operand(f"{pb}.attn.qkv.weight"), ar.master(f"{pb}.attn.qkv.bias"), None, qkv)
                 d_att = ops.attn_desc(cc, B, H, W, Cc, geo["heads"], wh, ww, sh, sw, p_attn, rng,
                                       ((view * 8 + self.mod_index) * 64 + uid) * 8 + 3)
                 o = torch.empty(M, Cc, dtype=ct, device=x.device)
-                ops.window_attn_fwd(d_att, qkv, ar.master(f"{pb}.attn.relative_position_bias_table"), o)
+                if ops.attn_qkv_supported(cc, Cc, geo["heads"], wh * ww):
+                    # 64-channel blocks: the attention kernel projects q / k / v of a (window, head) item itself -- no qkv GEMM launch,
+                    # no [M, 3C] tensor written, read back or saved (the backward kernel recomputes it from a1)
+                    qkv = None
+                    ops.window_attn_qkv_fwd(d_att, a1, ar.operand(f"{pb}.attn.qkv.weight"), ar.master(f"{pb}.attn.qkv.bias"),
+                                            ar.master(f"{pb}.attn.relative_position_bias_table"), o)
+                else:
+                    qkv = torch.empty(M, 3 * Cc, dtype=ct, device=x.device)
+                    ops.linear_fwd(d_qkv, a1, ar.operand(f"{pb}.attn.qkv.weight"), ar.master(f"{pb}.attn.qkv.bias"), None, qkv)
+                    ops.window_attn_fwd(d_att, qkv, ar.master(f"{pb}.attn.relative_position_bias_table"), o)
                 d_proj = ops.linear_desc(cc, M, Cc, Cc, cc, f32, ACT_NONE, EPI_RESIDUAL,
                                          out_drop=self._drop(rng, view, uid, 0, p_drop, p_path, L))
                 x_mid = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
@@ -293,9 +300,14 @@ class SwinModEncoder:
             weight_grad(d_proj_b, gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
             do = dc  # reuse the [M, C] CT buffer
             ops.linear_bwd_data(d_proj_b, gm_attn, ar.operand(f"{pb}.attn.proj.weight"), None, do)
-            dqkv = torch.empty_like(s["qkv"])
-            ops.window_attn_bwd(s["d_att"], s["qkv"], ar.master(f"{pb}.attn.relative_position_bias_table"), do, dqkv,
-                                ar.g(f"{pb}.attn.relative_position_bias_table"))
+            dqkv = torch.empty(M, 3 * Cc, dtype=ct, device=dev)
+            if s["qkv"] is None:  # q / k / v recomputed from a1 inside the kernel (see forward)
+                ops.window_attn_qkv_bwd(s["d_att"], s["a1"], ar.operand(f"{pb}.attn.qkv.weight"), ar.master(f"{pb}.attn.qkv.bias"),
+                                        ar.master(f"{pb}.attn.relative_position_bias_table"), do, dqkv,
+                                        ar.g(f"{pb}.attn.relative_position_bias_table"))
+            else:
+                ops.window_attn_bwd(s["d_att"], s["qkv"], ar.master(f"{pb}.attn.relative_position_bias_table"), do, dqkv,
+                                    ar.g(f"{pb}.attn.relative_position_bias_table"))
             weight_grad(s["d_qkv"], dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias"))
             da = do
             ln1_fused = fuse_ln_bwd and Cc <= ln_bwd_max_c and ops.bwd_data_ln_supported(cc, 3 * Cc, Cc)

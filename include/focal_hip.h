@@ -262,6 +262,17 @@ typedef struct {
 int focal_window_attn_fwd(const focal_attn_desc* d, const void* qkv, const float* bias_table, void* out, void* stream);
 int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, const float* bias_table, const void* dout,
                           void* dqkv, float* dbias_table, void* stream);
+/* The same two operators with the qkv Linear (models/SwinModules.py:113, 128-130) folded in, for 64-channel blocks (bf16, 4 heads of
+ * 16: Swin stage 0; focal_window_attn_qkv_supported): a1 [B*H*W, C] is the output of norm1, wqkv [3C, C] / bqkv [3C] the qkv layer.  A
+ * wave's head is fixed, so its 48 rows of wqkv are loop-invariant MFMA operands and q / k / v of a (window, head) item are projected
+ * from the window's a1 rows inside the kernel: the [B*H*W, 3C] qkv tensor never reaches HBM -- the forward pass saves a1 only, the
+ * backward pass recomputes (and still emits dqkv for the layer's weight / input gradients).  Results equal focal_linear_fwd +
+ * focal_window_attn_fwd / _bwd up to the accumulation order of the projection. */
+int focal_window_attn_qkv_supported(int dtype, int C, int heads, int window_tokens);
+int focal_window_attn_qkv_fwd(const focal_attn_desc* d, const void* a1, const void* wqkv, const float* bqkv, const float* bias_table,
+                              void* out, void* stream);
+int focal_window_attn_qkv_bwd(const focal_attn_desc* d, const void* a1, const void* wqkv, const float* bqkv, const float* bias_table,
+                              const void* dout, void* dqkv, float* dbias_table, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 5: DeepSense convs
  * ConvBlock (models/ConvModules.py:115-216) on CHANNEL-LAST tokens: activation [B*I*S, C] (row = (b, interval, s)).

@@ -441,6 +441,48 @@ def test_window_attention(ops, ct, H, W, C, sh, sw):
     assert rel_err(dqkv.float(), q32.grad) < (3e-5 if ct == torch.float32 else 8e-3)
     assert rel_err(dt, t32.grad) < (1e-4 if ct == torch.float32 else 5e-3)
 
+@pytest.mark.parametrize("H,W,sh,sw,p_attn", [(12, 48, 0, 0, 0.0), (12, 48, 1, 1, 0.0), (12, 24, 1, 1, 0.2), (12, 24, 0, 0, 0.2)])
+def test_window_attention_with_qkv_projection_folded_in(ops, H, W, sh, sw, p_attn):
+    """focal_window_attn_qkv_fwd / _bwd (64-channel blocks, bf16: the attention kernels project q / k / v of an item from the window's
+    norm1 rows; reference models/SwinModules.py:113-152 + :294-334) against (1) the fp32 torch restatement `_ref_window_attn` applied
+    to the fp32 qkv Linear (dropout off) and (2) the unfused HIP path -- focal_linear_fwd -> focal_window_attn_fwd / _bwd -- with the
+    same seed words and stream id, i.e. the same attention-dropout mask (dropout on and off)."""
+    B, C, heads, wh, ww = 5, 64, 4, 3, 3
+    M = B * H * W
+    ct = torch.bfloat16
+    cc = ops.code(ct)
+    assert ops.attn_qkv_supported(cc, C, heads, wh * ww) and not ops.attn_qkv_supported(cc, 128, heads, wh * ww)
+    a1 = rnd(M, C, seed=130, dtype=ct)
+    wqkv = rnd(3 * C, C, scale=C ** -0.5, seed=131, dtype=ct)
+    bqkv = rnd(3 * C, scale=0.2, seed=132)
+    table = rnd(25, heads, scale=0.5, seed=133)
+    state = ops.new_rng_state(11, DEV) if p_attn > 0 else None
+    d = ops.attn_desc(cc, B, H, W, C, heads, wh, ww, sh, sw, p_attn, state, 91)
+    out = torch.empty(M, C, dtype=ct, device=DEV)
+    ops.window_attn_qkv_fwd(d, a1, wqkv, bqkv, table, out)
+    # unfused HIP path on the same operands
+    d_qkv = ops.linear_desc(cc, M, 3 * C, C, cc, cc)
+    qkv = torch.empty(M, 3 * C, dtype=ct, device=DEV)
+    ops.linear_fwd(d_qkv, a1, wqkv, bqkv, None, qkv)
+    out_u = torch.empty(M, C, dtype=ct, device=DEV)
+    ops.window_attn_fwd(d, qkv, table, out_u)
+    assert rel_err(out.float(), out_u.float()) < 4e-3, rel_err(out.float(), out_u.float())   # (q / k / v rounded to bf16 from two accumulation orders)
+    do = rnd(M, C, seed=134, dtype=ct)
+    dqkv, dt = torch.empty(M, 3 * C, dtype=ct, device=DEV), torch.zeros_like(table)
+    ops.window_attn_qkv_bwd(d, a1, wqkv, bqkv, table, do, dqkv, dt)
+    dqkv_u, dt_u = torch.empty_like(dqkv), torch.zeros_like(table)
+    ops.window_attn_bwd(d, qkv, table, do, dqkv_u, dt_u)
+    assert rel_err(dqkv.float(), dqkv_u.float()) < 6e-3 and rel_err(dt, dt_u) < 4e-3
+    if p_attn == 0.0:  # ... and the reference formula in fp32
+        a32, w32, b32 = a1.float().requires_grad_(True), wqkv.float(), bqkv.clone()
+        t32 = table.clone().requires_grad_(True)
+        q32 = a32 @ w32.t() + b32
+        q32.retain_grad()
+        ref = _ref_window_attn(q32, t32, B, H, W, C, heads, wh, ww, sh, sw)
+        assert rel_err(out.float(), ref) < 6e-3
+        ref.backward(do.float())
+        assert rel_err(dqkv.float(), q32.grad) < 1e-2 and rel_err(dt, t32.grad) < 6e-3
+
 
 # ---------------------------------------------------------------------------------------------- embed / fft
 @pytest.mark.parametrize("S,pw,Hp,Wp,cin", [(1600, 40, 12, 48, 2), (20, 1, 12, 24, 2)])
