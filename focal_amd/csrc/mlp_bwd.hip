@@ -36,7 +36,10 @@ constexpr int L_W1T = L_DU + 65536;      // W1^T [64 c][256 hid] bf16: 512-B row
 constexpr int MB_LD = 132;               // mask words [8 columns][128 tok (+ 4 pad)]: the pad spreads the 8 columns over the banks
 constexpr int L_MB = L_W1T + 32768;
 constexpr int L_DB2 = L_MB + 8 * MB_LD * 4;  // db2 [64] f32: per-tile column sums of gm, added up in LDS
-constexpr int L_END = L_DB2 + 256;
+constexpr int L_LNX = L_DB2 + 256;       // LN: half-row sums {sum dxhat, sum dxhat xhat} [2 halves][128 tok] float2, exchanged between the two waves of a row
+constexpr int L_DGB = L_LNX + 2048;      // LN: dgamma [64] | dbeta [64] f32, summed in LDS over the launch
+constexpr int L_GAM = L_DGB + 512;       // LN: gamma [64] f32
+constexpr int L_END = L_GAM + 256;
 constexpr int LDS_BWD_BYTES = L_END;     // 132 KB: one workgroup per CU; the final flush reuses [0, 128 KB) as two fp32 images
 
 typedef __attribute__((address_space(3))) bf16x4* lds_tr_ptr;
@@ -58,7 +61,11 @@ __device__ __forceinline__ bf16x4 tr_read(const char* lds, int addr) { return __
 // next tile's prefetch at the first barrier behind it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool DROP>
+// LN: the backward of the LayerNorm that produced a2 (norm2) runs in the exchange phase on the fp32 accumulators of dL/da2 -- dL/da2 is
+// never stored, the separate LayerNorm-backward launch (one pass over 1 KB per token) is gone: g (the fp32 residual-stream gradient)
+// += dLN, gm_next = bf16(g x next_mask) for the attention branch, dgamma / dbeta accumulated.  A token's row is split over the two
+// waves that share its block (32 channels each): they exchange their two half-row sums through LDS -- one more barrier per tile.
+template <bool DROP, bool LN>
 __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3;
@@ -88,6 +95,16 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
   uint32_t scale_bits = 0;
   int mask_shift = 0;
   if (tid < C) reinterpret_cast<float*>(lds + L_DB2)[tid] = 0.f;
+  MaskEval mk;
+  if (LN) {
+    mk.init(p.next_mask);  // (uniform values: into scalar registers, the vector file is full)
+    mk.e.key = __builtin_amdgcn_readfirstlane(mk.e.key); mk.e.thresh = __builtin_amdgcn_readfirstlane(mk.e.thresh);
+    mk.e.scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mk.e.scale)));
+    mk.p.key = __builtin_amdgcn_readfirstlane(mk.p.key); mk.p.thresh = __builtin_amdgcn_readfirstlane(mk.p.thresh);
+    mk.p.scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(mk.p.scale)));
+    if (tid < 2 * C) reinterpret_cast<float*>(lds + L_DGB)[tid] = 0.f;
+    if (tid < C) reinterpret_cast<float*>(lds + L_GAM)[tid] = p.ln_gamma[tid];
+  }
   if (DROP) {
     scale_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(1.0f / (1.0f - p.drop_h.p_elem)));
     mask_shift = (w & 7) * 4 + (l15 & 3);  // the forward kernel's bit of (token, hidden 16 T + 4 G + e): word 2 G + T / 8, bit 4 (T % 8) + e
@@ -119,18 +136,9 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
   };
   if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
 
-  // ---- per-lane LDS addresses: ONE register per image; what a loop index adds to a swizzled chunk index is an XOR constant (the
-  // swizzles only mix bits the address's other terms leave free), so no address is recomputed and none is kept per index value
-  const int b_dir = L_A2 + l15 * 128 + ((g ^ sw_tok(l15)) << 4);              // a2 fragment kk of token block tb: (b_dir ^ 64 kk) + 2048 tb; gm: - 16384
-  const int b_tr = L_GM + (4 * g + tq) * 128 + (((tp >> 1) ^ sw_tok(4 * g + tq)) << 4) + (tp & 1) * 8;  // gm^T of channel tile ct: (b_tr ^ 32 ct) + 4096 p (+ 2048)
-  const int b_duw = L_DU + hid * 256, du_xs = g ^ du_sw(l15);                 // store slot (4 tb + g) ^ du_sw = du_xs ^ 4 tb
+  // (per-lane LDS addresses are derived inside the tile loop, per phase, from a laundered copy of the thread index: as loop invariants
+  // they would occupy eleven registers through both phases)
   const int tb2 = w >> 1, ctb = 2 * (w & 1);                                  // exchange phase: token block and the first of two channel tiles
-  const int h_lo = 8 * (g & 1) + tq;                                           // (row & 15) of this lane's transposed du reads (rows 32 ks + 8 g + tq, + 4)
-  const int a_dur_lo = L_DU + (8 * g + tq) * 256 + (((4 * tb2 + tp) ^ du_sw(h_lo)) << 3);       // + 8192 ks
-  const int a_dur_hi = L_DU + (8 * g + tq + 4) * 256 + (((4 * tb2 + tp) ^ du_sw(h_lo + 4)) << 3);
-  const int a_w1t = L_W1T + (16 * ctb + l15) * 512 + ((g ^ l15) << 4);        // chunk (4 ks + g) ^ l15: a_w1t ^ 64 ks; second tile + 8192
-  const int b_mb = L_MB + ((2 * (l15 >> 2) + (w >> 3)) * MB_LD + 4 * g) * 4;  // + 64 tb
-
   f32x4 acc1[4], acc2[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc1[i] = acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -140,6 +148,15 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     stage();
     lds_barrier();  // the tile is in LDS; every wave has left the previous tile's exchange phase (the du image is free)
+    int t1 = tid;
+    asm volatile("" : "+v"(t1));
+    const int l1 = t1 & 15, g1 = (t1 >> 4) & 3, tq1 = l1 >> 2, tp1 = l1 & 3;
+    // one register per image; what a loop index adds to a swizzled chunk index is an XOR constant (the swizzles only mix bits the
+    // address's other terms leave free)
+    const int b_dir = L_A2 + l1 * 128 + ((g1 ^ sw_tok(l1)) << 4);              // a2 fragment kk of token block tb: (b_dir ^ 64 kk) + 2048 tb; gm: - 16384
+    const int b_tr = L_GM + (4 * g1 + tq1) * 128 + (((tp1 >> 1) ^ sw_tok(4 * g1 + tq1)) << 4) + (tp1 & 1) * 8;  // gm^T of channel tile ct: (b_tr ^ 32 ct) + 4096 p (+ 2048)
+    const int b_duw = L_DU + (16 * w + l1) * 256, du_xs = g1 ^ du_sw(l1);      // store slot (4 tb + g1) ^ du_sw = du_xs ^ 4 tb
+    const int b_mb = L_MB + ((2 * (l1 >> 2) + (w >> 3)) * MB_LD + 4 * g1) * 4;  // + 64 tb
     // ================================================================================ recompute + weight gradients, all waves alike
 #pragma unroll 1
     for (int pr = 0; pr < 4; ++pr) {
@@ -195,20 +212,44 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
       }
     }
     if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);  // lands during the exchange phase; staged at the top of the loop
+    // LN: everything the exchange phase needs from memory (x_mid, the old g, the statistics of this wave's 16 tokens x 32 channels) is
+    // requested here, in front of the barrier, so that it arrives while the waves wait and multiply
+    float4 xv[2], go[2];
+    float mean = 0.f, rstd = 0.f;
+    if (LN) {
+      const int m = tile * BM + 16 * tb2 + l1;
+      const bool ok = m < p.M;
+      const float2 stt = ok ? *reinterpret_cast<const float2*>(p.stats + 2 * (long)m) : make_float2(0.f, 0.f);
+      mean = stt.x; rstd = stt.y;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const long off = (long)m * C + 16 * (ctb + j) + 4 * g1;
+        xv[j] = ok ? *reinterpret_cast<const float4*>(p.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        go[j] = ok ? *reinterpret_cast<const float4*>(p.g + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     lds_barrier();  // the du image of all 256 hidden units is complete
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+    const int l2 = t2 & 15, g2 = (t2 >> 4) & 3, tq2 = l2 >> 2, tp2 = l2 & 3;
+    const int h_lo = 8 * (g2 & 1) + tq2;                                         // (row & 15) of this lane's transposed du reads (rows 32 ks + 8 g2 + tq, + 4)
+    const int a_dur_lo = L_DU + (8 * g2 + tq2) * 256 + (((4 * tb2 + tp2) ^ du_sw(h_lo)) << 3);       // + 8192 ks
+    const int a_dur_hi = L_DU + (8 * g2 + tq2 + 4) * 256 + (((4 * tb2 + tp2) ^ du_sw(h_lo + 4)) << 3);
+    const int a_w1t = L_W1T + (16 * ctb + l2) * 512 + ((g2 ^ l2) << 4);        // chunk (4 ks + g2) ^ l2: a_w1t ^ 64 ks; second tile + 8192
+    const int b_tr2 = L_GM + (4 * g2 + tq2) * 128 + (((tp2 >> 1) ^ sw_tok(4 * g2 + tq2)) << 4) + (tp2 & 1) * 8;
     // ================================================================================ dL/da2[tb2][ctb, ctb + 1] = W1^T du^T over all hidden units
     {
       f32x4 dc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      int w1t0 = a_w1t, tr0 = b_tr;
-      asm volatile("" : "+v"(w1t0), "+v"(tr0));
+      const int m = tile * BM + 16 * tb2 + l2;
+      int w1t0 = a_w1t, tr0 = b_tr2;
       {  // db2[c] += sum over tokens of gm[.][c]: wave w takes block pair w / 4, channel tile w % 4 (gm^T fragment x ones), summed in LDS
         const int a0 = (tr0 ^ (32 * (w & 3))) + (w >> 2) * 4096;
         const bf16x8 gt = join(tr_read(lds, a0), tr_read(lds, a0 + 2048));
         const bf16_t one_b = (bf16_t)1.0f;
         const f32x4 cs = mma16(gt, bf16x8{one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b}, f32x4{0.f, 0.f, 0.f, 0.f});
-        if (l15 == 0) {
+        if (l2 == 0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(reinterpret_cast<float*>(lds + L_DB2) + 16 * (w & 3) + 4 * g + r, cs[r]);
+          for (int r = 0; r < 4; ++r) atomicAdd(reinterpret_cast<float*>(lds + L_DB2) + 16 * (w & 3) + 4 * g2 + r, cs[r]);
         }
       }
 #pragma unroll
@@ -220,14 +261,58 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
           dc[j] = mma16(wt, duf, dc[j]);
         }
       }
-      const int m = tile * BM + 16 * tb2 + l15;
-      if (m < p.M) {
+      if (LN) {
+        // D[c = 16 ct + 4 g2 + r][token l2]: this lane holds 8 of its token's 64 channels
+        float xh[2][4], dxh[2][4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 gam = *reinterpret_cast<const f32x4*>(lds + L_GAM + (16 * (ctb + j) + 4 * g2) * 4);
+          const float xr[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            xh[j][r] = (xr[r] - mean) * rstd;
+            dxh[j][r] = dc[j][r] * gam[r];
+            s1 += dxh[j][r];
+            s2 += dxh[j][r] * xh[j][r];
+            // dgamma / dbeta: sums over the 16 tokens of the block (the lanes of a row of 16), then one LDS add per channel and wave
+            const float pg = row16_sum(dc[j][r] * xh[j][r]), pb = row16_sum(dc[j][r]);
+            if (l2 == 0) {
+              atomicAdd(reinterpret_cast<float*>(lds + L_DGB) + 16 * (ctb + j) + 4 * g2 + r, pg);
+              atomicAdd(reinterpret_cast<float*>(lds + L_DGB) + C + 16 * (ctb + j) + 4 * g2 + r, pb);
+            }
+          }
+        }
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (g2 == 0) *reinterpret_cast<float2*>(lds + L_LNX + ((w & 1) * BM + 16 * tb2 + l2) * 8) = make_float2(s1, s2);
+        lds_barrier();  // both halves of every row are in LDS
+        const float2 oth = *reinterpret_cast<const float2*>(lds + L_LNX + (((w & 1) ^ 1) * BM + 16 * tb2 + l2) * 8);
+        const float m1 = (s1 + oth.x) * (1.0f / C), m2 = (s2 + oth.y) * (1.0f / C);
+        if (m < p.M) {
+          const float rowm = mk.row_mult(m);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int c0 = 16 * (ctb + j) + 4 * g2;
+            const float gr[4] = {go[j].x, go[j].y, go[j].z, go[j].w};
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = gr[r] + rstd * (dxh[j][r] - m1 - xh[j][r] * m2);
+            *reinterpret_cast<float4*>(p.g + (long)m * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            if (p.gm_next) {
+              bf16x4 t;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) t[r] = (bf16_t)(o[r] * rowm * mk.elem_mult(m, c0 + r));
+              *reinterpret_cast<bf16x4*>(p.gm_next + (long)m * C + c0) = t;
+            }
+          }
+        }
+      } else if (m < p.M) {
         char* da_base = reinterpret_cast<char*>(p.da);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           bf16x4 o;
           o[0] = (bf16_t)dc[j][0]; o[1] = (bf16_t)dc[j][1]; o[2] = (bf16_t)dc[j][2]; o[3] = (bf16_t)dc[j][3];
-          *reinterpret_cast<bf16x4*>(da_base + ((uint32_t)m * (C * 2) + (uint32_t)(16 * (ctb + j) + 4 * g) * 2u)) = o;
+          *reinterpret_cast<bf16x4*>(da_base + ((uint32_t)m * (C * 2) + (uint32_t)(16 * (ctb + j) + 4 * g2) * 2u)) = o;
         }
       }
     }
@@ -249,6 +334,7 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
     if (g == 0) atomicAdd(p.db1 + hid, v);
   }
   if (p.db2 && tid < C) atomicAdd(p.db2 + tid, reinterpret_cast<const float*>(lds + L_DB2)[tid]);
+  if (LN && tid < 2 * C) atomicAdd((tid < C ? p.dgamma : p.dbeta - C) + tid, reinterpret_cast<const float*>(lds + L_DGB)[tid]);
   __syncthreads();
   // ---- 256-byte contiguous atomics of the two weight gradients, all 1024 threads
   // (33.5 MB of fp32 atomics per launch -- 256 workgroups x 128 KB -- drain at the memory side in ~30 us (1.3 TB/s); the waves end as
@@ -283,14 +369,15 @@ extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void
                              float* dbeta, const uint32_t* mask_bits, void* stream) {
   if (int rc = mlp_check_desc(d, "mlp_bwd")) return rc;
   FOCAL_CHECK_ARG(gm && a && w1 && b1 && w2 && dw1 && dw2, "mlp_bwd: null tensor");
-  if (ln_x != nullptr) {
-    focal_set_error("mlp_bwd: the fused LayerNorm backward is not built in this version (pass ln_x = NULL and run focal_layernorm_bwd)");
-    return FOCAL_EUNSUPPORTED;
-  }
-  FOCAL_CHECK_ARG(da != nullptr, "mlp_bwd: da is required without the fused LayerNorm backward");
-  (void)ln_stats; (void)ln_gamma; (void)g; (void)gm_next; (void)next_mask; (void)dgamma; (void)dbeta;
+  const bool ln = ln_x != nullptr;
+  if (ln) FOCAL_CHECK_ARG(ln_stats && ln_gamma && g && dgamma && dbeta, "mlp_bwd: the fused LayerNorm backward needs ln_stats, ln_gamma, g, dgamma and dbeta");
+  else FOCAL_CHECK_ARG(da != nullptr, "mlp_bwd: da is required without the fused LayerNorm backward");
   MlpBwdParams p;
   memset(&p, 0, sizeof(p));
+  if (ln) {
+    p.x = ln_x; p.stats = ln_stats; p.ln_gamma = ln_gamma; p.g = g; p.gm_next = reinterpret_cast<bf16_t*>(gm_next); p.dgamma = dgamma; p.dbeta = dbeta;
+    if (next_mask) p.next_mask = mlp_bwd_mask(*next_mask, MLP_C);
+  }
   p.M = d->M;
   p.gm = reinterpret_cast<const bf16_t*>(gm);
   p.a = reinterpret_cast<const bf16_t*>(a);
@@ -303,14 +390,16 @@ extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void
   const bool drop = d->drop_hidden.p_elem > 0.f;
   FOCAL_CHECK_ARG(!drop || mask_bits != nullptr, "mlp_bwd: hidden dropout is on (p = %g) but mask_bits is NULL: pass the [M][8] words focal_mlp_fwd wrote", (double)d->drop_hidden.p_elem);
   p.mask_bits = mask_bits;
-  void (*kern)(const MlpBwdParams) = drop ? mlp_bwd_kernel<true> : mlp_bwd_kernel<false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[drop]) {
+  void (*kern)(const MlpBwdParams) = ln ? (drop ? mlp_bwd_kernel<true, true> : mlp_bwd_kernel<false, true>)
+                                        : (drop ? mlp_bwd_kernel<true, false> : mlp_bwd_kernel<false, false>);
+  static bool attr_set[4] = {false, false, false, false};
+  const int ki = (ln ? 2 : 0) + (drop ? 1 : 0);
+  if (!attr_set[ki]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD_BYTES) != hipSuccess) {
       focal_set_error("mlp_bwd: cannot reserve %d bytes of LDS", LDS_BWD_BYTES);
       return FOCAL_EHIP;
     }
-    attr_set[drop] = true;
+    attr_set[ki] = true;
   }
   const int ntiles = (d->M + BM - 1) / BM;
   const int grid = ntiles < 256 ? ntiles : 256;  // one persistent 16-wave workgroup per CU

@@ -273,10 +273,17 @@ class SwinModEncoder:
             dc = torch.empty_like(s["a2"])
             du = None
             ln2_done = False
-            if fused_mlp:  # fused branch: h and h' recomputed from a2, all four parameter gradients from one pass
+            ln2_in_mlp = False
+            if fused_mlp:
+                # fused branch: h and h' recomputed from a2, all four parameter gradients from one pass -- and norm2's backward on the
+                # kernel's fp32 dL/da2: g += dLN, the attention branch's masked copy (written over gm: a tile's rows are read before
+                # they are written) and dgamma / dbeta come out of the same launch; no dL/da2 tensor, no LayerNorm-backward launch
+                ln2_in_mlp = True
                 ops.mlp_bwd(s["d_mlp"], gm, s["a2"], ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
-                            ar.operand(f"{pb}.mlp.fc2.weight"), dc, ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"),
-                            ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"), mask_bits=s["mlp_bits"])
+                            ar.operand(f"{pb}.mlp.fc2.weight"), None, ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"),
+                            ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"), mask_bits=s["mlp_bits"],
+                            ln=dict(x=s["x_mid"], stats=s["st2"], gamma=ar.master(f"{pb}.norm2.weight"), g=g, gm_next=gm,
+                                    next_mask=s["d_proj"].out_drop, dgamma=ar.g(f"{pb}.norm2.weight"), dbeta=ar.g(f"{pb}.norm2.bias")))
             else:
                 d_fc2_b = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, cc, ACT_GELU)  # dy = gm: operand dtype, already masked
                 weight_grad(d_fc2_b, gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
@@ -289,7 +296,9 @@ class SwinModEncoder:
                     ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
             # (the MLP branch's gm is still an operand of a pending weight gradient unless the fused branch has consumed it)
             gm_attn = torch.empty_like(gm) if (not fused_mlp and grouped) else gm
-            if ln2_done:
+            if ln2_in_mlp:
+                pass
+            elif ln2_done:
                 ops.linear_bwd_data_ln(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), s["x_mid"], s["st2"], ar.master(f"{pb}.norm2.weight"), g,
                                        ar.g(f"{pb}.norm2.weight"), ar.g(f"{pb}.norm2.bias"), g_masked=gm_attn, mask=s["d_proj"].out_drop)
             else:

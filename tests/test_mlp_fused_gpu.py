@@ -187,3 +187,55 @@ def test_fused_mlp_hidden_dropout_rate_scale_and_forward_backward_consistency(op
     ops.mlp_fwd(d, a, r, w1, b1, w2s.to(BF), b2, ya)
     ops.mlp_fwd(d2, a, r, w1, b1, w2s.to(BF), b2, yb)
     assert ((ya != 0) != (yb != 0)).float().mean().item() > 0.2
+
+
+@pytest.mark.parametrize("M,p_drop", [(4096, 0.0), (9216 + 48, 0.2)])
+def test_fused_mlp_backward_with_norm2_backward_folded_in(ops, M, p_drop):
+    """focal_mlp_bwd with ln_x: the backward of the LayerNorm in front of the branch (norm2, models/SwinModules.py:339-341) on the kernel's
+    fp32 dL/da2 -- g += dLN, gm_next = bf16(g x mask of the attention branch), dgamma / dbeta -- must equal the two-launch form
+    (focal_mlp_bwd -> dL/da2 in bf16 -> focal_layernorm_bwd) to the rounding of that bf16 intermediate; the parameter gradients of the
+    MLP itself must be identical (same code path).  Ragged M (not a multiple of the 128-token tile) and dropout masks included."""
+    C, H, L = 64, 256, 576
+    a, w1, b1, w2, b2, r = _operands(M, seed=70)
+    gm = rnd(M, C, scale=0.5, seed=71, dtype=BF)
+    x_mid = rnd(M, C, seed=72)
+    gamma, beta = rnd(C, seed=73).abs() + 0.5, rnd(C, seed=74)
+    cc = ops.code(BF)
+    rng = ops.new_rng_state(99, DEV)
+    drop_h = ops.drop_desc(rng, 31, p_drop, 35, 0.0, L)
+    next_mask = ops.drop_desc(rng, 33, p_drop, 37, 0.1 if p_drop else 0.0, L)
+    d = ops.mlp_desc(cc, M, C, H, drop_h, ops.drop_desc(rng, 32, 0.0, 36, 0.0, L))
+    bits = ops.mlp_mask_bits(d, DEV)
+    a2, stats = ops.layernorm_fwd(x_mid, gamma, beta, BF)
+    y = torch.empty(M, C, device=DEV)
+    ops.mlp_fwd(d, a2, r, w1, b1, w2, b2, y, mask_bits=bits)
+    g0 = rnd(M, C, seed=75)
+
+    def grads():
+        return (torch.zeros(H, C, device=DEV), torch.zeros(H, device=DEV), torch.zeros(C, H, device=DEV), torch.zeros(C, device=DEV),
+                torch.zeros(C, device=DEV), torch.zeros(C, device=DEV))
+    # two launches
+    dw1, db1, dw2, db2, dg, dbt = grads()
+    da = torch.empty(M, C, dtype=BF, device=DEV)
+    ops.mlp_bwd(d, gm, a2, w1, b1, w2, da, dw1, db1, dw2, db2, mask_bits=bits)
+    g_ref, gmn_ref = g0.clone(), torch.empty(M, C, dtype=BF, device=DEV)
+    ops.layernorm_bwd(da, x_mid, stats, gamma, g_ref, True, dg, dbt, dx_masked=gmn_ref, mask=next_mask)
+    # one launch, gm_next written over gm (what the engine does)
+    ew1, eb1, ew2, eb2, eg, ebt = grads()
+    g_one, gm_io = g0.clone(), gm.clone()
+    ops.mlp_bwd(d, gm_io, a2, w1, b1, w2, None, ew1, eb1, ew2, eb2, mask_bits=bits,
+                ln=dict(x=x_mid, stats=stats, gamma=gamma, g=g_one, gm_next=gm_io, next_mask=next_mask, dgamma=eg, dbeta=ebt))
+    assert rel_err(ew1, dw1) < 1e-5 and rel_err(ew2, dw2) < 1e-5 and rel_err(eb1, db1) < 1e-5 and rel_err(eb2, db2) < 1e-5
+    assert rel_err(g_one - g0, g_ref - g0) < 6e-3            # (the two-launch form rounds dL/da2 to bf16 on the way)
+    assert rel_err(eg, dg) < 4e-3 and rel_err(ebt, dbt) < 4e-3
+    same_mask = ((gm_io.float() == 0) == (gmn_ref.float() == 0)) | (g_ref.abs() < 1e-3)
+    assert same_mask.float().mean().item() > 0.999           # the attention branch's dropout x drop-path mask is the same function
+    assert rel_err(gm_io.float(), gmn_ref.float()) < 1e-2
+    # and against torch autograd through LayerNorm + MLP in fp32 (dropout off only)
+    if p_drop == 0.0:
+        xt = x_mid.clone().requires_grad_(True)
+        gt, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        a_t = F.layer_norm(xt, (C,), gt, bt, 1e-5)
+        yt = F.gelu(a_t.to(BF).float() @ w1.float().t() + b1) @ w2.float().t() + b2
+        yt.backward(gm.float())
+        assert rel_err(g_one - g0, xt.grad) < 1.5e-2 and rel_err(eg, gt.grad) < 1.5e-2 and rel_err(ebt, bt.grad) < 1e-2

@@ -1,4 +1,9 @@
 #!/bin/bash
-# usage: bash tools/scratch/ab_env.sh "CFG_A" "CFG_B" ...   (each an env assignment list, "X=1" for the default) -- 3 interleaved repetitions
-run() { env "$@" python bench.py --no-cpu-baseline --no-roofline --steps 40 --warmup 10 $BENCH_ARGS 2>&1 | tail -1 | sed 's/.*"value": \([0-9.]*\).*/\1/'; }
-for rep in 1 2 3; do for cfg in "$@"; do echo "$rep | $cfg | $(run $cfg)"; done; done
+# Usage: bash tools/scratch/ab_env.sh <ENVVAR> [bench args]  -- same-box A/B of one environment switch, 3 interleaved repetitions
+v=$1; shift
+for i in 1 2 3; do
+  for on in 0 1; do
+    r=$(env $v=$on python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-roofline "$@" | python3 -c "import json,sys; p=json.loads(sys.stdin.readline()); print(p['value'], p['ms_per_step'])")
+    echo "$v=$on rep $i: $r"
+  done
+done
