@@ -143,3 +143,87 @@ def test_rccl_two_gpus(cfg, tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert '"n_gpus": 2' in r.stdout
+
+
+@pytest.mark.parametrize("ct", ["fp32", "bf16"])
+def test_split_backward_first_phase_is_final_on_its_spans(cfg, ct):
+    """The bucketed all-reduce (focal_amd/graph_step.py) starts on the spans `final_after_first_phase()` names as soon as the FIRST phase
+    of the split backward pass has run, while `backward_continue()` still writes the arena.  One device, no process group:
+    (1) after phase 1 alone those spans already hold the gradients of a whole backward pass -- bit for bit in fp32, and in bf16 too
+    (the grouped weight-gradient launches with read-add-write "exclusive" stores, the PatchMerging gradient folded into the last
+    stage's group and the fused LayerNorm-backward epilogues all run under split_backward there); (2) phase 2 writes nothing into them;
+    (3) after phase 2 every span equals the whole pass."""
+    from conftest import make_args, no_dropout
+    from models.FOCALModules import FOCAL
+    from models.loss import FOCALLoss
+    from models.SW_Transformer import SW_Transformer
+    from oracle.weights import fill_state_dict_, synthetic_freq_input
+    args = make_args(no_dropout(cfg), "SW_Transformer", torch.device("cuda"), ct)
+    net = SW_Transformer(args)
+    fill_state_dict_(net.state_dict())
+    net = net.to("cuda").train()
+    focal, loss_fn = FOCAL(args, net), FOCALLoss(args)
+    dev = lambda d: {l: {m: v.cuda() for m, v in mm.items()} for l, mm in d.items()}
+    x1, x2 = dev(synthetic_freq_input(cfg, 16, seed=401)), dev(synthetic_freq_input(cfg, 16, seed=402))
+    ar = net.arena()
+
+    def backward(split):
+        ar.zero_grad()
+        f1, f2 = focal(x1, x2, proj_head=True)
+        loss = loss_fn(f1, f2)
+        net.split_backward = split
+        try:
+            loss.backward()
+        finally:
+            net.split_backward = False
+        torch.cuda.synchronize()
+
+    backward(False)
+    whole = ar.grad.clone()
+    first = set(net.final_after_first_phase())
+    rest = [n for n in ar.index if n not in first]
+    assert rest and first
+    first_spans, rest_spans = ar.spans(first), ar.spans(rest)
+    assert sum(hi - lo for lo, hi in first_spans) > 4 * sum(hi - lo for lo, hi in rest_spans)   # most gradient BYTES travel in the first bucket
+    in_first = torch.zeros_like(whole, dtype=torch.bool)
+    for lo, hi in first_spans:
+        in_first[lo:hi] = True
+    for lo, hi in rest_spans:
+        assert not in_first[lo:hi].any()          # the two buckets do not overlap
+    # run-to-run noise of the fp32 atomics (two whole passes differ by this much): the yardstick for "equal"
+    backward(False)
+    noise = (ar.grad - whole).abs().max().item() / whole.abs().max().item()
+    backward(True)
+    assert len(net.pending_backward) == len(cfg["modality_names"]), "split_backward must park one second half per encoder"
+    phase1 = ar.grad.clone()
+    tol = max(10 * noise, 1e-6 if ct == "fp32" else 1e-3)
+    scale = whole.abs().max().item()
+    assert (phase1[in_first] - whole[in_first]).abs().max().item() < tol * scale, "a first-bucket gradient is not final after phase 1"
+    # (phase 1 may already write second-bucket gradients -- in bf16 the PatchMerging reduction in front of the last stage gets its weight
+    # gradient from the last stage's grouped launch -- which is harmless: that bucket is reduced after phase 2; what must hold is above)
+    early = [n for n in rest if (phase1[ar.index[n][0]:ar.index[n][0] + ar.index[n][1]] != 0).any()]
+    assert all("downsample.reduction" in n for n in early), early
+    net.backward_continue()
+    torch.cuda.synchronize()
+    both = ar.grad.clone()
+    assert torch.equal(both[in_first], phase1[in_first]), "phase 2 wrote into the first bucket (it is on the wire by then)"
+    assert (both - whole).abs().max().item() < tol * scale
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_rccl_two_gpus_bf16_split_backward_equals_blocking_all_reduce(cfg, tmp_path):
+    """Two ranks over RCCL, bf16 operands: six steps with the captured, split backward pass and the two-bucket all-reduce (the first
+    bucket in flight on RCCL's stream while the graph-replayed rest of backward writes the other spans of the SAME arena) against the
+    same job with FOCAL_NO_SPLIT_BACKWARD=1 (whole backward, one blocking all-reduce): same weights to bf16 run-to-run noise (ADVICE r3:
+    the gloo test on one device cannot overlap the collective with the replay).  Skipped on the 1-GPU boxes of this build."""
+    c, ypath = _deterministic_yaml(cfg, tmp_path)
+    outs = []
+    for i, env_extra in enumerate(({}, {"FOCAL_NO_SPLIT_BACKWARD": "1"})):
+        extra = ["-model=SW_Transformer", "-dataset=MOD", "-learn_framework=FOCAL", "-batch_size=32", "-synthetic_batches=6", "-epochs=1",
+                 "-compute_dtype=bf16", f"-config={ypath}"]
+        r = _launch(2, extra, env_extra, 29571 + i)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+        outs.append(torch.load(os.path.join(ROOT, "weights", "MOD_SW_Transformer", "MOD_SW_Transformer_pretrain_latest.pt"), map_location="cpu"))
+    a, b = outs
+    worst = max(((a[k].float() - b[k].float()).abs().max().item() / max(1e-6, b[k].float().abs().max().item())) for k in a if a[k].is_floating_point())
+    assert worst < 2e-2, worst
