@@ -196,7 +196,9 @@ def test_split_backward_first_phase_is_final_on_its_spans(cfg, ct):
     backward(True)
     assert len(net.pending_backward) == len(cfg["modality_names"]), "split_backward must park one second half per encoder"
     phase1 = ar.grad.clone()
-    tol = max(10 * noise, 1e-6 if ct == "fp32" else 1e-3)
+    # (bf16: two passes are not bit-equal -- the order of the fp32 atomics moves a few activations to the neighbouring bf16 value and
+    # gradients by up to ~1e-2 of their maximum, DESIGN 4 -- so "equal" is that noise there; the exact check is (2) below)
+    tol = max(10 * noise, 1e-6 if ct == "fp32" else 3e-2)
     scale = whole.abs().max().item()
     assert (phase1[in_first] - whole[in_first]).abs().max().item() < tol * scale, "a first-bucket gradient is not final after phase 1"
     # (phase 1 may already write second-bucket gradients -- in bf16 the PatchMerging reduction in front of the last stage gets its weight
