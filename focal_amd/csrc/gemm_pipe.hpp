@@ -381,7 +381,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
         const int mm = min(mbase + it * RPI + lane / LPR, p.M - 1);
         loadN<CPL>(p.resid + (long)mm * p.ldr + n, rpre[it]);
         if (EPI == EPI_LN_BWD) {  // the LayerNorm's input row (resid), the residual-stream gradient it is added to, the row's statistics
-          loadN<CPL>(reinterpret_cast<const float*>(C) + (long)mm * p.ldc + n, gpre[it]);
+          // (C == NULL: nobody needs the input gradient -- the first block behind a frozen patch embedding -- only dgamma / dbeta:
+          // the 8 + 4 bytes per element of reading, updating and re-casting the residual-stream gradient are skipped)
+          if (C != nullptr) loadN<CPL>(reinterpret_cast<const float*>(C) + (long)mm * p.ldc + n, gpre[it]);
           spre[it] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mm);
         }
       }
@@ -459,6 +461,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
         if (LPR >= 32) { s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); }
         if (LPR >= 64) { s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); }
         const float m1 = s1 * (1.0f / WC), m2 = s2 * (1.0f / WC);
+        if (C == nullptr) continue;
         float o[CPL];
 #pragma unroll
         for (int e = 0; e < CPL; ++e) o[e] = gpre[it][e] + rstd * (gd[e] - m1 - xh[e] * m2);

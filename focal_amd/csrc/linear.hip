@@ -144,7 +144,8 @@ extern "C" int focal_linear_bwd_data_ln(const focal_linear_desc* d, const void* 
                                         const float* ln_gamma, float* g, float* dgamma, float* dbeta, void* g_masked,
                                         const focal_drop_desc* mask, void* stream) {
   if (int rc = check_desc(d)) return rc;
-  FOCAL_CHECK_ARG(dy && w && ln_x && ln_stats && ln_gamma && g && dgamma && dbeta, "linear_bwd_data_ln: null tensor");
+  FOCAL_CHECK_ARG(dy && w && ln_x && ln_stats && ln_gamma && dgamma && dbeta, "linear_bwd_data_ln: null tensor");
+  FOCAL_CHECK_ARG(g || !g_masked, "linear_bwd_data_ln: g_masked without g");  // g == NULL: only dgamma / dbeta (nobody needs the input gradient)
   FOCAL_CHECK_ARG(focal_linear_bwd_data_ln_supported(d->dtype, d->N, d->K) && d->x_dtype == d->dtype && d->y_dtype == d->dtype &&
                   d->epilogue != FOCAL_EPI_RESIDUAL && d->act_in == FOCAL_ACT_NONE,  // (a GELU epilogue's derivative is already in dy)
                   "linear_bwd_data_ln: bf16 layers with 64 / 128 / 256 input features, plain `dtype` dy (N = %d, K = %d)", d->N, d->K);

@@ -337,7 +337,10 @@ class SwinModEncoder:
             if want_gm and mg_dw is not None:
                 gm = torch.empty_like(gm)  # the old buffer is an operand of the group launch that has not run yet
             if ln1_fused:  # dX of qkv and norm1's backward in one kernel
-                ops.linear_bwd_data_ln(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g,
+                # the encoder's first block behind the frozen patch embedding: its input is a leaf nobody differentiates, so the
+                # residual-stream gradient stops here -- only norm1's dgamma / dbeta are produced (no read / update / re-cast of g)
+                g_out = None if (k == 0 and saved.get("embed") is None and not want_gm) else g
+                ops.linear_bwd_data_ln(s["d_qkv"], dqkv, ar.operand(f"{pb}.attn.qkv.weight"), s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g_out,
                                        ar.g(f"{pb}.norm1.weight"), ar.g(f"{pb}.norm1.bias"), g_masked=gm if want_gm else None, mask=nxt)
             else:
                 ops.layernorm_bwd(da, s["x"], s["st1"], ar.master(f"{pb}.norm1.weight"), g, True,

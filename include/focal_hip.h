@@ -186,6 +186,8 @@ int focal_linear_bwd_data(const focal_linear_desc* d, const void* dy, const void
  * TOGETHER with that LayerNorm's backward (focal_layernorm_bwd with accumulate_dx = 1): g (fp32 [M, K], the residual-stream gradient) +=
  * dLN(dy . w; ln_x, ln_stats, ln_gamma); dgamma / dbeta += ...; g_masked (optional, `dtype`) = dtype(g * mask).  The [M, K] product never
  * reaches memory.  bf16, K = 64 or 128 (focal_linear_bwd_data_ln_supported); d describes the LINEAR layer (plain `dtype` x / y). */
+/* (g == NULL: only dgamma / dbeta are produced -- the LayerNorm's input is a leaf nobody differentiates, e.g. norm1 of the first block behind
+ * the frozen patch embedding in FOCAL pretraining; the residual-stream gradient is then neither read, updated nor re-cast) */
 int focal_linear_bwd_data_ln(const focal_linear_desc* d, const void* dy, const void* w, const float* ln_x, const float* ln_stats,
                              const float* ln_gamma, float* g, float* dgamma, float* dbeta, void* g_masked, const focal_drop_desc* mask,
                              void* stream);
