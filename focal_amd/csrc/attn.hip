@@ -322,7 +322,7 @@ extern "C" int focal_window_attn_qkv_fwd(const focal_attn_desc* d, const void* a
 }
 
 extern "C" int focal_window_attn_qkv_bwd(const focal_attn_desc* d, const void* a1, const void* wqkv, const float* bqkv, const float* bias_table,
-                                         const void* dout, void* dqkv, float* dbias_table, void* stream) {
+                                         const void* dout, const void* wproj, void* dqkv, float* dbias_table, void* stream) {
   AttnGeom g;
   if (int rc = attn_geometry(d, &g)) return rc;
   FOCAL_CHECK_ARG(a1 && wqkv && bqkv && bias_table && dout && dqkv && dbias_table, "window_attn_qkv_bwd: null tensor");
@@ -330,7 +330,7 @@ extern "C" int focal_window_attn_qkv_bwd(const focal_attn_desc* d, const void* a
                   d->dtype, g.C, g.heads);
   FOCAL_CHECK_ARG((2 * g.wh - 1) * (2 * g.ww - 1) * g.heads <= 256, "window_attn_qkv_bwd: bias table too large");
   return focal_attn_mfma_bwd(g, (const bf16_t*)a1, bias_table, (const bf16_t*)dout, (bf16_t*)dqkv, dbias_table, d->rng, d->stream, d->p_attn,
-                             (hipStream_t)stream, (const bf16_t*)wqkv, bqkv);
+                             (hipStream_t)stream, (const bf16_t*)wqkv, bqkv, (const bf16_t*)wproj);
 }
 
 extern "C" int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, const float* bias_table, const void* dout,

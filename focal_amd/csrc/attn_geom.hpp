@@ -43,4 +43,4 @@ int focal_attn_mfma_fwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
                         float p_attn, hipStream_t st, const bf16_t* wqkv = nullptr, const float* bqkv = nullptr);
 int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, const bf16_t* dout, bf16_t* dqkv, float* dbias_table,
                         const uint32_t* rng, uint32_t stream_id, float p_attn, hipStream_t st, const bf16_t* wqkv = nullptr,
-                        const float* bqkv = nullptr);
+                        const float* bqkv = nullptr, const bf16_t* wproj = nullptr);  // wproj (with wqkv): dout is the gradient of the proj OUTPUT

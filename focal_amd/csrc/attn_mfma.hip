@@ -149,17 +149,17 @@ __device__ __forceinline__ void tile_softmax(const AttnGeom& g, const TileIdx& t
 // exists in HBM: the forward pass saves a1 (the weight gradient needs it anyway) and the backward pass recomputes -- 1 KB of traffic per
 // token and step, and one GEMM launch per block, less.  Padded slots are written as zeros, as the tile fetch did.
 struct QkvFrags {
-  bf16x8 w[3][2];   // A fragments: row = this lane's d (l & 15) of q / k / v for the wave's head, k = channels 32 kk + 8 (l >> 4) ..
-  f32x4 bias[3];    // bias of d = 4 (l >> 4) + r
+  bf16x8 w[3][2];     // A fragments: row = this lane's d (l & 15) of q / k / v for the wave's head, k = channels 32 kk + 8 (l >> 4) ..
+  const float* bias;  // LDS copy of bqkv [3C] + this lane's offset h 16 + 4 (l >> 4): 12 registers less than keeping the three bias quads
 };
-__device__ __forceinline__ QkvFrags qkv_frags(const bf16_t* wqkv, const float* bqkv, int C, int h, int lane) {
+__device__ __forceinline__ QkvFrags qkv_frags(const bf16_t* wqkv, const float* bias_lds, int C, int h, int lane) {
   QkvFrags f;
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) f.w[t][kk] = *reinterpret_cast<const bf16x8*>(wqkv + (long)(t * C + h * 16 + (lane & 15)) * C + 32 * kk + 8 * (lane >> 4));
-    f.bias[t] = *reinterpret_cast<const f32x4*>(bqkv + t * C + h * 16 + 4 * (lane >> 4));
   }
+  f.bias = bias_lds + h * 16 + 4 * (lane >> 4);
   return f;
 }
 struct RowRegs { bf16x8 v[2]; };  // this lane's slot: channels 8 (l >> 4) .. + 7 and 32 + 8 (l >> 4) .. of its token's a1 row
@@ -178,7 +178,7 @@ template <int P> __device__ __forceinline__ void qkv_project(bf16_t* Qt, bf16_t*
     // (products first, bias last: the order of the GEMM epilogue this replaces, so that q / k / v round to the same bf16 values)
     f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t][0], x.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t][1], x.v[1], acc, 0, 0, 0);
-    acc += f.bias[t];
+    acc += *reinterpret_cast<const f32x4*>(f.bias + t * 64);
     float o[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
     *reinterpret_cast<bf16x4*>(dst[t] + (lane & 15) * P + 4 * (lane >> 4)) = pack4(o);
   }
@@ -208,7 +208,12 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
   // FUSE: `qkv` is the LayerNorm output a1 [M][C] and q / k / v of an item are projected here (HD == 16, C == 64: see qkv_project)
   constexpr int P = HD + 4, TILE = 16 * P;
   __shared__ __attribute__((aligned(16))) bf16_t tiles[4][3][TILE];
+  __shared__ __attribute__((aligned(16))) float qkv_bias[FUSE ? 192 : 4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: item, window and head arithmetic then runs on the SALU
+  if constexpr (FUSE) {
+    if (threadIdx.x < 192) qkv_bias[threadIdx.x] = bqkv[threadIdx.x];
+    __syncthreads();
+  }
   bf16_t* Qt = tiles[wave][0];
   bf16_t* Kt = tiles[wave][1];
   bf16_t* Vt = tiles[wave][2];
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
   item_of(0, live_n, win_n, h_n);
   tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
   if constexpr (FUSE) {
-    qf = qkv_frags(wqkv, bqkv, C, wave % g.heads, lane);  // item = (..) * 4 + wave and heads == 4: the wave's head never changes
+    qf = qkv_frags(wqkv, qkv_bias, C, wave % g.heads, lane);  // item = (..) * 4 + wave and heads == 4: the wave's head never changes
     row_fetch(rx, qkv, C, tok_n, slot < g.N, lane);
   } else {
     tile_fetch<HD>(rq, qkv + h_n * HD, 3 * C, tok_n, g.N, lane);
@@ -320,18 +325,25 @@ __device__ __forceinline__ void tile_fetch_rows(TileRegs<HD>& r, const bf16_t* b
 // is what bounds this kernel (4 waves per SIMD, ~400 VALU instructions per (window, head) item: profiles/r3_attn_bwd_depth_ab.txt).
 // dS^T is directly the B operand of dQ; dS and Pd in the other orientation (B operands of dK, dV) come from two bf16 tiles written
 // [i][j] into wave-private LDS and read back with the hardware transpose read.
-template <int HD, int NW, bool FUSE>
+template <int HD, int NW, bool FUSE, bool PROJ>
 __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_table,
                                                                    const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                                    float* __restrict__ dbias_table, AttnGeom g, int total_items,
                                                                    int iters, const uint32_t* rng, uint32_t stream, float p_attn,
-                                                                   const bf16_t* __restrict__ wqkv, const float* __restrict__ bqkv) {
+                                                                   const bf16_t* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                                                   const bf16_t* __restrict__ wproj) {
   // FUSE: `qkv` is the LayerNorm output a1 [M][C]; q / k / v are recomputed per item (qkv_project), nothing of them was saved
+  // PROJ: `dout` is the gradient w.r.t. the proj Linear's OUTPUT [M][C] (already x the branch's mask); this head's slice of
+  //       dO = dout . Wproj is computed per item (2 MFMAs) -- no dX launch of the proj layer, no [M][C] dO tensor
   constexpr int P = HD + 4, TILE = 16 * P;
   __shared__ __attribute__((aligned(16))) bf16_t tiles[NW][4][TILE];
   __shared__ __attribute__((aligned(16))) bf16_t trt[NW][2][16 * 20];  // dS^T / Pd^T tiles, written [i][j], read back transposed
   __shared__ float dbacc[256];  // (2wh-1)(2ww-1) x heads <= 256 entries
+  __shared__ __attribute__((aligned(16))) float qkv_bias[FUSE ? 192 : 4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: item, window and head arithmetic then runs on the SALU
+  if constexpr (FUSE) {
+    if (threadIdx.x < 192) qkv_bias[threadIdx.x] = bqkv[threadIdx.x];
+  }
   bf16_t* Qt = tiles[wave][0];
   bf16_t* Kt = tiles[wave][1];
   bf16_t* Vt = tiles[wave][2];
@@ -367,22 +379,31 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
     h = live ? item - win * g.heads : 0;
   };
   TileRegs<HD> rq, rk, rv, rg;
-  RowRegs rx;
+  RowRegs rx, rgm;
   QkvFrags qf;
+  bf16x8 wpt[2];  // PROJ: A fragments of Wproj^T for this wave's head: row d = l & 15 <-> column h 16 + d of Wproj, k = output channels 32 kk + 8 (l >> 4) ..
   bool live_n; int win_n, h_n, reg_n = 0, tok_n = 0;
   item_of(0, live_n, win_n, h_n);
   tok_n = slot < g.N ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
   {
     const TileRows<HD> rows = tile_rows<HD>(tok_n, lane);
     if constexpr (FUSE) {
-      qf = qkv_frags(wqkv, bqkv, C, wave % g.heads, lane);  // NW % heads == 0: the wave's head never changes
+      qf = qkv_frags(wqkv, qkv_bias, C, wave % g.heads, lane);  // NW % heads == 0: the wave's head never changes
       row_fetch(rx, qkv, C, tok_n, slot < g.N, lane);
     } else {
       tile_fetch_rows<HD>(rq, qkv + h_n * HD, 3 * C, rows, g.N, lane);
       tile_fetch_rows<HD>(rk, qkv + C + h_n * HD, 3 * C, rows, g.N, lane);
       tile_fetch_rows<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, rows, g.N, lane);
     }
-    tile_fetch_rows<HD>(rg, dout + h_n * HD, C, rows, g.N, lane);
+    if constexpr (PROJ) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wpt[kk][e] = wproj[(long)(32 * kk + 8 * grp + e) * C + (wave % g.heads) * 16 + col];
+      row_fetch(rgm, dout, C, tok_n, slot < g.N, lane);
+    } else {
+      tile_fetch_rows<HD>(rg, dout + h_n * HD, C, rows, g.N, lane);
+    }
   }
   for (int it = 0; it < iters; ++it) {
     const bool live = live_n;
@@ -399,7 +420,15 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       tile_commit<HD>(Kt, rk, lane);
       tile_commit<HD>(Vt, rv, lane);
     }
-    tile_commit<HD>(Gt, rg, lane);
+    if constexpr (PROJ) {  // dO^T[d][slot] = sum_c Wproj[c][h 16 + d] dout[token(slot)][c]: 4 consecutive d of one token per lane, as qkv_project
+      f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpt[0], rgm.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpt[1], rgm.v[1], acc, 0, 0, 0);
+      const bool valid = slot < g.N;
+      const float o4[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
+      *reinterpret_cast<bf16x4*>(Gt + col * P + 4 * grp) = pack4(o4);
+    } else {
+      tile_commit<HD>(Gt, rg, lane);
+    }
     wave_lds_fence();
     if (it + 1 < iters) {  // the next item's tiles fly while this one is multiplied
       item_of(it + 1, live_n, win_n, h_n);
@@ -413,7 +442,8 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
         tile_fetch_rows<HD>(rk, qkv + C + h_n * HD, 3 * C, rows, g.N, lane);
         tile_fetch_rows<HD>(rv, qkv + 2 * C + h_n * HD, 3 * C, rows, g.N, lane);
       }
-      tile_fetch_rows<HD>(rg, dout + h_n * HD, C, rows, g.N, lane);
+      if constexpr (PROJ) row_fetch(rgm, dout, C, tok_n, slot < g.N, lane);
+      else tile_fetch_rows<HD>(rg, dout + h_n * HD, C, rows, g.N, lane);
     }
     f32x4 st = {0.f, 0.f, 0.f, 0.f}, dt = st;
 #pragma unroll
@@ -511,7 +541,8 @@ int focal_attn_mfma_fwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
 }
 
 int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, const bf16_t* dout, bf16_t* dqkv, float* dbias_table,
-                        const uint32_t* rng, uint32_t stream_id, float p_attn, hipStream_t st, const bf16_t* wqkv, const float* bqkv) {
+                        const uint32_t* rng, uint32_t stream_id, float p_attn, hipStream_t st, const bf16_t* wqkv, const float* bqkv,
+                        const bf16_t* wproj) {
   const int items = g.B * g.nW * g.heads;
   // Every workgroup ends with one atomic per bias-table entry, and atomics onto one address are a serial chain
   // (~10 ns a link): the grid is kept small (workgroups loop over items) so the chain, not the math, does not set the
@@ -522,9 +553,10 @@ int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
   int blocks = ceil_div(items, nw);
   if (blocks > maxb) blocks = maxb;
   const int iters = ceil_div(items, blocks * nw);
-#define LAUNCH(HD, FUSE) FOCAL_LAUNCH((window_attn_bwd_mfma_kernel<HD, 16, FUSE>), dim3(blocks), dim3(16 * 64), 0, st, qkv, bias_table, dout, dqkv, dbias_table, g, items, iters, rng, stream_id, p_attn, wqkv, bqkv)
-  if (wqkv != nullptr) LAUNCH(16, true);
-  else if (g.hd == 16) LAUNCH(16, false); else if (g.hd == 32) LAUNCH(32, false); else LAUNCH(64, false);
+#define LAUNCH(HD, FUSE, PROJ) FOCAL_LAUNCH((window_attn_bwd_mfma_kernel<HD, 16, FUSE, PROJ>), dim3(blocks), dim3(16 * 64), 0, st, qkv, bias_table, dout, dqkv, dbias_table, g, items, iters, rng, stream_id, p_attn, wqkv, bqkv, wproj)
+  if (wqkv != nullptr && wproj != nullptr) LAUNCH(16, true, true);
+  else if (wqkv != nullptr) LAUNCH(16, true, false);
+  else if (g.hd == 16) LAUNCH(16, false, false); else if (g.hd == 32) LAUNCH(32, false, false); else LAUNCH(64, false, false);
 #undef LAUNCH
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;

@@ -463,10 +463,11 @@ def window_attn_qkv_fwd(d, a1, wqkv, bqkv, bias_table, out):
     check(_lib.load().focal_window_attn_qkv_fwd(C.byref(d), _p(a1), _p(wqkv), _p(bqkv), _p(bias_table), _p(out), _stream()))
 
 
-def window_attn_qkv_bwd(d, a1, wqkv, bqkv, bias_table, dout, dqkv, dbias_table):
-    _need_cuda(a1, wqkv, bqkv, bias_table, dout, dqkv, dbias_table)
-    check(_lib.load().focal_window_attn_qkv_bwd(C.byref(d), _p(a1), _p(wqkv), _p(bqkv), _p(bias_table), _p(dout), _p(dqkv), _p(dbias_table),
-                                                _stream()))
+def window_attn_qkv_bwd(d, a1, wqkv, bqkv, bias_table, dout, dqkv, dbias_table, wproj=None):
+    """wproj given: `dout` is the gradient w.r.t. the proj Linear's OUTPUT (masked, operand dtype) and the kernel forms dout . wproj itself."""
+    _need_cuda(a1, wqkv, bqkv, bias_table, dout, dqkv, dbias_table, wproj)
+    check(_lib.load().focal_window_attn_qkv_bwd(C.byref(d), _p(a1), _p(wqkv), _p(bqkv), _p(bias_table), _p(dout), _p(wproj), _p(dqkv),
+                                                _p(dbias_table), _stream()))
 
 
 # ------------------------------------------------------------------------------------------------ rows 11-13

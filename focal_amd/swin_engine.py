@@ -308,13 +308,15 @@ class SwinModEncoder:
             d_proj_b = ops.linear_desc(cc, M, Cc, Cc, cc, cc)
             weight_grad(d_proj_b, gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
             do = dc  # reuse the [M, C] CT buffer
-            ops.linear_bwd_data(d_proj_b, gm_attn, ar.operand(f"{pb}.attn.proj.weight"), None, do)
             dqkv = torch.empty(M, 3 * Cc, dtype=ct, device=dev)
-            if s["qkv"] is None:  # q / k / v recomputed from a1 inside the kernel (see forward)
+            if s["qkv"] is None:
+                # 64-channel blocks: q / k / v are recomputed from a1 inside the kernel (see forward), and so is the proj layer's input
+                # gradient -- the kernel forms its head's slice of gm_attn . Wproj per item: no dX launch, no dO tensor
                 ops.window_attn_qkv_bwd(s["d_att"], s["a1"], ar.operand(f"{pb}.attn.qkv.weight"), ar.master(f"{pb}.attn.qkv.bias"),
-                                        ar.master(f"{pb}.attn.relative_position_bias_table"), do, dqkv,
-                                        ar.g(f"{pb}.attn.relative_position_bias_table"))
+                                        ar.master(f"{pb}.attn.relative_position_bias_table"), gm_attn, dqkv,
+                                        ar.g(f"{pb}.attn.relative_position_bias_table"), wproj=ar.operand(f"{pb}.attn.proj.weight"))
             else:
+                ops.linear_bwd_data(d_proj_b, gm_attn, ar.operand(f"{pb}.attn.proj.weight"), None, do)
                 ops.window_attn_bwd(s["d_att"], s["qkv"], ar.master(f"{pb}.attn.relative_position_bias_table"), do, dqkv,
                                     ar.g(f"{pb}.attn.relative_position_bias_table"))
             weight_grad(s["d_qkv"], dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias"))

@@ -273,8 +273,11 @@ int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, const float
 int focal_window_attn_qkv_supported(int dtype, int C, int heads, int window_tokens);
 int focal_window_attn_qkv_fwd(const focal_attn_desc* d, const void* a1, const void* wqkv, const float* bqkv, const float* bias_table,
                               void* out, void* stream);
+/* _bwd: wproj == NULL: dout = dL/d(attention output) as in focal_window_attn_bwd; wproj [C, C] (the proj Linear's weight): dout = dL/d(proj
+ * output) [B*H*W, C] (already x the branch's dropout / drop-path mask) and the kernel forms its head's slice of dout . wproj per item itself --
+ * the proj layer's input-gradient launch and the [B*H*W, C] tensor between the two are gone. */
 int focal_window_attn_qkv_bwd(const focal_attn_desc* d, const void* a1, const void* wqkv, const float* bqkv, const float* bias_table,
-                              const void* dout, void* dqkv, float* dbias_table, void* stream);
+                              const void* dout, const void* wproj, void* dqkv, float* dbias_table, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 5: DeepSense convs
  * ConvBlock (models/ConvModules.py:115-216) on CHANNEL-LAST tokens: activation [B*I*S, C] (row = (b, interval, s)).

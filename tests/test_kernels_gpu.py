@@ -473,6 +473,17 @@ def test_window_attention_with_qkv_projection_folded_in(ops, H, W, sh, sw, p_att
     dqkv_u, dt_u = torch.empty_like(dqkv), torch.zeros_like(table)
     ops.window_attn_bwd(d, qkv, table, do, dqkv_u, dt_u)
     assert rel_err(dqkv.float(), dqkv_u.float()) < 6e-3 and rel_err(dt, dt_u) < 4e-3
+    # ... and with the proj Linear's input gradient folded in as well: dout = dL/d(proj output), the kernel forms dout . Wproj per item
+    wproj = rnd(C, C, scale=C ** -0.5, seed=135, dtype=ct)
+    gy = rnd(M, C, seed=136, dtype=ct)
+    d_proj = ops.linear_desc(cc, M, C, C, cc, cc)
+    do_u = torch.empty(M, C, dtype=ct, device=DEV)
+    ops.linear_bwd_data(d_proj, gy, wproj, None, do_u)
+    dq_u, dtb_u = torch.empty_like(dqkv), torch.zeros_like(table)
+    ops.window_attn_qkv_bwd(d, a1, wqkv, bqkv, table, do_u, dq_u, dtb_u)
+    dq_f, dtb_f = torch.empty_like(dqkv), torch.zeros_like(table)
+    ops.window_attn_qkv_bwd(d, a1, wqkv, bqkv, table, gy, dq_f, dtb_f, wproj=wproj)
+    assert rel_err(dq_f.float(), dq_u.float()) < 2e-3 and rel_err(dtb_f, dtb_u) < 2e-3   # same products, same bf16 rounding of dO
     if p_attn == 0.0:  # ... and the reference formula in fp32
         a32, w32, b32 = a1.float().requires_grad_(True), wqkv.float(), bqkv.clone()
         t32 = table.clone().requires_grad_(True)
