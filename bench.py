@@ -708,10 +708,14 @@ def dp_diagnostics(a, step, world, device, graphed):
     the graph segments, the embedding all-gather, the gradient all-reduce and how much of it stays exposed behind the split backward."""
     ones = torch.ones(1, device=device)
     dist.all_reduce(ones)
-    out = {"backend": dist.get_backend(), "world": world, "ranks_seen": int(ones.item()),
-           "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None),
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+    except Exception as e:  # noqa: BLE001  (a version query must not cost the line)
+        ver = f"unavailable ({type(e).__name__})"
+    out = {"backend": dist.get_backend(), "world": world, "ranks_seen": int(ones.item()), "rccl_version": ver,
            "loss_head_sharded": bool(step.dist.shard_loss_head()), "split_backward": step.seg.buckets() is not None}
     if graphed:
+        # (collective: every rank replays these 5 steps; a failure here is a failure of the step itself and is not swallowed)
         pieces = step.seg.measure_pieces(step.last_run, 5)
         out["us_segments"] = pieces
         out["us_exchange"] = round(sum(v for k, v in pieces.items() if k.startswith("exchange")), 1)
