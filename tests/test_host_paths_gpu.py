@@ -163,3 +163,53 @@ def test_static_views_pair_host_sourced_batches():
     for m in cfg["modality_names"]:
         a, b = v1[loc][m], v2[loc][m]
         assert a.data_ptr() == bases[m] and b.data_ptr() == bases[m] + a.numel() * 4, m
+
+
+def test_launch_trace_records_kernels_with_their_own_durations():
+    """focal_trace_* (include/focal_hip.h): bench.py's in-step roofline.  Between begin and end every launch of the library is recorded with
+    the launched kernel's symbol and the dispatch's own duration; both modes see the same launches; a launch onto a stream that is being
+    captured into a hipGraph is not recorded; durations are positive and a 75 MB AdamW-sized pass takes longer than a tiny one."""
+    import ctypes
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_names import short_kernel_name
+    from focal_amd import _lib, ops
+    lib = _lib.load()
+    big_x, small_x = torch.randn(1 << 22, 64, device="cuda"), torch.randn(256, 64, device="cuda")
+    gamma, beta = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+
+    def run():
+        ops.layernorm_fwd(big_x, gamma, beta, torch.bfloat16)
+        ops.layernorm_fwd(small_x, gamma, beta, torch.bfloat16)
+    run()
+    torch.cuda.synchronize()
+    seen = {}
+    for mode in (_lib.TRACE_DISPATCH, _lib.TRACE_EVENTS):
+        _lib.check(lib.focal_trace_begin(64, mode))
+        run()
+        torch.cuda.synchronize()
+        lib.focal_trace_end()
+        n = lib.focal_trace_count()
+        assert n == 2, n
+        recs = (_lib.TraceRecord * n)()
+        _lib.check(lib.focal_trace_read(0, n, recs))
+        names = [short_kernel_name(r.kernel.decode()) for r in recs]
+        assert all(nm.startswith("ln_fwd_kernel<bf16") for nm in names), names
+        assert recs[0].us > 5 * recs[1].us > 0, (recs[0].us, recs[1].us)      # 1.6 GB moved against 100 KB
+        assert recs[0].grid[0] >= recs[1].grid[0] and recs[0].block[0] == 256
+        seen[mode] = [r.us for r in recs]
+    # the big launch agrees between the two modes within the markers' own cost; and with the bytes it moves
+    assert abs(seen[_lib.TRACE_DISPATCH][0] - seen[_lib.TRACE_EVENTS][0]) < 0.25 * seen[_lib.TRACE_DISPATCH][0]
+    gbps = big_x.numel() * 6 / (seen[_lib.TRACE_DISPATCH][0] * 1e-6) / 1e9
+    assert 1000 < gbps < 8000, gbps
+    # nothing is recorded from a stream under capture, and an ended trace records nothing
+    _lib.check(lib.focal_trace_begin(64, _lib.TRACE_DISPATCH))
+    g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            run()
+    assert lib.focal_trace_count() == 0
+    lib.focal_trace_end()
+    run()
+    assert lib.focal_trace_count() == 0
+    assert lib.focal_trace_begin(0, 1) != 0 and b"capacity" in lib.focal_last_error()

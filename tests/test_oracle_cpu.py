@@ -292,3 +292,20 @@ def test_mixup_oracle_reproduces_reference_fixture():
                 box = mixup_bbox(x.shape[2], x.shape[3], lam, *[int(v) for v in fx[f"{tag}.centre.{m}"]])
                 assert list(box) == [int(v) for v in fx[f"{tag}.box.{m}"]]
             assert torch.equal(mixup_batch_random(x, perm, lam, box), torch.from_numpy(fx[f"{tag}.out.{m}"]))
+
+
+def test_kernel_symbol_decoder():
+    """tools/kernel_names.py: bench.py's launch trace and `rocprofv3 -M` both give mangled symbols; both sides go through this decoder
+    (the image's demanglers print __bf16 as `bool _Accum` or give up on DF16b)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_names import short_kernel_name as f
+    assert f("_Z13ln_bwd_kernelIDF16bLi1EEvPKT_PKfS4_S4_PfiS4_S4_iii6RowMapPS0_15focal_drop_desci") == "ln_bwd_kernel<bf16, 1>"
+    assert f("_Z22focal_gemm_pipe_kernelIDF16bLi6ELb0ELi128ELi128ELi2ELi2ELi2EEv10GemmParams") == "focal_gemm_pipe_kernel<bf16, 6, false, 128, 128, 2, 2, 2>"
+    assert f("_ZN17focal_mlp_kernels14mlp_bwd_kernelILb1ELb1EEEv12MlpBwdParams") == "mlp_bwd_kernel<true, true>"
+    assert f("_Z12adamw_kernelPfPKfS_S_PDF16blS1_PjS3_i16focal_adamw_desc") == "adamw_kernel"
+    assert f("_Z17focal_gemm_kernelIDF16bffDF16bLb1ELb1ELi0ELi0ELi5ELi64ELi64ELi2EEv10GemmParams") == "focal_gemm_kernel<bf16, float, float, bf16, true, true, 0, 0, 5, 64, 64, 2>"
+    assert f("__amd_rocclr_copyBuffer") == "__amd_rocclr_copyBuffer"
+    # already (mis-)demangled input, as hipKernelNameRefByPtr / rocprofv3 without -M print it
+    assert f("void (anonymous namespace)::mlp_bwd_kernel<true>(MlpBwdParams)") == "mlp_bwd_kernel<true>"
+    assert f("void ln_bwd_kernel<bool _Accum, 1>(bool _Accum const*, float)") == "ln_bwd_kernel<bf16, 1>"
