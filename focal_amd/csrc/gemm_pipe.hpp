@@ -109,7 +109,7 @@ __device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, 
       const int mm = min(mbase + it * RPI + lane / LPR, p.M - 1);
       loadN<4>(p.resid + (long)mm * p.ldr + n, rpre[it]);
       if (EPI == EPI_LN_BWD) {
-        loadN<4>(Cf + (long)mm * p.ldc + n, gpre[it]);
+        if (Cf != nullptr) loadN<4>(Cf + (long)mm * p.ldc + n, gpre[it]);  // (NULL: dgamma / dbeta only, see the one-wave-per-row epilogue below)
         spre[it] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mm);
       }
     }
@@ -175,6 +175,7 @@ __device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, 
         storeN<4>(reinterpret_cast<bf16_t*>(p.aux_out) + (long)m * p.ldc + n, y);
         if (wn == 0 && (lane % LPR) == 0) *reinterpret_cast<float2*>(p.ln_stats + 2 * (long)m) = make_float2(mean, rstd);
       } else {
+        if (Cf == nullptr) continue;
         const float rstd = spre[it].y, m1 = (h1[it] + o.x) * (1.0f / BN), m2 = (h2[it] + o.y) * (1.0f / BN);
         float g[4];
 #pragma unroll

@@ -190,6 +190,13 @@ def test_linear_bwd_data_ln(ops, M, N, K, drop):
     g2 = g0.clone()
     ops.linear_bwd_data_ln(d, dy, w, x, stats, gamma, g2, torch.zeros(K, device=DEV), torch.zeros(K, device=DEV))
     assert rel_err(g2, g) < 1e-6
+    # g = None: the LayerNorm's input is a leaf nobody differentiates (norm1 of the first block behind the frozen patch embedding):
+    # dgamma / dbeta exactly as before, no residual-stream gradient read or written
+    dg3, db3 = torch.full((K,), 0.5, device=DEV), torch.full((K,), -0.5, device=DEV)
+    ops.linear_bwd_data_ln(d, dy, w, x, stats, gamma, None, dg3, db3)
+    assert rel_err(dg3 - 0.5, dg - 0.5) < 1e-5 and rel_err(db3 + 0.5, db + 0.5) < 1e-5
+    with pytest.raises(Exception, match="g_masked without g"):
+        ops.linear_bwd_data_ln(d, dy, w, x, stats, gamma, None, dg3, db3, g_masked=gm, mask=mask)
 
 
 @pytest.mark.parametrize("rows,C,exclusive", [(2304, 128, True), (2304, 128, False), (64, 128, True), (1152, 256, True), (4672, 256, False),
