@@ -145,6 +145,7 @@ PROTOTYPES = {
     "focal_window_attn_qkv_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "focal_window_attn_qkv_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P]),
     "focal_window_attn_qkv_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P, P, P, P]),
+    "focal_window_attn_branch_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P]),
     "focal_fusion_attn_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint32, C.c_float, P]),
     "focal_fusion_attn_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P, P]),
     "focal_cross_entropy": (C.c_int, [C.c_int, C.c_int, P, P, P, P, P]),

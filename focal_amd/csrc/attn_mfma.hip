@@ -561,3 +561,314 @@ int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
+
+// ============================================================================================================================
+// Round 4: the whole attention-branch backward of a 64-channel block per WINDOW and wave.
+//
+//   gm (= dL/d(proj output) x mask), a1 (= norm1 output)  ->  dqkv (for the layer's weight gradient), dL/da1 -> norm1's backward:
+//   g += dLN, gm_next = bf16(g x mask of the previous block's MLP branch), dgamma / dbeta, dbias_table.
+//
+// window_attn_bwd_mfma_kernel gives a wave one (window, head) item; what comes behind it -- dX of the qkv Linear and norm1's backward, a
+// GEMM launch that re-reads dqkv (384 B per token) -- contracts over all 192 qkv columns, i.e. over the four heads, which live in four
+// waves.  Here a wave owns a WINDOW and walks its four heads: per head q / k / v and dO are projected as before (the weight fragments
+// now come from swizzled LDS images of Wqkv and Wproj^T, they change with the head), the item math is window_attn_bwd_mfma_kernel's,
+// and the head's dq / dk / dv -- accumulators D[d][token], already the B-operand layout of a 16 x 16 x 16 MFMA -- are contracted with
+// the transposed-read fragments of Wqkv into  dL/da1^T[c][token]  (12 MFMAs per head, 4 accumulator tiles per window).  After the
+// fourth head the lane holds 16 of its token's 64 channels; the row sums of LayerNorm's backward are two cross-row shuffles, nothing is
+// exchanged between waves, and the residual-stream gradient is updated in place at the token's original position (the roll / window
+// partition is index arithmetic, as everywhere).  No [M, C] dL/da1 tensor, no second read of dqkv, one launch less per block.
+#ifndef BRANCH_NW
+#define BRANCH_NW 8
+#endif
+struct BranchBwdParams {
+  const bf16_t* a1; const bf16_t* gm; const bf16_t* wqkv; const float* bqkv; const bf16_t* wproj; const float* bias_table;
+  bf16_t* dqkv; float* dbias_table;
+  const float* x; const float* stats; const float* gamma; float* g; bf16_t* g_masked; float* dgamma; float* dbeta;
+  focal_drop_desc mask;
+  AttnGeom geo;
+  int total_windows, iters;
+  const uint32_t* rng; uint32_t stream; float p_attn;
+};
+
+__device__ __forceinline__ int br_sw(int row) { return ((row >> 1) & 3) << 1; }  // chunk swizzle of the 128-byte-row weight images (as mlp_bwd.hip: sw_tok)
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void swin_attn_branch_bwd_kernel(const BranchBwdParams p) {
+  constexpr int HD = 16, C = 64, P = HD + 4, TILE = 16 * P, HEADS = 4;
+  __shared__ __attribute__((aligned(16))) bf16_t tiles[NW][4][TILE];
+  __shared__ __attribute__((aligned(16))) bf16_t trt[NW][2][16 * 20];
+  __shared__ __attribute__((aligned(16))) char wq_img[192 * 128];   // Wqkv [3C][C] bf16, 16-byte chunk c of row r at c ^ br_sw(r & 15)
+  __shared__ __attribute__((aligned(16))) char wpt_img[64 * 128];   // Wproj^T [C in][C out] bf16, same swizzle
+  __shared__ __attribute__((aligned(16))) float qb[192], gam[64], dgb[128];
+  __shared__ float btab[256], dbacc[256];
+  const AttnGeom& g = p.geo;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = lane >> 4, col = lane & 15, tq = col >> 2, tp = col & 3;
+  bf16_t* Qt = tiles[wave][0];
+  bf16_t* Kt = tiles[wave][1];
+  bf16_t* Vt = tiles[wave][2];
+  bf16_t* Gt = tiles[wave][3];
+  const int table = (2 * g.wh - 1) * (2 * g.ww - 1) * g.heads;
+  // ---- images and small tables
+  for (int q = threadIdx.x; q < 192 * 8; q += NW * 64) {
+    const int r = q >> 3, c = q & 7;
+    *reinterpret_cast<uint4*>(wq_img + r * 128 + ((c ^ br_sw(r & 15)) << 4)) = *reinterpret_cast<const uint4*>(p.wqkv + r * C + c * 8);
+  }
+  for (int q = threadIdx.x; q < 64 * 8; q += NW * 64) {
+    const int co = q >> 3, c0 = (q & 7) * 8;  // Wproj[co][c0 .. c0 + 7] -> rows c0 + e, column co of the transposed image
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.wproj + co * C + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = c0 + e;
+      *reinterpret_cast<bf16_t*>(wpt_img + r * 128 + (((co >> 3) ^ br_sw(r & 15)) << 4) + (co & 7) * 2) = v[e];
+    }
+  }
+  for (int t = threadIdx.x; t < 256; t += NW * 64) {
+    dbacc[t] = 0.f;
+    btab[t] = t < table ? p.bias_table[t] : 0.f;
+    if (t < 192) qb[t] = p.bqkv[t];
+    if (t < 64) gam[t] = p.gamma[t];
+    if (t < 128) dgb[t] = 0.f;
+  }
+  __syncthreads();
+  // (uniform values into scalar registers: the vector file is the scarce resource of this kernel)
+  auto uni = [](DropCtx c) {
+    c.key = __builtin_amdgcn_readfirstlane(c.key); c.thresh = __builtin_amdgcn_readfirstlane(c.thresh);
+    c.scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c.scale)));
+    return c;
+  };
+  const DropCtx dc = uni(make_drop(p.rng, p.stream, p.p_attn));
+  const bool drop_on = p.p_attn > 0.f;
+  const DropCtx me = uni(make_drop(p.mask.rng, p.mask.stream_elem, p.mask.p_elem)), mp = uni(make_drop(p.mask.rng, p.mask.stream_path, p.mask.p_path));
+  const bool m_on_e = p.mask.p_elem > 0.f, m_on_p = p.mask.p_path > 0.f;
+  const int m_rps = p.mask.rows_per_sample > 0 ? p.mask.rows_per_sample : 1;
+  const TileIdx tA = make_tile_idx<true>(g, lane);  // rows j = 4 grp + r, column i = col
+  const int slot = col, sy = slot / g.ww, sx = slot - sy * g.ww;
+  const bool valid = slot < g.N;
+  float dbreg[HEADS][4];
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dbreg[h][r] = 0.f;
+  // per-lane byte offsets into the images (the head / gate / tile terms are added per use: they are multiples of the 16-row swizzle period)
+  const int o_dir = col * 128;                                   // direct fragment: row (base + col), chunk (4 kk + grp) ^ br_sw(col)
+  const int x_dir = (grp ^ br_sw(col)) << 4;                     // kk = 0; kk = 1: ^ 64
+  const int o_tr = (4 * grp + tq) * 128 + (tp & 1) * 8;          // transposed fragment: row (base + 4 grp + tq), chunk (2 ct + tp / 2) ^ br_sw(row)
+  const int x_tr = ((tp >> 1) ^ br_sw(4 * grp + tq)) << 4;       // ct = 0; ct: ^ (ct << 5)
+
+  auto win_of = [&](int it, bool& live) {
+    const int w = (it * gridDim.x + blockIdx.x) * NW + wave;
+    live = w < p.total_windows;
+    return live ? w : 0;
+  };
+  RowRegs rx, rgm;
+  bool live_n;
+  int win_n = win_of(0, live_n), reg_n = 0, tok_n = 0;
+  tok_n = valid ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
+  row_fetch(rx, p.a1, C, tok_n, valid, lane);
+  row_fetch(rgm, p.gm, C, tok_n, valid, lane);
+  for (int it = 0; it < p.iters; ++it) {
+    const bool live = live_n;
+    const int win = win_n, reg_own = reg_n, tok_own = tok_n;
+    f32x4 dacc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) dacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int h = 0; h < HEADS; ++h) {  // (not unrolled: four copies of the item let the compiler hoist address arithmetic across heads -- 50 spilled registers)
+      wave_lds_fence();  // the previous head's fragment reads are issued before these tile writes
+      // ---- q / k / v and dO of this head
+      {
+        bf16_t* dst[3] = {Qt, Kt, Vt};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const char* wb = wq_img + (t * 64 + h * 16) * 128 + o_dir;
+          f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb + x_dir), rx.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb + (x_dir ^ 64)), rx.v[1], acc, 0, 0, 0);
+          acc += *reinterpret_cast<const f32x4*>(qb + t * 64 + h * 16 + 4 * grp);
+          const float o[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
+          *reinterpret_cast<bf16x4*>(dst[t] + col * P + 4 * grp) = pack4(o);
+        }
+        const char* wb = wpt_img + (h * 16) * 128 + o_dir;
+        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb + x_dir), rgm.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb + (x_dir ^ 64)), rgm.v[1], acc, 0, 0, 0);
+        const float o[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
+        *reinterpret_cast<bf16x4*>(Gt + col * P + 4 * grp) = pack4(o);
+      }
+      wave_lds_fence();
+      if (h == HEADS - 1 && it + 1 < p.iters) {  // the window's rows are consumed: the next window's fly behind this head and the LayerNorm phase
+        win_n = win_of(it + 1, live_n);
+        reg_n = 0;
+        tok_n = valid ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
+        row_fetch(rx, p.a1, C, tok_n, valid, lane);
+        row_fetch(rgm, p.gm, C, tok_n, valid, lane);
+      }
+      // ---- the item (window, h): window_attn_bwd_mfma_kernel's math
+      const bf16x4 fq = frag_rows(Qt, P, 0, lane), fk = frag_rows(Kt, P, 0, lane);
+      const bf16x4 fv = frag_rows(Vt, P, 0, lane), fg = frag_rows(Gt, P, 0, lane);
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 st = mma16x16(fk, fq, z4);  // S^T  : rows j, col i
+      const f32x4 dt = mma16x16(fv, fg, z4);  // dPd^T: rows j, col i
+      float pr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float badd = tA.ok[r] ? btab[tA.rel[r] + h] : (tA.qpad[r] ? 0.f : -1.0e30f);
+        pr[r] = fmaf(st[r], g.scale, badd);
+      }
+      if (g.shifted) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int reg_j = __shfl(reg_own, 4 * grp + r, 64);
+          pr[r] += (tA.ok[r] && reg_j != reg_own) ? -100.0f : 0.f;
+        }
+      }
+      float mx = fmaxf(fmaxf(pr[0], pr[1]), fmaxf(pr[2], pr[3]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pr[r] = __expf(pr[r] - mx); sum += pr[r]; }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      const uint32_t ebase = (((uint32_t)win * g.heads + h) * g.N + col) * g.N + 4 * grp;  // element (i = col, j = 4 grp + r)
+      float dsT[4], pdT[4], dot = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[r] *= inv;
+        const float mlt = (drop_on && tA.ok[r]) ? drop_mult(dc, ebase + r) : 1.f;
+        pdT[r] = pr[r] * mlt;
+        dsT[r] = dt[r] * mlt;
+        dot += pr[r] * dsT[r];
+      }
+      dot += __shfl_xor(dot, 16, 64);
+      dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsT[r] = pr[r] * (dsT[r] - dot);
+      if (live) {  // (h is wave-uniform: a scalar branch picks the head's four accumulators -- no dynamically indexed register array)
+#pragma unroll
+        for (int hh = 0; hh < HEADS; ++hh)
+          if (h == hh) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dbreg[hh][r] += dsT[r];
+          }
+      }
+      const bf16x4 bdsT = pack4(dsT), bpdT = pack4(pdT);
+      bf16_t* tw = trt[wave][0];
+      *reinterpret_cast<bf16x4*>(tw + col * 20 + 4 * grp) = bdsT;
+      *reinterpret_cast<bf16x4*>(tw + 16 * 20 + col * 20 + 4 * grp) = bpdT;
+      wave_lds_fence();
+      const bf16x4 bds = frag_cols(tw, 20, 0, lane);
+      const bf16x4 bpd = frag_cols(tw + 16 * 20, 20, 0, lane);
+      const f32x4 dq = mma16x16(frag_cols(Kt, P, 0, lane), bdsT, z4);  // dQ^T[d][i]
+      const f32x4 dk = mma16x16(frag_cols(Qt, P, 0, lane), bds, z4);   // dK^T[d][j]
+      const f32x4 dv = mma16x16(frag_cols(Gt, P, 0, lane), bpd, z4);   // dV^T[d][j]
+      // padded slots carry garbage (a padded query's softmax row): zeroed here, they feed the dL/da1 products below
+      const float a[4] = {valid ? dq[0] * g.scale : 0.f, valid ? dq[1] * g.scale : 0.f, valid ? dq[2] * g.scale : 0.f, valid ? dq[3] * g.scale : 0.f};
+      const float b[4] = {valid ? dk[0] * g.scale : 0.f, valid ? dk[1] * g.scale : 0.f, valid ? dk[2] * g.scale : 0.f, valid ? dk[3] * g.scale : 0.f};
+      const float c[4] = {valid ? dv[0] : 0.f, valid ? dv[1] : 0.f, valid ? dv[2] : 0.f, valid ? dv[3] : 0.f};
+      const bf16x4 bq = pack4(a), bk = pack4(b), bv = pack4(c);
+      if (live && valid) {
+        bf16_t* dst = p.dqkv + (long)tok_own * 3 * C + h * HD + 4 * grp;
+        *reinterpret_cast<bf16x4*>(dst) = bq;
+        *reinterpret_cast<bf16x4*>(dst + C) = bk;
+        *reinterpret_cast<bf16x4*>(dst + 2 * C) = bv;
+      }
+      // ---- dL/da1^T[c][token] += Wqkv_t[h 16 + d][c] . dT^T[d][token]: the accumulators above ARE the B operands (k = d = 4 grp + e)
+      const bf16x4 bt[3] = {bq, bk, bv};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const char* wb = wq_img + (t * 64 + h * 16) * 128 + o_tr;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const bf16x4 wf = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(wb + (x_tr ^ (ct << 5))));
+          dacc[ct] = mma16x16(wf, bt[t], dacc[ct]);
+        }
+      }
+    }
+    // ---- norm1's backward on this window's rows: lane (grp, slot) holds channels 16 ct + 4 grp + r of its token
+    {
+      const bool row_ok = live && valid;
+      const long roff = (long)tok_own * C;
+      const float2 stt = row_ok ? *reinterpret_cast<const float2*>(p.stats + 2 * (long)tok_own) : make_float2(0.f, 0.f);
+      float s1 = 0.f, s2 = 0.f;
+      // pass 1: the two row sums and the parameter gradients; pass 2 re-reads x (L1) and forms the input gradient -- keeping xhat and
+      // dy gamma between the passes would cost 32 registers
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float4 xv = row_ok ? *reinterpret_cast<const float4*>(p.x + roff + 16 * ct + 4 * grp) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gam + 16 * ct + 4 * grp);
+        const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dy = row_ok ? dacc[ct][r] : 0.f;
+          const float xh = (xr[r] - stt.x) * stt.y, dxh = dy * gm4[r];
+          s1 += dxh;
+          s2 += dxh * xh;
+          const float pg = row16_sum(dy * xh), pb = row16_sum(dy);   // over the window's tokens (the 16 lanes of this row group)
+          if (col == 0) {
+            atomicAdd(&dgb[16 * ct + 4 * grp + r], pg);
+            atomicAdd(&dgb[64 + 16 * ct + 4 * grp + r], pb);
+          }
+        }
+      }
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
+      if (row_ok && p.g != nullptr) {
+        const float rowm = m_on_p ? drop_mult(mp, (uint32_t)(tok_own / m_rps)) : 1.0f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int c0 = 16 * ct + 4 * grp;
+          const float4 xv = *reinterpret_cast<const float4*>(p.x + roff + c0);
+          const float4 go = *reinterpret_cast<const float4*>(p.g + roff + c0);
+          const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gam + c0);
+          const float xr[4] = {xv.x, xv.y, xv.z, xv.w}, gr[4] = {go.x, go.y, go.z, go.w};
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xh = (xr[r] - stt.x) * stt.y, dxh = dacc[ct][r] * gm4[r];
+            o[r] = gr[r] + stt.y * (dxh - m1 - xh * m2);
+          }
+          *reinterpret_cast<float4*>(p.g + roff + c0) = make_float4(o[0], o[1], o[2], o[3]);
+          if (p.g_masked != nullptr) {
+            float om[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) om[r] = o[r] * (m_on_e ? rowm * drop_mult(me, (uint32_t)tok_own * C + c0 + r) : rowm);
+            *reinterpret_cast<bf16x4*>(p.g_masked + roff + c0) = pack4(om);
+          }
+        }
+      }
+    }
+  }
+  // ---- bias-table, gamma and beta gradients: registers -> LDS -> one atomic per entry and workgroup
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (tA.ok[r]) atomicAdd(&dbacc[tA.rel[r] + h], dbreg[h][r]);
+  __syncthreads();
+  for (int t = threadIdx.x; t < table; t += NW * 64) atomicAdd(p.dbias_table + t, dbacc[t]);
+  for (int t = threadIdx.x; t < 2 * C; t += NW * 64) atomicAdd((t < C ? p.dgamma : p.dbeta - C) + t, dgb[t]);
+}
+
+int focal_attn_branch_bwd(const AttnGeom& g, const bf16_t* a1, const bf16_t* gm, const bf16_t* wqkv, const float* bqkv, const bf16_t* wproj,
+                          const float* bias_table, bf16_t* dqkv, float* dbias_table, const float* x, const float* stats, const float* gamma,
+                          float* gres, bf16_t* g_masked, const focal_drop_desc* mask, float* dgamma, float* dbeta, const uint32_t* rng,
+                          uint32_t stream_id, float p_attn, hipStream_t st) {
+  BranchBwdParams p;
+  memset(&p, 0, sizeof(p));
+  p.a1 = a1; p.gm = gm; p.wqkv = wqkv; p.bqkv = bqkv; p.wproj = wproj; p.bias_table = bias_table;
+  p.dqkv = dqkv; p.dbias_table = dbias_table;
+  p.x = x; p.stats = stats; p.gamma = gamma; p.g = gres; p.g_masked = g_masked; p.dgamma = dgamma; p.dbeta = dbeta;
+  if (mask) p.mask = *mask;
+  p.geo = g;
+  p.total_windows = g.B * g.nW;
+  constexpr int NW = BRANCH_NW;
+  int blocks = ceil_div(p.total_windows, NW);
+  if (blocks > (NW == 16 ? 256 : 512)) blocks = NW == 16 ? 256 : 512;
+  p.iters = ceil_div(p.total_windows, blocks * NW);
+  p.rng = rng; p.stream = stream_id; p.p_attn = p_attn;
+  FOCAL_LAUNCH((swin_attn_branch_bwd_kernel<NW>), dim3(blocks), dim3(NW * 64), 0, st, p);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}

@@ -470,6 +470,19 @@ def window_attn_qkv_bwd(d, a1, wqkv, bqkv, bias_table, dout, dqkv, dbias_table, 
                                                 _p(dbias_table), _stream()))
 
 
+def window_attn_branch_bwd(d, a1, gm, wqkv, bqkv, wproj, bias_table, dqkv, dbias_table, ln_x, ln_stats, ln_gamma, g, dgamma, dbeta,
+                           g_masked=None, mask=None):
+    """The attention branch's backward of a 64-channel block in one launch (focal_window_attn_branch_bwd): attention backward with q / k / v
+    and dO formed in the kernel + the qkv layer's input gradient + norm1's backward (g += dLN, g_masked, dgamma / dbeta).  g = None: only
+    the parameter gradients (the first block behind a frozen embedding)."""
+    _need_cuda(a1, gm, wqkv, bqkv, wproj, bias_table, dqkv, dbias_table, ln_x, ln_stats, ln_gamma, g, dgamma, dbeta, g_masked)
+    if g_masked is not None:
+        mask = mask or NO_DROP
+    check(_lib.load().focal_window_attn_branch_bwd(C.byref(d), _p(a1), _p(gm), _p(wqkv), _p(bqkv), _p(wproj), _p(bias_table), _p(dqkv),
+                                                   _p(dbias_table), _p(ln_x), _p(ln_stats), _p(ln_gamma), _p(g), _p(g_masked),
+                                                   C.byref(mask) if mask is not None else None, _p(dgamma), _p(dbeta), _stream()))
+
+
 # ------------------------------------------------------------------------------------------------ rows 11-13
 _LOSS_WS = {}
 

@@ -309,6 +309,9 @@ class SwinModEncoder:
             weight_grad(d_proj_b, gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
             do = dc  # reuse the [M, C] CT buffer
             dqkv = torch.empty(M, 3 * Cc, dtype=ct, device=dev)
+            # (the branch's backward as ONE launch -- a wave per window walking its heads, norm1's backward on the accumulators:
+            # focal_window_attn_branch_bwd, tested in tests/test_kernels_gpu.py -- was measured and is not used: 236 vs 193 us at the audio
+            # shape, it needs 180 registers, i.e. half the waves per CU: profiles/r4_attn_branch_bwd.txt)
             if s["qkv"] is None:
                 # 64-channel blocks: q / k / v are recomputed from a1 inside the kernel (see forward), and so is the proj layer's input
                 # gradient -- the kernel forms its head's slice of gm_attn . Wproj per item: no dX launch, no dO tensor
@@ -319,6 +322,8 @@ class SwinModEncoder:
                 ops.linear_bwd_data(d_proj_b, gm_attn, ar.operand(f"{pb}.attn.proj.weight"), None, do)
                 ops.window_attn_bwd(s["d_att"], s["qkv"], ar.master(f"{pb}.attn.relative_position_bias_table"), do, dqkv,
                                     ar.g(f"{pb}.attn.relative_position_bias_table"))
+            # the next consumer of g: block k-1's MLP branch, unless a PatchMerging (handled above) or the embedding comes first
+            nxt = blocks[k - 1]["d_fc2"].out_drop if (k > 0 and k not in merges) else None
             weight_grad(s["d_qkv"], dqkv, s["a1"], ar.g(f"{pb}.attn.qkv.weight"), ar.g(f"{pb}.attn.qkv.bias"))
             da = do
             ln1_fused = fuse_ln_bwd and Cc <= ln_bwd_max_c and ops.bwd_data_ln_supported(cc, 3 * Cc, Cc)
@@ -333,8 +338,6 @@ class SwinModEncoder:
             if mg_dw is None and dw_items:
                 ops.linear_bwd_weight_group(cc, dw_items, exclusive=exclusive_dw)
             du = None
-            # the next consumer of g: block k-1's MLP branch, unless a PatchMerging (handled above) or the embedding comes first
-            nxt = blocks[k - 1]["d_fc2"].out_drop if (k > 0 and k not in merges) else None
             want_gm = nxt is not None or mg_dw is not None
             if want_gm and mg_dw is not None:
                 gm = torch.empty_like(gm)  # the old buffer is an operand of the group launch that has not run yet

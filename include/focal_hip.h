@@ -279,6 +279,18 @@ int focal_window_attn_qkv_fwd(const focal_attn_desc* d, const void* a1, const vo
 int focal_window_attn_qkv_bwd(const focal_attn_desc* d, const void* a1, const void* wqkv, const float* bqkv, const float* bias_table,
                               const void* dout, const void* wproj, void* dqkv, float* dbias_table, void* stream);
 
+/* The backward of the whole attention BRANCH of a 64-channel block in one launch (focal_window_attn_qkv_supported shapes):
+ * focal_window_attn_qkv_bwd (with wproj) followed by focal_linear_bwd_data_ln of the qkv layer -- i.e. SwinTransformerBlock.forward's
+ * `x + drop_path(attn(norm1(x)))` (models/SwinModules.py:294-334) differentiated down to the residual stream.  A wave owns a window and walks
+ * its heads, so dL/d(norm1 output) -- a contraction over all qkv columns -- is complete inside the wave and norm1's backward runs on the
+ * accumulators: g (fp32 residual-stream gradient, NULL: dgamma / dbeta only) += dLN, g_masked (optional) = dtype(g x mask), dgamma / dbeta
+ * / dbias_table accumulated; dqkv [B*H*W, 3C] is still written, for the qkv layer's weight gradient.  gm = dL/d(proj output) x the branch's
+ * mask (what the LayerNorm backward behind it emits as dx_masked). */
+int focal_window_attn_branch_bwd(const focal_attn_desc* d, const void* a1, const void* gm, const void* wqkv, const float* bqkv,
+                                 const void* wproj, const float* bias_table, void* dqkv, float* dbias_table, const float* ln_x,
+                                 const float* ln_stats, const float* ln_gamma, float* g, void* g_masked, const focal_drop_desc* mask,
+                                 float* dgamma, float* dbeta, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ row 5: DeepSense convs
  * ConvBlock (models/ConvModules.py:115-216) on CHANNEL-LAST tokens: activation [B*I*S, C] (row = (b, interval, s)).
  * in-conv: Conv2d(cin -> C, [1,k], stride [1,stride], zero pad `pad_left`) read straight from the reference's NCHW fp32
