@@ -563,72 +563,83 @@ int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
 }
 
 // ============================================================================================================================
-// Round 4: the whole attention-branch backward of a 64-channel block per WINDOW and wave.
+// Round 4: the whole attention-branch backward of a 64-channel block in one launch.
 //
 //   gm (= dL/d(proj output) x mask), a1 (= norm1 output)  ->  dqkv (for the layer's weight gradient), dL/da1 -> norm1's backward:
 //   g += dLN, gm_next = bf16(g x mask of the previous block's MLP branch), dgamma / dbeta, dbias_table.
 //
-// window_attn_bwd_mfma_kernel gives a wave one (window, head) item; what comes behind it -- dX of the qkv Linear and norm1's backward, a
-// GEMM launch that re-reads dqkv (384 B per token) -- contracts over all 192 qkv columns, i.e. over the four heads, which live in four
-// waves.  Here a wave owns a WINDOW and walks its four heads: per head q / k / v and dO are projected as before (the weight fragments
-// now come from swizzled LDS images of Wqkv and Wproj^T, they change with the head), the item math is window_attn_bwd_mfma_kernel's,
-// and the head's dq / dk / dv -- accumulators D[d][token], already the B-operand layout of a 16 x 16 x 16 MFMA -- are contracted with
-// the transposed-read fragments of Wqkv into  dL/da1^T[c][token]  (12 MFMAs per head, 4 accumulator tiles per window).  After the
-// fourth head the lane holds 16 of its token's 64 channels; the row sums of LayerNorm's backward are two cross-row shuffles, nothing is
-// exchanged between waves, and the residual-stream gradient is updated in place at the token's original position (the roll / window
-// partition is index arithmetic, as everywhere).  No [M, C] dL/da1 tensor, no second read of dqkv, one launch less per block.
-#ifndef BRANCH_NW
-#define BRANCH_NW 8
-#endif
+// What follows window_attn_bwd_mfma_kernel in the two-launch form -- dX of the qkv Linear with norm1's backward as its epilogue, a GEMM
+// launch that re-reads dqkv (384 B per token) -- contracts over all 192 qkv columns, i.e. over the four heads, which live in four
+// waves.  The item decomposition of that kernel is kept (a wave = one (window, head); waves 4 s .. 4 s + 3 of a workgroup hold the four
+// heads of one window in every step of the item loop):
+//   1. the item math as before; the head's dq / dk / dv accumulators D[d][token] are already the B operands of a 16 x 16 x 16 MFMA and
+//      are contracted with transposed-read fragments of the head's 48 Wqkv rows (a swizzled LDS image) into the head's PARTIAL
+//      dL/da1^T[c][token] -- 12 MFMAs, 4 accumulator tiles;
+//   2. the partials go to LDS (fp32, [wave][token][channel]), one workgroup barrier;
+//   3. wave h of the window finishes tokens 4 h .. 4 h + 3: 16 lanes per token, 4 channels per lane, the four heads' partials summed;
+//      LayerNorm's two row sums are DPP reductions over the 16 lanes; the residual-stream gradient is updated in place at the token's
+//      original position (roll / window partition are index arithmetic, as everywhere).  x, g and the row statistics of these tokens were
+//      requested at the top of the step, so the phase between the two barriers waits on nothing.
+// No [M, C] dL/da1 tensor, no second read of dqkv, one launch less per block.  (First attempt, wave per WINDOW walking the heads with the
+// LayerNorm on the accumulators and no exchange: 180 registers -> 8 waves per CU, 20 % slower than two launches;
+// profiles/r4_attn_branch_bwd.txt.  This form keeps the 16-wave occupancy of the attention kernel.)
 struct BranchBwdParams {
   const bf16_t* a1; const bf16_t* gm; const bf16_t* wqkv; const float* bqkv; const bf16_t* wproj; const float* bias_table;
   bf16_t* dqkv; float* dbias_table;
   const float* x; const float* stats; const float* gamma; float* g; bf16_t* g_masked; float* dgamma; float* dbeta;
   focal_drop_desc mask;
   AttnGeom geo;
-  int total_windows, iters;
+  int total_items, iters;
   const uint32_t* rng; uint32_t stream; float p_attn;
 };
 
-__device__ __forceinline__ int br_sw(int row) { return ((row >> 1) & 3) << 1; }  // chunk swizzle of the 128-byte-row weight images (as mlp_bwd.hip: sw_tok)
+__device__ __forceinline__ int br_sw(int row) { return ((row >> 1) & 3) << 1; }  // chunk swizzle of the 128-byte-row weight image (as mlp_bwd.hip: sw_tok)
+
+// (32-bit byte offsets off the scalar base pointers: global_load v, v_off, s[base] -- a hoisted 64-bit per-lane pointer costs two registers each)
+template <class T> __device__ __forceinline__ const T& br_ld(const void* base, uint32_t byte_off) { return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off); }
+template <class T> __device__ __forceinline__ T& br_st(void* base, uint32_t byte_off) { return *reinterpret_cast<T*>(static_cast<char*>(base) + byte_off); }
+__device__ __forceinline__ void br_row_fetch(RowRegs& r, const bf16_t* a1, uint32_t tok, bool valid, int grp) {
+  const bf16_t z = (bf16_t)0.f;
+  r.v[0] = r.v[1] = bf16x8{z, z, z, z, z, z, z, z};
+  if (valid) {
+    r.v[0] = br_ld<bf16x8>(a1, tok * 128u + 16u * grp);
+    r.v[1] = br_ld<bf16x8>(a1, tok * 128u + 16u * grp + 64u);
+  }
+}
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void swin_attn_branch_bwd_kernel(const BranchBwdParams p) {
   constexpr int HD = 16, C = 64, P = HD + 4, TILE = 16 * P, HEADS = 4;
+  static_assert(NW % HEADS == 0, "the waves of a window sit side by side");
   __shared__ __attribute__((aligned(16))) bf16_t tiles[NW][4][TILE];
   __shared__ __attribute__((aligned(16))) bf16_t trt[NW][2][16 * 20];
-  __shared__ __attribute__((aligned(16))) char wq_img[192 * 128];   // Wqkv [3C][C] bf16, 16-byte chunk c of row r at c ^ br_sw(r & 15)
-  __shared__ __attribute__((aligned(16))) char wpt_img[64 * 128];   // Wproj^T [C in][C out] bf16, same swizzle
+  __shared__ __attribute__((aligned(16))) char wq_img[192 * 128];        // Wqkv [3C][C] bf16, 16-byte chunk c of row r at c ^ br_sw(r & 15)
+  __shared__ __attribute__((aligned(16))) float part[NW][ATT_NMAX][C];   // partial dL/da1 [wave][token slot][channel], 16-byte chunk s of a row at s ^ slot
   __shared__ __attribute__((aligned(16))) float qb[192], gam[64], dgb[128];
-  __shared__ float btab[256], dbacc[256];
+  __shared__ float dbacc[256];
+  __shared__ int grp_cnt[NW / HEADS][2];  // per window group: partials written / partials consumed (monotonic wave counts)
   const AttnGeom& g = p.geo;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Window slot ws and head h of the wave, for the whole kernel.  Waves w, w + 4, w + 8, w + 12 share a SIMD: they get four different
+  // windows (so that they drift apart and fill each other's waits -- only the four waves of a WINDOW synchronise, through LDS counters,
+  // never the workgroup) and four different heads (the finishing phase below is unequal over the heads).
+  const int ws = wave >> 2, h = (wave + ws) & (HEADS - 1);
   const int grp = lane >> 4, col = lane & 15, tq = col >> 2, tp = col & 3;
   bf16_t* Qt = tiles[wave][0];
   bf16_t* Kt = tiles[wave][1];
   bf16_t* Vt = tiles[wave][2];
   bf16_t* Gt = tiles[wave][3];
   const int table = (2 * g.wh - 1) * (2 * g.ww - 1) * g.heads;
-  // ---- images and small tables
   for (int q = threadIdx.x; q < 192 * 8; q += NW * 64) {
     const int r = q >> 3, c = q & 7;
     *reinterpret_cast<uint4*>(wq_img + r * 128 + ((c ^ br_sw(r & 15)) << 4)) = *reinterpret_cast<const uint4*>(p.wqkv + r * C + c * 8);
   }
-  for (int q = threadIdx.x; q < 64 * 8; q += NW * 64) {
-    const int co = q >> 3, c0 = (q & 7) * 8;  // Wproj[co][c0 .. c0 + 7] -> rows c0 + e, column co of the transposed image
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.wproj + co * C + c0);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int r = c0 + e;
-      *reinterpret_cast<bf16_t*>(wpt_img + r * 128 + (((co >> 3) ^ br_sw(r & 15)) << 4) + (co & 7) * 2) = v[e];
-    }
-  }
   for (int t = threadIdx.x; t < 256; t += NW * 64) {
     dbacc[t] = 0.f;
-    btab[t] = t < table ? p.bias_table[t] : 0.f;
     if (t < 192) qb[t] = p.bqkv[t];
     if (t < 64) gam[t] = p.gamma[t];
     if (t < 128) dgb[t] = 0.f;
+    if (t < 2 * (NW / HEADS)) (&grp_cnt[0][0])[t] = 0;
   }
   __syncthreads();
   // (uniform values into scalar registers: the vector file is the scarce resource of this kernel)
@@ -645,118 +656,140 @@ __global__ __launch_bounds__(NW * 64) void swin_attn_branch_bwd_kernel(const Bra
   const TileIdx tA = make_tile_idx<true>(g, lane);  // rows j = 4 grp + r, column i = col
   const int slot = col, sy = slot / g.ww, sx = slot - sy * g.ww;
   const bool valid = slot < g.N;
-  float dbreg[HEADS][4];
+  float dbreg[4] = {0.f, 0.f, 0.f, 0.f}, badd[4];
 #pragma unroll
-  for (int h = 0; h < HEADS; ++h)
+  for (int r = 0; r < 4; ++r) badd[r] = tA.ok[r] ? p.bias_table[tA.rel[r] + h] : (tA.qpad[r] ? 0.f : -1.0e30f);
+  // Wqkv fragments of the wave's head out of the image: direct (q / k / v projection) and transposed (dL/da1)
+  const char* w_dir = wq_img + (h * 16 + col) * 128 + ((grp ^ br_sw(col)) << 4);                                   // + t 64 rows; kk = 1: ^ 64
+  const char* w_tr = wq_img + (h * 16 + 4 * grp + tq) * 128 + (tp & 1) * 8;                                        // + t 64 rows
+  const int x_tr = ((tp >> 1) ^ br_sw(4 * grp + tq)) << 4;                                                         // ct: ^ (ct << 5)
+  bf16x8 wpt[2];  // A fragments of Wproj^T for the wave's head: row d = col <-> column h 16 + d of Wproj, k = output channels 32 kk + 8 grp ..
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dbreg[h][r] = 0.f;
-  // per-lane byte offsets into the images (the head / gate / tile terms are added per use: they are multiples of the 16-row swizzle period)
-  const int o_dir = col * 128;                                   // direct fragment: row (base + col), chunk (4 kk + grp) ^ br_sw(col)
-  const int x_dir = (grp ^ br_sw(col)) << 4;                     // kk = 0; kk = 1: ^ 64
-  const int o_tr = (4 * grp + tq) * 128 + (tp & 1) * 8;          // transposed fragment: row (base + 4 grp + tq), chunk (2 ct + tp / 2) ^ br_sw(row)
-  const int x_tr = ((tp >> 1) ^ br_sw(4 * grp + tq)) << 4;       // ct = 0; ct: ^ (ct << 5)
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wpt[kk][e] = p.wproj[(long)(32 * kk + 8 * grp + e) * C + h * 16 + col];
+  // the finishing phase: this lane works on token slot 4 h + grp of the window, channels 4 col .. 4 col + 3
+  const int fslot = 4 * h + grp;
+  const bool fvalid = fslot < g.N;
+  const bool fin_any = 4 * h < g.N;  // (scalar) heads past the window's last token have nothing to finish
+  float* part_w = &part[ws * HEADS + h][0][0];
+  const float* part_r = &part[ws * HEADS][fslot][0];
+  int* cnt_w = &grp_cnt[ws][0];
+  int* cnt_r = &grp_cnt[ws][1];
+  auto grp_signal = [&](int* c) {  // DS operations of a wave execute in issue order: the count follows the wave's writes / reads above it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto grp_wait = [&](int* c, int target) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  float dgr[4] = {0.f, 0.f, 0.f, 0.f}, dbr[4] = {0.f, 0.f, 0.f, 0.f};
 
-  auto win_of = [&](int it, bool& live) {
-    const int w = (it * gridDim.x + blockIdx.x) * NW + wave;
-    live = w < p.total_windows;
-    return live ? w : 0;
+  auto item_of = [&](int it, bool& live) {
+    const int win = (it * gridDim.x + blockIdx.x) * (NW / HEADS) + ws;
+    live = win * HEADS < p.total_items;
+    return live ? win : 0;
   };
   RowRegs rx, rgm;
   bool live_n;
-  int win_n = win_of(0, live_n), reg_n = 0, tok_n = 0;
+  int win_n = item_of(0, live_n), reg_n = 0, tok_n = 0;
   tok_n = valid ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
-  row_fetch(rx, p.a1, C, tok_n, valid, lane);
-  row_fetch(rgm, p.gm, C, tok_n, valid, lane);
+  br_row_fetch(rx, p.a1, tok_n, valid, grp);
+  br_row_fetch(rgm, p.gm, tok_n, valid, grp);
+#pragma unroll 1
   for (int it = 0; it < p.iters; ++it) {
     const bool live = live_n;
     const int win = win_n, reg_own = reg_n, tok_own = tok_n;
-    f32x4 dacc[4];
+    // ---- the finishing phase's rows are requested now: they land behind the item math
+    const int tok_f = __shfl(tok_own, fslot, 64);
+    const bool row_ok = live && fvalid;
+    const uint32_t roff = (uint32_t)tok_f * 256u + 16u * col;  // byte offset of the lane's four fp32 channels
+    float2 stt = make_float2(0.f, 0.f);
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), go = xv;
+    if (row_ok) {
+      stt = br_ld<float2>(p.stats, (uint32_t)tok_f * 8u);
+      xv = br_ld<float4>(p.x, roff);
+      if (p.g != nullptr) go = br_ld<float4>(p.g, roff);
+    }
+    wave_lds_fence();
+    // ---- q / k / v and dO of this item
+    {
+      bf16_t* dst[3] = {Qt, Kt, Vt};
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) dacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int h = 0; h < HEADS; ++h) {  // (not unrolled: four copies of the item let the compiler hoist address arithmetic across heads -- 50 spilled registers)
-      wave_lds_fence();  // the previous head's fragment reads are issued before these tile writes
-      // ---- q / k / v and dO of this head
-      {
-        bf16_t* dst[3] = {Qt, Kt, Vt};
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const char* wb = wq_img + (t * 64 + h * 16) * 128 + o_dir;
-          f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb + x_dir), rx.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb + (x_dir ^ 64)), rx.v[1], acc, 0, 0, 0);
-          acc += *reinterpret_cast<const f32x4*>(qb + t * 64 + h * 16 + 4 * grp);
-          const float o[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
-          *reinterpret_cast<bf16x4*>(dst[t] + col * P + 4 * grp) = pack4(o);
-        }
-        const char* wb = wpt_img + (h * 16) * 128 + o_dir;
-        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb + x_dir), rgm.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb + (x_dir ^ 64)), rgm.v[1], acc, 0, 0, 0);
+      for (int t = 0; t < 3; ++t) {
+        const char* wb = w_dir + t * 64 * 128;
+        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb), rx.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>((const char*)((uintptr_t)wb ^ 64)), rx.v[1], acc, 0, 0, 0);
+        acc += *reinterpret_cast<const f32x4*>(qb + t * 64 + h * 16 + 4 * grp);
         const float o[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
-        *reinterpret_cast<bf16x4*>(Gt + col * P + 4 * grp) = pack4(o);
+        *reinterpret_cast<bf16x4*>(dst[t] + col * P + 4 * grp) = pack4(o);
       }
-      wave_lds_fence();
-      if (h == HEADS - 1 && it + 1 < p.iters) {  // the window's rows are consumed: the next window's fly behind this head and the LayerNorm phase
-        win_n = win_of(it + 1, live_n);
-        reg_n = 0;
-        tok_n = valid ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
-        row_fetch(rx, p.a1, C, tok_n, valid, lane);
-        row_fetch(rgm, p.gm, C, tok_n, valid, lane);
-      }
-      // ---- the item (window, h): window_attn_bwd_mfma_kernel's math
+      f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpt[0], rgm.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpt[1], rgm.v[1], acc, 0, 0, 0);
+      const float o[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
+      *reinterpret_cast<bf16x4*>(Gt + col * P + 4 * grp) = pack4(o);
+    }
+    wave_lds_fence();
+    if (it + 1 < p.iters) {  // the next item's rows fly while this one is multiplied
+      win_n = item_of(it + 1, live_n);
+      reg_n = 0;
+      tok_n = valid ? slot_token(g, win_n, sy, sx, &reg_n) : 0;
+      br_row_fetch(rx, p.a1, tok_n, valid, grp);
+      br_row_fetch(rgm, p.gm, tok_n, valid, grp);
+    }
+    // ---- the item (window, h): window_attn_bwd_mfma_kernel's math
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 st, dt;
+    {
       const bf16x4 fq = frag_rows(Qt, P, 0, lane), fk = frag_rows(Kt, P, 0, lane);
       const bf16x4 fv = frag_rows(Vt, P, 0, lane), fg = frag_rows(Gt, P, 0, lane);
-      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 st = mma16x16(fk, fq, z4);  // S^T  : rows j, col i
-      const f32x4 dt = mma16x16(fv, fg, z4);  // dPd^T: rows j, col i
-      float pr[4];
+      st = mma16x16(fk, fq, z4);  // S^T  : rows j, col i
+      dt = mma16x16(fv, fg, z4);  // dPd^T: rows j, col i
+    }
+    float pr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pr[r] = fmaf(st[r], g.scale, badd[r]);
+    if (g.shifted) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float badd = tA.ok[r] ? btab[tA.rel[r] + h] : (tA.qpad[r] ? 0.f : -1.0e30f);
-        pr[r] = fmaf(st[r], g.scale, badd);
+        const int reg_j = __shfl(reg_own, 4 * grp + r, 64);
+        pr[r] += (tA.ok[r] && reg_j != reg_own) ? -100.0f : 0.f;
       }
-      if (g.shifted) {
+    }
+    float mx = fmaxf(fmaxf(pr[0], pr[1]), fmaxf(pr[2], pr[3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int reg_j = __shfl(reg_own, 4 * grp + r, 64);
-          pr[r] += (tA.ok[r] && reg_j != reg_own) ? -100.0f : 0.f;
-        }
-      }
-      float mx = fmaxf(fmaxf(pr[0], pr[1]), fmaxf(pr[2], pr[3]));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
+    for (int r = 0; r < 4; ++r) { pr[r] = __expf(pr[r] - mx); sum += pr[r]; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    const uint32_t ebase = (((uint32_t)win * g.heads + h) * g.N + col) * g.N + 4 * grp;  // element (i = col, j = 4 grp + r)
+    float dsT[4], pdT[4], dot = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { pr[r] = __expf(pr[r] - mx); sum += pr[r]; }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = __builtin_amdgcn_rcpf(sum);
-      const uint32_t ebase = (((uint32_t)win * g.heads + h) * g.N + col) * g.N + 4 * grp;  // element (i = col, j = 4 grp + r)
-      float dsT[4], pdT[4], dot = 0.f;
+    for (int r = 0; r < 4; ++r) {
+      pr[r] *= inv;
+      const float mlt = (drop_on && tA.ok[r]) ? drop_mult(dc, ebase + r) : 1.f;
+      pdT[r] = pr[r] * mlt;
+      dsT[r] = dt[r] * mlt;
+      dot += pr[r] * dsT[r];
+    }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pr[r] *= inv;
-        const float mlt = (drop_on && tA.ok[r]) ? drop_mult(dc, ebase + r) : 1.f;
-        pdT[r] = pr[r] * mlt;
-        dsT[r] = dt[r] * mlt;
-        dot += pr[r] * dsT[r];
-      }
-      dot += __shfl_xor(dot, 16, 64);
-      dot += __shfl_xor(dot, 32, 64);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dsT[r] = pr[r] * (dsT[r] - dot);
-      if (live) {  // (h is wave-uniform: a scalar branch picks the head's four accumulators -- no dynamically indexed register array)
-#pragma unroll
-        for (int hh = 0; hh < HEADS; ++hh)
-          if (h == hh) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dbreg[hh][r] += dsT[r];
-          }
-      }
-      const bf16x4 bdsT = pack4(dsT), bpdT = pack4(pdT);
-      bf16_t* tw = trt[wave][0];
-      *reinterpret_cast<bf16x4*>(tw + col * 20 + 4 * grp) = bdsT;
-      *reinterpret_cast<bf16x4*>(tw + 16 * 20 + col * 20 + 4 * grp) = bpdT;
-      wave_lds_fence();
+    for (int r = 0; r < 4; ++r) {
+      dsT[r] = pr[r] * (dsT[r] - dot);
+      if (live) dbreg[r] += dsT[r];
+    }
+    const bf16x4 bdsT = pack4(dsT), bpdT = pack4(pdT);
+    bf16_t* tw = trt[wave][0];
+    *reinterpret_cast<bf16x4*>(tw + col * 20 + 4 * grp) = bdsT;
+    *reinterpret_cast<bf16x4*>(tw + 16 * 20 + col * 20 + 4 * grp) = bpdT;
+    wave_lds_fence();
+    bf16x4 bt[3];
+    {
       const bf16x4 bds = frag_cols(tw, 20, 0, lane);
       const bf16x4 bpd = frag_cols(tw + 16 * 20, 20, 0, lane);
       const f32x4 dq = mma16x16(frag_cols(Kt, P, 0, lane), bdsT, z4);  // dQ^T[d][i]
@@ -766,86 +799,76 @@ __global__ __launch_bounds__(NW * 64) void swin_attn_branch_bwd_kernel(const Bra
       const float a[4] = {valid ? dq[0] * g.scale : 0.f, valid ? dq[1] * g.scale : 0.f, valid ? dq[2] * g.scale : 0.f, valid ? dq[3] * g.scale : 0.f};
       const float b[4] = {valid ? dk[0] * g.scale : 0.f, valid ? dk[1] * g.scale : 0.f, valid ? dk[2] * g.scale : 0.f, valid ? dk[3] * g.scale : 0.f};
       const float c[4] = {valid ? dv[0] : 0.f, valid ? dv[1] : 0.f, valid ? dv[2] : 0.f, valid ? dv[3] : 0.f};
-      const bf16x4 bq = pack4(a), bk = pack4(b), bv = pack4(c);
-      if (live && valid) {
-        bf16_t* dst = p.dqkv + (long)tok_own * 3 * C + h * HD + 4 * grp;
-        *reinterpret_cast<bf16x4*>(dst) = bq;
-        *reinterpret_cast<bf16x4*>(dst + C) = bk;
-        *reinterpret_cast<bf16x4*>(dst + 2 * C) = bv;
-      }
-      // ---- dL/da1^T[c][token] += Wqkv_t[h 16 + d][c] . dT^T[d][token]: the accumulators above ARE the B operands (k = d = 4 grp + e)
-      const bf16x4 bt[3] = {bq, bk, bv};
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const char* wb = wq_img + (t * 64 + h * 16) * 128 + o_tr;
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const bf16x4 wf = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(wb + (x_tr ^ (ct << 5))));
-          dacc[ct] = mma16x16(wf, bt[t], dacc[ct]);
-        }
-      }
+      bt[0] = pack4(a); bt[1] = pack4(b); bt[2] = pack4(c);
     }
-    // ---- norm1's backward on this window's rows: lane (grp, slot) holds channels 16 ct + 4 grp + r of its token
-    {
-      const bool row_ok = live && valid;
-      const long roff = (long)tok_own * C;
-      const float2 stt = row_ok ? *reinterpret_cast<const float2*>(p.stats + 2 * (long)tok_own) : make_float2(0.f, 0.f);
-      float s1 = 0.f, s2 = 0.f;
-      // pass 1: the two row sums and the parameter gradients; pass 2 re-reads x (L1) and forms the input gradient -- keeping xhat and
-      // dy gamma between the passes would cost 32 registers
+    if (live && valid) {
+      const uint32_t doff = (uint32_t)tok_own * 384u + (uint32_t)(h * HD + 4 * grp) * 2u;
+      br_st<bf16x4>(p.dqkv, doff) = bt[0];
+      br_st<bf16x4>(p.dqkv, doff + 128u) = bt[1];
+      br_st<bf16x4>(p.dqkv, doff + 256u) = bt[2];
+    }
+    // ---- this head's part of dL/da1^T[c][token] = sum_d Wqkv_t[h 16 + d][c] . dT^T[d][token]: the accumulators ARE the B operands (k = d = 4 grp + e)
+    f32x4 dacc[4] = {z4, z4, z4, z4};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const char* wb = w_tr + t * 64 * 128;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        const float4 xv = row_ok ? *reinterpret_cast<const float4*>(p.x + roff + 16 * ct + 4 * grp) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gam + 16 * ct + 4 * grp);
-        const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float dy = row_ok ? dacc[ct][r] : 0.f;
-          const float xh = (xr[r] - stt.x) * stt.y, dxh = dy * gm4[r];
-          s1 += dxh;
-          s2 += dxh * xh;
-          const float pg = row16_sum(dy * xh), pb = row16_sum(dy);   // over the window's tokens (the 16 lanes of this row group)
-          if (col == 0) {
-            atomicAdd(&dgb[16 * ct + 4 * grp + r], pg);
-            atomicAdd(&dgb[64 + 16 * ct + 4 * grp + r], pb);
-          }
-        }
+        const bf16x4 wf = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(wb + (x_tr ^ (ct << 5))));
+        dacc[ct] = mma16x16(wf, bt[t], dacc[ct]);
       }
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    }
+    grp_wait(cnt_r, HEADS * it);  // the previous step's partials have been read by the window's four waves
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<f32x4*>(part_w + col * C + (((4 * ct + grp) ^ col) << 2)) = dacc[ct];
+    grp_signal(cnt_w);
+    // ---- norm1's backward on token slot 4 h + grp of the window, channels 4 col .. + 3
+    if (!fin_any) {
+      grp_signal(cnt_r);
+    } else {
+      grp_wait(cnt_w, HEADS * (it + 1));
+      f32x4 da = *reinterpret_cast<const f32x4*>(part_r + ((col ^ fslot) << 2));
+#pragma unroll
+      for (int hh = 1; hh < HEADS; ++hh) da += *reinterpret_cast<const f32x4*>(part_r + hh * ATT_NMAX * C + ((col ^ fslot) << 2));
+      grp_signal(cnt_r);
+      const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gam + 4 * col);
+      const float xr[4] = {xv.x, xv.y, xv.z, xv.w}, gr[4] = {go.x, go.y, go.z, go.w};
+      float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dy = row_ok ? da[r] : 0.f;
+        xh[r] = (xr[r] - stt.x) * stt.y;
+        dxh[r] = dy * gm4[r];
+        s1 += dxh[r];
+        s2 += dxh[r] * xh[r];
+        dgr[r] += dy * xh[r];
+        dbr[r] += dy;
+      }
+      s1 = row16_sum(s1);
+      s2 = row16_sum(s2);
       const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
       if (row_ok && p.g != nullptr) {
-        const float rowm = m_on_p ? drop_mult(mp, (uint32_t)(tok_own / m_rps)) : 1.0f;
+        float o[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const int c0 = 16 * ct + 4 * grp;
-          const float4 xv = *reinterpret_cast<const float4*>(p.x + roff + c0);
-          const float4 go = *reinterpret_cast<const float4*>(p.g + roff + c0);
-          const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gam + c0);
-          const float xr[4] = {xv.x, xv.y, xv.z, xv.w}, gr[4] = {go.x, go.y, go.z, go.w};
-          float o[4];
+        for (int r = 0; r < 4; ++r) o[r] = gr[r] + stt.y * (dxh[r] - m1 - xh[r] * m2);
+        br_st<float4>(p.g, roff) = make_float4(o[0], o[1], o[2], o[3]);
+        if (p.g_masked != nullptr) {
+          const float rowm = m_on_p ? drop_mult(mp, (uint32_t)(tok_f / m_rps)) : 1.0f;
+          float om[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float xh = (xr[r] - stt.x) * stt.y, dxh = dacc[ct][r] * gm4[r];
-            o[r] = gr[r] + stt.y * (dxh - m1 - xh * m2);
-          }
-          *reinterpret_cast<float4*>(p.g + roff + c0) = make_float4(o[0], o[1], o[2], o[3]);
-          if (p.g_masked != nullptr) {
-            float om[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) om[r] = o[r] * (m_on_e ? rowm * drop_mult(me, (uint32_t)tok_own * C + c0 + r) : rowm);
-            *reinterpret_cast<bf16x4*>(p.g_masked + roff + c0) = pack4(om);
-          }
+          for (int r = 0; r < 4; ++r) om[r] = o[r] * (m_on_e ? rowm * drop_mult(me, (uint32_t)tok_f * C + 4 * col + r) : rowm);
+          br_st<bf16x4>(p.g_masked, roff >> 1) = pack4(om);
         }
       }
     }
   }
   // ---- bias-table, gamma and beta gradients: registers -> LDS -> one atomic per entry and workgroup
 #pragma unroll
-  for (int h = 0; h < HEADS; ++h)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (tA.ok[r]) atomicAdd(&dbacc[tA.rel[r] + h], dbreg[h][r]);
+  for (int r = 0; r < 4; ++r) {
+    if (tA.ok[r]) atomicAdd(&dbacc[tA.rel[r] + h], dbreg[r]);
+    atomicAdd(&dgb[4 * col + r], dgr[r]);
+    atomicAdd(&dgb[64 + 4 * col + r], dbr[r]);
+  }
   __syncthreads();
   for (int t = threadIdx.x; t < table; t += NW * 64) atomicAdd(p.dbias_table + t, dbacc[t]);
   for (int t = threadIdx.x; t < 2 * C; t += NW * 64) atomicAdd((t < C ? p.dgamma : p.dbeta - C) + t, dgb[t]);
@@ -855,6 +878,7 @@ int focal_attn_branch_bwd(const AttnGeom& g, const bf16_t* a1, const bf16_t* gm,
                           const float* bias_table, bf16_t* dqkv, float* dbias_table, const float* x, const float* stats, const float* gamma,
                           float* gres, bf16_t* g_masked, const focal_drop_desc* mask, float* dgamma, float* dbeta, const uint32_t* rng,
                           uint32_t stream_id, float p_attn, hipStream_t st) {
+  if ((long)g.B * g.H * g.W * 384 >= (1L << 32)) return FOCAL_EUNSUPPORTED;  // the kernel addresses rows with 32-bit byte offsets
   BranchBwdParams p;
   memset(&p, 0, sizeof(p));
   p.a1 = a1; p.gm = gm; p.wqkv = wqkv; p.bqkv = bqkv; p.wproj = wproj; p.bias_table = bias_table;
@@ -862,11 +886,11 @@ int focal_attn_branch_bwd(const AttnGeom& g, const bf16_t* a1, const bf16_t* gm,
   p.x = x; p.stats = stats; p.gamma = gamma; p.g = gres; p.g_masked = g_masked; p.dgamma = dgamma; p.dbeta = dbeta;
   if (mask) p.mask = *mask;
   p.geo = g;
-  p.total_windows = g.B * g.nW;
-  constexpr int NW = BRANCH_NW;
-  int blocks = ceil_div(p.total_windows, NW);
-  if (blocks > (NW == 16 ? 256 : 512)) blocks = NW == 16 ? 256 : 512;
-  p.iters = ceil_div(p.total_windows, blocks * NW);
+  p.total_items = g.B * g.nW * 4;
+  constexpr int NW = 16;
+  int blocks = ceil_div(p.total_items, NW);
+  if (blocks > 256) blocks = 256;  // persistent, one workgroup per CU (148 KB of LDS), as focal_attn_mfma_bwd
+  p.iters = ceil_div(p.total_items, blocks * NW);
   p.rng = rng; p.stream = stream_id; p.p_attn = p_attn;
   FOCAL_LAUNCH((swin_attn_branch_bwd_kernel<NW>), dim3(blocks), dim3(NW * 64), 0, st, p);
   FOCAL_LAUNCH_CHECK();

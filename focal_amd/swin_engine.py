@@ -309,9 +309,9 @@ class SwinModEncoder:
             weight_grad(d_proj_b, gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
             do = dc  # reuse the [M, C] CT buffer
             dqkv = torch.empty(M, 3 * Cc, dtype=ct, device=dev)
-            # (the branch's backward as ONE launch -- a wave per window walking its heads, norm1's backward on the accumulators:
-            # focal_window_attn_branch_bwd, tested in tests/test_kernels_gpu.py -- was measured and is not used: 236 vs 193 us at the audio
-            # shape, it needs 180 registers, i.e. half the waves per CU: profiles/r4_attn_branch_bwd.txt)
+            # (the branch's backward as ONE launch -- focal_window_attn_branch_bwd, tested in tests/test_kernels_gpu.py -- was measured in
+            # two forms and is not used: 236 us (a wave per window, 180 registers) and 207 us (four waves per window, partials through
+            # LDS) against 191 us for these two launches at the audio shape: profiles/r4_attn_branch_bwd.txt)
             if s["qkv"] is None:
                 # 64-channel blocks: q / k / v are recomputed from a1 inside the kernel (see forward), and so is the proj layer's input
                 # gradient -- the kernel forms its head's slice of gm_attn . Wproj per item: no dX launch, no dO tensor

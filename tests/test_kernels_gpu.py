@@ -491,7 +491,7 @@ def test_window_attention_with_qkv_projection_folded_in(ops, H, W, sh, sw, p_att
     dq_f, dtb_f = torch.empty_like(dqkv), torch.zeros_like(table)
     ops.window_attn_qkv_bwd(d, a1, wqkv, bqkv, table, gy, dq_f, dtb_f, wproj=wproj)
     assert rel_err(dq_f.float(), dq_u.float()) < 2e-3 and rel_err(dtb_f, dtb_u) < 2e-3   # same products, same bf16 rounding of dO
-    # ... and the whole branch backward in one launch: + the qkv layer's input gradient + norm1's backward (window per wave)
+    # ... and the whole branch backward in one launch: + the qkv layer's input gradient + norm1's backward (the window's four waves exchange dL/da1 through LDS)
     x = rnd(M, C, seed=137) * 1.5 + 0.2
     gamma, beta = rnd(C, seed=138) * 0.1 + 1.0, rnd(C, seed=139) * 0.1
     _, stats = ops.layernorm_fwd(x, gamma, beta, ct)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stage-0 attention-branch backward at the step's shapes (B = 256 windows, both views): the two launches the engine uses --
 focal_window_attn_qkv_bwd (q / k / v and dO formed in the kernel) + focal_linear_bwd_data_ln (dX of qkv + norm1's backward) -- against
-the one-launch form focal_window_attn_branch_bwd (a wave owns a window and walks its heads).  Cold operands (rotated through > 600 MB).
+the one-launch form focal_window_attn_branch_bwd (the window's four heads on four waves, dL/da1 partials summed through LDS).  Cold operands (rotated through > 600 MB).
   python tools/mb_attn_branch.py [iters]      FOCAL_MB_ONLY=two|one for rocprofv3 --pmc passes"""
 import os
 import sys
