@@ -590,6 +590,9 @@ def dump_trace(a, step):
         out[tag] = {"same_sequence": same, "kernel_ms_per_step": sum(g["us_per_step"] for g in groups) / 1e3,
                     "kernels": {g["kernel"]: {"calls_per_step": g["calls_per_step"], "avg_us": g["avg_us"], "bytes_per_launch": g["bytes_per_launch"],
                                               "flops_per_launch": g["flops_per_launch"], "bound": g["bound"]} for g in groups}}
+        if tag == "dispatch" and same:  # every launch position of the step, in launch order (median over the steps): tools/step_instances.py reads this
+            out["launches"] = [dict(kernel=r["kernel"], inst=r["inst"], wgs=r["wgs"], threads=r["threads"], bytes=r["bytes"], flops=r["flops"],
+                                    us=_median([s[j]["us"] for s in per_step])) for j, r in enumerate(per_step[0])]
     json.dump(out, open(a.trace_dump, "w"), indent=1)
 
 

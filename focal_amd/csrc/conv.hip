@@ -521,7 +521,7 @@ __global__ void unpack_add_multi_kernel(PackTable t) {
   const float* src = reinterpret_cast<const float*>(q.src);
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
     const int c = e % q.C, b = (e / q.C) % q.B, a = e / ((long)q.B * q.C);  // dst[a][b][c] += src[a][c][b]
-    dst[e] += src[((long)a * q.C + c) * q.B + b];
+    atomicAdd(dst + e, src[((long)a * q.C + c) * q.B + b]);  // (the two views' passes of a step end on different streams and add into the same gradient)
   }
 }
 static int pack_table(int n, const focal_pack_entry* e, PackTable* t, long* most) {
