@@ -857,10 +857,11 @@ def test_masked_gradient_copy_matches_forward_mask(ops):
     assert torch.equal(dxm4, dx4 * y)
 
 
-@pytest.mark.parametrize("B,H", [(40, 256), (16, 128)])
+@pytest.mark.parametrize("B,H", [(40, 256), (43, 256), (600, 256), (16, 128)])
 def test_gru_whole_sequence_kernels_match_per_step_path(ops, B, H):
     """focal_gru_seq_fwd / _bwd (one launch per layer, both directions, bf16 W_hh) against the per-step GEMM + gate kernels
-    given the same bf16 operands; B = 40 exercises the partial 16-sample tile."""
+    given the same bf16 operands.  H = 256, B = 40 / 43: two lanes per sample, 8 samples per workgroup (43: a ragged last workgroup, its
+    spare lanes recompute the last sample); B = 600: 16 samples per workgroup (the grid of the 8-sample form would exceed 64), ragged."""
     T = 10
     f32c, bfc = ops.code(torch.float32), ops.code(torch.bfloat16)
     gd = ops.GRUDesc(B, T, H)
