@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(const T* __restric
       float p[NT];
       att_row_probs<HD, NT>(g, q, lw, pitch, C, h, i, bias_table, regs + wl * g.N, p);
       if (drop_on) {
-        const uint32_t base = (((uint32_t)(win0 + wl) * g.heads + h) * g.N + i) * g.N;
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) if (j < g.N) p[j] *= drop_mult(dc, base + j);
+        const uint32_t wh = (uint32_t)(win0 + wl) * g.heads + h;
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) if (j < g.N) p[j] *= att_drop1(dc, wh, i, j);
       }
       float o[HD];
 #pragma unroll
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
       }
       float p[NT], dp[NT];
       att_row_probs<HD, NT>(g, q, lw, pitch, C, h, i, bias_table, regs + wl * g.N, p);
-      const uint32_t base = (((uint32_t)(win0 + wl) * g.heads + h) * g.N + i) * g.N;
+      const uint32_t drop_wh = (uint32_t)(win0 + wl) * g.heads + h;
       float dot = 0.f;
       _Pragma("unroll") for (int j = 0; j < NT; ++j) if (j < g.N) {
         const float* vj = lw + j * pitch + 2 * C + h * HD;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
           const float4 vv = *reinterpret_cast<const float4*>(vj + d);
           s += go[d] * vv.x + go[d + 1] * vv.y + go[d + 2] * vv.z + go[d + 3] * vv.w;
         }
-        const float dm = drop_on ? drop_mult(dc, base + j) : 1.0f;
+        const float dm = drop_on ? att_drop1(dc, drop_wh, i, j) : 1.0f;
         dp[j] = s * dm;                                             // dL/dP (through the dropout mask)
         Pd[((wl * g.heads + h) * g.N + i) * g.N + j] = p[j] * dm;   // what multiplied V in forward
         dot += p[j] * dp[j];

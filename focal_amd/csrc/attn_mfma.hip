@@ -12,10 +12,21 @@
 typedef __attribute__((address_space(3))) bf16x4* lds_b4;
 
 __device__ __forceinline__ f32x4 mma16x16(bf16x4 a, bf16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+// Four fp32 -> bf16x4 as TWO v_cvt_pk_bf16_f32 (element-wise casts compile to four single conversions + two byte permutes: with ~9 such packs
+// per item that was a fifth of the backward kernel's vector instructions).  pack4z: the same, zero unless `keep` -- the select runs on the two
+// packed words, not on the four floats.
+typedef float att_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 att_b2 __attribute__((ext_vector_type(2)));
+typedef uint32_t att_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x4 pack4(const float* v) {
-  bf16x4 o;
-  o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
-  return o;
+  const att_b2 lo = __builtin_convertvector(att_f2{v[0], v[1]}, att_b2), hi = __builtin_convertvector(att_f2{v[2], v[3]}, att_b2);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+__device__ __forceinline__ bf16x4 pack4z(const float* v, bool keep) {
+  att_u2 w = __builtin_bit_cast(att_u2, pack4(v));
+  w[0] = keep ? w[0] : 0u;
+  w[1] = keep ? w[1] : 0u;
+  return __builtin_bit_cast(bf16x4, w);
 }
 // direct fragment: rows = tokens; lane (row = l&15) holds d = kk*16 + 4*(l>>4) .. +3
 __device__ __forceinline__ bf16x4 frag_rows(const bf16_t* tile, int P, int kk, int lane) {
@@ -163,15 +174,16 @@ __device__ __forceinline__ QkvFrags qkv_frags(const bf16_t* wqkv, const float* b
   return f;
 }
 struct RowRegs { bf16x8 v[2]; };  // this lane's slot: channels 8 (l >> 4) .. + 7 and 32 + 8 (l >> 4) .. of its token's a1 row
-__device__ __forceinline__ void row_fetch(RowRegs& r, const bf16_t* a1, int C, int tok_own, bool valid, int lane) {
-  const bf16_t z = (bf16_t)0.f;
-  r.v[0] = r.v[1] = bf16x8{z, z, z, z, z, z, z, z};
-  if (valid) {
-    r.v[0] = *reinterpret_cast<const bf16x8*>(a1 + (long)tok_own * C + 8 * (lane >> 4));
-    r.v[1] = *reinterpret_cast<const bf16x8*>(a1 + (long)tok_own * C + 32 + 8 * (lane >> 4));
-  }
+// (a padded slot reads the row of token 0 -- `tok_own` is 0 there -- instead of being zero-filled under a branch: what is projected from it is
+// either zeroed behind the product (backward: ZERO_PAD, the dO tile) or never used (forward); 16 moves and a divergent region less per item)
+__device__ __forceinline__ void row_fetch(RowRegs& r, const bf16_t* a1, int C, int tok_own, bool /*valid*/, int lane) {
+  r.v[0] = *reinterpret_cast<const bf16x8*>(a1 + (long)tok_own * C + 8 * (lane >> 4));
+  r.v[1] = *reinterpret_cast<const bf16x8*>(a1 + (long)tok_own * C + 32 + 8 * (lane >> 4));
 }
-template <int P> __device__ __forceinline__ void qkv_project(bf16_t* Qt, bf16_t* Kt, bf16_t* Vt, const QkvFrags& f, const RowRegs& x, bool valid, int lane) {
+// ZERO_PAD: rows of padded window slots are written as zeros (the backward kernel needs them: a padded query's softmax row meets Q / dO rows).
+// The forward kernel does not: padded keys are masked by the additive -1e30, padded queries are never stored, and what stands in
+// those rows -- the projection's bias, the input row is zero -- is finite.
+template <int P, bool ZERO_PAD = true> __device__ __forceinline__ void qkv_project(bf16_t* Qt, bf16_t* Kt, bf16_t* Vt, const QkvFrags& f, const RowRegs& x, bool valid, int lane) {
   bf16_t* dst[3] = {Qt, Kt, Vt};
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
@@ -179,8 +191,8 @@ template <int P> __device__ __forceinline__ void qkv_project(bf16_t* Qt, bf16_t*
     f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t][0], x.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[t][1], x.v[1], acc, 0, 0, 0);
     acc += *reinterpret_cast<const f32x4*>(f.bias + t * 64);
-    float o[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
-    *reinterpret_cast<bf16x4*>(dst[t] + (lane & 15) * P + 4 * (lane >> 4)) = pack4(o);
+    const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<bf16x4*>(dst[t] + (lane & 15) * P + 4 * (lane >> 4)) = ZERO_PAD ? pack4z(o, valid) : pack4(o);
   }
 }
 
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
     const bool edge = g.shifted;  // (restricting this to the windows that really mix mask regions costs more in index arithmetic than it saves)
     wave_lds_fence();  // previous iteration's fragment reads are issued before these tile writes
     if constexpr (FUSE) {
-      qkv_project<P>(Qt, Kt, Vt, qf, rx, slot < g.N, lane);
+      qkv_project<P, false>(Qt, Kt, Vt, qf, rx, slot < g.N, lane);
     } else {
       tile_commit<HD>(Qt, rq, lane);
       tile_commit<HD>(Kt, rk, lane);
@@ -273,18 +285,42 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
     f32x4 st = {0.f, 0.f, 0.f, 0.f};  // S^T: rows j (keys), col i (query)
 #pragma unroll
     for (int kk = 0; kk < HD / 16; ++kk) st = mma16x16(frag_rows(Kt, P, kk, lane), frag_rows(Qt, P, kk, lane), st);
-    float p[4] = {st[0], st[1], st[2], st[3]};
     if (h != h_cur) {
       h_cur = h;
+      // bias + validity of this lane's four (i, j) as ONE additive constant per head (as the backward kernel): the relative-position bias inside
+      // the window, 0 on a padded query row (kept finite), -1e30 on a padded key
 #pragma unroll
-      for (int r = 0; r < 4; ++r) biasA[r] = tA.ok[r] ? bias_table[tA.rel[r] + h] : 0.f;
+      for (int r = 0; r < 4; ++r) biasA[r] = tA.ok[r] ? bias_table[tA.rel[r] + h] : (tA.qpad[r] ? 0.f : -1.0e30f);
     }
-    tile_softmax<true>(g, tA, p, biasA, reg_own, edge);
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = fmaf(st[r], g.scale, biasA[r]);
+    if (edge) {  // (wave-uniform) SwinModules.py:287: -100 between tokens of different mask regions; the query's region is the lane's own
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int reg_j = __shfl(reg_own, 4 * (lane >> 4) + r, 64);
+        p[r] += (tA.ok[r] && reg_j != reg_own) ? -100.0f : 0.f;
+      }
+    }
+    {  // softmax over the keys of query i = lane & 15: in-lane over r, then across the four row groups
+      float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[r] = __expf(p[r] - m); sum += p[r]; }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] *= inv;
+    }
     const int i = lane & 15;
     if (drop_on) {
-      const uint32_t base = (((uint32_t)win * g.heads + h) * g.N + i) * g.N;
+      float dm[4];
+      att_drop4(dc, att_drop_q((uint32_t)win * g.heads + h, i, lane >> 4), dm);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[r] *= drop_mult(dc, base + 4 * (lane >> 4) + r);
+      for (int r = 0; r < 4; ++r) p[r] *= dm[r];
     }
     const bf16x4 pb = pack4(p);
 #pragma unroll
@@ -423,9 +459,8 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
     if constexpr (PROJ) {  // dO^T[d][slot] = sum_c Wproj[c][h 16 + d] dout[token(slot)][c]: 4 consecutive d of one token per lane, as qkv_project
       f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpt[0], rgm.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpt[1], rgm.v[1], acc, 0, 0, 0);
-      const bool valid = slot < g.N;
-      const float o4[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
-      *reinterpret_cast<bf16x4*>(Gt + col * P + 4 * grp) = pack4(o4);
+      const float o4[4] = {acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<bf16x4*>(Gt + col * P + 4 * grp) = pack4z(o4, slot < g.N);
     } else {
       tile_commit<HD>(Gt, rg, lane);
     }
@@ -479,12 +514,13 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
     sum += __shfl_xor(sum, 32, 64);
     const float inv = __builtin_amdgcn_rcpf(sum);
     // ---- dP (through the dropout mask), the row dot, dS^T and Pd^T
-    const uint32_t ebase = (((uint32_t)win * g.heads + h) * g.N + col) * g.N + 4 * grp;  // element (i = col, j = 4 grp + r)
+    float dm[4] = {1.f, 1.f, 1.f, 1.f};
+    if (drop_on) att_drop4(dc, att_drop_q((uint32_t)win * g.heads + h, col, grp), dm);  // (i = col, j = 4 grp + r)
     float dsT[4], pdT[4], dot = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       p[r] *= inv;
-      const float mlt = (drop_on && tA.ok[r]) ? drop_mult(dc, ebase + r) : 1.f;
+      const float mlt = tA.ok[r] ? dm[r] : 1.f;
       pdT[r] = p[r] * mlt;
       dsT[r] = dt[r] * mlt;      // dP
       dot += p[r] * dsT[r];
@@ -598,13 +634,9 @@ __device__ __forceinline__ int br_sw(int row) { return ((row >> 1) & 3) << 1; } 
 // (32-bit byte offsets off the scalar base pointers: global_load v, v_off, s[base] -- a hoisted 64-bit per-lane pointer costs two registers each)
 template <class T> __device__ __forceinline__ const T& br_ld(const void* base, uint32_t byte_off) { return *reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off); }
 template <class T> __device__ __forceinline__ T& br_st(void* base, uint32_t byte_off) { return *reinterpret_cast<T*>(static_cast<char*>(base) + byte_off); }
-__device__ __forceinline__ void br_row_fetch(RowRegs& r, const bf16_t* a1, uint32_t tok, bool valid, int grp) {
-  const bf16_t z = (bf16_t)0.f;
-  r.v[0] = r.v[1] = bf16x8{z, z, z, z, z, z, z, z};
-  if (valid) {
-    r.v[0] = br_ld<bf16x8>(a1, tok * 128u + 16u * grp);
-    r.v[1] = br_ld<bf16x8>(a1, tok * 128u + 16u * grp + 64u);
-  }
+__device__ __forceinline__ void br_row_fetch(RowRegs& r, const bf16_t* a1, uint32_t tok, bool /*valid*/, int grp) {
+  r.v[0] = br_ld<bf16x8>(a1, tok * 128u + 16u * grp);
+  r.v[1] = br_ld<bf16x8>(a1, tok * 128u + 16u * grp + 64u);
 }
 
 template <int NW>
@@ -722,13 +754,13 @@ __global__ __launch_bounds__(NW * 64) void swin_attn_branch_bwd_kernel(const Bra
         f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb), rx.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>((const char*)((uintptr_t)wb ^ 64)), rx.v[1], acc, 0, 0, 0);
         acc += *reinterpret_cast<const f32x4*>(qb + t * 64 + h * 16 + 4 * grp);
-        const float o[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
-        *reinterpret_cast<bf16x4*>(dst[t] + col * P + 4 * grp) = pack4(o);
+        const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<bf16x4*>(dst[t] + col * P + 4 * grp) = pack4z(o, valid);
       }
       f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpt[0], rgm.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpt[1], rgm.v[1], acc, 0, 0, 0);
-      const float o[4] = {valid ? acc[0] : 0.f, valid ? acc[1] : 0.f, valid ? acc[2] : 0.f, valid ? acc[3] : 0.f};
-      *reinterpret_cast<bf16x4*>(Gt + col * P + 4 * grp) = pack4(o);
+      const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<bf16x4*>(Gt + col * P + 4 * grp) = pack4z(o, valid);
     }
     wave_lds_fence();
     if (it + 1 < p.iters) {  // the next item's rows fly while this one is multiplied
@@ -766,12 +798,13 @@ __global__ __launch_bounds__(NW * 64) void swin_attn_branch_bwd_kernel(const Bra
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = __builtin_amdgcn_rcpf(sum);
-    const uint32_t ebase = (((uint32_t)win * g.heads + h) * g.N + col) * g.N + 4 * grp;  // element (i = col, j = 4 grp + r)
+    float dm[4] = {1.f, 1.f, 1.f, 1.f};
+    if (drop_on) att_drop4(dc, att_drop_q((uint32_t)win * g.heads + h, col, grp), dm);  // (i = col, j = 4 grp + r)
     float dsT[4], pdT[4], dot = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       pr[r] *= inv;
-      const float mlt = (drop_on && tA.ok[r]) ? drop_mult(dc, ebase + r) : 1.f;
+      const float mlt = tA.ok[r] ? dm[r] : 1.f;
       pdT[r] = pr[r] * mlt;
       dsT[r] = dt[r] * mlt;
       dot += pr[r] * dsT[r];
@@ -796,10 +829,10 @@ __global__ __launch_bounds__(NW * 64) void swin_attn_branch_bwd_kernel(const Bra
       const f32x4 dk = mma16x16(frag_cols(Qt, P, 0, lane), bds, z4);   // dK^T[d][j]
       const f32x4 dv = mma16x16(frag_cols(Gt, P, 0, lane), bpd, z4);   // dV^T[d][j]
       // padded slots carry garbage (a padded query's softmax row): zeroed here, they feed the dL/da1 products below
-      const float a[4] = {valid ? dq[0] * g.scale : 0.f, valid ? dq[1] * g.scale : 0.f, valid ? dq[2] * g.scale : 0.f, valid ? dq[3] * g.scale : 0.f};
-      const float b[4] = {valid ? dk[0] * g.scale : 0.f, valid ? dk[1] * g.scale : 0.f, valid ? dk[2] * g.scale : 0.f, valid ? dk[3] * g.scale : 0.f};
-      const float c[4] = {valid ? dv[0] : 0.f, valid ? dv[1] : 0.f, valid ? dv[2] : 0.f, valid ? dv[3] : 0.f};
-      bt[0] = pack4(a); bt[1] = pack4(b); bt[2] = pack4(c);
+      const float a[4] = {dq[0] * g.scale, dq[1] * g.scale, dq[2] * g.scale, dq[3] * g.scale};
+      const float b[4] = {dk[0] * g.scale, dk[1] * g.scale, dk[2] * g.scale, dk[3] * g.scale};
+      const float c[4] = {dv[0], dv[1], dv[2], dv[3]};
+      bt[0] = pack4z(a, valid); bt[1] = pack4z(b, valid); bt[2] = pack4z(c, valid);
     }
     if (live && valid) {
       const uint32_t doff = (uint32_t)tok_own * 384u + (uint32_t)(h * HD + 4 * grp) * 2u;
