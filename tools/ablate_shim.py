@@ -6,13 +6,14 @@ Usage: bench.py imports this module only when FOCAL_ABLATE is set (tools/scratch
 import os
 
 FAMILIES = {
-    "linear_fwd": ["focal_linear_fwd", "focal_linear_resid_ln_fwd"], "linear_bwd_data": ["focal_linear_bwd_data"],
+    "linear_fwd": ["focal_linear_fwd", "focal_linear_resid_ln_fwd"], "linear_bwd_data": ["focal_linear_bwd_data"], "linear_bwd_data_ln": ["focal_linear_bwd_data_ln"],
     "linear_bwd_weight": ["focal_linear_bwd_weight", "focal_linear_bwd_weight_group"], "layernorm_fwd": ["focal_layernorm_fwd"], "layernorm_bwd": ["focal_layernorm_bwd"],
-    "mlp_fwd": ["focal_mlp_fwd"], "mlp_bwd": ["focal_mlp_bwd"], "window_attn_fwd": ["focal_window_attn_fwd"],
-    "window_attn_bwd": ["focal_window_attn_bwd"], "conv_fwd": ["focal_conv_fwd"], "conv_bwd_data": ["focal_conv_bwd_data"],
+    "mlp_fwd": ["focal_mlp_fwd"], "mlp_bwd": ["focal_mlp_bwd"], "window_attn_fwd": ["focal_window_attn_fwd", "focal_window_attn_qkv_fwd"],
+    "window_attn_bwd": ["focal_window_attn_bwd", "focal_window_attn_qkv_bwd"], "conv_fwd": ["focal_conv_fwd"], "conv_bwd_data": ["focal_conv_bwd_data"],
     "conv_bwd_weight": ["focal_conv_bwd_weight"], "bn_stats": ["focal_bn_stats"], "bn_act_fwd": ["focal_bn_act_fwd"],
     "bn_act_bwd": ["focal_bn_act_bwd"], "fft": ["focal_fft_realpack_fwd", "focal_augment_fft_fwd"], "loss_head": ["focal_loss_head"],
     "adamw": ["focal_adamw_multi"], "embed": ["focal_pad_patch_embed_ln_fwd", "focal_pad_patch_embed_ln2_fwd"], "packs": ["focal_pack_multi", "focal_unpack_add_multi"], "gru_seq_fwd": ["focal_gru_seq_fwd"], "gru_seq_bwd": ["focal_gru_seq_bwd"],
+    "axpy": ["focal_axpy"], "dropout": ["focal_dropout"], "conv_in": ["focal_conv_in_fwd", "focal_conv_in_bwd_weight"],
 }
 
 
