@@ -14,7 +14,8 @@ ACT_NONE, ACT_GELU, ACT_RELU_OUT = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
-ABI_VERSION = 7
+BN_STAT_SLOTS = 16      # focal_conv_fwd_bn: column sums are spread over this many slots of the scratch
+ABI_VERSION = 8
 
 
 class DropDesc(C.Structure):
@@ -169,6 +170,7 @@ PROTOTYPES = {
     "focal_unpack_add_multi": (C.c_int, [C.c_int, C.POINTER(PackEntry), P]),
     "focal_conv_pack_bwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P]),
     "focal_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
+    "focal_conv_fwd_bn": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, C.POINTER(BNDesc), P, P, P, P, P]),
     "focal_conv_bwd_data": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
     "focal_conv_bwd_weight": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
     "focal_bn_stats": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, C.c_int, P]),

@@ -574,6 +574,34 @@ static MaskParams conv_window(int S, int C, int pad) {
 }
 static size_t esize(int dtype) { return dtype == FOCAL_F32 ? 4 : 2; }
 
+// focal_conv_fwd + the training-mode statistics of the BatchNorm behind it (focal_bn_stats, FOCAL_BN_TRAIN) from the GEMM's epilogue: the
+// pre-BN tensor z is not read back for them and the statistics launch is gone (EPI_STORE_STATS, gemm_body.inc).
+extern "C" int focal_conv_fwd_bn(const focal_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* z,
+                                 const focal_bn_desc* bn, float* scratch, float* mean_rstd, float* running_mean, float* running_var,
+                                 void* stream) {
+  if (int rc = conv_check(d)) return rc;
+  FOCAL_CHECK_ARG(x && w_fwd && z && bn && scratch && mean_rstd, "conv_fwd_bn: null tensor");
+  FOCAL_CHECK_ARG(bn->rows == d->rows && bn->C == d->C_out && (running_mean == nullptr) == (running_var == nullptr),
+                  "conv_fwd_bn: the BatchNorm descriptor does not describe the convolution's output");
+  if (d->dtype != FOCAL_BF16) {
+    focal_set_error("conv_fwd_bn: bf16 operands only (fp32: focal_conv_fwd + focal_bn_stats)");
+    return FOCAL_EUNSUPPORTED;
+  }
+  const int pad = d->k / 2, K = d->k * d->C_in;
+  GemmSpec s{d->dtype, d->dtype, d->dtype, FOCAL_F32, false, false, PRO_CONV, PRO_NONE, EPI_STORE_STATS};
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->rows; p.N = d->C_out; p.K = K;
+  p.A = (const char*)x - (size_t)pad * d->C_in * esize(d->dtype); p.lda = d->C_in;
+  p.B = w_fwd; p.ldb = K;
+  p.C = z; p.ldc = d->C_out;
+  p.batch = 1; p.splits = 1; p.alpha = 1.f; p.bias = bias;
+  p.proA = conv_window(d->S, d->C_in, pad);
+  p.bn_sums = scratch; p.bn_mean_rstd = mean_rstd; p.bn_run_mean = running_mean; p.bn_run_var = running_var;
+  p.bn_rows = bn->stat_rows > 0 ? bn->stat_rows : bn->rows; p.bn_eps = bn->eps; p.bn_momentum = bn->momentum;
+  return focal_launch_gemm(s, p, (hipStream_t)stream);
+}
+
 extern "C" int focal_conv_fwd(const focal_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* z, void* stream) {
   if (int rc = conv_check(d)) return rc;
   FOCAL_CHECK_ARG(x && w_fwd && z, "conv_fwd: null tensor");

@@ -16,8 +16,10 @@
 enum GemmPro { PRO_NONE = 0, PRO_GELU = 1, PRO_MASK = 2, PRO_CONV = 3 };
 enum GemmEpi { EPI_STORE = 0, EPI_RESID = 1, EPI_MUL_AUX = 2, EPI_RELU = 3, EPI_RELU_BWD = 4, EPI_ATOMIC = 5, EPI_GELU_FWD = 6,
                EPI_RESID_LN = 7,    // EPI_RESID, then LayerNorm of the finished row (N == 64 == one wave's tile width): y_ln, statistics
-               EPI_LN_BWD = 8 };    // the product IS the gradient w.r.t. a LayerNorm's output: finish that LayerNorm's backward on the row
+               EPI_LN_BWD = 8,      // the product IS the gradient w.r.t. a LayerNorm's output: finish that LayerNorm's backward on the row
                                     // (gemm_pipe.hpp, row-complete wave tiles): C (fp32) += dx, aux_out = dtype(C * mask), dgamma / dbeta
+               EPI_STORE_STATS = 9 };  // EPI_STORE (fp32 C) + the BatchNorm statistics of C's columns: per-column sum / sum of squares into
+                                    // bn_sums (16 slots x 2N, zeroed by the caller), the last workgroup to arrive finalises mean / rstd
 
 struct MaskParams {
   const uint32_t* seed;  // device word (null -> seed 0)
@@ -46,7 +48,11 @@ struct GemmParams {
   const float* ln_gamma; const float* ln_beta; float* ln_stats; float ln_eps;  // stats f32 [M][2] = {mean, rstd}
   // EPI_LN_BWD: resid = the LayerNorm's input x (fp32 [M][N], ldr), ln_stats read, ln_gamma; column sums of dy * xhat / dy are added here
   float* ln_dgamma; float* ln_dbeta;
+  // EPI_STORE_STATS (training-mode BatchNorm behind a [1,k] convolution, DeepSense): bn_sums = 16 slots of {sum[N], sum of squares[N]} followed
+  // by the arrival counter, all zero on entry; statistics over bn_rows rows; outputs as focal_bn_stats in FOCAL_BN_TRAIN mode
+  float* bn_sums; float* bn_mean_rstd; float* bn_run_mean; float* bn_run_var; long bn_rows; float bn_eps, bn_momentum;
 };
+constexpr int BN_STAT_SLOTS = 16;
 
 struct MaskEval {
   DropCtx e, p;

@@ -134,9 +134,13 @@ class DeepSenseModEncoder:
             pl = f"{self.pre}.conv_layers_inter.{li}"
             w = ar.master(f"{pl}.conv.weight")  # [C, C, 1, k]
             w_fwd = self._packed(("fwd", li), lambda: ops.permute_pack(w, C, C, k, ct))
-            z = ops.conv_fwd(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"))
             d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 1 + li), momentum=momentum)
-            mr = ops.bn_stats(d_bn, z, *running(pl, 1 + li), training, bb.sync_bn)
+            if training and ct == torch.bfloat16 and not (bb.sync_bn and ops._sync_world() > 1):
+                # the statistics come out of the convolution's epilogue: z is not read back for them, one launch less per layer
+                z, mr = ops.conv_fwd_bn(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"), d_bn, *running(pl, 1 + li))
+            else:
+                z = ops.conv_fwd(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"))
+                mr = ops.bn_stats(d_bn, z, *running(pl, 1 + li), training, bb.sync_bn)
             y_next, ya_next = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pl}.batch_norm.weight"), ar.master(f"{pl}.batch_norm.bias"), y, ct)
             sv["layers"].append(dict(p=pl, z=z, mr=mr, d_bn=d_bn, xa=ya))
             y, ya = y_next, ya_next

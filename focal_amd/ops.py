@@ -622,6 +622,21 @@ def conv_fwd(d, x, w_fwd, bias):
     return z
 
 
+def conv_fwd_bn(d, x, w_fwd, bias, d_bn, running_mean, running_var):
+    """conv_fwd + the training-mode statistics of the BatchNorm behind it in one launch (focal_conv_fwd_bn): -> (z, mean_rstd).  One rank /
+    no sync_bn (the global-batch form all-reduces the sums between two kernels: conv_fwd + bn_stats)."""
+    dev = x.device
+    z = torch.empty(d.rows, d.C_out, dtype=torch.float32, device=dev)
+    n = _lib.BN_STAT_SLOTS * 2 * d_bn.C + 1
+    scratch = pool_zeros(n, dev)
+    if scratch is None:
+        scratch = torch.zeros(n, dtype=torch.float32, device=dev)
+    mean_rstd = torch.empty(2 * d_bn.C, dtype=torch.float32, device=dev)
+    check(_lib.load().focal_conv_fwd_bn(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(z), C.byref(d_bn), _p(scratch), _p(mean_rstd),
+                                        _p(running_mean), _p(running_var), _stream()))
+    return z, mean_rstd
+
+
 def conv_bwd_data(d, dz, w_bwd, g_in, g_out):
     check(_lib.load().focal_conv_bwd_data(C.byref(d), _p(dz), _p(w_bwd), _p(g_in), _p(g_out), _stream()))
 

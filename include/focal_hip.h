@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* 7: launch trace (focal_trace_*), focal_adamw_multi_advance takes the step-state length; 2: BatchNorm scratch of 2C + 1 floats; 3: fused MLP, warps, Mixup; 4: row-sharded loss head, weight-gradient launch queries */
-#define FOCAL_ABI_VERSION 7
+#define FOCAL_ABI_VERSION 8
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -342,6 +342,13 @@ enum { FOCAL_BN_EVAL = 0, FOCAL_BN_TRAIN = 1, FOCAL_BN_PARTIAL = 2, FOCAL_BN_FIN
 #define FOCAL_BN_SCRATCH_ZEROED 16
 int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scratch, float* mean_rstd, float* running_mean, float* running_var,
                    int training, void* stream);
+/* focal_conv_fwd AND the training-mode statistics of the BatchNorm that follows it (ConvModules.py:54-112: conv -> BatchNorm2d), from the
+ * convolution's epilogue: what focal_bn_stats(bn, z, ..., FOCAL_BN_TRAIN) would compute, without reading z back and without its launch.
+ * bf16 operands.  scratch: FOCAL_BN_STAT_SLOTS x 2C + 1 floats, ZERO on entry (column sums in 16 slots + the arrival counter of the last-
+ * workgroup finalisation); mean_rstd [2C] out; running_mean / running_var updated with bn->momentum (both NULL: not touched). */
+#define FOCAL_BN_STAT_SLOTS 16
+int focal_conv_fwd_bn(const focal_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* z,
+                      const focal_bn_desc* bn, float* scratch, float* mean_rstd, float* running_mean, float* running_var, void* stream);
 /* The running-buffer updates of TWO passes (the two augmented views of a FOCAL step), applied after both have run: each pass records
  * its batch statistics instead of updating the buffers (focal_bn_stats with d->momentum = 1 and a per-pass sink in place of the running
  * buffers), this applies r <- (1 - m) ((1 - m) r + m s1) + m s2 to n buffers of C values in one launch -- what the reference's two

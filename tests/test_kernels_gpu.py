@@ -725,6 +725,30 @@ def test_conv_in(ops, S_in, k, stride, pad):
     assert rel_err(dw, wr.grad) < 2e-5 and rel_err(db, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("B,I,S", [(3, 10, 20), (64, 10, 80), (7, 10, 9)])
+def test_conv_fwd_with_batchnorm_statistics_in_the_epilogue(ops, B, I, S):
+    """focal_conv_fwd_bn == focal_conv_fwd followed by focal_bn_stats (training mode): z bit for bit, mean / rstd and the running buffers
+    to summation order; 1 / 800 / a ragged number of workgroups (the last-arriver finalisation, 16 slots of partial sums)."""
+    C, k, ct = 64, 3, torch.bfloat16
+    rows = B * I * S
+    x = rnd(rows, C, seed=174, dtype=ct)
+    w, b = rnd(C, C, 1, k, scale=(C * k) ** -0.5, seed=175), rnd(C, seed=176)
+    d = ops.conv_desc(ops.code(ct), rows, S, C, C, k)
+    w_fwd = ops.permute_pack(w, C, C, k, ct)
+    d_bn = ops.bn_desc(ops.code(ct), rows, C, I * S, 0.0, None, 0, momentum=0.1)
+    rm0, rv0 = rnd(C, seed=177), rnd(C, seed=178).abs() + 0.5
+    z_ref = ops.conv_fwd(d, x, w_fwd, b)
+    rm, rv = rm0.clone(), rv0.clone()
+    mr_ref = ops.bn_stats(d_bn, z_ref, rm, rv, True)
+    rm2, rv2 = rm0.clone(), rv0.clone()
+    z, mr = ops.conv_fwd_bn(d, x, w_fwd, b, d_bn, rm2, rv2)
+    assert torch.equal(z, z_ref)
+    assert rel_err(mr, mr_ref) < 1e-5 and rel_err(rm2, rm) < 1e-5 and rel_err(rv2, rv) < 1e-5
+    # and against the definition
+    mean, var = z_ref.mean(0), z_ref.var(0, unbiased=False)
+    assert rel_err(mr[:C], mean) < 1e-4 and rel_err(mr[C:], (var + d_bn.eps).rsqrt()) < 1e-4
+
+
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("k", [3, 5])
 def test_conv1xk_same_as_sliding_window_gemm(ops, ct, k):
