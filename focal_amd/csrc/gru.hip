@@ -451,6 +451,10 @@ extern "C" int focal_gru_seq_fwd(const focal_gru_desc* d, int n_dir, const float
     focal_set_error("gru_seq_fwd: hidden size %d not in {128, 256} (use the per-step kernels)", d->H);
     return FOCAL_EUNSUPPORTED;
   }
+  if ((long)d->B * d->T * 3 * d->H * 4 >= (1L << 32)) {  // (the kernels address gi / out / save planes with 32-bit byte offsets)
+    focal_set_error("gru_seq_fwd: B x T x 3H = %ld elements exceed the kernel's 32-bit addressing", (long)d->B * d->T * 3 * d->H);
+    return FOCAL_EUNSUPPORTED;
+  }
   GruFwdArgs a;
   memset(&a, 0, sizeof(a));
   for (int i = 0; i < n_dir; ++i) {
@@ -482,6 +486,10 @@ extern "C" int focal_gru_seq_bwd(const focal_gru_desc* d, int n_dir, const float
   FOCAL_CHECK_ARG(ld_b % 4 == 0 && ld_t % 4 == 0, "gru_seq_bwd: dout strides must be multiples of 4");
   if (d->H != 128 && d->H != 256) {
     focal_set_error("gru_seq_bwd: hidden size %d not in {128, 256} (use the per-step kernels)", d->H);
+    return FOCAL_EUNSUPPORTED;
+  }
+  if ((long)d->B * d->T * 3 * d->H * 4 >= (1L << 32) || (long)d->B * ld_b * 4 >= (1L << 32)) {
+    focal_set_error("gru_seq_bwd: tensors exceed the kernel's 32-bit addressing (B %d, T %d, H %d, ld_b %ld)", d->B, d->T, d->H, ld_b);
     return FOCAL_EUNSUPPORTED;
   }
   GruBwdArgs a;

@@ -376,7 +376,9 @@ int focal_gru_gate_bwd(const focal_gru_desc* d, int t, int dir_offset, const flo
  * (direction 0 walks t = 0..T-1, direction 1 t = T-1..0 and writes out[..., H:2H]).  Per-direction HOST arrays of device
  * pointers: gi [B*T, 3H] (b_ih included), whh bf16 [3H, H], bhh [3H], hs [T+1, B, H] (hs[0] = h0, written from hs[1]),
  * save [T, 4, B, H] indexed by step s.  Backward: whh_t = bf16 [H, 3H] (the transposed W_hh), dgi [B*T, 3H], dgh [T, B, 3H]
- * (step-indexed) are written for the weight / input gradient GEMMs; dout as in focal_gru_gate_bwd. */
+ * (step-indexed) are written for the weight / input gradient GEMMs; dout as in focal_gru_gate_bwd.
+ * Tensors must stay below 4 GB (32-bit byte offsets).  A batch that is not a multiple of the kernel's samples per workgroup (8 while
+ * ceil(B / 8) * n_dir <= 64 at H = 256, else 16) is handled by recomputing the last sample in the spare lanes. */
 int focal_gru_seq_fwd(const focal_gru_desc* d, int n_dir, const float* const* gi, const void* const* whh, const float* const* bhh,
                       float* const* hs, float* const* save, float* out, void* stream);
 int focal_gru_seq_bwd(const focal_gru_desc* d, int n_dir, const float* dout, long ld_b, long ld_t, float scale,
