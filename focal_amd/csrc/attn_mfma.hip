@@ -10,6 +10,24 @@
 #include "attn_geom.hpp"
 
 typedef __attribute__((address_space(3))) bf16x4* lds_b4;
+
+// All-reduce over a lane's four row groups (lanes l, l ^ 16, l ^ 32, l ^ 48) with the gfx950 row / half swaps -- vector instructions of a
+// few cycles' latency -- instead of two ds_bpermute round trips through the LDS pipeline (hundreds of cycles each under load, six of them on
+// the backward item's dependency chain).  v_permlane16_swap(a, b) exchanges a's odd 16-lane rows with b's even rows: with a = b = x the two
+// results hold (R0, R0, R2, R2) and (R1, R1, R3, R3); v_permlane32_swap does the same with the 32-lane halves.  Same pairing, same operand
+// order as `x op= shfl_xor(x, 16); x op= shfl_xor(x, 32)`: bit-identical.
+__device__ __forceinline__ float rows4_sum(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows4_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 // (Scores in the base-2 domain -- exp2 without the multiply per element -- were tried: 3 instructions less, and the bf16 rank-loss term of
 // the reference fixture moved from 0.98e-2 to 1.12e-2 of its bound-defining value; the natural-base form is kept bit for bit.)
 
@@ -140,13 +158,11 @@ __device__ __forceinline__ void tile_softmax(const AttnGeom& g, const TileIdx& t
   }
   if (ROWS_ARE_KEYS) {
     float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = rows4_max(m);
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - m); sum += s[r]; }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = rows4_sum(sum);
     const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[r] *= inv;
@@ -327,13 +343,11 @@ __global__ __launch_bounds__(256) void window_attn_fwd_mfma_kernel(const bf16_t*
     }
     {  // softmax over the keys of query i = lane & 15: in-lane over r, then across the four row groups
       float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = rows4_max(m);
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { p[r] = __expf(p[r] - m); sum += p[r]; }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = rows4_sum(sum);
       const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
       for (int r = 0; r < 4; ++r) p[r] *= inv;
@@ -529,13 +543,11 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       }
     }
     float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = rows4_max(m);
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { p[r] = __expf(p[r] - m); sum += p[r]; }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = rows4_sum(sum);
     const float inv = __builtin_amdgcn_rcpf(sum);
     // ---- dP (through the dropout mask), the row dot, dS^T and Pd^T
     float dm[4] = {1.f, 1.f, 1.f, 1.f};
@@ -549,8 +561,7 @@ __global__ __launch_bounds__(NW * 64) void window_attn_bwd_mfma_kernel(const bf1
       dsT[r] = dt[r] * mlt;      // dP
       dot += p[r] * dsT[r];
     }
-    dot += __shfl_xor(dot, 16, 64);
-    dot += __shfl_xor(dot, 32, 64);
+    dot = rows4_sum(dot);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       dsT[r] = p[r] * (dsT[r] - dot);  // 0 on padded keys (p = 0); padded query columns meet zero rows of Q / dO below and are not stored
@@ -822,13 +833,11 @@ __global__ __launch_bounds__(NW * 64) void swin_attn_branch_bwd_kernel(const Bra
       }
     }
     float mx = fmaxf(fmaxf(pr[0], pr[1]), fmaxf(pr[2], pr[3]));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows4_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { pr[r] = __expf(pr[r] - mx); sum += pr[r]; }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = rows4_sum(sum);
     const float inv = __builtin_amdgcn_rcpf(sum);
     float dm[4] = {1.f, 1.f, 1.f, 1.f};
     if (drop_on) att_drop4(dc, att_drop_q((uint32_t)win * g.heads + h, col, grp), dm);  // (i = col, j = 4 grp + r)
@@ -841,8 +850,7 @@ __global__ __launch_bounds__(NW * 64) void swin_attn_branch_bwd_kernel(const Bra
       dsT[r] = dt[r] * mlt;
       dot += pr[r] * dsT[r];
     }
-    dot += __shfl_xor(dot, 16, 64);
-    dot += __shfl_xor(dot, 32, 64);
+    dot = rows4_sum(dot);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       dsT[r] = pr[r] * (dsT[r] - dot);

@@ -309,9 +309,10 @@ class SwinModEncoder:
             weight_grad(d_proj_b, gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
             do = dc  # reuse the [M, C] CT buffer
             dqkv = torch.empty(M, 3 * Cc, dtype=ct, device=dev)
-            # (the branch's backward as ONE launch -- focal_window_attn_branch_bwd, tested in tests/test_kernels_gpu.py -- was measured in
-            # two forms and is not used: 236 us (a wave per window, 180 registers) and 207 us (four waves per window, partials through
-            # LDS) against 191 us for these two launches at the audio shape: profiles/r4_attn_branch_bwd.txt)
+            # (the branch's backward as ONE launch -- focal_window_attn_branch_bwd, tested in tests/test_kernels_gpu.py -- is not used: its
+            # second form, four waves per window with the partials through LDS, is ahead of these two launches in isolation since the
+            # cross-row reductions moved off the LDS pipeline (178 vs 189 us at the audio shape, cold) and exactly even inside the replayed
+            # step (48 130 vs 48 090 windows/s over five alternating pairs; HAR4 -1.3 %): profiles/r4_attn_branch_bwd.txt)
             if s["qkv"] is None:
                 # 64-channel blocks: q / k / v are recomputed from a1 inside the kernel (see forward), and so is the proj layer's input
                 # gradient -- the kernel forms its head's slice of gm_attn . Wproj per item: no dX launch, no dO tensor
