@@ -11,23 +11,11 @@
 
 typedef __attribute__((address_space(3))) bf16x4* lds_b4;
 
-// All-reduce over a lane's four row groups (lanes l, l ^ 16, l ^ 32, l ^ 48) with the gfx950 row / half swaps -- vector instructions of a
-// few cycles' latency -- instead of two ds_bpermute round trips through the LDS pipeline (hundreds of cycles each under load, six of them on
-// the backward item's dependency chain).  v_permlane16_swap(a, b) exchanges a's odd 16-lane rows with b's even rows: with a = b = x the two
-// results hold (R0, R0, R2, R2) and (R1, R1, R3, R3); v_permlane32_swap does the same with the 32-lane halves.  Same pairing, same operand
-// order as `x op= shfl_xor(x, 16); x op= shfl_xor(x, 32)`: bit-identical.
-__device__ __forceinline__ float rows4_sum(float v) {
-  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-__device__ __forceinline__ float rows4_max(float v) {
-  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
+// All-reduce over a lane's four row groups (lanes l, l ^ 16, l ^ 32, l ^ 48) without the LDS pipeline (common.hpp: xadd16 / xadd32, the gfx950
+// row / half swaps): six ds_bpermute round trips sat on the backward item's dependency chain.  Same pairing and operand order as
+// `x op= shfl_xor(x, 16); x op= shfl_xor(x, 32)`: bit-identical.
+__device__ __forceinline__ float rows4_sum(float v) { return xadd32(xadd16(v)); }
+__device__ __forceinline__ float rows4_max(float v) { return xmax32(xmax16(v)); }
 // (Scores in the base-2 domain -- exp2 without the multiply per element -- were tried: 3 instructions less, and the bf16 rank-loss term of
 // the reference fixture moved from 0.98e-2 to 1.12e-2 of its bound-defining value; the natural-base form is kept bit for bit.)
 

@@ -17,7 +17,7 @@ __device__ __forceinline__ void bn_commit_sums(float* red, float* __restrict__ s
   for (int i = threadIdx.x; i < nw * 2 * C; i += blockDim.x) red[i] = 0.f;
   for (int o = lpr; o < 64; o <<= 1) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { a[k] += __shfl_xor(a[k], o, 64); b[k] += __shfl_xor(b[k], o, 64); }
+    for (int k = 0; k < 4; ++k) { a[k] = xadd(a[k], o); b[k] = xadd(b[k], o); }
   }
   __syncthreads();
   if (lpr >= 64 || lane < lpr) {

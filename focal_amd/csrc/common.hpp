@@ -148,14 +148,42 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
+// v + (v of lane ^ 16) / v + (v of lane ^ 32) with the gfx950 row / half swaps: v_permlane16_swap(a, b) exchanges a's odd 16-lane rows with b's
+// even rows -- with a = b = v the two results hold rows (R0, R0, R2, R2) and (R1, R1, R3, R3) --, v_permlane32_swap the 32-lane halves.  Vector
+// instructions of a few cycles' latency where `v += __shfl_xor(v, 16 | 32)` is a ds_bpermute round trip through the LDS pipeline (hundreds of
+// cycles under load, on the dependency chain of every LayerNorm row in the GEMM epilogues); same pairs, same value: bit-identical.
+__device__ __forceinline__ float xadd16(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float xadd32(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float xmax16(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float xmax32(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+
+// v + (v of lane ^ o): the swaps for o = 16 / 32 (a wave-uniform or compile-time o), ds_bpermute otherwise
+__device__ __forceinline__ float xadd(float v, int o) { return o == 16 ? xadd16(v) : (o == 32 ? xadd32(v) : v + __shfl_xor(v, o, 64)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
+  v = xadd32(v);
+  v = xadd16(v);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
+  v = xmax32(v);
+  v = xmax16(v);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
 

@@ -135,13 +135,13 @@ __device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, 
         }
         if (m < p.M) storeN<4>(Cf + (long)m * p.ldc + n, a[it]);
         s1 = row16_sum(s1);
-        s1 += __shfl_xor(s1, 16, 64);
+        s1 = xadd16(s1);
         const float mh = s1 * (1.0f / WC);
         float s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) s2 += (a[it][e] - mh) * (a[it][e] - mh);
         s2 = row16_sum(s2);
-        s2 += __shfl_xor(s2, 16, 64);
+        s2 = xadd16(s2);
         h1[it] = mh; h2[it] = s2;
       } else {
         const float mean = spre[it].x, rstd = spre[it].y;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, 
           if (m < p.M) { pg[e] += v[e] * b[it][e]; pb[e] += v[e]; }
         }
         s1 = row16_sum(s1); s2 = row16_sum(s2);
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 = xadd16(s1); s2 = xadd16(s2);
         h1[it] = s1; h2[it] = s2;
       }
       if ((lane % LPR) == 0) xch[(lrow0 + row) * 2 + wn] = make_float2(h1[it], h2[it]);
@@ -194,8 +194,8 @@ __device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, 
   if (EPI == EPI_LN_BWD) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      pg[e] += __shfl_xor(pg[e], 32, 64);
-      pb[e] += __shfl_xor(pb[e], 32, 64);
+      pg[e] = xadd32(pg[e]);
+      pb[e] = xadd32(pb[e]);
     }
     if (lane < LPR) {
       *reinterpret_cast<float4*>(red + wave * 2 * WC + c) = make_float4(pg[0], pg[1], pg[2], pg[3]);
@@ -424,15 +424,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
 #pragma unroll
         for (int e = 0; e < CPL; ++e) s1 += v[e];
         s1 = row16_sum(s1);
-        if (LPR >= 32) s1 += __shfl_xor(s1, 16, 64);
-        if (LPR >= 64) s1 += __shfl_xor(s1, 32, 64);
+        if (LPR >= 32) s1 = xadd16(s1);
+        if (LPR >= 64) s1 = xadd32(s1);
         const float mean = s1 * (1.0f / WC);
         float s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < CPL; ++e) s2 += (v[e] - mean) * (v[e] - mean);
         s2 = row16_sum(s2);
-        if (LPR >= 32) s2 += __shfl_xor(s2, 16, 64);
-        if (LPR >= 64) s2 += __shfl_xor(s2, 32, 64);
+        if (LPR >= 32) s2 = xadd16(s2);
+        if (LPR >= 64) s2 = xadd32(s2);
         const float rstd = rsqrtf(s2 * (1.0f / WC) + p.ln_eps);
         float gq[CPL], bt[CPL], yq[CPL];
         loadN<CPL>(p.ln_gamma + n, gq);
@@ -459,8 +459,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
           pb[e] += v[e];
         }
         s1 = row16_sum(s1); s2 = row16_sum(s2);
-        if (LPR >= 32) { s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); }
-        if (LPR >= 64) { s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); }
+        if (LPR >= 32) { s1 = xadd16(s1); s2 = xadd16(s2); }
+        if (LPR >= 64) { s1 = xadd32(s1); s2 = xadd32(s2); }
         const float m1 = s1 * (1.0f / WC), m2 = s2 * (1.0f / WC);
         if (C == nullptr) continue;
         float o[CPL];
@@ -503,8 +503,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       for (int o = LPR; o < 64; o <<= 1) {
-        pg[e] += __shfl_xor(pg[e], o, 64);
-        pb[e] += __shfl_xor(pb[e], o, 64);
+        pg[e] = xadd(pg[e], o);
+        pb[e] = xadd(pb[e], o);
       }
     }
     float* red = reinterpret_cast<float*>(pipe_lds) + NW * 16 * WPITCH;

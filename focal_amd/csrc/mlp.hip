@@ -143,16 +143,16 @@ __global__ __launch_bounds__(512, 4) void mlp_fwd_kernel(const MlpFwdParams p) {
       if (mok) store4(p.y + (long)m * C + c0, yacc[j]);
     }
     if (LN) {
-      s1 += __shfl_xor(s1, 16, 64);
-      s1 += __shfl_xor(s1, 32, 64);
+      s1 = xadd16(s1);
+      s1 = xadd32(s1);
       const float mean = s1 * (1.0f / C);
       float s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s2 += (yacc[j][e] - mean) * (yacc[j][e] - mean);
-      s2 += __shfl_xor(s2, 16, 64);
-      s2 += __shfl_xor(s2, 32, 64);
+      s2 = xadd16(s2);
+      s2 = xadd32(s2);
       const float rstd = rsqrtf(s2 * (1.0f / C) + p.ln_eps);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

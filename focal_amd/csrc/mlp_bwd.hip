@@ -282,8 +282,8 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
             }
           }
         }
-        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        s1 = xadd16(s1); s1 = xadd32(s1);
+        s2 = xadd16(s2); s2 = xadd32(s2);
         if (g2 == 0) *reinterpret_cast<float2*>(lds + L_LNX + ((w & 1) * BM + 16 * tb2 + l2) * 8) = make_float2(s1, s2);
         lds_barrier();  // both halves of every row are in LDS
         const float2 oth = *reinterpret_cast<const float2*>(lds + L_LNX + (((w & 1) ^ 1) * BM + 16 * tb2 + l2) * 8);
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
   }
   if (p.db1) {
     float v = db1acc;
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v = xadd16(v);
+    v = xadd32(v);
     if (g == 0) atomicAdd(p.db1 + hid, v);
   }
   if (p.db2 && tid < C) atomicAdd(p.db2 + tid, reinterpret_cast<const float*>(lds + L_DB2)[tid]);

@@ -21,10 +21,10 @@ struct RowMap {
 __device__ __forceinline__ float group_sum(float v, int lpr) {
   if (lpr >= 16) {  // the 16-lane part with DPP row operations (no LDS round trips), whole rows beyond that by shuffle
     v = row16_sum(v);
-    for (int o = 16; o < lpr; o <<= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 16; o < lpr; o <<= 1) v = xadd(v, o);
     return v;
   }
-  for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = lpr >> 1; o > 0; o >>= 1) v = xadd(v, o);
   return v;
 }
 
@@ -188,10 +188,10 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const TY* __restrict__ dy,
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     for (int o = lpr; o < 64; o <<= 1) {
-      pg[k].x += __shfl_xor(pg[k].x, o, 64); pg[k].y += __shfl_xor(pg[k].y, o, 64);
-      pg[k].z += __shfl_xor(pg[k].z, o, 64); pg[k].w += __shfl_xor(pg[k].w, o, 64);
-      pb[k].x += __shfl_xor(pb[k].x, o, 64); pb[k].y += __shfl_xor(pb[k].y, o, 64);
-      pb[k].z += __shfl_xor(pb[k].z, o, 64); pb[k].w += __shfl_xor(pb[k].w, o, 64);
+      pg[k].x = xadd(pg[k].x, o); pg[k].y = xadd(pg[k].y, o);
+      pg[k].z = xadd(pg[k].z, o); pg[k].w = xadd(pg[k].w, o);
+      pb[k].x = xadd(pb[k].x, o); pb[k].y = xadd(pb[k].y, o);
+      pb[k].z = xadd(pb[k].z, o); pb[k].w = xadd(pb[k].w, o);
     }
     if (sub == 0) {
       float* row = part + (threadIdx.x >> 6) * 2 * C;
