@@ -23,19 +23,19 @@ __host__ __device__ __forceinline__ uint32_t att_div(uint32_t n, uint32_t magic,
 // Attention-dropout stream (round 4).  The kernels are bound by vector-instruction issue, and a 32-bit hash per probability (two integer
 // multiplies at quarter rate) was 24 of the forward kernel's 223 vector instructions per item.  One hash now decides TWO probabilities with its
 // 16-bit halves (keep iff half >= p * 2^16: p resolved to 1.5e-5): element (window-head wh, query i, key j) uses half (j & 1) of
-//     mix32( ((((wh * 16 + i) * 4 + (j >> 2)) * 2 + ((j >> 1) & 1))) ^ key ),
+//     hash24( ((((wh * 16 + i) * 4 + (j >> 2)) * 2 + ((j >> 1) & 1))) ^ key ),
 // i.e. an MFMA lane (query i, keys 4 g .. 4 g + 3) needs the two hashes 2 q, 2 q + 1 of q = (wh * 16 + i) * 4 + g.  All attention kernels
 // (fp32 VALU and bf16 MFMA, forward and backward) draw from this one definition.
 __device__ __forceinline__ uint32_t att_drop_q(uint32_t wh, int i, int jg) { return ((wh * 16u + (uint32_t)i) * 4u + (uint32_t)jg) * 2u; }
 __device__ __forceinline__ void att_drop4(const DropCtx& d, uint32_t q2, float* m) {  // multipliers of keys 4 g .. 4 g + 3
-  const uint32_t h0 = focal_mix32(q2 ^ d.key), h1 = focal_mix32((q2 + 1u) ^ d.key), t16 = d.thresh >> 8;
+  const uint32_t h0 = focal_hash24(q2 ^ d.key), h1 = focal_hash24((q2 + 1u) ^ d.key), t16 = d.thresh >> 8;
   m[0] = (h0 & 0xffffu) < t16 ? 0.0f : d.scale;
   m[1] = (h0 >> 16) < t16 ? 0.0f : d.scale;
   m[2] = (h1 & 0xffffu) < t16 ? 0.0f : d.scale;
   m[3] = (h1 >> 16) < t16 ? 0.0f : d.scale;
 }
 __device__ __forceinline__ float att_drop1(const DropCtx& d, uint32_t wh, int i, int j) {
-  const uint32_t hh = focal_mix32((att_drop_q(wh, i, j >> 2) + (uint32_t)((j >> 1) & 1)) ^ d.key);
+  const uint32_t hh = focal_hash24((att_drop_q(wh, i, j >> 2) + (uint32_t)((j >> 1) & 1)) ^ d.key);
   return ((j & 1) ? (hh >> 16) : (hh & 0xffffu)) < (d.thresh >> 8) ? 0.0f : d.scale;
 }
 

@@ -71,6 +71,19 @@ __device__ __forceinline__ uint32_t focal_mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// The per-element hash of the dropout streams.  focal_mix32's two 32-bit multiplies issue at quarter rate (v_mul_lo_u32: 8 of the hash's
+// 14 issue slots), and the element masks of the GEMM / MLP epilogues and the attention kernels draw one hash per element or pair inside
+// vector-bound loops.  This one multiplies 24-bit operands (v_mad_u32_u24 / v_mul_u32_u24, full rate: 8 slots); the addend of the first round
+// carries the bits the 24-bit operand drops.  Not a bijection (2^24 distinct values per key), which a keep / drop decision does not need:
+// keep rates, neighbour / row / column correlations, byte chi-squares and avalanche (0.500 per input bit) are indistinguishable from
+// focal_mix32's over 2 M consecutive indices.  Seeds and keys are still mixed with focal_mix32 (a bijection: the seed sequence must not cycle).
+__device__ __forceinline__ uint32_t focal_hash24(uint32_t x) {
+  uint32_t h = x ^ (x >> 16);
+  h = __umul24(h, 0xE35A2Bu) + x;
+  h ^= h >> 15;
+  h = __umul24(h, 0xB5297Bu);
+  return h ^ (h >> 16);
+}
 struct DropCtx {
   uint32_t key;     // mixed (seed, stream)
   uint32_t thresh;  // drop if (hash >> 8) < thresh  (24-bit resolution)
@@ -86,7 +99,7 @@ __device__ __forceinline__ DropCtx make_drop(const uint32_t* seed_ptr, uint32_t 
 }
 // multiplier (0 or 1/(1-p)) for element `idx`
 __device__ __forceinline__ float drop_mult(const DropCtx& d, uint32_t idx) {
-  uint32_t h = focal_mix32(idx ^ d.key);
+  uint32_t h = focal_hash24(idx ^ d.key);
   return ((h >> 8) < d.thresh) ? 0.0f : d.scale;
 }
 

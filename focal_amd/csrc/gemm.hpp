@@ -85,7 +85,7 @@ struct MaskEval {
   __device__ __forceinline__ gelu_f2 elem_mult_pair(int row, int col) const {
     if (!on_e) return gelu_f2{1.0f, 1.0f};
     const uint32_t idx = ((uint32_t)row * (uint32_t)ncols + (uint32_t)col) >> 1;
-    const uint32_t h = focal_mix32(idx ^ e.key), t16 = e.thresh >> 8;
+    const uint32_t h = focal_hash24(idx ^ e.key), t16 = e.thresh >> 8;
     return gelu_f2{(h & 0xffffu) < t16 ? 0.0f : e.scale, (h >> 16) < t16 ? 0.0f : e.scale};
   }
 };

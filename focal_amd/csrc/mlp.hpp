@@ -132,7 +132,7 @@ struct MlpDropStream {
     scale = c.scale;
   }
   __device__ __forceinline__ uint32_t start(uint32_t key, int row, int group) const {
-    const uint32_t v = focal_mix32((((uint32_t)row << 2) | (uint32_t)group) ^ key);
+    const uint32_t v = focal_hash24((((uint32_t)row << 2) | (uint32_t)group) ^ key);
     return v ? v : 0x9E3779B9u;
   }
   __device__ __forceinline__ gelu_f2 next(uint32_t& st) const {
