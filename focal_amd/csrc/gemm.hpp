@@ -58,7 +58,7 @@ struct MaskEval {
   DropCtx e, p;
   bool on_e, on_p;
   int rps, ncols;
-  uint32_t pad;
+  uint32_t pad, rps_magic;  // ceil(2^32 / rps): row / rps == mulhi(row, magic) while row * rps < 2^32
   __device__ __forceinline__ void init(const MaskParams& m) {
     pad = m.stream_elem;
     on_e = m.p_elem > 0.f;
@@ -67,6 +67,7 @@ struct MaskEval {
     p = make_drop(m.seed, m.stream_path, m.p_path);
     rps = m.rows_per_sample > 0 ? m.rows_per_sample : 1;
     ncols = m.ncols;
+    rps_magic = 0xFFFFFFFFu / (uint32_t)rps + 1u;
   }
   // PRO_CONV: the operand is a [1, k] "same" convolution window over channel-last tokens: memory row m, column
   // kk = tap * Cin + ci reads token m + tap - pad, valid only while it stays inside the same interval of S tokens
@@ -76,15 +77,22 @@ struct MaskEval {
     const int q = s + t - (int)pad;
     return q >= 0 && q < rps;
   }
-  __device__ __forceinline__ float row_mult(int row) const { return on_p ? drop_mult(p, (uint32_t)(row / rps)) : 1.0f; }
+  // (the sample index by multiply-high -- a runtime division is ~20 vector instructions per row, two of them at quarter rate; exact for
+  //  row < 2^20, rps < 2^12, else the division -- and the element index by a 24-bit multiply: rows and columns are far below 2^24, the
+  //  launchers check)
+  __device__ __forceinline__ uint32_t sample_of(int row) const {
+    if (rps == 1) return (uint32_t)row;
+    return ((uint32_t)row < (1u << 20) && rps < (1 << 12)) ? __umulhi((uint32_t)row, rps_magic) : (uint32_t)(row / rps);
+  }
+  __device__ __forceinline__ float row_mult(int row) const { return on_p ? drop_mult(p, sample_of(row)) : 1.0f; }
   __device__ __forceinline__ float elem_mult(int row, int col) const {
-    return on_e ? drop_mult(e, (uint32_t)row * (uint32_t)ncols + (uint32_t)col) : 1.0f;
+    return on_e ? drop_mult(e, __umul24((uint32_t)row, (uint32_t)ncols) + (uint32_t)col) : 1.0f;
   }
   // Two neighbouring elements (col even) from ONE hash: its two 16-bit halves against a 16-bit threshold.  Only for sites whose
   // mask is consumed where it is drawn and never regenerated elsewhere (the fc1 GELU epilogue: the saved derivative carries it).
   __device__ __forceinline__ gelu_f2 elem_mult_pair(int row, int col) const {
     if (!on_e) return gelu_f2{1.0f, 1.0f};
-    const uint32_t idx = ((uint32_t)row * (uint32_t)ncols + (uint32_t)col) >> 1;
+    const uint32_t idx = (__umul24((uint32_t)row, (uint32_t)ncols) + (uint32_t)col) >> 1;
     const uint32_t h = focal_hash24(idx ^ e.key), t16 = e.thresh >> 8;
     return gelu_f2{(h & 0xffffu) < t16 ? 0.0f : e.scale, (h >> 16) < t16 ? 0.0f : e.scale};
   }
@@ -382,5 +390,9 @@ struct GemmSpec {
 int focal_launch_gemm_bf16(const GemmSpec& s, const GemmParams& p, hipStream_t stream);
 int focal_launch_gemm_f32(const GemmSpec& s, const GemmParams& p, hipStream_t stream);
 static inline int focal_launch_gemm(const GemmSpec& s, const GemmParams& p, hipStream_t stream) {
+  if ((p.epi.p_elem > 0.f || p.proA.p_elem > 0.f || p.proB.p_elem > 0.f) && ((long)p.M >= (1L << 24) || (long)p.K >= (1L << 24) || (long)p.N >= (1L << 24))) {
+    focal_set_error("gemm: a dimension beyond 2^24 with an element mask (MaskEval indexes elements with 24-bit multiplies)");
+    return FOCAL_EUNSUPPORTED;
+  }
   return s.compute == FOCAL_F32 ? focal_launch_gemm_f32(s, p, stream) : focal_launch_gemm_bf16(s, p, stream);
 }

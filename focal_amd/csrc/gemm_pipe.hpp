@@ -28,6 +28,15 @@ template <int N> __device__ __forceinline__ void pipe_wait_barrier() {
 typedef __attribute__((address_space(3))) void* pipe_lds_ptr;
 typedef const __attribute__((address_space(1))) void* pipe_glb_ptr;
 
+// Row addressing in the epilogues: a uniform pointer to the tile's first row + a 32-bit lane offset (24-bit multiply: the row inside the tile
+// x the row pitch in bytes, both far below 2^24).  `ptr + (long)m * ld + n` per row and tensor was a 64-bit multiply-add chain at quarter rate --
+// 190-240 of the 2 200-3 100 vector instructions of these kernels, a quarter of the epilogues' issue slots.
+template <class T> __device__ __forceinline__ const T* pipe_row(const T* tile0, int lrow, long ld, int n) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(tile0) + (__umul24((uint32_t)lrow, (uint32_t)ld * (uint32_t)sizeof(T)) + (uint32_t)n * (uint32_t)sizeof(T)));
+}
+template <class T> __device__ __forceinline__ T* pipe_row(T* tile0, int lrow, long ld, int n) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(tile0) + (__umul24((uint32_t)lrow, (uint32_t)ld * (uint32_t)sizeof(T)) + (uint32_t)n * (uint32_t)sizeof(T)));
+}
 // LDS fragment reads as inline asm.  hipcc cannot tell which ring stage a visible LDS read touches, so it guards EVERY such read with
 // s_waitcnt vmcnt(0) while an LDS-DMA is in flight -- i.e. it waits for the prefetch it has just issued, and a ring of any depth
 // degenerates to load -> wait -> multiply (the r1 kernels ran like that; build/isa shows the wait in front of the first ds_read of
@@ -99,6 +108,11 @@ __device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, 
   loadN<4>(p.ln_gamma + n, lng);
   if (EPI == EPI_RESID_LN) loadN<4>(p.ln_beta + n, lnb);
   float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+  // (uniform pointers to the tile's first row: pipe_row)
+  const float* resid_t = p.resid + (long)m0 * p.ldr;
+  float* Cf_t = Cf + (long)m0 * p.ldc;
+  bf16_t* auxo_t = reinterpret_cast<bf16_t*>(p.aux_out) + (long)m0 * p.ldc;
+  float* stats_t = p.ln_stats + 2 * (long)m0;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int lrow0 = wm * WR + i * 16, mbase = m0 + lrow0;
@@ -107,10 +121,10 @@ __device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {  // every global read of the pass is requested before the accumulators are staged
       const int mm = min(mbase + it * RPI + lane / LPR, p.M - 1);
-      loadN<4>(p.resid + (long)mm * p.ldr + n, rpre[it]);
+      loadN<4>(pipe_row(resid_t, mm - m0, p.ldr, n), rpre[it]);
       if (EPI == EPI_LN_BWD) {
-        if (Cf != nullptr) loadN<4>(Cf + (long)mm * p.ldc + n, gpre[it]);  // (NULL: dgamma / dbeta only, see the one-wave-per-row epilogue below)
-        spre[it] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mm);
+        if (Cf != nullptr) loadN<4>(pipe_row(Cf_t, mm - m0, p.ldc, n), gpre[it]);  // (NULL: dgamma / dbeta only, see the one-wave-per-row epilogue below)
+        spre[it] = *reinterpret_cast<const float2*>(stats_t + 2 * (mm - m0));
       }
     }
 #pragma unroll
@@ -133,7 +147,7 @@ __device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, 
           a[it][e] = rpre[it][e] + (v[e] + bias[e]) * rowm * meE.elem_mult(min(m, p.M - 1), n + e);
           s1 += a[it][e];
         }
-        if (m < p.M) storeN<4>(Cf + (long)m * p.ldc + n, a[it]);
+        if (m < p.M) storeN<4>(pipe_row(Cf_t, m - m0, p.ldc, n), a[it]);
         s1 = row16_sum(s1);
         s1 = xadd16(s1);
         const float mh = s1 * (1.0f / WC);
@@ -172,21 +186,21 @@ __device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, 
         float y[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (a[it][e] - mean) * rstd * lng[e] + lnb[e];
-        storeN<4>(reinterpret_cast<bf16_t*>(p.aux_out) + (long)m * p.ldc + n, y);
-        if (wn == 0 && (lane % LPR) == 0) *reinterpret_cast<float2*>(p.ln_stats + 2 * (long)m) = make_float2(mean, rstd);
+        storeN<4>(pipe_row(auxo_t, m - m0, p.ldc, n), y);
+        if (wn == 0 && (lane % LPR) == 0) *reinterpret_cast<float2*>(stats_t + 2 * (m - m0)) = make_float2(mean, rstd);
       } else {
         if (Cf == nullptr) continue;
         const float rstd = spre[it].y, m1 = (h1[it] + o.x) * (1.0f / BN), m2 = (h2[it] + o.y) * (1.0f / BN);
         float g[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] = gpre[it][e] + rstd * (a[it][e] - m1 - b[it][e] * m2);
-        storeN<4>(Cf + (long)m * p.ldc + n, g);
+        storeN<4>(pipe_row(Cf_t, m - m0, p.ldc, n), g);
         if (p.aux_out) {
           const float rowm = meE.row_mult(m);
           float gq[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) gq[e] = g[e] * rowm * meE.elem_mult(m, n + e);
-          storeN<4>(reinterpret_cast<bf16_t*>(p.aux_out) + (long)m * p.ldc + n, gq);
+          storeN<4>(pipe_row(auxo_t, m - m0, p.ldc, n), gq);
         }
       }
     }
@@ -362,6 +376,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
   constexpr int CPL = (sizeof(TC) == 2) ? 8 : 4;
   constexpr int LPR = WC / CPL, RPI = 64 / LPR;
   const int c = (lane % LPR) * CPL, n = n0 + wn * WC + c;
+  // (uniform pointers to the tile's first row: pipe_row)
+  const float* resid_t = p.resid + (long)m0 * p.ldr;
+  TC* C_t = C + (long)m0 * p.ldc;
+  const float* Cc_t = reinterpret_cast<const float*>(C) + (long)m0 * p.ldc;
+  bf16_t* auxo_t = reinterpret_cast<bf16_t*>(p.aux_out) + (long)m0 * p.ldc;
+  TC* auxoT_t = reinterpret_cast<TC*>(p.aux_out) + (long)m0 * p.ldc;
+  const bf16_t* aux_t = reinterpret_cast<const bf16_t*>(p.aux) + (long)m0 * p.ldaux;
+  float* stats_t = p.ln_stats + 2 * (long)m0;
   float bias[CPL];
 #pragma unroll
   for (int e = 0; e < CPL; ++e) bias[e] = 0.f;
@@ -380,12 +402,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int mm = min(mbase + it * RPI + lane / LPR, p.M - 1);
-        loadN<CPL>(p.resid + (long)mm * p.ldr + n, rpre[it]);
+        loadN<CPL>(pipe_row(resid_t, mm - m0, p.ldr, n), rpre[it]);
         if (EPI == EPI_LN_BWD) {  // the LayerNorm's input row (resid), the residual-stream gradient it is added to, the row's statistics
           // (C == NULL: nobody needs the input gradient -- the first block behind a frozen patch embedding -- only dgamma / dbeta:
           // the 8 + 4 bytes per element of reading, updating and re-casting the residual-stream gradient are skipped)
-          if (C != nullptr) loadN<CPL>(reinterpret_cast<const float*>(C) + (long)mm * p.ldc + n, gpre[it]);
-          spre[it] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mm);
+          if (C != nullptr) loadN<CPL>(pipe_row(Cc_t, mm - m0, p.ldc, n), gpre[it]);
+          spre[it] = *reinterpret_cast<const float2*>(stats_t + 2 * (mm - m0));
         }
       }
     }
@@ -402,12 +424,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
       loadN<CPL>(est + row * WPITCH + c, v);
 #pragma unroll
       for (int e = 0; e < CPL; ++e) v[e] += bias[e];
-      TC* dst = C + (long)m * p.ldc + n;
+      TC* dst = pipe_row(C_t, m - m0, p.ldc, n);
       if (EPI == EPI_STORE) {
         storeN<CPL>(dst, v);
       } else if (EPI == EPI_RESID) {
         float r[CPL];
-        loadN<CPL>(p.resid + (long)m * p.ldr + n, r);
+        loadN<CPL>(pipe_row(resid_t, m - m0, p.ldr, n), r);
         const float rowm = meE.row_mult(m);
 #pragma unroll
         for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
@@ -439,8 +461,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
         loadN<CPL>(p.ln_beta + n, bt);
 #pragma unroll
         for (int e = 0; e < CPL; ++e) yq[e] = (v[e] - mean) * rstd * gq[e] + bt[e];
-        storeN<CPL>(reinterpret_cast<bf16_t*>(p.aux_out) + (long)m * p.ldc + n, yq);
-        if ((lane % LPR) == 0) *reinterpret_cast<float2*>(p.ln_stats + 2 * (long)m) = make_float2(mean, rstd);
+        storeN<CPL>(pipe_row(auxo_t, m - m0, p.ldc, n), yq);
+        if ((lane % LPR) == 0) *reinterpret_cast<float2*>(stats_t + 2 * (m - m0)) = make_float2(mean, rstd);
       } else if (EPI == EPI_LN_BWD) {
         // v = dy of the LayerNorm (this GEMM's product, fp32 -- never written): dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;
         // the residual-stream gradient row gets += dx and leaves a second time as dtype(row * mask) for the next branch's GEMMs
@@ -472,11 +494,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
           float om[CPL];
 #pragma unroll
           for (int e = 0; e < CPL; ++e) om[e] = o[e] * rowm * meE.elem_mult(m, n + e);
-          storeN<CPL>(reinterpret_cast<bf16_t*>(p.aux_out) + (long)m * p.ldc + n, om);
+          storeN<CPL>(pipe_row(auxo_t, m - m0, p.ldc, n), om);
         }
       } else if (EPI == EPI_MUL_AUX) {
         float a[CPL];
-        loadN<CPL>(reinterpret_cast<const bf16_t*>(p.aux) + (long)m * p.ldaux + n, a);
+        loadN<CPL>(pipe_row(aux_t, m - m0, p.ldaux, n), a);
 #pragma unroll
         for (int e = 0; e < CPL; ++e) v[e] *= a[e];
         storeN<CPL>(dst, v);
@@ -493,7 +515,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
           v[e] = hh.x; v[e + 1] = hh.y;
         }
         storeN<CPL>(dst, v);
-        storeN<CPL>(reinterpret_cast<TC*>(p.aux_out) + (long)m * p.ldc + n, gq);
+        storeN<CPL>(pipe_row(auxoT_t, m - m0, p.ldc, n), gq);
       }
     }
   }
