@@ -169,6 +169,7 @@ PROTOTYPES = {
     "focal_pack_multi": (C.c_int, [C.c_int, C.c_int, C.POINTER(PackEntry), P]),
     "focal_unpack_add_multi": (C.c_int, [C.c_int, C.POINTER(PackEntry), P]),
     "focal_conv_pack_bwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P]),
+    "focal_set_dw_workgroup_target": (C.c_int, [C.c_int]),
     "focal_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
     "focal_conv_fwd_bn": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, C.POINTER(BNDesc), P, P, P, P, P]),
     "focal_conv_bwd_data": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),

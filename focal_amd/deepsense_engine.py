@@ -215,6 +215,9 @@ class DeepSenseModEncoder:
         B, T, H, gd = sv["B"], sv["T"], sv["H"], sv["gd"]
         # ---- GRU, last layer first
         dout, ld_b, ld_t, scale = dfeat, 2 * H, 0, 1.0 / T  # d(mean over time): every step gets dfeat / T
+        # four passes (two views x two modalities) run their backward side by side: a third of the default workgroups per weight gradient,
+        # i.e. a third of the fp32 atomics of their small outputs (+4 % on the step: include/focal_hip.h, gemm.hpp: focal_dw_plan)
+        ops.set_dw_workgroup_target(192)
         for layer in range(geo["n_rnn"] - 1, -1, -1):
             lsv = sv["gru"][layer]
             x_l = lsv["x"]

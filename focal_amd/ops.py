@@ -347,6 +347,11 @@ def linear_bwd_data_ln(d, dy, w, ln_x, ln_stats, ln_gamma, g, dgamma, dbeta, g_m
                                                _p(g_masked), C.byref(mask) if mask is not None else None, _stream()))
 
 
+def set_dw_workgroup_target(target):
+    """Workgroup target of the stand-alone weight gradients' token-split plan (0 = default); returns the previous value."""
+    return int(_lib.load().focal_set_dw_workgroup_target(int(target)))
+
+
 def linear_bwd_weight(d, dy, x, dw, dbias):
     check(_lib.load().focal_linear_bwd_weight(C.byref(d), _p(dy), _p(x), _p(dw), _p(dbias), _stream()))
 

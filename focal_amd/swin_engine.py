@@ -175,6 +175,7 @@ class SwinModEncoder:
         return feat, saved
 
     def backward(self, saved, dfeat):
+        ops.set_dw_workgroup_target(0)  # (a DeepSense model of the same process lowers it for its four side-by-side passes)
         """Accumulates every parameter gradient of this encoder into the arena; returns nothing (input is a leaf).
 
         Data parallel (bb.split_backward, set by focal_amd/graph_step.py): the pass stops once the LAST stage's blocks are done -- by

@@ -197,6 +197,11 @@ int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const vo
 /* Number of workgroups focal_linear_bwd_weight launches for this descriptor (output tiles x token splits): lets a caller match its
  * calls against the launch shapes of a profiler trace (bench.py's in-step roofline).  0 = invalid descriptor. */
 int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d);
+/* Tuning hint, process-wide: how many workgroups the token-split plan of the stand-alone weight gradients (focal_linear_bwd_weight,
+ * focal_conv_bwd_weight) aims at; 0 restores the default (~512: one launch fills the chip).  A caller that runs several passes side by
+ * side on their own streams -- the DeepSense engine: two views x two modalities -- asks for ~192: the launches share the chip anyway and a
+ * third of the workgroups is a third of the fp32 atomics of their small outputs.  Returns the previous value. */
+int focal_set_dw_workgroup_target(int target);
 /* Which kernel that launch runs: 1 = focal_gemm_kernel (register-staged, any dtype / loader), 2 = focal_dw_ring_kernel (the LDS-DMA
  * ring for bf16 shapes made of whole 64-tiles, given 16-byte aligned operands; 512-thread workgroups of two token slices each).  0 = invalid descriptor. */
 int focal_linear_bwd_weight_kernel(const focal_linear_desc* d);
