@@ -15,7 +15,7 @@ EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
 BN_STAT_SLOTS = 16      # focal_conv_fwd_bn: column sums are spread over this many slots of the scratch
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class DropDesc(C.Structure):
@@ -48,7 +48,7 @@ class LNDesc(C.Structure):
 class LinearDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("x_dtype", C.c_int),
                 ("y_dtype", C.c_int), ("act_in", C.c_int), ("epilogue", C.c_int), ("splits", C.c_int),
-                ("out_drop", DropDesc)]
+                ("out_drop", DropDesc), ("dw_workgroups", C.c_int)]
 
 
 class DwProblem(C.Structure):
@@ -82,7 +82,7 @@ class ConvInDesc(C.Structure):
 
 
 class ConvDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("dtype", "rows", "S", "C_in", "C_out", "k")]
+    _fields_ = [(n, C.c_int) for n in ("dtype", "rows", "S", "C_in", "C_out", "k", "dw_workgroups")]
 
 
 class BNDesc(C.Structure):
@@ -146,7 +146,6 @@ PROTOTYPES = {
     "focal_window_attn_qkv_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "focal_window_attn_qkv_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P]),
     "focal_window_attn_qkv_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P, P, P, P]),
-    "focal_window_attn_branch_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P]),
     "focal_fusion_attn_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint32, C.c_float, P]),
     "focal_fusion_attn_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P, P]),
     "focal_cross_entropy": (C.c_int, [C.c_int, C.c_int, P, P, P, P, P]),
@@ -169,7 +168,6 @@ PROTOTYPES = {
     "focal_pack_multi": (C.c_int, [C.c_int, C.c_int, C.POINTER(PackEntry), P]),
     "focal_unpack_add_multi": (C.c_int, [C.c_int, C.POINTER(PackEntry), P]),
     "focal_conv_pack_bwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P]),
-    "focal_set_dw_workgroup_target": (C.c_int, [C.c_int]),
     "focal_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),
     "focal_conv_fwd_bn": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, C.POINTER(BNDesc), P, P, P, P, P]),
     "focal_conv_bwd_data": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P]),

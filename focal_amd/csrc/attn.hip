@@ -333,22 +333,6 @@ extern "C" int focal_window_attn_qkv_bwd(const focal_attn_desc* d, const void* a
                              (hipStream_t)stream, (const bf16_t*)wqkv, bqkv, (const bf16_t*)wproj);
 }
 
-extern "C" int focal_window_attn_branch_bwd(const focal_attn_desc* d, const void* a1, const void* gm, const void* wqkv, const float* bqkv,
-                                            const void* wproj, const float* bias_table, void* dqkv, float* dbias_table, const float* ln_x,
-                                            const float* ln_stats, const float* ln_gamma, float* g, void* g_masked, const focal_drop_desc* mask,
-                                            float* dgamma, float* dbeta, void* stream) {
-  AttnGeom geo;
-  if (int rc = attn_geometry(d, &geo)) return rc;
-  FOCAL_CHECK_ARG(a1 && gm && wqkv && bqkv && wproj && bias_table && dqkv && dbias_table && ln_x && ln_stats && ln_gamma && dgamma && dbeta,
-                  "window_attn_branch_bwd: null tensor");
-  FOCAL_CHECK_ARG(focal_window_attn_qkv_supported(d->dtype, geo.C, geo.heads, geo.N), "window_attn_branch_bwd: built for bf16, C = 64, 4 heads (got dtype %d, C = %d, heads = %d)",
-                  d->dtype, geo.C, geo.heads);
-  FOCAL_CHECK_ARG((2 * geo.wh - 1) * (2 * geo.ww - 1) * geo.heads <= 256, "window_attn_branch_bwd: bias table too large");
-  FOCAL_CHECK_ARG(g || !g_masked, "window_attn_branch_bwd: g_masked without g");
-  return focal_attn_branch_bwd(geo, (const bf16_t*)a1, (const bf16_t*)gm, (const bf16_t*)wqkv, bqkv, (const bf16_t*)wproj, bias_table, (bf16_t*)dqkv,
-                               dbias_table, ln_x, ln_stats, ln_gamma, g, (bf16_t*)g_masked, mask, dgamma, dbeta, d->rng, d->stream, d->p_attn,
-                               (hipStream_t)stream);
-}
 
 extern "C" int focal_window_attn_bwd(const focal_attn_desc* d, const void* qkv, const float* bias_table, const void* dout,
                                      void* dqkv, float* dbias_table, void* stream) {

@@ -57,11 +57,6 @@ __device__ __forceinline__ int att_token(const AttnGeom& g, int win, int i, int*
 }
 
 
-// the attention branch's backward of a 64-channel block per window and wave (attn_mfma.hip: swin_attn_branch_bwd_kernel)
-int focal_attn_branch_bwd(const AttnGeom& g, const bf16_t* a1, const bf16_t* gm, const bf16_t* wqkv, const float* bqkv, const bf16_t* wproj,
-                          const float* bias_table, bf16_t* dqkv, float* dbias_table, const float* x, const float* stats, const float* gamma,
-                          float* gres, bf16_t* g_masked, const focal_drop_desc* mask, float* dgamma, float* dbeta, const uint32_t* rng,
-                          uint32_t stream_id, float p_attn, hipStream_t st);
 // wqkv / bqkv non-NULL: `qkv` is the LayerNorm output a1 [M][C] and the kernels project q / k / v themselves (C == 64, 4 heads of 16)
 int focal_attn_mfma_fwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_table, bf16_t* out, const uint32_t* rng, uint32_t stream_id,
                         float p_attn, hipStream_t st, const bf16_t* wqkv = nullptr, const float* bqkv = nullptr);

@@ -630,330 +630,3 @@ int focal_attn_mfma_bwd(const AttnGeom& g, const bf16_t* qkv, const float* bias_
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
-
-// ============================================================================================================================
-// Round 4: the whole attention-branch backward of a 64-channel block in one launch.
-//
-//   gm (= dL/d(proj output) x mask), a1 (= norm1 output)  ->  dqkv (for the layer's weight gradient), dL/da1 -> norm1's backward:
-//   g += dLN, gm_next = bf16(g x mask of the previous block's MLP branch), dgamma / dbeta, dbias_table.
-//
-// What follows window_attn_bwd_mfma_kernel in the two-launch form -- dX of the qkv Linear with norm1's backward as its epilogue, a GEMM
-// launch that re-reads dqkv (384 B per token) -- contracts over all 192 qkv columns, i.e. over the four heads, which live in four
-// waves.  The item decomposition of that kernel is kept (a wave = one (window, head); waves 4 s .. 4 s + 3 of a workgroup hold the four
-// heads of one window in every step of the item loop):
-//   1. the item math as before; the head's dq / dk / dv accumulators D[d][token] are already the B operands of a 16 x 16 x 16 MFMA and
-//      are contracted with transposed-read fragments of the head's 48 Wqkv rows (a swizzled LDS image) into the head's PARTIAL
-//      dL/da1^T[c][token] -- 12 MFMAs, 4 accumulator tiles;
-//   2. the partials go to LDS (fp32, [wave][token][channel]), one workgroup barrier;
-//   3. wave h of the window finishes tokens 4 h .. 4 h + 3: 16 lanes per token, 4 channels per lane, the four heads' partials summed;
-//      LayerNorm's two row sums are DPP reductions over the 16 lanes; the residual-stream gradient is updated in place at the token's
-//      original position (roll / window partition are index arithmetic, as everywhere).  x, g and the row statistics of these tokens were
-//      requested at the top of the step, so the phase between the two barriers waits on nothing.
-// No [M, C] dL/da1 tensor, no second read of dqkv, one launch less per block.  (First attempt, wave per WINDOW walking the heads with the
-// LayerNorm on the accumulators and no exchange: 180 registers -> 8 waves per CU, 20 % slower than two launches;
-// profiles/r4_attn_branch_bwd.txt.  This form keeps the 16-wave occupancy of the attention kernel.)
-struct BranchBwdParams {
-  const bf16_t* a1; const bf16_t* gm; const bf16_t* wqkv; const float* bqkv; const bf16_t* wproj; const float* bias_table;
-  bf16_t* dqkv; float* dbias_table;
-  const float* x; const float* stats; const float* gamma; float* g; bf16_t* g_masked; float* dgamma; float* dbeta;
-  focal_drop_desc mask;
-  AttnGeom geo;
-  int total_items, iters;
-  const uint32_t* rng; uint32_t stream; float p_attn;
-};
-
-__device__ __forceinline__ int br_sw(int row) { return ((row >> 1) & 3) << 1; }  // chunk swizzle of the 128-byte-row weight image (as mlp_bwd.hip: sw_tok)
-
-__device__ __forceinline__ void br_row_fetch(RowRegs& r, const bf16_t* a1, uint32_t tok, bool /*valid*/, int grp) {
-  r.v[0] = br_ld<bf16x8>(a1, tok * 128u + 16u * grp);
-  r.v[1] = br_ld<bf16x8>(a1, tok * 128u + 16u * grp + 64u);
-}
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void swin_attn_branch_bwd_kernel(const BranchBwdParams p) {
-  constexpr int HD = 16, C = 64, P = HD + 4, TILE = 16 * P, HEADS = 4;
-  static_assert(NW % HEADS == 0, "the waves of a window sit side by side");
-  __shared__ __attribute__((aligned(16))) bf16_t tiles[NW][4][TILE];
-  __shared__ __attribute__((aligned(16))) bf16_t trt[NW][2][16 * 20];
-  __shared__ __attribute__((aligned(16))) char wq_img[192 * 128];        // Wqkv [3C][C] bf16, 16-byte chunk c of row r at c ^ br_sw(r & 15)
-  __shared__ __attribute__((aligned(16))) float part[NW][ATT_NMAX][C];   // partial dL/da1 [wave][token slot][channel], 16-byte chunk s of a row at s ^ slot
-  __shared__ __attribute__((aligned(16))) float qb[192], gam[64], dgb[128];
-  __shared__ float dbacc[256];
-  __shared__ int grp_cnt[NW / HEADS][2];  // per window group: partials written / partials consumed (monotonic wave counts)
-  const AttnGeom& g = p.geo;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // Window slot ws and head h of the wave, for the whole kernel.  Waves w, w + 4, w + 8, w + 12 share a SIMD: they get four different
-  // windows (so that they drift apart and fill each other's waits -- only the four waves of a WINDOW synchronise, through LDS counters,
-  // never the workgroup) and four different heads (the finishing phase below is unequal over the heads).
-  const int ws = wave >> 2, h = (wave + ws) & (HEADS - 1);
-  const int grp = lane >> 4, col = lane & 15, tq = col >> 2, tp = col & 3;
-  bf16_t* Qt = tiles[wave][0];
-  bf16_t* Kt = tiles[wave][1];
-  bf16_t* Vt = tiles[wave][2];
-  bf16_t* Gt = tiles[wave][3];
-  const int table = (2 * g.wh - 1) * (2 * g.ww - 1) * g.heads;
-  for (int q = threadIdx.x; q < 192 * 8; q += NW * 64) {
-    const int r = q >> 3, c = q & 7;
-    *reinterpret_cast<uint4*>(wq_img + r * 128 + ((c ^ br_sw(r & 15)) << 4)) = *reinterpret_cast<const uint4*>(p.wqkv + r * C + c * 8);
-  }
-  for (int t = threadIdx.x; t < 256; t += NW * 64) {
-    dbacc[t] = 0.f;
-    if (t < 192) qb[t] = p.bqkv[t];
-    if (t < 64) gam[t] = p.gamma[t];
-    if (t < 128) dgb[t] = 0.f;
-    if (t < 2 * (NW / HEADS)) (&grp_cnt[0][0])[t] = 0;
-  }
-  __syncthreads();
-  // (uniform values into scalar registers: the vector file is the scarce resource of this kernel)
-  auto uni = [](DropCtx c) {
-    c.key = __builtin_amdgcn_readfirstlane(c.key); c.thresh = __builtin_amdgcn_readfirstlane(c.thresh);
-    c.scale = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c.scale)));
-    return c;
-  };
-  const DropCtx dc = uni(make_drop(p.rng, p.stream, p.p_attn));
-  const bool drop_on = p.p_attn > 0.f;
-  const DropCtx me = uni(make_drop(p.mask.rng, p.mask.stream_elem, p.mask.p_elem)), mp = uni(make_drop(p.mask.rng, p.mask.stream_path, p.mask.p_path));
-  const bool m_on_e = p.mask.p_elem > 0.f, m_on_p = p.mask.p_path > 0.f;
-  const int m_rps = p.mask.rows_per_sample > 0 ? p.mask.rows_per_sample : 1;
-  const TileIdx tA = make_tile_idx<true>(g, lane);  // rows j = 4 grp + r, column i = col
-  const int slot = col;
-  const SlotLane SL = slot_lane(g, slot);
-  const bool valid = slot < g.N;
-  float dbreg[4] = {0.f, 0.f, 0.f, 0.f}, badd[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) badd[r] = tA.ok[r] ? p.bias_table[tA.rel[r] + h] : (tA.qpad[r] ? 0.f : -1.0e30f);
-  // Wqkv fragments of the wave's head out of the image: direct (q / k / v projection) and transposed (dL/da1)
-  const char* w_dir = wq_img + (h * 16 + col) * 128 + ((grp ^ br_sw(col)) << 4);                                   // + t 64 rows; kk = 1: ^ 64
-  const char* w_tr = wq_img + (h * 16 + 4 * grp + tq) * 128 + (tp & 1) * 8;                                        // + t 64 rows
-  const int x_tr = ((tp >> 1) ^ br_sw(4 * grp + tq)) << 4;                                                         // ct: ^ (ct << 5)
-  bf16x8 wpt[2];  // A fragments of Wproj^T for the wave's head: row d = col <-> column h 16 + d of Wproj, k = output channels 32 kk + 8 grp ..
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) wpt[kk][e] = p.wproj[(long)(32 * kk + 8 * grp + e) * C + h * 16 + col];
-  // the finishing phase: this lane works on token slot 4 h + grp of the window, channels 4 col .. 4 col + 3
-  const int fslot = 4 * h + grp;
-  const bool fvalid = fslot < g.N;
-  const bool fin_any = 4 * h < g.N;  // (scalar) heads past the window's last token have nothing to finish
-  float* part_w = &part[ws * HEADS + h][0][0];
-  const float* part_r = &part[ws * HEADS][fslot][0];
-  int* cnt_w = &grp_cnt[ws][0];
-  int* cnt_r = &grp_cnt[ws][1];
-  auto grp_signal = [&](int* c) {  // DS operations of a wave execute in issue order: the count follows the wave's writes / reads above it
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (lane == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  auto grp_wait = [&](int* c, int target) {
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  float dgr[4] = {0.f, 0.f, 0.f, 0.f}, dbr[4] = {0.f, 0.f, 0.f, 0.f};
-
-  auto item_of = [&](int it, bool& live) {
-    const int win = (it * gridDim.x + blockIdx.x) * (NW / HEADS) + ws;
-    live = win * HEADS < p.total_items;
-    return live ? win : 0;
-  };
-  RowRegs rx, rgm;
-  bool live_n;
-  int win_n = item_of(0, live_n), reg_n = 0, tok_n = 0;
-  tok_n = slot_token(g, win_n, SL, &reg_n);
-  br_row_fetch(rx, p.a1, tok_n, valid, grp);
-  br_row_fetch(rgm, p.gm, tok_n, valid, grp);
-#pragma unroll 1
-  for (int it = 0; it < p.iters; ++it) {
-    const bool live = live_n;
-    const int win = win_n, reg_own = reg_n, tok_own = tok_n;
-    // ---- the finishing phase's rows are requested now: they land behind the item math
-    const int tok_f = __shfl(tok_own, fslot, 64);
-    const bool row_ok = live && fvalid;
-    const uint32_t roff = (uint32_t)tok_f * 256u + 16u * col;  // byte offset of the lane's four fp32 channels
-    float2 stt = make_float2(0.f, 0.f);
-    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), go = xv;
-    if (row_ok) {
-      stt = br_ld<float2>(p.stats, (uint32_t)tok_f * 8u);
-      xv = br_ld<float4>(p.x, roff);
-      if (p.g != nullptr) go = br_ld<float4>(p.g, roff);
-    }
-    wave_lds_fence();
-    // ---- q / k / v and dO of this item
-    {
-      bf16_t* dst[3] = {Qt, Kt, Vt};
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const char* wb = w_dir + t * 64 * 128;
-        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wb), rx.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>((const char*)((uintptr_t)wb ^ 64)), rx.v[1], acc, 0, 0, 0);
-        acc += *reinterpret_cast<const f32x4*>(qb + t * 64 + h * 16 + 4 * grp);
-        const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-        *reinterpret_cast<bf16x4*>(dst[t] + col * P + 4 * grp) = pack4z(o, valid);
-      }
-      f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpt[0], rgm.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wpt[1], rgm.v[1], acc, 0, 0, 0);
-      const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
-      *reinterpret_cast<bf16x4*>(Gt + col * P + 4 * grp) = pack4z(o, valid);
-    }
-    wave_lds_fence();
-    if (it + 1 < p.iters) {  // the next item's rows fly while this one is multiplied
-      win_n = item_of(it + 1, live_n);
-      reg_n = 0;
-      tok_n = slot_token(g, win_n, SL, &reg_n);
-      br_row_fetch(rx, p.a1, tok_n, valid, grp);
-      br_row_fetch(rgm, p.gm, tok_n, valid, grp);
-    }
-    // ---- the item (window, h): window_attn_bwd_mfma_kernel's math
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 st, dt;
-    {
-      const bf16x4 fq = frag_rows(Qt, P, 0, lane), fk = frag_rows(Kt, P, 0, lane);
-      const bf16x4 fv = frag_rows(Vt, P, 0, lane), fg = frag_rows(Gt, P, 0, lane);
-      st = mma16x16(fk, fq, z4);  // S^T  : rows j, col i
-      dt = mma16x16(fv, fg, z4);  // dPd^T: rows j, col i
-    }
-    float pr[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pr[r] = fmaf(st[r], g.scale, badd[r]);
-    if (g.shifted) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int reg_j = __shfl(reg_own, 4 * grp + r, 64);
-        pr[r] += (tA.ok[r] && reg_j != reg_own) ? -100.0f : 0.f;
-      }
-    }
-    float mx = fmaxf(fmaxf(pr[0], pr[1]), fmaxf(pr[2], pr[3]));
-    mx = rows4_max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pr[r] = __expf(pr[r] - mx); sum += pr[r]; }
-    sum = rows4_sum(sum);
-    const float inv = __builtin_amdgcn_rcpf(sum);
-    float dm[4] = {1.f, 1.f, 1.f, 1.f};
-    if (drop_on) att_drop4(dc, att_drop_q((uint32_t)win * g.heads + h, col, grp), dm);  // (i = col, j = 4 grp + r)
-    float dsT[4], pdT[4], dot = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pr[r] *= inv;
-      const float mlt = tA.ok[r] ? dm[r] : 1.f;
-      pdT[r] = pr[r] * mlt;
-      dsT[r] = dt[r] * mlt;
-      dot += pr[r] * dsT[r];
-    }
-    dot = rows4_sum(dot);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dsT[r] = pr[r] * (dsT[r] - dot);
-      if (live) dbreg[r] += dsT[r];
-    }
-    const bf16x4 bdsT = pack4(dsT), bpdT = pack4(pdT);
-    bf16_t* tw = trt[wave][0];
-    *reinterpret_cast<bf16x4*>(tw + col * 20 + 4 * grp) = bdsT;
-    *reinterpret_cast<bf16x4*>(tw + 16 * 20 + col * 20 + 4 * grp) = bpdT;
-    wave_lds_fence();
-    bf16x4 bt[3];
-    {
-      const bf16x4 bds = frag_cols(tw, 20, 0, lane);
-      const bf16x4 bpd = frag_cols(tw + 16 * 20, 20, 0, lane);
-      const f32x4 dq = mma16x16(frag_cols(Kt, P, 0, lane), bdsT, z4);  // dQ^T[d][i]
-      const f32x4 dk = mma16x16(frag_cols(Qt, P, 0, lane), bds, z4);   // dK^T[d][j]
-      const f32x4 dv = mma16x16(frag_cols(Gt, P, 0, lane), bpd, z4);   // dV^T[d][j]
-      // padded slots carry garbage (a padded query's softmax row): zeroed here, they feed the dL/da1 products below
-      const float a[4] = {dq[0] * g.scale, dq[1] * g.scale, dq[2] * g.scale, dq[3] * g.scale};
-      const float b[4] = {dk[0] * g.scale, dk[1] * g.scale, dk[2] * g.scale, dk[3] * g.scale};
-      const float c[4] = {dv[0], dv[1], dv[2], dv[3]};
-      bt[0] = pack4z(a, valid); bt[1] = pack4z(b, valid); bt[2] = pack4z(c, valid);
-    }
-    if (live && valid) {
-      const uint32_t doff = (uint32_t)tok_own * 384u + (uint32_t)(h * HD + 4 * grp) * 2u;
-      br_st<bf16x4>(p.dqkv, doff) = bt[0];
-      br_st<bf16x4>(p.dqkv, doff + 128u) = bt[1];
-      br_st<bf16x4>(p.dqkv, doff + 256u) = bt[2];
-    }
-    // ---- this head's part of dL/da1^T[c][token] = sum_d Wqkv_t[h 16 + d][c] . dT^T[d][token]: the accumulators ARE the B operands (k = d = 4 grp + e)
-    f32x4 dacc[4] = {z4, z4, z4, z4};
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const char* wb = w_tr + t * 64 * 128;
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const bf16x4 wf = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(wb + (x_tr ^ (ct << 5))));
-        dacc[ct] = mma16x16(wf, bt[t], dacc[ct]);
-      }
-    }
-    grp_wait(cnt_r, HEADS * it);  // the previous step's partials have been read by the window's four waves
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<f32x4*>(part_w + col * C + (((4 * ct + grp) ^ col) << 2)) = dacc[ct];
-    grp_signal(cnt_w);
-    // ---- norm1's backward on token slot 4 h + grp of the window, channels 4 col .. + 3
-    if (!fin_any) {
-      grp_signal(cnt_r);
-    } else {
-      grp_wait(cnt_w, HEADS * (it + 1));
-      f32x4 da = *reinterpret_cast<const f32x4*>(part_r + ((col ^ fslot) << 2));
-#pragma unroll
-      for (int hh = 1; hh < HEADS; ++hh) da += *reinterpret_cast<const f32x4*>(part_r + hh * ATT_NMAX * C + ((col ^ fslot) << 2));
-      grp_signal(cnt_r);
-      const f32x4 gm4 = *reinterpret_cast<const f32x4*>(gam + 4 * col);
-      const float xr[4] = {xv.x, xv.y, xv.z, xv.w}, gr[4] = {go.x, go.y, go.z, go.w};
-      float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float dy = row_ok ? da[r] : 0.f;
-        xh[r] = (xr[r] - stt.x) * stt.y;
-        dxh[r] = dy * gm4[r];
-        s1 += dxh[r];
-        s2 += dxh[r] * xh[r];
-        dgr[r] += dy * xh[r];
-        dbr[r] += dy;
-      }
-      s1 = row16_sum(s1);
-      s2 = row16_sum(s2);
-      const float m1 = s1 * (1.0f / C), m2 = s2 * (1.0f / C);
-      if (row_ok && p.g != nullptr) {
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = gr[r] + stt.y * (dxh[r] - m1 - xh[r] * m2);
-        br_st<float4>(p.g, roff) = make_float4(o[0], o[1], o[2], o[3]);
-        if (p.g_masked != nullptr) {
-          const float rowm = m_on_p ? drop_mult(mp, (uint32_t)(tok_f / m_rps)) : 1.0f;
-          float om[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) om[r] = o[r] * (m_on_e ? rowm * drop_mult(me, (uint32_t)tok_f * C + 4 * col + r) : rowm);
-          br_st<bf16x4>(p.g_masked, roff >> 1) = pack4(om);
-        }
-      }
-    }
-  }
-  // ---- bias-table, gamma and beta gradients: registers -> LDS -> one atomic per entry and workgroup
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (tA.ok[r]) atomicAdd(&dbacc[tA.rel[r] + h], dbreg[r]);
-    atomicAdd(&dgb[4 * col + r], dgr[r]);
-    atomicAdd(&dgb[64 + 4 * col + r], dbr[r]);
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < table; t += NW * 64) atomicAdd(p.dbias_table + t, dbacc[t]);
-  for (int t = threadIdx.x; t < 2 * C; t += NW * 64) atomicAdd((t < C ? p.dgamma : p.dbeta - C) + t, dgb[t]);
-}
-
-int focal_attn_branch_bwd(const AttnGeom& g, const bf16_t* a1, const bf16_t* gm, const bf16_t* wqkv, const float* bqkv, const bf16_t* wproj,
-                          const float* bias_table, bf16_t* dqkv, float* dbias_table, const float* x, const float* stats, const float* gamma,
-                          float* gres, bf16_t* g_masked, const focal_drop_desc* mask, float* dgamma, float* dbeta, const uint32_t* rng,
-                          uint32_t stream_id, float p_attn, hipStream_t st) {
-  if ((long)g.B * g.H * g.W * 384 >= (1L << 32)) return FOCAL_EUNSUPPORTED;  // the kernel addresses rows with 32-bit byte offsets
-  BranchBwdParams p;
-  memset(&p, 0, sizeof(p));
-  p.a1 = a1; p.gm = gm; p.wqkv = wqkv; p.bqkv = bqkv; p.wproj = wproj; p.bias_table = bias_table;
-  p.dqkv = dqkv; p.dbias_table = dbias_table;
-  p.x = x; p.stats = stats; p.gamma = gamma; p.g = gres; p.g_masked = g_masked; p.dgamma = dgamma; p.dbeta = dbeta;
-  if (mask) p.mask = *mask;
-  p.geo = g;
-  p.total_items = g.B * g.nW * 4;
-  constexpr int NW = 16;
-  int blocks = ceil_div(p.total_items, NW);
-  if (blocks > 256) blocks = 256;  // persistent, one workgroup per CU (148 KB of LDS), as focal_attn_mfma_bwd
-  p.iters = ceil_div(p.total_items, blocks * NW);
-  p.rng = rng; p.stream = stream_id; p.p_attn = p_attn;
-  FOCAL_LAUNCH((swin_attn_branch_bwd_kernel<NW>), dim3(blocks), dim3(NW * 64), 0, st, p);
-  FOCAL_LAUNCH_CHECK();
-  return FOCAL_OK;
-}

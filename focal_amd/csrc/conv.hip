@@ -650,6 +650,7 @@ extern "C" int focal_conv_bwd_weight(const focal_conv_desc* d, const void* dz, c
   p.C = dw_packed; p.ldc = K;
   p.batch = 1; p.alpha = 1.f;
   p.splits = 1;  // chosen with the tile shape in gemm_dispatch.inc (launch_dw)
+  p.dw_target = d->dw_workgroups;
   p.proB = conv_window(d->S, d->C_in, pad);
   p.colsumA = dbias;
   return focal_launch_gemm(s, p, (hipStream_t)stream);

@@ -26,10 +26,3 @@ extern "C" const char* focal_last_kernel(void) { return g_kernel; }
 extern "C" int focal_abi_version(void) { return FOCAL_ABI_VERSION; }
 extern "C" const char* focal_last_error(void) { return g_err; }
 
-// Workgroup target of the split plan of focal_linear_bwd_weight / focal_conv_bwd_weight (gemm.hpp: focal_dw_plan); 0 = the default.
-int g_focal_dw_target = 0;
-extern "C" int focal_set_dw_workgroup_target(int target) {
-  const int old = g_focal_dw_target;
-  g_focal_dw_target = target > 0 ? target : 0;
-  return old;
-}

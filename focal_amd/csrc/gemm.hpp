@@ -37,6 +37,7 @@ struct GemmParams {
   const void* B; long ldb; long strideB;
   void* C; long ldc; long strideC;
   int batch, splits;
+  int dw_target;                  // weight-gradient launches: workgroups the token-split plan aims at (0 = default; focal_dw_plan)
   float alpha;
   const float* bias;              // [N] f32 or null
   const float* resid; long ldr;   // f32 [M][N] (EPI_RESID)
@@ -346,18 +347,17 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
 // Launch plan of a weight-gradient GEMM (output [M][N], reduction over `rows` tokens split across workgroups): tile shape and split
 // count.  Shared by the dispatcher (gemm_dispatch.inc: launch_dw) and by focal_linear_bwd_weight_workgroups, which tells a caller
 // how a launch will show up in a profiler trace.
-extern int g_focal_dw_target;  // error.cpp; focal_set_dw_workgroup_target
-static inline void focal_dw_plan(int M, int N, long rows, int* bm_out, int* bn_out, int* splits_out) {
+static inline void focal_dw_plan(int M, int N, long rows, int target, int* bm_out, int* bn_out, int* splits_out) {
   // 64 x 64 tiles, at least 256 reduction rows each: the wide register-staged shapes (256 x 64 ... 128 x 128) were swept in rounds 1-2 and
   // lost everywhere (profiles/r1_i_dw_tile_sweep.txt, r2_dw_variants.txt); round 4 removed them
   const int bm = 64, bn = 64;
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-  // ~512 workgroups by default; a caller that runs several passes side by side lowers the target (focal_set_dw_workgroup_target): what is left
+  // ~512 workgroups by default; a caller that runs several passes side by side lowers the target (the descriptor's dw_workgroups): what is left
   // on this path after the grouped launches took the Swin blocks are DeepSense's weight gradients -- tiny outputs (64 x 192 ... 768 x 512)
   // reduced over 2 560 - 51 200 rows, four passes of them on four streams -- and there the fp32 atomic epilogue is the cost: 513 workgroups of a
   // [64, 192] convolution gradient are 2.1 M atomics onto 12 k addresses.  Same-box sweep, DeepSense windows/s: 512: 113 500 / 114 200,
   // 256: 115 500 / 116 300, 192: 119 000 / 118 700, 128: 117 500 / 118 000 / 115 400 / 119 000, 96: 114 900 / 115 100, 64: 111 900 / 112 600.
-  const long target_wg = g_focal_dw_target > 0 ? g_focal_dw_target : 512;
+  const long target_wg = target > 0 ? target : 512;
   long splits = (target_wg + tiles - 1) / tiles;
   const long min_rows = 256;  // reduction rows per workgroup, at least
   const long max_splits = (rows + min_rows - 1) / min_rows;

@@ -204,6 +204,7 @@ extern "C" int focal_linear_bwd_weight(const focal_linear_desc* d, const void* d
   p.C = dw; p.ldc = d->K;
   p.batch = 1; p.alpha = 1.f;
   p.splits = 1;  // chosen with the tile shape in gemm_dispatch.inc (launch_dw)
+  p.dw_target = d->dw_workgroups;
   p.proA = masked ? to_mask(d->out_drop, d->N) : no_mask();
   p.proB = no_mask();
   p.epi = no_mask();
@@ -215,7 +216,7 @@ extern "C" int focal_linear_bwd_weight(const focal_linear_desc* d, const void* d
 static bool dw_launch_plan(const focal_linear_desc* d, int* kernel, int* wgs) {
   if (check_desc(d) != FOCAL_OK) return false;
   int bm, bn, splits;
-  focal_dw_plan(d->N, d->K, d->M, &bm, &bn, &splits);
+  focal_dw_plan(d->N, d->K, d->M, d->dw_workgroups, &bm, &bn, &splits);
   const bool masked = d->epilogue == FOCAL_EPI_RESIDUAL || (d->y_dtype == FOCAL_F32 && d->x_dtype != FOCAL_F32);
   const bool ring = d->dtype == FOCAL_BF16 && d->x_dtype == FOCAL_BF16 && d->y_dtype == FOCAL_BF16 && !masked && bm == 64 && bn == 64 &&
                     focal_dw_ring_shape(d->N, d->K, d->M);

@@ -132,7 +132,9 @@ struct MlpDropStream {
     scale = c.scale;
   }
   __device__ __forceinline__ uint32_t start(uint32_t key, int row, int group) const {
-    const uint32_t v = focal_hash24((((uint32_t)row << 2) | (uint32_t)group) ^ key);
+    // (the bijection, not focal_hash24: a launch starts ~6e5 streams, and a hash with 2^24 distinct outputs per key would give ~1e4 pairs
+    // of (row, group)s identical 64-unit masks; the seed is drawn once per row, outside the issue-bound loops -- ADVICE r4)
+    const uint32_t v = focal_mix32((((uint32_t)row << 2) | (uint32_t)group) ^ key);
     return v ? v : 0x9E3779B9u;
   }
   __device__ __forceinline__ gelu_f2 next(uint32_t& st) const {

@@ -316,6 +316,10 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
         }
       }
     }
+    // Without LN nothing separates this phase's gm^T reads (the db2 column sums) from the next iteration's stage(), which overwrites
+    // the gm / a2 / mask images in front of the loop's first barrier: a wave that runs ahead would corrupt a slower wave's db2
+    // (ADVICE r4).  With LN the row-exchange barrier above already stands between the two.
+    if (!LN) lds_barrier();
   }
   __syncthreads();  // every wave is out of the loop: the images are free
   // ---- weight gradients -> two fp32 images ([64][256] dW2, [256][64] dW1), bias gradients

@@ -16,6 +16,11 @@ import torch
 from . import ops
 from ._lib import ACT_NONE, EPI_NONE
 
+# Four passes (two views x two modalities) run their backward side by side: their stand-alone weight gradients ask for a third of the default
+# workgroups, i.e. a third of the fp32 atomics of their small outputs (+4 % on the step: include/focal_hip.h focal_linear_desc.dw_workgroups,
+# gemm.hpp: focal_dw_plan).  A field of the descriptors, not a process-wide switch: other models of the process keep their own plans.
+DW_WORKGROUPS = 192
+
 
 class DeepSenseModEncoder:
     def __init__(self, backbone, loc, mod, mod_index):
@@ -129,7 +134,7 @@ class DeepSenseModEncoder:
         if training:
             bb.bump_bn_counters(self.pre)  # every BatchNorm of this encoder: num_batches_tracked += 1, one launch
         k = geo["k"]
-        d_cv = ops.conv_desc(cc, rows, S, C, C, k)
+        d_cv = ops.conv_desc(cc, rows, S, C, C, k, dw_workgroups=DW_WORKGROUPS)
         for li in range(geo["n_inter"]):
             pl = f"{self.pre}.conv_layers_inter.{li}"
             w = ar.master(f"{pl}.conv.weight")  # [C, C, 1, k]
@@ -153,7 +158,7 @@ class DeepSenseModEncoder:
         pout = f"{self.pre}.conv_layer_out"
         n_out = geo["C_out"]
         w_out = self._packed(("out",), lambda: ops.permute_pack(ar.master(f"{pout}.weight"), n_out, C, S, ct))  # [n][c*S + s] -> [n][s*C + c]
-        d_out = ops.linear_desc(cc, B * I, n_out, S * C, cc, f32)
+        d_out = ops.linear_desc(cc, B * I, n_out, S * C, cc, f32, dw_workgroups=DW_WORKGROUPS)
         c_out = torch.empty(B * I, n_out, dtype=torch.float32, device=y.device)
         ops.linear_fwd(d_out, ya, w_out, ar.master(f"{pout}.bias"), None, c_out)
         sv.update(ya_last=ya, w_out=w_out, d_out=d_out, pout=pout)
@@ -172,7 +177,7 @@ class DeepSenseModEncoder:
             for di, suf in enumerate(("", "_reverse")):
                 wih, whh = f"{self.rnn}.weight_ih_l{layer}{suf}", f"{self.rnn}.weight_hh_l{layer}{suf}"
                 bih, bhh = f"{self.rnn}.bias_ih_l{layer}{suf}", f"{self.rnn}.bias_hh_l{layer}{suf}"
-                d_ih = ops.linear_desc(cc, B * T, 3 * H, F, f32, f32)
+                d_ih = ops.linear_desc(cc, B * T, 3 * H, F, f32, f32, dw_workgroups=DW_WORKGROUPS)
                 gi = torch.empty(B * T, 3 * H, dtype=torch.float32, device=y.device)
                 ops.linear_fwd(d_ih, x_l, ar.operand(wih), ar.master(bih), None, gi)
                 d_hh = ops.linear_desc(cc, B, 3 * H, H, f32, f32)
@@ -215,9 +220,6 @@ class DeepSenseModEncoder:
         B, T, H, gd = sv["B"], sv["T"], sv["H"], sv["gd"]
         # ---- GRU, last layer first
         dout, ld_b, ld_t, scale = dfeat, 2 * H, 0, 1.0 / T  # d(mean over time): every step gets dfeat / T
-        # four passes (two views x two modalities) run their backward side by side: a third of the default workgroups per weight gradient,
-        # i.e. a third of the fp32 atomics of their small outputs (+4 % on the step: include/focal_hip.h, gemm.hpp: focal_dw_plan)
-        ops.set_dw_workgroup_target(192)
         for layer in range(geo["n_rnn"] - 1, -1, -1):
             lsv = sv["gru"][layer]
             x_l = lsv["x"]
@@ -249,7 +251,7 @@ class DeepSenseModEncoder:
                         if s > 0:
                             ops.linear_bwd_data(dsv["d_hh"], dgh[s], ar.operand(whh), None, dh_rec)
                             have = True
-                d_hh_all = ops.linear_desc(cc, T * B, 3 * H, H, f32, f32)
+                d_hh_all = ops.linear_desc(cc, T * B, 3 * H, H, f32, f32, dw_workgroups=DW_WORKGROUPS)
                 ops.linear_bwd_weight(d_hh_all, dgh, hs[:T], ar.g(whh), ar.g(bhh))
                 ops.linear_bwd_weight(dsv["d_ih"], dgi, x_l, ar.g(wih), ar.g(bih))
                 dxi = torch.empty(B * T, F, dtype=torch.float32, device=dev)

@@ -342,13 +342,20 @@ class CapturedTrainStep:
         self.seen = self.seen + 1 if key == self.key else 1
         self.key = key
         if self.seen >= self.warm_steps:
-            # (the ranks agree segment by segment inside capture(): a failure on any rank raises here on every rank, at the same point)
+            # (the ranks agree segment by segment inside capture(): a segment that fails on any rank raises here on every rank, at the
+            # same point.  A rank can still fail OUTSIDE a segment capture -- an eager allocation between segments, the pool hand-over --
+            # after its peers have finished: the final agreement below makes every rank either replay or stay eager.)
+            ok = True
             try:
                 self._capture(v1, v2)
             except Exception as e:  # noqa: BLE001 -- capture is an optimisation: stay eager, say so once
+                ok = False
                 logging.warning(f"hipGraph capture of the training step unavailable ({type(e).__name__}: {e}); running eagerly")
                 torch.cuda.synchronize()
-                self.enabled, self.replay = False, None
+            if not agree(ok, seg.device):
+                if ok:
+                    logging.warning("hipGraph capture of the training step failed on another rank; running eagerly on all ranks")
+                self.enabled, self.replay, self.segments = False, None, None
         return out
 
     def _capture(self, v1, v2):

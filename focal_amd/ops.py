@@ -307,8 +307,8 @@ def mask_cast(g, mask, dtype):
 
 
 # ------------------------------------------------------------------------------------------------ Linear family
-def linear_desc(dtype_code, M, N, K, x_dtype, y_dtype, act_in=ACT_NONE, epilogue=EPI_NONE, splits=1, out_drop=None):
-    return LinearDesc(dtype_code, M, N, K, x_dtype, y_dtype, act_in, epilogue, splits, out_drop or NO_DROP)
+def linear_desc(dtype_code, M, N, K, x_dtype, y_dtype, act_in=ACT_NONE, epilogue=EPI_NONE, splits=1, out_drop=None, dw_workgroups=0):
+    return LinearDesc(dtype_code, M, N, K, x_dtype, y_dtype, act_in, epilogue, splits, out_drop or NO_DROP, dw_workgroups)
 
 
 def linear_fwd(d, x, w, bias, resid, y, act_grad=None):
@@ -345,11 +345,6 @@ def linear_bwd_data_ln(d, dy, w, ln_x, ln_stats, ln_gamma, g, dgamma, dbeta, g_m
         mask = mask or NO_DROP
     check(_lib.load().focal_linear_bwd_data_ln(C.byref(d), _p(dy), _p(w), _p(ln_x), _p(ln_stats), _p(ln_gamma), _p(g), _p(dgamma), _p(dbeta),
                                                _p(g_masked), C.byref(mask) if mask is not None else None, _stream()))
-
-
-def set_dw_workgroup_target(target):
-    """Workgroup target of the stand-alone weight gradients' token-split plan (0 = default); returns the previous value."""
-    return int(_lib.load().focal_set_dw_workgroup_target(int(target)))
 
 
 def linear_bwd_weight(d, dy, x, dw, dbias):
@@ -432,7 +427,9 @@ def mlp_fwd(d, a, resid, w1, b1, w2, b2, y, next_ln=None, mask_bits=None):
 
 def mlp_bwd(d, gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, ln=None, mask_bits=None):
     """focal_mlp_bwd.  mask_bits: what mlp_fwd filled (required when the descriptor has hidden dropout).  ln = dict(x=, stats=, gamma=,
-    g=, gm_next=, next_mask=, dgamma=, dbeta=) would fuse the norm2 backward behind it (not built: FOCAL_EUNSUPPORTED)."""
+    g=, gm_next=, next_mask=, dgamma=, dbeta=) fuses the backward of the LayerNorm that produced `a` (norm2) into the kernel: g += dLN,
+    gm_next = dtype(g x next_mask), dgamma / dbeta accumulate, and `da` is neither needed nor written (pass None) -- what the Swin engine
+    always does."""
     _need_cuda(gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, mask_bits)
     if ln is None:
         check(_lib.load().focal_mlp_bwd(C.byref(d), _p(gm), _p(a), _p(w1), _p(b1), _p(w2), _p(da), _p(dw1), _p(db1), _p(dw2), _p(db2),
@@ -473,19 +470,6 @@ def window_attn_qkv_bwd(d, a1, wqkv, bqkv, bias_table, dout, dqkv, dbias_table, 
     _need_cuda(a1, wqkv, bqkv, bias_table, dout, dqkv, dbias_table, wproj)
     check(_lib.load().focal_window_attn_qkv_bwd(C.byref(d), _p(a1), _p(wqkv), _p(bqkv), _p(bias_table), _p(dout), _p(wproj), _p(dqkv),
                                                 _p(dbias_table), _stream()))
-
-
-def window_attn_branch_bwd(d, a1, gm, wqkv, bqkv, wproj, bias_table, dqkv, dbias_table, ln_x, ln_stats, ln_gamma, g, dgamma, dbeta,
-                           g_masked=None, mask=None):
-    """The attention branch's backward of a 64-channel block in one launch (focal_window_attn_branch_bwd): attention backward with q / k / v
-    and dO formed in the kernel + the qkv layer's input gradient + norm1's backward (g += dLN, g_masked, dgamma / dbeta).  g = None: only
-    the parameter gradients (the first block behind a frozen embedding)."""
-    _need_cuda(a1, gm, wqkv, bqkv, wproj, bias_table, dqkv, dbias_table, ln_x, ln_stats, ln_gamma, g, dgamma, dbeta, g_masked)
-    if g_masked is not None:
-        mask = mask or NO_DROP
-    check(_lib.load().focal_window_attn_branch_bwd(C.byref(d), _p(a1), _p(gm), _p(wqkv), _p(bqkv), _p(wproj), _p(bias_table), _p(dqkv),
-                                                   _p(dbias_table), _p(ln_x), _p(ln_stats), _p(ln_gamma), _p(g), _p(g_masked),
-                                                   C.byref(mask) if mask is not None else None, _p(dgamma), _p(dbeta), _stream()))
 
 
 # ------------------------------------------------------------------------------------------------ rows 11-13
@@ -611,8 +595,8 @@ def unpack_add_multi(entries):
     check(_lib.load().focal_unpack_add_multi(len(entries), arr, _stream()))
 
 
-def conv_desc(dtype_code, rows, S, C_in, C_out, k):
-    return ConvDesc(dtype_code, rows, S, C_in, C_out, k)
+def conv_desc(dtype_code, rows, S, C_in, C_out, k, dw_workgroups=0):
+    return ConvDesc(dtype_code, rows, S, C_in, C_out, k, dw_workgroups)
 
 
 def conv_pack_bwd(d, w, dtype):

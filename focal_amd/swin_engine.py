@@ -175,7 +175,6 @@ class SwinModEncoder:
         return feat, saved
 
     def backward(self, saved, dfeat):
-        ops.set_dw_workgroup_target(0)  # (a DeepSense model of the same process lowers it for its four side-by-side passes)
         """Accumulates every parameter gradient of this encoder into the arena; returns nothing (input is a leaf).
 
         Data parallel (bb.split_backward, set by focal_amd/graph_step.py): the pass stops once the LAST stage's blocks are done -- by
@@ -310,10 +309,8 @@ class SwinModEncoder:
             weight_grad(d_proj_b, gm_attn, s["o"], ar.g(f"{pb}.attn.proj.weight"), ar.g(f"{pb}.attn.proj.bias"))
             do = dc  # reuse the [M, C] CT buffer
             dqkv = torch.empty(M, 3 * Cc, dtype=ct, device=dev)
-            # (the branch's backward as ONE launch -- focal_window_attn_branch_bwd, tested in tests/test_kernels_gpu.py -- is not used: its
-            # second form, four waves per window with the partials through LDS, is ahead of these two launches in isolation since the
-            # cross-row reductions moved off the LDS pipeline (178 vs 189 us at the audio shape, cold) and exactly even inside the replayed
-            # step (48 130 vs 48 090 windows/s over five alternating pairs; HAR4 -1.3 %): profiles/r4_attn_branch_bwd.txt)
+            # (the branch's backward as ONE launch was built and measured in round 4 and is no faster inside the step: profiles/r4_attn_branch_bwd.txt,
+            # tools/lab_attn_branch_bwd/)
             if s["qkv"] is None:
                 # 64-channel blocks: q / k / v are recomputed from a1 inside the kernel (see forward), and so is the proj layer's input
                 # gradient -- the kernel forms its head's slice of gm_attn . Wproj per item: no dX launch, no dO tensor

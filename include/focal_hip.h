@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* 7: launch trace (focal_trace_*), focal_adamw_multi_advance takes the step-state length; 2: BatchNorm scratch of 2C + 1 floats; 3: fused MLP, warps, Mixup; 4: row-sharded loss head, weight-gradient launch queries */
-#define FOCAL_ABI_VERSION 8
+#define FOCAL_ABI_VERSION 9
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -167,6 +167,10 @@ typedef struct {
   int act_in, epilogue;
   int splits;
   focal_drop_desc out_drop;
+  int dw_workgroups;  /* bwd_weight only: workgroups the token-split plan aims at; 0 = the default (~512: one launch fills the chip).  A
+                       * caller that runs several passes side by side on their own streams (the DeepSense engine: two views x two
+                       * modalities) asks for ~192: the launches share the chip anyway, and a third of the workgroups is a third of the
+                       * fp32 atomics of their small outputs */
 } focal_linear_desc;
 int focal_linear_fwd(const focal_linear_desc* d, const void* x, const void* w, const float* bias, const float* resid,
                      void* y, void* act_grad, void* stream);
@@ -197,11 +201,6 @@ int focal_linear_bwd_weight(const focal_linear_desc* d, const void* dy, const vo
 /* Number of workgroups focal_linear_bwd_weight launches for this descriptor (output tiles x token splits): lets a caller match its
  * calls against the launch shapes of a profiler trace (bench.py's in-step roofline).  0 = invalid descriptor. */
 int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d);
-/* Tuning hint, process-wide: how many workgroups the token-split plan of the stand-alone weight gradients (focal_linear_bwd_weight,
- * focal_conv_bwd_weight) aims at; 0 restores the default (~512: one launch fills the chip).  A caller that runs several passes side by
- * side on their own streams -- the DeepSense engine: two views x two modalities -- asks for ~192: the launches share the chip anyway and a
- * third of the workgroups is a third of the fp32 atomics of their small outputs.  Returns the previous value. */
-int focal_set_dw_workgroup_target(int target);
 /* Which kernel that launch runs: 1 = focal_gemm_kernel (register-staged, any dtype / loader), 2 = focal_dw_ring_kernel (the LDS-DMA
  * ring for bf16 shapes made of whole 64-tiles, given 16-byte aligned operands; 512-thread workgroups of two token slices each).  0 = invalid descriptor. */
 int focal_linear_bwd_weight_kernel(const focal_linear_desc* d);
@@ -240,8 +239,9 @@ int focal_linear_bwd_weight_group_workgroups(int dtype, int n, const focal_dw_pr
  *        stream gradient) += LayerNorm-backward(da; ln_x, ln_stats, ln_gamma), gm_next (bf16 [M, C], optional) = g x next_mask,
  *        dgamma / dbeta accumulated.
  * drop_hidden is a per-(row, lane group) xorshift stream seeded from (seed word, stream id, row); the forward kernel writes its keep
- * decisions to mask_bits (uint32 [M][8], one bit per hidden unit: 32 bytes per token; required by both calls when drop_hidden.p_elem
- * > 0, ignored otherwise) and the backward kernel reads them back: the saved state of the branch is `a` plus these words.
+ * decisions to mask_bits (uint32 [M][8], one bit per hidden unit: 32 bytes per token; ignored when drop_hidden.p_elem == 0;
+ * otherwise focal_mlp_bwd requires it, and focal_mlp_fwd takes NULL only from a caller that never differentiates the call -- a
+ * forward-only pass with dropout on) and the backward kernel reads them back: the saved state of the branch is `a` plus these words.
  * drop_out follows the element / DropPath convention of FOCAL_EPI_RESIDUAL (over [M, C]). */
 typedef struct { int dtype; int M, C, hidden; focal_drop_desc drop_hidden, drop_out; float ln_eps; } focal_mlp_desc;
 int focal_mlp_supported(int dtype, int C, int hidden);
@@ -284,17 +284,6 @@ int focal_window_attn_qkv_fwd(const focal_attn_desc* d, const void* a1, const vo
 int focal_window_attn_qkv_bwd(const focal_attn_desc* d, const void* a1, const void* wqkv, const float* bqkv, const float* bias_table,
                               const void* dout, const void* wproj, void* dqkv, float* dbias_table, void* stream);
 
-/* The backward of the whole attention BRANCH of a 64-channel block in one launch (focal_window_attn_qkv_supported shapes):
- * focal_window_attn_qkv_bwd (with wproj) followed by focal_linear_bwd_data_ln of the qkv layer -- i.e. SwinTransformerBlock.forward's
- * `x + drop_path(attn(norm1(x)))` (models/SwinModules.py:294-334) differentiated down to the residual stream.  A wave owns a window and walks
- * its heads, so dL/d(norm1 output) -- a contraction over all qkv columns -- is complete inside the wave and norm1's backward runs on the
- * accumulators: g (fp32 residual-stream gradient, NULL: dgamma / dbeta only) += dLN, g_masked (optional) = dtype(g x mask), dgamma / dbeta
- * / dbias_table accumulated; dqkv [B*H*W, 3C] is still written, for the qkv layer's weight gradient.  gm = dL/d(proj output) x the branch's
- * mask (what the LayerNorm backward behind it emits as dx_masked). */
-int focal_window_attn_branch_bwd(const focal_attn_desc* d, const void* a1, const void* gm, const void* wqkv, const float* bqkv,
-                                 const void* wproj, const float* bias_table, void* dqkv, float* dbias_table, const float* ln_x,
-                                 const float* ln_stats, const float* ln_gamma, float* g, void* g_masked, const focal_drop_desc* mask,
-                                 float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 5: DeepSense convs
  * ConvBlock (models/ConvModules.py:115-216) on CHANNEL-LAST tokens: activation [B*I*S, C] (row = (b, interval, s)).
@@ -311,7 +300,7 @@ int focal_conv_in_bwd_weight(const focal_conv_in_desc* d, const float* x, const 
  * fwd: z (fp32) = conv(x) + bias.  bwd_data: g_out = g_in + conv^T(dz) (fp32; the residual-gradient stream).
  * bwd_weight: dw_packed [C_out][k][C_in] += dz^T window(x); dbias += column sums; focal_permute_unpack_add folds
  * dw_packed back into the [C_out][C_in][1][k] gradient. */
-typedef struct { int dtype; int rows, S, C_in, C_out, k; } focal_conv_desc;
+typedef struct { int dtype; int rows, S, C_in, C_out, k; int dw_workgroups; /* bwd_weight: as focal_linear_desc.dw_workgroups */ } focal_conv_desc;
 int focal_permute_pack(int A, int Bd, int Cd, const float* src, void* dst, int dtype, void* stream);      /* dst[a][c][b] = src[a][b][c] */
 int focal_permute_unpack_add(int A, int Bd, int Cd, const float* src, float* dst, void* stream);          /* dst[a][b][c] += src[a][c][b] */
 int focal_conv_pack_bwd(const focal_conv_desc* d, const float* w, void* w_bwd, void* stream);

@@ -88,7 +88,7 @@ def test_four_modality_full_batch_equals_small_batches(ct):
     sub = lambda lo, hi: {loc: {m: v[lo:hi] for m, v in x[loc].items()}}
     # (the un-projected features: the projector's ReLU makes the gradient discontinuous where a hidden unit sits within fp32 summation
     # noise of zero -- mod_in is a split-K GEMM whose atomics arrive in any order -- and with these seeds one unit of the `gyr` projector
-    # does: full-batch gradients then come out bimodal, 1.9e-2 apart, whatever they are compared with (tools/scratch/dbg_har4_additivity.py);
+    # does: full-batch gradients then come out bimodal, 1.9e-2 apart, whatever they are compared with (round 3, profiles/r3_fd_outlier.txt);
     # the projector itself is pinned by the reference fixture above)
     r = {m: torch.randn(B, cfg["SW_Transformer"]["loc_out_channels"], generator=g).cuda() for m in cfg["modality_names"]}
 

@@ -274,7 +274,7 @@ def test_full_batch_backward_bf16_follows_fp32(cfg):
     and cotangents (the fp32 path at this size is pinned by the replicated-block test above, and at B = 8 by the reference fixture).
     Not the replicated batch: there a single ReLU / rounding decision that flips for one window of the block flips for all 32 copies
     of it, and BatchNorm's atomically summed statistics differ in the last bit from run to run -- the replicated bf16 gradients were
-    bimodal (1 % or 6 % from 32 x the block's, tools/scratch/dbg_ds_rep4.py: the same window of every copy changes)."""
+    bimodal (1 % or 6 % from 32 x the block's, round 3: the same window of every copy changes)."""
     from oracle.weights import synthetic_freq_input
     x = synthetic_freq_input(cfg, 256, seed=909)
     x = {l: {m: v.cuda() for m, v in mm.items()} for l, mm in x.items()}

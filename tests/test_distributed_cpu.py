@@ -166,3 +166,47 @@ def test_two_rank_loaders_take_equal_shares_of_a_ragged_epoch(tmp_path):
             assert len(a[-1]) == (rem // 2) * 4, kind                               # the remainder's odd subsequence is dropped
     # un-sharded loaders (validation / test) hand the whole batch to whichever rank iterates them
     assert r0["whole"] == r1["whole"] and sum(r0["whole"]) == n_sub * 4
+
+
+def _capture_agreement_worker(rank, world, port, out):
+    """A rank whose capture fails OUTSIDE a segment capture (after its peers have finished theirs) must take every rank back to the
+    eager step: the final agreement of CapturedTrainStep.__call__.  The capture itself is stubbed -- it needs a GPU."""
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from focal_amd import graph_step
+    torch.cuda.synchronize = lambda *a, **k: None
+
+    class Seg:
+        device, loss = torch.device("cpu"), torch.zeros(())
+
+        def run(self):
+            pass
+
+    res = {}
+    for failing in (1, None):
+        step = graph_step.CapturedTrainStep(None, None, None, warm_steps=1)
+        step._segments = lambda v1, v2: Seg()
+
+        def capture(v1, v2, step=step, failing=failing):
+            if rank == failing:
+                raise RuntimeError("out of memory between two segments")
+            step.replay, step.loss = (lambda: None), Seg.loss
+        step._capture = capture
+        v = {"shake": {"audio": torch.zeros(2)}}
+        step(v, v)
+        res[failing] = (step.replay is None, step.enabled)
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_capture_failure_on_one_rank_keeps_every_rank_eager():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_capture_agreement_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r][1] == (True, False), dict(out)     # rank 1 failed: nobody replays
+        assert out[r][None] == (False, True), dict(out)  # nobody failed: everybody replays

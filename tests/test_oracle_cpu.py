@@ -221,7 +221,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name)
     assert lib.focal_abi_version() == _lib.ABI_VERSION
     import ctypes as C
-    assert C.sizeof(_lib.DropDesc) == 32 and C.sizeof(_lib.LinearDesc) == 9 * 4 + 4 + 32
+    assert C.sizeof(_lib.DropDesc) == 32 and C.sizeof(_lib.LinearDesc) == 9 * 4 + 4 + 32 + 8
 
 
 def test_host_side_launch_plans_of_the_abi():
@@ -238,8 +238,9 @@ def test_host_side_launch_plans_of_the_abi():
         return d
     d = desc(18432, 1024, 256, bf, bf, bf)           # whole 64-tiles in bf16: the LDS-DMA ring kernel, 64 tiles x 4 workgroups of 2 token slices
     assert lib.focal_linear_bwd_weight_kernel(C.byref(d)) == 2 and lib.focal_linear_bwd_weight_workgroups(C.byref(d)) == 256
-    assert lib.focal_set_dw_workgroup_target(192) == 0                   # the hint of a caller with several passes side by side: 64 tiles x 2
-    assert lib.focal_linear_bwd_weight_workgroups(C.byref(d)) == 128 and lib.focal_set_dw_workgroup_target(0) == 192
+    d.dw_workgroups = 192                            # the hint of a caller with several passes side by side: 64 tiles x 2
+    assert lib.focal_linear_bwd_weight_workgroups(C.byref(d)) == 128
+    d.dw_workgroups = 0
     assert lib.focal_linear_bwd_weight_workgroups(C.byref(d)) == 256
     d = desc(1000, 64, 256, bf, bf, bf)              # ragged token count: the register-staged kernel
     assert lib.focal_linear_bwd_weight_kernel(C.byref(d)) == 1

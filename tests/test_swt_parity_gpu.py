@@ -220,7 +220,7 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
     # ~eps * |analytic| away from its siblings (the size of the perturbation's own effect, i.e. as if that one pass had not seen the
     # weight update), and the test took medians of five.  Round 3 could not reproduce it: 60 000 evaluations of this very sequence in
     # fresh processes -- streams on / off, a synchronize after the update, the late and the early stream fork, NaN-poisoned allocator
-    # caches (tools/scratch/dbg_fd_outlier.py, dbg_fd_test_repro.py, dbg_poison.py; profiles/r3_fd_outlier.txt) -- produced none.  So the
+    # caches (profiles/r3_fd_outlier.txt; the scripts are in the history at commit 46f3c3d, tools/scratch/dbg_*.py) -- produced none.  So the
     # check is single again (one repeat per side as the tripwire); should an evaluation ever disagree with its repeat, the evidence --
     # every value, the pre-update value, the perturbation's own size -- is written down before more evaluations settle the quotient.
     from conftest import record_observed

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage: bash tools/scratch/ab_env.sh <ENVVAR> [bench args]  -- same-box A/B of one environment switch, 3 interleaved repetitions
+# Usage: bash tools/ab_env.sh <ENVVAR> [bench args]  -- same-box A/B of one environment switch, 3 interleaved repetitions
 v=$1; shift
 for i in 1 2 3; do
   for on in 0 1; do

@@ -2,7 +2,7 @@
 points return FOCAL_OK without launching anything, so that the graph-replayed step can be timed WITHOUT one kernel family -- its
 marginal cost under the real two-stream concurrency, which a profiler (it serialises the streams) cannot show.  Outputs of the
 skipped kernels stay uninitialised: every result of such a run is garbage, and bench.py marks its JSON line DIAGNOSTIC_ABLATED_INVALID.
-Usage: bench.py imports this module only when FOCAL_ABLATE is set (tools/scratch/ablate.sh)."""
+Usage: bench.py imports this module only when FOCAL_ABLATE is set (tools/ablate.sh)."""
 import os
 
 FAMILIES = {

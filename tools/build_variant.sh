@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage: bash tools/scratch/build_variant.sh <name> "<-D flags>" <file.hip> [more files]   -> focal_amd/lab/libfocal_hip_<name>.so
+# Usage: bash tools/build_variant.sh <name> "<-D flags>" <file.hip> [more files]   -> focal_amd/lab/libfocal_hip_<name>.so
 # A/B builds of single translation units for same-box comparisons (FOCAL_HIP_LIB=... selects the library at run time).
 name=$1; flags=$2; shift; shift
 root=$(cd "$(dirname "$0")/../.." && pwd)

@@ -1,5 +1,5 @@
 // GEMM lab: times focal_gemm_pipe_kernel variants against the 64x64 kernel of gemm.hpp on the deep-stage shapes, in one process.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I focal_amd/csrc tools/scratch/gemm_lab.hip focal_amd/csrc/error.cpp -o build/gemm_lab
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I focal_amd/csrc tools/gemm_lab.hip focal_amd/csrc/error.cpp -o build/gemm_lab
 #include <vector>
 #include <cstdlib>
 #include <cmath>

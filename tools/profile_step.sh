@@ -14,4 +14,4 @@ python3 $root/profiles/summarize.py $root/gpurun_out/${tag}_kernel_stats.csv $((
 t=$(find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1)
 python3 $root/tools/instance_table.py "$t" $((STEPS+WARM+2)) $root/gpurun_out/${tag}_instances.csv > $root/gpurun_out/${tag}_instances.txt
 head -40 $root/gpurun_out/${tag}_instances.txt
-[ -f $root/tools/scratch/copy_context.py ] && python3 $root/tools/scratch/copy_context.py "$t" > $root/gpurun_out/${tag}_copy_context.txt 2>&1
+[ -f $root/tools/copy_context.py ] && python3 $root/tools/copy_context.py "$t" > $root/gpurun_out/${tag}_copy_context.txt 2>&1
