@@ -1,7 +1,7 @@
 // bf16-compute instantiations of the MFMA GEMM family (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
 #include <stdlib.h>
 #include <type_traits>
-#include "gemm_pipe.hpp"
+#include "gemm_ring.hpp"
 #include "gemm_dw_ring.hpp"
 #define GEMM_CT bf16_t
 #define GEMM_FN focal_launch_gemm_bf16

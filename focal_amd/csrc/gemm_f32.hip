@@ -2,7 +2,7 @@
 // the loss head's similarity / distance products).
 #include <stdlib.h>
 #include <type_traits>
-#include "gemm_pipe.hpp"
+#include "gemm_ring.hpp"
 #include "gemm_dw_ring.hpp"
 #define GEMM_CT float
 #define GEMM_FN focal_launch_gemm_f32

@@ -226,6 +226,245 @@ __device__ __forceinline__ void pipe_ln_epilogue_two_waves(const GemmParams& p, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- epilogue of a tile
+// (shared by focal_gemm_pipe_kernel, one tile per workgroup, and the persistent ring kernel of gemm_ring.hpp)
+// One wave's WR x WC outputs: 16 rows at a time transposed through the wave-private LDS region `est`, then walked row-major (16 B per lane).
+// pg / pb (EPI_LN_BWD): this lane's column partials of dy * xhat and dy -- accumulated over every tile the workgroup finishes, folded
+// and added to dgamma / dbeta once by pipe_ln_bwd_flush; lng: the lane's four gamma values.
+// pipe_epilogue_group: ONE 16-row group (rows mbase .. mbase + 15 of the tile at (m0, n0); accrow = the group's TN accumulator tiles);
+// pipe_epilogue_rows: a wave's groups I0 .. I1 (all of them by default).  bias: the lane's CPL bias values (pipe_epilogue_bias).
+template <int CPL> struct PipeBias { float v[CPL]; };
+// (alpha, bias, resid travel as scalar arguments: read through the argument struct from inside the ring kernel's nested loops -- or
+// packed into a small struct -- hipcc kept exactly these 20 bytes in a scratch copy)
+template <typename TC, int EPI, int BN, int WGN>
+__device__ __forceinline__ PipeBias<(sizeof(TC) == 2) ? 8 : 4> pipe_epilogue_bias(const float* bias_ptr, int n0, int wn, int lane) {
+  constexpr int WC = BN / WGN, CPL = (sizeof(TC) == 2) ? 8 : 4, LPR = WC / CPL;
+  const int n = n0 + wn * WC + (lane % LPR) * CPL;
+  PipeBias<CPL> b;
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) b.v[e] = 0.f;
+  if (bias_ptr) {
+    // (an explicit global-memory load: through the generic pointer this was a flat_load, whose result waits for vmcnt(0) AND lgkmcnt(0))
+    typedef float f32x4g __attribute__((ext_vector_type(4)));
+    const __attribute__((address_space(1))) f32x4g* g = (const __attribute__((address_space(1))) f32x4g*)(bias_ptr + n);
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q) {
+      const f32x4g t = g[q];
+      b.v[4 * q] = t[0]; b.v[4 * q + 1] = t[1]; b.v[4 * q + 2] = t[2]; b.v[4 * q + 3] = t[3];
+    }
+  }
+  return b;
+}
+// What a 16-row group's epilogue reads from memory, requested up front (pipe_epilogue_prefetch) and consumed by pipe_epilogue_finish:
+//   r: EPI_RESID / EPI_RESID_LN / EPI_LN_BWD: the fp32 residual rows (the LayerNorm's input rows);  EPI_MUL_AUX: the aux rows (as floats)
+//   g, s: EPI_LN_BWD: the residual-stream gradient rows the result is added to, the rows' {mean, rstd}
+// The one-tile-per-workgroup kernel requests them at the top of the group (hipcc will not move a global load above the staging's LDS
+// traffic: left inside the row loop each row exposed a full memory latency); the ring kernel requests a whole tile's rows BEFORE the tile's
+// k loop, so they land while it multiplies (lab: the epilogue's exposed load latency was half of a MUL_AUX / RESID launch).
+// Rows past M re-read the last row.
+template <typename TC, int EPI, int BN, int WGN> struct PipePre {
+  static constexpr int CPL = (sizeof(TC) == 2) ? 8 : 4, LPR = (BN / WGN) / CPL, RPI = 64 / LPR, NIT = 16 / RPI;
+  static constexpr bool HAS_R = EPI == EPI_RESID || EPI == EPI_RESID_LN || EPI == EPI_LN_BWD || EPI == EPI_MUL_AUX;
+  float r[HAS_R ? NIT : 1][CPL];
+  float g[EPI == EPI_LN_BWD ? NIT : 1][CPL];
+  float2 s[EPI == EPI_LN_BWD ? NIT : 1];
+};
+template <typename TC, int EPI, int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void pipe_epilogue_prefetch(const GemmParams& p, const float* ea_resid, int m0, int n0, int mbase, int wn, int lane, const TC* C,
+                                                       PipePre<TC, EPI, BN, WGN>& pre) {
+  using P = PipePre<TC, EPI, BN, WGN>;
+  constexpr int WC = BN / WGN, CPL = P::CPL, LPR = P::LPR, RPI = P::RPI, NIT = P::NIT;
+  const int c = (lane % LPR) * CPL, n = n0 + wn * WC + c;
+  if constexpr (P::HAS_R) {
+    const float* resid_t = ea_resid + (long)m0 * p.ldr;
+    const float* Cc_t = reinterpret_cast<const float*>(C) + (long)m0 * p.ldc;
+    const bf16_t* aux_t = reinterpret_cast<const bf16_t*>(p.aux) + (long)m0 * p.ldaux;
+    const float* stats_t = p.ln_stats + 2 * (long)m0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int mm = min(mbase + it * RPI + lane / LPR, p.M - 1);
+      if constexpr (EPI == EPI_MUL_AUX) {
+        loadN<CPL>(pipe_row(aux_t, mm - m0, p.ldaux, n), pre.r[it]);
+      } else {
+        loadN<CPL>(pipe_row(resid_t, mm - m0, p.ldr, n), pre.r[it]);
+      }
+      if constexpr (EPI == EPI_LN_BWD) {  // the LayerNorm's input row (resid), the residual-stream gradient it is added to, the row's statistics
+        // (C == NULL: nobody needs the input gradient -- the first block behind a frozen patch embedding -- only dgamma / dbeta:
+        // the 8 + 4 bytes per element of reading, updating and re-casting the residual-stream gradient are skipped)
+        if (C != nullptr) loadN<CPL>(pipe_row(Cc_t, mm - m0, p.ldc, n), pre.g[it]);
+        pre.s[it] = *reinterpret_cast<const float2*>(stats_t + 2 * (mm - m0));
+      }
+    }
+  }
+}
+template <typename TC, int EPI, int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void pipe_epilogue_finish(const GemmParams& p, float ea_alpha, f32x4 (&accrow)[BN / WGN / 16], float* est, const MaskEval& meE, int m0, int n0,
+                                                     int mbase, int wn, int lane, TC* C, const float (&bias)[(sizeof(TC) == 2) ? 8 : 4], float (&pg)[4],
+                                                     float (&pb)[4], const float (&lng)[4], const PipePre<TC, EPI, BN, WGN>& pre) {
+  constexpr int WR = BM / WGM, WC = BN / WGN, TM = WR / 16, TN = WC / 16, WPITCH = WC + 4;
+  constexpr int CPL = (sizeof(TC) == 2) ? 8 : 4;
+  constexpr int LPR = WC / CPL, RPI = 64 / LPR;
+  const int c = (lane % LPR) * CPL, n = n0 + wn * WC + c;
+  // (uniform pointers to the tile's first row: pipe_row)
+  TC* C_t = C + (long)m0 * p.ldc;
+  bf16_t* auxo_t = reinterpret_cast<bf16_t*>(p.aux_out) + (long)m0 * p.ldc;
+  TC* auxoT_t = reinterpret_cast<TC*>(p.aux_out) + (long)m0 * p.ldc;
+  float* stats_t = p.ln_stats + 2 * (long)m0;
+  constexpr int NIT = 16 / RPI;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const f32x4 v = accrow[j] * ea_alpha;
+    *reinterpret_cast<float4*>(est + (lane & 15) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+#pragma unroll
+  for (int rr = 0; rr < 16; rr += RPI) {
+    const int row = rr + lane / LPR, m = mbase + row;
+    if (m >= p.M) continue;
+    float v[CPL];
+    loadN<CPL>(est + row * WPITCH + c, v);
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) v[e] += bias[e];
+    TC* dst = pipe_row(C_t, m - m0, p.ldc, n);
+    if (EPI == EPI_STORE) {
+      storeN<CPL>(dst, v);
+    } else if (EPI == EPI_RESID) {
+      const float rowm = meE.row_mult(m);
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) v[e] = pre.r[EPI == EPI_RESID ? rr / RPI : 0][e] + v[e] * rowm * meE.elem_mult(m, n + e);
+      storeN<CPL>(dst, v);
+    } else if (EPI == EPI_RESID_LN) {
+      // y = resid + drop(v); then the LayerNorm that follows in the block, finished while the row is in registers: the LPR lanes of a
+      // row (16 / 32 / 64: a DPP row, two, or the whole wave) fold their sums -- statistics, normalised row and residual row leave
+      // together, no second pass over the residual stream
+      const float rowm = meE.row_mult(m);
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) v[e] = pre.r[EPI == EPI_RESID_LN ? rr / RPI : 0][e] + v[e] * rowm * meE.elem_mult(m, n + e);
+      storeN<CPL>(dst, v);
+      float s1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) s1 += v[e];
+      s1 = row16_sum(s1);
+      if (LPR >= 32) s1 = xadd16(s1);
+      if (LPR >= 64) s1 = xadd32(s1);
+      const float mean = s1 * (1.0f / WC);
+      float s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) s2 += (v[e] - mean) * (v[e] - mean);
+      s2 = row16_sum(s2);
+      if (LPR >= 32) s2 = xadd16(s2);
+      if (LPR >= 64) s2 = xadd32(s2);
+      const float rstd = rsqrtf(s2 * (1.0f / WC) + p.ln_eps);
+      float gq[CPL], bt[CPL], yq[CPL];
+      loadN<CPL>(p.ln_gamma + n, gq);
+      loadN<CPL>(p.ln_beta + n, bt);
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) yq[e] = (v[e] - mean) * rstd * gq[e] + bt[e];
+      storeN<CPL>(pipe_row(auxo_t, m - m0, p.ldc, n), yq);
+      if ((lane % LPR) == 0) *reinterpret_cast<float2*>(stats_t + 2 * (m - m0)) = make_float2(mean, rstd);
+    } else if (EPI == EPI_LN_BWD) {
+      // v = dy of the LayerNorm (this GEMM's product, fp32 -- never written): dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;
+      // the residual-stream gradient row gets += dx and leaves a second time as dtype(row * mask) for the next branch's GEMMs
+      constexpr int IT = (EPI == EPI_LN_BWD) ? 1 : 0;
+      const int it = IT * (rr / RPI);
+      const float mean = pre.s[it].x, rstd = pre.s[it].y;
+      float xh[CPL], gd[CPL];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) {
+        xh[e] = (pre.r[it][e] - mean) * rstd;
+        gd[e] = v[e] * lng[e];
+        s1 += gd[e];
+        s2 += gd[e] * xh[e];
+        pg[e] += v[e] * xh[e];
+        pb[e] += v[e];
+      }
+      s1 = row16_sum(s1); s2 = row16_sum(s2);
+      if (LPR >= 32) { s1 = xadd16(s1); s2 = xadd16(s2); }
+      if (LPR >= 64) { s1 = xadd32(s1); s2 = xadd32(s2); }
+      const float m1 = s1 * (1.0f / WC), m2 = s2 * (1.0f / WC);
+      if (C == nullptr) continue;
+      float o[CPL];
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) o[e] = pre.g[it][e] + rstd * (gd[e] - m1 - xh[e] * m2);
+      storeN<CPL>(dst, o);
+      if (p.aux_out) {
+        const float rowm = meE.row_mult(m);
+        float om[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) om[e] = o[e] * rowm * meE.elem_mult(m, n + e);
+        storeN<CPL>(pipe_row(auxo_t, m - m0, p.ldc, n), om);
+      }
+    } else if (EPI == EPI_MUL_AUX) {
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) v[e] *= pre.r[EPI == EPI_MUL_AUX ? rr / RPI : 0][e];
+      storeN<CPL>(dst, v);
+    } else if (EPI == EPI_GELU_FWD) {
+      float gq[CPL];
+#pragma unroll
+      for (int e = 0; e < CPL; e += 2) {
+        const gelu_f2 x = {v[e], v[e + 1]};
+        gelu_f2 cdf, pdf;
+        gelu_parts2(x, cdf, pdf);
+        const gelu_f2 mult = meE.elem_mult_pair(m, n + e);
+        const gelu_f2 gg = (x * pdf + cdf) * mult, hh = x * cdf * mult;
+        gq[e] = gg.x; gq[e + 1] = gg.y;
+        v[e] = hh.x; v[e + 1] = hh.y;
+      }
+      storeN<CPL>(dst, v);
+      storeN<CPL>(pipe_row(auxoT_t, m - m0, p.ldc, n), gq);
+    }
+  }
+}
+// one group, loads and all (the one-tile-per-workgroup kernel)
+template <typename TC, int EPI, int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void pipe_epilogue_group(const GemmParams& p, float ea_alpha, const float* ea_resid, f32x4 (&accrow)[BN / WGN / 16], float* est, const MaskEval& meE, int m0, int n0,
+                                                    int mbase, int wn, int lane, TC* C, const float (&bias)[(sizeof(TC) == 2) ? 8 : 4], float (&pg)[4],
+                                                    float (&pb)[4], const float (&lng)[4]) {
+  PipePre<TC, EPI, BN, WGN> pre;
+  pipe_epilogue_prefetch<TC, EPI, BM, BN, WGM, WGN>(p, ea_resid, m0, n0, mbase, wn, lane, C, pre);
+  pipe_epilogue_finish<TC, EPI, BM, BN, WGM, WGN>(p, ea_alpha, accrow, est, meE, m0, n0, mbase, wn, lane, C, bias, pg, pb, lng, pre);
+}
+template <typename TC, int EPI, int BM, int BN, int WGM, int WGN, int I0 = 0, int I1 = BM / WGM / 16>
+__device__ __forceinline__ void pipe_epilogue_rows(const GemmParams& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], float* est, const MaskEval& meE, int m0,
+                                                   int n0, int wm, int wn, int lane, TC* C, float (&pg)[4], float (&pb)[4], const float (&lng)[4]) {
+  constexpr int WR = BM / WGM;
+  // (p.alpha / p.bias / p.resid passed as they are: copied into three locals first, hipcc turns the adjacent loads into a 20-byte copy
+  // of the argument struct into scratch)
+  const PipeBias<(sizeof(TC) == 2) ? 8 : 4> bias = pipe_epilogue_bias<TC, EPI, BN, WGN>(p.bias, n0, wn, lane);
+#pragma unroll
+  for (int i = I0; i < I1; ++i)
+    pipe_epilogue_group<TC, EPI, BM, BN, WGM, WGN>(p, p.alpha, p.resid, acc[i], est, meE, m0, n0, m0 + wm * WR + i * 16, wn, lane, C, bias.v, pg, pb, lng);
+}
+
+// EPI_LN_BWD, after the workgroup's last tile: dgamma / dbeta from the lanes' column partials
+template <int BN, int WGM, int WGN, int CPL>
+__device__ __forceinline__ void pipe_ln_bwd_flush(const GemmParams& p, float (&pg)[4], float (&pb)[4], float* red, int n0, int wn, int wave, int lane, int tid) {
+  constexpr int NW = WGM * WGN, WC = BN / WGN, LPR = WC / CPL;
+  const int c = (lane % LPR) * CPL;
+  {
+    // dgamma / dbeta: the lanes of a wave that share columns fold by shuffles, one [2][WC] row per wave goes to LDS behind the staging
+    // regions, the waves are summed and every column leaves as ONE atomic per workgroup
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      for (int o = LPR; o < 64; o <<= 1) {
+        pg[e] = xadd(pg[e], o);
+        pb[e] = xadd(pb[e], o);
+      }
+    }
+    if (lane < LPR) {
+      *reinterpret_cast<float4*>(red + wave * 2 * WC + c) = make_float4(pg[0], pg[1], pg[2], pg[3]);
+      *reinterpret_cast<float4*>(red + wave * 2 * WC + WC + c) = make_float4(pb[0], pb[1], pb[2], pb[3]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * WC; i += 64 * NW) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a += red[w * 2 * WC + i];
+      atomicAdd(i < WC ? p.ln_dgamma + n0 + i : p.ln_dbeta + n0 + (i - WC), a);
+    }
+  }
+}
+
 template <typename TC, int EPI, bool TRB, int BM, int BN, int NST, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const GemmParams p) {
   constexpr int NW = WGM * WGN;
@@ -373,175 +612,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void focal_gemm_pipe_kernel(const G
   float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};  // EPI_LN_BWD: this lane's column partials of dy * xhat, dy
   float lng[4] = {0.f, 0.f, 0.f, 0.f};
   if (EPI == EPI_LN_BWD) loadN<4>(p.ln_gamma + (n0 + wn * WC + (lane % (WC / 4)) * 4), lng);
-  constexpr int CPL = (sizeof(TC) == 2) ? 8 : 4;
-  constexpr int LPR = WC / CPL, RPI = 64 / LPR;
-  const int c = (lane % LPR) * CPL, n = n0 + wn * WC + c;
-  // (uniform pointers to the tile's first row: pipe_row)
-  const float* resid_t = p.resid + (long)m0 * p.ldr;
-  TC* C_t = C + (long)m0 * p.ldc;
-  const float* Cc_t = reinterpret_cast<const float*>(C) + (long)m0 * p.ldc;
-  bf16_t* auxo_t = reinterpret_cast<bf16_t*>(p.aux_out) + (long)m0 * p.ldc;
-  TC* auxoT_t = reinterpret_cast<TC*>(p.aux_out) + (long)m0 * p.ldc;
-  const bf16_t* aux_t = reinterpret_cast<const bf16_t*>(p.aux) + (long)m0 * p.ldaux;
-  float* stats_t = p.ln_stats + 2 * (long)m0;
-  float bias[CPL];
-#pragma unroll
-  for (int e = 0; e < CPL; ++e) bias[e] = 0.f;
-  if (p.bias) loadN<CPL>(p.bias + n, bias);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int mbase = m0 + wm * WR + i * 16;
-    // LayerNorm epilogue: the pass's residual rows are requested together, before the accumulators are staged (the row loop below has
-    // LDS traffic between its iterations -- staging reads, cross-lane sums -- and hipcc will not move a global load above those: left
-    // inside the loop each row exposed a full memory latency, 16 in a row at 256 channels).  Rows past M re-read the last row.
-    constexpr int NIT = 16 / RPI;
-    float rpre[(EPI == EPI_RESID_LN || EPI == EPI_LN_BWD) ? NIT : 1][CPL];
-    float gpre[EPI == EPI_LN_BWD ? NIT : 1][CPL];
-    float2 spre[EPI == EPI_LN_BWD ? NIT : 1];
-    if (EPI == EPI_RESID_LN || EPI == EPI_LN_BWD) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int mm = min(mbase + it * RPI + lane / LPR, p.M - 1);
-        loadN<CPL>(pipe_row(resid_t, mm - m0, p.ldr, n), rpre[it]);
-        if (EPI == EPI_LN_BWD) {  // the LayerNorm's input row (resid), the residual-stream gradient it is added to, the row's statistics
-          // (C == NULL: nobody needs the input gradient -- the first block behind a frozen patch embedding -- only dgamma / dbeta:
-          // the 8 + 4 bytes per element of reading, updating and re-casting the residual-stream gradient are skipped)
-          if (C != nullptr) loadN<CPL>(pipe_row(Cc_t, mm - m0, p.ldc, n), gpre[it]);
-          spre[it] = *reinterpret_cast<const float2*>(stats_t + 2 * (mm - m0));
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const f32x4 v = acc[i][j] * p.alpha;
-      *reinterpret_cast<float4*>(est + (lane & 15) * WPITCH + j * 16 + (lane >> 4) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-#pragma unroll
-    for (int rr = 0; rr < 16; rr += RPI) {
-      const int row = rr + lane / LPR, m = mbase + row;
-      if (m >= p.M) continue;
-      float v[CPL];
-      loadN<CPL>(est + row * WPITCH + c, v);
-#pragma unroll
-      for (int e = 0; e < CPL; ++e) v[e] += bias[e];
-      TC* dst = pipe_row(C_t, m - m0, p.ldc, n);
-      if (EPI == EPI_STORE) {
-        storeN<CPL>(dst, v);
-      } else if (EPI == EPI_RESID) {
-        float r[CPL];
-        loadN<CPL>(pipe_row(resid_t, m - m0, p.ldr, n), r);
-        const float rowm = meE.row_mult(m);
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) v[e] = r[e] + v[e] * rowm * meE.elem_mult(m, n + e);
-        storeN<CPL>(dst, v);
-      } else if (EPI == EPI_RESID_LN) {
-        // y = resid + drop(v); then the LayerNorm that follows in the block, finished while the row is in registers: the LPR lanes of a
-        // row (16 / 32 / 64: a DPP row, two, or the whole wave) fold their sums -- statistics, normalised row and residual row leave
-        // together, no second pass over the residual stream
-        const float rowm = meE.row_mult(m);
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) v[e] = rpre[EPI == EPI_RESID_LN ? rr / RPI : 0][e] + v[e] * rowm * meE.elem_mult(m, n + e);
-        storeN<CPL>(dst, v);
-        float s1 = 0.f;
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) s1 += v[e];
-        s1 = row16_sum(s1);
-        if (LPR >= 32) s1 = xadd16(s1);
-        if (LPR >= 64) s1 = xadd32(s1);
-        const float mean = s1 * (1.0f / WC);
-        float s2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) s2 += (v[e] - mean) * (v[e] - mean);
-        s2 = row16_sum(s2);
-        if (LPR >= 32) s2 = xadd16(s2);
-        if (LPR >= 64) s2 = xadd32(s2);
-        const float rstd = rsqrtf(s2 * (1.0f / WC) + p.ln_eps);
-        float gq[CPL], bt[CPL], yq[CPL];
-        loadN<CPL>(p.ln_gamma + n, gq);
-        loadN<CPL>(p.ln_beta + n, bt);
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) yq[e] = (v[e] - mean) * rstd * gq[e] + bt[e];
-        storeN<CPL>(pipe_row(auxo_t, m - m0, p.ldc, n), yq);
-        if ((lane % LPR) == 0) *reinterpret_cast<float2*>(stats_t + 2 * (m - m0)) = make_float2(mean, rstd);
-      } else if (EPI == EPI_LN_BWD) {
-        // v = dy of the LayerNorm (this GEMM's product, fp32 -- never written): dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;
-        // the residual-stream gradient row gets += dx and leaves a second time as dtype(row * mask) for the next branch's GEMMs
-        constexpr int IT = (EPI == EPI_LN_BWD) ? 1 : 0;
-        const int it = IT * (rr / RPI);
-        const float mean = spre[it].x, rstd = spre[it].y;
-        float xh[CPL], gd[CPL];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) {
-          xh[e] = (rpre[it][e] - mean) * rstd;
-          gd[e] = v[e] * lng[e];
-          s1 += gd[e];
-          s2 += gd[e] * xh[e];
-          pg[e] += v[e] * xh[e];
-          pb[e] += v[e];
-        }
-        s1 = row16_sum(s1); s2 = row16_sum(s2);
-        if (LPR >= 32) { s1 = xadd16(s1); s2 = xadd16(s2); }
-        if (LPR >= 64) { s1 = xadd32(s1); s2 = xadd32(s2); }
-        const float m1 = s1 * (1.0f / WC), m2 = s2 * (1.0f / WC);
-        if (C == nullptr) continue;
-        float o[CPL];
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) o[e] = gpre[it][e] + rstd * (gd[e] - m1 - xh[e] * m2);
-        storeN<CPL>(dst, o);
-        if (p.aux_out) {
-          const float rowm = meE.row_mult(m);
-          float om[CPL];
-#pragma unroll
-          for (int e = 0; e < CPL; ++e) om[e] = o[e] * rowm * meE.elem_mult(m, n + e);
-          storeN<CPL>(pipe_row(auxo_t, m - m0, p.ldc, n), om);
-        }
-      } else if (EPI == EPI_MUL_AUX) {
-        float a[CPL];
-        loadN<CPL>(pipe_row(aux_t, m - m0, p.ldaux, n), a);
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) v[e] *= a[e];
-        storeN<CPL>(dst, v);
-      } else if (EPI == EPI_GELU_FWD) {
-        float gq[CPL];
-#pragma unroll
-        for (int e = 0; e < CPL; e += 2) {
-          const gelu_f2 x = {v[e], v[e + 1]};
-          gelu_f2 cdf, pdf;
-          gelu_parts2(x, cdf, pdf);
-          const gelu_f2 mult = meE.elem_mult_pair(m, n + e);
-          const gelu_f2 gg = (x * pdf + cdf) * mult, hh = x * cdf * mult;
-          gq[e] = gg.x; gq[e + 1] = gg.y;
-          v[e] = hh.x; v[e + 1] = hh.y;
-        }
-        storeN<CPL>(dst, v);
-        storeN<CPL>(pipe_row(auxoT_t, m - m0, p.ldc, n), gq);
-      }
-    }
-  }
-  if (EPI == EPI_LN_BWD) {
-    // dgamma / dbeta: the lanes of a wave that share columns fold by shuffles, one [2][WC] row per wave goes to LDS behind the staging
-    // regions, the waves are summed and every column leaves as ONE atomic per workgroup
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      for (int o = LPR; o < 64; o <<= 1) {
-        pg[e] = xadd(pg[e], o);
-        pb[e] = xadd(pb[e], o);
-      }
-    }
-    float* red = reinterpret_cast<float*>(pipe_lds) + NW * 16 * WPITCH;
-    if (lane < LPR) {
-      *reinterpret_cast<float4*>(red + wave * 2 * WC + c) = make_float4(pg[0], pg[1], pg[2], pg[3]);
-      *reinterpret_cast<float4*>(red + wave * 2 * WC + WC + c) = make_float4(pb[0], pb[1], pb[2], pb[3]);
-    }
-    __syncthreads();
-    for (int i = tid; i < 2 * WC; i += 64 * NW) {
-      float a = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) a += red[w * 2 * WC + i];
-      atomicAdd(i < WC ? p.ln_dgamma + n0 + i : p.ln_dbeta + n0 + (i - WC), a);
-    }
-  }
+  pipe_epilogue_rows<TC, EPI, BM, BN, WGM, WGN>(p, acc, est, meE, m0, n0, wm, wn, lane, C, pg, pb, lng);
+  if constexpr (EPI == EPI_LN_BWD)
+    pipe_ln_bwd_flush<BN, WGM, WGN, 4>(p, pg, pb, reinterpret_cast<float*>(pipe_lds) + NW * 16 * WPITCH, n0, wn, wave, lane, tid);
 }
 
 template <typename TC, int EPI, bool TRB, int BM, int BN, int NST, int WGM = 2, int WGN = 2>

@@ -4,6 +4,7 @@
 #include "gemm.hpp"
 #include "gemm_dw_group.hpp"
 #include "gemm_dw_ring.hpp"
+#include "gemm_ring.hpp"
 
 static MaskParams to_mask(const focal_drop_desc& d, int ncols) {
   MaskParams m;
@@ -169,11 +170,18 @@ extern "C" int focal_linear_bwd_data_ln(const focal_linear_desc* d, const void* 
   memset(&dd, 0, sizeof(dd));
   if (mask) dd = *mask;
   p.epi = to_mask(dd, d->K);
-  focal_note_kernel("focal_gemm_pipe_kernel<f32, epi=%d (LayerNorm backward), trB=1, %dx%d, 4x%d waves>", EPI_LN_BWD, d->K == 256 ? 64 : 128,
-                    d->K, d->K == 256 ? 2 : 1);
-  hipError_t e = d->K == 64    ? focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 128, 64, 2, 4, 1>(p, (hipStream_t)stream)
-                 : d->K == 128 ? focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 128, 128, 2, 4, 1>(p, (hipStream_t)stream)
-                               : focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 64, 256, 2, 4, 2>(p, (hipStream_t)stream);
+  hipError_t e;
+  if (d->K == 64 && d->M >= 4096 && !focal_ring_disabled() &&
+      focal_ring_fits<float, EPI_LN_BWD, true, 128, 64, 6, true, 8, 1, 2, false>(p)) {  // (stage 0, 192 -> 64: the weight panel is 24 KB; lab 0.82)
+    focal_note_kernel("focal_gemm_ring_kernel<f32, epi=%d (LayerNorm backward), trB=1, 128x64, 8x1 waves, ring 6, panel resident>", EPI_LN_BWD);
+    e = focal_launch_gemm_ring<float, EPI_LN_BWD, true, 128, 64, 6, true, 8, 1, 2, false>(p, (hipStream_t)stream);
+  } else {
+    focal_note_kernel("focal_gemm_pipe_kernel<f32, epi=%d (LayerNorm backward), trB=1, %dx%d, 4x%d waves>", EPI_LN_BWD, d->K == 256 ? 64 : 128,
+                      d->K, d->K == 256 ? 2 : 1);
+    e = d->K == 64    ? focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 128, 64, 2, 4, 1>(p, (hipStream_t)stream)
+        : d->K == 128 ? focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 128, 128, 2, 4, 1>(p, (hipStream_t)stream)
+                      : focal_launch_gemm_pipe<float, EPI_LN_BWD, true, 64, 256, 2, 4, 2>(p, (hipStream_t)stream);
+  }
   if (e != hipSuccess) {
     focal_set_error("linear_bwd_data_ln: launch failed: %s", hipGetErrorString(e));
     return FOCAL_EHIP;

@@ -123,7 +123,8 @@ def test_weight_gradient_ring_kernel_shapes(ops, M, N, K):
     assert rel_err(dw2, ref) < 2e-4
 
 
-@pytest.mark.parametrize("M,N,K", [(2304, 128, 128), (2304, 128, 512), (1000, 128, 128), (576, 256, 256), (592, 256, 1024), (64, 256, 256), (9216, 256, 1024)])
+@pytest.mark.parametrize("M,N,K", [(2304, 128, 128), (2304, 128, 512), (1000, 128, 128), (576, 256, 256), (592, 256, 1024), (64, 256, 256), (9216, 256, 1024),
+                                   (36864, 128, 512), (4096 + 24, 128, 128)])   # (the last two: the ring kernel, full and ragged)
 def test_linear_resid_ln_wide(ops, M, N, K):
     """focal_linear_resid_ln_fwd at 128 / 256 columns (bf16): y = resid + x w^T + b from the LDS-DMA GEMM with row-complete wave tiles,
     LayerNorm(y) and its statistics from the same epilogue = focal_linear_fwd followed by focal_layernorm_fwd (ragged M included)."""
@@ -149,7 +150,8 @@ def test_linear_resid_ln_wide(ops, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,drop", [(2304, 192, 64, False), (2304, 384, 128, True), (1000, 512, 128, True), (64, 256, 64, False), (9216, 384, 128, False),
-                                         (4672, 192, 64, True), (1152, 768, 256, True), (1000, 1024, 256, False), (64, 768, 256, True), (9216, 1024, 256, True)])
+                                         (4672, 192, 64, True), (1152, 768, 256, True), (1000, 1024, 256, False), (64, 768, 256, True), (9216, 1024, 256, True),
+                                         (73728, 192, 64, True), (4096 + 40, 192, 64, False)])   # (M >= 4096 at 64 channels: the ring kernel, full and ragged)
 def test_linear_bwd_data_ln(ops, M, N, K, drop):
     """focal_linear_bwd_data_ln = focal_linear_bwd_data followed by focal_layernorm_bwd (accumulating into g, with the masked operand copy
     for the next branch): the LayerNorm backward as the epilogue of the dX GEMM (row-complete wave tiles), ragged M, with / without a mask."""
@@ -315,6 +317,63 @@ def test_linear_pipelined_kernel_fwd_and_data_gradient(ops, M, N, K):
     dx = torch.full((M, K), float("nan"), dtype=ct, device=DEV)
     ops.linear_bwd_data(d, dy, w, None, dx)
     assert rel_err(dx.float(), dy.float() @ w.float()) < 6e-3
+
+
+# The persistent ring kernel (gemm_ring.hpp) takes the Swin stage-1 / stage-2 shapes from M >= 4096: every configuration the dispatcher
+# picks (gemm_dispatch.inc: launch_ring; the LayerNorm epilogues in test_linear_resid_ln_wide / test_linear_bwd_data_ln below), full and
+# ragged row counts (a last row tile with 8 valid rows), a workgroup walking one, several and unequal numbers of tiles.
+@pytest.mark.parametrize("M", [4096, 9216 + 8, 18432])
+def test_linear_ring_kernel_configurations(ops, M):
+    from focal_amd import _lib
+    from focal_amd._lib import ACT_GELU, EPI_GELU, EPI_RESIDUAL
+    ct = torch.bfloat16
+    c, f32 = ops.code(ct), ops.code(torch.float32)
+    lib = _lib.load()
+
+    def kernel():
+        return lib.focal_last_kernel().decode()
+    for C in (128, 256):
+        # fc1 + GELU (+ derivative): wide output, panel resident (K = 128: 128 x 128 tiles; K = 256: 64 x 128)
+        a, w1, b1 = rnd(M, C, seed=31, dtype=ct), rnd(4 * C, C, scale=C ** -0.5, seed=32, dtype=ct), rnd(4 * C, seed=33)
+        hg = torch.full((M, 4 * C), float("nan"), dtype=ct, device=DEV)
+        h, _ = ops.linear(a, w1, b1, compute=ct, epilogue=EPI_GELU, act_grad=hg)
+        assert "focal_gemm_ring_kernel" in kernel(), kernel()
+        u = (a.float() @ w1.float().t() + b1).requires_grad_(True)
+        href = F.gelu(u)
+        href.sum().backward()
+        assert rel_err(h.float(), href) < 5e-3 and rel_err(hg.float(), u.grad) < 5e-3
+        # dX of fc2 x the saved derivative: the weight read in its [K][N] orientation, aux rows requested before the k loop
+        w2 = rnd(C, 4 * C, scale=(4 * C) ** -0.5, seed=34, dtype=ct)
+        gm = rnd(M, C, seed=35, dtype=ct)
+        d2 = ops.linear_desc(c, M, C, 4 * C, c, c, ACT_GELU)
+        du = torch.full((M, 4 * C), float("nan"), dtype=ct, device=DEV)
+        ops.linear_bwd_data(d2, gm, w2, hg, du)
+        assert "focal_gemm_ring_kernel" in kernel(), kernel()
+        assert rel_err(du.float(), (gm.float() @ w2.float()) * hg.float()) < 8e-3
+    C = 256
+    # fc2 + residual (fp32 stream, K = 1024), proj + residual (K = 256), dX of fc1 / qkv (N = 256, K = 1024 / 768)
+    for K in (1024, 256):
+        x, w, b, r = rnd(M, K, seed=36, dtype=ct), rnd(C, K, scale=K ** -0.5, seed=37, dtype=ct), rnd(C, seed=38), rnd(M, C, seed=39)
+        y, _ = ops.linear(x, w, b, compute=ct, y_dtype=torch.float32, resid=r, epilogue=EPI_RESIDUAL)
+        assert "focal_gemm_ring_kernel" in kernel(), kernel()
+        assert rel_err(y, r + x.float() @ w.float().t() + b) < 3e-3
+    for N in (1024, 768):
+        dy, w = rnd(M, N, seed=40, dtype=ct), rnd(N, C, scale=N ** -0.5, seed=41, dtype=ct)
+        d = ops.linear_desc(c, M, N, C, c, c)
+        dx = torch.full((M, C), float("nan"), dtype=ct, device=DEV)
+        ops.linear_bwd_data(d, dy, w, None, dx)
+        assert "focal_gemm_ring_kernel" in kernel(), kernel()
+        assert rel_err(dx.float(), dy.float() @ w.float()) < 6e-3
+    # qkv at stage 1 (K = 128, bf16 out)
+    x, w, b = rnd(M, 128, seed=42, dtype=ct), rnd(384, 128, scale=128 ** -0.5, seed=43, dtype=ct), rnd(384, seed=44)
+    y, _ = ops.linear(x, w, b, compute=ct)
+    assert "focal_gemm_ring_kernel" in kernel(), kernel()
+    assert rel_err(y.float(), x.float() @ w.float().t() + b) < 6e-3
+    # ... and the shapes the lab left on the one-tile kernel stay there (qkv at K = 256)
+    x, w, b = rnd(M, 256, seed=45, dtype=ct), rnd(768, 256, scale=256 ** -0.5, seed=46, dtype=ct), rnd(768, seed=47)
+    y, _ = ops.linear(x, w, b, compute=ct)
+    assert "focal_gemm_pipe_kernel" in kernel(), kernel()
+    assert rel_err(y.float(), x.float() @ w.float().t() + b) < 6e-3
 
 
 def test_linear_pipelined_kernel_epilogues(ops):
