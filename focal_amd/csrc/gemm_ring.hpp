@@ -67,7 +67,7 @@ struct RingLayout {
   static inline int total(int kt) { return panel_bytes(kt) + R * SLOT_BYTES + STG_BYTES + CTRL_BYTES; }
 };
 
-template <typename TC, int EPI, bool TRB, int BM, int BN, int R, bool WS, int WGM, int WGN, int NLOAD, bool ASYNC = true>
+template <typename TC, int EPI, bool TRB, int BM, int BN, int R, bool WS, int WGM, int WGN, int NLOAD, bool ASYNC = false, bool HOIST = true>
 __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void focal_gemm_ring_kernel(const GemmParams p) {
   using L = RingLayout<TC, EPI, BM, BN, R, WS, WGM, WGN>;
   constexpr int NW = WGM * WGN;
@@ -297,9 +297,12 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void focal_gemm_ring_kern
       for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     // everything the tile's epilogue reads from memory (residual / aux rows, LayerNorm rows and statistics, bias) is requested HERE and
     // lands while the k loop multiplies; the loop's asm barriers keep hipcc from sinking the loads to their uses
+    // (HOIST = false: the LayerNorm backward at 128 columns -- 80 more registers per lane across the k loop made it slower, 0.97 against 0.88)
     PipePre<TC, EPI, BN, WGN> pre[TM];
+    if constexpr (HOIST) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a) pipe_epilogue_prefetch<TC, EPI, BM, BN, WGM, WGN>(p, p.resid, m0, n0, m0 + wm * WR + a * 16, wn, lane, C, pre[a]);
+      for (int a = 0; a < TM; ++a) pipe_epilogue_prefetch<TC, EPI, BM, BN, WGM, WGN>(p, p.resid, m0, n0, m0 + wm * WR + a * 16, wn, lane, C, pre[a]);
+    }
     const PipeBias<(sizeof(TC) == 2) ? 8 : 4> bias = pipe_epilogue_bias<TC, EPI, BN, WGN>(p.bias, n0, wn, lane);
     {
       RS_T0();
@@ -322,8 +325,10 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NLOAD)) void focal_gemm_ring_kern
     {
       RS_T0();
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+      for (int a = 0; a < TM; ++a) {
+        if constexpr (!HOIST) pipe_epilogue_prefetch<TC, EPI, BM, BN, WGM, WGN>(p, p.resid, m0, n0, m0 + wm * WR + a * 16, wn, lane, C, pre[a]);
         pipe_epilogue_finish<TC, EPI, BM, BN, WGM, WGN>(p, p.alpha, acc[a], est, meE, m0, n0, m0 + wm * WR + a * 16, wn, lane, C, bias.v, pg, pb, lng, pre[a]);
+      }
       RS_ADD(rs_cepi);
     }
   }
@@ -369,17 +374,17 @@ static inline int focal_cu_count() {
 }
 
 // false: the configuration does not take this problem (LDS), the caller uses another kernel
-template <typename TC, int EPI, bool TRB, int BM, int BN, int R, bool WS, int WGM, int WGN, int NLOAD, bool ASYNC = true>
+template <typename TC, int EPI, bool TRB, int BM, int BN, int R, bool WS, int WGM, int WGN, int NLOAD, bool ASYNC = false, bool HOIST = true>
 static inline bool focal_ring_fits(const GemmParams& p) {
   using L = RingLayout<TC, EPI, BM, BN, R, WS, WGM, WGN>;
   return p.batch == 1 && p.splits == 1 && p.K % 64 == 0 && p.N % BN == 0 && L::total(p.K / 64) <= 160 * 1024;
 }
 
-template <typename TC, int EPI, bool TRB, int BM, int BN, int R, bool WS, int WGM, int WGN, int NLOAD, bool ASYNC = true>
+template <typename TC, int EPI, bool TRB, int BM, int BN, int R, bool WS, int WGM, int WGN, int NLOAD, bool ASYNC = false, bool HOIST = true>
 static inline hipError_t focal_launch_gemm_ring(const GemmParams& p, hipStream_t stream) {
   using L = RingLayout<TC, EPI, BM, BN, R, WS, WGM, WGN>;
   const int lds_bytes = L::total(p.K / 64);
-  auto kern = focal_gemm_ring_kernel<TC, EPI, TRB, BM, BN, R, WS, WGM, WGN, NLOAD, ASYNC>;
+  auto kern = focal_gemm_ring_kernel<TC, EPI, TRB, BM, BN, R, WS, WGM, WGN, NLOAD, ASYNC, HOIST>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

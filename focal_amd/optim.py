@@ -77,6 +77,8 @@ class FocalAdamW(torch.optim.Optimizer):
         """Data parallel, split backward pass (HipBackbone.split_backward): ([spans final after the first phase], [the rest]) per
         arena, or None when the model's backward cannot be split (DeepSense; supervised stages)."""
         bb = getattr(model, "backbone", model)
+        if distributed.grad_reduce_dtype() != "fp32":
+            return None   # (the bf16-wire reduction is an all-to-all + all-gather over the whole arena: one blocking call behind backward)
         if not hasattr(bb, "final_after_first_phase") or not hasattr(bb, "_encoders"):
             return None
         if not all(hasattr(e, "backward_rest") for e in bb._encoders.values()):

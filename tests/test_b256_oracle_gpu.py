@@ -1,7 +1,9 @@
-"""The benchmarked batch against the oracle (VERDICT r3 "what's missing" 3): one fp32 HIP training step at B = 256 -- the batch
-bench.py times -- compared with oracle.step.OracleTrainer run on the box's CPU cores on the same weights and the same two views:
-every loss term within 1e-3 (north_star's fp32 bound), the embeddings within 1e-3 of scale, and the gradient norms of 20 parameters
-sampled over the whole arena within 2e-3.  The reference fixtures (tests/golden/*_b8.npz, loss_*_b2048.npz) pin the oracle and stop at
+"""The benchmarked batch against the oracle (VERDICT r3 "what's missing" 3; r4: in the benchmarked dtype too): one HIP training step at
+B = 256 -- the batch bench.py times -- in fp32 AND in bf16, the dtype bench.py times, compared with oracle.step.OracleTrainer run on
+the box's CPU cores (fp32) on the same weights and the same two views.  fp32: every loss term within 1e-3 (north_star's fp32 bound), the
+embeddings within 1e-3 of scale, the gradient norms of 20 parameters sampled over the whole arena within 2e-3.  bf16: north_star's
+1e-2 as stated -- embeddings within 1e-2 of scale, every loss term within 1e-2 max(1, |term|); gradient norms (no north_star bound)
+within 6e-2.  The reference fixtures (tests/golden/*_b8.npz, loss_*_b2048.npz) pin the oracle and stop at
 B = 8 for the encoders; this test carries the pin to the batch size of the headline number.  Dropout off (the parity convention of
 SURVEY 8c); DeepSense's BatchNorm runs on the batch statistics of all 256 windows on both sides."""
 import time
@@ -15,7 +17,10 @@ pytestmark = pytest.mark.gpu
 B = 256
 
 
-def _build(cfg, model):
+_ORACLE = {}   # model -> the oracle step (6 s for SW_Transformer): shared by the two dtypes
+
+
+def _build(cfg, model, ct="fp32"):
     from models.FOCALModules import FOCAL
     from models.loss import FOCALLoss
     from oracle.weights import fill_state_dict_
@@ -23,7 +28,7 @@ def _build(cfg, model):
         from models.SW_Transformer import SW_Transformer as Net
     else:
         from models.DeepSense import DeepSense as Net
-    args = make_args(no_dropout(cfg), model, torch.device("cuda"), "fp32")
+    args = make_args(no_dropout(cfg), model, torch.device("cuda"), ct)
     net = Net(args)
     fill_state_dict_(net.state_dict())
     state0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
@@ -31,11 +36,13 @@ def _build(cfg, model):
     return args, net, FOCAL(args, net), FOCALLoss(args), state0
 
 
+@pytest.mark.parametrize("ct", ["fp32", "bf16"])
 @pytest.mark.parametrize("model", ["SW_Transformer", "DeepSense"])
-def test_fp32_train_step_at_the_benchmarked_batch_matches_the_oracle(cfg, model):
+def test_train_step_at_the_benchmarked_batch_matches_the_oracle(cfg, model, ct):
     from oracle.step import OracleTrainer
     from oracle.weights import synthetic_freq_input
-    args, net, focal, loss_fn, state0 = _build(cfg, model)
+    emb_tol, term_tol, gn_tol = (1e-3, 1e-3, 2e-3) if ct == "fp32" else (1e-2, 1e-2, 6e-2)
+    args, net, focal, loss_fn, state0 = _build(cfg, model, ct)
     x1, x2 = synthetic_freq_input(cfg, B, seed=301), synthetic_freq_input(cfg, B, seed=302)
     dev = lambda d: {l: {m: v.cuda() for m, v in mm.items()} for l, mm in d.items()}
     f1, f2 = focal(dev(x1), dev(x2), proj_head=True)
@@ -45,22 +52,24 @@ def test_fp32_train_step_at_the_benchmarked_batch_matches_the_oracle(cfg, model)
     torch.cuda.synchronize()
     terms = loss_fn.last_terms.cpu().tolist()
 
-    torch.set_num_threads(min(32, torch.get_num_threads()))
-    t0 = time.time()
-    tr = OracleTrainer(model, no_dropout(cfg), state0)
-    ref_terms, r1, r2, ref_grads = tr.loss_and_grads(x1, x2)
-    record_observed(f"b256.{model}.oracle_seconds", time.time() - t0)
+    if model not in _ORACLE:   # (same weights -- the name-seeded fill -- and the same views for both dtypes)
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        t0 = time.time()
+        tr = OracleTrainer(model, no_dropout(cfg), state0)
+        _ORACLE[model] = (tr, tr.loss_and_grads(x1, x2))
+        record_observed(f"b256.{model}.oracle_seconds", time.time() - t0)
+    tr, (ref_terms, r1, r2, ref_grads) = _ORACLE[model]
 
     for m in f1:
         for got, ref in ((f1[m], r1[m]), (f2[m], r2[m])):
             e = ((got.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max()).item()
-            record_observed(f"b256.{model}.emb.{m}.max_err_over_max_ref", e)
-            assert e < 1e-3, (m, e)
+            record_observed(f"b256.{model}.{ct}.emb.{m}.max_err_over_max_ref", e)
+            assert e < emb_tol, (m, e)
     for i, k in enumerate(("shared", "private", "orth", "rank", "total")):
         ref = float(ref_terms[k])
         err = abs(terms[i] - ref) / max(1.0, abs(ref))
-        record_observed(f"b256.{model}.loss.{k}.abs_err_over_max1", err)
-        assert err < 1e-3, (k, terms[i], ref)
+        record_observed(f"b256.{model}.{ct}.loss.{k}.abs_err_over_max1", err)
+        assert err < term_tol, (k, terms[i], ref)
     params = dict(net.named_parameters())
     names = [k for k in tr.train_keys if ref_grads[k] is not None]
     assert len(names) > 60
@@ -73,10 +82,10 @@ def test_fp32_train_step_at_the_benchmarked_batch_matches_the_oracle(cfg, model)
         got = g.double().norm().item()
         err = abs(got - ref) / max(ref, 1e-6)
         worst = max(worst, err)
-        assert err < 2e-3 or abs(got - ref) < 1e-6, (n, got, ref)
-        # and element-wise on a strided sample of the tensor
-        flat_g, flat_r = g.detach().reshape(-1).cpu().double(), ref_grads[n].reshape(-1).double()
-        step = max(1, flat_g.numel() // 64)
-        scale = max(flat_r.abs().max().item(), ref / max(flat_g.numel() ** 0.5, 1), 1e-9)
-        assert (flat_g[::step] - flat_r[::step]).abs().max().item() < 2e-3 * scale + 1e-7, n
-    record_observed(f"b256.{model}.grad_norm.worst_rel_err_of_{len(sample)}", worst)
+        assert err < gn_tol or abs(got - ref) < 1e-6, (n, got, ref)
+        if ct == "fp32":  # and element-wise on a strided sample of the tensor
+            flat_g, flat_r = g.detach().reshape(-1).cpu().double(), ref_grads[n].reshape(-1).double()
+            step = max(1, flat_g.numel() // 64)
+            scale = max(flat_r.abs().max().item(), ref / max(flat_g.numel() ** 0.5, 1), 1e-9)
+            assert (flat_g[::step] - flat_r[::step]).abs().max().item() < 2e-3 * scale + 1e-7, n
+    record_observed(f"b256.{model}.{ct}.grad_norm.worst_rel_err_of_{len(sample)}", worst)

@@ -210,3 +210,51 @@ def test_capture_failure_on_one_rank_keeps_every_rank_eager():
     for r in range(world):
         assert out[r][1] == (True, False), dict(out)     # rank 1 failed: nobody replays
         assert out[r][None] == (False, True), dict(out)  # nobody failed: everybody replays
+
+
+def _bf16_reduce_worker(rank, world, port, out):
+    """The bf16-wire gradient reduction (FOCAL_GRAD_REDUCE=bf16) against the fp32 all-reduce on the same gradients: the summed gradient
+    within 1e-2 of its norm (observed ~2e-3: one bf16 rounding per contribution and one of the sum), a rank's own shard better than the
+    others' (its contribution is never rounded), sizes that do not divide by the world size, repeated calls on the persistent buffers."""
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from focal_amd import distributed as fd
+
+    class Arena:
+        pass
+    res = {}
+    for n in (1001, 4096):
+        for rep in range(2):
+            g = torch.Generator().manual_seed(100 * n + 10 * rep + rank)
+            mine = torch.randn(n, generator=g) * torch.logspace(-3, 1, n)   # gradients over four decades
+            ref = mine.clone()
+            dist.all_reduce(ref)
+            ar = Arena()
+            ar.grad = mine.clone()
+            os.environ["FOCAL_GRAD_REDUCE"] = "bf16"
+            fd.all_reduce_gradients(ar)
+            del os.environ["FOCAL_GRAD_REDUCE"]
+            mag = mine.abs()
+            dist.all_reduce(mag)   # sum over ranks of |contribution|: what an element's rounding errors scale with (the sum itself may cancel)
+            res[(n, rep)] = ((ar.grad - ref).norm() / ref.norm()).item(), ((ar.grad - ref).abs() / mag.clamp_min(1e-30)).max().item()
+            ar2 = Arena()
+            ar2.grad = mine.clone()
+            fd.all_reduce_gradients(ar2)                                     # the default stays the exact fp32 sum
+            assert torch.equal(ar2.grad, ref)
+    assert fd.grad_reduce_dtype() == "fp32"
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_gradient_reduction_matches_fp32_all_reduce():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bf16_reduce_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        for key, (rel_l2, rel_max) in out[r].items():
+            assert rel_l2 < 1e-2, (r, key, rel_l2)        # of the update's norm
+            assert rel_max < 1.2e-2, (r, key, rel_max)    # element-wise, of the summed magnitudes: bf16 roundings of 2^-9 each

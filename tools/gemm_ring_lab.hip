@@ -215,8 +215,11 @@ static void run_case(const char* name, int M, int N, int K) {
     if (N == 128) {
       OLD(128, 128, 2, 4, 1)
       RING(64, 128, 4, false, 4, 1, 2, false)
+      if constexpr (EPI == EPI_LN_BWD) {
+        checked("64x128/4 w4x1+2 no hoist", [&] { CK((focal_launch_gemm_ring<TC, EPI, TRB, 64, 128, 4, false, 4, 1, 2, false, false>(p, 0))); });
+        report("64x128/4 w4x1+2 nohoist", time_us([&] { next(); CK((focal_launch_gemm_ring<TC, EPI, TRB, 64, 128, 4, false, 4, 1, 2, false, false>(p, 0))); }, iters));
+      }
       RING(64, 128, 5, false, 4, 1, 2, false)
-      RING(128, 128, 3, false, 4, 1, 2, false)
     } else if (N == 64) {
       OLD(128, 64, 2, 4, 1)
       RING(128, 64, 6, true, 4, 1, 2, false)
