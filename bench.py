@@ -55,10 +55,11 @@ def parse():
     p.add_argument("--roofline-iters", type=int, default=20)
     p.add_argument("--from-host", action="store_true", help="diagnostic (never the reported `value`): every step's windows start in pinned "
                    "host memory, as the reference's DataLoader hands them over; H2D on a copy stream one step ahead")
-    p.add_argument("--views", default="fixed", choices=["fixed", "random"],
+    p.add_argument("--views", default="fixed", choices=["fixed", "random", "random-host"],
                    help="fixed: identity / x * -1.1 folded into the DFT inside the captured step (the default, what `value` is quoted on); random: the "
-                        "product Augmenter's draws (data_augmenter/Augmenter.py: coin flips, permutation / flip / phase / warp tables on the host, one "
-                        "DFT launch per modality and view plus a warp pass when drawn) made eagerly before every replay, inside the timed region")
+                        "product Augmenter's views as train.py makes them since round 5 -- every draw on the device, inside the captured step "
+                        "(Augmenter.forward_random_pair: focal_view_draw, the warp tables and the transforms read the drawn records); random-host: "
+                        "the round-4 form, draws and warp tables on the host, eagerly before every replay, inside the timed region")
     p.add_argument("--trace-dump", default=None, help="write the library's launch trace of 5 eager steps (per-instance medians, both trace modes) to this JSON file and exit")
     p.add_argument("--no-roofline", action="store_true", help="profiling runs: skip the dominant-kernel timing loop (the JSON line then has roofline null)")
     return p.parse_args()
@@ -116,11 +117,14 @@ class Step:
                 self.x[loc][mod] = torch.randn(shape, generator=g).to(device)
         from focal_amd.graph_step import StepSegments
         self.aug = None
-        if a.views == "random":
+        self.host_draws = False
+        if a.views in ("random", "random-host"):
             from data_augmenter.Augmenter import Augmenter
             self.aug = Augmenter(args)
-            self.aug.static_views = True  # address-stable two-view buffers: the captured step reads them
-            self.draw_views()
+            self.host_draws = a.views == "random-host" or not self.aug.device_draws_supported()
+            if self.host_draws:
+                self.aug.static_views = True  # address-stable two-view buffers: the captured step reads them
+                self.draw_views()
         self.seg = StepSegments(self.model, self.loss_fn, self.opt, self.views, device)
         self.feed = None
 
@@ -162,6 +166,8 @@ class Step:
 
     def views(self):
         if self.aug is not None:
+            if not self.host_draws:   # the product's form since round 5: both views drawn on the device, inside the captured step
+                return self.aug.forward_random_pair(self.x)
             return self.v1, self.v2
         # both views of a modality are written into the halves of one [2B, ...] tensor (what Augmenter.forward_random does for
         # back-to-back draws): SW_Transformer runs them as one batch without a concatenation
@@ -665,7 +671,7 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
             except Exception as e:  # noqa: BLE001
                 print(f"[bench] rank {rank}: hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 torch.cuda.synchronize()
-        if a.views == "random":
+        if step.host_draws:
             drawn = run
 
             def run():
@@ -806,7 +812,9 @@ def main():
                           **({"DIAGNOSTIC_from_host": True} if a.from_host else {}),
 **({"DIAGNOSTIC_ABLATED_INVALID": os.environ["FOCAL_ABLATE"]} if os.environ.get("FOCAL_ABLATE") else {}),
                           "views": ("identity / negation+scaling (x * -1.1) folded into the DFT" if a.views == "fixed" else
-                                    "random: the product Augmenter's draws, made eagerly before every replay inside the timed region (DIAGNOSTIC: not the quoted configuration)"),
+                                    "random: the product Augmenter's views, every draw made on the device inside the captured step (train.py's form; not the quoted configuration)"
+                                    if not step.host_draws else
+                                    "random-host: the product Augmenter's draws on the host, made eagerly before every replay inside the timed region (DIAGNOSTIC: not the quoted configuration)"),
                           "last_loss": round(last_loss, 4),
                           "parity": "this configuration (train mode, dropout / DropPath on) is covered by statistical and finite-difference tests; "
                                     "the same kernels with dropout off are pinned bit-for-tolerance against reference fixtures (tests/golden, DESIGN 1)"},

@@ -33,7 +33,27 @@ class AugDesc(C.Structure):
 
 
 class FftProblem(C.Structure):
-    _fields_ = [("d", FFTDesc), ("has_aug", C.c_int), ("aug", AugDesc), ("x", C.c_void_p), ("twiddle", C.c_void_p), ("out", C.c_void_p)]
+    _fields_ = [("d", FFTDesc), ("has_aug", C.c_int), ("aug", AugDesc), ("x", C.c_void_p), ("twiddle", C.c_void_p), ("out", C.c_void_p),
+                ("plan", C.c_void_p), ("x_warped", C.c_void_p)]
+
+
+VIEW_MAX_KNOTS, VIEW_MAX_POOL, VIEW_MAX_SLOTS = 16, 8, 8
+VIEW_NONE, VIEW_NEGATION, VIEW_SCALING, VIEW_HFLIP, VIEW_PERMUTATION, VIEW_PHASE_SHIFT, VIEW_MAG_WARP, VIEW_TIME_WARP = range(8)
+
+
+class ViewPlan(C.Structure):
+    _fields_ = [("aug", AugDesc), ("kind", C.c_int), ("pool_index", C.c_int), ("warp", C.c_int), ("nknots", C.c_int),
+                ("knots", C.c_float * VIEW_MAX_KNOTS)]
+
+
+class ViewPool(C.Structure):
+    _fields_ = [("n_aug", C.c_int), ("kind", C.c_int * VIEW_MAX_POOL), ("prob", C.c_float * VIEW_MAX_POOL), ("scaling_std", C.c_float),
+                ("mag_magnitude", C.c_float), ("time_magnitude", C.c_float), ("mag_order", C.c_int), ("time_order", C.c_int),
+                ("intervals", C.c_int * VIEW_MAX_SLOTS)]
+
+
+class WarpProblem(C.Structure):
+    _fields_ = [("rows", C.c_int), ("L", C.c_int), ("x", C.c_void_p), ("plan", C.c_void_p), ("tables", C.c_void_p), ("y", C.c_void_p)]
 
 
 class EmbedDesc(C.Structure):
@@ -119,6 +139,8 @@ PROTOTYPES = {
     "focal_augment_fft_fwd": (C.c_int, [C.POINTER(FFTDesc), C.POINTER(AugDesc), P, P, P, P]),
     "focal_fft_realpack_multi": (C.c_int, [C.c_int, C.POINTER(FftProblem), P]),
     "focal_warp_fwd": (C.c_int, [C.c_int, C.c_int, P, P, P, P, C.c_int, P, P]),
+    "focal_view_draw": (C.c_int, [C.POINTER(ViewPool), C.c_int, C.c_int, P, C.c_uint32, P, P]),
+    "focal_warp_plan_multi": (C.c_int, [C.c_int, C.POINTER(WarpProblem), P, P]),
     "focal_mixup_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "focal_pad_patch_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P]),
     "focal_pad_patch_embed_ln2_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P, P, C.c_float, C.c_int, P, P, P]),
@@ -140,7 +162,8 @@ PROTOTYPES = {
     "focal_linear_bwd_weight_group_kind": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "focal_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "focal_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P, P]),
+    "focal_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P, P, P]),
+    "focal_mlp_bwd_partials_floats": (C.c_long, [C.POINTER(MlpDesc)]),
     "focal_window_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P]),
     "focal_window_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P, P]),
     "focal_window_attn_qkv_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -10,10 +10,14 @@
 // View augmentations that commute with (or fold into) the transform, applied while the rows are staged / stored instead of as
 // separate passes over the window (the reference data_augmenter package): scaling / negation (x * a), horizontal flip (intervals and samples
 // reversed), interval permutation, and the frequency-domain phase shift (every bin rotated by one angle).
+// plan != NULL (round 5): the values come from that device record instead -- focal_view_draw wrote it earlier in the same stream, so
+// a captured step draws a fresh view on every replay -- and when the record says the view is warped the rows are read from x_alt.
 struct AugParams {
   float scale, pc, ps;
   int flip, use_perm;
   int perm[FOCAL_AUG_MAX_INTERVALS];
+  const focal_view_plan* plan;
+  const float* x_alt;
 };
 static AugParams aug_identity() {
   AugParams a;
@@ -21,17 +25,40 @@ static AugParams aug_identity() {
   a.scale = 1.f; a.pc = 1.f;
   return a;
 }
+// The augmentation a kernel applies, resolved once per workgroup: from the kernel arguments, or from the device plan.  The interval
+// permutation goes to LDS (s_perm, FOCAL_AUG_MAX_INTERVALS ints; the caller's next __syncthreads() publishes it).
+struct AugLive {
+  float scale, pc, ps;
+  int flip, use_perm;
+  const float* x;
+};
+__device__ __forceinline__ AugLive aug_resolve(const AugParams& a, const float* x, int* s_perm, int tid) {
+  AugLive v{a.scale, a.pc, a.ps, a.flip, a.use_perm, x};
+  if (a.plan != nullptr) {  // (uniform)
+    const focal_view_plan* pl = a.plan;
+    v.scale = pl->aug.scale; v.pc = pl->aug.phase_cos; v.ps = pl->aug.phase_sin;
+    v.flip = pl->aug.flip != 0; v.use_perm = pl->aug.use_perm != 0;
+    if (pl->warp != 0) v.x = a.x_alt;
+    if (tid < FOCAL_AUG_MAX_INTERVALS) s_perm[tid] = pl->aug.perm[tid];
+  } else if (tid < FOCAL_AUG_MAX_INTERVALS) {
+    s_perm[tid] = a.perm[tid];
+  }
+  return v;
+}
 // source row of output row `row` = (bc, i)
-__device__ __forceinline__ int aug_src_row(const AugParams& a, int row, int I) {
+__device__ __forceinline__ int aug_src_row(const AugLive& a, const int* s_perm, int row, int I) {
   const int i = row % I, bc = row / I;
-  int j = a.use_perm ? a.perm[i] : i;
+  int j = a.use_perm ? s_perm[i] : i;
   if (a.flip) j = I - 1 - j;
   return bc * I + j;
 }
 
-__global__ __launch_bounds__(256) void fft_realpack_kernel(const float* __restrict__ x, const float* __restrict__ tw,
-                                                           float* __restrict__ out, focal_fft_desc d, int rows, AugParams aug) {
+__global__ __launch_bounds__(256) void fft_realpack_kernel(const float* __restrict__ x_arg, const float* __restrict__ tw,
+                                                           float* __restrict__ out, focal_fft_desc d, int rows, AugParams aug_arg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_perm[FOCAL_AUG_MAX_INTERVALS];
+  const AugLive aug = aug_resolve(aug_arg, x_arg, s_perm, threadIdx.x);
+  const float* x = aug.x;
   const int n = d.n, n1 = d.n1, n2 = d.n2;
   float* xs = smem;            // [n]
   float* yr = smem + n;        // [n2][n1]  stage-1 output, real
@@ -45,7 +72,7 @@ __global__ __launch_bounds__(256) void fft_realpack_kernel(const float* __restri
   }
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     __syncthreads();
-    const float* xr = x + (long)aug_src_row(aug, row, d.I) * n;
+    const float* xr = x + (long)aug_src_row(aug, s_perm, row, d.I) * n;
     for (int i = tid; i < n; i += 256) xs[i] = aug.scale * xr[aug.flip ? n - 1 - i : i];
     __syncthreads();
     // stage 1: for each m2, n1-point DFT over m1, then twiddle W_n^{m2 k1}
@@ -102,10 +129,13 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_a
 // N1 / N2 are compile-time: the index arithmetic below is full of divisions by them (runtime divisors cost ~40
 // instructions each and dominated the first version of this kernel).
 template <int N1, int N2>
-__global__ __launch_bounds__(256) void fft_realpack_mfma_kernel(const float* __restrict__ x, const float* __restrict__ tw,
-                                                                float* __restrict__ out, focal_fft_desc d, int rows, AugParams aug) {
+__global__ __launch_bounds__(256) void fft_realpack_mfma_kernel(const float* __restrict__ x_arg, const float* __restrict__ tw,
+                                                                float* __restrict__ out, focal_fft_desc d, int rows, AugParams aug_arg) {
   constexpr int P = 48;  // padded tile pitch (3 x 16)
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_perm[FOCAL_AUG_MAX_INTERVALS];
+  const AugLive aug = aug_resolve(aug_arg, x_arg, s_perm, threadIdx.x);
+  const float* x = aug.x;
   constexpr int n = N1 * N2, n1 = N1, n2 = N2;
   float* twc = smem;                 // [n]  cos(2 pi j / n)
   float* tws = twc + n;              // [n] -sin
@@ -143,7 +173,7 @@ __global__ __launch_bounds__(256) void fft_realpack_mfma_kernel(const float* __r
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (e < 2 * n / 4 && pair < rows / 2) {
         const int rl = e / (n / 4), q = e - rl * (n / 4);
-        const float4* src = reinterpret_cast<const float4*>(x + (long)aug_src_row(aug, pair * 2 + rl, d.I) * n);
+        const float4* src = reinterpret_cast<const float4*>(x + (long)aug_src_row(aug, s_perm, pair * 2 + rl, d.I) * n);
         if (aug.flip) {
           const float4 t = src[n / 4 - 1 - q];
           v = make_float4(t.w, t.z, t.y, t.x);
@@ -162,6 +192,7 @@ __global__ __launch_bounds__(256) void fft_realpack_mfma_kernel(const float* __r
       if (e < 2 * n / 4) reinterpret_cast<float4*>(xs)[e] = xn[i];
     }
   };
+  __syncthreads();  // s_perm
   fetch(blockIdx.x);
   stash();
   for (int pair = blockIdx.x; pair < rows / 2; pair += gridDim.x) {
@@ -290,7 +321,7 @@ static int fft_launch(const focal_fft_desc* d, const AugParams& aug, const float
 // launch per (view, modality) on its serial head -- 8 launches of ~20 us + gaps for the four-modality config.  Here a thread owns one
 // output bin of one row (256 / n rows per workgroup pass), and a table in the kernel arguments maps blockIdx ranges to problems.
 #define FFT_MULTI_MAX 8
-struct FftSmallProblem { const float* x; const float* tw; float* out; int rows, I, n, rpb; AugParams aug; };
+struct FftSmallProblem { const float* x; const float* tw; float* out; int rows, I, n, rpb; AugParams aug; };  // (aug.plan / aug.x_alt as above)
 struct FftSmallTable { int nprob; int wg_end[FFT_MULTI_MAX]; FftSmallProblem p[FFT_MULTI_MAX]; };
 
 __global__ __launch_bounds__(256) void fft_small_multi_kernel(const FftSmallTable t) {
@@ -300,6 +331,8 @@ __global__ __launch_bounds__(256) void fft_small_multi_kernel(const FftSmallTabl
 #pragma unroll
   for (int q = 0; q < FFT_MULTI_MAX - 1; ++q) pi += (q < t.nprob - 1 && b >= t.wg_end[q]) ? 1 : 0;
   const FftSmallProblem& P = t.p[pi];
+  __shared__ int s_perm[FOCAL_AUG_MAX_INTERVALS];
+  const AugLive aug = aug_resolve(P.aug, P.x, s_perm, tid);
   const int start = pi > 0 ? t.wg_end[pi - 1] : 0, nb = t.wg_end[pi] - start;
   const int n = P.n, rpb = P.rpb;
   if (tid < n) { twc[tid] = P.tw[2 * tid]; tws[tid] = P.tw[2 * tid + 1]; }
@@ -309,7 +342,7 @@ __global__ __launch_bounds__(256) void fft_small_multi_kernel(const FftSmallTabl
     const int row = row0 + r;
     const bool ok = active && row < P.rows;
     __syncthreads();
-    if (ok) xs[tid] = P.aug.scale * P.x[(long)aug_src_row(P.aug, row, P.I) * n + (P.aug.flip ? n - 1 - k : k)];
+    if (ok) xs[tid] = aug.scale * aug.x[(long)aug_src_row(aug, s_perm, row, P.I) * n + (aug.flip ? n - 1 - k : k)];
     __syncthreads();
     if (!ok) continue;
     const float* xr = xs + r * n;
@@ -323,8 +356,8 @@ __global__ __launch_bounds__(256) void fft_small_multi_kernel(const FftSmallTabl
       if (ph >= n) ph -= n;
     }
     const int ci = row % P.I, bc = row / P.I;  // row = (b*C + c)*I + i
-    P.out[((long)(2 * bc) * P.I + ci) * n + k] = re * P.aug.pc - im * P.aug.ps;
-    P.out[((long)(2 * bc + 1) * P.I + ci) * n + k] = re * P.aug.ps + im * P.aug.pc;
+    P.out[((long)(2 * bc) * P.I + ci) * n + k] = re * aug.pc - im * aug.ps;
+    P.out[((long)(2 * bc + 1) * P.I + ci) * n + k] = re * aug.ps + im * aug.pc;
   }
 }
 
@@ -364,6 +397,11 @@ extern "C" int focal_fft_realpack_multi(int n, const focal_fft_problem* probs, v
     FOCAL_CHECK_ARG(q.d.B > 0 && q.d.C > 0 && q.d.I > 0 && q.d.n > 0, "fft_realpack: bad shape");
     AugParams ap;
     if (int rc = aug_params(&q.d, q.has_aug ? &q.aug : nullptr, &ap)) return rc;
+    if (q.plan != nullptr) {
+      FOCAL_CHECK_ARG(q.x_warped != nullptr && q.d.I <= FOCAL_AUG_MAX_INTERVALS, "fft_realpack_multi: a device plan needs x_warped and at most %d intervals", FOCAL_AUG_MAX_INTERVALS);
+      ap.plan = q.plan;
+      ap.x_alt = q.x_warped;
+    }
     if (!no_multi && q.d.n <= 64 && q.d.n2 == 1 && q.d.n1 == q.d.n) {  // short rows: the shared launch
       FftSmallProblem& P = t.p[t.nprob];
       P.x = q.x; P.tw = q.twiddle; P.out = q.out;

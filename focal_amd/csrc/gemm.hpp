@@ -89,13 +89,19 @@ struct MaskEval {
   __device__ __forceinline__ float elem_mult(int row, int col) const {
     return on_e ? drop_mult(e, __umul24((uint32_t)row, (uint32_t)ncols) + (uint32_t)col) : 1.0f;
   }
-  // Two neighbouring elements (col even) from ONE hash: its two 16-bit halves against a 16-bit threshold.  Only for sites whose
-  // mask is consumed where it is drawn and never regenerated elsewhere (the fc1 GELU epilogue: the saved derivative carries it).
-  __device__ __forceinline__ gelu_f2 elem_mult_pair(int row, int col) const {
-    if (!on_e) return gelu_f2{1.0f, 1.0f};
-    const uint32_t idx = (__umul24((uint32_t)row, (uint32_t)ncols) + (uint32_t)col) >> 1;
+  // FOUR neighbouring elements (col % 4 == 0) from ONE hash and a three-instruction second word: 16-bit fields against a 16-bit
+  // threshold.  Only for sites whose mask is consumed where it is drawn and never regenerated elsewhere (the fc1 GELU epilogue: the
+  // saved derivative carries it).  Round 5: the epilogue is vector-issue-bound (profiles/r5_ring_lab.txt) and the per-pair hash was
+  // a third of its instructions; keep rates, pairwise and lag correlations of the four decisions: tools/hash_eval.py (all < 1e-3).
+  __device__ __forceinline__ void elem_mult_quad(int row, int col, gelu_f2& m01, gelu_f2& m23) const {
+    if (!on_e) { m01 = gelu_f2{1.0f, 1.0f}; m23 = gelu_f2{1.0f, 1.0f}; return; }
+    const uint32_t idx = (__umul24((uint32_t)row, (uint32_t)ncols) + (uint32_t)col) >> 2;
     const uint32_t h = focal_hash24(idx ^ e.key), t16 = e.thresh >> 8;
-    return gelu_f2{(h & 0xffffu) < t16 ? 0.0f : e.scale, (h >> 16) < t16 ? 0.0f : e.scale};
+    uint32_t g = h ^ (h >> 13);
+    g = __umul24(g, 0xC2B2AFu) + 0x165667B1u;
+    g ^= g >> 15;
+    m01 = gelu_f2{(h & 0xffffu) < t16 ? 0.0f : e.scale, (h >> 16) < t16 ? 0.0f : e.scale};
+    m23 = gelu_f2{(g & 0xffffu) < t16 ? 0.0f : e.scale, (g >> 16) < t16 ? 0.0f : e.scale};
   }
 };
 

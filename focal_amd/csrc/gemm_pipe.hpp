@@ -401,14 +401,18 @@ __device__ __forceinline__ void pipe_epilogue_finish(const GemmParams& p, float 
     } else if (EPI == EPI_GELU_FWD) {
       float gq[CPL];
 #pragma unroll
-      for (int e = 0; e < CPL; e += 2) {
-        const gelu_f2 x = {v[e], v[e + 1]};
-        gelu_f2 cdf, pdf;
-        gelu_parts2(x, cdf, pdf);
-        const gelu_f2 mult = meE.elem_mult_pair(m, n + e);
-        const gelu_f2 gg = (x * pdf + cdf) * mult, hh = x * cdf * mult;
-        gq[e] = gg.x; gq[e + 1] = gg.y;
-        v[e] = hh.x; v[e + 1] = hh.y;
+      for (int e = 0; e < CPL; e += 4) {  // one mask hash per four elements (MaskEval::elem_mult_quad)
+        gelu_f2 mult[2];
+        meE.elem_mult_quad(m, n + e, mult[0], mult[1]);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const gelu_f2 x = {v[e + 2 * h2], v[e + 2 * h2 + 1]};
+          gelu_f2 cdf, pdf;
+          gelu_parts2(x, cdf, pdf);
+          const gelu_f2 gg = (x * pdf + cdf) * mult[h2], hh = x * cdf * mult[h2];
+          gq[e + 2 * h2] = gg.x; gq[e + 2 * h2 + 1] = gg.y;
+          v[e + 2 * h2] = hh.x; v[e + 2 * h2 + 1] = hh.y;
+        }
       }
       storeN<CPL>(dst, v);
       storeN<CPL>(pipe_row(auxoT_t, m - m0, p.ldc, n), gq);

@@ -26,6 +26,7 @@ struct MlpBwdParams {
   const bf16_t* w1; const float* b1; const bf16_t* w2;
   bf16_t* da;           // [M][C]   dL/da (LN_BWD = false)
   float* dw1; float* db1; float* dw2; float* db2;   // fp32, accumulated (+=)
+  float* partials;      // non-null: every workgroup stores its [dW2 | dW1] image here (32 768 floats each) for mlp_bwd_reduce_kernel
   MaskParams drop_h;
   const uint32_t* mask_bits;  // [M][8]: the forward kernel's keep bits of drop_h (required when p_elem > 0)
   // LN_BWD: the norm2 backward fused behind dL/da -- completes the residual-stream gradient g (+= in place) and emits

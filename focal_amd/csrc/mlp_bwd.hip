@@ -343,6 +343,15 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
   // ---- 256-byte contiguous atomics of the two weight gradients, all 1024 threads
   // (33.5 MB of fp32 atomics per launch -- 256 workgroups x 128 KB -- drain at the memory side in ~30 us (1.3 TB/s); the waves end as
   // soon as they are issued, so the CUs are free for the other encoder stream's kernels meanwhile: profiles/r4_mlp_bwd.txt)
+  if (p.partials != nullptr) {
+    // Round 5: plain 16-byte stores of the workgroup's 128 KB into its own slot of a workspace (6 TB/s class), summed over the
+    // workgroups by mlp_bwd_reduce_kernel behind this launch -- 33.5 MB of fp32 atomics drain at 1.3 TB/s at the memory side
+    float4* dst = reinterpret_cast<float4*>(p.partials + (long)blockIdx.x * (2 * C * H));
+    const float4* src = reinterpret_cast<const float4*>(lds);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[tid + 1024 * i] = src[tid + 1024 * i];
+    return;
+  }
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
     const int idx = tid + 1024 * i;
@@ -350,6 +359,29 @@ __global__ __launch_bounds__(1024) void mlp_bwd_kernel(const MlpBwdParams p) {
     atomicAdd(p.dw1 + idx, F1[idx]);
   }
 
+}
+
+// dw2 / dw1 += the sum over G workgroup images [dW2 (C x H) | dW1 (H x C)] of mlp_bwd_kernel: grid (32 column chunks of 1024 floats, 8
+// slices of the images); a thread sums one float4 column over its slice, the chunk's 1024 sums cross LDS so that the eight adds per
+// address leave as contiguous 256-byte atomic rows.
+__global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float* __restrict__ partials, int G, float* __restrict__ dw2, float* __restrict__ dw1) {
+  __shared__ float4 sums[256];
+  const int tid = threadIdx.x, chunk = blockIdx.x, per = (G + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
+  const float4* src = reinterpret_cast<const float4*>(partials) + chunk * 256 + tid;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int g = g0; g < g1; ++g) {
+    const float4 v = src[(long)g * (2 * C * H / 4)];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  sums[tid] = acc;
+  __syncthreads();
+  if (g1 <= g0) return;
+  const float* sf = reinterpret_cast<const float*>(sums);
+  float* out = chunk < 16 ? dw2 + chunk * 1024 : dw1 + (chunk - 16) * 1024;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) atomicAdd(out + j * 256 + tid, sf[j * 256 + tid]);
 }
 
 }  // namespace focal_mlp_kernels
@@ -370,7 +402,7 @@ static MaskParams mlp_bwd_mask(const focal_drop_desc& d, int ncols) {
 extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void* a, const void* w1, const float* b1, const void* w2,
                              void* da, float* dw1, float* db1, float* dw2, float* db2, const float* ln_x, const float* ln_stats,
                              const float* ln_gamma, float* g, void* gm_next, const focal_drop_desc* next_mask, float* dgamma,
-                             float* dbeta, const uint32_t* mask_bits, void* stream) {
+                             float* dbeta, const uint32_t* mask_bits, float* dw_partials, void* stream) {
   if (int rc = mlp_check_desc(d, "mlp_bwd")) return rc;
   FOCAL_CHECK_ARG(gm && a && w1 && b1 && w2 && dw1 && dw2, "mlp_bwd: null tensor");
   const bool ln = ln_x != nullptr;
@@ -394,6 +426,8 @@ extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void
   const bool drop = d->drop_hidden.p_elem > 0.f;
   FOCAL_CHECK_ARG(!drop || mask_bits != nullptr, "mlp_bwd: hidden dropout is on (p = %g) but mask_bits is NULL: pass the [M][8] words focal_mlp_fwd wrote", (double)d->drop_hidden.p_elem);
   p.mask_bits = mask_bits;
+  p.partials = dw_partials;
+  FOCAL_CHECK_ARG(dw_partials == nullptr || ((uintptr_t)dw_partials % 16) == 0, "mlp_bwd: dw_partials must be 16-byte aligned");
   void (*kern)(const MlpBwdParams) = ln ? (drop ? mlp_bwd_kernel<true, true> : mlp_bwd_kernel<false, true>)
                                         : (drop ? mlp_bwd_kernel<true, false> : mlp_bwd_kernel<false, false>);
   static bool attr_set[4] = {false, false, false, false};
@@ -408,6 +442,13 @@ extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void
   const int ntiles = (d->M + BM - 1) / BM;
   const int grid = ntiles < 256 ? ntiles : 256;  // one persistent 16-wave workgroup per CU
   FOCAL_LAUNCH(kern, dim3(grid), dim3(1024), LDS_BWD_BYTES, (hipStream_t)stream, p);
+  if (dw_partials != nullptr) FOCAL_LAUNCH(mlp_bwd_reduce_kernel, dim3(32, 8), dim3(256), 0, (hipStream_t)stream, dw_partials, grid, dw2, dw1);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
+}
+
+extern "C" long focal_mlp_bwd_partials_floats(const focal_mlp_desc* d) {
+  if (mlp_check_desc(d, "mlp_bwd_partials_floats")) return 0;
+  const int ntiles = (d->M + BM - 1) / BM;
+  return (long)(ntiles < 256 ? ntiles : 256) * (2 * C * H);
 }

@@ -326,14 +326,36 @@ class CapturedTrainStep:
 
     def __call__(self, v1, v2):
         """One optimiser step on the two views; returns the (device) loss of the step."""
-        key = self._key(v1, v2)
+        return self._step(self._key(v1, v2), lambda: self._segments(v1, v2), lambda: None)
+
+    def step_from_inputs(self, augmenter, time_loc_inputs):
+        """One optimiser step on a batch of TIME-domain windows (device tensors): the two random views are drawn on the device inside
+        the step (Augmenter.forward_random_pair), so the replayed graph holds the whole reference loop body -- augmenter x 2, backbone,
+        loss, backward, optimizer.  The batch is copied into address-stable input buffers in front of the replay (one device-to-device
+        copy per modality; a loader that already fills fixed device buffers could hand those over instead)."""
+        flat = [(loc, mod) for loc in time_loc_inputs for mod in time_loc_inputs[loc]]
+        key = ("time",) + tuple((loc, mod, tuple(time_loc_inputs[loc][mod].shape)) for loc, mod in flat)
+        st = self.__dict__.setdefault("_static_inputs", {})
+        if key not in st:
+            st[key] = {loc: {mod: torch.empty_like(t, dtype=torch.float32).contiguous() for mod, t in mods.items()}
+                       for loc, mods in time_loc_inputs.items()}
+        static = st[key]
+
+        def load():
+            for loc, mod in flat:
+                static[loc][mod].copy_(time_loc_inputs[loc][mod], non_blocking=True)
+        dev = static[flat[0][0]][flat[0][1]].device
+        return self._step(key, lambda: StepSegments(self.model, self.loss_func, self.opt, lambda: augmenter.forward_random_pair(static), dev), load)
+
+    def _step(self, key, make_segments, load_inputs):
+        load_inputs()
         if self.replay is not None and key == self.key:
             self.opt.sync_lr()
             self.replay()
             self.replays += 1
             return self.loss
         self.eager_steps += 1
-        seg = self._segments(v1, v2)
+        seg = make_segments()
         seg.run()
         out = seg.loss
         if not self.enabled or self.replay is not None:
@@ -347,7 +369,7 @@ class CapturedTrainStep:
             # after its peers have finished: the final agreement below makes every rank either replay or stay eager.)
             ok = True
             try:
-                self._capture(v1, v2)
+                self._capture(make_segments)
             except Exception as e:  # noqa: BLE001 -- capture is an optimisation: stay eager, say so once
                 ok = False
                 logging.warning(f"hipGraph capture of the training step unavailable ({type(e).__name__}: {e}); running eagerly")
@@ -358,9 +380,9 @@ class CapturedTrainStep:
                 self.enabled, self.replay, self.segments = False, None, None
         return out
 
-    def _capture(self, v1, v2):
+    def _capture(self, make_segments):
         torch.cuda.synchronize()
-        seg = self._segments(v1, v2)
+        seg = make_segments()
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             replay = seg.capture(side)

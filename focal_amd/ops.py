@@ -153,8 +153,9 @@ def _factor(n):
     return n // best, best
 
 
-def _fft_problem(x, scale=1.0, flip=False, perm=None, phase=0.0, out=None):
-    """(descriptor, augmentation descriptor | None, x, twiddle table, out) of one transform."""
+def _fft_problem(x, scale=1.0, flip=False, perm=None, phase=0.0, out=None, plan=None, x_warped=None):
+    """(descriptor, augmentation descriptor | None, x, twiddle table, out) of one transform.  plan (a row of ops.view_draw's tensor) /
+    x_warped are bound by fft_realpack_multi."""
     _need_cuda(x)
     B, Cc, I, n = x.shape
     key = (n, x.device)
@@ -208,8 +209,98 @@ def fft_realpack_multi(items):
         if a is not None:
             arr[i].aug = a
         arr[i].x, arr[i].twiddle, arr[i].out = _p(x), _p(tw), _p(out)
+        plan = items[i].get("plan")
+        if plan is not None:  # the augmentation is read from the device record when the kernel runs (view draws inside the captured step)
+            _need_cuda(plan, items[i]["x_warped"])
+            arr[i].plan, arr[i].x_warped = _p(plan), _p(items[i]["x_warped"])
     check(_lib.load().focal_fft_realpack_multi(len(probs), arr, _stream()))
     return [p[4] for p in probs]
+
+
+# ---- view draws on the device (focal_view_draw / focal_warp_plan_multi: include/focal_hip.h)
+VIEW_KINDS = {"no": _lib.VIEW_NONE, "negation": _lib.VIEW_NEGATION, "scaling": _lib.VIEW_SCALING, "horizontal_flip": _lib.VIEW_HFLIP,
+              "permutation": _lib.VIEW_PERMUTATION, "phase_shift": _lib.VIEW_PHASE_SHIFT, "mag_warp": _lib.VIEW_MAG_WARP,
+              "time_warp": _lib.VIEW_TIME_WARP}
+VIEW_PLAN_BYTES = C.sizeof(_lib.ViewPlan)
+
+
+def view_pool(entries, intervals, scaling_std=0.2, mag_warp=(0.05, 4), time_warp=(0.2, 6)):
+    """entries: [(augmenter name, coin probability)] -- the pool ONE entry of which is drawn per view; intervals: per slot ((location,
+    modality) pair) the interval count a permutation shuffles; the two warps' (magnitude, spline ord)."""
+    if not 1 <= len(entries) <= _lib.VIEW_MAX_POOL or not 1 <= len(intervals) <= _lib.VIEW_MAX_SLOTS:
+        raise ValueError("view_pool: 1 .. 8 pool entries, 1 .. 8 slots")
+    pool = _lib.ViewPool()
+    pool.n_aug = len(entries)
+    for i, (name, prob) in enumerate(entries):
+        pool.kind[i], pool.prob[i] = VIEW_KINDS[name], float(prob)
+    pool.scaling_std = float(scaling_std)
+    pool.mag_magnitude, pool.mag_order = float(mag_warp[0]), int(mag_warp[1])
+    pool.time_magnitude, pool.time_order = float(time_warp[0]), int(time_warp[1])
+    for i, n in enumerate(intervals):
+        pool.intervals[i] = int(n)
+    return pool
+
+
+def new_view_plans(n_views, n_slots, device):
+    """uint8 [n_views * n_slots, sizeof(focal_view_plan)]: row v * n_slots + s is the plan of (view v, slot s)."""
+    return torch.zeros(n_views * n_slots, VIEW_PLAN_BYTES, dtype=torch.uint8, device=device)
+
+
+def view_draw(pool, n_views, n_slots, seed_state, stream_id, plans):
+    """The draws of n_views views over n_slots slots into `plans` (new_view_plans), keyed by seed_state[0] (the device seed word the
+    optimizer advances every step) and stream_id."""
+    _need_cuda(plans, seed_state)
+    assert plans.shape == (n_views * n_slots, VIEW_PLAN_BYTES) and plans.dtype == torch.uint8 and plans.is_contiguous()
+    check(_lib.load().focal_view_draw(C.byref(pool), n_views, n_slots, _p(seed_state), int(stream_id) & 0xFFFFFFFF, _p(plans), _stream()))
+    return plans
+
+
+def read_view_plans(plans):
+    """Host copies of the plan records (tests, diagnostics): a list of _lib.ViewPlan."""
+    raw = plans.cpu().numpy().tobytes()
+    return [_lib.ViewPlan.from_buffer_copy(raw[i * VIEW_PLAN_BYTES:(i + 1) * VIEW_PLAN_BYTES]) for i in range(plans.shape[0])]
+
+
+def write_view_plan(plans, index, scale=1.0, flip=False, perm=None, phase=0.0, warp=0, knots=None, kind=0):
+    """Force one plan record (tests: the reference fixtures' forced draws through the device-plan path)."""
+    pl = _lib.ViewPlan()
+    pl.aug.scale, pl.aug.flip, pl.aug.use_perm = float(scale), int(bool(flip)), int(perm is not None)
+    pl.aug.phase_cos, pl.aug.phase_sin = math.cos(phase), math.sin(phase)
+    for i in range(32):
+        pl.aug.perm[i] = int(perm[i]) if perm is not None and i < len(perm) else i
+    pl.kind, pl.warp = int(kind), int(warp)
+    if knots is not None:
+        pl.nknots = len(knots)
+        for i, v in enumerate(knots):
+            pl.knots[i] = float(v)
+    buf = torch.frombuffer(bytearray(bytes(pl)), dtype=torch.uint8)
+    plans[index].copy_(buf)
+
+
+_END_COEF = {}
+
+
+def warp_end_coefficients(device):
+    """Device fp32 [47][4][48]: the end-window basis splines of the time warp (focal_amd.warp.end_window_coefficients), once per device."""
+    key = torch.device(device)
+    if key not in _END_COEF:
+        from . import warp
+        _END_COEF[key] = torch.from_numpy(warp.end_window_coefficients()).to(device)
+    return _END_COEF[key]
+
+
+def warp_plan_multi(problems):
+    """problems: [dict(x=[B, C, I, S] fp32, plan=row of the plan tensor, tables=fp32 [2 * I * S] workspace, y=like x)]: the warps the
+    plans ask for (focal_warp_plan_multi: two launches whatever they ask)."""
+    arr = (_lib.WarpProblem * len(problems))()
+    for i, q in enumerate(problems):
+        x, y = q["x"], q["y"]
+        _need_cuda(x, y, q["plan"], q["tables"])
+        B, Cc, I, S = x.shape
+        assert y.shape == x.shape and x.is_contiguous() and y.is_contiguous() and q["tables"].numel() >= 2 * I * S
+        arr[i].rows, arr[i].L = B * Cc, I * S
+        arr[i].x, arr[i].plan, arr[i].tables, arr[i].y = _p(x), _p(q["plan"]), _p(q["tables"]), _p(y)
+    check(_lib.load().focal_warp_plan_multi(len(problems), arr, _p(warp_end_coefficients(problems[0]["x"].device)), _stream()))
 
 
 def mag_warp(x, mult):
@@ -425,20 +516,29 @@ def mlp_fwd(d, a, resid, w1, b1, w2, b2, y, next_ln=None, mask_bits=None):
     return y_ln, stats
 
 
-def mlp_bwd(d, gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, ln=None, mask_bits=None):
+def mlp_bwd_partials_floats(d):
+    return int(_lib.load().focal_mlp_bwd_partials_floats(C.byref(d)))
+
+
+def mlp_bwd_partials(d, device):
+    """The workspace focal_mlp_bwd sums its workgroups' weight-gradient images through (instead of fp32 atomics): fp32 [workgroups * 32768]."""
+    return torch.empty(int(_lib.load().focal_mlp_bwd_partials_floats(C.byref(d))), dtype=torch.float32, device=device)
+
+
+def mlp_bwd(d, gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, ln=None, mask_bits=None, partials=None):
     """focal_mlp_bwd.  mask_bits: what mlp_fwd filled (required when the descriptor has hidden dropout).  ln = dict(x=, stats=, gamma=,
     g=, gm_next=, next_mask=, dgamma=, dbeta=) fuses the backward of the LayerNorm that produced `a` (norm2) into the kernel: g += dLN,
     gm_next = dtype(g x next_mask), dgamma / dbeta accumulate, and `da` is neither needed nor written (pass None) -- what the Swin engine
-    always does."""
-    _need_cuda(gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, mask_bits)
+    always does.  partials (mlp_bwd_partials): the weight gradients leave through a workspace + a reduce launch instead of atomics."""
+    _need_cuda(gm, a, w1, b1, w2, da, dw1, db1, dw2, db2, mask_bits, partials)
     if ln is None:
         check(_lib.load().focal_mlp_bwd(C.byref(d), _p(gm), _p(a), _p(w1), _p(b1), _p(w2), _p(da), _p(dw1), _p(db1), _p(dw2), _p(db2),
-                                        None, None, None, None, None, None, None, None, _p(mask_bits), _stream()))
+                                        None, None, None, None, None, None, None, None, _p(mask_bits), _p(partials), _stream()))
         return
     mask = ln.get("next_mask") or NO_DROP
     check(_lib.load().focal_mlp_bwd(C.byref(d), _p(gm), _p(a), _p(w1), _p(b1), _p(w2), _p(da), _p(dw1), _p(db1), _p(dw2), _p(db2),
                                     _p(ln["x"]), _p(ln["stats"]), _p(ln["gamma"]), _p(ln["g"]), _p(ln.get("gm_next")), C.byref(mask),
-                                    _p(ln["dgamma"]), _p(ln["dbeta"]), _p(mask_bits), _stream()))
+                                    _p(ln["dgamma"]), _p(ln["dbeta"]), _p(mask_bits), _p(partials), _stream()))
 
 
 # ------------------------------------------------------------------------------------------------ row 10

@@ -3,8 +3,12 @@
 `forward("random", time_loc_inputs)` draws ONE augmenter from the configured pool per call, flips a coin per
 (location, modality) as the reference's augmenter classes do, and always ends with the time->frequency transform,
 which runs on the HIP DFT kernel.  The augmentation arithmetic (negation, scaling, horizontal flip, interval
-permutation, phase shift) is folded into that kernel (`focal_augment_fft_fwd`); only the random draws stay on the host,
-unseeded as in the reference.
+permutation, phase shift) is folded into that kernel (`focal_augment_fft_fwd`); in this form the random draws are made on the
+host, unseeded as in the reference.
+`forward_random_pair(time_loc_inputs)` (round 5) is what the training loop uses: BOTH views of a step with every draw made on the
+DEVICE (`focal_view_draw`: the augmenter of each view, the per-(location, modality) coins, scale factors, interval orders, phase
+angles, warp knots), the warp tables built on the device (`focal_warp_plan_multi`) and the transforms reading their augmentation
+from the drawn records -- launches of fixed shape, so the views are part of the captured step and a replay draws fresh ones.
 `time_warp` / `mag_warp` wrap tsai's random-spline transforms, whose source is not available in this build environment: they
 are restated from tsai's published algorithm in focal_amd/warp.py (the curve, drawn on the host like every other augmenter's
 randomness) and run as one device pass in front of the transform (focal_warp_fwd); see that module for the one documented
@@ -206,6 +210,65 @@ class Augmenter:
                 src = pre(x.contiguous()) if pre is not None else x.contiguous()
                 items[loc][mod] = dict(x=src, out=self._view_slot(loc, mod, x), **k)
         return _transform_all(items)
+
+    # ------------------------------------------------------------------------------------------ random views, drawn on the device
+    def device_draws_supported(self):
+        """The pool is made of augmenters focal_view_draw knows (every shipped `random_augmenters` pool is)."""
+        return all(n in ops.VIEW_KINDS for n in self.aug_names) and 1 <= len(self.aug_names) <= 8
+
+    def _device_state(self, inputs):
+        flat = [(loc, mod) for loc in inputs for mod in inputs[loc]]
+        key = tuple((loc, mod, tuple(inputs[loc][mod].shape), inputs[loc][mod].device) for loc, mod in flat)
+        st = self.__dict__.get("_dev_state")
+        if st is not None and st["key"] == key:
+            return st
+        cfg = self.args.dataset_config
+        pool = ops.view_pool([(n, cfg[n]["prob"] if n != "no" else 0.0) for n in self.aug_names],
+                             [inputs[loc][mod].shape[2] for loc, mod in flat],
+                             scaling_std=cfg.get("scaling", {}).get("std", 0.2),
+                             mag_warp=(cfg.get("mag_warp", {}).get("magnitude", 0.05), cfg.get("mag_warp", {}).get("order", 4)),
+                             time_warp=(cfg.get("time_warp", {}).get("magnitude", 0.2), cfg.get("time_warp", {}).get("order", 6)))
+        dev = inputs[flat[0][0]][flat[0][1]].device
+        n = len(flat)
+        warps = any(k in ("mag_warp", "time_warp") for k in self.aug_names)
+        st = {"key": key, "flat": flat, "pool": pool, "plans": ops.new_view_plans(2, n, dev), "warps": warps,
+              "both": {k: torch.empty((2 * inputs[k[0]][k[1]].shape[0], 2 * inputs[k[0]][k[1]].shape[1]) + tuple(inputs[k[0]][k[1]].shape[2:]),
+                                      dtype=torch.float32, device=dev) for k in flat},
+              # the warped copies and the tables of (view, slot): written only when the plan drew a warp
+              "warped": [{k: torch.empty_like(inputs[k[0]][k[1]], dtype=torch.float32) for k in flat} for _ in range(2)] if warps else None,
+              "tables": [{k: torch.empty(2 * inputs[k[0]][k[1]].shape[2] * inputs[k[0]][k[1]].shape[3], dtype=torch.float32, device=dev)
+                          for k in flat} for _ in range(2)] if warps else None}
+        self._dev_state = st
+        return st
+
+    def forward_random_pair(self, time_loc_inputs, stream_id=None):
+        """(view 1, view 2) of the same windows with every random draw made on the device (reference: two calls of forward("random"),
+        data_augmenter/Augmenter.py:76-113): one draw launch, two warp launches (they return at once unless a plan drew a warp), one
+        transform call for all (view, location, modality).  Inputs: fp32 [B, C, I, S] device tensors.  The two views of a modality are
+        the halves of one [2B, 2C, I, S] tensor, as forward("random") arranges them."""
+        from focal_amd import distributed, runtime
+        x = {loc: {mod: t.contiguous() for mod, t in mods.items()} for loc, mods in time_loc_inputs.items()}
+        st = self._device_state(x)
+        flat, n = st["flat"], len(st["flat"])
+        dev = x[flat[0][0]][flat[0][1]].device
+        if stream_id is None:
+            stream_id = 0x56494557 + 977 * distributed.rank()   # ("VIEW"; every data-parallel rank draws its own views)
+        ops.view_draw(st["pool"], 2, n, runtime.rng_state(dev), stream_id, st["plans"])
+        if st["warps"]:
+            ops.warp_plan_multi([dict(x=x[l][m], plan=st["plans"][v * n + i], tables=st["tables"][v][(l, m)], y=st["warped"][v][(l, m)])
+                                 for v in range(2) for i, (l, m) in enumerate(flat)])
+        items = []
+        for v in range(2):
+            for i, (l, m) in enumerate(flat):
+                B = x[l][m].shape[0]
+                items.append(dict(x=x[l][m], plan=st["plans"][v * n + i], x_warped=st["warped"][v][(l, m)] if st["warps"] else x[l][m],
+                                  out=st["both"][(l, m)][v * B:(v + 1) * B]))
+        outs = ops.fft_realpack_multi(items)
+        views = ({loc: {} for loc in x}, {loc: {} for loc in x})
+        for v in range(2):
+            for i, (l, m) in enumerate(flat):
+                views[v][l][m] = outs[v * n + i]
+        return views
 
     def begin_step(self):
         """Called by the training loop before the first of a step's two draws (static_views): the next draw of every tensor gets the FIRST

@@ -19,6 +19,7 @@ def parse_base_args(option="train"):
     p.add_argument("-synthetic_batches", type=int, default=8, help="[build extension] batches per synthetic epoch.")
     p.add_argument("-resume", action="store_true", help="[build extension] continue from the latest weights + optimizer state.")
     p.add_argument("-no_graph", action="store_true", help="[build extension] launch every kernel eagerly instead of replaying the captured step.")
+    p.add_argument("-host_draws", action="store_true", help="[build extension] draw the random views on the host (the reference's form) instead of on the device inside the step.")
     p.add_argument("-init_weight", type=str, default=None, help="[build extension] backbone state dict to start pretraining from.")
     p.add_argument("-config", type=str, default=None, help="[build extension] dataset YAML to use instead of ./data/{dataset}.yaml.")
     p.add_argument("-sync_bn", action="store_true", help="[build extension] DeepSense under torchrun: cross-rank BatchNorm statistics.")

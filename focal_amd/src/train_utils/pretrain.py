@@ -64,6 +64,11 @@ def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, 
     # shapes have repeated; the views themselves are drawn eagerly every step (focal_amd/graph_step.py)
     graphed = CapturedTrainStep(default_model, loss_func, optimizer, enabled=not getattr(args, "no_graph", False))
     augmenter.static_views = graphed.enabled
+    # Round 5: the two random views of a step are drawn ON THE DEVICE, inside the step (Augmenter.forward_random_pair: the reference's
+    # `augmenter.forward("random", x)` x 2, loss_calc_utils.py:4-5) -- no host draw, no upload, nothing eager between two replays but
+    # the copy of the batch into the step's input buffers.  -host_draws (FOCAL_HOST_DRAWS=1) keeps the host-drawn form.
+    device_draws = augmenter.device_draws_supported() and not getattr(args, "host_draws", False) and os.environ.get("FOCAL_HOST_DRAWS") != "1"
+    logging.info(f"random views: drawn on the {'device, inside the step' if device_draws else 'host'}")
     for epoch in range(start_epoch, epochs):
         default_model.train()
         for owner in (train_dataloader, getattr(train_dataloader, "batch_sampler", None)):
@@ -79,12 +84,17 @@ def pretrain(args, backbone_model, augmenter, train_dataloader, val_dataloader, 
             # (the batch crosses to the device once; both draws then see the same device tensors, which is also what pairs the two
             # views of a modality into the halves of one tensor, data_augmenter/Augmenter.py::_view_slot)
             time_loc_inputs, _ = augmenter.move_to_target_device(time_loc_inputs, None)
-            augmenter.begin_step()  # view 1 -> first half, view 2 -> second half of the static two-view buffers, whatever came before
-            view1 = augmenter.forward("random", time_loc_inputs)
-            view2 = augmenter.forward("random", time_loc_inputs)
-            if pending is not None:
-                train_loss_list.append(pending.item())
-            pending = graphed(view1, view2)
+            if device_draws:
+                if pending is not None:
+                    train_loss_list.append(pending.item())
+                pending = graphed.step_from_inputs(augmenter, time_loc_inputs)
+            else:
+                augmenter.begin_step()  # view 1 -> first half, view 2 -> second half of the static two-view buffers, whatever came before
+                view1 = augmenter.forward("random", time_loc_inputs)
+                view2 = augmenter.forward("random", time_loc_inputs)
+                if pending is not None:
+                    train_loss_list.append(pending.item())
+                pending = graphed(view1, view2)
             n = next(iter(next(iter(time_loc_inputs.values())).values())).shape[0] * fdist.world()
             windows += n
             epoch_windows += n

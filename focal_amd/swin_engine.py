@@ -174,6 +174,17 @@ class SwinModEncoder:
         saved.update(x_final=x, d_in=d_in, pin=pin)
         return feat, saved
 
+    def _mlp_partials(self, d_mlp, dev):
+        """Workspace of the fused MLP backward's weight-gradient flush (one per encoder: its blocks run one after the other on the
+        encoder's stream); FOCAL_MLP_BWD_ATOMICS=1 keeps the round-4 atomic flush (same-box A/B)."""
+        if os.environ.get("FOCAL_MLP_BWD_ATOMICS") == "1":
+            return None
+        ws = self.__dict__.get("_mlp_ws")
+        n = ops.mlp_bwd_partials_floats(d_mlp)
+        if ws is None or ws.numel() < n or ws.device != dev:
+            ws = self._mlp_ws = torch.empty(n, dtype=torch.float32, device=dev)
+        return ws
+
     def backward(self, saved, dfeat):
         """Accumulates every parameter gradient of this encoder into the arena; returns nothing (input is a leaf).
 
@@ -281,7 +292,7 @@ class SwinModEncoder:
                 ln2_in_mlp = True
                 ops.mlp_bwd(s["d_mlp"], gm, s["a2"], ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
                             ar.operand(f"{pb}.mlp.fc2.weight"), None, ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"),
-                            ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"), mask_bits=s["mlp_bits"],
+                            ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"), mask_bits=s["mlp_bits"], partials=self._mlp_partials(s["d_mlp"], dev),
                             ln=dict(x=s["x_mid"], stats=s["st2"], gamma=ar.master(f"{pb}.norm2.weight"), g=g, gm_next=gm,
                                     next_mask=s["d_proj"].out_drop, dgamma=ar.g(f"{pb}.norm2.weight"), dbeta=ar.g(f"{pb}.norm2.bias")))
             else:

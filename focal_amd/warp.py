@@ -104,6 +104,11 @@ def _end_window_spline():
     return _CACHE["end"]
 
 
+def end_window_coefficients():
+    """fp32 [47 segments][4 powers][48 basis splines]: the table focal_warp_plan_multi evaluates the end windows from on the device."""
+    return np.ascontiguousarray(_end_window_spline().astype(np.float32))
+
+
 def _end_weights(q):
     """[len(q), 48] basis weights of the end-window spline at positions q in [0, 47]."""
     coef = _end_window_spline()

@@ -95,8 +95,53 @@ int focal_augment_fft_fwd(const focal_fft_desc* d, const focal_aug_desc* a, cons
  * (n <= 64 samples as a direct DFT, n2 == 1: the 20-sample sensor modalities) share one launch -- a thread per output bin, 256 / n
  * rows per workgroup pass, a problem table in the kernel arguments, up to 8 problems per launch -- the others are launched as by
  * focal_fft_realpack_fwd / focal_augment_fft_fwd.  Results are those of the single calls. */
-typedef struct { focal_fft_desc d; int has_aug; focal_aug_desc aug; const float* x; const float* twiddle; float* out; } focal_fft_problem;
+typedef struct focal_view_plan focal_view_plan;
+/* plan (round 5) non-NULL: the augmentation of this transform is read from that DEVICE record when the kernel runs (focal_view_draw
+ * fills it inside the same captured step) instead of from `aug`; when the record says the view is warped, rows come from x_warped. */
+typedef struct { focal_fft_desc d; int has_aug; focal_aug_desc aug; const float* x; const float* twiddle; float* out;
+                 const focal_view_plan* plan; const float* x_warped; } focal_fft_problem;
 int focal_fft_realpack_multi(int n, const focal_fft_problem* problems, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ view draws on the device (round 5)
+ * The reference draws a view's augmentation in Python before every forward (data_augmenter/Augmenter.py:76-113 forward_random: ONE
+ * augmenter of the pool per call, np.random.randint; each augmenter class then flips its coin per (location, modality), random() < p, and
+ * draws its own parameters: ScalingAugmenter.py:35-36 N(1, std), PermutationAugmenter.py:35-36 torch.randperm(intervals),
+ * PhaseShiftAugmenter.py:39-54 an angle in (-pi, pi), tsai's random-curve knots N(1, magnitude) for the two warps).  focal_view_draw
+ * makes exactly these draws on the device from a counter RNG keyed by (seed word, stream id, view, slot) -- the seed word is the one the
+ * optimizer advances every step -- and writes one focal_view_plan per (view, slot); slot = a (location, modality) pair.  Nothing of a
+ * random view is left on the host: the draw, the warp tables (focal_warp_plan_fwd) and the transform (focal_fft_realpack_multi with
+ * `plan`) are launches of fixed shape, so the whole view generation sits inside the captured step. */
+#define FOCAL_VIEW_MAX_KNOTS 16
+#define FOCAL_VIEW_MAX_POOL 8
+#define FOCAL_VIEW_MAX_SLOTS 8
+enum { FOCAL_VIEW_NONE = 0, FOCAL_VIEW_NEGATION = 1, FOCAL_VIEW_SCALING = 2, FOCAL_VIEW_HFLIP = 3, FOCAL_VIEW_PERMUTATION = 4,
+       FOCAL_VIEW_PHASE_SHIFT = 5, FOCAL_VIEW_MAG_WARP = 6, FOCAL_VIEW_TIME_WARP = 7 };
+struct focal_view_plan {
+  focal_aug_desc aug;                  /* what the transform applies: the identity when the coin flip missed */
+  int kind;                            /* the augmenter drawn for this (view, slot): FOCAL_VIEW_*, 0 = the coin flip missed */
+  int pool_index;                      /* which pool entry the view drew (the same for all its slots) */
+  int warp;                            /* 0, FOCAL_VIEW_MAG_WARP or FOCAL_VIEW_TIME_WARP: the transform reads the warped copy */
+  int nknots;                          /* 3 (ord - 1) + 1 */
+  float knots[FOCAL_VIEW_MAX_KNOTS];   /* the warp's random-curve ordinates */
+};
+typedef struct {
+  int n_aug;                                                   /* pool size: one entry is drawn per view, uniformly */
+  int kind[FOCAL_VIEW_MAX_POOL]; float prob[FOCAL_VIEW_MAX_POOL]; /* FOCAL_VIEW_* and the per-slot coin of each entry */
+  float scaling_std, mag_magnitude, time_magnitude;
+  int mag_order, time_order;                                   /* spline `ord` of the warps (tsai defaults 4 / 6) */
+  int intervals[FOCAL_VIEW_MAX_SLOTS];                         /* per slot: the interval count the permutation shuffles */
+} focal_view_pool;
+/* plans: device [n_views][n_slots].  seed: the device seed word (NULL = 0); stream_id separates this draw from the dropout streams. */
+int focal_view_draw(const focal_view_pool* pool, int n_views, int n_slots, const uint32_t* seed, uint32_t stream_id, focal_view_plan* plans,
+                    void* stream);
+/* The warps of up to 8 (view, slot) pairs whose plans may ask for one, as TWO launches (the tables of all of them, then the passes over
+ * their windows); a problem whose plan says "no warp" costs nothing and leaves its y unwritten.  Per problem: the random curve through the
+ * plan's knots and, for the time warp, its cumulative positions (one workgroup per problem; focal_amd/warp.py is the host statement of the
+ * same arithmetic), then x [rows][L] -> y with the 24 resampling weights of focal_warp_fwd's tables formed per position by the pass.  end_coef: device fp32 [47][4][48], the
+ * not-a-knot basis splines of a 48-sample end window (focal_amd.warp.end_window_coefficients(), a constant of the method); tables:
+ * device workspace of 2 L floats per problem (multipliers, or floor | fraction of the positions), 16-byte aligned. */
+typedef struct { int rows, L; const float* x; const focal_view_plan* plan; float* tables; float* y; } focal_warp_problem;
+int focal_warp_plan_multi(int n, const focal_warp_problem* problems, const float* end_coef, void* stream);
 
 /* TimeWarp / MagWarp (data_augmenter/TimeWarpAugmenter.py:18,44, MagWarpAugmenter.py:18,44 -> tsai 0.3.7 TSTimeWarp / TSMagWarp;
  * SURVEY 8f rank 1): one smooth random curve per call over the flattened (I*S) axis of [B, C, I, S], shared by batch and channels;
@@ -251,7 +296,11 @@ int focal_mlp_fwd(const focal_mlp_desc* d, const void* a, const float* resid, co
 int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void* a, const void* w1, const float* b1, const void* w2,
                   void* da, float* dw1, float* db1, float* dw2, float* db2,
                   const float* ln_x, const float* ln_stats, const float* ln_gamma, float* g, void* gm_next,
-                  const focal_drop_desc* next_mask, float* dgamma, float* dbeta, const uint32_t* mask_bits, void* stream);
+                  const focal_drop_desc* next_mask, float* dgamma, float* dbeta, const uint32_t* mask_bits, float* dw_partials, void* stream);
+/* dw_partials (round 5; NULL = every workgroup adds its 128 KB of weight gradients with fp32 atomics, 33.5 MB per launch at the memory
+ * side's 1.3 TB/s): a device workspace of focal_mlp_bwd_partials_floats(d) floats, 16-byte aligned -- the workgroups store their images
+ * there with plain stores and a second, small launch on the same stream sums them into dw1 / dw2. */
+long focal_mlp_bwd_partials_floats(const focal_mlp_desc* d);
 
 /* ------------------------------------------------------------------------------------------------ row 10: W-MSA
  * WindowAttention between its qkv and proj Linears (models/SwinModules.py:121-152) with the cyclic shift, window

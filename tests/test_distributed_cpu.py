@@ -190,7 +190,7 @@ def _capture_agreement_worker(rank, world, port, out):
         step = graph_step.CapturedTrainStep(None, None, None, warm_steps=1)
         step._segments = lambda v1, v2: Seg()
 
-        def capture(v1, v2, step=step, failing=failing):
+        def capture(make_segments, step=step, failing=failing):
             if rank == failing:
                 raise RuntimeError("out of memory between two segments")
             step.replay, step.loss = (lambda: None), Seg.loss

@@ -1041,6 +1041,167 @@ def test_product_augmenter_random_views_follow_the_oracle(ops, cfg, monkeypatch)
     assert {"scale", "flip", "perm", "phase"} <= seen  # 64 seeded draws from a 7-entry pool at p = 0.5 each: all four kinds appear
 
 
+# ---- round 5: the random views drawn on the device, inside the step (focal_view_draw / focal_warp_plan_multi / the transform's `plan`)
+FOCAL_POOL = [("permutation", 0.5), ("negation", 0.5), ("time_warp", 0.5), ("horizontal_flip", 0.5), ("mag_warp", 0.5), ("scaling", 0.5),
+              ("phase_shift", 0.5)]
+
+
+def test_device_view_draws_have_the_reference_distributions(ops):
+    """focal_view_draw over 6000 seed words, the shipped FOCAL pool: the augmenter of a view is uniform over the pool and shared by the
+    view's slots (Augmenter.py:86), a slot's coin hits with p = 0.5 independently of the other slot (each augmenter class's random() <
+    prob), the scale factors are N(1, 0.2) (ScalingAugmenter.py:35-36), the phase angles uniform on (-pi, pi) (PhaseShiftAugmenter.py:
+    39-54), the interval orders uniform permutations (torch.randperm), the warp knots N(1, magnitude) with tsai's knot counts; the two
+    views of a step and consecutive seeds are uncorrelated; the same seed gives the same plans."""
+    import numpy as np
+    from focal_amd import _lib
+    pool = ops.view_pool(FOCAL_POOL, [10, 10])
+    n_views, n_slots, N = 2, 2, 6000
+    seed = ops.new_rng_state(1, DEV)
+    plans = ops.new_view_plans(n_views, n_slots, DEV)
+    recs = []
+    for i in range(N):
+        seed[0] = 7919 * i + 13
+        ops.view_draw(pool, n_views, n_slots, seed, 0x56494557, plans)
+        recs.append(ops.read_view_plans(plans))
+    again = ops.read_view_plans(ops.view_draw(pool, n_views, n_slots, seed, 0x56494557, ops.new_view_plans(n_views, n_slots, DEV)))
+    assert all(bytes(a) == bytes(b) for a, b in zip(again, recs[-1]))                       # a pure function of (seed, stream, view, slot)
+    other = ops.read_view_plans(ops.view_draw(pool, n_views, n_slots, seed, 0x56494557 + 977, ops.new_view_plans(n_views, n_slots, DEV)))
+    assert any(bytes(a) != bytes(b) for a, b in zip(other, recs[-1]))                       # another rank's stream draws differently
+    k = np.array([[r[v * n_slots].pool_index for v in range(n_views)] for r in recs])       # [N, views]
+    for r in recs:
+        assert all(r[v * n_slots + s].pool_index == r[v * n_slots].pool_index for v in range(n_views) for s in range(n_slots))
+    freq = np.bincount(k.ravel(), minlength=7) / k.size
+    assert np.abs(freq - 1 / 7).max() < 0.012, freq                                         # (sigma = 0.0032 at 12 000 draws)
+    assert abs(np.corrcoef(k[:, 0], k[:, 1])[0, 1]) < 0.04 and abs(np.corrcoef(k[:-1, 0], k[1:, 0])[0, 1]) < 0.04
+    hit = np.array([[int(r[v * n_slots + s].kind != 0) for s in range(n_slots)] for r in recs for v in range(n_views)])
+    assert np.abs(hit.mean(0) - 0.5).max() < 0.015 and abs(np.corrcoef(hit[:, 0], hit[:, 1])[0, 1]) < 0.03
+    flat = [p for r in recs for p in r]
+    kinds = {name: ops.VIEW_KINDS[name] for name, _ in FOCAL_POOL}
+    for p in flat:   # the record applies exactly what was drawn, the identity otherwise
+        ident = p.aug.scale == 1.0 and p.aug.flip == 0 and p.aug.use_perm == 0 and p.aug.phase_cos == 1.0 and p.aug.phase_sin == 0.0 and p.warp == 0
+        assert (p.kind == 0) == ident or p.kind in (kinds["scaling"], kinds["phase_shift"])   # (a drawn factor / angle may be the identity by chance)
+    sc = np.array([p.aug.scale for p in flat if p.kind == kinds["scaling"]])
+    assert len(sc) > 1200 and abs(sc.mean() - 1.0) < 0.02 and abs(sc.std() - 0.2) < 0.015
+    assert all(p.aug.scale == -1.0 for p in flat if p.kind == kinds["negation"]) and all(p.aug.flip == 1 for p in flat if p.kind == kinds["horizontal_flip"])
+    ang = np.array([math.atan2(p.aug.phase_sin, p.aug.phase_cos) for p in flat if p.kind == kinds["phase_shift"]])
+    assert len(ang) > 1200 and abs(ang.mean()) < 0.15 and abs(ang.std() - math.pi / math.sqrt(3)) < 0.08
+    assert np.abs(np.histogram(ang, bins=8, range=(-math.pi, math.pi))[0] / len(ang) - 0.125).max() < 0.035
+    perms = np.array([[p.aug.perm[i] for i in range(10)] for p in flat if p.kind == kinds["permutation"]])
+    assert len(perms) > 1200 and all(sorted(row) == list(range(10)) for row in perms[:200])
+    pos = np.stack([(perms == v).mean(0) for v in range(10)])                                # P(value v at position i) = 1 / 10
+    assert np.abs(pos - 0.1).max() < 0.035, pos
+    for name, nk, mag in (("mag_warp", 10, 0.05), ("time_warp", 16, 0.2)):
+        kn = np.array([[p.knots[i] for i in range(nk)] for p in flat if p.kind == kinds[name]])
+        assert len(kn) > 1200 and all(p.nknots == nk and p.warp == kinds[name] for p in flat if p.kind == kinds[name])
+        assert abs(kn.mean() - 1.0) < 0.01 and abs(kn.std() - mag) < 0.04 * mag + 0.002
+        assert abs(np.corrcoef(kn[:, 0], kn[:, 1])[0, 1]) < 0.08
+
+
+@pytest.mark.parametrize("name", ["negation", "scaling", "horizontal_flip", "permutation", "phase_shift"])
+def test_forced_device_plans_match_the_reference_augmenters(ops, name):
+    """The transform reading its augmentation from a DEVICE plan record (what the captured step does) reproduces the reference augmenter
+    classes' outputs for their forced draws: tests/golden/augment_b2_seed77.npz, the fixture of test_augmentation_folded_into_dft."""
+    import numpy as np
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "augment_b2_seed77.npz"))
+    kw = {"negation": dict(scale=-1.0), "scaling": dict(scale=float(fx["draw.scaling"])), "horizontal_flip": dict(flip=True),
+          "permutation": dict(perm=[int(v) for v in fx["draw.permutation"]]), "phase_shift": dict(phase=float(fx["draw.phase_shift"]))}[name]
+    keys = [k[3:] for k in fx.files if k.startswith("in.")]
+    plans = ops.new_view_plans(1, len(keys), DEV)
+    items = []
+    for i, k in enumerate(keys):
+        ops.write_view_plan(plans, i, **kw)
+        x = torch.from_numpy(fx[f"in.{k}"]).to(DEV)
+        items.append(dict(x=x, plan=plans[i], x_warped=x))
+    outs = ops.fft_realpack_multi(items)    # (the long rows on the MFMA kernel, the 20-sample rows in the shared small-row launch)
+    for k, out in zip(keys, outs):
+        ref = torch.from_numpy(fx[f"{name}.{k}"]).to(DEV)
+        assert (out.double() - ref.double()).abs().max().item() < 2e-4 * math.sqrt(out.shape[-1]) * max(1.0, abs(kw.get("scale", 1.0))), (name, k)
+        host = ops.fft_realpack(items[keys.index(k)]["x"], **kw)
+        assert torch.equal(out, host), (name, k)   # the same kernels, the same values: only where they read them from differs
+
+
+@pytest.mark.parametrize("I,S,C", [(10, 1600, 1), (10, 20, 2)])
+def test_device_built_warp_tables_match_the_host_statement(ops, I, S, C):
+    """focal_warp_plan_multi: the curve and the cumulative positions built ON THE DEVICE from a plan's knots equal focal_amd/warp.py's
+    for the same knots (the host statement test_spline_warps_on_device_match_the_oracle pins against the oracle), and the warped rows --
+    the pass forms the 24 weights of a position itself -- equal the oracle's; a plan without a warp leaves y alone."""
+    import numpy as np
+    from focal_amd import _lib, warp
+    from oracle import augment
+    x = rnd(8, C, I, S, seed=61)
+    L = I * S
+    plans = ops.new_view_plans(1, 3, DEV)
+    kn_m = warp.draw_knots(4, 0.05, np.random.RandomState(2)).astype(np.float32)
+    kn_t = warp.draw_knots(6, 0.2, np.random.RandomState(3)).astype(np.float32)
+    ops.write_view_plan(plans, 0, warp=_lib.VIEW_MAG_WARP, knots=kn_m, kind=_lib.VIEW_MAG_WARP)
+    ops.write_view_plan(plans, 1, warp=_lib.VIEW_TIME_WARP, knots=kn_t, kind=_lib.VIEW_TIME_WARP)
+    ops.write_view_plan(plans, 2)
+    tabs = [torch.zeros(2 * L, device=DEV) for _ in range(3)]
+    ys = [torch.full_like(x, 7.0) for _ in range(3)]
+    ops.warp_plan_multi([dict(x=x, plan=plans[i], tables=tabs[i], y=ys[i]) for i in range(3)])
+    mult = warp.random_curve(L, kn_m.astype(np.float64), 4)
+    assert np.abs(tabs[0][:L].cpu().numpy() - mult).max() < 2e-6
+    pos = warp.warp_positions(L, kn_t.astype(np.float64), 6)
+    pos_dev = tabs[1][:L].view(torch.int32).cpu().numpy().astype(np.float64) + tabs[1][L:].cpu().numpy().astype(np.float64)
+    assert np.abs(pos_dev - pos).max() < 1e-6 * L, np.abs(pos_dev - pos).max()   # (fp64 on both sides; the fraction travels as fp32)
+    assert pos_dev[0] == 0.0 and abs(pos_dev[-1] - (L - 1)) < 1e-9
+    ref_m, ref_t = augment.mag_warp(x.cpu(), kn_m.astype(np.float64), 4), augment.time_warp(x.cpu(), kn_t.astype(np.float64), 6)
+    assert (ys[0].cpu() - ref_m).abs().max().item() < 1e-5 * ref_m.abs().max().item()
+    assert (ys[1].cpu() - ref_t).abs().max().item() < 5e-5 * ref_t.abs().max().item()
+    assert torch.all(ys[2] == 7.0)                      # no warp drawn: nothing written
+    # and the transform follows the plan's source choice: warped rows for plans 0 / 1, the plain rows for plan 2
+    outs = ops.fft_realpack_multi([dict(x=x, plan=plans[i], x_warped=ys[i]) for i in range(3)])
+    assert torch.equal(outs[0], ops.fft_realpack(ys[0])) and torch.equal(outs[1], ops.fft_realpack(ys[1])) and torch.equal(outs[2], ops.fft_realpack(x))
+
+
+def test_product_augmenter_device_pair_follows_the_oracle(ops, cfg):
+    """Augmenter.forward_random_pair (what train.py's step runs, captured): whatever the device drew, each view is the oracle's view for
+    that draw; both views land in the halves of one tensor; over 40 seeds all seven augmenters of the FOCAL pool and the identity occur."""
+    import numpy as np
+    from conftest import make_args
+    from data_augmenter import Augmenter as A
+    from focal_amd import _lib, runtime
+    from oracle import augment as oa
+    args = make_args(cfg, "SW_Transformer", torch.device(DEV), "bf16")
+    aug = A.Augmenter(args)
+    assert aug.device_draws_supported()
+    tx = {"shake": {"audio": torch.randn(2, 1, 10, 1600).to(DEV), "seismic": torch.randn(2, 1, 10, 20).to(DEV)}}
+    seed = runtime.rng_state(torch.device(DEV))
+    saved = seed.clone()
+    seen = set()
+    try:
+        for it in range(40):
+            seed[0] = 1000 + 17 * it
+            v = aug.forward_random_pair(tx)
+            plans = ops.read_view_plans(aug._dev_state["plans"])
+            for view in range(2):
+                for i, m in enumerate(("audio", "seismic")):
+                    p = plans[view * 2 + i]
+                    seen.add(p.kind)
+                    ref = tx["shake"][m].cpu()
+                    if p.warp == _lib.VIEW_MAG_WARP:
+                        ref = oa.mag_warp(ref, np.array([p.knots[j] for j in range(p.nknots)], np.float64), 4)
+                    elif p.warp == _lib.VIEW_TIME_WARP:
+                        ref = oa.time_warp(ref, np.array([p.knots[j] for j in range(p.nknots)], np.float64), 6)
+                    if p.aug.scale != 1.0:
+                        ref = oa.scaling(ref, p.aug.scale)
+                    if p.aug.flip:
+                        ref = oa.horizontal_flip(ref)
+                    if p.aug.use_perm:
+                        ref = oa.permutation(ref, [p.aug.perm[j] for j in range(10)])
+                    f = oa.fft_realpack(ref)
+                    if p.kind == _lib.VIEW_PHASE_SHIFT:
+                        f = oa.phase_shift(f, math.atan2(p.aug.phase_sin, p.aug.phase_cos))
+                    got = v[view]["shake"][m]
+                    assert got.shape[0] == 2 and (got.cpu() - f).abs().max().item() < 2e-4 * math.sqrt(got.shape[-1]) * 2 + 1e-4 * f.abs().max().item(), (it, view, m, p.kind)
+            both = aug._dev_state["both"][("shake", "audio")]
+            assert v[0]["shake"]["audio"].data_ptr() == both.data_ptr() and v[1]["shake"]["audio"].data_ptr() == both[2:].data_ptr()
+    finally:
+        seed.copy_(saved)
+    assert seen == set(range(8)), seen
+
+
 def test_gpu_knn_matches_sklearn(ops):
     """train_utils.knn.GpuKNNClassifier (distances from the fp32 MFMA GEMM, top-5, majority vote, ties to the smallest label)
     against sklearn.neighbors.KNeighborsClassifier() -- the estimator the reference fits (train_utils/knn.py:38-40)."""

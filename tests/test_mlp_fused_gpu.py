@@ -229,6 +229,17 @@ def test_fused_mlp_backward_with_norm2_backward_folded_in(ops, M, p_drop):
     ops.mlp_bwd(d, gm_io, a2, w1, b1, w2, None, ew1, eb1, ew2, eb2, mask_bits=bits,
                 ln=dict(x=x_mid, stats=stats, gamma=gamma, g=g_one, gm_next=gm_io, next_mask=next_mask, dgamma=eg, dbeta=ebt))
     assert rel_err(ew1, dw1) < 1e-5 and rel_err(ew2, dw2) < 1e-5 and rel_err(eb1, db1) < 1e-5 and rel_err(eb2, db2) < 1e-5
+    # round 5: the weight gradients through the workspace + reduce launch instead of 33 MB of atomics (what the engine does), accumulating
+    # into buffers that already hold a gradient: the same sums
+    pw1, pb1, pw2, pb2, pg_, pbt = grads()
+    pw1.fill_(0.25), pw2.fill_(-0.5)
+    ws = ops.mlp_bwd_partials(d, DEV)
+    assert ws.numel() == min((M + 127) // 128, 256) * 2 * C * H
+    g_p, gm_p = g0.clone(), gm.clone()
+    ops.mlp_bwd(d, gm_p, a2, w1, b1, w2, None, pw1, pb1, pw2, pb2, mask_bits=bits, partials=ws,
+                ln=dict(x=x_mid, stats=stats, gamma=gamma, g=g_p, gm_next=gm_p, next_mask=next_mask, dgamma=pg_, dbeta=pbt))
+    assert rel_err(pw1 - 0.25, ew1) < 1e-5 and rel_err(pw2 + 0.5, ew2) < 1e-5 and rel_err(pb1, eb1) < 1e-5 and rel_err(pb2, eb2) < 1e-5
+    assert torch.equal(g_p, g_one) and torch.equal(gm_p, gm_io)
     assert rel_err(g_one - g0, g_ref - g0) < 6e-3            # (the two-launch form rounds dL/da2 to bf16 on the way)
     assert rel_err(eg, dg) < 4e-3 and rel_err(ebt, dbt) < 4e-3
     same_mask = ((gm_io.float() == 0) == (gmn_ref.float() == 0)) | (g_ref.abs() < 1e-3)

@@ -98,9 +98,10 @@ def test_finetune_stage_runs_on_pretrained_weights(model):
 
 
 def test_train_py_sustains_the_benchmarked_step():
-    """`train.py` replays the captured step (focal_amd/graph_step.py) with real `Augmenter.forward("random")` views drawn eagerly
-    every step: its steady-state windows/s (last epoch, logged by train_utils/pretrain.py) must be within 10 % of what bench.py
-    measures on the same box with the batch handed over from the host (`--from-host`)."""
+    """`train.py` replays the captured step (focal_amd/graph_step.py) with the two random views of every step drawn on the device
+    INSIDE the replayed graph (round 5: Augmenter.forward_random_pair): its steady-state windows/s (last epoch, logged by
+    train_utils/pretrain.py) must be within 5 % of what bench.py measures on the same box with the batch handed over from the host
+    (`--from-host`; fixed views) -- the observed ratio is recorded (`train_py.over_bench_from_host`)."""
     import json
     import re
     src = os.path.join(ROOT, "focal_amd", "src")
@@ -118,4 +119,5 @@ def test_train_py_sustains_the_benchmarked_step():
     from conftest import record_observed
     record_observed("train_py.windows_per_s", rates[-1])
     record_observed("train_py.over_bench_from_host", rates[-1] / bench)
-    assert rates[-1] >= 0.9 * bench, (rates, bench)
+    assert "drawn on the device" in log, log[-1500:]
+    assert rates[-1] >= 0.95 * bench, (rates, bench)

@@ -54,3 +54,35 @@ for name,h in (('mix32',mix32),('mad24',fast2)):
 # sequential-index 16-bit halves: birthday-ish duplicate count
 v=fast2(np.arange(4_000_000,dtype=np.uint64)^np.uint64(0x1234567)); print('distinct outputs of 4M sequential inputs:',len(np.unique(v)))
 v=mix32(np.arange(4_000_000,dtype=np.uint64)^np.uint64(0x1234567)); print('mix32:',len(np.unique(v)))
+
+
+def quad_stream_report():
+    """Round 5: MaskEval::elem_mult_quad (gemm.hpp) -- four keep / drop decisions from one focal_hash24 word and a three-instruction
+    second word.  Rates, pairwise correlations of the four decisions and lag-1 / lag-256 correlations over 4 M quads at p = 0.1 / 0.2 / 0.5."""
+    import numpy as np
+
+    def hash24(x):
+        x = x.astype(np.uint32)
+        h = x ^ (x >> np.uint32(16))
+        h = ((h & np.uint32(0xFFFFFF)).astype(np.uint64) * np.uint64(0xE35A2B)).astype(np.uint32) + x
+        h ^= h >> np.uint32(15)
+        h = ((h & np.uint32(0xFFFFFF)).astype(np.uint64) * np.uint64(0xB5297B)).astype(np.uint32)
+        return h ^ (h >> np.uint32(16))
+
+    def second(h):
+        g = h ^ (h >> np.uint32(13))
+        g = ((g & np.uint32(0xFFFFFF)).astype(np.uint64) * np.uint64(0xC2B2AF)).astype(np.uint32) + np.uint32(0x165667B1)
+        return g ^ (g >> np.uint32(15))
+    idx = np.arange(1 << 22, dtype=np.uint32)
+    for p in (0.1, 0.2, 0.5):
+        t16 = np.uint32(int(p * 16777216) >> 8)
+        h = hash24(idx ^ np.uint32(0x9E3779B9))
+        g = second(h)
+        d = np.stack([(h & 0xffff) < t16, (h >> 16) < t16, (g & 0xffff) < t16, (g >> 16) < t16]).astype(np.float64)
+        print(f"quad stream p = {p}: rates {d.mean(1).round(4)}, pairwise corr {np.corrcoef(d)[np.triu_indices(4, 1)].round(4)}")
+        for lag in (1, 256):
+            print(f"   lag {lag}: {[round(float(np.corrcoef(d[i][:-lag], d[i][lag:])[0, 1]), 4) for i in range(4)]}")
+
+
+if __name__ == "__main__" and "--quad" in __import__("sys").argv:
+    quad_stream_report()
