@@ -15,7 +15,7 @@ EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
 BN_STAT_SLOTS = 16      # focal_conv_fwd_bn: column sums are spread over this many slots of the scratch
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class DropDesc(C.Structure):
@@ -108,7 +108,7 @@ class ConvDesc(C.Structure):
 class BNDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("rows", C.c_int), ("C", C.c_int), ("rows_per_sample", C.c_int), ("eps", C.c_float),
                 ("momentum", C.c_float), ("p_drop", C.c_float), ("rng", C.c_void_p), ("stream", C.c_uint32),
-                ("stat_rows", C.c_int)]
+                ("stat_rows", C.c_int), ("groups", C.c_int)]
 
 
 class GRUDesc(C.Structure):

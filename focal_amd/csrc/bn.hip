@@ -45,6 +45,11 @@ struct BnFinalize { float* mean_rstd; float* run_mean; float* run_var; long stat
 __global__ __launch_bounds__(1024) void bn_partial_kernel(const float* __restrict__ z, float* __restrict__ sums, long rows, int C,
                                                           BnFinalize fin) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][C]
+  // (blockIdx.y = statistic group, focal_bn_desc.groups: `rows` rows each, every per-call array one copy per group)
+  z += (size_t)blockIdx.y * rows * C;
+  sums += (size_t)blockIdx.y * (2 * C + 1);
+  if (fin.mean_rstd) fin.mean_rstd += (size_t)blockIdx.y * 2 * C;
+  if (fin.run_mean) { fin.run_mean += (size_t)blockIdx.y * C; fin.run_var += (size_t)blockIdx.y * C; }
   const int lpr = C / 4;                 // lanes per row
   const int rpb = blockDim.x / lpr;      // rows per block-iteration
   const int li = threadIdx.x % lpr, sub = threadIdx.x / lpr;
@@ -125,8 +130,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   const bool drop_on = p > 0.f;
   const long n4 = rows * C / 4;
   const int cshift = (C & (C - 1)) == 0 ? __builtin_ctz(C) : -1;  // power-of-two channel count: shift / mask, no 64-bit division
+  {  // blockIdx.y = statistic group: its `rows` rows, its mean / rstd
+    const size_t off = (size_t)blockIdx.y * rows * C;
+    z += off; y += off;
+    if (resid) resid += off;
+    if (ya) ya += off;
+    mean_rstd += (size_t)blockIdx.y * 2 * C;
+  }
+  const long row0 = (long)blockIdx.y * rows;  // (Dropout2d samples are numbered through the whole tensor)
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
-    const long r = cshift >= 0 ? (e * 4) >> cshift : (e * 4) / C;
+    const long r = row0 + (cshift >= 0 ? (e * 4) >> cshift : (e * 4) / C);
     const int c = cshift >= 0 ? (int)((e * 4) & (C - 1)) : (int)((e * 4) % C);
     const float4 v = reinterpret_cast<const float4*>(z)[e];
     const float4 mu = *reinterpret_cast<const float4*>(mean_rstd + c), rs = *reinterpret_cast<const float4*>(mean_rstd + C + c);
@@ -178,11 +191,16 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float* __rest
   const bool drop_on = p > 0.f;
   const int lpr = C / 4, rpb = blockDim.x / lpr;
   const int li = threadIdx.x % lpr, sub = threadIdx.x / lpr, c = li * 4;
+  // blockIdx.y = statistic group
+  z += (size_t)blockIdx.y * rows * C; g += (size_t)blockIdx.y * rows * C;
+  mean_rstd += (size_t)blockIdx.y * 2 * C;
+  sums += (size_t)blockIdx.y * (2 * C + 1);
+  const long row0 = (long)blockIdx.y * rows;
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   for (long r = (long)blockIdx.x * rpb + sub; r < rows; r += (long)gridDim.x * rpb) {
     float da[4], zh[4];
     bn_da4(*reinterpret_cast<const float4*>(z + r * C + c), *reinterpret_cast<const float4*>(g + r * C + c), mean_rstd, gamma, beta, c, C,
-           dc, drop_on, drop_on ? ((uint32_t)r / (uint32_t)rows_per_sample) : 0u, da, zh);
+           dc, drop_on, drop_on ? ((uint32_t)(row0 + r) / (uint32_t)rows_per_sample) : 0u, da, zh);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { s1[k] += da[k]; s2[k] += da[k] * zh[k]; }
   }
@@ -204,13 +222,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const DropCtx dc = make_drop(rng, stream, p);
   const bool drop_on = p > 0.f;
   const float inv_n = 1.0f / (float)stat_rows;
-  if (blockIdx.x == 0 && dgamma) {
-    for (int i = threadIdx.x; i < C; i += 256) { dbeta[i] += sums[i]; dgamma[i] += sums[C + i]; }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {  // the parameter gradients: the sums of every statistic group
+    for (int i = threadIdx.x; i < C; i += 256) {
+      float sb = 0.f, sg = 0.f;
+      for (int gr = 0; gr < (int)gridDim.y; ++gr) { sb += sums[(size_t)gr * (2 * C + 1) + i]; sg += sums[(size_t)gr * (2 * C + 1) + C + i]; }
+      dbeta[i] += sb; dgamma[i] += sg;
+    }
   }
+  {  // blockIdx.y = statistic group
+    const size_t off = (size_t)blockIdx.y * rows * C;
+    z += off; g += off; dz += off;
+    mean_rstd += (size_t)blockIdx.y * 2 * C;
+    sums += (size_t)blockIdx.y * (2 * C + 1);
+  }
+  const long row0 = (long)blockIdx.y * rows;
   const long n4 = rows * C / 4;
   const int cshift = (C & (C - 1)) == 0 ? __builtin_ctz(C) : -1;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
-    const long r = cshift >= 0 ? (e * 4) >> cshift : (e * 4) / C;
+    const long r = row0 + (cshift >= 0 ? (e * 4) >> cshift : (e * 4) / C);
     const int c = cshift >= 0 ? (int)((e * 4) & (C - 1)) : (int)((e * 4) % C);
     float da[4], zh[4], o[4];
     bn_da4(reinterpret_cast<const float4*>(z)[e], reinterpret_cast<const float4*>(g)[e], mean_rstd, gamma, beta, c, C, dc, drop_on,
@@ -232,8 +261,13 @@ static int bn_check(const focal_bn_desc* d) {
   FOCAL_CHECK_ARG(d->dtype == FOCAL_F32 || d->dtype == FOCAL_BF16, "bn: bad dtype");
   FOCAL_CHECK_ARG(d->C >= 4 && d->C <= 1024 && d->C % 4 == 0 && 256 % (d->C / 4) == 0, "bn: unsupported channel count %d", d->C);
   FOCAL_CHECK_ARG(d->rows > 0 && d->rows_per_sample > 0 && d->rows % d->rows_per_sample == 0, "bn: rows %% rows_per_sample != 0");
+  FOCAL_CHECK_ARG(d->groups >= 0 && d->groups <= 16, "bn: %d statistic groups (0 .. 16)", d->groups);
+  if (d->groups > 1)
+    FOCAL_CHECK_ARG(d->rows % d->groups == 0 && (d->rows / d->groups) % d->rows_per_sample == 0 && d->stat_rows <= 0,
+                    "bn: %d statistic groups need rows (%d) to split into whole samples and stat_rows = 0 (one rank)", d->groups, d->rows);
   return FOCAL_OK;
 }
+static int bn_groups(const focal_bn_desc* d) { return d->groups > 1 ? d->groups : 1; }
 static int stream_blocks(long rows, int C) {
   long b = (rows * C / 4 + 255) / 256;
   return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
@@ -246,7 +280,9 @@ extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scr
   training &= ~FOCAL_BN_SCRATCH_ZEROED;
   FOCAL_CHECK_ARG(training >= FOCAL_BN_EVAL && training <= FOCAL_BN_FINALIZE, "bn_stats: bad mode %d", training);
   hipStream_t st = (hipStream_t)stream;
-  const int C = d->C;
+  const int C = d->C, G = bn_groups(d);
+  FOCAL_CHECK_ARG(G == 1 || training == FOCAL_BN_TRAIN, "bn_stats: statistic groups are a training-mode, one-rank feature (mode %d)", training);
+  const long rows_g = d->rows / G;
   if (training == FOCAL_BN_EVAL) {
     FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
     FOCAL_LAUNCH(bn_eval_stats_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, running_mean, running_var, mean_rstd, C, d->eps);
@@ -257,15 +293,15 @@ extern "C" int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scr
   const long n_stat = d->stat_rows > 0 ? d->stat_rows : d->rows;
   if (training != FOCAL_BN_FINALIZE) {
     FOCAL_CHECK_ARG(z, "bn_stats: null tensor");
-    if (!prezeroed) (void)hipMemsetAsync(scratch, 0, (2 * C + 1) * sizeof(float), st);
-    int blocks = ceil_div((long)d->rows * C / 4, 1024 * 2);
-    if (blocks > 256) blocks = 256;
-    BnFinalize fin = {nullptr, nullptr, nullptr, n_stat, d->eps, d->momentum};
+    if (!prezeroed) (void)hipMemsetAsync(scratch, 0, (size_t)G * (2 * C + 1) * sizeof(float), st);
+    int blocks = ceil_div(rows_g * C / 4, 1024 * 2);
+    if (blocks > 256 / G) blocks = 256 / G;
+    BnFinalize fin = {nullptr, nullptr, nullptr, G > 1 ? rows_g : n_stat, d->eps, d->momentum};
     if (training == FOCAL_BN_TRAIN) {
       FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
       fin.mean_rstd = mean_rstd; fin.run_mean = running_mean; fin.run_var = running_var;
     }
-    FOCAL_LAUNCH(bn_partial_kernel, dim3(blocks), dim3(1024), 32 * C * sizeof(float), st, z, scratch, (long)d->rows, C, fin);
+    FOCAL_LAUNCH(bn_partial_kernel, dim3(blocks, G), dim3(1024), 32 * C * sizeof(float), st, z, scratch, rows_g, C, fin);
   }
   if (training == FOCAL_BN_FINALIZE) {
     FOCAL_CHECK_ARG(mean_rstd && running_mean && running_var, "bn_stats: null tensor");
@@ -281,13 +317,15 @@ extern "C" int focal_bn_act_fwd(const focal_bn_desc* d, const float* z, const fl
   if (int rc = bn_check(d)) return rc;
   FOCAL_CHECK_ARG(z && mean_rstd && gamma && beta && y, "bn_act_fwd: null tensor");
   hipStream_t st = (hipStream_t)stream;
-  const int blocks = stream_blocks(d->rows, d->C);
+  const int G = bn_groups(d);
+  const long rows_g = d->rows / G;
+  const int blocks = ceil_div(stream_blocks(d->rows, d->C), G);
   if (d->dtype == FOCAL_F32)
-    FOCAL_LAUNCH((bn_act_fwd_kernel<float>), dim3(blocks), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (float*)y_cast,
-                       (long)d->rows, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+    FOCAL_LAUNCH((bn_act_fwd_kernel<float>), dim3(blocks, G), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (float*)y_cast,
+                       rows_g, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
   else
-    FOCAL_LAUNCH((bn_act_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (bf16_t*)y_cast,
-                       (long)d->rows, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+    FOCAL_LAUNCH((bn_act_fwd_kernel<bf16_t>), dim3(blocks, G), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (bf16_t*)y_cast,
+                       rows_g, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }
@@ -300,13 +338,15 @@ extern "C" int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const fl
   FOCAL_CHECK_ARG(phase == FOCAL_BN_TRAIN || phase == FOCAL_BN_PARTIAL || phase == FOCAL_BN_FINALIZE, "bn_act_bwd: bad phase %d", phase);
   FOCAL_CHECK_ARG(z && g && mean_rstd && gamma && beta && scratch, "bn_act_bwd: null tensor");
   hipStream_t st = (hipStream_t)stream;
-  const int C = d->C;
+  const int C = d->C, G = bn_groups(d);
+  FOCAL_CHECK_ARG(G == 1 || phase == FOCAL_BN_TRAIN, "bn_act_bwd: statistic groups are a one-rank feature (phase %d)", phase);
+  const long rows_g = d->rows / G;
   if (phase != FOCAL_BN_FINALIZE) {
-    if (!prezeroed) (void)hipMemsetAsync(scratch, 0, (2 * C + 1) * sizeof(float), st);
-    int rb = ceil_div((long)d->rows * C / 4, 1024 * 2);
-    if (rb > 256) rb = 256;
-    FOCAL_LAUNCH(bn_bwd_reduce_kernel, dim3(rb), dim3(1024), 32 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
-                       (long)d->rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+    if (!prezeroed) (void)hipMemsetAsync(scratch, 0, (size_t)G * (2 * C + 1) * sizeof(float), st);
+    int rb = ceil_div(rows_g * C / 4, 1024 * 2);
+    if (rb > 256 / G) rb = 256 / G;
+    FOCAL_LAUNCH(bn_bwd_reduce_kernel, dim3(rb, G), dim3(1024), 32 * C * sizeof(float), st, z, g, mean_rstd, gamma, beta, scratch,
+                       rows_g, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
   }
   if (phase == FOCAL_BN_PARTIAL) {  // the parameter gradients are the LOCAL sums (the gradient all-reduce adds the other ranks')
     FOCAL_CHECK_ARG(dgamma && dbeta, "bn_act_bwd: null tensor");
@@ -314,14 +354,14 @@ extern "C" int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const fl
   } else {
     FOCAL_CHECK_ARG(dz && (phase == FOCAL_BN_FINALIZE || (dgamma && dbeta)), "bn_act_bwd: null tensor");
     float* dgm = phase == FOCAL_BN_FINALIZE ? nullptr : dgamma;
-    const long stat_rows = (phase == FOCAL_BN_FINALIZE && d->stat_rows > 0) ? d->stat_rows : d->rows;
-    const int blocks = stream_blocks(d->rows, C);
+    const long stat_rows = (phase == FOCAL_BN_FINALIZE && d->stat_rows > 0) ? d->stat_rows : rows_g;
+    const int blocks = ceil_div(stream_blocks(d->rows, C), G);
     if (d->dtype == FOCAL_F32)
-      FOCAL_LAUNCH((bn_bwd_apply_kernel<float>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (float*)dz,
-                         dgm, dbeta, (long)d->rows, stat_rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+      FOCAL_LAUNCH((bn_bwd_apply_kernel<float>), dim3(blocks, G), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (float*)dz,
+                         dgm, dbeta, rows_g, stat_rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
     else
-      FOCAL_LAUNCH((bn_bwd_apply_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (bf16_t*)dz,
-                         dgm, dbeta, (long)d->rows, stat_rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+      FOCAL_LAUNCH((bn_bwd_apply_kernel<bf16_t>), dim3(blocks, G), dim3(256), 0, st, z, g, mean_rstd, gamma, beta, scratch, (bf16_t*)dz,
+                         dgm, dbeta, rows_g, stat_rows, C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
   }
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;

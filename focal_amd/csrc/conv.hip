@@ -599,6 +599,11 @@ extern "C" int focal_conv_fwd_bn(const focal_conv_desc* d, const void* x, const 
   p.proA = conv_window(d->S, d->C_in, pad);
   p.bn_sums = scratch; p.bn_mean_rstd = mean_rstd; p.bn_run_mean = running_mean; p.bn_run_var = running_var;
   p.bn_rows = bn->stat_rows > 0 ? bn->stat_rows : bn->rows; p.bn_eps = bn->eps; p.bn_momentum = bn->momentum;
+  if (bn->groups > 1) {  // (the GEMM tiles are 64 or 128 rows high: a tile then lies inside one group)
+    FOCAL_CHECK_ARG(bn->stat_rows <= 0 && bn->rows % bn->groups == 0 && (bn->rows / bn->groups) % 128 == 0,
+                    "conv_fwd_bn: %d statistic groups need rows / groups (%d / %d) to be a multiple of 128 and no stat_rows", bn->groups, bn->rows, bn->groups);
+    p.bn_groups = bn->groups; p.bn_rows = bn->rows / bn->groups;
+  }
   return focal_launch_gemm(s, p, (hipStream_t)stream);
 }
 

@@ -52,6 +52,9 @@ struct GemmParams {
   // EPI_STORE_STATS (training-mode BatchNorm behind a [1,k] convolution, DeepSense): bn_sums = 16 slots of {sum[N], sum of squares[N]} followed
   // by the arrival counter, all zero on entry; statistics over bn_rows rows; outputs as focal_bn_stats in FOCAL_BN_TRAIN mode
   float* bn_sums; float* bn_mean_rstd; float* bn_run_mean; float* bn_run_var; long bn_rows; float bn_eps, bn_momentum;
+  // bn_groups > 1: rows [g bn_rows, (g + 1) bn_rows) have statistics of their own (bn_rows a multiple of the tile height); sums / counter,
+  // mean_rstd, run_* are bn_groups copies of the one-group layout
+  int bn_groups;
 };
 constexpr int BN_STAT_SLOTS = 16;
 

@@ -437,10 +437,11 @@ extern "C" int focal_axpy(long n, float a, const float* x, float* y, void* strea
 }
 
 // Twins (lanes per sample, see gru_seq_fwd_kernel) of a sequence launch: 2 -- 8 samples per workgroup, twice the grid -- while that grid stays
-// within 64 workgroups: the four (view, modality) passes of a DeepSense step run their recurrences side by side on 256 CUs, one workgroup per
-// CU (LDS).  H = 128 has one tile per wave: nothing to split.
+// within 128 workgroups: the passes of a DeepSense step run their recurrences side by side on 256 CUs, one workgroup per CU (LDS) -- four
+// passes of 256 windows (view x modality: 64 workgroups each) or, with both views of a modality in one pass (round 5), two of 512 (128 each).
+// H = 128 has one tile per wave: nothing to split.
 #ifndef GRU_GRID_TARGET
-#define GRU_GRID_TARGET 64
+#define GRU_GRID_TARGET 128
 #endif
 static int gru_twins(int B, int H, int n_dir) { return (H == 256 && GRU_NW == 8 && ceil_div(B, 8) * n_dir <= GRU_GRID_TARGET) ? 2 : 1; }
 

@@ -32,12 +32,14 @@ class DeepSenseModEncoder:
     def _stream(self, view, uid):
         return ((view * 8 + self.mod_index) * 64 + uid) * 8
 
-    def _sink(self, order, device):
-        """[BatchNorm layer, {mean, unbiased variance}, C]: where pass `order` of a step records its batch statistics."""
+    def _sink(self, order, device, groups=1):
+        """[BatchNorm layer, {mean, unbiased variance}, C]: where pass `order` of a step records its batch statistics
+        ([layer, {mean, variance}, view, C] for a pass that carries both views: order "both")."""
         sinks = self.__dict__.setdefault("_sinks", {})
         key = (order, torch.device(device))
         if key not in sinks:
-            sinks[key] = torch.zeros(1 + self.geo["n_inter"], 2, self.geo["C"], dtype=torch.float32, device=device)
+            shape = (1 + self.geo["n_inter"], 2, self.geo["C"]) if groups == 1 else (1 + self.geo["n_inter"], 2, groups, self.geo["C"])
+            sinks[key] = torch.zeros(shape, dtype=torch.float32, device=device)
         return sinks[key]
 
     def prepare_packs(self):
@@ -74,6 +76,17 @@ class DeepSenseModEncoder:
         packs = getattr(self, "_packs", None)
         return packs[key] if packs is not None and key in packs else make()
 
+    def _combine_running(self, v1_of, v2_of):
+        buf = self.bb.buffer
+        names = [f"{self.pre}.conv_layer_in"] + [f"{self.pre}.conv_layers_inter.{li}" for li in range(self.geo["n_inter"])]
+        run, v1, v2 = [], [], []
+        for i, p in enumerate(names):
+            for j, which in enumerate(("running_mean", "running_var")):
+                run.append(buf(f"{p}.batch_norm.{which}"))
+                v1.append(v1_of(i, j))
+                v2.append(v2_of(i, j))
+        ops.bn_running_combine(run, v1, v2, 0.1)
+
     def finish_views(self, device):
         """Both passes of a step have recorded their statistics: apply the two running-buffer updates (view 1's, then view 2's)."""
         if getattr(self, "_sinks_filled", 0) != 3:
@@ -81,16 +94,8 @@ class DeepSenseModEncoder:
                 raise ops._lib.FocalHipError("DeepSense: one view's pass recorded BatchNorm statistics and the other did not")
             return
         self._sinks_filled = 0
-        buf = self.bb.buffer
-        names = [f"{self.pre}.conv_layer_in"] + [f"{self.pre}.conv_layers_inter.{li}" for li in range(self.geo["n_inter"])]
         s0, s1 = self._sink(0, device), self._sink(1, device)
-        run, v1, v2 = [], [], []
-        for i, p in enumerate(names):
-            for j, which in enumerate(("running_mean", "running_var")):
-                run.append(buf(f"{p}.batch_norm.{which}"))
-                v1.append(s0[i, j])
-                v2.append(s1[i, j])
-        ops.bn_running_combine(run, v1, v2, 0.1)
+        self._combine_running(lambda i, j: s0[i, j], lambda i, j: s1[i, j])
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x_freq, view, training):
@@ -112,8 +117,16 @@ class DeepSenseModEncoder:
         # (momentum 1: the "running" buffer it is given simply receives the statistic) and DeepSense.finish_views applies both updates
         # afterwards in one launch (ops.bn_running_combine) -- the same two updates, in the reference's order.
         order = getattr(self, "pass_order", None)
-        side_by_side = order is not None and training
-        sink = self._sink(order, x_freq.device) if side_by_side else None
+        # Round 5: BOTH views in this pass (the batch is view 1's B windows, then view 2's; DeepSense.views_share_pass).  Every BatchNorm
+        # keeps one set of batch statistics per view (focal_bn_desc.groups = 2: the reference normalises each backbone call by itself,
+        # ConvModules.py:86) and records them in a sink; the two running-buffer updates are applied, in the reference's order, at the end of
+        # the convolution stack.  Everything else -- convolutions, the GRU, the projector -- is per window: the same kernels on 2B windows,
+        # half the launches of two passes.
+        G = int(getattr(self, "views_in_batch", 1) or 1) if training else 1
+        if G > 1 and (order is not None or B % G):
+            raise ops._lib.FocalHipError(f"DeepSense: a pass with {G} views needs a batch of {G} equal parts and no pass order (B = {B})")
+        side_by_side = (order is not None or G > 1) and training
+        sink = self._sink(order if G == 1 else "both", x_freq.device, G) if side_by_side else None
         if order == 1 and not side_by_side and getattr(self, "_bn_done", None) is not None:
             torch.cuda.current_stream(x_freq.device).wait_event(self._bn_done)
             self._bn_done = None
@@ -127,30 +140,33 @@ class DeepSenseModEncoder:
         pin = f"{self.pre}.conv_layer_in"
         d_in = ops.conv_in_desc(B, cin, I, S_in, S, geo["k_in"], geo["stride"], geo["pad_in"], C)
         z = ops.conv_in_fwd(d_in, x_freq, ar.master(f"{pin}.conv.weight"), ar.master(f"{pin}.conv.bias"))
-        d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 0), momentum=momentum)
-        mr = ops.bn_stats(d_bn, z, *running(pin, 0), training, bb.sync_bn)
+        d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 0), momentum=momentum, groups=G)
+        mr = ops.bn_stats(d_bn, z, *running(pin, 0), training, bb.sync_bn and G == 1)
         y, ya = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pin}.batch_norm.weight"), ar.master(f"{pin}.batch_norm.bias"), None, ct)
         sv["in"] = dict(d=d_in, z=z, mr=mr, d_bn=d_bn, p=pin)
         if training:
-            bb.bump_bn_counters(self.pre)  # every BatchNorm of this encoder: num_batches_tracked += 1, one launch
+            bb.bump_bn_counters(self.pre, G)  # every BatchNorm of this encoder: num_batches_tracked += 1 per view, one launch
         k = geo["k"]
         d_cv = ops.conv_desc(cc, rows, S, C, C, k, dw_workgroups=DW_WORKGROUPS)
         for li in range(geo["n_inter"]):
             pl = f"{self.pre}.conv_layers_inter.{li}"
             w = ar.master(f"{pl}.conv.weight")  # [C, C, 1, k]
             w_fwd = self._packed(("fwd", li), lambda: ops.permute_pack(w, C, C, k, ct))
-            d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 1 + li), momentum=momentum)
-            if training and ct == torch.bfloat16 and not (bb.sync_bn and ops._sync_world() > 1):
+            d_bn = ops.bn_desc(cc, rows, C, I * S, p_drop, rng, self._stream(view, 1 + li), momentum=momentum, groups=G)
+            # (per-view statistics from the epilogue: a 64- or 128-row tile must lie inside one view)
+            if training and ct == torch.bfloat16 and not (bb.sync_bn and ops._sync_world() > 1) and (G == 1 or (rows // G) % 128 == 0):
                 # the statistics come out of the convolution's epilogue: z is not read back for them, one launch less per layer
                 z, mr = ops.conv_fwd_bn(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"), d_bn, *running(pl, 1 + li))
             else:
                 z = ops.conv_fwd(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"))
-                mr = ops.bn_stats(d_bn, z, *running(pl, 1 + li), training, bb.sync_bn)
+                mr = ops.bn_stats(d_bn, z, *running(pl, 1 + li), training, bb.sync_bn and G == 1)
             y_next, ya_next = ops.bn_act_fwd(d_bn, z, mr, ar.master(f"{pl}.batch_norm.weight"), ar.master(f"{pl}.batch_norm.bias"), y, ct)
             sv["layers"].append(dict(p=pl, z=z, mr=mr, d_bn=d_bn, xa=ya))
             y, ya = y_next, ya_next
         sv["d_cv"] = d_cv
-        if side_by_side:
+        if G > 1:
+            self._combine_running(lambda i, j: sink[i, j, 0], lambda i, j: sink[i, j, 1])
+        elif side_by_side:
             self._sinks_filled = getattr(self, "_sinks_filled", 0) | (1 << order)
         elif order == 0:
             self._bn_done = torch.cuda.Event()

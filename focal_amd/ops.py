@@ -716,11 +716,12 @@ def conv_fwd_bn(d, x, w_fwd, bias, d_bn, running_mean, running_var):
     no sync_bn (the global-batch form all-reduces the sums between two kernels: conv_fwd + bn_stats)."""
     dev = x.device
     z = torch.empty(d.rows, d.C_out, dtype=torch.float32, device=dev)
-    n = _lib.BN_STAT_SLOTS * 2 * d_bn.C + 1
+    G = _bn_groups(d_bn)
+    n = G * (_lib.BN_STAT_SLOTS * 2 * d_bn.C + 1)
     scratch = pool_zeros(n, dev)
     if scratch is None:
         scratch = torch.zeros(n, dtype=torch.float32, device=dev)
-    mean_rstd = torch.empty(2 * d_bn.C, dtype=torch.float32, device=dev)
+    mean_rstd = torch.empty(G * 2 * d_bn.C, dtype=torch.float32, device=dev)
     check(_lib.load().focal_conv_fwd_bn(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(z), C.byref(d_bn), _p(scratch), _p(mean_rstd),
                                         _p(running_mean), _p(running_var), _stream()))
     return z, mean_rstd
@@ -734,8 +735,14 @@ def conv_bwd_weight(d, dz, x, dw_packed, dbias):
     check(_lib.load().focal_conv_bwd_weight(C.byref(d), _p(dz), _p(x), _p(dw_packed), _p(dbias), _stream()))
 
 
-def bn_desc(dtype_code, rows, Cc, rows_per_sample, p_drop=0.0, rng=None, stream=0, eps=1e-5, momentum=0.1, stat_rows=0):
-    return BNDesc(dtype_code, rows, Cc, rows_per_sample, eps, momentum, p_drop, _p(rng), stream, stat_rows)
+def bn_desc(dtype_code, rows, Cc, rows_per_sample, p_drop=0.0, rng=None, stream=0, eps=1e-5, momentum=0.1, stat_rows=0, groups=1):
+    """groups > 1: the rows are `groups` equal consecutive ranges with batch statistics of their own (the two views of a FOCAL step as
+    one batch): mean_rstd [groups, 2C], the running buffers handed to bn_stats / conv_fwd_bn are per-group sinks [groups, C]."""
+    return BNDesc(dtype_code, rows, Cc, rows_per_sample, eps, momentum, p_drop, _p(rng), stream, stat_rows, groups)
+
+
+def _bn_groups(d):
+    return d.groups if d.groups > 1 else 1
 
 
 def _sync_world():
@@ -747,11 +754,12 @@ def bn_stats(d, z, running_mean, running_var, training, sync=False):
     """mean / rstd of z [rows, C].  sync=True under torch.distributed: the 2C per-channel sums are all-reduced between the
     partial and the finalize kernels, so every rank normalises with the statistics of the GLOBAL batch (equal shards)."""
     dev = running_mean.device
-    scratch = pool_zeros(2 * d.C + 1, dev) if training else None  # {sum, sum of squares} + the statistics kernel's arrival counter
+    G = _bn_groups(d)
+    scratch = pool_zeros(G * (2 * d.C + 1), dev) if training else None  # {sum, sum of squares} + the statistics kernel's arrival counter
     pre = _lib.BN_SCRATCH_ZEROED if scratch is not None else 0
     if scratch is None:
-        scratch = torch.empty(2 * d.C + 1, dtype=torch.float32, device=dev)
-    mean_rstd = torch.empty(2 * d.C, dtype=torch.float32, device=dev)
+        scratch = torch.empty(G * (2 * d.C + 1), dtype=torch.float32, device=dev)
+    mean_rstd = torch.empty(G * 2 * d.C, dtype=torch.float32, device=dev)
     lib = _lib.load()
     args = (_p(z), _p(scratch), _p(mean_rstd), _p(running_mean), _p(running_var))
     world = _sync_world() if (sync and training) else 1
@@ -780,10 +788,11 @@ def bn_act_fwd(d, z, mean_rstd, gamma, beta, resid, cast_dtype=None):
 
 
 def bn_act_bwd(d, z, g, mean_rstd, gamma, beta, dgamma, dbeta, out_dtype, sync=False):
-    scratch = pool_zeros(2 * d.C + 1, z.device)
+    G = _bn_groups(d)
+    scratch = pool_zeros(G * (2 * d.C + 1), z.device)
     pre = _lib.BN_SCRATCH_ZEROED if scratch is not None else 0
     if scratch is None:
-        scratch = torch.empty(2 * d.C + 1, dtype=torch.float32, device=z.device)
+        scratch = torch.empty(G * (2 * d.C + 1), dtype=torch.float32, device=z.device)
     dz = torch.empty(z.shape, dtype=out_dtype, device=z.device)
     lib = _lib.load()
     args = (_p(z), _p(g), _p(mean_rstd), _p(gamma), _p(beta), _p(scratch), _p(dz), _p(dgamma), _p(dbeta))

@@ -84,8 +84,18 @@ class DeepSense(HipBackbone):
         self._class_head = ClassifierHead(self)
         self._buffers_by_name = None
 
-    def bump_bn_counters(self, prefix):
-        """num_batches_tracked += 1 for every BatchNorm under `prefix` (torch does it per layer in forward, nn/modules/batchnorm.py).
+    @property
+    def views_share_pass(self):
+        """FOCAL.forward hands the two views to ONE backbone call as a batch of 2B (models/FOCALModules.py) while training on per-rank
+        statistics: every BatchNorm then keeps one set of batch statistics per view (focal_amd/deepsense_engine.py).  Evaluation (running
+        statistics) and the global-batch -sync_bn mode keep the reference's two calls.  FOCAL_DEEPSENSE_TWO_PASSES=1: two calls always."""
+        if os.environ.get("FOCAL_DEEPSENSE_TWO_PASSES", "0") == "1" or not self.training:
+            return False
+        from focal_amd import ops
+        return not (self.sync_bn and ops._sync_world() > 1)
+
+    def bump_bn_counters(self, prefix, n=1):
+        """num_batches_tracked += n for every BatchNorm under `prefix` (torch does it per layer in forward, nn/modules/batchnorm.py).
         The counters of one encoder are 0-dim views of ONE int64 tensor, so this is a single launch instead of one per layer;
         state_dict() / load_state_dict() see ordinary per-layer buffers."""
         cache = self.__dict__.setdefault("_bn_counter_blocks", {})
@@ -98,7 +108,7 @@ class DeepSense(HipBackbone):
                 m._buffers["num_batches_tracked"] = blk[i]
             cache[prefix] = blk
             self._buffers_by_name = None
-        blk.add_(1)
+        blk.add_(n)
 
     def buffer(self, name):
         if self._buffers_by_name is None or self._buffers_by_name.get("__dev") != next(self.parameters()).device:
@@ -106,7 +116,7 @@ class DeepSense(HipBackbone):
             self._buffers_by_name["__dev"] = next(self.parameters()).device
         return self._buffers_by_name[name]
 
-    def forward_encoder(self, freq_x, class_head=True, proj_head=False, defer_join=False, view_index=None):
+    def forward_encoder(self, freq_x, class_head=True, proj_head=False, defer_join=False, view_index=None, views_in_batch=1):
         if class_head:
             return self.forward_classifier(freq_x)
         loc = self.locations[0]
@@ -138,6 +148,7 @@ class DeepSense(HipBackbone):
             st = runtime.fork_from(dev, (view_index * len(self.modalities) + 1 if view_streams else 0) + mi, point)
             with torch.cuda.stream(st):
                 self._encoders[(loc, mod)].pass_order = view_index if view_streams else None
+                self._encoders[(loc, mod)].views_in_batch = views_in_batch if self.training else 1
                 f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
                 out[mod] = run_stage(self, self._heads[mod], f) if proj_head else f
                 out[mod].record_stream(cur)
@@ -167,5 +178,5 @@ class DeepSense(HipBackbone):
         x = torch.cat([feats[m] for m in self.modalities], dim=1)
         return run_stage(self, self._class_head, x, self.training)
 
-    def forward(self, freq_x, class_head=True, proj_head=False, defer_join=False, view_index=None):
-        return self.forward_encoder(freq_x, class_head, proj_head, defer_join, view_index)
+    def forward(self, freq_x, class_head=True, proj_head=False, defer_join=False, view_index=None, views_in_batch=1):
+        return self.forward_encoder(freq_x, class_head, proj_head, defer_join, view_index, views_in_batch)

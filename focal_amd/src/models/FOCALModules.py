@@ -27,9 +27,12 @@ class FOCAL(nn.Module):
         if getattr(self.backbone, "views_share_pass", False):
             # A backbone without batch statistics (SW_Transformer: LayerNorm only) gives the same features whether the two
             # views are two batches or one batch of 2B; one pass halves the launch count and doubles every kernel's size.
+            # DeepSense's BatchNorms compute per-view statistics inside the one batch (views_in_batch).
             both = {loc: {mod: _as_one_batch(x, aug_freq_input2[loc][mod]) for mod, x in mods.items()}
                     for loc, mods in aug_freq_input1.items()}
-            feats = self.backbone(both, class_head=False, proj_head=proj_head)
+            # (a backbone with batch statistics -- DeepSense -- is told that the batch is two views: its BatchNorms keep them apart)
+            kw = {"views_in_batch": 2} if "views_in_batch" in inspect.signature(self.backbone.forward).parameters else {}
+            feats = self.backbone(both, class_head=False, proj_head=proj_head, **kw)
             halves = {m: _SplitHalves.apply(f) for m, f in feats.items()}
             return {m: h[0] for m, h in halves.items()}, {m: h[1] for m, h in halves.items()}
         kw = {}

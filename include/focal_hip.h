@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* 7: launch trace (focal_trace_*), focal_adamw_multi_advance takes the step-state length; 2: BatchNorm scratch of 2C + 1 floats; 3: fused MLP, warps, Mixup; 4: row-sharded loss head, weight-gradient launch queries */
-#define FOCAL_ABI_VERSION 9
+#define FOCAL_ABI_VERSION 10
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -378,7 +378,13 @@ int focal_conv_bwd_weight(const focal_conv_desc* d, const void* dz, const void* 
  *   focal_bn_act_bwd phase = FOCAL_BN_PARTIAL: scratch <- local {sum da, sum da*zhat}, dgamma / dbeta += the LOCAL sums;
  *                    FOCAL_BN_FINALIZE: dz from the (all-reduced) scratch and d->stat_rows.
  * stat_rows = 0 means rows. */
-typedef struct { int dtype; int rows, C, rows_per_sample; float eps, momentum, p_drop; const uint32_t* rng; uint32_t stream; int stat_rows; } focal_bn_desc;
+typedef struct { int dtype; int rows, C, rows_per_sample; float eps, momentum, p_drop; const uint32_t* rng; uint32_t stream; int stat_rows; int groups; } focal_bn_desc;
+/* groups (0 or 1: one): the tensor's `rows` are `groups` equal, consecutive row ranges with batch statistics of their OWN -- the two
+ * augmented views of a FOCAL step as one batch of 2B windows (models/FOCALModules.py:21-34 calls the backbone once per view, so
+ * every BatchNorm2d normalises each view by itself, ConvModules.py:86).  With groups > 1 every per-call array is `groups` copies of its
+ * one-group layout, group after group: scratch, mean_rstd [groups][2C], running_mean / running_var [groups][C] (sinks that RECORD each
+ * group's statistics: d->momentum = 1, then focal_bn_running_combine); gamma / beta / dgamma / dbeta stay [C] (the gradients are the sum
+ * over the groups).  Dropout2d samples are numbered through the whole tensor.  Training mode on one rank only (stat_rows = 0). */
 enum { FOCAL_BN_EVAL = 0, FOCAL_BN_TRAIN = 1, FOCAL_BN_PARTIAL = 2, FOCAL_BN_FINALIZE = 3 };
 /* OR into `training` / `phase`: the caller guarantees `scratch` holds zeros (e.g. a slice of a per-step zeroed pool), so the call
  * does not enqueue its own memset (one launch less per BatchNorm pass). */
@@ -421,7 +427,7 @@ int focal_gru_gate_bwd(const focal_gru_desc* d, int t, int dir_offset, const flo
  * save [T, 4, B, H] indexed by step s.  Backward: whh_t = bf16 [H, 3H] (the transposed W_hh), dgi [B*T, 3H], dgh [T, B, 3H]
  * (step-indexed) are written for the weight / input gradient GEMMs; dout as in focal_gru_gate_bwd.
  * Tensors must stay below 4 GB (32-bit byte offsets).  A batch that is not a multiple of the kernel's samples per workgroup (8 while
- * ceil(B / 8) * n_dir <= 64 at H = 256, else 16) is handled by recomputing the last sample in the spare lanes. */
+ * ceil(B / 8) * n_dir <= 128 at H = 256, else 16) is handled by recomputing the last sample in the spare lanes. */
 int focal_gru_seq_fwd(const focal_gru_desc* d, int n_dir, const float* const* gi, const void* const* whh, const float* const* bhh,
                       float* const* hs, float* const* save, float* out, void* stream);
 int focal_gru_seq_bwd(const focal_gru_desc* d, int n_dir, const float* dout, long ld_b, long ld_t, float scale,

@@ -295,3 +295,44 @@ def test_full_batch_backward_bf16_follows_fp32(cfg):
     # features are 4.9 % from the reference's in eval mode, the embeddings 2.4 %: tests above); the cotangent here is random
     assert total < 8e-2, (total, worst[:6])
     assert worst[0][0] < 1e-1, worst[:6]
+
+
+@pytest.mark.parametrize("ct", ["fp32", "bf16"])
+@pytest.mark.parametrize("B", [8, 64])
+def test_both_views_in_one_pass_equal_two_passes(cfg, ct, B, monkeypatch):
+    """Round 5: FOCAL runs DeepSense once on the batch [view 1; view 2] with per-view BatchNorm statistics (focal_bn_desc.groups = 2)
+    instead of once per view (FOCAL_DEEPSENSE_TWO_PASSES=1, the reference's program order).  Same embeddings, loss terms, parameter
+    gradients and BatchNorm buffers; B = 64 takes the statistics out of the convolution's epilogue (whole 128-row tiles per view),
+    B = 8 the stand-alone statistics kernel."""
+    from oracle.weights import synthetic_freq_input
+    dev = lambda d: {l: {m: v.cuda() for m, v in mm.items()} for l, mm in d.items()}
+    x1, x2 = dev(synthetic_freq_input(cfg, B, seed=311)), dev(synthetic_freq_input(cfg, B, seed=312))
+    got = {}
+    for mode in ("one", "two"):
+        monkeypatch.setenv("FOCAL_DEEPSENSE_TWO_PASSES", "1" if mode == "two" else "0")
+        args, net, focal, loss_fn = build(cfg, ct)
+        net.train()
+        assert bool(net.views_share_pass) == (mode == "one")
+        f1, f2 = focal(x1, x2, proj_head=True)
+        net.arena().zero_grad()
+        loss = loss_fn(f1, f2)
+        loss.backward()
+        torch.cuda.synchronize()
+        got[mode] = dict(f1={m: v.detach().clone() for m, v in f1.items()}, f2={m: v.detach().clone() for m, v in f2.items()},
+                         terms=loss_fn.last_terms.clone(), grads={n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None},
+                         bufs={k: v.detach().clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k})
+    a, b = got["one"], got["two"]
+    tol = 2e-5 if ct == "fp32" else 2e-2     # bf16: the weight gradients' atomics and the statistics' summation order differ between the two forms
+    for m in a["f1"]:
+        assert scale_err(a["f1"][m].cpu(), b["f1"][m].cpu()) < tol and scale_err(a["f2"][m].cpu(), b["f2"][m].cpu()) < tol, m
+    assert (a["terms"] - b["terms"]).abs().max().item() < tol * max(1.0, b["terms"].abs().max().item())
+    assert a["grads"].keys() == b["grads"].keys()
+    num = sum((a["grads"][n].double() - b["grads"][n].double()).pow(2).sum().item() for n in a["grads"]) ** 0.5
+    den = sum(b["grads"][n].double().pow(2).sum().item() for n in a["grads"]) ** 0.5
+    record_observed(f"deepsense.one_pass_vs_two.{ct}.B{B}.grad_l2_rel", num / den)
+    assert num / den < (1e-4 if ct == "fp32" else 6e-2)
+    for k in a["bufs"]:
+        if "num_batches" in k:
+            assert int(a["bufs"][k]) == int(b["bufs"][k]) == (2 if k.startswith("loc_mod_extractors.") else 0), k
+        else:
+            assert scale_err(a["bufs"][k].cpu(), b["bufs"][k].cpu()) < (1e-5 if ct == "fp32" else 2e-2), k

@@ -789,6 +789,81 @@ def test_conv_fwd_with_batchnorm_statistics_in_the_epilogue(ops, B, I, S):
 
 
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,p_drop", [(4, 0.0), (6, 0.3)])
+def test_batchnorm_statistic_groups_equal_separate_calls(ops, ct, B, p_drop):
+    """focal_bn_desc.groups = 2 (round 5: the two views of a step as one batch of 2B windows, each normalised by its own batch statistics):
+    statistics, running-buffer sinks, forward, backward and the parameter gradients equal two one-group calls on the halves.  With
+    Dropout2d on, the samples are numbered through the whole tensor: the second half equals a call whose rows start at sample B."""
+    I, S, C = 10, 20, 64
+    rows = B * I * S
+    z = rnd(2 * rows, C, scale=2.0, seed=280) + 0.3
+    z[rows:] = z[rows:] * 1.7 - 0.9          # the halves have different statistics
+    gam, bet, res = 1 + 0.1 * rnd(C, seed=281), 0.1 * rnd(C, seed=282), rnd(2 * rows, C, seed=283)
+    g = rnd(2 * rows, C, seed=284)
+    state = ops.new_rng_state(9, DEV) if p_drop > 0 else None
+    d2 = ops.bn_desc(ops.code(ct), 2 * rows, C, I * S, p_drop, state, 40, momentum=1.0, groups=2)
+    sink_m, sink_v = torch.zeros(2, C, device=DEV), torch.zeros(2, C, device=DEV)
+    mr2 = ops.bn_stats(d2, z, sink_m, sink_v, True)
+    y2, ya2 = ops.bn_act_fwd(d2, z, mr2, gam, bet, res, ct)
+    dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dz2 = ops.bn_act_bwd(d2, z, g, mr2, gam, bet, dg2, db2, ct)
+    dg1, db1 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    for h in range(2):
+        sl = slice(h * rows, (h + 1) * rows)
+        if p_drop > 0 and h == 1:
+            # a one-group call numbers its samples from 0: give it the whole tensor's statistics rows through a descriptor over 2B samples
+            # whose first half is a copy of the second (same statistics), and compare the rows of its second half
+            zz, gg, rr = torch.cat([z[sl], z[sl]]), torch.cat([g[sl], g[sl]]), torch.cat([res[sl], res[sl]])
+            dd = ops.bn_desc(ops.code(ct), 2 * rows, C, I * S, p_drop, state, 40, momentum=1.0)
+            rm, rv = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            mr = ops.bn_stats(dd, zz, rm, rv, True)
+            y, ya = ops.bn_act_fwd(dd, zz, mr, gam, bet, rr, ct)
+            assert rel_err(mr2[2 * C:], mr) < 1e-5
+            assert rel_err(y2[sl], y[rows:]) < 1e-5 and rel_err(ya2[sl].float(), ya[rows:].float()) < (1e-5 if ct == torch.float32 else 2e-3)
+            continue
+        d1 = ops.bn_desc(ops.code(ct), rows, C, I * S, p_drop, state, 40, momentum=1.0)
+        rm, rv = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        mr = ops.bn_stats(d1, z[sl], rm, rv, True)
+        # (the column sums are atomic adds: equal to summation order, not bit for bit)
+        assert rel_err(mr2[h * 2 * C:(h + 1) * 2 * C], mr) < 1e-6 and rel_err(sink_m[h], rm) < 1e-6 and rel_err(sink_v[h], rv) < 1e-6
+        y, ya = ops.bn_act_fwd(d1, z[sl], mr, gam, bet, res[sl], ct)
+        assert rel_err(y2[sl], y) < 1e-5 and rel_err(ya2[sl].float(), ya.float()) < (1e-5 if ct == torch.float32 else 2e-3)
+        dz = ops.bn_act_bwd(d1, z[sl], g[sl], mr, gam, bet, dg1, db1, ct)
+        assert rel_err(dz2[sl].float(), dz.float()) < (1e-5 if ct == torch.float32 else 2e-3)
+    if p_drop == 0:
+        assert rel_err(dg2, dg1) < 1e-5 and rel_err(db2, db1) < 1e-5
+    # the two recorded statistics become the reference's two running-buffer updates (view 1, then view 2)
+    run = rnd(C, seed=285)
+    want = 0.9 * (0.9 * run + 0.1 * sink_m[0]) + 0.1 * sink_m[1]
+    ops.bn_running_combine([run], [sink_m[0]], [sink_m[1]], 0.1)
+    assert rel_err(run, want) < 1e-6
+
+
+def test_conv_fwd_batchnorm_epilogue_with_statistic_groups(ops):
+    """focal_conv_fwd_bn with two statistic groups == the one-group call on each half (rows per group a multiple of the tile height)."""
+    B, I, S, C, k, ct = 32, 10, 20, 64, 3, torch.bfloat16
+    rows = B * I * S                       # 6400 = 50 x 128
+    x = rnd(2 * rows, C, seed=290, dtype=ct)
+    x[rows:] = (x[rows:].float() * 1.5 + 0.25).to(ct)
+    w, b = rnd(C, C, 1, k, scale=(C * k) ** -0.5, seed=291), rnd(C, seed=292)
+    w_fwd = ops.permute_pack(w, C, C, k, ct)
+    d2 = ops.conv_desc(ops.code(ct), 2 * rows, S, C, C, k)
+    bn2 = ops.bn_desc(ops.code(ct), 2 * rows, C, I * S, 0.0, None, 0, momentum=1.0, groups=2)
+    sm, sv_ = torch.zeros(2, C, device=DEV), torch.zeros(2, C, device=DEV)
+    z2, mr2 = ops.conv_fwd_bn(d2, x, w_fwd, b, bn2, sm, sv_)
+    d1 = ops.conv_desc(ops.code(ct), rows, S, C, C, k)
+    bn1 = ops.bn_desc(ops.code(ct), rows, C, I * S, 0.0, None, 0, momentum=1.0)
+    for h in range(2):
+        rm, rv = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        z, mr = ops.conv_fwd_bn(d1, x[h * rows:(h + 1) * rows].contiguous(), w_fwd, b, bn1, rm, rv)
+        assert torch.equal(z2[h * rows:(h + 1) * rows], z)
+        assert rel_err(mr2[h * 2 * C:(h + 1) * 2 * C], mr) < 1e-5 and rel_err(sm[h], rm) < 1e-5 and rel_err(sv_[h], rv) < 1e-5
+    bad = ops.bn_desc(ops.code(ct), 2 * 1600, C, I * S, 0.0, None, 0, momentum=1.0, groups=2)   # 1600 rows per group: not whole tiles
+    with pytest.raises(Exception, match="multiple of"):
+        ops.conv_fwd_bn(ops.conv_desc(ops.code(ct), 3200, S, C, C, k), x[:3200].contiguous(), w_fwd, b, bad, sm, sv_)
+
+
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("k", [3, 5])
 def test_conv1xk_same_as_sliding_window_gemm(ops, ct, k):
     B, I, S, C = 3, 10, 20, 64
