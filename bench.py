@@ -216,13 +216,13 @@ def time_kernel(fn, iters=20):
 # of libfocal_hip carries a start / stop event pair on the dispatch, so a record is the kernel's own begin -> end time -- what
 # `rocprofv3 --kernel-trace` reports -- labelled with the launched kernel's symbol.  Groups are therefore rocprofv3's rows (one per
 # kernel instantiation; an op that launches two kernels is two groups) and are checked against the committed trace of the same
-# workload (profiles/r4_reference_<model>_<dataset>.json, made by tools/profile_round.sh from `rocprofv3 --kernel-trace --stats -M`).
+# workload (profiles/r5_reference_<model>_<dataset>.json, made by tools/profile_round.sh from `rocprofv3 --kernel-trace --stats -M`).
 # The Python side only attributes ALGORITHMIC bytes / flops: every public op of focal_amd.ops is wrapped, notes which trace records its
 # call produced, and describes what the call has to move.
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from kernel_names import short_kernel_name  # noqa: E402
 
-ROUND = "r4"
+ROUND = "r5"
 
 
 def _dw_bytes_flops(d):
@@ -585,7 +585,7 @@ def roofline_isolated(a, step, device):
 
 
 def dump_trace(a, step):
-    """tools/profile_round.sh: the launch trace in both modes next to the rocprofv3 pass of the same box (profiles/r4_trace_vs_rocprof_*.txt)."""
+    """tools/profile_round.sh: the launch trace in both modes next to the rocprofv3 pass of the same box (profiles/r5_z_*_trace_vs_rocprof.txt)."""
     from focal_amd._lib import TRACE_DISPATCH, TRACE_EVENTS
     for _ in range(2):
         step.run()

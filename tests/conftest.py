@@ -40,7 +40,7 @@ _OBSERVED = {}
 
 
 def record_observed(key, value):
-    """Observed parity errors of this run -> gpurun_out/observed_parity.json (copied to tests/golden/OBSERVED_r4.json (round 3: OBSERVED_r3.json) and
+    """Observed parity errors of this run -> gpurun_out/observed_parity.json (copied to tests/golden/OBSERVED_r5.json (earlier rounds: OBSERVED_r3.json, OBSERVED_r4.json) and
     committed: VERDICT r1 asked for the measured errors behind every tolerance)."""
     import json
     _OBSERVED[key] = float(value)
