@@ -241,6 +241,8 @@ static void run_case(const char* name, int M, int N, int K) {
     RING(128, 128, 3, false, 4, 2, 2, false)
     RING(64, 128, 5, false, 2, 4, 2, false)
     RING(64, 128, 5, true, 2, 4, 2, false)
+    RING(128, 256, 2, false, 2, 4, 2, false)
+    RING(64, 256, 3, false, 2, 4, 2, false)
   }
   printf("\n");
   for (char* q : {b.A, b.C, b.R, b.X, b.O, b.S, b.Cref, b.Oref, b.Cinit}) if (q) CK(hipFree(q));
