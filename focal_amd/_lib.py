@@ -159,6 +159,8 @@ PROTOTYPES = {
     "focal_linear_bwd_weight_group": (C.c_int, [C.c_int, C.c_int, C.POINTER(DwProblem), P]),
     "focal_linear_bwd_weight_group_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "focal_linear_bwd_weight_group_workgroups": (C.c_int, [C.c_int, C.c_int, C.POINTER(DwProblem)]),
+    "focal_linear_bwd_weight_group_f32": (C.c_int, [C.c_int, C.c_int, C.POINTER(DwProblem), C.c_int, C.c_void_p]),
+    "focal_linear_bwd_weight_group_f32_workgroups": (C.c_int, [C.c_int, C.c_int, C.POINTER(DwProblem), C.c_int]),
     "focal_linear_bwd_weight_group_kind": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "focal_mlp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P]),

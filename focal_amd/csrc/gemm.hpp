@@ -353,6 +353,28 @@ __global__ __launch_bounds__(256) void focal_gemm_kernel(const GemmParams p) {
 #include "gemm_body.inc"
 }
 
+// Several weight gradients with fp32 operands (dW = dy^T x; DeepSense's GRU: eight per layer pair, 16 us each at M = 5 120 rows) as ONE
+// launch of the same 64 x 64 tiles behind a problem table (round 5).  The body is included textually, as in focal_gemm_kernel: as a called
+// device function the BKM = 2 instances ran 1.7x slower.
+constexpr int DW_TAIL_MAX = 8;
+struct DwTailGroup { int n; int wg_end[DW_TAIL_MAX]; GemmParams p[DW_TAIL_MAX]; };
+static_assert(sizeof(DwTailGroup) <= 4096, "kernel arguments");
+template <typename CT>
+__global__ __launch_bounds__(256) void focal_dw_tail_group_kernel(const DwTailGroup g) {
+  using TA = float;
+  using TB = float;
+  using TC = float;
+  constexpr bool TRA = true, TRB = true;
+  constexpr int PROA = PRO_NONE, PROB = PRO_NONE, EPI = EPI_ATOMIC, BM = 64, BN = 64, BKM = 2;
+  int pi = 0;
+#pragma unroll
+  for (int q = 0; q < DW_TAIL_MAX - 1; ++q) pi += (q < g.n - 1 && (int)blockIdx.x >= g.wg_end[q]) ? 1 : 0;
+  const int start = pi > 0 ? g.wg_end[pi - 1] : 0;
+  const GemmParams& p = g.p[pi];
+  const int block = (int)blockIdx.x - start, nblocks = g.wg_end[pi] - start;
+#include "gemm_body.inc"
+}
+
 // Launch plan of a weight-gradient GEMM (output [M][N], reduction over `rows` tokens split across workgroups): tile shape and split
 // count.  Shared by the dispatcher (gemm_dispatch.inc: launch_dw) and by focal_linear_bwd_weight_workgroups, which tells a caller
 // how a launch will show up in a profiler trace.
@@ -399,6 +421,8 @@ struct GemmSpec {
 };
 int focal_launch_gemm_bf16(const GemmSpec& s, const GemmParams& p, hipStream_t stream);
 int focal_launch_gemm_f32(const GemmSpec& s, const GemmParams& p, hipStream_t stream);
+int focal_launch_dw_tail_bf16(const DwTailGroup& g, hipStream_t stream);
+int focal_launch_dw_tail_f32(const DwTailGroup& g, hipStream_t stream);
 static inline int focal_launch_gemm(const GemmSpec& s, const GemmParams& p, hipStream_t stream) {
   if ((p.epi.p_elem > 0.f || p.proA.p_elem > 0.f || p.proB.p_elem > 0.f) && ((long)p.M >= (1L << 24) || (long)p.K >= (1L << 24) || (long)p.N >= (1L << 24))) {
     focal_set_error("gemm: a dimension beyond 2^24 with an element mask (MaskEval indexes elements with 24-bit multiplies)");

@@ -4,5 +4,6 @@
 #include "gemm_ring.hpp"
 #include "gemm_dw_ring.hpp"
 #define GEMM_CT bf16_t
+#define GEMM_TAIL_FN focal_launch_dw_tail_bf16
 #define GEMM_FN focal_launch_gemm_bf16
 #include "gemm_dispatch.inc"

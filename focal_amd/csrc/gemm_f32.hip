@@ -5,5 +5,6 @@
 #include "gemm_ring.hpp"
 #include "gemm_dw_ring.hpp"
 #define GEMM_CT float
+#define GEMM_TAIL_FN focal_launch_dw_tail_f32
 #define GEMM_FN focal_launch_gemm_f32
 #include "gemm_dispatch.inc"

@@ -338,6 +338,45 @@ extern "C" int focal_linear_bwd_weight_group(int dtype, int n, const focal_dw_pr
   return FOCAL_OK;
 }
 
+// n weight gradients whose operands are fp32 tensors, one launch (gemm.hpp: focal_dw_tail_group_kernel)
+static int dw_tail_build(int compute, int n, const focal_dw_problem* probs, int workgroups, DwTailGroup* g) {
+  FOCAL_CHECK_ARG(compute == FOCAL_BF16 || compute == FOCAL_F32, "linear_bwd_weight_group_f32: bad compute dtype %d", compute);
+  FOCAL_CHECK_ARG(n >= 1 && n <= DW_TAIL_MAX && probs, "linear_bwd_weight_group_f32: 1 .. %d problems (got %d)", DW_TAIL_MAX, n);
+  memset(g, 0, sizeof(*g));
+  g->n = n;
+  // every problem gets its share of the launch's workgroup target (default ~4 workgroups per CU over the whole launch); a slice is never
+  // shorter than focal_dw_plan's 256 reduction rows
+  const int target = (workgroups > 0 ? workgroups : 1024) / n;
+  int end = 0;
+  for (int i = 0; i < n; ++i) {
+    const focal_dw_problem& q = probs[i];
+    FOCAL_CHECK_ARG(q.dy && q.x && q.dw && q.M > 0 && q.N > 0 && q.K > 0, "linear_bwd_weight_group_f32: problem %d: null tensor or empty shape", i);
+    GemmParams& p = g->p[i];
+    p.M = q.N; p.N = q.K; p.K = q.M;
+    p.A = q.dy; p.lda = q.N;
+    p.B = q.x; p.ldb = q.K;
+    p.C = q.dw; p.ldc = q.K;
+    p.batch = 1; p.alpha = 1.f;
+    p.colsumA = q.dbias;
+    int bm, bn, splits;
+    focal_dw_plan(p.M, p.N, q.M, target < 1 ? 1 : target, &bm, &bn, &splits);
+    p.splits = splits;
+    end += ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * splits;
+    g->wg_end[i] = end;
+  }
+  for (int i = n; i < DW_TAIL_MAX; ++i) g->wg_end[i] = end;
+  return FOCAL_OK;
+}
+extern "C" int focal_linear_bwd_weight_group_f32(int compute, int n, const focal_dw_problem* probs, int workgroups, void* stream) {
+  DwTailGroup g;
+  if (int rc = dw_tail_build(compute, n, probs, workgroups, &g)) return rc;
+  return compute == FOCAL_F32 ? focal_launch_dw_tail_f32(g, (hipStream_t)stream) : focal_launch_dw_tail_bf16(g, (hipStream_t)stream);
+}
+extern "C" int focal_linear_bwd_weight_group_f32_workgroups(int compute, int n, const focal_dw_problem* probs, int workgroups) {
+  DwTailGroup g;
+  return dw_tail_build(compute, n, probs, workgroups, &g) == FOCAL_OK ? g.wg_end[n - 1] : 0;
+}
+
 extern "C" int focal_linear_bwd_weight_group_workgroups(int dtype, int n, const focal_dw_problem* probs) {
   if (dw_group_uses_ring(n, probs)) {
     DwRingGroupParams rp;

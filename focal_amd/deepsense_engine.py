@@ -20,6 +20,8 @@ from ._lib import ACT_NONE, EPI_NONE
 # workgroups, i.e. a third of the fp32 atomics of their small outputs (+4 % on the step: include/focal_hip.h focal_linear_desc.dw_workgroups,
 # gemm.hpp: focal_dw_plan).  A field of the descriptors, not a process-wide switch: other models of the process keep their own plans.
 DW_WORKGROUPS = 192
+# the GRU's eight weight gradients of a pass as one launch: its workgroup target over all of them (two passes run side by side)
+GRU_DW_WORKGROUPS = int(os.environ.get("FOCAL_GRU_DW_WORKGROUPS", "1536"))
 
 
 class DeepSenseModEncoder:
@@ -236,6 +238,9 @@ class DeepSenseModEncoder:
         B, T, H, gd = sv["B"], sv["T"], sv["H"], sv["gd"]
         # ---- GRU, last layer first
         dout, ld_b, ld_t, scale = dfeat, 2 * H, 0, 1.0 / T  # d(mean over time): every step gets dfeat / T
+        # The GRU's weight gradients (W_hh, W_ih of every layer and direction: fp32 operands, 5 120 rows each) do not feed the backward chain:
+        # they are collected and leave as ONE launch behind a problem table (round 5: eight 16 us launches per pass before)
+        gru_dw = []
         for layer in range(geo["n_rnn"] - 1, -1, -1):
             lsv = sv["gru"][layer]
             x_l = lsv["x"]
@@ -267,9 +272,8 @@ class DeepSenseModEncoder:
                         if s > 0:
                             ops.linear_bwd_data(dsv["d_hh"], dgh[s], ar.operand(whh), None, dh_rec)
                             have = True
-                d_hh_all = ops.linear_desc(cc, T * B, 3 * H, H, f32, f32, dw_workgroups=DW_WORKGROUPS)
-                ops.linear_bwd_weight(d_hh_all, dgh, hs[:T], ar.g(whh), ar.g(bhh))
-                ops.linear_bwd_weight(dsv["d_ih"], dgi, x_l, ar.g(wih), ar.g(bih))
+                gru_dw.append((dgh.view(T * B, 3 * H), hs[:T].reshape(T * B, H), ar.g(whh), ar.g(bhh)))
+                gru_dw.append((dgi, x_l, ar.g(wih), ar.g(bih)))
                 dxi = torch.empty(B * T, F, dtype=torch.float32, device=dev)
                 ops.linear_bwd_data(dsv["d_ih"], dgi, ar.operand(wih), None, dxi)
                 if dx is None:
@@ -282,6 +286,9 @@ class DeepSenseModEncoder:
                     rng, sid, p = prev["drop"]
                     dx = ops.dropout(dx, rng, sid, p)
                 dout, ld_b, ld_t, scale = dx, T * 2 * H, 2 * H, 1.0
+        for lo in range(0, len(gru_dw), ops.DW_TAIL_MAX):
+            ops.linear_bwd_weight_group_f32(cc, gru_dw[lo:lo + ops.DW_TAIL_MAX], GRU_DW_WORKGROUPS)
+        del gru_dw
         # ---- flatten + 1x1 output conv
         C, S, I = geo["C"], geo["S"], T
         rows = B * I * S

@@ -466,6 +466,18 @@ def linear_bwd_weight_group(dtype_code, items, exclusive=True):
     check(_lib.load().focal_linear_bwd_weight_group(dtype_code, len(items), arr, _stream()))
 
 
+DW_TAIL_MAX = 8
+
+
+def linear_bwd_weight_group_f32(compute_code, items, workgroups=0):
+    """items: [(dy [M, N] fp32, x [M, K] fp32, dw [N, K] fp32, dbias [N] fp32 | None)], at most 8 -- weight gradients whose operands are fp32
+    tensors (DeepSense's GRU) as ONE launch (focal_linear_bwd_weight_group_f32); `compute_code`: the matrix cores' operand type."""
+    for dy, x, dw, db in items:
+        if dy.dtype != torch.float32 or x.dtype != torch.float32 or dy.dim() != 2 or x.dim() != 2 or not (dy.is_contiguous() and x.is_contiguous()):
+            raise _lib.FocalHipError("linear_bwd_weight_group_f32: dy and x must be contiguous fp32 matrices")
+    check(_lib.load().focal_linear_bwd_weight_group_f32(compute_code, len(items), _dw_problems(items, False), workgroups, _stream()))
+
+
 def linear_bwd_weight_group_workgroups(dtype_code, items, exclusive=True):
     return _lib.load().focal_linear_bwd_weight_group_workgroups(dtype_code, len(items), _dw_problems(items, exclusive))
 

@@ -269,6 +269,12 @@ int focal_linear_bwd_weight_group_supported(int dtype, int M, int N, int K);
 int focal_linear_bwd_weight_group_kind(int dtype, int M, int N, int K);
 /* workgroups that launch consists of (profiler-trace matching, as focal_linear_bwd_weight_workgroups); 0 = invalid */
 int focal_linear_bwd_weight_group_workgroups(int dtype, int n, const focal_dw_problem* problems);
+/* The same for linears whose dy and x are FP32 tensors (DeepSense's nn.GRU: weight_ih / weight_hh of a layer's two directions,
+ * models/RecurrentModule.py:5-31 -- dgi, dgh, the hidden states and the layer input are fp32): up to 8 problems of any shape as ONE launch
+ * of the 64 x 64 tiles focal_linear_bwd_weight uses for them (operands rounded to `compute` on load, fp32 atomics; `exclusive` is not
+ * used).  workgroups: the launch's target over all problems (0 = default), cf. focal_linear_desc.dw_workgroups. */
+int focal_linear_bwd_weight_group_f32(int compute, int n, const focal_dw_problem* problems, int workgroups, void* stream);
+int focal_linear_bwd_weight_group_f32_workgroups(int compute, int n, const focal_dw_problem* problems, int workgroups);
 
 /* Fused MLP branch of a Swin block (models/SwinModules.py:18-34 Mlp.forward + the residual / DropPath of :339-341), bf16,
  * C = 64 -> hidden = 256 -> C (Swin stage 0, where 2/3 of the model's hidden-activation bytes are; focal_mlp_supported says

@@ -789,6 +789,36 @@ def test_conv_fwd_with_batchnorm_statistics_in_the_epilogue(ops, B, I, S):
 
 
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
+def test_weight_gradients_with_fp32_operands_as_one_launch(ops, ct):
+    """focal_linear_bwd_weight_group_f32 (round 5: the GRU's W_hh / W_ih gradients of a DeepSense pass, fp32 dy and x): eight problems of
+    different shapes in one launch == the single launches == dy^T x, accumulated onto what the buffers hold; bias gradients where asked."""
+    shapes = [(5120, 768, 256), (5120, 768, 128), (5120, 768, 512), (2560, 384, 128), (1000, 96, 40), (5120, 768, 256), (640, 64, 64), (5120, 128, 1600)]
+    items, refs, singles = [], [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dy, x = rnd(M, N, seed=300 + i), rnd(M, K, seed=320 + i)
+        dw0 = rnd(N, K, seed=340 + i)
+        db0 = rnd(N, seed=360 + i) if i % 2 == 0 else None
+        dw, db = dw0.clone(), (db0.clone() if db0 is not None else None)
+        items.append((dy, x, dw, db))
+        a, b = (dy, x) if ct == torch.float32 else (dy.bfloat16().float(), x.bfloat16().float())
+        refs.append((dw0.double() + a.double().t() @ b.double(), None if db0 is None else db0.double() + a.double().sum(0)))
+        dw1, db1 = dw0.clone(), (db0.clone() if db0 is not None else None)
+        d = ops.linear_desc(ops.code(ct), M, N, K, ops.code(torch.float32), ops.code(torch.float32))
+        ops.linear_bwd_weight(d, dy, x, dw1, db1)
+        singles.append((dw1, db1))
+    ops.linear_bwd_weight_group_f32(ops.code(ct), items)
+    # (bf16: the reference rounds the operands the same way; what is left is fp32 accumulation order over up to 5 120 rows)
+    tol_ref, tol_single = (2e-5, 2e-5) if ct == torch.float32 else (1e-3, 2e-4)
+    for (dy, x, dw, db), (rw, rb), (sw, sb) in zip(items, refs, singles):
+        assert rel_err(dw.double(), rw) < tol_ref and rel_err(dw, sw) < tol_single
+        if db is not None:
+            # (the bias gradient sums dy as it was loaded: in bf16 mode the reference's operand rounding is the difference)
+            assert rel_err(db.double(), rb) < (tol_ref if ct == torch.float32 else 5e-3) and rel_err(db, sb) < tol_single
+    with pytest.raises(Exception, match="1 .. 8 problems"):
+        ops.linear_bwd_weight_group_f32(ops.code(ct), items + items[:1])
+
+
+@pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,p_drop", [(4, 0.0), (6, 0.3)])
 def test_batchnorm_statistic_groups_equal_separate_calls(ops, ct, B, p_drop):
     """focal_bn_desc.groups = 2 (round 5: the two views of a step as one batch of 2B windows, each normalised by its own batch statistics):
