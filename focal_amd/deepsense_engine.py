@@ -16,10 +16,11 @@ import torch
 from . import ops
 from ._lib import ACT_NONE, EPI_NONE
 
-# Four passes (two views x two modalities) run their backward side by side: their stand-alone weight gradients ask for a third of the default
-# workgroups, i.e. a third of the fp32 atomics of their small outputs (+4 % on the step: include/focal_hip.h focal_linear_desc.dw_workgroups,
-# gemm.hpp: focal_dw_plan).  A field of the descriptors, not a process-wide switch: other models of the process keep their own plans.
-DW_WORKGROUPS = 192
+# The passes of a step run their backward side by side: their stand-alone weight gradients (the convolutions', the 1x1 output conv's) ask for
+# fewer workgroups than the default plan, i.e. fewer fp32 atomics onto their small outputs (include/focal_hip.h focal_linear_desc.dw_workgroups,
+# gemm.hpp: focal_dw_plan).  Four passes (round 4): 192 was the optimum (+4 % over the default 512); two passes of both views (round 5), same
+# box: 128: 129.9 k, 192: 133.5 k, 256: 133.7 k, 384: 135.5 k, 512: 134.8 k windows/s.  A field of the descriptors, not a process-wide switch.
+DW_WORKGROUPS = int(os.environ.get("FOCAL_DS_DW_WORKGROUPS", "384"))
 # the GRU's eight weight gradients of a pass as one launch: its workgroup target over all of them (two passes run side by side)
 GRU_DW_WORKGROUPS = int(os.environ.get("FOCAL_GRU_DW_WORKGROUPS", "1536"))
 
