@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 struct DropMask {
   DropCtx e, p;
   int on_e, on_p, rps, ncols;
+  uint32_t rps_magic;  // ceil(2^32 / rps): row / rps == mulhi(row, magic) while row * rps < 2^32 (checked by the launchers); rps == 1: unused
 };
 __device__ __forceinline__ DropMask make_mask(const focal_drop_desc& d, int ncols) {
   DropMask m;
@@ -97,14 +98,15 @@ __device__ __forceinline__ DropMask make_mask(const focal_drop_desc& d, int ncol
   m.on_p = d.p_path > 0.f;
   m.rps = d.rows_per_sample > 0 ? d.rows_per_sample : 1;
   m.ncols = ncols;
+  m.rps_magic = 0xFFFFFFFFu / (uint32_t)m.rps + 1u;
   m.e = make_drop(d.rng, d.stream_elem, d.p_elem);
   m.p = make_drop(d.rng, d.stream_path, d.p_path);
   return m;
 }
-template <typename TY> __device__ __forceinline__ void store_masked4(TY* out, long off, float4 v, const DropMask& m) {
+// (`row` = off / ncols where the caller knows it: the 64-bit division by a run-time width was ~40 instructions per 16-byte store)
+template <typename TY> __device__ __forceinline__ void store_masked4_row(TY* out, long off, uint32_t row, float4 v, const DropMask& m) {
   float a[4] = {v.x, v.y, v.z, v.w};
-  const uint32_t row = (uint32_t)(off / m.ncols);
-  const float pm = m.on_p ? drop_mult(m.p, row / (uint32_t)m.rps) : 1.0f;
+  const float pm = m.on_p ? drop_mult(m.p, m.rps > 1 ? __umulhi(row, m.rps_magic) : row) : 1.0f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) a[k] *= m.on_e ? pm * drop_mult(m.e, (uint32_t)off + k) : pm;
   if (sizeof(TY) == 4) *reinterpret_cast<float4*>(out + off) = make_float4(a[0], a[1], a[2], a[3]);
@@ -113,6 +115,9 @@ template <typename TY> __device__ __forceinline__ void store_masked4(TY* out, lo
     t[0] = (bf16_t)a[0]; t[1] = (bf16_t)a[1]; t[2] = (bf16_t)a[2]; t[3] = (bf16_t)a[3];
     *reinterpret_cast<bf16x4*>(out + off) = t;
   }
+}
+template <typename TY> __device__ __forceinline__ void store_masked4(TY* out, long off, float4 v, const DropMask& m) {
+  store_masked4_row(out, off, (uint32_t)(off / m.ncols), v, m);
 }
 
 template <typename TY> __device__ __forceinline__ float4 load_dy4(const TY* p);
@@ -178,7 +183,10 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const TY* __restrict__ dy,
                              rstd * (g[k].z - m1 - xh[k].z * m2), rstd * (g[k].w - m1 - xh[k].w * m2));
       o.x += old[k].x; o.y += old[k].y; o.z += old[k].z; o.w += old[k].w;
       *reinterpret_cast<float4*>(dst) = o;
-      if (dxm) store_masked4(dxm, dst - dx, o, mk);
+      if (dxm) {  // the token row of this element: the LayerNorm row itself unless the rows are gathered 2 x 2 neighbourhoods (PatchMerging)
+        const long off = dst - dx;
+        store_masked4_row(dxm, off, map.gather ? (uint32_t)(off / mk.ncols) : (uint32_t)r, o, mk);
+      }
     }
   }
   // Column partials: fold the rows that share a wave with xor-shuffles, park one [2][C] row per wave in LDS (plain
@@ -257,6 +265,11 @@ extern "C" int focal_layernorm_bwd(const focal_ln_desc* d, const void* dy, const
   memset(&dd, 0, sizeof(dd));
   if (mask) dd = *mask;
   FOCAL_CHECK_ARG(!mask || dx_masked, "layernorm_bwd: mask without dx_masked");
+  {  // (the masked copy divides token rows by rows_per_sample with a 32-bit magic multiply)
+    const long token_rows = d->gather ? (long)d->B * d->H * d->W : (long)d->rows;
+    FOCAL_CHECK_ARG(!mask || mask->rows_per_sample <= 1 || token_rows * (long)mask->rows_per_sample < (1L << 32),
+                    "layernorm_bwd: %ld token rows x %d rows per sample exceed the mask's 32-bit row arithmetic", token_rows, mask->rows_per_sample);
+  }
   const int mcols = d->gather ? d->Cin : d->C;  // columns of the token tensor dx lives in
   int blocks = ceil_div(d->rows, rpw * (tpb / 64) * 2);  // ~2 rows per wave
   if (blocks > maxb) blocks = maxb;
@@ -282,6 +295,8 @@ __global__ __launch_bounds__(256) void mask_cast_kernel(const float* __restrict_
 extern "C" int focal_mask_cast(int dtype, int rows, int C, const float* g, const focal_drop_desc* mask, void* out, void* stream) {
   FOCAL_CHECK_ARG(dtype == FOCAL_F32 || dtype == FOCAL_BF16, "mask_cast: bad dtype");
   FOCAL_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && g && out, "mask_cast: bad arguments");
+  FOCAL_CHECK_ARG(!mask || mask->rows_per_sample <= 1 || (long)rows * mask->rows_per_sample < (1L << 32),
+                  "mask_cast: %d rows x %d rows per sample exceed the mask's 32-bit row arithmetic", rows, mask->rows_per_sample);
   focal_drop_desc dd;
   memset(&dd, 0, sizeof(dd));
   if (mask) dd = *mask;
