@@ -289,6 +289,11 @@ class StepTracer:
             rows, C = items[0][0].shape[0], min(min(dy.shape[1], x.shape[1]) for dy, x, _, _ in items)
             return dict(bytes=b, flops=f, bound="hbm", inst=f"{len(items)} dW of a C={C} block over {rows} rows")
 
+        def dwg32(out, compute_code, items, workgroups=0):
+            b = sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + w.numel() * 4 for dy, x, w, _ in items)
+            f = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)
+            return dict(bytes=b, flops=f, bound="hbm", inst=f"{len(items)} dW with fp32 operands over {items[0][0].shape[0]} rows")
+
         def lnb(out, dy, x, stats, gamma, dx, accumulate, dgamma, dbeta, gather=None, desc=None, dx_masked=None, mask=None):
             rows, C = dy.shape
             es = dy.element_size()
@@ -324,7 +329,7 @@ class StepTracer:
 
         def fftm(out, items):
             return dict(bytes=sum(3 * it["x"].numel() * 4 for it in items), flops=0.0, bound="hbm", inst=f"{len(items)} transforms")
-        special = {"linear_bwd_weight": dw, "linear_bwd_weight_group": dwg, "layernorm_bwd": lnb, "mlp_bwd": mlpb, "mlp_fwd": mlpf,
+        special = {"linear_bwd_weight": dw, "linear_bwd_weight_group": dwg, "linear_bwd_weight_group_f32": dwg32, "layernorm_bwd": lnb, "mlp_bwd": mlpb, "mlp_fwd": mlpf,
                    "fft_realpack_multi": fftm, "bn_act_bwd": bnb}
         for name in dir(ops):
             fn = getattr(ops, name)
@@ -539,7 +544,7 @@ def _families(groups):
     fam = {}
     for g in groups:
         k = g["kernel"]
-        name = ("weight gradients (all dW launches)" if (k.startswith(("focal_dw_ring", "focal_dw_group")) or (k.startswith("focal_gemm_kernel<") and ", true, true," in k))
+        name = ("weight gradients (all dW launches)" if (k.startswith(("focal_dw_ring", "focal_dw_group", "focal_dw_tail_group")) or (k.startswith("focal_gemm_kernel<") and ", true, true," in k))
                 else k.split("<")[0].split(" ")[0])
         f = fam.setdefault(name, [0.0, 0.0, 0.0, 0.0])
         f[0] += g["calls_per_step"]
