@@ -16,6 +16,7 @@ import csv, glob, sys, collections, re
 tag, root, steps, warm = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 def fam(n):
     n = re.sub(r"\(Gemm(Epi|Pro)\)", "", n)
+    if "gemm_ring" in n: return "gemm_ring"
     if "gemm_pipe" in n: return "gemm_pipe"
     if "focal_dw_ring" in n or "focal_dw_group" in n: return "gemm dW"
     if "mlp_bwd" in n: return "mlp_bwd"

@@ -23,8 +23,9 @@ from kernel_names import short_kernel_name  # noqa: E402
 
 
 def fam(n):
+    if n.startswith("focal_gemm_ring"): return "gemm_ring"
     if n.startswith("focal_gemm_pipe"): return "gemm_pipe"
-    if n.startswith(("focal_dw_ring", "focal_dw_group")): return "gemm dW"
+    if n.startswith(("focal_dw_ring", "focal_dw_group", "focal_dw_tail_group")): return "gemm dW"
     if n.startswith("focal_gemm_kernel"):
         return "gemm dW" if ", true, true," in n else "gemm fwd/dX 64x64"
     for k in ("mlp_bwd", "mlp_fwd", "swin_attn_branch_bwd", "swin_attn_branch_fwd", "ln_bwd", "ln_fwd", "window_attn_bwd", "window_attn_fwd", "patch_embed", "fft_", "adamw", "mask_cast",
