@@ -104,9 +104,11 @@ __global__ __launch_bounds__(256) void patch_embed_ln_kernel(const float* __rest
       if (tok < total_tokens) {
 #pragma unroll
         for (int n = 0; n < CPT; n += 4) {
+          const float4 g2 = *reinterpret_cast<const float4*>(l2.gamma + q * CPT + n), b2 = *reinterpret_cast<const float4*>(l2.beta + q * CPT + n);
+          const float ga2[4] = {g2.x, g2.y, g2.z, g2.w}, ba2[4] = {b2.x, b2.y, b2.z, b2.w};
           float y[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = (acc[n + e] - m2) * r2 * l2.gamma[q * CPT + n + e] + l2.beta[q * CPT + n + e];
+          for (int e = 0; e < 4; ++e) y[e] = (acc[n + e] - m2) * r2 * ga2[e] + ba2[e];
           if (l2.bf16) emb_store4(reinterpret_cast<bf16_t*>(l2.y) + (long)tok * C0 + q * CPT + n, y);
           else emb_store4(reinterpret_cast<float*>(l2.y) + (long)tok * C0 + q * CPT + n, y);
         }
@@ -206,9 +208,12 @@ __global__ __launch_bounds__(256) void patch_embed_ln_mfma_kernel(const float* _
       if (tok < total_tokens) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
+          // (16-byte loads: as 32 one-dword loads per tile these were the kernel's largest group of memory instructions)
+          const float4 g2 = *reinterpret_cast<const float4*>(l2.gamma + 16 * nt + 4 * lg), b2 = *reinterpret_cast<const float4*>(l2.beta + 16 * nt + 4 * lg);
+          const float ga2[4] = {g2.x, g2.y, g2.z, g2.w}, ba2[4] = {b2.x, b2.y, b2.z, b2.w};
           float y[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) y[r] = (acc[nt][r] - m2) * r2 * l2.gamma[16 * nt + 4 * lg + r] + l2.beta[16 * nt + 4 * lg + r];
+          for (int r = 0; r < 4; ++r) y[r] = (acc[nt][r] - m2) * r2 * ga2[r] + ba2[r];
           if (l2.bf16) emb_store4(reinterpret_cast<bf16_t*>(l2.y) + (long)tok * 64 + 16 * nt + 4 * lg, y);
           else emb_store4(reinterpret_cast<float*>(l2.y) + (long)tok * 64 + 16 * nt + 4 * lg, y);
         }
