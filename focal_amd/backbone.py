@@ -110,6 +110,8 @@ class StageFn(torch.autograd.Function):
         x.record_stream(torch.cuda.current_stream(x.device))
         y, saved = engine.forward(x, *args)
         ctx.engine, ctx.saved = engine, saved
+        # the stream the caller of the backbone works on (set by forward_encoder around a stage that runs on a side stream): see backward
+        ctx.caller_stream = getattr(engine, "caller_stream", None)
         return y
 
     @staticmethod
@@ -118,6 +120,16 @@ class StageFn(torch.autograd.Function):
         dy.record_stream(torch.cuda.current_stream(dy.device))  # produced by the loss head on the caller's stream
         dx = ctx.engine.backward(ctx.saved, dy)
         ctx.saved = None
+        # The parameter gradients were written straight into the arena on THIS stream (the stage's forward stream).  Autograd orders the
+        # caller's stream behind the streams of the leaves that received a gradient through it -- none here (the anchor gets None) -- so a
+        # caller that reads p.grad right after backward() raced the last kernels of a side-stream encoder (round 5: the partially summed
+        # norm1 gradient of the seismic encoder's first block, 1 run in 24 of tests/test_swt_parity_gpu.py's finite-difference check).
+        # The optimizer joins every side stream itself; this makes plain `loss.backward(); p.grad` correct as well.  No kernel: an event.
+        cs = ctx.caller_stream
+        if cs is not None:
+            cur = torch.cuda.current_stream(dy.device)
+            if cs != cur:
+                cs.wait_stream(cur)
         return None, dx, None, None
 
 

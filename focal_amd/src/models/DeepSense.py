@@ -135,6 +135,7 @@ class DeepSense(HipBackbone):
         # encoder has left its convolution stack (the last BatchNorm), see deepsense_engine.forward.
         # (view_index: FOCAL.forward numbers its two backbone calls 0 / 1; any other caller runs one stream per modality)
         view_streams = view_index is not None and self.training
+        self.arena()  # built (and its bf16 shadow filled) on the caller's stream before any encoder stream forks from it
         if view_index in (None, 0):
             for enc in self._encoders.values():
                 enc.prepare_packs()  # re-ordered weights for both views' passes: one launch per encoder, before the streams fork
@@ -146,6 +147,7 @@ class DeepSense(HipBackbone):
             # with one stream per (view, modality) no encoder runs on the caller's stream (index 0): view 2's forks would otherwise
             # wait for the view-1 pass that was enqueued there
             st = runtime.fork_from(dev, (view_index * len(self.modalities) + 1 if view_streams else 0) + mi, point)
+            self._encoders[(loc, mod)].caller_stream = self._heads[mod].caller_stream = cur
             with torch.cuda.stream(st):
                 self._encoders[(loc, mod)].pass_order = view_index if view_streams else None
                 self._encoders[(loc, mod)].views_in_batch = views_in_batch if self.training else 1

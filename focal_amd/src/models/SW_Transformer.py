@@ -126,6 +126,10 @@ class SW_Transformer(HipBackbone):
             raise FocalHipError("the FOCAL HIP path needs the model on a ROCm device (no CPU fallback)")
         cur = torch.cuda.current_stream(dev)
         out = {}
+        # The parameter arena (and its bf16 shadow) must exist BEFORE the fork point: built lazily inside the first encoder's pass it was
+        # filled on that encoder's stream AFTER the point the other encoders start from, and on a fresh model they could read a zero arena
+        # (round 5: test_train_step_loss_and_gradients[bf16] saw an all-zero seismic embedding in 2 of 16 fresh processes).
+        self.arena()
         point = runtime.fork_point(dev)  # every encoder starts from here: none waits for the one launched before it
         # The heaviest modality is enqueued first: the order of enqueueing is the order of the nodes in the captured step, and what the
         # runtime dispatches first gets a head start on the stream that ends the step (audio has 2/3 of the MOD step's work).  Autograd
@@ -142,6 +146,7 @@ class SW_Transformer(HipBackbone):
             # profiles/r3_encoder_streams_ab.txt)
             slot = 0 if self.views_share_pass else view % 2
             st = runtime.fork_from(dev, slot * len(self.modalities) + mi, point)
+            self._encoders[(loc, mod)].caller_stream = self._heads[mod].caller_stream = cur
             with torch.cuda.stream(st):
                 f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
                 out[mod] = run_stage(self, self._heads[mod], f) if proj_head else f
