@@ -195,6 +195,13 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
     net = SW_Transformer(args)
     fill_state_dict_(net.state_dict())
     net = net.to("cuda").train()
+    # A FIXED device seed (round 5).  The process's seed word is drawn from os.urandom, so every run of this test differentiated a different
+    # mask realisation -- and the function is strongly curved along the random directions at this step size (the evidence the test kept of
+    # a miss: f(p + eps d) and f(p - eps d) BOTH 2-3 x (eps x derivative) below f(p)); for about one realisation in 25 the central
+    # difference's own truncation error exceeded the 3 % bound on one parameter, the same quotient on every repeat, the analytic gradient of
+    # a second backward pass unchanged.  That was the "flake" hunted since round 2 (profiles/r3_fd_outlier.txt, r5_stream_races.txt).
+    from focal_amd import runtime
+    runtime.rng_state(torch.device("cuda"), seed=int(os.environ.get("FOCAL_TEST_FD_SEED", "20260605")))
     x1, _ = inputs(cfg, B=4)
     r = {m: torch.randn(4, 256, device="cuda", generator=torch.Generator("cuda").manual_seed(i)) for i, m in enumerate(cfg["modality_names"])}
 
@@ -223,7 +230,7 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
     # check is single again (one repeat per side as the tripwire); should an evaluation ever disagree with its repeat, the evidence --
     # every value, the pre-update value, the perturbation's own size -- is written down before more evaluations settle the quotient.
     from conftest import record_observed
-    worst_repeat = 0.0
+    worst_repeat = worst_margin = 0.0
     for i, n in enumerate(names):
         p = params[n]
         d = torch.randn(p.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(100 + i))
@@ -283,8 +290,11 @@ def test_dropout_on_backward_matches_forward_masks(cfg):
             json.dump(old_ev + [ev], open(path, "w"), indent=1)
             record_observed("swt.fd_dropout.quotient_retries", len([e for e in old_ev + [ev] if e.get("kind") == "quotient"]))
             num, ana = num2, ana2
+        worst_margin = max(worst_margin, abs(num - ana) / tol(ana, num))
         assert abs(num - ana) < tol(ana, num), (n, num, ana, noise, eps)
     record_observed("swt.fd_dropout.worst_repeat_over_noise", worst_repeat)
+    record_observed("swt.fd_dropout.worst_miss_over_tolerance", worst_margin)
+    print(f"fd worst |num - ana| / tol = {worst_margin:.3f}")
 
 
 @pytest.mark.parametrize("ct", ["fp32", "bf16"])
