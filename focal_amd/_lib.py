@@ -15,7 +15,7 @@ EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
 BN_STAT_SLOTS = 16      # focal_conv_fwd_bn: column sums are spread over this many slots of the scratch
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class DropDesc(C.Structure):
@@ -112,7 +112,7 @@ class BNDesc(C.Structure):
 
 
 class GRUDesc(C.Structure):
-    _fields_ = [("B", C.c_int), ("T", C.c_int), ("H", C.c_int)]
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("whh_frag", C.c_int)]
 
 
 class AdamWDesc(C.Structure):

@@ -508,9 +508,20 @@ template <typename TD> __global__ void pack_multi_kernel(PackTable t) {
     if (q.kind == FOCAL_PACK_PERMUTE) {          // dst[a][c][b] = src[a][b][c]
       const int b = e % q.B, c = (e / q.B) % q.C, a = e / ((long)q.B * q.C);
       dst[e] = from_f32<TD>(src[((long)a * q.B + b) * q.C + c]);
-    } else {                                     // FOCAL_PACK_CONV_BWD: dst[ci][t][co] = src[co][ci][k-1-t]  (A = Co, B = Ci, C = k)
+    } else if (q.kind == FOCAL_PACK_CONV_BWD) {  // dst[ci][t][co] = src[co][ci][k-1-t]  (A = Co, B = Ci, C = k)
       const int co = e % q.A, tt = (e / q.A) % q.C, ci = e / ((long)q.A * q.C);
       dst[e] = from_f32<TD>(src[((long)co * q.B + ci) * q.C + (q.C - 1 - tt)]);
+    } else {
+      // FOCAL_PACK_FRAG / _FRAG_T: the [R][Cc] matrix m (= src, or its transpose) in MFMA-fragment order -- e enumerates dst:
+      // e = ((tile_r * (Cc / 32) + ks) * 64 + lane) * 8 + j   <->   m[16 tile_r + lane % 16][32 ks + 8 (lane / 16) + j]
+      const bool tr = q.kind == FOCAL_PACK_FRAG_T;
+      const int R = tr ? q.B : q.A, Cc = tr ? q.A : q.B;
+      const int j = e & 7, lane = (e >> 3) & 63;
+      const long frag = e >> 9;
+      const int ks = (int)(frag % (Cc / 32)), tile_r = (int)(frag / (Cc / 32));
+      const int r = 16 * tile_r + (lane & 15), c = 32 * ks + 8 * (lane >> 4) + j;
+      (void)R;
+      dst[e] = from_f32<TD>(tr ? src[(long)c * q.B + r] : src[(long)r * q.B + c]);
     }
   }
 }
@@ -529,8 +540,10 @@ static int pack_table(int n, const focal_pack_entry* e, PackTable* t, long* most
   t->n = n;
   *most = 0;
   for (int i = 0; i < n; ++i) {
-    FOCAL_CHECK_ARG(e[i].src && e[i].dst && e[i].A > 0 && e[i].B > 0 && e[i].C > 0 && (e[i].kind == FOCAL_PACK_PERMUTE || e[i].kind == FOCAL_PACK_CONV_BWD),
+    FOCAL_CHECK_ARG(e[i].src && e[i].dst && e[i].A > 0 && e[i].B > 0 && e[i].C > 0 && e[i].kind >= FOCAL_PACK_PERMUTE && e[i].kind <= FOCAL_PACK_FRAG_T,
                     "pack_multi: bad entry %d", i);
+    if (e[i].kind == FOCAL_PACK_FRAG) FOCAL_CHECK_ARG(e[i].C == 1 && e[i].A % 16 == 0 && e[i].B % 32 == 0, "pack_multi: entry %d: fragment order needs [16 m][32 n], C = 1", i);
+    if (e[i].kind == FOCAL_PACK_FRAG_T) FOCAL_CHECK_ARG(e[i].C == 1 && e[i].B % 16 == 0 && e[i].A % 32 == 0, "pack_multi: entry %d: transposed fragment order needs [32 m][16 n], C = 1", i);
     t->e[i] = e[i];
     const long cnt = (long)e[i].A * e[i].B * e[i].C;
     if (cnt > *most) *most = cnt;

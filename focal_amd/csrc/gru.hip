@@ -149,7 +149,9 @@ __global__ __launch_bounds__(NW * 64) void gru_seq_fwd_kernel(focal_gru_desc gd,
     for (int q = 0; q < QT; ++q)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const gbf16x8 w = *reinterpret_cast<const gbf16x8*>(p.whh + (long)(g * H + jw + 16 * q + lm) * H + 32 * ks + 8 * lg);
+        // (fragment order, focal_gru_desc.whh_frag: row tile g H / 16 + wave QT + q, k-step ks -> one contiguous KB per load instruction)
+        const gbf16x8 w = gd.whh_frag ? *reinterpret_cast<const gbf16x8*>(p.whh + (((long)(g * (H / 16) + wave * QT + q) * KS + ks) * 64 + lane) * 8)
+                                      : *reinterpret_cast<const gbf16x8*>(p.whh + (long)(g * H + jw + 16 * q + lm) * H + 32 * ks + 8 * lg);
         if (g == 2) wl[((wave * QT + q) * KS + ks) * 64 + lane] = w;
         else if (g == 1 && ks >= KS - XS) wx[((wave * QT + q) * XS + ks - (KS - XS)) * 64 + lane] = w;
         else wreg[g][q][ks] = w;
@@ -268,7 +270,8 @@ __global__ __launch_bounds__(NW * 64) void gru_seq_bwd_kernel(focal_gru_desc gd,
   for (int q = 0; q < QT; ++q)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const gbf16x8 w = *reinterpret_cast<const gbf16x8*>(p.whh_t + (long)(jw + 16 * q + lm) * 3 * H + 32 * ks + 8 * lg);
+      const gbf16x8 w = gd.whh_frag ? *reinterpret_cast<const gbf16x8*>(p.whh_t + (((long)(wave * QT + q) * KS + ks) * 64 + lane) * 8)
+                                    : *reinterpret_cast<const gbf16x8*>(p.whh_t + (long)(jw + 16 * q + lm) * 3 * H + 32 * ks + 8 * lg);
       if (ks < KR) wreg[q][ks] = w;
       else wl[((wave * QT + q) * (KS - KR) + ks - KR) * 64 + lane] = w;
     }

@@ -67,11 +67,19 @@ class DeepSenseModEncoder:
         n_out = geo["C_out"]
         entries.append((ar.master(f"{self.pre}.conv_layer_out.weight"), dst(("out",), (n_out, S, C)), n_out, C, S, ops.PACK_PERMUTE))
         if ct == torch.bfloat16 and H in (128, 256):
+            # W_hh for the sequence kernels in MFMA-fragment order (round 5: their prologue then loads one contiguous KB per instruction
+            # instead of sixteen 64-byte row segments): [3H, H] for the forward recurrence, its transpose [H, 3H] for the backward one
+            rowmajor = os.environ.get("FOCAL_GRU_WHH_ROWMAJOR") == "1"  # (same-box A/B: the round-4 operands)
             for layer in range(geo["n_rnn"]):
                 for suf in ("", "_reverse"):
-                    entries.append((ar.master(f"{self.rnn}.weight_hh_l{layer}{suf}"), dst(("whh", layer, suf), (1, H, 3 * H)), 1, 3 * H, H, ops.PACK_PERMUTE))
-        for lo in range(0, len(entries), 16):
-            ops.pack_multi(entries[lo:lo + 16], ct)
+                    w = ar.master(f"{self.rnn}.weight_hh_l{layer}{suf}")
+                    if rowmajor:
+                        entries.append((w, dst(("whh", layer, suf), (1, H, 3 * H)), 1, 3 * H, H, ops.PACK_PERMUTE))
+                        continue
+                    entries.append((w, dst(("whh_frag", layer, suf), (3 * H * H,)), 3 * H, H, 1, ops.PACK_FRAG))
+                    entries.append((w, dst(("whh_t_frag", layer, suf), (3 * H * H,)), 3 * H, H, 1, ops.PACK_FRAG_T))
+        for lo in range(0, len(entries), ops.PACK_MAX):
+            ops.pack_multi(entries[lo:lo + ops.PACK_MAX], ct)
         self._packs = store
 
     def _packed(self, key, make):
@@ -211,7 +219,10 @@ class DeepSenseModEncoder:
                 lsv["dirs"].append(dict(names=(wih, whh, bih, bhh), d_ih=d_ih, d_hh=d_hh, hs=hs, save=save, gi=gi))
             if seq:
                 dirs = lsv["dirs"]
-                ops.gru_seq_fwd(gd, [d["gi"] for d in dirs], [ar.operand(d["names"][1]) for d in dirs],
+                packs = getattr(self, "_packs", None) or {}
+                frag = all(("whh_frag", layer, suf) in packs for suf in ("", "_reverse"))
+                whh = [packs[("whh_frag", layer, suf)] for suf in ("", "_reverse")] if frag else [ar.operand(d["names"][1]) for d in dirs]
+                ops.gru_seq_fwd(ops.GRUDesc(B, T, H, 1 if frag else 0), [d["gi"] for d in dirs], whh,
                                 [ar.master(d["names"][3]) for d in dirs], [d["hs"] for d in dirs], [d["save"] for d in dirs], out)
             for d in lsv["dirs"]:
                 del d["gi"]
@@ -254,10 +265,15 @@ class DeepSenseModEncoder:
                 bufs.append((dgi, dgh))
             if lsv["seq"]:
                 dirs = lsv["dirs"]
-                whh_t = [self._packed(("whh", layer, suf), lambda d=d: ops.permute_pack(ar.master(d["names"][1]), 1, 3 * H, H, ct))
-                         for d, suf in zip(dirs, ("", "_reverse"))]  # [H][3H] bf16
-                ops.gru_seq_bwd(gd, dout, ld_b, ld_t, scale, whh_t, [d["hs"] for d in dirs], [d["save"] for d in dirs],
-                                [b_[0] for b_ in bufs], [b_[1] for b_ in bufs])
+                packs = getattr(self, "_packs", None) or {}
+                frag = all(("whh_t_frag", layer, suf) in packs for suf in ("", "_reverse"))
+                if frag:  # W_hh^T in fragment order (prepare_packs)
+                    whh_t = [packs[("whh_t_frag", layer, suf)] for suf in ("", "_reverse")]
+                else:     # row-major [H][3H] bf16: FOCAL_GRU_WHH_ROWMAJOR's packs, or made on the spot (a caller that runs a pass on its own)
+                    whh_t = [self._packed(("whh", layer, suf), lambda d=d: ops.permute_pack(ar.master(d["names"][1]), 1, 3 * H, H, ct))
+                             for d, suf in zip(dirs, ("", "_reverse"))]
+                ops.gru_seq_bwd(ops.GRUDesc(B, T, H, 1 if frag else 0), dout, ld_b, ld_t, scale, whh_t, [d["hs"] for d in dirs],
+                                [d["save"] for d in dirs], [b_[0] for b_ in bufs], [b_[1] for b_ in bufs])
             for di, dsv in enumerate(lsv["dirs"]):
                 wih, whh, bih, bhh = dsv["names"]
                 hs, save = dsv["hs"], dsv["save"]

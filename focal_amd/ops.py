@@ -686,7 +686,8 @@ def permute_unpack_add(src, dst, A, Bd, Cd):
     check(_lib.load().focal_permute_unpack_add(A, Bd, Cd, _p(src), _p(dst), _stream()))
 
 
-PACK_PERMUTE, PACK_CONV_BWD = 0, 1
+PACK_PERMUTE, PACK_CONV_BWD, PACK_FRAG, PACK_FRAG_T = 0, 1, 2, 3
+PACK_MAX = 24
 
 
 def pack_multi(entries, dtype):

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* 7: launch trace (focal_trace_*), focal_adamw_multi_advance takes the step-state length; 2: BatchNorm scratch of 2C + 1 floats; 3: fused MLP, warps, Mixup; 4: row-sharded loss head, weight-gradient launch queries */
-#define FOCAL_ABI_VERSION 10
+#define FOCAL_ABI_VERSION 11
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -362,8 +362,11 @@ int focal_conv_pack_bwd(const focal_conv_desc* d, const float* w, void* w_bwd, v
 /* Several re-orderings in one launch (an encoder's 13 per pass): kind FOCAL_PACK_PERMUTE = focal_permute_pack's dst[a][c][b] = src[a][b][c]
  * (A, B, C as there), FOCAL_PACK_CONV_BWD = focal_conv_pack_bwd's dst[ci][t][co] = src[co][ci][k-1-t] with (A, B, C) = (C_out, C_in, k);
  * src fp32, dst `dtype`.  focal_unpack_add_multi: dst[a][b][c] += src[a][c][b] per entry (fp32; focal_permute_unpack_add). */
-enum { FOCAL_PACK_PERMUTE = 0, FOCAL_PACK_CONV_BWD = 1 };
-#define FOCAL_PACK_MAX 16
+enum { FOCAL_PACK_PERMUTE = 0, FOCAL_PACK_CONV_BWD = 1, FOCAL_PACK_FRAG = 2, FOCAL_PACK_FRAG_T = 3 };
+/* FOCAL_PACK_FRAG: the matrix src[A][B] (C = 1; A % 16 == 0, B % 32 == 0) in MFMA-fragment order:
+ *   dst[((r / 16) * (B / 32) + c / 32) * 512 + ((c % 32) / 8 * 16 + r % 16) * 8 + c % 8] = src[r][c];
+ * FOCAL_PACK_FRAG_T: the same of its TRANSPOSE m[r][c] = src[c][r] (an [B][A] matrix: B % 16 == 0, A % 32 == 0). */
+#define FOCAL_PACK_MAX 24
 typedef struct { const void* src; void* dst; int A, B, C; int kind; } focal_pack_entry;
 int focal_pack_multi(int dtype, int n, const focal_pack_entry* entries, void* stream);
 int focal_unpack_add_multi(int n, const focal_pack_entry* entries, void* stream);
@@ -421,7 +424,11 @@ int focal_bn_act_bwd(const focal_bn_desc* d, const float* z, const float* g, con
  * focal_linear_*; these are the per-step gate kernels.  gi: [B*T, 3H] (rows (b, t), b_ih included), gh: [B, 3H] (b_hh
  * included), out: [B, T, 2H], save: [4][B][H] per step (r, z, n, W_hn h + b_hn).
  * bwd: dh = scale * dout[b*ld_b + t*ld_t + dir_offset + j] + dh_rec + dhz_in; writes dgi rows (b, t), dgh [B, 3H], dhz_out. */
-typedef struct { int B, T, H; } focal_gru_desc;
+typedef struct { int B, T, H; int whh_frag; } focal_gru_desc;
+/* whh_frag (focal_gru_seq_fwd / _bwd only; 0 = as documented below): the W_hh operands are given in MFMA-fragment order instead of
+ * row-major -- 16-row x 32-column tiles, tile-major, inside a tile the 64 lanes' 16-byte pieces back to back
+ * (FOCAL_PACK_FRAG / FOCAL_PACK_FRAG_T of focal_pack_multi): every load instruction of the kernels' prologue then reads one contiguous KB
+ * instead of sixteen 64-byte row segments. */
 int focal_gru_gate_fwd(const focal_gru_desc* d, int t, int dir_offset, const float* gi, const float* gh, const float* h_prev,
                        float* h_new, float* out, float* save, void* stream);
 int focal_gru_gate_bwd(const focal_gru_desc* d, int t, int dir_offset, const float* dout, long ld_b, long ld_t, float scale,

@@ -1077,6 +1077,34 @@ def test_gru_whole_sequence_kernels_match_per_step_path(ops, B, H):
                 have = True
         assert rel_err(got[di][0], dgi) < 5e-3, di
         assert rel_err(got[di][1], dgh) < 5e-3, di
+    # round 5: W_hh handed over in MFMA-fragment order (focal_pack_multi FOCAL_PACK_FRAG / _FRAG_T, focal_gru_desc.whh_frag): the same
+    # fragments in the same registers -- bit-identical results
+    frag = [torch.empty(3 * H * H, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    frag_t = [torch.empty(3 * H * H, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    ops.pack_multi([(whh[d], frag[d], 3 * H, H, 1, ops.PACK_FRAG) for d in range(2)] + [(whh[d], frag_t[d], 3 * H, H, 1, ops.PACK_FRAG_T) for d in range(2)],
+                   torch.bfloat16)
+    # the packed layout itself, against its definition
+    m = w16[0]
+    r, c = torch.meshgrid(torch.arange(3 * H, device=DEV), torch.arange(H, device=DEV), indexing="ij")
+    idx = ((r // 16) * (H // 32) + c // 32) * 512 + ((c % 32) // 8 * 16 + r % 16) * 8 + c % 8
+    want = torch.empty_like(frag[0])
+    want[idx.reshape(-1)] = m.reshape(-1)
+    assert torch.equal(frag[0], want)
+    mt = w16[0].t().contiguous()
+    r, c = torch.meshgrid(torch.arange(H, device=DEV), torch.arange(3 * H, device=DEV), indexing="ij")
+    idx = ((r // 16) * (3 * H // 32) + c // 32) * 512 + ((c % 32) // 8 * 16 + r % 16) * 8 + c % 8
+    want[idx.reshape(-1)] = mt.reshape(-1)
+    assert torch.equal(frag_t[0], want)
+    gdf = ops.GRUDesc(B, T, H, 1)
+    out_f = torch.zeros(B, T, 2 * H, device=DEV)
+    hs_f = [torch.zeros(T + 1, B, H, device=DEV) for _ in range(2)]
+    save_f = [torch.empty(T, 4, B, H, device=DEV) for _ in range(2)]
+    ops.gru_seq_fwd(gdf, gi, frag, bhh, hs_f, save_f, out_f)
+    assert torch.equal(out_f, out) and all(torch.equal(a, b) for a, b in zip(hs_f, hs)) and all(torch.equal(a, b) for a, b in zip(save_f, save))
+    got_f = [(torch.empty(B * T, 3 * H, device=DEV), torch.empty(T, B, 3 * H, device=DEV)) for _ in range(2)]
+    ops.gru_seq_bwd(gdf, dout, ld_b, ld_t, 1.0, frag_t, ref["hs"], ref["save"], [g[0] for g in got_f], [g[1] for g in got_f])
+    for di in range(2):
+        assert torch.equal(got_f[di][0], got[di][0]) and torch.equal(got_f[di][1], got[di][1])
 
 
 @pytest.mark.parametrize("name", ["negation", "scaling", "horizontal_flip", "permutation", "phase_shift"])
