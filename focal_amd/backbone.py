@@ -101,6 +101,14 @@ class HipBackbone(nn.Module):
         return torch.zeros(1, device=device, requires_grad=True)
 
 
+def _join_after_backward(device):
+    """When the autograd engine has run every node of this backward pass, the thread that called backward() makes its current stream
+    wait for all encoder side streams (runtime.join_all: event waits).  Queued by every stage node: a few redundant waits per pass, no
+    state that an exception inside a backward pass could leave behind."""
+    key = torch.device(device)
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: runtime.join_all(key))
+
+
 class StageFn(torch.autograd.Function):
     """One autograd node around an engine object exposing forward(x, ...)->(y, saved) / backward(saved, dy)->dx|None."""
 
@@ -110,8 +118,6 @@ class StageFn(torch.autograd.Function):
         x.record_stream(torch.cuda.current_stream(x.device))
         y, saved = engine.forward(x, *args)
         ctx.engine, ctx.saved = engine, saved
-        # the stream the caller of the backbone works on (set by forward_encoder around a stage that runs on a side stream): see backward
-        ctx.caller_stream = getattr(engine, "caller_stream", None)
         return y
 
     @staticmethod
@@ -122,14 +128,11 @@ class StageFn(torch.autograd.Function):
         ctx.saved = None
         # The parameter gradients were written straight into the arena on THIS stream (the stage's forward stream).  Autograd orders the
         # caller's stream behind the streams of the leaves that received a gradient through it -- none here (the anchor gets None) -- so a
-        # caller that reads p.grad right after backward() raced the last kernels of a side-stream encoder (round 5: the partially summed
-        # norm1 gradient of the seismic encoder's first block, 1 run in 24 of tests/test_swt_parity_gpu.py's finite-difference check).
-        # The optimizer joins every side stream itself; this makes plain `loss.backward(); p.grad` correct as well.  No kernel: an event.
-        cs = ctx.caller_stream
-        if cs is not None:
-            cur = torch.cuda.current_stream(dy.device)
-            if cs != cur:
-                cs.wait_stream(cur)
+        # caller that reads p.grad right after backward() raced the last kernels of a side-stream encoder (round 5).  The optimizer joins
+        # every side stream itself; a callback at the END of the backward pass does it for everybody else: an event wait, no kernel.  (Not
+        # a wait per stage: the caller's stream carries the first modality's own backward pass, which would then queue behind every other
+        # modality's -- measured -7 % on the four-modality HAR4 step.)
+        _join_after_backward(dy.device)
         return None, dx, None, None
 
 

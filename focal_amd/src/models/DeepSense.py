@@ -147,7 +147,6 @@ class DeepSense(HipBackbone):
             # with one stream per (view, modality) no encoder runs on the caller's stream (index 0): view 2's forks would otherwise
             # wait for the view-1 pass that was enqueued there
             st = runtime.fork_from(dev, (view_index * len(self.modalities) + 1 if view_streams else 0) + mi, point)
-            self._encoders[(loc, mod)].caller_stream = self._heads[mod].caller_stream = cur
             with torch.cuda.stream(st):
                 self._encoders[(loc, mod)].pass_order = view_index if view_streams else None
                 self._encoders[(loc, mod)].views_in_batch = views_in_batch if self.training else 1

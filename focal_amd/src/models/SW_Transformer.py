@@ -146,7 +146,6 @@ class SW_Transformer(HipBackbone):
             # profiles/r3_encoder_streams_ab.txt)
             slot = 0 if self.views_share_pass else view % 2
             st = runtime.fork_from(dev, slot * len(self.modalities) + mi, point)
-            self._encoders[(loc, mod)].caller_stream = self._heads[mod].caller_stream = cur
             with torch.cuda.stream(st):
                 f = run_stage(self, self._encoders[(loc, mod)], freq_x[loc][mod], view, self.training)
                 out[mod] = run_stage(self, self._heads[mod], f) if proj_head else f
