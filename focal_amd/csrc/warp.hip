@@ -159,6 +159,8 @@ __global__ __launch_bounds__(WT_THREADS) void warp_curve_kernel(const WarpTable 
   __shared__ double xk[FOCAL_VIEW_MAX_KNOTS], yk[FOCAL_VIEW_MAX_KNOTS], sk[FOCAL_VIEW_MAX_KNOTS], c2[FOCAL_VIEW_MAX_KNOTS], c3[FOCAL_VIEW_MAX_KNOTS];
   __shared__ double Am[FOCAL_VIEW_MAX_KNOTS][FOCAL_VIEW_MAX_KNOTS + 1];
   __shared__ double part[WT_THREADS];
+  __shared__ double hk[FOCAL_VIEW_MAX_KNOTS], slk[FOCAL_VIEW_MAX_KNOTS], fcol[FOCAL_VIEW_MAX_KNOTS];
+  __shared__ int pivot_row;
   const int tid = threadIdx.x, n = plan->nknots;
   if (tid == 0) {
     // knot abscissae: numpy.linspace(-L, 2 L - 1, n, dtype=int) = floor(arange(n) * step + start) (integer linspace floors since
@@ -183,25 +185,41 @@ __global__ __launch_bounds__(WT_THREADS) void warp_curve_kernel(const WarpTable 
     d = xk[n - 1] - xk[n - 3];
     Am[n - 1][n - 1] = h[n - 3]; Am[n - 1][n - 2] = d;
     Am[n - 1][n] = (h[n - 2] * h[n - 2] * slope[n - 3] + (2.0 * d + h[n - 2]) * h[n - 3] * slope[n - 2]) / d;
-    for (int c = 0; c < n; ++c) {  // Gaussian elimination with partial pivoting
-      int piv = c;
-      for (int r = c + 1; r < n; ++r)
-        if (fabs(Am[r][c]) > fabs(Am[piv][c])) piv = r;
-      if (piv != c)
-        for (int j = c; j <= n; ++j) { const double tmp = Am[c][j]; Am[c][j] = Am[piv][j]; Am[piv][j] = tmp; }
-      for (int r = c + 1; r < n; ++r) {
-        const double f = Am[r][c] / Am[c][c];
-        for (int j = c; j <= n; ++j) Am[r][j] -= f * Am[c][j];
+    for (int i = 0; i < n - 1; ++i) { hk[i] = h[i]; slk[i] = slope[i]; }
+  }
+  __syncthreads();
+  // Gaussian elimination with partial pivoting, the row operations spread over the workgroup (thread -> (row, column) of the augmented
+  // matrix): the same arithmetic per element as one thread walking the LDS-resident matrix, which took 25-35 us of dependent LDS round
+  // trips on the serial head of every step with random views (round 5: warp_curve_kernel 37-53 us -> see profiles/r5_views_random.txt).
+  {
+    constexpr int W = FOCAL_VIEW_MAX_KNOTS + 1;
+    const int er = tid / W, ej = tid % W;
+    for (int c = 0; c < n; ++c) {
+      if (tid == 0) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r)
+          if (fabs(Am[r][c]) > fabs(Am[piv][c])) piv = r;
+        pivot_row = piv;
       }
+      __syncthreads();
+      const int piv = pivot_row;
+      if (piv != c && tid >= c && tid <= n) { const double tmp = Am[c][tid]; Am[c][tid] = Am[piv][tid]; Am[piv][tid] = tmp; }
+      __syncthreads();
+      if (tid > c && tid < n) fcol[tid] = Am[tid][c] / Am[c][c];
+      __syncthreads();
+      if (er > c && er < n && ej >= c && ej <= n) Am[er][ej] -= fcol[er] * Am[c][ej];
+      __syncthreads();
     }
+  }
+  if (tid == 0) {
     for (int r = n - 1; r >= 0; --r) {
       double acc = Am[r][n];
       for (int j = r + 1; j < n; ++j) acc -= Am[r][j] * sk[j];
       sk[r] = acc / Am[r][r];
     }
     for (int i = 0; i < n - 1; ++i) {
-      c2[i] = (3.0 * slope[i] - 2.0 * sk[i] - sk[i + 1]) / h[i];
-      c3[i] = (sk[i] + sk[i + 1] - 2.0 * slope[i]) / (h[i] * h[i]);
+      c2[i] = (3.0 * slk[i] - 2.0 * sk[i] - sk[i + 1]) / hk[i];
+      c3[i] = (sk[i] + sk[i + 1] - 2.0 * slk[i]) / (hk[i] * hk[i]);
     }
   }
   __syncthreads();
