@@ -248,6 +248,18 @@ def test_host_side_launch_plans_of_the_abi():
     assert lib.focal_linear_bwd_weight_kernel(C.byref(d)) == 1
     d = desc(18432, 1024, 256, f32, f32, f32)
     assert lib.focal_linear_bwd_weight_kernel(C.byref(d)) == 1
+    # round 5: several weight gradients with fp32 operands behind one problem table (DeepSense's GRU: W_hh [768, 256] and W_ih [768, 128 /
+    # 512] over 5 120 rows).  The launch's workgroup target is shared by the problems; a token slice is never shorter than 256 rows.
+    probs = (_lib.DwProblem * 4)()
+    for i, (M, N, K) in enumerate([(5120, 768, 256), (5120, 768, 128), (5120, 768, 512), (5120, 768, 256)]):
+        probs[i] = _lib.DwProblem(1, 1, 1, None, M, N, K, 0)   # (non-null placeholders: the plan touches no memory)
+    tiles = [12 * 4, 12 * 2, 12 * 8, 12 * 4]
+    wg = lib.focal_linear_bwd_weight_group_f32_workgroups(bf, 4, probs, 1024)       # 256 per problem -> splits 6, 11, 3, 6
+    assert wg == sum(t * s for t, s in zip(tiles, (6, 11, 3, 6)))
+    assert lib.focal_linear_bwd_weight_group_f32_workgroups(bf, 4, probs, 100000) == sum(t * 20 for t in tiles)   # 5 120 / 256 = 20 slices at most
+    assert lib.focal_linear_bwd_weight_group_f32_workgroups(bf, 9, probs, 0) == 0 and b"1 .. 8 problems" in lib.focal_last_error()
+    # BatchNorm statistic groups: the descriptor grew by one field (ABI 10), the GRU descriptor by one (ABI 11)
+    assert C.sizeof(_lib.BNDesc) == 56 and C.sizeof(_lib.GRUDesc) == 16 and lib.focal_abi_version() == 11
     ld = _lib.LossDesc(2, 2048, 256, 4, 0.07, 1.0, 1.0, 1.0, 3.0, 5.0, 0)  # config 4's global batch: b = 512 subsequences
     need = lib.focal_loss_head_workspace(C.byref(ld))
     assert need > 0
