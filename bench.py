@@ -658,6 +658,26 @@ def cpu_baseline(a, cfg):
     return out
 
 
+def gpu_clocks(device):
+    """sclk (MHz), mclk level and socket power (W) of this rank's GPU from sysfs, read OUTSIDE the timed region (one sample right before it,
+    one right after): tells a power- or clock-limited box from a fast one in the driver's record.  None where sysfs is not readable."""
+    import glob
+    try:
+        cards = [d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if os.path.exists(d + "/pp_dpm_sclk")]
+        d = cards[min(device.index or 0, len(cards) - 1)]
+
+        def rd(pat, div):
+            g = sorted(glob.glob(d + pat))
+            return int(open(g[0]).read().strip()) // div if g else None
+        mclk = [ln.split(":")[1].strip().rstrip("*").strip() for ln in open(d + "/pp_dpm_mclk") if "*" in ln]
+        power = rd("/hwmon/hwmon*/power1_input", 1000000)
+        return {"sclk_mhz": rd("/hwmon/hwmon*/freq1_input", 1000000), "mclk": mclk[0] if mclk else None,
+                "power_w": power if power is not None else rd("/hwmon/hwmon*/power1_average", 1000000),
+                "power_cap_w": rd("/hwmon/hwmon*/power1_cap", 1000000)}
+    except Exception:  # noqa: BLE001  (a diagnostic must not cost the line)
+        return None
+
+
 def timed_steps(a, step, world, rank, device, steps, warmup):
     """Capture (unless --no-graph), `warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides.
     Returns (seconds of this rank, whether graphs were replayed, the stream everything ran on)."""
@@ -689,9 +709,38 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
             def run():
                 step.feed_step_inputs()
                 inner()
+        # Every step ends with loss.item(), so host stamps after it are the steps' durations: the JSON line carries the whole series
+        # (`step_series`), warm-up included.  After the `warmup` requested steps the UNTIMED phase goes on until three consecutive steps
+        # agree to 1 % (cap 0.5 s): the first replays of a cold process run 3-10 % slow while clocks / power ramp (profiles/
+        # r6_warmup_transient.txt), and a 0.1 s timed region must not start inside that ramp.  The timed region below is untouched:
+        # exactly `steps` full steps.  `warmup_effective` = the untimed steps actually run.
+        series = step.series = {"warmup_ms": [], "settle_ms": [], "timed_ms": []}
+        tp = time.perf_counter()
         for _ in range(warmup):
             run()
             step.loss.item()
+            tn = time.perf_counter()
+            series["warmup_ms"].append(round((tn - tp) * 1e3, 3))
+            tp = tn
+        t_settle = tp
+        recent = series["warmup_ms"][-3:]
+        while os.environ.get("FOCAL_BENCH_NO_SETTLE") != "1" and warmup > 0:
+            more = not (len(recent) == 3 and max(recent) <= 1.01 * min(recent)) and (tp - t_settle) < 0.5
+            if world > 1:  # the ranks must leave this loop together (the step holds collectives)
+                f = torch.tensor([1 if more else 0], device=device, dtype=torch.int32)
+                dist.all_reduce(f, op=dist.ReduceOp.MAX)
+                more = bool(f.item())
+                tp = time.perf_counter()
+            if not more:
+                break
+            run()
+            step.loss.item()
+            tn = time.perf_counter()
+            series["settle_ms"].append(round((tn - tp) * 1e3, 3))
+            recent = (recent + [series["settle_ms"][-1]])[-3:]
+            tp = tn
+        series["warmup_effective"] = warmup + len(series["settle_ms"])
+        series["clocks_before_timed"] = gpu_clocks(device)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -699,6 +748,7 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
         t0 = time.perf_counter()
         lag = os.environ.get("FOCAL_BENCH_LAGGED_LOSS") == "1"  # diagnostic: read step k-1's loss after launching step k
         prev = None
+        stamps = [t0]
         for _ in range(steps):
             run()
             if lag:
@@ -707,11 +757,14 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
                 prev = step.loss.clone()
             else:
                 step.loss.item()  # the reference syncs on loss.item() every step (pretrain.py:74)
+            stamps.append(time.perf_counter())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        series["clocks_after_timed"] = gpu_clocks(device)
+        series["timed_ms"] = [round((b - a_) * 1e3, 3) for a_, b in zip(stamps[:-1], stamps[1:])]
         step.last_run = run
     return dt, graphed, side
 
@@ -763,11 +816,22 @@ def secondary_workloads(a, device):
 
 def main():
     a = parse()
+    test_backend = os.environ.get("FOCAL_BENCH_TEST_BACKEND")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: N fresh child ranks (focal_amd/launch.py, what `train.py -gpu=0,..,N-1` uses),
+        # spawned BEFORE any HIP call in this process (device_count() does not initialise the GPU); never a silent 1-GPU run
+        from focal_amd.launch import spawn_ranks
+        have = torch.cuda.device_count()
+        if have < a.gpus and not test_backend:
+            sys.exit(f"bench.py --gpus {a.gpus}: {have} GPU(s) visible.  Launch line on an {a.gpus}-GPU node: python -m torch.distributed.run --nnodes=1 "
+                     f"--nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {a.gpus} --steps {a.steps} --warmup {a.warmup}")
+        sys.exit(spawn_ranks(__file__, sys.argv[1:], list(range(a.gpus)), narrow_visible=not test_backend))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py --gpus {a.gpus} launched with WORLD_SIZE={world}: the two must agree (the JSON line's n_gpus is the number of ranks that ran)")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # test hook (tests/ and single-GPU boxes only): FOCAL_BENCH_TEST_BACKEND=gloo runs every rank on cuda:0 over gloo so
     # that the N>1 control flow can be exercised on a 1-GPU box; the driver's multi-GPU runs use RCCL, one GPU per rank.
-    test_backend = os.environ.get("FOCAL_BENCH_TEST_BACKEND")
     if test_backend:
         local = 0
     torch.cuda.set_device(local)
@@ -809,7 +873,7 @@ def main():
     if rank == 0:
         wps = a.batch * world * a.steps / dt
         out = {"metric": "pretrain windows/sec (whole node), FOCAL " + a.model, "value": round(wps, 1), "unit": "windows/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "warmup_effective": step.series.get("warmup_effective"), "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": f"{a.model} + FOCAL pretrain step, {a.batch} {a.dataset}-shaped {len(step.cfg['modality_names'])}-modality windows/GPU "
                                       f"(global batch {a.batch * world}), train mode, DFT + fwd x2 + loss + bwd + AdamW",
@@ -826,7 +890,7 @@ def main():
                "model_flops_frac_of_bf16_mfma_peak": (round(wps / world * flops_per_window(a.model, a.dataset) / (MFMA_BF16_PEAK_TF * 1e12), 5)
                                                        if flops_per_window(a.model, a.dataset) else None),
                "flops_per_window": flops_per_window(a.model, a.dataset),
-               "roofline": rl, "cpu_baseline": cb, "secondary": sec, "dp": dp}
+               "step_series": step.series, "roofline": rl, "cpu_baseline": cb, "secondary": sec, "dp": dp}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

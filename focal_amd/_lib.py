@@ -15,7 +15,7 @@ EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
 BN_STAT_SLOTS = 16      # focal_conv_fwd_bn: column sums are spread over this many slots of the scratch
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class DropDesc(C.Structure):
@@ -140,6 +140,7 @@ PROTOTYPES = {
     "focal_fft_realpack_multi": (C.c_int, [C.c_int, C.POINTER(FftProblem), P]),
     "focal_warp_fwd": (C.c_int, [C.c_int, C.c_int, P, P, P, P, C.c_int, P, P]),
     "focal_view_draw": (C.c_int, [C.POINTER(ViewPool), C.c_int, C.c_int, P, C.c_uint32, P, P]),
+    "focal_view_draw_shared": (C.c_int, [C.POINTER(ViewPool), C.c_int, C.c_int, P, C.c_uint32, P, P]),
     "focal_warp_plan_multi": (C.c_int, [C.c_int, C.POINTER(WarpProblem), P, P]),
     "focal_mixup_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, P, P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "focal_pad_patch_embed_ln_fwd": (C.c_int, [C.POINTER(EmbedDesc), P, P, P, P, P, P, P]),

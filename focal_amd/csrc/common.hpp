@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include "../../include/focal_hip.h"
 
 typedef __bf16 bf16_t;
@@ -201,3 +202,10 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// The warp a plan record asks for: 0 unless it names one AND carries the knots of one (a record with fewer than 4 knots is not something
+// focal_view_draw writes; every consumer -- the curve solve, the apply pass, the transform's source selection -- reads it through here)
+__device__ __forceinline__ int focal_plan_warp(const focal_view_plan* pl) {
+  const int w = pl->warp, n = pl->nknots;
+  return (w != 0 && n >= 4 && n <= FOCAL_VIEW_MAX_KNOTS) ? w : 0;
+}

@@ -262,6 +262,7 @@ extern "C" int focal_pad_patch_embed_ln2_fwd(const focal_embed_desc* d, const fl
                                              const float* gamma, const float* beta, float* tokens, const float* gamma2,
                                              const float* beta2, float eps2, int ln_dtype, void* y_ln, float* stats, void* stream) {
   FOCAL_CHECK_ARG(gamma2 && beta2 && y_ln && stats, "pad_patch_embed_ln2: null argument");
+  FOCAL_CHECK_ARG(((uintptr_t)gamma2 | (uintptr_t)beta2) % 16 == 0, "pad_patch_embed_ln2: gamma2 / beta2 are read as float4: 16-byte aligned pointers");
   FOCAL_CHECK_ARG(ln_dtype == FOCAL_F32 || ln_dtype == FOCAL_BF16, "pad_patch_embed_ln2: bad dtype %d", ln_dtype);
   const EmbedLn2 l2 = {gamma2, beta2, y_ln, stats, eps2, ln_dtype == FOCAL_BF16};
   return embed_launch(d, x, w, b, gamma, beta, tokens, l2, stream);

@@ -38,7 +38,7 @@ __device__ __forceinline__ AugLive aug_resolve(const AugParams& a, const float* 
     const focal_view_plan* pl = a.plan;
     v.scale = pl->aug.scale; v.pc = pl->aug.phase_cos; v.ps = pl->aug.phase_sin;
     v.flip = pl->aug.flip != 0; v.use_perm = pl->aug.use_perm != 0;
-    if (pl->warp != 0) v.x = a.x_alt;
+    if (focal_plan_warp(pl) != 0) v.x = a.x_alt;
     if (tid < FOCAL_AUG_MAX_INTERVALS) s_perm[tid] = pl->aug.perm[tid];
   } else if (tid < FOCAL_AUG_MAX_INTERVALS) {
     s_perm[tid] = a.perm[tid];

@@ -240,11 +240,11 @@ template <int RPS, int NST>
 static inline hipError_t focal_launch_dw_group(const DwGroupParams& gp, int wgs, hipStream_t stream) {
   constexpr int LDS_BYTES = NST * 4 * RPS * 128;
   auto kern = focal_dw_group_kernel<RPS, NST>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};  // (the grant is idempotent: two first callers may both issue it; the flag itself is race-free)
+  if (!attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   FOCAL_LAUNCH(kern, dim3(wgs), dim3(512), LDS_BYTES, stream, gp);
   return hipGetLastError();

@@ -270,11 +270,11 @@ template <int RPS, int NST, int HALVES>
 static inline hipError_t focal_launch_dw_ring_group(const DwRingGroupParams& gp, int wgs, hipStream_t stream) {
   constexpr int LDS_BYTES = HALVES * NST * RPS * 64 * 4;
   auto kern = focal_dw_ring_group_kernel<RPS, NST, HALVES>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};  // (the grant is idempotent: two first callers may both issue it; the flag itself is race-free)
+  if (!attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   FOCAL_LAUNCH(kern, dim3(wgs), dim3(256 * HALVES), LDS_BYTES, stream, gp);
   return hipGetLastError();
@@ -286,12 +286,12 @@ static inline hipError_t focal_launch_dw_ring(const GemmParams& p, hipStream_t s
   constexpr int LDS_BYTES = HALVES * NST * RPS * TILE * 4;
   auto kern = focal_dw_ring_kernel<RPS, NST, true, HALVES>;
   auto kern0 = focal_dw_ring_kernel<RPS, NST, false, HALVES>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};  // (the grant is idempotent: two first callers may both issue it; the flag itself is race-free)
+  if (!attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern0), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   dim3 grid((p.M / TILE) * (p.N / TILE) * p.splits);
   if (p.colsumA) FOCAL_LAUNCH(kern, grid, dim3(256 * HALVES), LDS_BYTES, stream, p);

@@ -625,11 +625,11 @@ template <typename TC, int EPI, bool TRB, int BM, int BN, int NST, int WGM = 2, 
 static inline hipError_t focal_launch_gemm_pipe(const GemmParams& p, hipStream_t stream) {
   constexpr int LDS_BYTES = NST * (BM + BN) * 128;
   auto kern = focal_gemm_pipe_kernel<TC, EPI, TRB, BM, BN, NST, WGM, WGN>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};  // (the grant is idempotent: two first callers may both issue it; the flag itself is race-free)
+  if (!attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   dim3 grid(((p.M + BM - 1) / BM) * (p.N / BN) * p.batch);
   FOCAL_LAUNCH(kern, grid, dim3(64 * WGM * WGN), LDS_BYTES, stream, p);

@@ -364,12 +364,12 @@ static inline bool focal_ring_disabled() {
 }
 
 static inline int focal_cu_count() {
-  static int n = 0;
-  if (n == 0) {
+  // (initialised once, thread-safe: C++11 magic static; `static const bool off` above is one too)
+  static const int n = [] {
     int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
-  }
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+    return 256;
+  }();
   return n;
 }
 
@@ -385,11 +385,11 @@ static inline hipError_t focal_launch_gemm_ring(const GemmParams& p, hipStream_t
   using L = RingLayout<TC, EPI, BM, BN, R, WS, WGM, WGN>;
   const int lds_bytes = L::total(p.K / 64);
   auto kern = focal_gemm_ring_kernel<TC, EPI, TRB, BM, BN, R, WS, WGM, WGN, NLOAD, ASYNC, HOIST>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};  // (the grant is idempotent: two first callers may both issue it; the flag itself is race-free)
+  if (!attr_set.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   int per_cu = (160 * 1024) / lds_bytes;
   const int by_waves = 32 / (WGM * WGN + NLOAD);

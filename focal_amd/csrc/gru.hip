@@ -468,13 +468,13 @@ extern "C" int focal_gru_seq_fwd(const focal_gru_desc* d, int n_dir, const float
   const int H = d->H, tw = gru_twins(d->B, H, n_dir);
   const dim3 grid(ceil_div(d->B, 16 / tw), n_dir);
   const size_t lds = (size_t)(H / 16) * (H / 32 + (H > 128 ? 1 : 0)) * 64 * 16 + (size_t)16 * (H + 8) * 2 + (size_t)3 * H * 4;
-  static bool granted = false;
-  if (!granted) {  // up to 143 KB of the CU's 160 KB: above the default dynamic-LDS grant
+  static std::atomic<bool> granted{false};
+  if (!granted.load(std::memory_order_acquire)) {  // up to 143 KB of the CU's 160 KB: above the default dynamic-LDS grant
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_kernel<256, GRU_NW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_kernel<256, GRU_NW, GRU_TW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_kernel<128, GRU_NW_128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { focal_set_error("gru_seq_fwd: cannot reserve LDS: %s", hipGetErrorString(e)); return FOCAL_EHIP; }
-    granted = true;
+    granted.store(true, std::memory_order_release);
   }
   if (H == 256 && tw == 2) FOCAL_LAUNCH((gru_seq_fwd_kernel<256, GRU_NW, GRU_TW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, out);
   else if (H == 256) FOCAL_LAUNCH((gru_seq_fwd_kernel<256, GRU_NW, 1>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, out);
@@ -505,13 +505,13 @@ extern "C" int focal_gru_seq_bwd(const focal_gru_desc* d, int n_dir, const float
   const int H = d->H, tw = gru_twins(d->B, H, n_dir);
   const dim3 grid(ceil_div(d->B, 16 / tw), n_dir);
   const size_t lds = (size_t)(H / 16) * (H / 32) * 64 * 16 + (size_t)16 * (3 * H + 8) * 2;
-  static bool granted = false;
-  if (!granted) {
+  static std::atomic<bool> granted{false};
+  if (!granted.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_bwd_kernel<256, GRU_NW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_bwd_kernel<256, GRU_NW, GRU_TW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_bwd_kernel<128, GRU_NW_128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { focal_set_error("gru_seq_bwd: cannot reserve LDS: %s", hipGetErrorString(e)); return FOCAL_EHIP; }
-    granted = true;
+    granted.store(true, std::memory_order_release);
   }
   if (H == 256 && tw == 2) FOCAL_LAUNCH((gru_seq_bwd_kernel<256, GRU_NW, GRU_TW>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);
   else if (H == 256) FOCAL_LAUNCH((gru_seq_bwd_kernel<256, GRU_NW, 1>), grid, dim3(GRU_NW * 64), lds, (hipStream_t)stream, *d, a, dout, ld_b, ld_t, scale);

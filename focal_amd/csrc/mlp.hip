@@ -217,14 +217,14 @@ extern "C" int focal_mlp_fwd(const focal_mlp_desc* d, const void* a, const float
   const bool drop = d->drop_hidden.p_elem > 0.f;
   void (*kern)(const MlpFwdParams) = ln ? (drop ? mlp_fwd_kernel<true, true> : mlp_fwd_kernel<true, false>)
                                         : (drop ? mlp_fwd_kernel<false, true> : mlp_fwd_kernel<false, false>);
-  static bool attr_set[4] = {false, false, false, false};
+  static std::atomic<bool> attr_set[4] = {{false}, {false}, {false}, {false}};
   const int ki = (ln ? 2 : 0) + (drop ? 1 : 0);
-  if (!attr_set[ki]) {
+  if (!attr_set[ki].load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD_BYTES) != hipSuccess) {
       focal_set_error("mlp_fwd: cannot reserve %d bytes of LDS", LDS_FWD_BYTES);
       return FOCAL_EHIP;
     }
-    attr_set[ki] = true;
+    attr_set[ki].store(true, std::memory_order_release);
   }
   const int nwg = (d->M + 127) / 128;
   const int grid = nwg < 512 ? nwg : 512;  // two 8-wave workgroups per CU, persistent over 16-row wave tiles

@@ -430,14 +430,14 @@ extern "C" int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void
   FOCAL_CHECK_ARG(dw_partials == nullptr || ((uintptr_t)dw_partials % 16) == 0, "mlp_bwd: dw_partials must be 16-byte aligned");
   void (*kern)(const MlpBwdParams) = ln ? (drop ? mlp_bwd_kernel<true, true> : mlp_bwd_kernel<false, true>)
                                         : (drop ? mlp_bwd_kernel<true, false> : mlp_bwd_kernel<false, false>);
-  static bool attr_set[4] = {false, false, false, false};
+  static std::atomic<bool> attr_set[4] = {{false}, {false}, {false}, {false}};
   const int ki = (ln ? 2 : 0) + (drop ? 1 : 0);
-  if (!attr_set[ki]) {
+  if (!attr_set[ki].load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD_BYTES) != hipSuccess) {
       focal_set_error("mlp_bwd: cannot reserve %d bytes of LDS", LDS_BWD_BYTES);
       return FOCAL_EHIP;
     }
-    attr_set[ki] = true;
+    attr_set[ki].store(true, std::memory_order_release);
   }
   const int ntiles = (d->M + BM - 1) / BM;
   const int grid = ntiles < 256 ? ntiles : 256;  // one persistent 16-wave workgroup per CU

@@ -75,13 +75,23 @@ __device__ __forceinline__ float vd_normal(uint32_t key, uint32_t i) {  // Box-M
   return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
-__global__ __launch_bounds__(64) void view_draw_kernel(const focal_view_pool pool, int n_views, int n_slots, const uint32_t* __restrict__ seed,
-                                                       uint32_t stream_id, focal_view_plan* __restrict__ plans) {
+// `advance` (focal_view_draw_shared): the seed word is the draw's OWN state -- one every data-parallel rank holds a copy of, so that the global
+// batch gets one augmenter / coin / permutation / scale / phase per view as the reference's batch does -- and the kernel moves it on after
+// everybody has read it (the word the optimizer advances keys the per-rank dropout streams and stays per-rank).
+__global__ __launch_bounds__(64) void view_draw_kernel(const focal_view_pool pool, int n_views, int n_slots, uint32_t* seed,
+                                                       uint32_t stream_id, focal_view_plan* __restrict__ plans, int advance) {
   __shared__ int s_perm[64][FOCAL_AUG_MAX_INTERVALS + 1];
   const int t = threadIdx.x;
+  const uint32_t s0 = seed ? seed[0] : 0u;
+  if (advance) {
+    __syncthreads();
+    if (t == 0) {
+      seed[0] = focal_mix32(s0 + 0x9E3779B9U);
+      seed[1] += 1u;
+    }
+  }
   if (t >= n_views * n_slots) return;
   const int view = t / n_slots, slot = t - view * n_slots;
-  const uint32_t s0 = seed ? seed[0] : 0u;
   // ONE pool entry per view (Augmenter.py:86 np.random.randint), then per slot the augmenter's own coin and parameters
   const uint32_t kv = focal_mix32(s0 * 0x9E3779B9U + stream_id * 0x85EBCA6BU + (uint32_t)view * 0xC2B2AE35U + 0x27D4EB2FU);
   int k = (int)(vd_uniform(kv, 0) * (float)pool.n_aug);
@@ -126,8 +136,8 @@ __global__ __launch_bounds__(64) void view_draw_kernel(const focal_view_pool poo
   pl->kind = kind; pl->pool_index = k; pl->warp = warp; pl->nknots = nk;
 }
 
-extern "C" int focal_view_draw(const focal_view_pool* pool, int n_views, int n_slots, const uint32_t* seed, uint32_t stream_id,
-                               focal_view_plan* plans, void* stream) {
+static int view_draw_launch(const focal_view_pool* pool, int n_views, int n_slots, uint32_t* seed, uint32_t stream_id,
+                            focal_view_plan* plans, int advance, void* stream) {
   FOCAL_CHECK_ARG(pool && plans && n_views >= 1 && n_slots >= 1 && n_slots <= FOCAL_VIEW_MAX_SLOTS && n_views * n_slots <= 64,
                   "view_draw: 1 .. %d slots, at most 64 (view, slot) pairs", FOCAL_VIEW_MAX_SLOTS);
   FOCAL_CHECK_ARG(pool->n_aug >= 1 && pool->n_aug <= FOCAL_VIEW_MAX_POOL, "view_draw: pool of 1 .. %d augmenters", FOCAL_VIEW_MAX_POOL);
@@ -136,9 +146,20 @@ extern "C" int focal_view_draw(const focal_view_pool* pool, int n_views, int n_s
     const int ord = pool->kind[i] == FOCAL_VIEW_MAG_WARP ? pool->mag_order : pool->kind[i] == FOCAL_VIEW_TIME_WARP ? pool->time_order : 2;
     FOCAL_CHECK_ARG(ord >= 2 && 3 * (ord - 1) + 1 <= FOCAL_VIEW_MAX_KNOTS, "view_draw: spline order %d needs more than %d knots", ord, FOCAL_VIEW_MAX_KNOTS);
   }
-  FOCAL_LAUNCH(view_draw_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *pool, n_views, n_slots, seed, stream_id, plans);
+  FOCAL_LAUNCH(view_draw_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *pool, n_views, n_slots, seed, stream_id, plans, advance);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
+}
+
+extern "C" int focal_view_draw(const focal_view_pool* pool, int n_views, int n_slots, const uint32_t* seed, uint32_t stream_id,
+                               focal_view_plan* plans, void* stream) {
+  return view_draw_launch(pool, n_views, n_slots, const_cast<uint32_t*>(seed), stream_id, plans, 0, stream);
+}
+
+extern "C" int focal_view_draw_shared(const focal_view_pool* pool, int n_views, int n_slots, uint32_t* view_state, uint32_t stream_id,
+                                      focal_view_plan* plans, void* stream) {
+  FOCAL_CHECK_ARG(view_state != nullptr, "view_draw_shared: null view state (4 words: {seed, draw count, 0, 0})");
+  return view_draw_launch(pool, n_views, n_slots, view_state, stream_id, plans, 1, stream);
 }
 
 // The warp curves of focal_amd/warp.py on the device, one workgroup per problem: the not-a-knot cubic spline through the plan's knots
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(WT_THREADS) void warp_curve_kernel(const WarpTable 
   const focal_view_plan* plan = P.plan;
   const int L = P.L;
   float* tables = P.tables;
-  const int warp = plan->warp;
+  const int warp = focal_plan_warp(plan);
   if (warp == 0) return;
   __shared__ double xk[FOCAL_VIEW_MAX_KNOTS], yk[FOCAL_VIEW_MAX_KNOTS], sk[FOCAL_VIEW_MAX_KNOTS], c2[FOCAL_VIEW_MAX_KNOTS], c3[FOCAL_VIEW_MAX_KNOTS];
   __shared__ double Am[FOCAL_VIEW_MAX_KNOTS][FOCAL_VIEW_MAX_KNOTS + 1];
@@ -275,7 +296,7 @@ __device__ __forceinline__ float wt_prefilter(int i) {
 template <int TAPS, int RPT>
 __global__ __launch_bounds__(256) void warp_plan_apply_kernel(const WarpTable tab, const float* __restrict__ end_coef) {
   const focal_warp_problem& P = tab.p[blockIdx.z];
-  const int warp = P.plan->warp;
+  const int warp = focal_plan_warp(P.plan);
   if (warp == 0) return;
   const int rows = P.rows, L = P.L;
   const float* __restrict__ x = P.x;

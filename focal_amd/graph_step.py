@@ -76,6 +76,7 @@ class StepSegments:
         self.feats = None
         self.device = device
         self.timer = None      # a SegmentTimer while bench.py measures the pieces of the replayed step
+        self._agreed = 0       # per-segment agreements issued by the capture in progress
         self._buckets = False  # decided at the first data-parallel step (the arena exists by then)
 
     def buckets(self):
@@ -183,6 +184,7 @@ class StepSegments:
         if err is not None and not self.dist.is_dist():
             self.abort_capture()
             raise err
+        self._agreed += 1
         if not agree(err is None, self.device):
             self.abort_capture()
             raise CaptureAborted(f"{type(err).__name__}: {err}" if err is not None else "another rank failed to capture this segment")
@@ -207,6 +209,28 @@ class StepSegments:
         that placement replays 2.5 % faster (8.29 -> 8.08 ms, reproducible; the first set is kept alive so its blocks stay put)."""
         self.opt.sync_lr()
         multi = self.dist.is_dist()
+        if not multi:
+            return self._capture_all(stream, multi)
+        # N ranks: every rank must issue the SAME sequence of agreements.  A rank that fails BETWEEN two segment captures (an eager
+        # allocation, the pool hand-over) would go straight to its caller's final agreement while its peers sit in the next segment's --
+        # mispaired, and the peers' own final agreement would then wait for nobody (ADVICE r5).  Such a rank takes the next segment's slot
+        # with a "no": its peers raise CaptureAborted there, and everybody meets again in the final agreement.  (After the last segment's
+        # slot nothing is owed: the final agreement is next on every rank.)
+        self._agreed = 0
+        slots = 2 * (3 + (1 if self.dist.shard_loss_head() else 0) + (1 if self.buckets() is not None else 0))
+        try:
+            return self._capture_all(stream, multi)
+        except CaptureAborted:
+            raise
+        except Exception as e:  # noqa: BLE001
+            torch.cuda.synchronize()
+            if self._agreed < slots:
+                self._agreed += 1
+                agree(False, self.device)
+            self.abort_capture()
+            raise CaptureAborted(f"{type(e).__name__}: {e} (between segment captures)") from e
+
+    def _capture_all(self, stream, multi):
         # with a process group alive its watchdog thread polls events (cudaEventQuery) at any time: under the default "global"
         # capture mode that would invalidate a capture in progress, "thread_local" restricts the checks to the capturing thread
         mode = {"capture_error_mode": "thread_local"} if multi else {}

@@ -255,6 +255,16 @@ def view_draw(pool, n_views, n_slots, seed_state, stream_id, plans):
     return plans
 
 
+def view_draw_shared(pool, n_views, n_slots, view_state, stream_id, plans):
+    """view_draw from the draw's own device state (runtime.view_state: one seed broadcast to every data-parallel rank), which the kernel
+    advances itself: every rank draws the same plans, replay after replay."""
+    _need_cuda(plans, view_state)
+    assert plans.shape == (n_views * n_slots, VIEW_PLAN_BYTES) and plans.dtype == torch.uint8 and plans.is_contiguous()
+    assert view_state.dtype == torch.int32 and view_state.numel() >= 4
+    check(_lib.load().focal_view_draw_shared(C.byref(pool), n_views, n_slots, _p(view_state), int(stream_id) & 0xFFFFFFFF, _p(plans), _stream()))
+    return plans
+
+
 def read_view_plans(plans):
     """Host copies of the plan records (tests, diagnostics): a list of _lib.ViewPlan."""
     raw = plans.cpu().numpy().tobytes()
@@ -269,6 +279,8 @@ def write_view_plan(plans, index, scale=1.0, flip=False, perm=None, phase=0.0, w
     for i in range(32):
         pl.aug.perm[i] = int(perm[i]) if perm is not None and i < len(perm) else i
     pl.kind, pl.warp = int(kind), int(warp)
+    if int(warp) != 0 and (knots is None or not 4 <= len(knots) <= _lib.VIEW_MAX_KNOTS):
+        raise ValueError(f"write_view_plan: a warp needs 4 .. {_lib.VIEW_MAX_KNOTS} knots")
     if knots is not None:
         pl.nknots = len(knots)
         for i, v in enumerate(knots):
@@ -292,6 +304,10 @@ def warp_end_coefficients(device):
 def warp_plan_multi(problems):
     """problems: [dict(x=[B, C, I, S] fp32, plan=row of the plan tensor, tables=fp32 [2 * I * S] workspace, y=like x)]: the warps the
     plans ask for (focal_warp_plan_multi: two launches whatever they ask)."""
+    if len(problems) > 8:  # (the launch table holds 8 problems: a dataset with 5 .. 8 (location, modality) slots asks for 10 .. 16; ADVICE r5)
+        for k in range(0, len(problems), 8):
+            warp_plan_multi(problems[k:k + 8])
+        return
     arr = (_lib.WarpProblem * len(problems))()
     for i, q in enumerate(problems):
         x, y = q["x"], q["y"]

@@ -30,6 +30,29 @@ def rng_state(device, seed=None):
     return _RNG[key]
 
 
+_VIEW = {}
+
+
+def view_state(device, seed=None):
+    """Device words {seed, draw count, 0, 0} of the random-view draws (ops.view_draw_shared advances them itself).  Unlike rng_state --
+    per rank on purpose: dropout masks should differ between ranks -- the seed is ONE word for the whole data-parallel job: rank 0 draws it
+    and broadcasts it the first time a rank asks (every rank asks at the same point: the first training step, eagerly, before any capture),
+    so all ranks draw the same view plans and the global batch is augmented as the reference's batch is (one augmenter / coin /
+    permutation / scale / phase per view: data_augmenter/Augmenter.py:76-113).  A resumed job is a new process and draws a new word."""
+    import torch.distributed as dist
+    key = torch.device(device)
+    if key.index is None and key.type == "cuda":
+        key = torch.device("cuda", torch.cuda.current_device())
+    if key not in _VIEW or seed is not None:
+        s = (int.from_bytes(os.urandom(4), "little") if seed is None else seed) & 0x7FFFFFFF
+        if seed is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            word = torch.tensor([s], dtype=torch.int64, device=key if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(word, 0)
+            s = int(word.item())
+        _VIEW[key] = ops.new_rng_state(s, key)
+    return _VIEW[key]
+
+
 def advance_step(device):
     ops.rng_advance(rng_state(device))
 

@@ -214,13 +214,19 @@ class Augmenter:
     # ------------------------------------------------------------------------------------------ random views, drawn on the device
     def device_draws_supported(self):
         """The pool is made of augmenters focal_view_draw knows (every shipped `random_augmenters` pool is)."""
-        return all(n in ops.VIEW_KINDS for n in self.aug_names) and 1 <= len(self.aug_names) <= 8
+        cfg = self.args.dataset_config
+        n_slots = sum(len(cfg["modality_names"]) for _ in cfg["location_names"])
+        return all(n in ops.VIEW_KINDS for n in self.aug_names) and 1 <= len(self.aug_names) <= 8 and n_slots <= ops._lib.VIEW_MAX_SLOTS
 
     def _device_state(self, inputs):
         flat = [(loc, mod) for loc in inputs for mod in inputs[loc]]
         key = tuple((loc, mod, tuple(inputs[loc][mod].shape), inputs[loc][mod].device) for loc, mod in flat)
-        st = self.__dict__.get("_dev_state")
-        if st is not None and st["key"] == key:
+        # one state PER batch shape, never dropped: a captured step graph holds the addresses of its plans / views / warp tables, and the
+        # last batch of an epoch (no drop_last) is smaller -- replacing the state would hand those blocks back to the allocator while the
+        # graph keeps writing into them from the next epoch on (ADVICE r5)
+        states = self.__dict__.setdefault("_dev_states", {})
+        st = states.get(key)
+        if st is not None:
             return st
         cfg = self.args.dataset_config
         pool = ops.view_pool([(n, cfg[n]["prob"] if n != "no" else 0.0) for n in self.aug_names],
@@ -238,7 +244,9 @@ class Augmenter:
               "warped": [{k: torch.empty_like(inputs[k[0]][k[1]], dtype=torch.float32) for k in flat} for _ in range(2)] if warps else None,
               "tables": [{k: torch.empty(2 * inputs[k[0]][k[1]].shape[2] * inputs[k[0]][k[1]].shape[3], dtype=torch.float32, device=dev)
                           for k in flat} for _ in range(2)] if warps else None}
-        self._dev_state = st
+        from focal_amd import runtime
+        st["view_state"] = runtime.view_state(dev)  # (may broadcast the job's draw seed: eager, first step, every rank at the same point)
+        states[key] = st
         return st
 
     def forward_random_pair(self, time_loc_inputs, stream_id=None):
@@ -252,8 +260,10 @@ class Augmenter:
         flat, n = st["flat"], len(st["flat"])
         dev = x[flat[0][0]][flat[0][1]].device
         if stream_id is None:
-            stream_id = 0x56494557 + 977 * distributed.rank()   # ("VIEW"; every data-parallel rank draws its own views)
-        ops.view_draw(st["pool"], 2, n, runtime.rng_state(dev), stream_id, st["plans"])
+            stream_id = 0x56494557   # ("VIEW")
+        # the draw's own state, started from one seed on every data-parallel rank: identical plans on all ranks (the reference draws once
+        # per batch; the global batch is the batch), different dropout masks (runtime.rng_state stays per rank)
+        ops.view_draw_shared(st["pool"], 2, n, st["view_state"], stream_id, st["plans"])
         if st["warps"]:
             ops.warp_plan_multi([dict(x=x[l][m], plan=st["plans"][v * n + i], tables=st["tables"][v][(l, m)], y=st["warped"][v][(l, m)])
                                  for v in range(2) for i, (l, m) in enumerate(flat)])

@@ -37,46 +37,11 @@ def train(args):
 
 def spawn_data_parallel(devices):
     """`-gpu=0,1,...,7` (the reference already parses device lists, params/params_util.py:34-38, but trains on the first one):
-    one child process per listed GPU, each a rank of an RCCL data-parallel job -- what `torchrun --nproc-per-node N train.py`
-    does, without the launcher.  Runs before anything touches the GPU in this process.  The listed indices select among the
-    devices an outer HIP_VISIBLE_DEVICES already exposes; when a rank dies the others are terminated (they would otherwise sit
-    in their next collective until the process-group timeout)."""
-    import socket
-    import subprocess
-    import time
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    outer = [v for v in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
-    if outer:
-        if max(devices) >= len(outer):
-            raise SystemExit(f"-gpu={devices} does not fit HIP_VISIBLE_DEVICES={','.join(outer)}")
-        visible = [outer[d] for d in devices]
-    else:
-        visible = [str(d) for d in devices]
-    procs = []
-    for rank in range(len(devices)):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(len(devices)), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HIP_VISIBLE_DEVICES=",".join(visible))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    code = 0
-    while any(p.poll() is None for p in procs):
-        failed = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
-        if failed:
-            code = failed[0]
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            for p in procs:
-                try:
-                    p.wait(timeout=30)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        time.sleep(0.2)
-    if code == 0:
-        code = max((p.returncode for p in procs), key=abs)
-    sys.exit(code)
+    one child process per listed GPU, each a rank of an RCCL data-parallel job (focal_amd/launch.py, shared with `bench.py --gpus N`).
+    Runs before anything touches the GPU in this process."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+    from focal_amd.launch import spawn_ranks
+    sys.exit(spawn_ranks(__file__, sys.argv[1:], devices))
 
 
 def wants_data_parallel(base):

@@ -179,10 +179,13 @@ class SwinModEncoder:
         encoder's stream); FOCAL_MLP_BWD_ATOMICS=1 keeps the round-4 atomic flush (same-box A/B)."""
         if os.environ.get("FOCAL_MLP_BWD_ATOMICS") == "1":
             return None
-        ws = self.__dict__.get("_mlp_ws")
+        # one workspace per size, never dropped: a captured step graph holds its address, and a smaller batch later (the last one of an
+        # epoch) followed by the captured shape again must find the block where the graph left it (ADVICE r5)
+        pool = self.__dict__.setdefault("_mlp_ws", {})
         n = ops.mlp_bwd_partials_floats(d_mlp)
-        if ws is None or ws.numel() < n or ws.device != dev:
-            ws = self._mlp_ws = torch.empty(n, dtype=torch.float32, device=dev)
+        ws = pool.get((n, dev))
+        if ws is None:
+            ws = pool[(n, dev)] = torch.empty(n, dtype=torch.float32, device=dev)
         return ws
 
     def backward(self, saved, dfeat):

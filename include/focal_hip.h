@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* 7: launch trace (focal_trace_*), focal_adamw_multi_advance takes the step-state length; 2: BatchNorm scratch of 2C + 1 floats; 3: fused MLP, warps, Mixup; 4: row-sharded loss head, weight-gradient launch queries */
-#define FOCAL_ABI_VERSION 11
+#define FOCAL_ABI_VERSION 12
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -134,6 +134,14 @@ typedef struct {
 /* plans: device [n_views][n_slots].  seed: the device seed word (NULL = 0); stream_id separates this draw from the dropout streams. */
 int focal_view_draw(const focal_view_pool* pool, int n_views, int n_slots, const uint32_t* seed, uint32_t stream_id, focal_view_plan* plans,
                     void* stream);
+/* The same draws from a state of their own (round 6): view_state = 4 device words {seed, draw count, 0, 0} that the kernel advances after
+ * drawing (seed <- mix32(seed + golden), count += 1), so consecutive calls -- consecutive replays of a captured step -- draw different
+ * views without any other kernel touching the words.  Under data parallelism every rank holds a copy started from ONE broadcast seed: the
+ * ranks then draw identical plans, i.e. the global batch gets one augmenter / coin / permutation / scale / phase per view as the
+ * reference's batch does (Augmenter.py:76-113, ScalingAugmenter.py:35 size=(1,), PermutationAugmenter.py:35-36), while the dropout
+ * streams (keyed by the word the optimizer advances) stay per-rank. */
+int focal_view_draw_shared(const focal_view_pool* pool, int n_views, int n_slots, uint32_t* view_state, uint32_t stream_id, focal_view_plan* plans,
+                           void* stream);
 /* The warps of up to 8 (view, slot) pairs whose plans may ask for one, as TWO launches (the tables of all of them, then the passes over
  * their windows); a problem whose plan says "no warp" costs nothing and leaves its y unwritten.  Per problem: the random curve through the
  * plan's knots and, for the time warp, its cumulative positions (one workgroup per problem; focal_amd/warp.py is the host statement of the

@@ -212,6 +212,75 @@ def test_capture_failure_on_one_rank_keeps_every_rank_eager():
         assert out[r][None] == (False, True), dict(out)  # nobody failed: everybody replays
 
 
+def _between_segments_worker(rank, world, port, out):
+    """StepSegments.capture with the graph machinery stubbed (no GPU here): rank 1 fails BETWEEN segment A and segment B (its eager
+    exchange raises).  Every rank must leave capture() with CaptureAborted and the NEXT collective -- the caller's final agreement --
+    must pair up on both ranks (the failing rank used to skip segment B's agreement slot)."""
+    import contextlib
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FOCAL_LOSS_SHARD="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from focal_amd import graph_step
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.graph = lambda *a, **k: contextlib.nullcontext()
+
+    class G:
+        def pool(self):
+            return None
+
+        def replay(self):
+            pass
+    torch.cuda.CUDAGraph = G
+
+    class Opt:
+        def sync_lr(self):
+            pass
+
+        def reduce_buckets(self, model):
+            return None
+
+        def wait_reductions(self):
+            pass
+
+        def reduce_gradients(self):
+            pass
+
+    class Seg(graph_step.StepSegments):
+        def seg_a(self):
+            pass
+
+        def seg_b(self):
+            pass
+
+        def seg_c(self):
+            pass
+
+        def exchange(self):
+            if rank == 1:
+                raise RuntimeError("out of memory between two segments")
+
+    seg = Seg(None, None, Opt(), lambda: None, torch.device("cpu"))
+    try:
+        seg.capture(None)
+        got = "captured"
+    except graph_step.CaptureAborted as e:
+        got = "aborted: " + str(e)
+    final = graph_step.agree(got == "captured", torch.device("cpu"))   # what CapturedTrainStep._step does next
+    out[rank] = (got, final)
+    dist.destroy_process_group()
+
+
+def test_failure_between_segment_captures_keeps_the_agreements_paired():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_between_segments_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out[0][0].startswith("aborted") and "between segment captures" in out[1][0], dict(out)
+    assert out[0][1] is False and out[1][1] is False
+
+
 def _bf16_reduce_worker(rank, world, port, out):
     """The bf16-wire gradient reduction (FOCAL_GRAD_REDUCE=bf16) against the fp32 all-reduce on the same gradients: the summed gradient
     within 1e-2 of its norm (observed ~2e-3: one bf16 rounding per contribution and one of the sum), a rank's own shard better than the
@@ -258,3 +327,29 @@ def test_bf16_wire_gradient_reduction_matches_fp32_all_reduce():
         for key, (rel_l2, rel_max) in out[r].items():
             assert rel_l2 < 1e-2, (r, key, rel_l2)        # of the update's norm
             assert rel_max < 1.2e-2, (r, key, rel_max)    # element-wise, of the summed magnitudes: bf16 roundings of 2^-9 each
+
+
+def _view_seed_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from focal_amd import runtime
+    cpu = torch.device("cpu")
+    v = runtime.view_state(cpu)     # collective on first use: rank 0's word, broadcast
+    d = runtime.rng_state(cpu)      # per rank, from os.urandom
+    again = runtime.view_state(cpu)
+    out[rank] = (v.tolist(), d.tolist(), again.data_ptr() == v.data_ptr())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_view_seed_and_keep_their_own_dropout_seed():
+    """the random-view draws of a data-parallel job are keyed by ONE word (rank 0's, broadcast) so that the global
+    batch gets one augmenter / coin / permutation / scale / phase per view as the reference's batch does (Augmenter.py:76-113);
+    the dropout streams keep a word per rank.  (The plans drawn from equal states are equal: tests/test_kernels_gpu.py::
+    test_shared_view_draws_advance_their_own_state; the two-rank plans on a GPU: tests/test_dp_parity_gpu.py.)"""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_view_seed_worker, args=(world, port, out), nprocs=world, join=True)
+    (v0, d0, same0), (v1, d1, same1) = out[0], out[1]
+    assert v0 == v1 and len(v0) == 4 and v0[1:] == [0, 0, 0] and same0 and same1
+    assert d0[0] != d1[0]   # (two os.urandom words: equal with probability 2^-31)

@@ -56,3 +56,34 @@ def test_bench_contract_with_two_ranks(model):
     # (no bound against ms_per_step here: over gloo the collectives are host round trips of two processes sharing one GPU, and the 5
     # diagnostic steps run after rank 0's peers have gone idle; over RCCL the sum is the step)
     assert dp["us_step_from_events"] >= dp["us_exchange"] + dp["us_allreduce_exposed"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (no WORLD_SIZE in the environment) spawns two fresh ranks itself (focal_amd/launch.py)
+    before any HIP call -- never a silent 1-GPU run.  Both ranks share the box's one GPU over gloo here."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="8", FOCAL_BENCH_TEST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "16", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, tail
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 32
+    assert out["dp"]["world"] == 2 and out["dp"]["ranks_seen"] == 2
+    assert out["warmup_effective"] >= 2 and len(out["step_series"]["timed_ms"]) == 4
+
+
+def test_two_ranks_draw_the_same_views():
+    """VERDICT r5 item 3a on the device: both ranks of a job draw identical focal_view_plan records step after step (one broadcast draw
+    seed, focal_view_draw_shared), and different dropout masks (tests/dp_views_worker.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(HERE, "dp_views_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "plans identical on all ranks: True" in r.stdout, tail

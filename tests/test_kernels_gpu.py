@@ -1300,14 +1300,15 @@ def test_product_augmenter_device_pair_follows_the_oracle(ops, cfg):
     aug = A.Augmenter(args)
     assert aug.device_draws_supported()
     tx = {"shake": {"audio": torch.randn(2, 1, 10, 1600).to(DEV), "seismic": torch.randn(2, 1, 10, 20).to(DEV)}}
-    seed = runtime.rng_state(torch.device(DEV))
+    seed = runtime.view_state(torch.device(DEV))   # (the draws' own state since round 6: one seed for all data-parallel ranks)
     saved = seed.clone()
     seen = set()
     try:
         for it in range(40):
             seed[0] = 1000 + 17 * it
             v = aug.forward_random_pair(tx)
-            plans = ops.read_view_plans(aug._dev_state["plans"])
+            st = next(iter(aug._dev_states.values()))
+            plans = ops.read_view_plans(st["plans"])
             for view in range(2):
                 for i, m in enumerate(("audio", "seismic")):
                     p = plans[view * 2 + i]
@@ -1328,11 +1329,40 @@ def test_product_augmenter_device_pair_follows_the_oracle(ops, cfg):
                         f = oa.phase_shift(f, math.atan2(p.aug.phase_sin, p.aug.phase_cos))
                     got = v[view]["shake"][m]
                     assert got.shape[0] == 2 and (got.cpu() - f).abs().max().item() < 2e-4 * math.sqrt(got.shape[-1]) * 2 + 1e-4 * f.abs().max().item(), (it, view, m, p.kind)
-            both = aug._dev_state["both"][("shake", "audio")]
+            both = st["both"][("shake", "audio")]
             assert v[0]["shake"]["audio"].data_ptr() == both.data_ptr() and v[1]["shake"]["audio"].data_ptr() == both[2:].data_ptr()
     finally:
         seed.copy_(saved)
     assert seen == set(range(8)), seen
+    # a batch of another shape (the last batch of an epoch) gets a state of its own; the first one stays alive at its addresses: a captured
+    # step graph keeps writing into it
+    first = next(iter(aug._dev_states.values()))
+    ptr = first["plans"].data_ptr()
+    aug.forward_random_pair({"shake": {"audio": torch.randn(1, 1, 10, 1600).to(DEV), "seismic": torch.randn(1, 1, 10, 20).to(DEV)}})
+    aug.forward_random_pair(tx)
+    assert len(aug._dev_states) == 2 and next(iter(aug._dev_states.values()))["plans"].data_ptr() == ptr
+
+
+def test_shared_view_draws_advance_their_own_state(ops):
+    """focal_view_draw_shared (round 6): the draw reads its OWN 4-word state and moves it on (seed <- mix32(seed + golden), count += 1):
+    two states started from one seed -- two data-parallel ranks -- draw identical plan sequences, consecutive calls differ, and call k
+    equals focal_view_draw on the k-th word of the sequence."""
+    pool = ops.view_pool(FOCAL_POOL, [10, 10])
+    a, b = ops.new_rng_state(4242, DEV), ops.new_rng_state(4242, DEV)
+    pa, pb = ops.new_view_plans(2, 2, DEV), ops.new_view_plans(2, 2, DEV)
+    seq = []
+    for k in range(6):
+        word = a.clone()
+        ops.view_draw_shared(pool, 2, 2, a, 0x56494557, pa)
+        ops.view_draw_shared(pool, 2, 2, b, 0x56494557, pb)
+        assert torch.equal(pa, pb) and torch.equal(a, b)
+        assert int(a[1].item()) == k + 1 and int(a[0].item()) != int(word[0].item())
+        plain = ops.view_draw(pool, 2, 2, word, 0x56494557, ops.new_view_plans(2, 2, DEV))
+        assert torch.equal(plain, pa)
+        seq.append(pa.cpu().clone())
+    assert any(not torch.equal(seq[0], s) for s in seq[1:])
+    with pytest.raises(ValueError):
+        ops.write_view_plan(pa, 0, kind=6, warp=6)   # a warp without knots would be an out-of-bounds spline solve (ADVICE r5)
 
 
 def test_gpu_knn_matches_sklearn(ops):
