@@ -1,0 +1,434 @@
+// The MLP branch of a Swin block at 128 / 256 channels as ONE launch per direction (round 6).
+//
+//   forward    h, h' = drop_h(gelu(a2 W1^T + b1)) and its derivative      [M, 4C], written once for the backward pass, never read back
+//              x_out = x_mid + drop_o(h W2^T + b2)                         (+ the LayerNorm that reads x_out next, at 128 channels)
+//
+// replaces models/SwinModules.py:18-34 (Mlp.forward: fc1 -> GELU -> Dropout -> fc2 -> Dropout) + the residual add and DropPath of
+// SwinTransformerBlock.forward (:339-341) for stages 1-2, which ran as two GEMM launches (gemm_ring.hpp): fc1 wrote h and h', fc2 read h
+// back -- 8C of the ~72C bytes per token a block's forward pass moves -- and the hidden tensor's tile left the chip between the products.
+//
+// The 64-channel kernel (mlp.hip) keeps both weights in LDS; at 128 / 256 channels they are 256 KB / 1 MB, so they STREAM: a persistent
+// workgroup (one per CU) owns 128 token rows at a time -- 8 consumer waves x 16 rows, a2 fragments and the [16, C] fc2 accumulators in
+// registers -- and walks the hidden dimension 64 units per step.  Two loader waves fill a 2-slot ring with LDS-DMA
+// (global_load_lds_dwordx4, counted vmcnt, one s_barrier per step: the roles of gemm_ring.hpp): per step the 64 rows of W1 and the
+// 64-column slice of W2, 32 KB (C = 128) / 64 KB (C = 256), all of it L2-resident (every workgroup streams the same 256 KB / 1 MB).
+// A consumer wave multiplies its rows against the slice (fc1 accumulators [hidden][token]), applies bias + GELU + dropout in registers,
+// stores h / h' (16 B per lane) and feeds the SAME registers back to the matrix cores as the B operand of fc2: the accumulator layout of
+// v_mfma_f32_16x16x32_bf16 (lane = token, 4 consecutive rows per 16-row tile) is a legal operand layout once the W1 rows of a tile are
+// chosen so that a lane's 2 x 4 accumulators are 8 CONSECUTIVE hidden units -- the loader permutes the rows when it fills the image
+// (LDS row 16 T + r of a step <- hidden unit 32 (T / 2) + 8 (r / 4) + 4 (T % 2) + r % 4), free: LDS-DMA source addresses are per lane.
+// Waves never exchange data; the only synchronisation is the ring's barrier.
+//
+// Results are BIT-IDENTICAL to focal_linear_fwd(GELU) + focal_linear_fwd / focal_linear_resid_ln_fwd: same k order in both products, the
+// element math of EPI_GELU_FWD (gemm_pipe.hpp) on the same (row, column) mask indices, and fc2's epilogue is the shared code itself
+// (pipe_epilogue_finish, 128 channels) or its per-element arithmetic (256 channels: EPI_RESID straight from the accumulators).
+// tests/test_mlp_wide_gpu.py asserts torch.equal on every output, dropout on and off.
+#include "gemm_ring.hpp"
+#include "mlp.hpp"
+
+// Lab-only in-kernel stamps (-DWIDE_STAMPS: tools/mb_mlp_wide.py --stamps builds a variant and passes a u64 buffer in g2.colsumA)
+#ifdef WIDE_STAMPS
+#define WS_DECL(n) unsigned long long n = 0
+#define WS_T0() const unsigned long long ws_t0_ = __builtin_amdgcn_s_memtime()
+#define WS_ADD(n) n += __builtin_amdgcn_s_memtime() - ws_t0_
+#define WS_NOW(t) const unsigned long long t = __builtin_amdgcn_s_memtime()
+#define WS_ACC(n, a, b) n += (b) - (a)
+#define WS_OUT(i, n) if (lane == 0 && p.g2.colsumA) reinterpret_cast<unsigned long long*>(p.g2.colsumA)[((long)blockIdx.x * 16 + wave) * 8 + (i)] = n
+#else
+#define WS_DECL(n)
+#define WS_T0()
+#define WS_ADD(n)
+#define WS_NOW(t)
+#define WS_ACC(n, a, b)
+#define WS_OUT(i, n)
+#endif
+
+namespace focal_mlp_wide {
+
+struct WideFwdParams {
+  int M;
+  const bf16_t* a;    // [M][C]   LayerNorm output (norm2)
+  const bf16_t* w1;   // [H][C]
+  const float* b1;    // [H]
+  const bf16_t* w2;   // [C][H]
+  bf16_t* h;          // [M][H]   drop(gelu(.))
+  bf16_t* hg;         // [M][H]   d gelu x mask
+  MaskParams drop_h;  // over [M][H]
+  GemmParams g2;      // the fc2 product as focal_linear_fwd / focal_linear_resid_ln_fwd would launch it: bias, resid, C, epi, ln_*, aux_out
+};
+
+constexpr int NLOAD = 2, R = 2;
+// consumer waves per workgroup: 8 at 128 channels (10 waves: 168 registers per lane are enough there); 6 at 256 channels -- 8 waves in
+// all, two per SIMD, 256 registers: a wave's 64 accumulator + 32 operand-fragment registers do not fit in 168
+#ifndef WIDE_NW128
+#define WIDE_NW128 8
+#endif
+template <int C> struct WideWaves { static constexpr int NW = C == 128 ? WIDE_NW128 : 6, BM = 16 * NW; };
+
+template <int C> struct WideLayout {
+  static constexpr int NW = WideWaves<C>::NW, BM = WideWaves<C>::BM;
+  static constexpr int H = 4 * C, KK = C / 32, NIMG1 = C / 64, CT = C / 16, NSTEP = H / 64;
+  static constexpr int W1_BYTES = NIMG1 * 8192, W2_BYTES = C * 128, SLOT_BYTES = W1_BYTES + W2_BYTES;
+  static constexpr int NP1 = NIMG1 * 8, NP2 = C / 8, L1 = NP1 / NLOAD, L2 = NP2 / NLOAD, LSTEP = L1 + L2;
+  static constexpr int WPITCH = C + 4;
+  static constexpr int STG_BYTES = C == 128 ? NW * 16 * WPITCH * 4 : 0;  // 128 channels: the shared epilogue's transposition region per wave
+  static constexpr int B1_BYTES = H * 4 + C * 4;  // fc1's bias, staged once (a global load inside the step loop would wait, through the in-order vmcnt, for the
+                                          // previous step's h / h' stores)
+  static constexpr int LDS_BYTES = R * SLOT_BYTES + STG_BYTES + B1_BYTES;
+};
+
+template <int N> __device__ __forceinline__ void tie4(bf16x8 (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i + 3 < N; i += 4) asm volatile("" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]));
+}
+__device__ __forceinline__ void lds_wait8(bf16x8 (&v)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+__device__ __forceinline__ f32x4 gload4(const float* p) {
+  typedef float f32x4g __attribute__((ext_vector_type(4)));
+  return *((const __attribute__((address_space(1))) f32x4g*)(p));  // global_load (a generic pointer would be a flat_load)
+}
+
+// EPI2: EPI_RESID or EPI_RESID_LN (128 channels only)
+template <int C, int EPI2>
+__global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_kernel(const WideFwdParams p) {
+  using L = WideLayout<C>;
+  constexpr int NW = L::NW, BM = L::BM;
+  constexpr int H = L::H, KK = L::KK, CT = L::CT, NSTEP = L::NSTEP, SLOT_BYTES = L::SLOT_BYTES, W1_BYTES = L::W1_BYTES;
+  static_assert(C == 128 || C == 256, "128 or 256 channels");
+  static_assert(EPI2 == EPI_RESID || (EPI2 == EPI_RESID_LN && C == 128), "fc2 epilogue");
+  extern __shared__ __attribute__((aligned(1024))) char wide_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = (p.M + BM - 1) / BM, G = gridDim.x;
+  const int ntl = (ntiles - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup: blockIdx.x, + G, ...
+  const int total = ntl * NSTEP;
+  {
+    float* b1s = reinterpret_cast<float*>(wide_lds + R * SLOT_BYTES + L::STG_BYTES);
+    for (int i = tid; i < H; i += 64 * (NW + NLOAD)) b1s[i] = p.b1[i];
+    for (int i = tid; i < C; i += 64 * (NW + NLOAD)) b1s[H + i] = p.g2.bias[i];
+    __syncthreads();
+  }
+
+  if (wave >= NW) {
+    // ================================================================================================ loader waves
+    const int lw = wave - NW;
+    constexpr int L1 = L::L1, L2 = L::L2, LSTEP = L::LSTEP;
+    uint32_t off1[L1], off2[L2];
+#pragma unroll
+    for (int t = 0; t < L1; ++t) {
+      const int i = lw + NLOAD * t, kc = i >> 3, q = i & 7;
+      const int lrow = 8 * q + (lane >> 3), pos = lane & 7, chunk = pos ^ ((lrow >> 1) & 7);
+      const int T = lrow >> 4, r = lrow & 15, hl = 32 * (T >> 1) + 8 * (r >> 2) + 4 * (T & 1) + (r & 3);  // the row permutation (see top)
+      off1[t] = (uint32_t)((hl * C + kc * 64 + chunk * 8) * 2);
+    }
+#pragma unroll
+    for (int t = 0; t < L2; ++t) {
+      const int q = lw + NLOAD * t, c = 8 * q + (lane >> 3), pos = lane & 7, chunk = pos ^ ((c >> 1) & 7);
+      off2[t] = (uint32_t)((c * H + chunk * 8) * 2);
+    }
+    const char* w1b = reinterpret_cast<const char*>(p.w1);
+    const char* w2b = reinterpret_cast<const char*>(p.w2);
+    int issued = 0, f_st = 0;
+    auto issue_next = [&]() __attribute__((always_inline)) {
+      const uint32_t slot = (uint32_t)(issued & (R - 1)) * SLOT_BYTES;
+      const char* s1 = w1b + (long)f_st * (64 * C * 2);
+      const char* s2 = w2b + (long)f_st * 128;
+#pragma unroll
+      for (int t = 0; t < L1; ++t) {
+        const int i = lw + NLOAD * t;
+        __builtin_amdgcn_global_load_lds((pipe_glb_ptr)(s1 + off1[t]), (pipe_lds_ptr)(wide_lds + slot + (i >> 3) * 8192 + (i & 7) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < L2; ++t) {
+        const int q = lw + NLOAD * t;
+        __builtin_amdgcn_global_load_lds((pipe_glb_ptr)(s2 + off2[t]), (pipe_lds_ptr)(wide_lds + slot + W1_BYTES + q * 1024), 16, 0, 0);
+      }
+      ++issued;
+      if (++f_st == NSTEP) f_st = 0;
+    };
+    static_assert(R == 2, "the wait below assumes one step in flight behind the one awaited");
+    WS_DECL(ws_wait); WS_DECL(ws_bar); WS_DECL(ws_issue); WS_DECL(ws_all);
+#ifdef WIDE_STAMPS
+    const unsigned long long ws_begin = __builtin_amdgcn_s_memtime();
+#endif
+    if (total > 0) issue_next();
+    for (int g = 0; g < total; ++g) {
+      { WS_T0(); ring_vmcnt<0>(); WS_ADD(ws_wait); }   // step g has landed (issued == g + 1: nothing younger is in flight)
+      { WS_T0(); ring_barrier(); WS_ADD(ws_bar); }     // B_g: the consumers are past step g - 1 -> its slot is free
+      { WS_T0(); if (issued < total) issue_next(); WS_ADD(ws_issue); }
+    }
+#ifdef WIDE_STAMPS
+    ws_all = __builtin_amdgcn_s_memtime() - ws_begin;
+#endif
+    WS_OUT(0, ws_wait); WS_OUT(1, ws_bar); WS_OUT(2, ws_issue); WS_OUT(3, ws_all); WS_OUT(4, 1ull);
+    (void)LSTEP;
+    return;
+  }
+
+  // ==================================================================================================== consumer waves
+  const int g4 = lane >> 4, l15 = lane & 15, swz = (lane >> 1) & 7;
+  const uint32_t lds0 = pipe_lds_addr(wide_lds);
+  const uint32_t fo0 = lds0 + l15 * 128 + ((g4 ^ swz) << 4), fo1 = lds0 + l15 * 128 + (((4 + g4) ^ swz) << 4);
+  MaskEval meH, meO;
+  meH.init(p.drop_h);
+  meO.init(p.g2.epi);
+  float* est = reinterpret_cast<float*>(wide_lds + R * SLOT_BYTES) + wave * 16 * L::WPITCH;
+  const float* b1s = reinterpret_cast<const float*>(wide_lds + R * SLOT_BYTES + L::STG_BYTES);
+  const float* b2s = b1s + H;
+  float* Cout = reinterpret_cast<float*>(p.g2.C);
+  float pgd[4] = {0.f, 0.f, 0.f, 0.f}, pbd[4] = {0.f, 0.f, 0.f, 0.f}, lngd[4] = {0.f, 0.f, 0.f, 0.f};  // (EPI_LN_BWD operands of the shared epilogue: unused)
+
+  int slot = 0;
+  WS_DECL(ws_cbar); WS_DECL(ws_fc1); WS_DECL(ws_gelu); WS_DECL(ws_fc2); WS_DECL(ws_epi); WS_DECL(ws_call);
+#ifdef WIDE_STAMPS
+  const unsigned long long ws_cbegin = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+  for (int i = 0, tile = blockIdx.x; i < ntl; ++i, tile += G) {
+    const int m0 = tile * BM, mbase = m0 + wave * 16, m = mbase + l15;
+    const bool mok = m < p.M;
+    const long mrow = mok ? m : p.M - 1;
+    bf16x8 xa[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) xa[kk] = *reinterpret_cast<const bf16x8*>(p.a + mrow * C + kk * 32 + 8 * g4);
+    f32x4 yacc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef WIDE_HOIST128
+    PipePre<float, EPI2, C, 1> pre;
+    if constexpr (C == 128) pipe_epilogue_prefetch<float, EPI2, BM, C, NW, 1>(p.g2, p.g2.resid, m0, 0, mbase, 0, lane, Cout, pre);
+#endif
+    bf16_t* hrow = p.h + (long)m * H + 8 * g4;
+    bf16_t* hgrow = p.hg + (long)m * H + 8 * g4;
+
+#pragma unroll 1
+    for (int st = 0; st < NSTEP; ++st) {
+      // this lane's 2 x 8 biases of the step (hidden 64 st + 32 s + 8 g .. + 7), from the LDS copy
+      f32x4 bq[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bq[s][0] = *reinterpret_cast<const f32x4*>(b1s + 64 * st + 32 * s + 8 * g4);
+        bq[s][1] = *reinterpret_cast<const f32x4*>(b1s + 64 * st + 32 * s + 8 * g4 + 4);
+      }
+      { WS_T0(); ring_barrier(); WS_ADD(ws_cbar); }  // B_g: the step is in LDS (the loaders waited for it)
+      const uint32_t sb = (uint32_t)slot * SLOT_BYTES;
+      WS_NOW(ws_a);
+      // ---- fc1: u[T] = W1 rows of tile T (16 hidden units, permuted) x this wave's 16 tokens
+      f32x4 u[4];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) u[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pipe_static_for<0, KK / 2>([&](auto kc_) {
+        constexpr int kc = decltype(kc_)::value;
+        bf16x8 w[8];
+        pipe_static_for<0, 4>([&](auto T_) {
+          constexpr int T = decltype(T_)::value;
+          w[T] = pipe_lds_read128<kc * 8192 + T * 2048>(fo0 + sb);
+          w[4 + T] = pipe_lds_read128<kc * 8192 + T * 2048>(fo1 + sb);
+        });
+        lds_wait8(w);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) u[T] = mma16(w[T], xa[2 * kc], u[T]);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) u[T] = mma16(w[4 + T], xa[2 * kc + 1], u[T]);
+      });
+      WS_NOW(ws_b);
+      // ---- bias + GELU (+ derivative) + dropout: the element math of EPI_GELU_FWD on columns 64 st + 32 s + 8 g .. + 7 (u[2 s] | u[2 s + 1])
+      bf16x8 hf[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8], gq[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = u[2 * s][e] + bq[s][0][e];
+          v[4 + e] = u[2 * s + 1][e] + bq[s][1][e];
+        }
+        const int n = 64 * st + 32 * s + 8 * g4;
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+          gelu_f2 mult[2];
+          meH.elem_mult_quad(m, n + e, mult[0], mult[1]);
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const gelu_f2 x = {v[e + 2 * h2], v[e + 2 * h2 + 1]};
+#ifndef WIDE_LAB_NO_GELU
+            gelu_f2 cdf, pdf;
+            gelu_parts2(x, cdf, pdf);
+#else
+            const gelu_f2 cdf = x, pdf = x;
+#endif
+            const gelu_f2 gg = (x * pdf + cdf) * mult[h2], hh = x * cdf * mult[h2];
+            gq[e + 2 * h2] = gg.x; gq[e + 2 * h2 + 1] = gg.y;
+            v[e + 2 * h2] = hh.x; v[e + 2 * h2 + 1] = hh.y;
+          }
+        }
+        bf16x8 hgv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          hf[s][e] = (bf16_t)v[e];
+          hgv[e] = (bf16_t)gq[e];
+        }
+#ifndef WIDE_LAB_NO_STORES
+        if (mok) {
+          *reinterpret_cast<bf16x8*>(hrow + 64 * st + 32 * s) = hf[s];
+          *reinterpret_cast<bf16x8*>(hgrow + 64 * st + 32 * s) = hgv;
+        }
+#else
+        if (m == -12345) *reinterpret_cast<bf16x8*>(hgrow) = hgv;
+#endif
+      }
+      WS_NOW(ws_c);
+      // ---- fc2: yacc[j] += W2 rows 16 j .. + 15 (this step's 64 hidden columns) x h
+      pipe_static_for<0, CT / 4>([&](auto jq_) {
+        constexpr int jq = decltype(jq_)::value;
+        bf16x8 w[8];
+        pipe_static_for<0, 4>([&](auto jj_) {
+          constexpr int j = 4 * jq + decltype(jj_)::value;
+          w[2 * decltype(jj_)::value] = pipe_lds_read128<W1_BYTES + j * 2048>(fo0 + sb);
+          w[2 * decltype(jj_)::value + 1] = pipe_lds_read128<W1_BYTES + j * 2048>(fo1 + sb);
+        });
+        lds_wait8(w);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          yacc[4 * jq + jj] = mma16(w[2 * jj], hf[0], yacc[4 * jq + jj]);
+          yacc[4 * jq + jj] = mma16(w[2 * jj + 1], hf[1], yacc[4 * jq + jj]);
+        }
+      });
+      slot ^= 1;
+      WS_NOW(ws_d);
+      WS_ACC(ws_fc1, ws_a, ws_b); WS_ACC(ws_gelu, ws_b, ws_c); WS_ACC(ws_fc2, ws_c, ws_d);
+    }
+    WS_NOW(ws_e0);
+
+    // ---- fc2's epilogue
+    if constexpr (C == 128) {
+      // (what the epilogue reads -- residual rows, bias -- is requested here, not before the steps: 36 registers less across the loop; the
+      // SIMD's other waves cover the latency)
+#ifndef WIDE_HOIST128
+      PipePre<float, EPI2, C, 1> pre;
+      pipe_epilogue_prefetch<float, EPI2, BM, C, NW, 1>(p.g2, p.g2.resid, m0, 0, mbase, 0, lane, Cout, pre);
+#endif
+      const PipeBias<4> bias2 = pipe_epilogue_bias<float, EPI2, C, 1>(p.g2.bias, 0, 0, lane);
+      pipe_epilogue_finish<float, EPI2, BM, C, NW, 1>(p.g2, p.g2.alpha, yacc, est, meO, m0, 0, mbase, 0, lane, Cout, bias2.v, pgd, pbd, lngd, pre);
+    } else {
+      // EPI_RESID, element by element as pipe_epilogue_finish does it (v = acc + bias; y = resid + v * row mask * element mask), straight
+      // from the accumulators: lane = token, columns 16 j + 4 g .. + 3
+      const float rowm = meO.row_mult(m);
+      const float* rrow = p.g2.resid + mrow * p.g2.ldr + 4 * g4;
+      float* yrow = Cout + (long)m * p.g2.ldc + 4 * g4;
+      // (the residual rows four column tiles ahead: the loads of batch q + 1 are issued BEFORE the stores of batch q, so waiting for them
+      // never waits for a store -- vmcnt counts both, in order)
+      f32x4 res[2][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) res[0][jj] = gload4(rrow + 16 * jj);
+      pipe_static_for<0, CT / 4>([&](auto q_) {
+        constexpr int q = decltype(q_)::value;
+        if constexpr (q + 1 < CT / 4) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) res[(q + 1) & 1][jj] = gload4(rrow + 16 * (4 * (q + 1) + jj));
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = 4 * q + jj;
+          const f32x4 b2 = *reinterpret_cast<const f32x4*>(b2s + 16 * j + 4 * g4);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = yacc[j][e] * p.g2.alpha;
+            v += b2[e];
+            o[e] = res[q & 1][jj][e] + v * rowm * meO.elem_mult(m, 16 * j + 4 * g4 + e);
+          }
+          if (mok) store4(yrow + 16 * j, o);
+        }
+      });
+    }
+    WS_NOW(ws_e1);
+    WS_ACC(ws_epi, ws_e0, ws_e1);
+  }
+#ifdef WIDE_STAMPS
+  ws_call = __builtin_amdgcn_s_memtime() - ws_cbegin;
+#endif
+  WS_OUT(0, ws_cbar); WS_OUT(1, ws_fc1); WS_OUT(2, ws_gelu); WS_OUT(3, ws_fc2); WS_OUT(5, ws_epi); WS_OUT(6, ws_call); WS_OUT(4, 2ull);
+}
+
+}  // namespace focal_mlp_wide
+using namespace focal_mlp_wide;
+
+static MaskParams wide_mask(const focal_drop_desc& d, int ncols) {
+  MaskParams m;
+  m.seed = d.rng;
+  m.stream_elem = d.stream_elem;
+  m.p_elem = d.p_elem;
+  m.stream_path = d.stream_path;
+  m.p_path = d.p_path;
+  m.rows_per_sample = d.rows_per_sample;
+  m.ncols = ncols;
+  return m;
+}
+
+// Not the default: measured against the two launches it replaces (profiles/r6_mlp_wide.txt) the one-launch form ties at 128 channels
+// (0.88-1.07 x) and loses at 256 (0.66-1.00 x) -- both forms are bound by vector-instruction issue (GELU + derivative + mask hash + packing:
+// ~35 issue slots per element pair), not by the 8C bytes per token the fusion removes.  FOCAL_MLP_WIDE=1 selects it (the Swin engine asks here).
+extern "C" int focal_mlp_wide_supported(int dtype, int C_, int hidden) {
+  const char* on = getenv("FOCAL_MLP_WIDE");
+  return dtype == FOCAL_BF16 && (C_ == 128 || C_ == 256) && hidden == 4 * C_ && on != nullptr && on[0] == '1';
+}
+
+template <int C, int EPI2>
+static int launch_wide_fwd(const WideFwdParams& p, hipStream_t st) {
+  using L = WideLayout<C>;
+  auto kern = mlp_wide_fwd_kernel<C, EPI2>;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set.load(std::memory_order_acquire)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES) != hipSuccess) {
+      focal_set_error("mlp_wide_fwd: cannot reserve %d bytes of LDS", L::LDS_BYTES);
+      return FOCAL_EHIP;
+    }
+    attr_set.store(true, std::memory_order_release);
+  }
+  constexpr int BM = L::BM, NW = L::NW;
+  const int ntiles = (p.M + BM - 1) / BM, cus = focal_cu_count();
+  // persistent, one workgroup per CU; every workgroup the same number of tiles where the tile count allows
+  const int rounds = (ntiles + cus - 1) / cus;
+  const int grid = (ntiles + rounds - 1) / rounds;
+  FOCAL_LAUNCH(kern, dim3(grid), dim3(64 * (NW + NLOAD)), L::LDS_BYTES, st, p);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+extern "C" int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
+                                  const float* b2, float* y, void* h, void* hg, const float* ln_gamma, const float* ln_beta, void* y_ln,
+                                  float* ln_stats, void* stream) {
+  FOCAL_CHECK_ARG(d != nullptr, "mlp_wide_fwd: null descriptor");
+  FOCAL_CHECK_ARG(d->dtype == FOCAL_BF16 && (d->C == 128 || d->C == 256) && d->hidden == 4 * d->C,
+                  "mlp_wide_fwd: bf16, C = 128 or 256, hidden = 4 C (got dtype %d, C %d, hidden %d)", d->dtype, d->C, d->hidden);
+  FOCAL_CHECK_ARG(d->M > 0, "mlp_wide_fwd: M = %d", d->M);
+  FOCAL_CHECK_ARG(a && resid && w1 && b1 && w2 && b2 && y && h && hg, "mlp_wide_fwd: null tensor");
+  const bool ln = y_ln != nullptr;
+  if (ln) FOCAL_CHECK_ARG(d->C == 128 && ln_gamma && ln_beta && ln_stats, "mlp_wide_fwd: the fused LayerNorm exists at 128 channels and needs gamma, beta and a statistics buffer");
+  WideFwdParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->M;
+  p.a = reinterpret_cast<const bf16_t*>(a);
+  p.w1 = reinterpret_cast<const bf16_t*>(w1);
+  p.b1 = b1;
+  p.w2 = reinterpret_cast<const bf16_t*>(w2);
+  p.h = reinterpret_cast<bf16_t*>(h);
+  p.hg = reinterpret_cast<bf16_t*>(hg);
+  p.drop_h = wide_mask(d->drop_hidden, d->hidden);
+  GemmParams& g = p.g2;  // (as focal_linear_fwd / focal_linear_resid_ln_fwd fill it for fc2)
+  g.M = d->M; g.N = d->C; g.K = d->hidden;
+  g.C = y; g.ldc = d->C;
+  g.batch = 1; g.splits = 1; g.alpha = 1.f;
+  g.bias = b2;
+  g.resid = resid; g.ldr = d->C;
+  g.aux_out = y_ln;
+  g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.ln_stats = ln_stats; g.ln_eps = d->ln_eps;
+  g.epi = wide_mask(d->drop_out, d->C);
+#ifdef WIDE_STAMPS
+  g.colsumA = reinterpret_cast<float*>(ln_stats && !ln ? ln_stats : nullptr);  // lab build: the stamp buffer rides in ln_stats when no LayerNorm is asked for
+#endif
+  hipStream_t st = (hipStream_t)stream;
+  if (d->C == 128) return ln ? launch_wide_fwd<128, EPI_RESID_LN>(p, st) : launch_wide_fwd<128, EPI_RESID>(p, st);
+  return launch_wide_fwd<256, EPI_RESID>(p, st);
+}

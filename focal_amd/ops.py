@@ -544,6 +544,26 @@ def mlp_fwd(d, a, resid, w1, b1, w2, b2, y, next_ln=None, mask_bits=None):
     return y_ln, stats
 
 
+def mlp_wide_supported(dtype, Cc, hidden):
+    return bool(_lib.load().focal_mlp_wide_supported(code(dtype), Cc, hidden))
+
+
+def mlp_wide_fwd(d, a, resid, w1, b1, w2, b2, y, h, hg, next_ln=None):
+    """The MLP branch at 128 / 256 channels as one launch (focal_mlp_wide_fwd): h, hg = drop_hidden(gelu(a w1^T + b1)) and its derivative
+    x mask ([M, hidden], written for the backward pass), y = resid + drop_out(h w2^T + b2); next_ln = (gamma, beta) (128 channels) also
+    returns (LayerNorm(y) in a's dtype, stats).  Bit-identical to linear_fwd(GELU) + linear_fwd / linear_resid_ln_fwd."""
+    _need_cuda(a, resid, w1, b1, w2, b2, y, h, hg)
+    assert h.shape == (d.M, d.hidden) and hg.shape == h.shape and h.dtype == a.dtype and hg.dtype == a.dtype and h.is_contiguous() and hg.is_contiguous()
+    if next_ln is None:
+        check(_lib.load().focal_mlp_wide_fwd(C.byref(d), _p(a), _p(resid), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(h), _p(hg), None, None, None, None, _stream()))
+        return None
+    y_ln = torch.empty(d.M, d.C, dtype=a.dtype, device=a.device)
+    stats = torch.empty(d.M, 2, dtype=torch.float32, device=a.device)
+    check(_lib.load().focal_mlp_wide_fwd(C.byref(d), _p(a), _p(resid), _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(h), _p(hg), _p(next_ln[0]), _p(next_ln[1]),
+                                         _p(y_ln), _p(stats), _stream()))
+    return y_ln, stats
+
+
 def mlp_bwd_partials_floats(d):
     return int(_lib.load().focal_mlp_bwd_partials_floats(C.byref(d)))
 

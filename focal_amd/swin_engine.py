@@ -141,6 +141,22 @@ class SwinModEncoder:
                     continue
                 h = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)
                 hg = torch.empty(M, 4 * Cc, dtype=ct, device=x.device)  # d h / d(pre-activation), dropout included
+                want_ln = fuse_ln and (Cc == 64 or fuse_wide) and ops.resid_ln_supported(cc, Cc, 4 * Cc) and bi + 1 < st["depth"]
+                if fuse_mlp and ops.mlp_wide_supported(ct, Cc, 4 * Cc):
+                    # stages 1-2 (round 6): fc1 -> GELU -> dropout -> fc2 -> residual (+ the next LayerNorm at 128 channels) as ONE launch; h and
+                    # hg are written once for the backward pass and never read back (bit-identical to the two launches below)
+                    d_wide = ops.mlp_desc(cc, M, Cc, 4 * Cc, d_fc1.out_drop, d_fc2.out_drop)
+                    nxt_ln = None
+                    if want_ln:
+                        nb = f"{self.pre}.{si}.blocks.{bi + 1}"
+                        nxt_ln = (ar.master(f"{nb}.norm1.weight"), ar.master(f"{nb}.norm1.bias"))
+                    pre_ln = ops.mlp_wide_fwd(d_wide, a2, x_mid, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
+                                              ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_out, h, hg, next_ln=nxt_ln)
+                    saved["blocks"].append(dict(pb=pb, x=x, st1=st1, a1=a1, qkv=qkv, o=o, x_mid=x_mid, st2=st2, a2=a2, h=h, hg=hg,
+                                                d_qkv=d_qkv, d_att=d_att, d_proj=d_proj, d_fc1=d_fc1, d_fc2=d_fc2, M=M, C=Cc))
+                    x = x_out
+                    uid += 1
+                    continue
                 ops.linear_fwd(d_fc1, a2, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"), None, h, hg)
                 if fuse_ln and (Cc == 64 or fuse_wide) and ops.resid_ln_supported(cc, Cc, 4 * Cc) and bi + 1 < st["depth"]:
                     nb = f"{self.pre}.{si}.blocks.{bi + 1}"

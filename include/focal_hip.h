@@ -315,6 +315,21 @@ int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void* a, const 
  * side's 1.3 TB/s): a device workspace of focal_mlp_bwd_partials_floats(d) floats, 16-byte aligned -- the workgroups store their images
  * there with plain stores and a second, small launch on the same stream sums them into dw1 / dw2. */
 long focal_mlp_bwd_partials_floats(const focal_mlp_desc* d);
+/* The same branch at 128 / 256 channels (Swin stages 1-2; round 6): ONE launch instead of the fc1 and fc2 launches of focal_linear_fwd /
+ * focal_linear_resid_ln_fwd.  The weights (256 KB / 1 MB) stream through an LDS ring 64 hidden units at a time; a wave keeps its 16 token
+ * rows' [16, C] fc2 accumulators in registers across the slices and feeds each slice's activation to fc2 straight from the fc1
+ * accumulators, so the hidden tensor's tiles never leave the chip between the two products.  h and hg ([M, hidden], dtype: the activation
+ * and its derivative x dropout mask) are still WRITTEN -- once -- because the backward pass of these widths reads them (a recomputing
+ * backward needs 1 MB of weight-gradient accumulators per workgroup).  y_ln / ln_* (C = 128 only): the LayerNorm that reads y next, as
+ * focal_linear_resid_ln_fwd emits it.  Every output is bit-identical to the two-launch form (same k order, same element math, same mask
+ * indices; with the masks on, to an ulp where hipcc contracts the residual expression differently).  MEASURED AND NOT THE DEFAULT
+ * (profiles/r6_mlp_wide.txt: 0.88-1.07 x the two launches at 128 channels, 0.66-1.00 x at 256: both forms are bound by vector-instruction
+ * issue, not by the bytes the fusion removes): focal_mlp_wide_supported returns 1 only under FOCAL_MLP_WIDE=1; focal_mlp_wide_fwd itself
+ * always works. */
+int focal_mlp_wide_supported(int dtype, int C, int hidden);
+int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
+                       const float* b2, float* y, void* h, void* hg, const float* ln_gamma, const float* ln_beta, void* y_ln,
+                       float* ln_stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 10: W-MSA
  * WindowAttention between its qkv and proj Linears (models/SwinModules.py:121-152) with the cyclic shift, window

@@ -1,0 +1,132 @@
+"""The Swin MLP branch at 128 / 256 channels as one launch (focal_mlp_wide_fwd, round 6; reference: models/SwinModules.py:18-34 +
+:339-341) through the C ABI: bit-identical to the two launches it replaces (focal_linear_fwd with the GELU epilogue, then
+focal_linear_fwd / focal_linear_resid_ln_fwd with the residual epilogue) -- every output, every dropout / drop-path mask on and off,
+ragged row counts -- and against torch fp32 of the same expression on the bf16-rounded operands."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def _operands(M, C, seed=0):
+    a = rnd(M, C, seed=seed + 1, dtype=BF)
+    w1, b1 = rnd(4 * C, C, scale=C ** -0.5, seed=seed + 2, dtype=BF), rnd(4 * C, scale=0.3, seed=seed + 3)
+    w2, b2 = rnd(C, 4 * C, scale=(4 * C) ** -0.5, seed=seed + 4, dtype=BF), rnd(C, scale=0.3, seed=seed + 5)
+    r = rnd(M, C, seed=seed + 6)
+    return a, w1, b1, w2, b2, r
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from focal_amd import ops as o
+    return o
+
+
+def _two_launches(ops, M, C, a, w1, b1, w2, b2, r, drop_h, drop_o, ln):
+    from focal_amd._lib import ACT_GELU, ACT_NONE, EPI_GELU, EPI_RESIDUAL
+    cc, f32 = ops.code(BF), ops.code(torch.float32)
+    d1 = ops.linear_desc(cc, M, 4 * C, C, cc, cc, ACT_NONE, EPI_GELU, out_drop=drop_h)
+    d2 = ops.linear_desc(cc, M, C, 4 * C, cc, f32, ACT_GELU, EPI_RESIDUAL, out_drop=drop_o)
+    h, hg = torch.empty(M, 4 * C, dtype=BF, device=DEV), torch.empty(M, 4 * C, dtype=BF, device=DEV)
+    ops.linear_fwd(d1, a, w1, b1, None, h, hg)
+    y = torch.empty(M, C, device=DEV)
+    if ln is not None:
+        y_ln, stats = ops.linear_resid_ln_fwd(d2, h, w2, b2, r, y, ln[0], ln[1], BF)
+        return h, hg, y, y_ln, stats
+    ops.linear_fwd(d2, h, w2, b2, r, y)
+    return h, hg, y, None, None
+
+
+@pytest.mark.parametrize("C,M,drop,ln", [(128, 36864, True, True), (128, 36864, False, False), (128, 1000, True, True), (128, 96, False, True),
+                                         (256, 9216, True, False), (256, 18432, False, False), (256, 1000, True, False), (256, 50, False, False)])
+def test_one_launch_equals_the_two_launches_bit_for_bit(ops, C, M, drop, ln, monkeypatch):
+    assert not ops.mlp_wide_supported(BF, C, 4 * C)   # opt-in: it does not beat the two launches (profiles/r6_mlp_wide.txt)
+    monkeypatch.setenv("FOCAL_MLP_WIDE", "1")
+    assert ops.mlp_wide_supported(BF, C, 4 * C) and not ops.mlp_wide_supported(torch.float32, C, 4 * C) and not ops.mlp_wide_supported(BF, 64, 256)
+    a, w1, b1, w2, b2, r = _operands(M, C, seed=3 * C + M)
+    rng = ops.new_rng_state(20260 + M, DEV)
+    drop_h = ops.drop_desc(rng, 17, 0.2, 21, 0.0, 1) if drop else None
+    drop_o = ops.drop_desc(rng, 18, 0.2, 22, 0.1, 9) if drop else None
+    lnp = (rnd(C, seed=11) * 0.2 + 1.0, rnd(C, seed=12) * 0.1) if ln else None
+    h0, hg0, y0, yln0, st0 = _two_launches(ops, M, C, a, w1, b1, w2, b2, r, drop_h, drop_o, lnp)
+    d = ops.mlp_desc(ops.code(BF), M, C, 4 * C, drop_h, drop_o)
+    h, hg = torch.full((M, 4 * C), 7.0, dtype=BF, device=DEV), torch.full((M, 4 * C), 7.0, dtype=BF, device=DEV)
+    y = torch.full((M, C), 7.0, device=DEV)
+    out = ops.mlp_wide_fwd(d, a, r, w1, b1, w2, b2, y, h, hg, next_ln=lnp)
+    torch.cuda.synchronize()
+    assert torch.equal(h, h0) and torch.equal(hg, hg0)
+    if not drop:
+        assert torch.equal(y, y0)
+        if ln:
+            assert torch.equal(out[0], yln0) and torch.equal(out[1], st0)
+    else:
+        # masks on: y = resid + v * row mask * element mask is one rounding or two depending on whether hipcc contracts it to an FMA, and it
+        # decides that per kernel instantiation (the ring and the one-tile GEMM already differ from each other in one of a lane's four
+        # columns): equal to an ulp of y, and the LayerNorm outputs to a bf16 ulp on a handful of elements
+        assert (y - y0).abs().max().item() <= 2.5e-7 * y0.abs().max().item()
+        assert (y != y0).float().mean().item() < 0.08
+        if ln:
+            assert (out[0].float() - yln0.float()).abs().max().item() <= 2.0 ** -7 * yln0.float().abs().max().item()
+            assert (out[0] != yln0).float().mean().item() < 1e-3 and torch.allclose(out[1], st0, rtol=1e-5, atol=1e-6)
+    if not ln:
+        assert out is None
+    if drop:  # the masks are on: a fifth of the hidden units are zero in h and in hg alike
+        z = (hg == 0).float().mean().item()
+        assert 0.18 < z < 0.22, z
+        assert bool(((hg == 0) <= (h == 0)).all())
+    if not drop:
+        hh = F.gelu(a.float() @ w1.float().t() + b1)
+        assert rel_err(h.float(), hh) < 4e-3
+        ref = r + hh.to(BF).float() @ w2.float().t() + b2
+        assert rel_err(y, ref) < 3e-3
+
+
+def test_wide_mlp_rejects_what_it_was_not_built_for(ops):
+    from focal_amd._lib import FocalHipError
+    a, w1, b1, w2, b2, r = _operands(64, 256)
+    d = ops.mlp_desc(ops.code(BF), 64, 256, 1024)
+    y, h, hg = torch.empty(64, 256, device=DEV), torch.empty(64, 1024, dtype=BF, device=DEV), torch.empty(64, 1024, dtype=BF, device=DEV)
+    with pytest.raises(FocalHipError):  # the fused LayerNorm exists at 128 channels only
+        ops.mlp_wide_fwd(d, a, r, w1, b1, w2, b2, y, h, hg, next_ln=(torch.ones(256, device=DEV), torch.zeros(256, device=DEV)))
+    d64 = ops.mlp_desc(ops.code(BF), 64, 64, 256)
+    with pytest.raises((FocalHipError, AssertionError)):
+        ops.mlp_wide_fwd(d64, a[:, :64].contiguous(), r[:, :64].contiguous(), w1, b1, w2, b2, y[:, :64].contiguous(), h, hg)
+
+
+def test_encoder_with_the_one_launch_mlp_equals_the_default(cfg, monkeypatch):
+    """FOCAL_MLP_WIDE=1 through the Swin engine (stages 1-2 of both modality encoders, dropout off): embeddings bit-identical to the default
+    two-launch form; h and hg are the same tensors, so the backward pass cannot tell (gradients equal up to the order of the weight
+    gradients' fp32 atomics, which differs between any two runs)."""
+    from test_swt_parity_gpu import build, inputs
+
+    def run():
+        args, net, focal, loss_fn = build(cfg, "bf16")
+        net.train()
+        x1, x2 = inputs(cfg)
+        f1, f2 = focal(x1, x2, proj_head=True)
+        loss = loss_fn(f1, f2)
+        net.arena().zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        return {m: f1[m].detach().clone() for m in f1}, net.arena().grad.clone()
+    e0, g0 = run()
+    monkeypatch.setenv("FOCAL_MLP_WIDE", "1")
+    e1, g1 = run()
+    for m in e0:
+        assert torch.equal(e0[m], e1[m])
+    assert (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item()

@@ -2,7 +2,7 @@
 # Usage: bash tools/build_variant.sh <name> "<-D flags>" <file.hip> [more files]   -> focal_amd/lab/libfocal_hip_<name>.so
 # A/B builds of single translation units for same-box comparisons (FOCAL_HIP_LIB=... selects the library at run time).
 name=$1; flags=$2; shift; shift
-root=$(cd "$(dirname "$0")/../.." && pwd)
+root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $root/focal_amd/lab $root/build/lab_$name
 objs=""
 for f in $(ls $root/build/csrc/*.o); do
