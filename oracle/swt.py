@@ -11,14 +11,27 @@ from .config import block_window_and_shift, swt_geometry
 
 # bf16 operand emulation (SURVEY appendix D's method): with `emulate_bf16` the functions below round, in fp32 arithmetic, exactly
 # the tensors that the MI355X bf16 path stores or feeds to the matrix cores as bf16 -- linear-layer weights, LayerNorm outputs, qkv,
-# the attention probabilities and output, the GELU output, the fp32 activations entering mod_in / the projector -- and nothing else
-# (residual stream, statistics, softmax, biases, patch embedding stay fp32).  The HIP bf16 path must agree with THIS to a few 1e-3;
+# the attention probabilities and output, the GELU output -- and nothing else (residual stream, statistics, softmax, biases, patch embedding
+# and, since round 6, the operands of the projector stay fp32).  The HIP bf16 path must agree with THIS to a few 1e-3;
 # what separates either from the fp32 reference is operand rounding, not arithmetic.
 _EMULATE = [False]
+# (attribution runs, tests/bf16_error_attribution.py: rounding sites whose name matches one of these regular expressions are left in fp32)
+_KEEP_FP32 = []
+# round 6: the projector multiplies fp32 operands in the HIP bf16 path (focal_amd/swin_engine.py: tail_fp32); False emulates the round-5
+# path, which rounded them
+_TAIL_FP32 = [True]
 
 
-def _r(t):
-    return t.bfloat16().to(t.dtype) if _EMULATE[0] else t
+def _r(t, site=""):
+    if not _EMULATE[0]:
+        return t
+    if _TAIL_FP32[0] and site.startswith("mod_projectors."):
+        return t
+    if _KEEP_FP32:
+        import re
+        if any(re.search(p, site) for p in _KEEP_FP32):
+            return t
+    return t.bfloat16().to(t.dtype)
 
 
 def relative_position_index(wh, ww):
@@ -61,7 +74,7 @@ def window_attention(P, pre, xw, heads, wh, ww, mask):
     """WindowAttention.forward, SwinModules.py:121-152 (dropouts are identity)."""
     Bw, N, C = xw.shape
     hd = C // heads
-    qkv = _r(F.linear(xw, _r(P[f"{pre}.qkv.weight"]), P[f"{pre}.qkv.bias"])).view(Bw, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    qkv = _r(F.linear(xw, _r(P[f"{pre}.qkv.weight"], f"{pre}.qkv.weight"), P[f"{pre}.qkv.bias"]), f"{pre}.qkv.out").view(Bw, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
     attn = q @ k.transpose(-2, -1)
     table = P[f"{pre}.relative_position_bias_table"]
@@ -70,16 +83,16 @@ def window_attention(P, pre, xw, heads, wh, ww, mask):
     if mask is not None:
         nW = mask.shape[0]
         attn = (attn.view(Bw // nW, nW, heads, N, N) + mask.to(attn.dtype)[None, :, None]).view(-1, heads, N, N)
-    attn = _r(attn.softmax(-1))
-    out = _r((attn @ v).transpose(1, 2).reshape(Bw, N, C))
-    return F.linear(out, _r(P[f"{pre}.proj.weight"]), P[f"{pre}.proj.bias"])
+    attn = _r(attn.softmax(-1), f"{pre}.probs")
+    out = _r((attn @ v).transpose(1, 2).reshape(Bw, N, C), f"{pre}.out")
+    return F.linear(out, _r(P[f"{pre}.proj.weight"], f"{pre}.proj.weight"), P[f"{pre}.proj.bias"])
 
 
 def swin_block(P, pre, x, H, W, heads, window, block_idx, taps=None):
     """SwinTransformerBlock.forward, SwinModules.py:294-343."""
     B, L, C = x.shape
     wh, ww, sh, sw, shifted = block_window_and_shift(H, W, window, block_idx)
-    y = _r(F.layer_norm(x, (C,), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], 1e-5)).view(B, H, W, C)
+    y = _r(F.layer_norm(x, (C,), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], 1e-5), f"{pre}.norm1.out").view(B, H, W, C)
     mask = None
     if shifted:
         y = torch.roll(y, shifts=(-sh, -sw), dims=(1, 2))
@@ -89,10 +102,10 @@ def swin_block(P, pre, x, H, W, heads, window, block_idx, taps=None):
     if shifted:
         y = torch.roll(y, shifts=(sh, sw), dims=(1, 2))
     x = x + y.reshape(B, L, C)
-    z = _r(F.layer_norm(x, (C,), P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], 1e-5))
-    z = F.linear(z, _r(P[f"{pre}.mlp.fc1.weight"]), P[f"{pre}.mlp.fc1.bias"])
-    z = _r(F.gelu(z))  # exact erf form, SwinModules.py:19
-    z = F.linear(z, _r(P[f"{pre}.mlp.fc2.weight"]), P[f"{pre}.mlp.fc2.bias"])
+    z = _r(F.layer_norm(x, (C,), P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"], 1e-5), f"{pre}.norm2.out")
+    z = F.linear(z, _r(P[f"{pre}.mlp.fc1.weight"], f"{pre}.mlp.fc1.weight"), P[f"{pre}.mlp.fc1.bias"])
+    z = _r(F.gelu(z), f"{pre}.mlp.gelu.out")  # exact erf form, SwinModules.py:19
+    z = F.linear(z, _r(P[f"{pre}.mlp.fc2.weight"], f"{pre}.mlp.fc2.weight"), P[f"{pre}.mlp.fc2.bias"])
     return x + z
 
 
@@ -101,8 +114,8 @@ def patch_merging(P, pre, x, H, W):
     B, L, C = x.shape
     x = x.view(B, H, W, C)
     x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).view(B, -1, 4 * C)
-    x = _r(F.layer_norm(x, (4 * C,), P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-5))
-    return F.linear(x, _r(P[f"{pre}.reduction.weight"]))
+    x = _r(F.layer_norm(x, (4 * C,), P[f"{pre}.norm.weight"], P[f"{pre}.norm.bias"], 1e-5), f"{pre}.norm.out")
+    return F.linear(x, _r(P[f"{pre}.reduction.weight"], f"{pre}.reduction.weight"))
 
 
 def pad_and_embed(P, cfg, x, loc, mod):
@@ -152,7 +165,8 @@ def swt_forward(P, cfg, freq_x, proj_head=True, taps=None, emulate_bf16=False):
                 x = patch_merging(P, f"freq_interval_layers.{loc}.{mod}.{si}.downsample", x, st["H"], st["W"])
                 if taps is not None:
                     taps[f"{loc}.{mod}.merge{si}"] = x
-        x = F.linear(_r(x.reshape(x.shape[0], -1)), _r(P[f"mod_in_layers.{loc}.{mod}.weight"]), P[f"mod_in_layers.{loc}.{mod}.bias"])
+        x = F.linear(_r(x.reshape(x.shape[0], -1), f"mod_in_layers.{loc}.{mod}.x"), _r(P[f"mod_in_layers.{loc}.{mod}.weight"], f"mod_in_layers.{loc}.{mod}.weight"),
+                     P[f"mod_in_layers.{loc}.{mod}.bias"])
         if taps is not None:
             taps[f"{loc}.{mod}.feat"] = x
         feats[mod] = x
@@ -160,6 +174,7 @@ def swt_forward(P, cfg, freq_x, proj_head=True, taps=None, emulate_bf16=False):
         return feats
     out = {}
     for mod in cfg["modality_names"]:
-        h = F.relu(F.linear(_r(feats[mod]), _r(P[f"mod_projectors.{mod}.0.weight"]), P[f"mod_projectors.{mod}.0.bias"]))
-        out[mod] = F.linear(_r(h), _r(P[f"mod_projectors.{mod}.2.weight"]), P[f"mod_projectors.{mod}.2.bias"])
+        h = F.relu(F.linear(_r(feats[mod], f"mod_projectors.{mod}.0.x"), _r(P[f"mod_projectors.{mod}.0.weight"], f"mod_projectors.{mod}.0.weight"),
+                            P[f"mod_projectors.{mod}.0.bias"]))
+        out[mod] = F.linear(_r(h, f"mod_projectors.{mod}.2.x"), _r(P[f"mod_projectors.{mod}.2.weight"], f"mod_projectors.{mod}.2.weight"), P[f"mod_projectors.{mod}.2.bias"])
     return out

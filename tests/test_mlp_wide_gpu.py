@@ -109,8 +109,8 @@ def test_wide_mlp_rejects_what_it_was_not_built_for(ops):
 
 
 def test_encoder_with_the_one_launch_mlp_equals_the_default(cfg, monkeypatch):
-    """FOCAL_MLP_WIDE=1 through the Swin engine (stages 1-2 of both modality encoders, dropout off): embeddings bit-identical to the default
-    two-launch form; h and hg are the same tensors, so the backward pass cannot tell (gradients equal up to the order of the weight
+    """FOCAL_MLP_WIDE=1 through the Swin engine (stages 1-2 of both modality encoders, dropout off): embeddings equal to the default two-launch
+    form up to the order of mod_in's split-K atomics; h and hg are the same tensors, so the backward pass cannot tell (gradients equal up to the order of the weight
     gradients' fp32 atomics, which differs between any two runs)."""
     from test_swt_parity_gpu import build, inputs
 
@@ -127,6 +127,6 @@ def test_encoder_with_the_one_launch_mlp_equals_the_default(cfg, monkeypatch):
     e0, g0 = run()
     monkeypatch.setenv("FOCAL_MLP_WIDE", "1")
     e1, g1 = run()
-    for m in e0:
-        assert torch.equal(e0[m], e1[m])
+    for m in e0:  # (mod_in's split-K product sums its slices with fp32 atomics: equal to their order)
+        assert (e0[m] - e1[m]).abs().max().item() <= 1e-5 * e0[m].abs().max().item()
     assert (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item()
