@@ -216,13 +216,13 @@ def time_kernel(fn, iters=20):
 # of libfocal_hip carries a start / stop event pair on the dispatch, so a record is the kernel's own begin -> end time -- what
 # `rocprofv3 --kernel-trace` reports -- labelled with the launched kernel's symbol.  Groups are therefore rocprofv3's rows (one per
 # kernel instantiation; an op that launches two kernels is two groups) and are checked against the committed trace of the same
-# workload (profiles/r5_reference_<model>_<dataset>.json, made by tools/profile_round.sh from `rocprofv3 --kernel-trace --stats -M`).
+# workload (profiles/r6_reference_<model>_<dataset>.json, made by tools/profile_round.sh from `rocprofv3 --kernel-trace --stats -M`).
 # The Python side only attributes ALGORITHMIC bytes / flops: every public op of focal_amd.ops is wrapped, notes which trace records its
 # call produced, and describes what the call has to move.
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from kernel_names import short_kernel_name  # noqa: E402
 
-ROUND = "r5"
+ROUND = "r6"
 
 
 def _dw_bytes_flops(d):
@@ -281,13 +281,13 @@ class StepTracer:
 
         def dw(out, d, dy, x, dw_, db):
             b, f = _dw_bytes_flops(d)
-            return dict(bytes=b, flops=f, bound="hbm", inst=f"dW[{d.N},{d.K}] over {d.M} rows")
+            return dict(bytes=b, flops=f, bound="hbm", inst=f"dW[{d.N},{d.K}] over {d.M} rows", rows=d.M)
 
         def dwg(out, dtype_code, items, exclusive=True):
             b = sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + w.numel() * 4 for dy, x, w, _ in items)
             f = sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _, _ in items)
             rows, C = items[0][0].shape[0], min(min(dy.shape[1], x.shape[1]) for dy, x, _, _ in items)
-            return dict(bytes=b, flops=f, bound="hbm", inst=f"{len(items)} dW of a C={C} block over {rows} rows")
+            return dict(bytes=b, flops=f, bound="hbm", inst=f"{len(items)} dW of a C={C} block over {rows} rows", rows=rows)
 
         def dwg32(out, compute_code, items, workgroups=0):
             b = sum(dy.numel() * dy.element_size() + x.numel() * x.element_size() + w.numel() * 4 for dy, x, w, _ in items)
@@ -298,14 +298,14 @@ class StepTracer:
             rows, C = dy.shape
             es = dy.element_size()
             b = rows * C * (es + 4 + (8 if accumulate else 4) + (es if dx_masked is not None else 0)) + rows * 8
-            return dict(bytes=b, flops=8.0 * rows * C, bound="hbm", inst=f"rows {rows} x C {C}")
+            return dict(bytes=b, flops=8.0 * rows * C, bound="hbm", inst=f"rows {rows} x C {C}", rows=rows * (4 if gather is not None else 1))
 
         def mlpb(out, d, gm, a, *rest, **kw):
             # recompute fc1 + dH + dX + dW1 + dW2 = 5 products of 2 M C H flops; bytes: gm, a in, da out
-            return dict(bytes=d.M * d.C * 6, flops=10.0 * d.M * d.C * d.hidden, bound="mfma", inst=f"M {d.M}")
+            return dict(bytes=d.M * d.C * 6, flops=10.0 * d.M * d.C * d.hidden, bound="mfma", inst=f"M {d.M}", rows=d.M)
 
         def mlpf(out, d, a, resid, *rest, **kw):
-            return dict(bytes=_tensor_bytes((a, resid) + rest, kw) + out_bytes(out), flops=4.0 * d.M * d.C * d.hidden, bound="hbm", inst=f"M {d.M}")
+            return dict(bytes=_tensor_bytes((a, resid) + rest, kw) + out_bytes(out), flops=4.0 * d.M * d.C * d.hidden, bound="hbm", inst=f"M {d.M}", rows=d.M)
 
         def bnb(out, d, z, g, *rest, **kw):
             es_o = out.element_size() if isinstance(out, torch.Tensor) else 4
@@ -324,7 +324,8 @@ class StepTracer:
                 elif d is not None and all(hasattr(d, k) for k in ("B", "T", "H")):
                     flops = 2.0 * d.B * d.T * 2 * 3 * d.H * d.H * (2 if name.endswith("bwd") else 1)
                 shp = " x ".join(str(tuple(t.shape)) for t in args if isinstance(t, torch.Tensor))[:70]
-                return dict(bytes=_tensor_bytes(args, kw) + out_bytes(out), flops=flops, bound="hbm", inst=f"{name} {shp}")
+                rows = max([t.shape[0] for t in list(args) + list(kw.values()) if isinstance(t, torch.Tensor) and t.dim() == 2] or [0])  # token rows the call works on
+                return dict(bytes=_tensor_bytes(args, kw) + out_bytes(out), flops=flops, bound="hbm", inst=f"{name} {shp}", rows=rows)
             return describe
 
         def fftm(out, items):
@@ -350,7 +351,7 @@ class StepTracer:
             from focal_amd._lib import check
             check(self.lib.focal_trace_read(0, n, recs))
         out = [dict(kernel=short_kernel_name(recs[i].kernel.decode()), us=float(recs[i].us), wgs=recs[i].grid[0] * recs[i].grid[1] * recs[i].grid[2],
-                    threads=recs[i].block[0] * recs[i].block[1] * recs[i].block[2], bytes=0.0, flops=0.0, bound="hbm", inst="(no op description)")
+                    threads=recs[i].block[0] * recs[i].block[1] * recs[i].block[2], bytes=0.0, flops=0.0, bound="hbm", inst="(no op description)", rows=0)
                for i in range(n)]
         for desc, n0, n1 in self.calls:
             mine = out[n0:n1]
@@ -364,7 +365,7 @@ class StepTracer:
                     r["flops"] = 0.0
                 else:
                     r["bytes"], r["flops"] = desc["bytes"] * share, desc["flops"] * share
-                r["bound"], r["inst"] = desc["bound"], desc["inst"]
+                r["bound"], r["inst"], r["rows"] = desc["bound"], desc["inst"], desc.get("rows", 0)
         return out
 
 
@@ -514,6 +515,7 @@ def roofline(a, step, device, ms_per_step=None):
            "instances": g0["instances"],
            "other_groups": [grp(g) for g in groups[1:13]],
            "families": _families(groups),
+           "stages": _stage_table(a, step, per_step),
            "step": {"hbm_bytes_per_step_pmc": step_bytes,
                     "hbm_frac_step": (round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (step_bytes and ms_per_step) else None),
                     "compulsory_bytes_per_step": compulsory,
@@ -522,6 +524,33 @@ def roofline(a, step, device, ms_per_step=None):
                             "compulsory = the windows read once + 40 B per trained parameter (SURVEY 8d)"},
            "isolated": roofline_isolated(a, step, device) if (a.model == "SW_Transformer" and a.dataset == "MOD") else None}
     return out
+
+
+def _stage_table(a, step, per_step):
+    """SW_Transformer: the traced launches folded by Swin stage: a launch belongs to the stage whose token-row count
+    (views x B x H x W of a modality's stage) its operands have; PatchMerging's reduction runs on the next stage's rows and counts there.
+    launches / serialized ms / algorithmic MB per step, medians over the traced steps as everywhere in `roofline`."""
+    geo = getattr(step.backbone, "geometry", None)
+    if a.model != "SW_Transformer" or geo is None or not per_step:
+        return None
+    views = 2 if getattr(step.backbone, "views_share_pass", False) else 1
+    owner = {}
+    for loc, mods in geo.items():
+        for mod, g in mods.items():
+            for si, st in enumerate(g["stages"]):
+                owner.setdefault(views * a.batch * st["H"] * st["W"], f"stage {si}")
+    n = len(per_step)
+    same = all(len(sx) == len(per_step[0]) for sx in per_step)
+    rows = {}
+    for j, r in enumerate(per_step[0]):
+        us = _median([sx[j]["us"] for sx in per_step]) if same else r["us"]
+        key = owner.get(r.get("rows", 0), "outside the encoder stages (DFT, embedding, mod_in, projector, loss head, AdamW)")
+        e = rows.setdefault(key, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += us
+        e[2] += r["bytes"]
+    return [{"stage": k, "launches": v[0], "ms": round(v[1] / 1e3, 4), "algorithmic_MB": round(v[2] / 1e6, 1),
+             "GBps": round(v[2] / (v[1] * 1e-6) / 1e9, 1) if v[1] > 0 else None} for k, v in sorted(rows.items())]
 
 
 def _lib_sha16():
@@ -590,7 +619,7 @@ def roofline_isolated(a, step, device):
 
 
 def dump_trace(a, step):
-    """tools/profile_round.sh: the launch trace in both modes next to the rocprofv3 pass of the same box (profiles/r5_z_*_trace_vs_rocprof.txt)."""
+    """tools/profile_round.sh: the launch trace in both modes next to the rocprofv3 pass of the same box (profiles/r6_z_*_trace_vs_rocprof.txt)."""
     from focal_amd._lib import TRACE_DISPATCH, TRACE_EVENTS
     for _ in range(2):
         step.run()
@@ -806,6 +835,9 @@ def secondary_workloads(a, device):
             dt, graphed, _ = timed_steps(b, st, 1, 0, device, 20, 10)
             out[f"{model}/{dataset}"] = {"value": round(b.batch * 20 / dt, 1), "unit": "windows/s", "ms_per_step": round(dt / 20 * 1e3, 3), "steps": 20, "warmup": 10,
                                          "hip_graph": graphed, "dtype": b.dtype, "batch": b.batch, "last_loss": round(st.loss.item(), 4)}
+            if model == "DeepSense" and not a.no_cpu_baseline:
+                # BASELINE configs[0] is DeepSense at batch 32 on the CPU: the oracle step on this box's host cores, next to the GPU line
+                out[f"{model}/{dataset}"]["cpu_baseline"] = cpu_baseline(b, st.cfg)
             del st
         except Exception as e:  # noqa: BLE001  (a secondary workload must never take the headline line down with it)
             out[f"{model}/{dataset}"] = {"error": f"{type(e).__name__}: {e}"}

@@ -128,6 +128,7 @@ P = C.c_void_p
 # name -> (restype, argtypes); every symbol include/focal_hip.h declares
 PROTOTYPES = {
     "focal_abi_version": (C.c_int, []),
+    "focal_mark": (C.c_int, [P, C.c_int, P]),
     "focal_last_error": (C.c_char_p, []),
     "focal_last_kernel": (C.c_char_p, []),
     "focal_trace_begin": (C.c_int, [C.c_int, C.c_int]),

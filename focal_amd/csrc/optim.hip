@@ -14,6 +14,17 @@ extern "C" int focal_rng_advance(uint32_t* state, void* stream) {
   return FOCAL_OK;
 }
 
+// Diagnostic: slots[index] = the device's constant-rate wall clock (100 MHz) when this one-thread launch runs -- a marker that can sit INSIDE
+// a captured hipGraph, where events cannot be read and rocprofv3 serialises the branches (tools/phase_marks.py).
+__global__ void mark_kernel(unsigned long long* slots, int index) { slots[index] = wall_clock64(); }
+
+extern "C" int focal_mark(unsigned long long* slots, int index, void* stream) {
+  FOCAL_CHECK_ARG(slots != nullptr && index >= 0, "mark: null buffer or negative index");
+  FOCAL_LAUNCH(mark_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slots, index);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
 // torch.optim.AdamW: p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // advance != 0 (focal_adamw_multi_advance): the update uses step count step_state[1] + 1, and the workgroup that finishes LAST -- by

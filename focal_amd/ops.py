@@ -112,6 +112,11 @@ def new_step_state(device, count=0):
     return st
 
 
+def mark(slots, index):
+    """Diagnostic: slots[index] (int64 device tensor) = device wall clock, 100 MHz ticks, when the launch runs on the current stream."""
+    check(_lib.load().focal_mark(_p(slots), int(index), _stream()))
+
+
 def rng_advance(state):
     check(_lib.load().focal_rng_advance(_p(state), _stream()))
 

@@ -63,6 +63,9 @@ int focal_trace_read(int first, int n, focal_trace_record* out); /* waits for th
  * on every replay because `focal_rng_advance` bumps the words on the device.  Replaces torch's Philox stream
  * for nn.Dropout / DropPath (models/SwinModules.py:26,115,257; models/ConvModules.py:96). */
 int focal_rng_advance(uint32_t* state, void* stream);
+/* Diagnostic marker (round 6): slots[index] = the device wall clock (100 MHz ticks) at the moment a one-thread launch on `stream` runs.
+ * Usable inside a captured hipGraph: the only way to time the BRANCHES of a replayed step (tools/phase_marks.py). */
+int focal_mark(unsigned long long* slots, int index, void* stream);
 
 typedef struct {
   const uint32_t* rng;   /* device RNG state or NULL (seed 0) */

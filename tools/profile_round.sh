@@ -4,7 +4,7 @@
 #   (1) rocprofv3 --kernel-trace --stats -M of an eager bench run  -> gpurun_out/<tag>_kernel_stats.csv, <tag>_instances.txt
 #   (2) --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, one pass each (--kernel-trace only) -> <tag>_step_traffic.txt
 #   (3) bench.py --trace-dump (the library's own launch trace, both modes) -> <tag>_trace_vs_rocprof.txt
-#   (4) <tag>_reference.json: what bench.py's roofline is checked against (copy to profiles/r5_reference_<model>_<dataset>.json)
+#   (4) <tag>_reference.json: what bench.py's roofline is checked against (copy to profiles/r6_reference_<model>_<dataset>.json)
 tag=$1; model=$2; dataset=$3; shift 3
 root=$(pwd)
 STEPS=10; WARM=3

@@ -1,15 +1,31 @@
 #!/bin/bash
 # round evidence: rocprofv3 + PMC + launch trace of the three workloads, then the driver-style bench lines
-tag=${1:-r5_z}
+tag=${1:-r6_z}
 mkdir -p gpurun_out
+python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/${tag}_pytest_gpu_summary.txt
 bash tools/profile_round.sh ${tag}_swt SW_Transformer MOD > gpurun_out/${tag}_profile_swt.log 2>&1
-cp gpurun_out/${tag}_swt_reference.json profiles/r5_reference_SW_Transformer_MOD.json
+cp gpurun_out/${tag}_swt_reference.json profiles/r6_reference_SW_Transformer_MOD.json
 bash tools/profile_round.sh ${tag}_deepsense DeepSense MOD > gpurun_out/${tag}_profile_ds.log 2>&1
-cp gpurun_out/${tag}_deepsense_reference.json profiles/r5_reference_DeepSense_MOD.json
+cp gpurun_out/${tag}_deepsense_reference.json profiles/r6_reference_DeepSense_MOD.json
 bash tools/profile_round.sh ${tag}_har4 SW_Transformer HAR4 > gpurun_out/${tag}_profile_har4.log 2>&1
-cp gpurun_out/${tag}_har4_reference.json profiles/r5_reference_SW_Transformer_HAR4.json
-python3 bench.py > gpurun_out/${tag}_bench_swt.json 2> gpurun_out/${tag}_bench.err
+cp gpurun_out/${tag}_har4_reference.json profiles/r6_reference_SW_Transformer_HAR4.json
+cp profiles/r6_reference_*.json gpurun_out/
+# the driver's command, verbatim, first; then the longer run and the other workloads
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_driver_line.json 2> gpurun_out/${tag}_bench.err
+python3 bench.py > gpurun_out/${tag}_bench_swt.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --model DeepSense --no-secondary > gpurun_out/${tag}_bench_deepsense.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --dataset HAR4 --no-secondary > gpurun_out/${tag}_bench_har4.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --views random --no-cpu-baseline > gpurun_out/${tag}_bench_swt_views_random.json 2>> gpurun_out/${tag}_bench.err
+python3 tools/phase_marks.py --no-secondary > gpurun_out/${tag}_phase_marks.txt 2>&1
+python3 tools/graph_launch_probe.py > gpurun_out/${tag}_graph_launch.txt 2>&1
 tail -25 gpurun_out/${tag}_profile_swt.log
+python3 - <<PY
+import json
+for n in ("driver_line", "swt", "deepsense", "har4", "swt_views_random"):
+    try:
+        d = json.loads(open("gpurun_out/${tag}_bench_%s.json" % n).read().strip().splitlines()[-1])
+        r = d.get("roofline") or {}
+        print(n, d["value"], d["ms_per_step"], "warmup_effective", d.get("warmup_effective"), "roofline", r.get("kernel"), r.get("frac"), "suspect", r.get("suspect"))
+    except Exception as e:
+        print(n, "unreadable", e)
+PY
