@@ -58,10 +58,14 @@ struct WideFwdParams {
 };
 
 constexpr int NLOAD = 2, R = 2;
-// consumer waves per workgroup: 8 at 128 channels (10 waves: 168 registers per lane are enough there); 6 at 256 channels -- 8 waves in
-// all, two per SIMD, 256 registers: a wave's 64 accumulator + 32 operand-fragment registers do not fit in 168
+// consumer waves per workgroup: 6 -- 8 waves in all, two per SIMD, 256 registers: at 256 channels a wave's 64 accumulator + 32 operand-fragment
+// registers do not fit in the 168 of a 10-wave workgroup; at 128 channels 8 consumers fit (166) but 6 with the epilogue's residual rows
+// requested before the steps measured faster (96-row tiles: 768 / 384 tiles = whole rounds of 256 CUs)
 #ifndef WIDE_NW128
-#define WIDE_NW128 8
+#define WIDE_NW128 6
+#endif
+#ifndef WIDE_NO_HOIST128
+#define WIDE_HOIST128 1
 #endif
 template <int C> struct WideWaves { static constexpr int NW = C == 128 ? WIDE_NW128 : 6, BM = 16 * NW; };
 
@@ -366,12 +370,16 @@ static MaskParams wide_mask(const focal_drop_desc& d, int ncols) {
   return m;
 }
 
-// Not the default: measured against the two launches it replaces (profiles/r6_mlp_wide.txt) the one-launch form ties at 128 channels
-// (0.88-1.07 x) and loses at 256 (0.66-1.00 x) -- both forms are bound by vector-instruction issue (GELU + derivative + mask hash + packing:
-// ~35 issue slots per element pair), not by the 8C bytes per token the fusion removes.  FOCAL_MLP_WIDE=1 selects it (the Swin engine asks here).
+// Launched back to back on cold operands the one-launch form only ties the two launches it replaces (profiles/r6_mlp_wide.txt: 0.88-1.07 x at
+// 128 channels, 0.66-1.00 x at 256 -- both forms are bound by vector-instruction issue, not by the 8C bytes per token the fusion removes);
+// INSIDE the replayed step, where the other modality's stream runs beside it, it wins: +1.5 % on the SW_Transformer step, three interleaved
+// same-box repetitions (fewer launches, 75 MB less traffic per block, and at 256 channels a grid that leaves CUs to the other stream).
+// FOCAL_MLP_WIDE=0 keeps the two launches, =128 / =256 fuses that width only (same-box A/B: tools/ab_wide.sh).
 extern "C" int focal_mlp_wide_supported(int dtype, int C_, int hidden) {
+  if (!(dtype == FOCAL_BF16 && (C_ == 128 || C_ == 256) && hidden == 4 * C_)) return 0;
   const char* on = getenv("FOCAL_MLP_WIDE");
-  return dtype == FOCAL_BF16 && (C_ == 128 || C_ == 256) && hidden == 4 * C_ && on != nullptr && on[0] == '1';
+  if (on == nullptr || strcmp(on, "1") == 0) return 1;
+  return atoi(on) == C_;
 }
 
 template <int C, int EPI2>

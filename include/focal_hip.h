@@ -325,10 +325,9 @@ long focal_mlp_bwd_partials_floats(const focal_mlp_desc* d);
  * and its derivative x dropout mask) are still WRITTEN -- once -- because the backward pass of these widths reads them (a recomputing
  * backward needs 1 MB of weight-gradient accumulators per workgroup).  y_ln / ln_* (C = 128 only): the LayerNorm that reads y next, as
  * focal_linear_resid_ln_fwd emits it.  Every output is bit-identical to the two-launch form (same k order, same element math, same mask
- * indices; with the masks on, to an ulp where hipcc contracts the residual expression differently).  MEASURED AND NOT THE DEFAULT
- * (profiles/r6_mlp_wide.txt: 0.88-1.07 x the two launches at 128 channels, 0.66-1.00 x at 256: both forms are bound by vector-instruction
- * issue, not by the bytes the fusion removes): focal_mlp_wide_supported returns 1 only under FOCAL_MLP_WIDE=1; focal_mlp_wide_fwd itself
- * always works. */
+ * indices; with the masks on, to an ulp where hipcc contracts the residual expression differently).  Back to back on cold operands it only
+ * ties the two launches (profiles/r6_mlp_wide.txt); inside the replayed step it is worth +1.5 % (tools/ab_wide.sh).  FOCAL_MLP_WIDE=0 makes
+ * focal_mlp_wide_supported return 0 (the engine then issues the two launches), =128 / =256 restrict it to one width. */
 int focal_mlp_wide_supported(int dtype, int C, int hidden);
 int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
                        const float* b2, float* y, void* h, void* hg, const float* ln_gamma, const float* ln_beta, void* y_ln,

@@ -55,8 +55,11 @@ def _two_launches(ops, M, C, a, w1, b1, w2, b2, r, drop_h, drop_o, ln):
 @pytest.mark.parametrize("C,M,drop,ln", [(128, 36864, True, True), (128, 36864, False, False), (128, 1000, True, True), (128, 96, False, True),
                                          (256, 9216, True, False), (256, 18432, False, False), (256, 1000, True, False), (256, 50, False, False)])
 def test_one_launch_equals_the_two_launches_bit_for_bit(ops, C, M, drop, ln, monkeypatch):
-    assert not ops.mlp_wide_supported(BF, C, 4 * C)   # opt-in: it does not beat the two launches (profiles/r6_mlp_wide.txt)
-    monkeypatch.setenv("FOCAL_MLP_WIDE", "1")
+    monkeypatch.setenv("FOCAL_MLP_WIDE", "0")
+    assert not ops.mlp_wide_supported(BF, C, 4 * C)   # (the same-box A/B switch)
+    monkeypatch.setenv("FOCAL_MLP_WIDE", str(C))
+    assert ops.mlp_wide_supported(BF, C, 4 * C) and not ops.mlp_wide_supported(BF, 384 - C, 4 * (384 - C))
+    monkeypatch.delenv("FOCAL_MLP_WIDE")
     assert ops.mlp_wide_supported(BF, C, 4 * C) and not ops.mlp_wide_supported(torch.float32, C, 4 * C) and not ops.mlp_wide_supported(BF, 64, 256)
     a, w1, b1, w2, b2, r = _operands(M, C, seed=3 * C + M)
     rng = ops.new_rng_state(20260 + M, DEV)
@@ -109,7 +112,7 @@ def test_wide_mlp_rejects_what_it_was_not_built_for(ops):
 
 
 def test_encoder_with_the_one_launch_mlp_equals_the_default(cfg, monkeypatch):
-    """FOCAL_MLP_WIDE=1 through the Swin engine (stages 1-2 of both modality encoders, dropout off): embeddings equal to the default two-launch
+    """The one-launch MLP (the default) against FOCAL_MLP_WIDE=0 through the Swin engine (stages 1-2 of both modality encoders, dropout off): embeddings equal to the default two-launch
     form up to the order of mod_in's split-K atomics; h and hg are the same tensors, so the backward pass cannot tell (gradients equal up to the order of the weight
     gradients' fp32 atomics, which differs between any two runs)."""
     from test_swt_parity_gpu import build, inputs
@@ -124,8 +127,9 @@ def test_encoder_with_the_one_launch_mlp_equals_the_default(cfg, monkeypatch):
         loss.backward()
         torch.cuda.synchronize()
         return {m: f1[m].detach().clone() for m in f1}, net.arena().grad.clone()
+    monkeypatch.setenv("FOCAL_MLP_WIDE", "0")
     e0, g0 = run()
-    monkeypatch.setenv("FOCAL_MLP_WIDE", "1")
+    monkeypatch.delenv("FOCAL_MLP_WIDE")
     e1, g1 = run()
     from conftest import record_observed
     record_observed("mlp_wide.encoder.emb_diff_over_max", max(((e0[m] - e1[m]).abs().max() / e0[m].abs().max()).item() for m in e0))
