@@ -67,7 +67,10 @@ constexpr int NLOAD = 2, R = 2;
 #ifndef WIDE_NO_HOIST128
 #define WIDE_HOIST128 1
 #endif
-template <int C> struct WideWaves { static constexpr int NW = C == 128 ? WIDE_NW128 : 6, BM = 16 * NW; };
+#ifndef WIDE_NW256
+#define WIDE_NW256 6
+#endif
+template <int C> struct WideWaves { static constexpr int NW = C == 128 ? WIDE_NW128 : WIDE_NW256, BM = 16 * NW; };
 
 template <int C> struct WideLayout {
   static constexpr int NW = WideWaves<C>::NW, BM = WideWaves<C>::BM;
@@ -355,6 +358,226 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
   WS_OUT(0, ws_cbar); WS_OUT(1, ws_fc1); WS_OUT(2, ws_gelu); WS_OUT(3, ws_fc2); WS_OUT(5, ws_epi); WS_OUT(6, ws_call); WS_OUT(4, 2ull);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------ backward (data path)
+//   du   = (gm W2) x h'                      [M, 4C]   gm = dL/dx_out x the branch's mask (operand dtype), h' = the forward pass's hg
+//   dc   = du W1                             [M, C]    = dL/da2: stored (256 channels) or finished as norm2's backward on the row (128:
+//                                                       g += dLN, gm_attn = dtype(g x mask), dgamma / dbeta -- EPI_LN_BWD, the shared epilogue)
+// The mirror image of the forward kernel: same tiles, same ring, same two weight slices per step -- now read through the hardware
+// transpose (ds_read_b64_tr_b16: both weights are [k][n] for these products; the loader fills the [64 k][BN] images of gemm_ring.hpp's TRB
+// path) -- and du's accumulators feed the second product from registers.  The first product reads its W2 columns in the forward kernel's
+// permuted order (a lane's 2 x 4 accumulators = 8 consecutive hidden units: 16-byte hg loads and du stores, natural k order for product 2).
+// du is written once (the fc1 weight gradient reads it) and not read back; replaces focal_linear_bwd_data(MUL_AUX) + focal_linear_bwd_data /
+// focal_linear_bwd_data_ln.  Same sums in the same k order; not bit-identical (the permuted k slots of product 1 change the order inside an MFMA).
+struct WideBwdParams {
+  int M;
+  const bf16_t* gm;   // [M][C]
+  const bf16_t* hg;   // [M][H]
+  const bf16_t* w1;   // [H][C]
+  const bf16_t* w2;   // [C][H]
+  bf16_t* du;         // [M][H]
+  bf16_t* dc;         // [M][C]  (EPI_STORE)
+  GemmParams g1;      // the dX-of-fc1 product's epilogue operands as focal_linear_bwd_data_ln fills them (EPI_LN_BWD)
+};
+
+template <int C> struct WideBwdLayout {
+  static constexpr int NW = WideWaves<C>::NW, BM = WideWaves<C>::BM;
+  static constexpr int H = 4 * C, KK = C / 32, KT1 = C / 64, CT = C / 16, NSTEP = H / 64;
+  static constexpr int W2_BYTES = KT1 * 8192;   // KT1 images [64 k = c][64 n = hidden], 128-byte rows
+  static constexpr int W1_BYTES = 64 * C * 2;   // one image [64 k = hidden][C], 2C-byte rows
+  static constexpr int SLOT_BYTES = W1_BYTES + W2_BYTES;
+  static constexpr int NP2 = KT1 * 8, NP1 = W1_BYTES / 1024, L2 = NP2 / NLOAD, L1 = NP1 / NLOAD;
+  static constexpr int WPITCH = C + 4;
+  static constexpr int STG_BYTES = C == 128 ? NW * 16 * WPITCH * 4 + NW * 2 * C * 4 : 0;  // shared epilogue's staging + the dgamma / dbeta fold
+  static constexpr int LDS_BYTES = R * SLOT_BYTES + STG_BYTES;
+};
+
+template <int C, int EPI1>
+__global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_bwd_kernel(const WideBwdParams p) {
+  using L = WideBwdLayout<C>;
+  constexpr int NW = L::NW, BM = L::BM;
+  constexpr int H = L::H, KK = L::KK, KT1 = L::KT1, CT = L::CT, NSTEP = L::NSTEP, SLOT_BYTES = L::SLOT_BYTES, W2_BYTES = L::W2_BYTES;
+  static_assert(EPI1 == EPI_STORE || (EPI1 == EPI_LN_BWD && C == 128), "dX-of-fc1 epilogue");
+  extern __shared__ __attribute__((aligned(1024))) char wide_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = (p.M + BM - 1) / BM, G = gridDim.x;
+  const int ntl = (ntiles - (int)blockIdx.x + G - 1) / G;
+  const int total = ntl * NSTEP;
+
+  if (wave >= NW) {
+    // ================================================================================================ loader waves (TRB images: gemm_ring.hpp)
+    const int lw = wave - NW;
+    constexpr int L1 = L::L1, L2 = L::L2;
+    constexpr int CPR1 = C / 8, RPP1 = 64 / CPR1;   // the W1 image: chunks per row, rows per 1-KB piece
+    uint32_t off1[L1], off2[L2];
+#pragma unroll
+    for (int t = 0; t < L2; ++t) {  // W2: image kt = i / 8, piece q = i % 8: k-rows (c) 8 q .. + 7 of that image, 8 chunks of this step's 64 hidden columns
+      const int i = lw + NLOAD * t, kt = i >> 3, q = i & 7;
+      const int krow = 8 * q + (lane >> 3), pos = lane & 7, chunk = pos ^ ((krow & 3) << 1);
+      off2[t] = (uint32_t)(((kt * 64 + krow) * H + chunk * 8) * 2);
+    }
+#pragma unroll
+    for (int t = 0; t < L1; ++t) {  // W1: piece q: k-rows (hidden) RPP1 q .. of the step, all C columns
+      const int q = lw + NLOAD * t;
+      const int krow = q * RPP1 + lane / CPR1, pos = lane % CPR1, chunk = pos ^ ((krow & 3) << 1);
+      off1[t] = (uint32_t)((krow * C + chunk * 8) * 2);
+    }
+    const char* w1b = reinterpret_cast<const char*>(p.w1);
+    const char* w2b = reinterpret_cast<const char*>(p.w2);
+    int issued = 0, f_st = 0;
+    auto issue_next = [&]() __attribute__((always_inline)) {
+      const uint32_t slot = (uint32_t)(issued & (R - 1)) * SLOT_BYTES;
+      const char* s2 = w2b + (long)f_st * 128;            // this step's 64 hidden columns of W2 [C][H]
+      const char* s1 = w1b + (long)f_st * (64 * C * 2);   // this step's 64 hidden rows of W1 [H][C]
+#pragma unroll
+      for (int t = 0; t < L2; ++t) {
+        const int i = lw + NLOAD * t;
+        __builtin_amdgcn_global_load_lds((pipe_glb_ptr)(s2 + off2[t]), (pipe_lds_ptr)(wide_lds + slot + i * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < L1; ++t) {
+        const int q = lw + NLOAD * t;
+        __builtin_amdgcn_global_load_lds((pipe_glb_ptr)(s1 + off1[t]), (pipe_lds_ptr)(wide_lds + slot + W2_BYTES + q * 1024), 16, 0, 0);
+      }
+      ++issued;
+      if (++f_st == NSTEP) f_st = 0;
+    };
+    if (total > 0) issue_next();
+    for (int g = 0; g < total; ++g) {
+      ring_vmcnt<0>();
+      ring_barrier();
+      if (issued < total) issue_next();
+    }
+    if (EPI1 == EPI_LN_BWD) ring_barrier();  // the consumers' __syncthreads() in pipe_ln_bwd_flush
+    return;
+  }
+
+  // ==================================================================================================== consumer waves
+  const int g4 = lane >> 4, l15 = lane & 15, tq = l15 >> 2, tp = lane & 3;
+  const uint32_t lds0 = pipe_lds_addr(wide_lds);
+  const int tr_krow = 8 * g4 + tq, tr_swz = tq << 1;
+  // product 1: tile T = (s, jj) of the step's 64 hidden columns, permuted: this lane's 4 columns are hidden 32 s + 8 tp + 4 jj .. + 3
+  uint32_t a1[4];
+#pragma unroll
+  for (int T = 0; T < 4; ++T) a1[T] = lds0 + tr_krow * 128 + (((4 * (T >> 1) + tp) ^ tr_swz) << 4) + 8 * (T & 1);
+  // product 2: c-tile ct of the [64 hidden][C] image, natural order
+  const int tr_in = (tp >> 1) * 16 + (tp & 1) * 8;
+  const uint32_t a2 = lds0 + W2_BYTES + tr_krow * (C * 2) + tr_in;
+  MaskEval meE;
+  meE.init(p.g1.epi);
+  float* est = reinterpret_cast<float*>(wide_lds + R * SLOT_BYTES) + wave * 16 * L::WPITCH;
+  float* Gout = reinterpret_cast<float*>(p.g1.C);
+  float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f}, lng[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI1 == EPI_LN_BWD) loadN<4>(p.g1.ln_gamma + (lane % (C / 4)) * 4, lng);
+  const float zero_bias[4] = {0.f, 0.f, 0.f, 0.f};
+
+  int slot = 0;
+#pragma unroll 1
+  for (int i = 0, tile = blockIdx.x; i < ntl; ++i, tile += G) {
+    const int m0 = tile * BM, mbase = m0 + wave * 16, m = mbase + l15;
+    const bool mok = m < p.M;
+    const long mrow = mok ? m : p.M - 1;
+    bf16x8 xa[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) xa[kk] = *reinterpret_cast<const bf16x8*>(p.gm + mrow * C + kk * 32 + 8 * g4);
+    f32x4 dacc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) dacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* hgrow = p.hg + mrow * H + 8 * g4;
+    bf16_t* durow = p.du + (long)m * H + 8 * g4;
+    // h' of the NEXT step is requested before this step's du stores are issued: waiting for it never waits for a store (in-order vmcnt)
+    bf16x8 hgn[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) hgn[s] = *reinterpret_cast<const bf16x8*>(hgrow + 32 * s);
+
+#pragma unroll 1
+    for (int st = 0; st < NSTEP; ++st) {
+      bf16x8 hgc[2] = {hgn[0], hgn[1]};
+      if (st + 1 < NSTEP) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) hgn[s] = *reinterpret_cast<const bf16x8*>(hgrow + 64 * (st + 1) + 32 * s);
+      }
+      ring_barrier();
+      const uint32_t sb = (uint32_t)slot * SLOT_BYTES;
+      // ---- product 1: v[T][e] = sum_c W2[c][hidden(T, 4 g + e)] gm[m][c]
+      f32x4 v[4];
+#pragma unroll
+      for (int T = 0; T < 4; ++T) v[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pipe_static_for<0, KT1>([&](auto kt_) {
+        constexpr int kt = decltype(kt_)::value;
+        pipe_static_for<0, 2>([&](auto kk_) {
+          constexpr int kk = decltype(kk_)::value;
+          bf16x4 lo[4], hi[4];
+          pipe_static_for<0, 4>([&](auto T_) {
+            constexpr int T = decltype(T_)::value;
+            lo[T] = pipe_lds_read_tr<kt * 8192 + kk * 32 * 128>(a1[T] + sb);
+            hi[T] = pipe_lds_read_tr<kt * 8192 + kk * 32 * 128 + 4 * 128>(a1[T] + sb);
+          });
+          bf16x8 w[4];
+#pragma unroll
+          for (int T = 0; T < 4; ++T) w[T] = __builtin_shufflevector(lo[T], hi[T], 0, 1, 2, 3, 4, 5, 6, 7);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+#pragma unroll
+          for (int T = 0; T < 4; ++T) v[T] = mma16(w[T], xa[2 * kt + kk], v[T]);
+        });
+      });
+      // ---- du = v x h' (the arithmetic of EPI_MUL_AUX), 8 consecutive hidden units per lane and s; stored once, kept for product 2
+      bf16x8 duf[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x0 = v[2 * s][e] * p.g1.alpha, x1 = v[2 * s + 1][e] * p.g1.alpha;
+          x0 *= (float)hgc[s][e];
+          x1 *= (float)hgc[s][4 + e];
+          duf[s][e] = (bf16_t)x0;
+          duf[s][4 + e] = (bf16_t)x1;
+        }
+        if (mok) *reinterpret_cast<bf16x8*>(durow + 64 * st + 32 * s) = duf[s];
+      }
+      // ---- product 2: dacc[ct][e] += sum_{hidden of this step} W1[hidden][16 ct + 4 g + e] du[m][hidden]
+      pipe_static_for<0, CT / 2>([&](auto jq_) {
+        constexpr int jq = decltype(jq_)::value;
+        bf16x4 lo[4], hi[4];
+        pipe_static_for<0, 2>([&](auto jj_) {
+          constexpr int jj = decltype(jj_)::value, ct = 2 * jq + jj;
+          pipe_static_for<0, 2>([&](auto s_) {
+            constexpr int s = decltype(s_)::value;
+            const uint32_t a = a2 + sb + ((((ct * 16) >> 3) ^ tr_swz) << 4);
+            lo[2 * jj + s] = pipe_lds_read_tr<s * 32 * C * 2>(a);
+            hi[2 * jj + s] = pipe_lds_read_tr<s * 32 * C * 2 + 4 * C * 2>(a);
+          });
+        });
+        bf16x8 w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = __builtin_shufflevector(lo[q], hi[q], 0, 1, 2, 3, 4, 5, 6, 7);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          dacc[2 * jq + jj] = mma16(w[2 * jj], duf[0], dacc[2 * jq + jj]);
+          dacc[2 * jq + jj] = mma16(w[2 * jj + 1], duf[1], dacc[2 * jq + jj]);
+        }
+      });
+      slot ^= 1;
+    }
+
+    // ---- epilogue of the second product
+    if constexpr (EPI1 == EPI_LN_BWD) {
+      PipePre<float, EPI1, C, 1> pre;
+      pipe_epilogue_prefetch<float, EPI1, BM, C, NW, 1>(p.g1, p.g1.resid, m0, 0, mbase, 0, lane, Gout, pre);
+      pipe_epilogue_finish<float, EPI1, BM, C, NW, 1>(p.g1, p.g1.alpha, dacc, est, meE, m0, 0, mbase, 0, lane, Gout, zero_bias, pg, pb, lng, pre);
+    } else {
+      bf16_t* drow = p.dc + (long)m * C + 4 * g4;
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+        if (mok) store4(drow + 16 * j, dacc[j] * p.g1.alpha);
+    }
+  }
+  if constexpr (EPI1 == EPI_LN_BWD)
+    pipe_ln_bwd_flush<C, NW, 1, 4>(p.g1, pg, pb, reinterpret_cast<float*>(wide_lds + R * SLOT_BYTES) + NW * 16 * L::WPITCH, 0, 0, wave, lane, tid);
+}
+
 }  // namespace focal_mlp_wide
 using namespace focal_mlp_wide;
 
@@ -439,4 +662,73 @@ extern "C" int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const 
   hipStream_t st = (hipStream_t)stream;
   if (d->C == 128) return ln ? launch_wide_fwd<128, EPI_RESID_LN>(p, st) : launch_wide_fwd<128, EPI_RESID>(p, st);
   return launch_wide_fwd<256, EPI_RESID>(p, st);
+}
+
+// NOT the default: inside the replayed step the one-launch backward data path is neutral at 128 channels and costs 1.2 % at 256 (three
+// interleaved same-box repetitions, tools/ab_wide_bwd.sh; profiles/r6_mlp_wide.txt) -- the two launches it replaces are the ring GEMM's
+// fastest shapes (26 us for both at M = 9 216 against 40 us for the forward pair), there is less to win and the transposed fragment reads
+// (two ds_read_b64_tr_b16 per MFMA against one ds_read_b128) cost more.  FOCAL_MLP_WIDE_BWD=1 / 128 / 256 selects it.
+extern "C" int focal_mlp_wide_bwd_supported(int dtype, int C_, int hidden) {
+  const char* sel = getenv("FOCAL_MLP_WIDE_BWD");
+  if (sel == nullptr || (strcmp(sel, "1") != 0 && atoi(sel) != C_)) return 0;
+  return focal_mlp_wide_supported(dtype, C_, hidden);
+}
+
+template <int C, int EPI1>
+static int launch_wide_bwd(const WideBwdParams& p, hipStream_t st) {
+  using L = WideBwdLayout<C>;
+  auto kern = mlp_wide_bwd_kernel<C, EPI1>;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set.load(std::memory_order_acquire)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES) != hipSuccess) {
+      focal_set_error("mlp_wide_bwd: cannot reserve %d bytes of LDS", L::LDS_BYTES);
+      return FOCAL_EHIP;
+    }
+    attr_set.store(true, std::memory_order_release);
+  }
+  constexpr int BM = L::BM, NW = L::NW;
+  const int ntiles = (p.M + BM - 1) / BM, cus = focal_cu_count();
+  const int rounds = (ntiles + cus - 1) / cus;
+  const int grid = (ntiles + rounds - 1) / rounds;
+  FOCAL_LAUNCH(kern, dim3(grid), dim3(64 * (NW + NLOAD)), L::LDS_BYTES, st, p);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+extern "C" int focal_mlp_wide_bwd_data(const focal_mlp_desc* d, const void* gm, const void* hg, const void* w1, const void* w2, void* du, void* dc,
+                                       const float* ln_x, const float* ln_stats, const float* ln_gamma, float* g, void* g_masked,
+                                       const focal_drop_desc* mask, float* dgamma, float* dbeta, void* stream) {
+  FOCAL_CHECK_ARG(d != nullptr, "mlp_wide_bwd_data: null descriptor");
+  FOCAL_CHECK_ARG(d->dtype == FOCAL_BF16 && (d->C == 128 || d->C == 256) && d->hidden == 4 * d->C,
+                  "mlp_wide_bwd_data: bf16, C = 128 or 256, hidden = 4 C (got dtype %d, C %d, hidden %d)", d->dtype, d->C, d->hidden);
+  FOCAL_CHECK_ARG(d->M > 0 && gm && hg && w1 && w2 && du, "mlp_wide_bwd_data: null tensor or M = %d", d->M);
+  const bool ln = ln_x != nullptr;
+  FOCAL_CHECK_ARG(ln || dc, "mlp_wide_bwd_data: neither dc nor the LayerNorm operands");
+  if (ln) FOCAL_CHECK_ARG(d->C == 128 && ln_stats && ln_gamma && g && dgamma && dbeta && (g_masked || !mask),
+                          "mlp_wide_bwd_data: the fused LayerNorm backward exists at 128 channels and needs x, statistics, gamma, g, dgamma, dbeta");
+  WideBwdParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = d->M;
+  p.gm = reinterpret_cast<const bf16_t*>(gm);
+  p.hg = reinterpret_cast<const bf16_t*>(hg);
+  p.w1 = reinterpret_cast<const bf16_t*>(w1);
+  p.w2 = reinterpret_cast<const bf16_t*>(w2);
+  p.du = reinterpret_cast<bf16_t*>(du);
+  p.dc = reinterpret_cast<bf16_t*>(dc);
+  GemmParams& q = p.g1;  // (as focal_linear_bwd_data_ln fills it for the dX of fc1)
+  q.M = d->M; q.N = d->C; q.K = d->hidden;
+  q.C = g; q.ldc = d->C;
+  q.batch = 1; q.splits = 1; q.alpha = 1.f;
+  q.resid = ln_x; q.ldr = d->C;
+  q.ln_stats = const_cast<float*>(ln_stats);
+  q.ln_gamma = ln_gamma;
+  q.ln_dgamma = dgamma; q.ln_dbeta = dbeta;
+  q.aux_out = g_masked;
+  focal_drop_desc dd;
+  memset(&dd, 0, sizeof(dd));
+  if (mask) dd = *mask;
+  q.epi = wide_mask(dd, d->C);
+  hipStream_t st = (hipStream_t)stream;
+  if (ln) return launch_wide_bwd<128, EPI_LN_BWD>(p, st);
+  return d->C == 128 ? launch_wide_bwd<128, EPI_STORE>(p, st) : launch_wide_bwd<256, EPI_STORE>(p, st);
 }

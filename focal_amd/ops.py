@@ -569,6 +569,24 @@ def mlp_wide_fwd(d, a, resid, w1, b1, w2, b2, y, h, hg, next_ln=None):
     return y_ln, stats
 
 
+def mlp_wide_bwd_supported(dtype, Cc, hidden):
+    return bool(_lib.load().focal_mlp_wide_bwd_supported(code(dtype), Cc, hidden))
+
+
+def mlp_wide_bwd_data(d, gm, hg, w1, w2, du, dc=None, ln=None):
+    """du = (gm w2) x hg and dc = du w1 in one launch (focal_mlp_wide_bwd_data).  dc: the [M, C] output; or ln = dict(x=, stats=, gamma=, g=,
+    g_masked=, mask=, dgamma=, dbeta=) (128 channels): norm2's backward finished on the row as linear_bwd_data_ln does."""
+    _need_cuda(gm, hg, w1, w2, du, dc)
+    assert du.shape == (d.M, d.hidden) and du.dtype == gm.dtype and du.is_contiguous() and hg.shape == du.shape
+    if ln is None:
+        assert dc is not None and dc.shape == (d.M, d.C) and dc.dtype == gm.dtype and dc.is_contiguous()
+        check(_lib.load().focal_mlp_wide_bwd_data(C.byref(d), _p(gm), _p(hg), _p(w1), _p(w2), _p(du), _p(dc), None, None, None, None, None, None, None, None, _stream()))
+        return
+    mask = ln.get("mask") or NO_DROP
+    check(_lib.load().focal_mlp_wide_bwd_data(C.byref(d), _p(gm), _p(hg), _p(w1), _p(w2), _p(du), None, _p(ln["x"]), _p(ln["stats"]), _p(ln["gamma"]), _p(ln["g"]),
+                                              _p(ln.get("g_masked")), C.byref(mask), _p(ln["dgamma"]), _p(ln["dbeta"]), _stream()))
+
+
 def mlp_bwd_partials_floats(d):
     return int(_lib.load().focal_mlp_bwd_partials_floats(C.byref(d)))
 

@@ -340,14 +340,31 @@ class SwinModEncoder:
                 d_fc2_b = ops.linear_desc(cc, M, Cc, 4 * Cc, cc, cc, ACT_GELU)  # dy = gm: operand dtype, already masked
                 weight_grad(d_fc2_b, gm, s["h"], ar.g(f"{pb}.mlp.fc2.weight"), ar.g(f"{pb}.mlp.fc2.bias"))
                 du = torch.empty_like(s["h"])
-                ops.linear_bwd_data(d_fc2_b, gm, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
-                weight_grad(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
-                if fuse_ln_bwd and Cc <= ln_bwd_max_c and ops.bwd_data_ln_supported(cc, 4 * Cc, Cc):
-                    ln2_done = True  # dX of fc1 and norm2's backward in one kernel (below)
+                want_ln2 = fuse_ln_bwd and Cc <= ln_bwd_max_c and ops.bwd_data_ln_supported(cc, 4 * Cc, Cc)
+                if ops.mlp_wide_bwd_supported(ct, Cc, 4 * Cc):
+                    # stages 1-2 (round 6): du = (gm W2) x h' and dL/da2 = du W1 as ONE launch -- du is written once for fc1's weight gradient
+                    # and feeds the second product from registers; at 128 channels norm2's backward is the launch's epilogue, as it is
+                    # focal_linear_bwd_data_ln's
+                    d_wide = ops.mlp_desc(cc, M, Cc, 4 * Cc)
+                    if want_ln2:
+                        gm_attn = torch.empty_like(gm) if grouped else gm
+                        ops.mlp_wide_bwd_data(d_wide, gm, s["hg"], ar.operand(f"{pb}.mlp.fc1.weight"), ar.operand(f"{pb}.mlp.fc2.weight"), du,
+                                              ln=dict(x=s["x_mid"], stats=s["st2"], gamma=ar.master(f"{pb}.norm2.weight"), g=g, g_masked=gm_attn,
+                                                      mask=s["d_proj"].out_drop, dgamma=ar.g(f"{pb}.norm2.weight"), dbeta=ar.g(f"{pb}.norm2.bias")))
+                        ln2_in_mlp = True
+                    else:
+                        ops.mlp_wide_bwd_data(d_wide, gm, s["hg"], ar.operand(f"{pb}.mlp.fc1.weight"), ar.operand(f"{pb}.mlp.fc2.weight"), du, dc=dc)
+                    weight_grad(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
                 else:
-                    ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
+                    ops.linear_bwd_data(d_fc2_b, gm, ar.operand(f"{pb}.mlp.fc2.weight"), s["hg"], du)
+                    weight_grad(s["d_fc1"], du, s["a2"], ar.g(f"{pb}.mlp.fc1.weight"), ar.g(f"{pb}.mlp.fc1.bias"))
+                    if want_ln2:
+                        ln2_done = True  # dX of fc1 and norm2's backward in one kernel (below)
+                    else:
+                        ops.linear_bwd_data(s["d_fc1"], du, ar.operand(f"{pb}.mlp.fc1.weight"), None, dc)
             # (the MLP branch's gm is still an operand of a pending weight gradient unless the fused branch has consumed it)
-            gm_attn = torch.empty_like(gm) if (not fused_mlp and grouped) else gm
+            if not (ln2_in_mlp and not fused_mlp):
+                gm_attn = torch.empty_like(gm) if (not fused_mlp and grouped) else gm
             if ln2_in_mlp:
                 pass
             elif ln2_done:

@@ -329,9 +329,20 @@ long focal_mlp_bwd_partials_floats(const focal_mlp_desc* d);
  * ties the two launches (profiles/r6_mlp_wide.txt); inside the replayed step it is worth +1.5 % (tools/ab_wide.sh).  FOCAL_MLP_WIDE=0 makes
  * focal_mlp_wide_supported return 0 (the engine then issues the two launches), =128 / =256 restrict it to one width. */
 int focal_mlp_wide_supported(int dtype, int C, int hidden);
+int focal_mlp_wide_bwd_supported(int dtype, int C, int hidden);
 int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
                        const float* b2, float* y, void* h, void* hg, const float* ln_gamma, const float* ln_beta, void* y_ln,
                        float* ln_stats, void* stream);
+/* The data path of the same branch's backward pass as one launch: du = (gm w2) x hg ([M, hidden], written once: fc1's weight gradient reads
+ * it), then dc = du w1 = dL/da2, either stored (dc, dtype [M, C]; ln_x == NULL) or -- C = 128 -- finished on the row as the backward of
+ * the LayerNorm that produced a2 (norm2), exactly as focal_linear_bwd_data_ln does: g += dLN (in place), g_masked = dtype(g x mask),
+ * dgamma / dbeta accumulate.  Replaces focal_linear_bwd_data (GELU derivative) + focal_linear_bwd_data / _ln; the two weights are read
+ * through the hardware transpose from the same ring the forward kernel uses.  Equal to the two launches up to the order inside an MFMA's
+ * 32-term sum.  Measured inside the replayed step: neutral at 128 channels, -1.2 % at 256 (tools/ab_wide_bwd.sh): NOT the default --
+ * focal_mlp_wide_bwd_supported answers 1 only under FOCAL_MLP_WIDE_BWD=1 (or =128 / =256 for one width); the entry point itself always works. */
+int focal_mlp_wide_bwd_data(const focal_mlp_desc* d, const void* gm, const void* hg, const void* w1, const void* w2, void* du, void* dc,
+                            const float* ln_x, const float* ln_stats, const float* ln_gamma, float* g, void* g_masked,
+                            const focal_drop_desc* mask, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ row 10: W-MSA
  * WindowAttention between its qkv and proj Linears (models/SwinModules.py:121-152) with the cyclic shift, window

@@ -139,3 +139,80 @@ def test_encoder_with_the_one_launch_mlp_equals_the_default(cfg, monkeypatch):
     # (mod_in's split-K atomics move dL/dfeat in the last fp32 bit between ANY two runs; the bf16 casts of the backward operands turn a
     # few of those into 2^-8 steps: the gradients of two runs of the SAME form differ by this much)
     assert (g0 - g1).abs().max().item() <= 1e-2 * g0.abs().max().item()   # (observed 0.9e-3 .. 2.6e-3 over six runs)
+
+
+@pytest.mark.parametrize("C,M,ln,drop", [(128, 36864, True, True), (128, 1000, True, False), (128, 96, False, False), (256, 9216, False, True), (256, 1000, False, False)])
+def test_backward_data_path_in_one_launch_equals_the_two_launches(ops, C, M, ln, drop):
+    """focal_mlp_wide_bwd_data against focal_linear_bwd_data (GELU derivative) + focal_linear_bwd_data / focal_linear_bwd_data_ln: du, dc or
+    the LayerNorm backward's g / g_masked / dgamma / dbeta.  The products are the same sums in the same 32-term groups; the first one's k slots
+    inside an MFMA are permuted, so the comparison is to fp32 accumulation order (1e-6-class) on top of bf16 outputs' last-bit flips."""
+    from focal_amd._lib import ACT_GELU, ACT_NONE
+    cc = ops.code(BF)
+    H = 4 * C
+    gm = rnd(M, C, scale=0.5, seed=41, dtype=BF)
+    hg = rnd(M, H, scale=0.7, seed=42, dtype=BF)
+    w1, w2 = rnd(H, C, scale=C ** -0.5, seed=43, dtype=BF), rnd(C, H, scale=H ** -0.5, seed=44, dtype=BF)
+    d2 = ops.linear_desc(cc, M, C, H, cc, cc, ACT_GELU)
+    d1 = ops.linear_desc(cc, M, H, C, cc, cc, ACT_NONE)
+    du0 = torch.empty(M, H, dtype=BF, device=DEV)
+    ops.linear_bwd_data(d2, gm, w2, hg, du0)
+    dw = ops.mlp_desc(cc, M, C, H)
+    du = torch.full((M, H), 3.0, dtype=BF, device=DEV)
+    if not ln:
+        dc0 = torch.empty(M, C, dtype=BF, device=DEV)
+        ops.linear_bwd_data(d1, du0, w1, None, dc0)
+        dc = torch.full((M, C), 3.0, dtype=BF, device=DEV)
+        ops.mlp_wide_bwd_data(dw, gm, hg, w1, w2, du, dc=dc)
+        torch.cuda.synchronize()
+    else:
+        x = rnd(M, C, seed=45)
+        stats = torch.stack([x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+        gamma = rnd(C, seed=46) * 0.2 + 1.0
+        rng = ops.new_rng_state(99, DEV)
+        mask = ops.drop_desc(rng, 33, 0.2, 37, 0.1, 9) if drop else None
+        g0, g1 = rnd(M, C, seed=47), rnd(M, C, seed=47)
+        gmk0, gmk1 = torch.empty(M, C, dtype=BF, device=DEV), torch.empty(M, C, dtype=BF, device=DEV)
+        dg0, db0, dg1, db1 = (torch.zeros(C, device=DEV) for _ in range(4))
+        ops.linear_bwd_data_ln(d1, du0, w1, x, stats, gamma, g0, dg0, db0, g_masked=gmk0, mask=mask)
+        ops.mlp_wide_bwd_data(dw, gm, hg, w1, w2, du, ln=dict(x=x, stats=stats, gamma=gamma, g=g1, g_masked=gmk1, mask=mask, dgamma=dg1, dbeta=db1))
+        torch.cuda.synchronize()
+    # du: bf16 of the same fp32 product up to accumulation order: a last-bit flip here and there
+    assert (du != du0).float().mean().item() < 0.02
+    assert (du.float() - du0.float()).abs().max().item() <= 2.0 ** -7 * du0.float().abs().max().item()
+    if not ln:
+        assert rel_err(dc.float(), dc0.float()) < 3e-3 and (dc.float() - dc0.float()).abs().max().item() <= 2.0 ** -6 * dc0.float().abs().max().item()
+        ref = (gm.float() @ w2.float()) * hg.float()
+        assert rel_err(du.float(), ref) < 4e-3
+        assert rel_err(dc.float(), ref.to(BF).float() @ w1.float()) < 6e-3
+    else:
+        assert rel_err(g1, g0) < 1e-3 and rel_err(dg1, dg0) < 2e-3 and rel_err(db1, db0) < 2e-3
+        assert (gmk1 != gmk0).float().mean().item() < 0.02
+        if drop:
+            assert bool(((gmk0 == 0) == (gmk1 == 0)).float().mean().item() > 0.999)
+
+
+def test_encoder_with_the_one_launch_backward_equals_the_default(cfg, monkeypatch):
+    """FOCAL_MLP_WIDE_BWD=1 through the Swin engine (the one-launch backward data path of stages 1-2; off by default: it does not pay inside
+    the step): same embeddings, gradients equal to run-to-run noise of the bf16 backward."""
+    from test_swt_parity_gpu import build, inputs
+
+    def run():
+        args, net, focal, loss_fn = build(cfg, "bf16")
+        net.train()
+        x1, x2 = inputs(cfg)
+        f1, f2 = focal(x1, x2, proj_head=True)
+        loss = loss_fn(f1, f2)
+        net.arena().zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        return {m: f1[m].detach().clone() for m in f1}, net.arena().grad.clone()
+    from focal_amd import ops as o
+    assert not o.mlp_wide_bwd_supported(BF, 128, 512)
+    e0, g0 = run()
+    monkeypatch.setenv("FOCAL_MLP_WIDE_BWD", "1")
+    assert o.mlp_wide_bwd_supported(BF, 128, 512) and o.mlp_wide_bwd_supported(BF, 256, 1024)
+    e1, g1 = run()
+    for m in e0:
+        assert (e0[m] - e1[m]).abs().max().item() <= 1e-5 * e0[m].abs().max().item()
+    assert (g0 - g1).abs().max().item() <= 1e-2 * g0.abs().max().item()
+    assert ((g0 - g1).norm() / g0.norm()).item() < 5e-3
