@@ -79,7 +79,7 @@ template <int C> struct WideLayout {
   static constexpr int NP1 = NIMG1 * 8, NP2 = C / 8, L1 = NP1 / NLOAD, L2 = NP2 / NLOAD, LSTEP = L1 + L2;
   static constexpr int WPITCH = C + 4;
   static constexpr int STG_BYTES = C == 128 ? NW * 16 * WPITCH * 4 : 0;  // 128 channels: the shared epilogue's transposition region per wave
-  static constexpr int B1_BYTES = H * 4 + C * 4;  // fc1's bias, staged once (a global load inside the step loop would wait, through the in-order vmcnt, for the
+  static constexpr int B1_BYTES = H * 4 + 3 * C * 4;  // + fc2's bias + (256 channels) the next LayerNorm's gamma / beta  // fc1's bias, staged once (a global load inside the step loop would wait, through the in-order vmcnt, for the
                                           // previous step's h / h' stores)
   static constexpr int LDS_BYTES = R * SLOT_BYTES + STG_BYTES + B1_BYTES;
 };
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
   constexpr int NW = L::NW, BM = L::BM;
   constexpr int H = L::H, KK = L::KK, CT = L::CT, NSTEP = L::NSTEP, SLOT_BYTES = L::SLOT_BYTES, W1_BYTES = L::W1_BYTES;
   static_assert(C == 128 || C == 256, "128 or 256 channels");
-  static_assert(EPI2 == EPI_RESID || (EPI2 == EPI_RESID_LN && C == 128), "fc2 epilogue");
+  static_assert(EPI2 == EPI_RESID || EPI2 == EPI_RESID_LN, "fc2 epilogue");
   extern __shared__ __attribute__((aligned(1024))) char wide_lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,6 +114,12 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
     float* b1s = reinterpret_cast<float*>(wide_lds + R * SLOT_BYTES + L::STG_BYTES);
     for (int i = tid; i < H; i += 64 * (NW + NLOAD)) b1s[i] = p.b1[i];
     for (int i = tid; i < C; i += 64 * (NW + NLOAD)) b1s[H + i] = p.g2.bias[i];
+    if (EPI2 == EPI_RESID_LN && C == 256) {
+      for (int i = tid; i < C; i += 64 * (NW + NLOAD)) {
+        b1s[H + C + i] = p.g2.ln_gamma[i];
+        b1s[H + 2 * C + i] = p.g2.ln_beta[i];
+      }
+    }
     __syncthreads();
   }
 
@@ -346,8 +352,61 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
             o[e] = res[q & 1][jj][e] + v * rowm * meO.elem_mult(m, 16 * j + 4 * g4 + e);
           }
           if (mok) store4(yrow + 16 * j, o);
+          if constexpr (EPI2 == EPI_RESID_LN) yacc[j] = o;  // the finished row stays in registers for the LayerNorm below
         }
       });
+      if constexpr (EPI2 == EPI_RESID_LN) {
+        // The LayerNorm that reads x_out next (the next block's norm1), on the row in registers, with ln_fwd_kernel's arithmetic AND its
+        // summation tree, so that the result is the stand-alone kernel's bit for bit: there lane li of a row holds columns 4 li .. + 3 and
+        // the 64 partial sums meet pairwise over li's bits 0, 1, 2 ... 5 (row16_sum, then xadd 16, xadd 32); here li = 4 j + g: bits 0 / 1 are
+        // lane bits 4 / 5 (xadd16 / xadd32), bits 2 - 5 are the column tile j.
+        const float* lngs = b2s + C;
+        const float* lnbs = b2s + 2 * C;
+        auto tree = [&](float (&t)[CT]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int j = 0; j < CT; ++j) t[j] = xadd32(xadd16(t[j]));
+#pragma unroll
+          for (int w = 1; w < CT; w <<= 1)
+#pragma unroll
+            for (int j = 0; j < CT; j += 2 * w) t[j] = t[j] + t[j + w];
+          return t[0];
+        };
+        float part[CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) part[j] = yacc[j][0] + yacc[j][1] + yacc[j][2] + yacc[j][3];
+        const float mean = tree(part) / C;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          const float a = yacc[j][0] - mean, b = yacc[j][1] - mean, c2 = yacc[j][2] - mean, d = yacc[j][3] - mean;
+          // (explicit roundings: ln_fwd_kernel's squares are packed multiplies followed by three adds -- hipcc contracts the same expression
+          // to an FMA chain here, one rounding less per term)
+          {
+#pragma clang fp contract(off)
+            part[j] = a * a + b * b + c2 * c2 + d * d;
+          }
+        }
+        const float rstd = rsqrtf(tree(part) / C + p.g2.ln_eps);
+        bf16_t* arow = reinterpret_cast<bf16_t*>(p.g2.aux_out) + (long)m * p.g2.ldc + 4 * g4;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          const f32x4 gq = *reinterpret_cast<const f32x4*>(lngs + 16 * j + 4 * g4), bq = *reinterpret_cast<const f32x4*>(lnbs + 16 * j + 4 * g4);
+          // ((x - mean) rstd, rounded, then ONE fused multiply-add with gamma and beta: what ln_fwd_kernel compiles to)
+          float t0, t1, t2, t3;
+          {
+#pragma clang fp contract(off)
+            t0 = (yacc[j][0] - mean) * rstd; t1 = (yacc[j][1] - mean) * rstd; t2 = (yacc[j][2] - mean) * rstd; t3 = (yacc[j][3] - mean) * rstd;
+          }
+          const float o0 = __builtin_fmaf(t0, gq[0], bq[0]), o1 = __builtin_fmaf(t1, gq[1], bq[1]);
+          const float o2 = __builtin_fmaf(t2, gq[2], bq[2]), o3 = __builtin_fmaf(t3, gq[3], bq[3]);
+          bf16x4 ob;
+          ob[0] = (bf16_t)o0; ob[1] = (bf16_t)o1; ob[2] = (bf16_t)o2; ob[3] = (bf16_t)o3;
+          if (mok) *reinterpret_cast<bf16x4*>(arow + 16 * j) = ob;
+        }
+        if (mok && g4 == 0) {
+          p.g2.ln_stats[2 * (long)m] = mean;
+          p.g2.ln_stats[2 * (long)m + 1] = rstd;
+        }
+      }
     }
     WS_NOW(ws_e1);
     WS_ACC(ws_epi, ws_e0, ws_e1);
@@ -636,7 +695,7 @@ extern "C" int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const 
   FOCAL_CHECK_ARG(d->M > 0, "mlp_wide_fwd: M = %d", d->M);
   FOCAL_CHECK_ARG(a && resid && w1 && b1 && w2 && b2 && y && h && hg, "mlp_wide_fwd: null tensor");
   const bool ln = y_ln != nullptr;
-  if (ln) FOCAL_CHECK_ARG(d->C == 128 && ln_gamma && ln_beta && ln_stats, "mlp_wide_fwd: the fused LayerNorm exists at 128 channels and needs gamma, beta and a statistics buffer");
+  if (ln) FOCAL_CHECK_ARG(ln_gamma && ln_beta && ln_stats, "mlp_wide_fwd: the fused LayerNorm needs gamma, beta and a statistics buffer");
   WideFwdParams p;
   memset(&p, 0, sizeof(p));
   p.M = d->M;
@@ -661,7 +720,7 @@ extern "C" int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const 
 #endif
   hipStream_t st = (hipStream_t)stream;
   if (d->C == 128) return ln ? launch_wide_fwd<128, EPI_RESID_LN>(p, st) : launch_wide_fwd<128, EPI_RESID>(p, st);
-  return launch_wide_fwd<256, EPI_RESID>(p, st);
+  return ln ? launch_wide_fwd<256, EPI_RESID_LN>(p, st) : launch_wide_fwd<256, EPI_RESID>(p, st);
 }
 
 // NOT the default: inside the replayed step the one-launch backward data path is neutral at 128 channels and costs 1.2 % at 256 (three

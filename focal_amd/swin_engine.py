@@ -169,7 +169,9 @@ class SwinModEncoder:
                     # hg are written once for the backward pass and never read back (bit-identical to the two launches below)
                     d_wide = ops.mlp_desc(cc, M, Cc, 4 * Cc, d_fc1.out_drop, d_fc2.out_drop)
                     nxt_ln = None
-                    if want_ln:
+                    if want_ln or (fuse_ln and bi + 1 < st["depth"] and os.environ.get("FOCAL_MLP_WIDE_LN256") != "0"):
+                        # (256 channels too: a wave of this kernel owns whole rows, and its LayerNorm repeats ln_fwd_kernel's summation tree --
+                        # the next block's norm1 comes out bit-identical to the stand-alone launch it replaces)
                         nb = f"{self.pre}.{si}.blocks.{bi + 1}"
                         nxt_ln = (ar.master(f"{nb}.norm1.weight"), ar.master(f"{nb}.norm1.bias"))
                     pre_ln = ops.mlp_wide_fwd(d_wide, a2, x_mid, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),

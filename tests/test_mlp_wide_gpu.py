@@ -38,6 +38,8 @@ def ops():
 
 
 def _two_launches(ops, M, C, a, w1, b1, w2, b2, r, drop_h, drop_o, ln):
+    """(h, hg, y, y_ln, stats) of the launches the wide kernel replaces: fc1 with the GELU epilogue, fc2 with the residual epilogue and -- as
+    the Swin engine runs them -- the next LayerNorm in fc2's epilogue at 128 channels, as a stand-alone launch at 256."""
     from focal_amd._lib import ACT_GELU, ACT_NONE, EPI_GELU, EPI_RESIDUAL
     cc, f32 = ops.code(BF), ops.code(torch.float32)
     d1 = ops.linear_desc(cc, M, 4 * C, C, cc, cc, ACT_NONE, EPI_GELU, out_drop=drop_h)
@@ -45,15 +47,19 @@ def _two_launches(ops, M, C, a, w1, b1, w2, b2, r, drop_h, drop_o, ln):
     h, hg = torch.empty(M, 4 * C, dtype=BF, device=DEV), torch.empty(M, 4 * C, dtype=BF, device=DEV)
     ops.linear_fwd(d1, a, w1, b1, None, h, hg)
     y = torch.empty(M, C, device=DEV)
-    if ln is not None:
+    if ln is not None and C == 128:
         y_ln, stats = ops.linear_resid_ln_fwd(d2, h, w2, b2, r, y, ln[0], ln[1], BF)
         return h, hg, y, y_ln, stats
     ops.linear_fwd(d2, h, w2, b2, r, y)
+    if ln is not None:
+        y_ln, stats = ops.layernorm_fwd(y, ln[0], ln[1], BF)
+        return h, hg, y, y_ln, stats
     return h, hg, y, None, None
 
 
 @pytest.mark.parametrize("C,M,drop,ln", [(128, 36864, True, True), (128, 36864, False, False), (128, 1000, True, True), (128, 96, False, True),
-                                         (256, 9216, True, False), (256, 18432, False, False), (256, 1000, True, False), (256, 50, False, False)])
+                                         (256, 9216, True, False), (256, 18432, False, False), (256, 1000, True, False), (256, 50, False, False),
+                                         (256, 9216, False, True), (256, 18432, True, True), (256, 1000, False, True)])
 def test_one_launch_equals_the_two_launches_bit_for_bit(ops, C, M, drop, ln, monkeypatch):
     monkeypatch.setenv("FOCAL_MLP_WIDE", "0")
     assert not ops.mlp_wide_supported(BF, C, 4 * C)   # (the same-box A/B switch)
@@ -104,8 +110,6 @@ def test_wide_mlp_rejects_what_it_was_not_built_for(ops):
     a, w1, b1, w2, b2, r = _operands(64, 256)
     d = ops.mlp_desc(ops.code(BF), 64, 256, 1024)
     y, h, hg = torch.empty(64, 256, device=DEV), torch.empty(64, 1024, dtype=BF, device=DEV), torch.empty(64, 1024, dtype=BF, device=DEV)
-    with pytest.raises(FocalHipError):  # the fused LayerNorm exists at 128 channels only
-        ops.mlp_wide_fwd(d, a, r, w1, b1, w2, b2, y, h, hg, next_ln=(torch.ones(256, device=DEV), torch.zeros(256, device=DEV)))
     d64 = ops.mlp_desc(ops.code(BF), 64, 64, 256)
     with pytest.raises((FocalHipError, AssertionError)):
         ops.mlp_wide_fwd(d64, a[:, :64].contiguous(), r[:, :64].contiguous(), w1, b1, w2, b2, y[:, :64].contiguous(), h, hg)
