@@ -687,22 +687,32 @@ def cpu_baseline(a, cfg):
     return out
 
 
-def gpu_clocks(device):
-    """sclk (MHz), mclk level and socket power (W) of this rank's GPU from sysfs, read OUTSIDE the timed region (one sample right before it,
-    one right after): tells a power- or clock-limited box from a fast one in the driver's record.  None where sysfs is not readable."""
-    import glob
-    try:
-        cards = [d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if os.path.exists(d + "/pp_dpm_sclk")]
-        d = cards[min(device.index or 0, len(cards) - 1)]
+_CLOCK_FILES = {}
 
-        def rd(pat, div):
-            g = sorted(glob.glob(d + pat))
-            return int(open(g[0]).read().strip()) // div if g else None
-        mclk = [ln.split(":")[1].strip().rstrip("*").strip() for ln in open(d + "/pp_dpm_mclk") if "*" in ln]
-        power = rd("/hwmon/hwmon*/power1_input", 1000000)
-        return {"sclk_mhz": rd("/hwmon/hwmon*/freq1_input", 1000000), "mclk": mclk[0] if mclk else None,
-                "power_w": power if power is not None else rd("/hwmon/hwmon*/power1_average", 1000000),
-                "power_cap_w": rd("/hwmon/hwmon*/power1_cap", 1000000)}
+
+def _clock_files(device):
+    """sysfs nodes of THIS rank's GPU, found by its PCI address (a box may expose many cards; the visible device is not card0)."""
+    import glob
+    key = device.index or 0
+    if key not in _CLOCK_FILES:
+        pr = torch.cuda.get_device_properties(device)
+        d = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        first = lambda pat: (sorted(glob.glob(d + pat)) or [None])[0]
+        _CLOCK_FILES[key] = {"sclk": first("/hwmon/hwmon*/freq1_input"), "power": first("/hwmon/hwmon*/power1_input") or first("/hwmon/hwmon*/power1_average"),
+                             "cap": first("/hwmon/hwmon*/power1_cap"), "mclk": d + "/pp_dpm_mclk" if os.path.exists(d + "/pp_dpm_mclk") else None}
+    return _CLOCK_FILES[key]
+
+
+def gpu_clocks(device):
+    """sclk (MHz), mclk level, socket power (W) and power cap of this rank's GPU from sysfs (a few tens of microseconds: the paths are
+    resolved once).  Read right before the timed region, once in its middle (after the middle step's loss.item(): the only sample that
+    sees the GPU under load -- it clocks down within a millisecond of its last kernel) and right after it: tells a power- or clock-limited
+    box from a fast one in the driver's record.  None where sysfs is not readable."""
+    try:
+        f = _clock_files(device)
+        rd = lambda path, div: (int(open(path).read().strip()) // div) if path else None
+        mclk = [ln.split(":")[1].strip().rstrip("*").strip() for ln in open(f["mclk"]) if "*" in ln] if f["mclk"] else []
+        return {"sclk_mhz": rd(f["sclk"], 1000000), "mclk": mclk[0] if mclk else None, "power_w": rd(f["power"], 1000000), "power_cap_w": rd(f["cap"], 1000000)}
     except Exception:  # noqa: BLE001  (a diagnostic must not cost the line)
         return None
 
@@ -774,11 +784,13 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        gpu_clocks(device)  # (resolves the sysfs paths outside the timed region)
         t0 = time.perf_counter()
         lag = os.environ.get("FOCAL_BENCH_LAGGED_LOSS") == "1"  # diagnostic: read step k-1's loss after launching step k
         prev = None
         stamps = [t0]
-        for _ in range(steps):
+        mid_clocks = None
+        for k_step in range(steps):
             run()
             if lag:
                 if prev is not None:
@@ -787,11 +799,14 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
             else:
                 step.loss.item()  # the reference syncs on loss.item() every step (pretrain.py:74)
             stamps.append(time.perf_counter())
+            if k_step == steps // 2 and os.environ.get("FOCAL_BENCH_NO_CLOCKS") != "1":
+                mid_clocks = gpu_clocks(device)  # one sysfs sample under load (~50 us of host time inside the timed region, once)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        series["clocks_mid_timed"] = mid_clocks
         series["clocks_after_timed"] = gpu_clocks(device)
         series["timed_ms"] = [round((b - a_) * 1e3, 3) for a_, b in zip(stamps[:-1], stamps[1:])]
         step.last_run = run

@@ -10,6 +10,8 @@ root=$(pwd)
 STEPS=10; WARM=3
 mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+# fixed step counts: bench.py's settle phase (untimed steps until three agree to 1 %) would add a run-dependent number of steps to every pass
+export FOCAL_BENCH_NO_SETTLE=1
 B="$root/bench.py --model $model --dataset $dataset --no-graph --no-cpu-baseline --no-roofline"
 rocprofv3 --kernel-trace --stats -M --output-format csv -d /tmp/prof_$tag -o $tag -- python3 $B --steps $STEPS --warmup $WARM "$@" > $root/gpurun_out/${tag}_bench.log 2>&1
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
