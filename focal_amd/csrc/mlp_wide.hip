@@ -96,8 +96,10 @@ __device__ __forceinline__ f32x4 gload4(const float* p) {
   return *((const __attribute__((address_space(1))) f32x4g*)(p));  // global_load (a generic pointer would be a flat_load)
 }
 
-// EPI2: EPI_RESID or EPI_RESID_LN (128 channels only)
-template <int C, int EPI2>
+// EPI2: EPI_RESID or EPI_RESID_LN.  DROP: the hidden dropout is on (its mask hash then runs unconditionally: MaskEval's run-time `on` test is
+// a scalar branch per four elements); FULL: M is a multiple of the tile height (every shape of the step: no row guards).  Both keep the
+// step loop ONE basic block, so that hipcc can interleave the second half's element math with the first half's fc2 MFMAs.
+template <int C, int EPI2, bool DROP, bool FULL>
 __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_kernel(const WideFwdParams p) {
   using L = WideLayout<C>;
   constexpr int NW = L::NW, BM = L::BM;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
 #pragma unroll 1
   for (int i = 0, tile = blockIdx.x; i < ntl; ++i, tile += G) {
     const int m0 = tile * BM, mbase = m0 + wave * 16, m = mbase + l15;
-    const bool mok = m < p.M;
+    const bool mok = FULL || m < p.M;
     const long mrow = mok ? m : p.M - 1;
     bf16x8 xa[KK];
 #pragma unroll
@@ -246,10 +248,12 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
         for (int T = 0; T < 4; ++T) u[T] = mma16(w[4 + T], xa[2 * kc + 1], u[T]);
       });
       WS_NOW(ws_b);
-      // ---- bias + GELU (+ derivative) + dropout: the element math of EPI_GELU_FWD on columns 64 st + 32 s + 8 g .. + 7 (u[2 s] | u[2 s + 1])
+      // ---- bias + GELU (+ derivative) + dropout: the element math of EPI_GELU_FWD on columns 64 st + 32 s + 8 g .. + 7 (u[2 s] | u[2 s + 1]),
+      // one half s at a time; the fc2 products of half 0 are issued between the two halves' element math (same accumulation order per
+      // output: half 0's 32 hidden units, then half 1's)
       bf16x8 hf[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      auto gelu_half = [&](auto s_) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_)::value;
         float v[8], gq[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -260,7 +264,18 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
 #pragma unroll
         for (int e = 0; e < 8; e += 4) {
           gelu_f2 mult[2];
-          meH.elem_mult_quad(m, n + e, mult[0], mult[1]);
+          if constexpr (DROP) {  // MaskEval::elem_mult_quad without its `on` test
+            const uint32_t idx = (__umul24((uint32_t)m, (uint32_t)meH.ncols) + (uint32_t)(n + e)) >> 2;
+            const uint32_t hh_ = focal_hash24(idx ^ meH.e.key), t16 = meH.e.thresh >> 8;
+            uint32_t g2 = hh_ ^ (hh_ >> 13);
+            g2 = __umul24(g2, 0xC2B2AFu) + 0x165667B1u;
+            g2 ^= g2 >> 15;
+            mult[0] = gelu_f2{(hh_ & 0xffffu) < t16 ? 0.0f : meH.e.scale, (hh_ >> 16) < t16 ? 0.0f : meH.e.scale};
+            mult[1] = gelu_f2{(g2 & 0xffffu) < t16 ? 0.0f : meH.e.scale, (g2 >> 16) < t16 ? 0.0f : meH.e.scale};
+          } else {
+            mult[0] = gelu_f2{1.0f, 1.0f};
+            mult[1] = gelu_f2{1.0f, 1.0f};
+          }
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
             const gelu_f2 x = {v[e + 2 * h2], v[e + 2 * h2 + 1]};
@@ -289,24 +304,27 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
 #else
         if (m == -12345) *reinterpret_cast<bf16x8*>(hgrow) = hgv;
 #endif
-      }
-      WS_NOW(ws_c);
-      // ---- fc2: yacc[j] += W2 rows 16 j .. + 15 (this step's 64 hidden columns) x h
-      pipe_static_for<0, CT / 4>([&](auto jq_) {
-        constexpr int jq = decltype(jq_)::value;
-        bf16x8 w[8];
-        pipe_static_for<0, 4>([&](auto jj_) {
-          constexpr int j = 4 * jq + decltype(jj_)::value;
-          w[2 * decltype(jj_)::value] = pipe_lds_read128<W1_BYTES + j * 2048>(fo0 + sb);
-          w[2 * decltype(jj_)::value + 1] = pipe_lds_read128<W1_BYTES + j * 2048>(fo1 + sb);
-        });
-        lds_wait8(w);
+      };
+      // ---- fc2, half s: yacc[j] += W2 rows 16 j .. + 15 (hidden columns 32 s .. + 31 of this step's 64) x h
+      auto fc2_half = [&](auto s_) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_)::value;
+        pipe_static_for<0, CT / 8>([&](auto jq_) {
+          constexpr int jq = decltype(jq_)::value;
+          bf16x8 w[8];
+          pipe_static_for<0, 8>([&](auto jj_) {
+            constexpr int jj = decltype(jj_)::value, j = 8 * jq + jj;
+            w[jj] = pipe_lds_read128<W1_BYTES + j * 2048>((s ? fo1 : fo0) + sb);
+          });
+          lds_wait8(w);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          yacc[4 * jq + jj] = mma16(w[2 * jj], hf[0], yacc[4 * jq + jj]);
-          yacc[4 * jq + jj] = mma16(w[2 * jj + 1], hf[1], yacc[4 * jq + jj]);
-        }
-      });
+          for (int jj = 0; jj < 8; ++jj) yacc[8 * jq + jj] = mma16(w[jj], hf[s], yacc[8 * jq + jj]);
+        });
+      };
+      gelu_half(std::integral_constant<int, 0>{});
+      WS_NOW(ws_c);
+      fc2_half(std::integral_constant<int, 0>{});
+      gelu_half(std::integral_constant<int, 1>{});
+      fc2_half(std::integral_constant<int, 1>{});
       slot ^= 1;
       WS_NOW(ws_d);
       WS_ACC(ws_fc1, ws_a, ws_b); WS_ACC(ws_gelu, ws_b, ws_c); WS_ACC(ws_fc2, ws_c, ws_d);
@@ -664,10 +682,10 @@ extern "C" int focal_mlp_wide_supported(int dtype, int C_, int hidden) {
   return atoi(on) == C_;
 }
 
-template <int C, int EPI2>
-static int launch_wide_fwd(const WideFwdParams& p, hipStream_t st) {
+template <int C, int EPI2, bool DROP, bool FULL>
+static int launch_wide_fwd_t(const WideFwdParams& p, hipStream_t st) {
   using L = WideLayout<C>;
-  auto kern = mlp_wide_fwd_kernel<C, EPI2>;
+  auto kern = mlp_wide_fwd_kernel<C, EPI2, DROP, FULL>;
   static std::atomic<bool> attr_set{false};
   if (!attr_set.load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES) != hipSuccess) {
@@ -684,6 +702,13 @@ static int launch_wide_fwd(const WideFwdParams& p, hipStream_t st) {
   FOCAL_LAUNCH(kern, dim3(grid), dim3(64 * (NW + NLOAD)), L::LDS_BYTES, st, p);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
+}
+
+template <int C, int EPI2>
+static int launch_wide_fwd(const WideFwdParams& p, hipStream_t st) {
+  const bool drop = p.drop_h.p_elem > 0.f, full = p.M % WideLayout<C>::BM == 0;
+  if (drop) return full ? launch_wide_fwd_t<C, EPI2, true, true>(p, st) : launch_wide_fwd_t<C, EPI2, true, false>(p, st);
+  return full ? launch_wide_fwd_t<C, EPI2, false, true>(p, st) : launch_wide_fwd_t<C, EPI2, false, false>(p, st);
 }
 
 extern "C" int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,

@@ -280,7 +280,7 @@ class SwinModEncoder:
         # LayerNorm backward as the epilogue of the dX GEMM in front of it (64 / 128 channels, bf16): focal_linear_bwd_data_ln; at 256
         # channels neither one nor two waves per row gained anything (profiles/r3_ln_bwd_fused_ab.txt)
         fuse_ln_bwd = ct == torch.bfloat16
-        ln_bwd_max_c = 128
+        ln_bwd_max_c = int(os.environ.get("FOCAL_LN_BWD_MAX_C", "128"))  # (256: measured again in round 6, tools/ab_env.sh)
         # one pass per step over this encoder's weights (both views in one batch): a gradient tile has a single writer per launch
         exclusive_dw = bool(getattr(bb, "views_share_pass", False))
         # (A block's weight gradients on a side stream -- nothing in the backward pass waits for them -- was measured in round 3 and lost
