@@ -168,6 +168,8 @@ PROTOTYPES = {
     "focal_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "focal_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P, P, P]),
     "focal_mlp_bwd_partials_floats": (C.c_long, [C.POINTER(MlpDesc)]),
+    "focal_mlp_proj_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "focal_mlp_proj_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, C.POINTER(DropDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "focal_mlp_wide_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_mlp_wide_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "focal_mlp_wide_bwd_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),

@@ -17,6 +17,18 @@ struct MlpFwdParams {
   MaskParams drop_o;    // Mlp.drop after fc2 x DropPath (over [M][C])
   const float* ln_gamma; const float* ln_beta; bf16_t* y_ln; float* ln_stats; float ln_eps;
   uint32_t* mask_bits;  // [M][8] (DROP): the keep bits of drop_h -- bit 4 (T % 8) + e of word 2 g + T / 8 = hidden unit 16 T + 4 g + e
+  // PROJ (round 6): the attention branch's tail in front of the MLP, in the same kernel -- x_mid = x + drop_p(o Wp^T + bp), a2 = norm2(x_mid):
+  // `a` and `resid` are then OUTPUTS (a2, x_mid: the backward pass reads them), st2 the LayerNorm's {mean, rstd}
+  const bf16_t* o;      // [M][C]   attention output
+  const float* x;       // [M][C]   the block's input (residual stream)
+  const bf16_t* wp;     // [C][C]
+  const float* bp;      // [C]
+  MaskParams drop_p;    // proj dropout x DropPath (over [M][C])
+  const float* g2; const float* bt2; float* st2;   // norm2
+#if defined(__HIPCC__)
+  __device__ __forceinline__ float* resid_out() const { return const_cast<float*>(resid); }
+  __device__ __forceinline__ bf16_t* a_out() const { return const_cast<bf16_t*>(a); }
+#endif
 };
 
 struct MlpBwdParams {

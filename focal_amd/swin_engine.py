@@ -134,7 +134,11 @@ class SwinModEncoder:
                                          out_drop=self._drop(rng, view, uid, 0, p_drop, p_path, L))
                 x_mid = torch.empty(M, Cc, dtype=torch.float32, device=x.device)
                 fuse_wide = Cc <= LN_FUSE_MAX_C
-                if fuse_ln and (Cc == 64 or fuse_wide) and ops.resid_ln_supported(cc, Cc, Cc):
+                # 64-channel blocks (round 6): proj + residual + norm2 ride in FRONT of the fused MLP, in its launch (ops.mlp_proj_fwd below)
+                proj_in_mlp = fuse_ln and fuse_mlp and ops.mlp_supported(ct, Cc, 4 * Cc) and ops.mlp_proj_supported(ct, Cc, 4 * Cc)
+                if proj_in_mlp:
+                    a2 = st2 = None
+                elif fuse_ln and (Cc == 64 or fuse_wide) and ops.resid_ln_supported(cc, Cc, Cc):
                     a2, st2 = ops.linear_resid_ln_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"),
                                                       x, x_mid, ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), ct)
                 else:
@@ -154,8 +158,14 @@ class SwinModEncoder:
                         nb = f"{self.pre}.{si}.blocks.{bi + 1}"
                         nxt_ln = (ar.master(f"{nb}.norm1.weight"), ar.master(f"{nb}.norm1.bias"))
                     mlp_bits = ops.mlp_mask_bits(d_mlp, x.device)  # the hidden dropout's keep bits (32 B per token): all the branch saves beside a2
-                    pre_ln = ops.mlp_fwd(d_mlp, a2, x_mid, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
-                                         ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_out, next_ln=nxt_ln, mask_bits=mlp_bits)
+                    if proj_in_mlp:
+                        (a2, st2), pre_ln = ops.mlp_proj_fwd(d_mlp, o, x, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"), d_proj.out_drop,
+                                                             ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), x_mid,
+                                                             ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
+                                                             ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_out, next_ln=nxt_ln, mask_bits=mlp_bits)
+                    else:
+                        pre_ln = ops.mlp_fwd(d_mlp, a2, x_mid, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
+                                             ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_out, next_ln=nxt_ln, mask_bits=mlp_bits)
                     saved["blocks"].append(dict(pb=pb, x=x, st1=st1, a1=a1, qkv=qkv, o=o, x_mid=x_mid, st2=st2, a2=a2, h=None, hg=None, mlp_bits=mlp_bits,
                                                 d_qkv=d_qkv, d_att=d_att, d_proj=d_proj, d_fc1=d_fc1, d_fc2=d_fc2, d_mlp=d_mlp, M=M, C=Cc))
                     x = x_out

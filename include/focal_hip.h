@@ -310,6 +310,16 @@ int focal_mlp_supported(int dtype, int C, int hidden);
 int focal_mlp_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
                   const float* b2, float* y, const float* ln_gamma, const float* ln_beta, void* y_ln, float* ln_stats,
                   uint32_t* mask_bits, void* stream);
+/* Round 6: the attention branch's tail in front of the MLP, in the same launch -- x_mid = x + drop_proj(o wp^T + bp) (the 64-channel proj
+ * Linear, its Dropout, DropPath and the residual add: SwinModules.py:147, :336-338), a2 = norm2(x_mid) (:339), then the MLP branch as
+ * focal_mlp_fwd.  x_mid [M, C] fp32, a2 [M, C] dtype and st2 [M, 2] are OUTPUTS (the backward pass reads them): everything
+ * focal_linear_resid_ln_fwd + focal_mlp_fwd produce, bit-identical with the masks off, in one launch instead of two.
+ * FOCAL_MLP_PROJ=0 makes focal_mlp_proj_supported return 0. */
+int focal_mlp_proj_supported(int dtype, int C, int hidden);
+int focal_mlp_proj_fwd(const focal_mlp_desc* d, const void* o, const float* x, const void* wp, const float* bp, const focal_drop_desc* drop_proj,
+                       const float* g2, const float* bt2, float* x_mid, void* a2, float* st2, const void* w1, const float* b1, const void* w2,
+                       const float* b2, float* y, const float* ln_gamma, const float* ln_beta, void* y_ln, float* ln_stats,
+                       uint32_t* mask_bits, void* stream);
 int focal_mlp_bwd(const focal_mlp_desc* d, const void* gm, const void* a, const void* w1, const float* b1, const void* w2,
                   void* da, float* dw1, float* db1, float* dw2, float* db2,
                   const float* ln_x, const float* ln_stats, const float* ln_gamma, float* g, void* gm_next,

@@ -253,3 +253,56 @@ def test_fused_mlp_backward_with_norm2_backward_folded_in(ops, M, p_drop):
         yt = F.gelu(a_t.to(BF).float() @ w1.float().t() + b1) @ w2.float().t() + b2
         yt.backward(gm.float())
         assert rel_err(g_one - g0, xt.grad) < 1.5e-2 and rel_err(eg, gt.grad) < 1.5e-2 and rel_err(ebt, bt.grad) < 1e-2
+
+
+@pytest.mark.parametrize("M,drop,ln", [(4608, False, True), (36864 + 48, False, False), (1000, True, True), (147456, True, True), (16, False, True)])
+def test_proj_and_norm2_in_front_of_the_fused_mlp_equal_the_two_launches(ops, M, drop, ln, monkeypatch):
+    """focal_mlp_proj_fwd (round 6): x_mid = x + drop(o Wp^T + bp), a2 = norm2(x_mid) and the MLP branch in ONE launch against
+    focal_linear_resid_ln_fwd + focal_mlp_fwd.  Masks off: every output bit-identical (the in-kernel LayerNorm repeats the GEMM epilogue's
+    summation tree and roundings).  Masks on: x_mid to an ulp (hipcc contracts the residual expression of the GEMM epilogue for three of a
+    lane's four columns), everything behind it to that ulp's consequences."""
+    from focal_amd._lib import ACT_NONE, EPI_RESIDUAL
+    C = 64
+    cc, f32 = ops.code(BF), ops.code(torch.float32)
+    monkeypatch.setenv("FOCAL_MLP_PROJ", "0")
+    assert not ops.mlp_proj_supported(BF, C, 4 * C)
+    monkeypatch.delenv("FOCAL_MLP_PROJ")
+    assert ops.mlp_proj_supported(BF, C, 4 * C) and not ops.mlp_proj_supported(BF, 128, 512)
+    _, w1, b1, w2, b2, _ = _operands(M, seed=50)
+    o, x = rnd(M, C, seed=61, dtype=BF), rnd(M, C, seed=62)
+    wp, bp = rnd(C, C, scale=C ** -0.5, seed=63, dtype=BF), rnd(C, scale=0.3, seed=64)
+    g2, bt2 = rnd(C, seed=65) * 0.2 + 1.0, rnd(C, seed=66) * 0.1
+    gn, btn = rnd(C, seed=67) * 0.2 + 1.0, rnd(C, seed=68) * 0.1
+    rng = ops.new_rng_state(4711 + M, DEV)
+    dp = ops.drop_desc(rng, 5, 0.2, 9, 0.1, 576) if drop else None
+    dh = ops.drop_desc(rng, 6, 0.2, 10, 0.0, 1) if drop else None
+    do = ops.drop_desc(rng, 7, 0.2, 11, 0.1, 576) if drop else None
+    d_proj = ops.linear_desc(cc, M, C, C, cc, f32, ACT_NONE, EPI_RESIDUAL, out_drop=dp)
+    d = ops.mlp_desc(cc, M, C, 4 * C, dh, do)
+    # the two launches
+    xm0 = torch.empty(M, C, device=DEV)
+    a20, st20 = ops.linear_resid_ln_fwd(d_proj, o, wp, bp, x, xm0, g2, bt2, BF)
+    y0 = torch.empty(M, C, device=DEV)
+    bits0 = ops.mlp_mask_bits(d, DEV)
+    n0 = ops.mlp_fwd(d, a20, xm0, w1, b1, w2, b2, y0, next_ln=(gn, btn) if ln else None, mask_bits=bits0)
+    # one launch
+    xm1 = torch.full((M, C), 5.0, device=DEV)
+    y1 = torch.full((M, C), 5.0, device=DEV)
+    bits1 = ops.mlp_mask_bits(d, DEV)
+    (a21, st21), n1 = ops.mlp_proj_fwd(d, o, x, wp, bp, dp, g2, bt2, xm1, w1, b1, w2, b2, y1, next_ln=(gn, btn) if ln else None, mask_bits=bits1)
+    torch.cuda.synchronize()
+    if not drop:
+        assert torch.equal(xm1, xm0) and torch.equal(st21, st20) and torch.equal(a21, a20)
+        assert torch.equal(y1, y0)
+        if ln:
+            assert torch.equal(n1[0], n0[0]) and torch.equal(n1[1], n0[1])
+    else:
+        assert (xm1 - xm0).abs().max().item() <= 2.5e-7 * xm0.abs().max().item()
+        assert (a21 != a20).float().mean().item() < 2e-3 and torch.allclose(st21, st20, rtol=1e-5, atol=1e-6)
+        assert torch.equal(bits1, bits0)
+        assert rel_err(y1, y0) < 2e-3
+        if ln:
+            assert rel_err(n1[0].float(), n0[0].float()) < 4e-3
+    ref = x + o.float() @ wp.float().t() + bp
+    if not drop:
+        assert rel_err(xm1, ref) < 2e-3
