@@ -172,6 +172,8 @@ PROTOTYPES = {
     "focal_mlp_proj_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, C.POINTER(DropDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "focal_mlp_wide_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_mlp_wide_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "focal_mlp_wide_proj_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "focal_mlp_wide_proj_fwd": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, C.POINTER(DropDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "focal_mlp_wide_bwd_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "focal_mlp_wide_bwd_data": (C.c_int, [C.POINTER(MlpDesc), P, P, P, P, P, P, P, P, P, P, P, C.POINTER(DropDesc), P, P, P]),
     "focal_window_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P]),

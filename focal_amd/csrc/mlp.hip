@@ -366,9 +366,20 @@ extern "C" int focal_mlp_fwd(const focal_mlp_desc* d, const void* a, const float
   return mlp_fwd_launch("mlp_fwd", d, a, resid, w1, b1, w2, b2, y, ln_gamma, ln_beta, y_ln, ln_stats, mask_bits, nullptr, stream);
 }
 
+// FOCAL_MLP_PROJ: unset = every width; "0" = none; otherwise the comma-separated widths that keep the fold ("64", "64,128", ...)
+bool focal_mlp_proj_width_enabled(int C_) {
+  const char* sel = getenv("FOCAL_MLP_PROJ");
+  if (sel == nullptr || sel[0] == 0) return true;
+  for (const char* p = sel; *p != 0;) {
+    if (atoi(p) == C_ && C_ != 0) return true;
+    while (*p != 0 && *p != ',') ++p;
+    if (*p == ',') ++p;
+  }
+  return false;
+}
+
 extern "C" int focal_mlp_proj_supported(int dtype, int C_, int hidden) {
-  const char* off = getenv("FOCAL_MLP_PROJ");
-  return focal_mlp_supported(dtype, C_, hidden) && !(off != nullptr && strcmp(off, "0") == 0);
+  return focal_mlp_supported(dtype, C_, hidden) && focal_mlp_proj_width_enabled(C_);
 }
 
 extern "C" int focal_mlp_proj_fwd(const focal_mlp_desc* d, const void* o, const float* x, const void* wp, const float* bp, const focal_drop_desc* drop_proj,

@@ -48,6 +48,7 @@ struct MlpBwdParams {
 };
 
 int mlp_check_desc(const focal_mlp_desc* d, const char* who);
+bool focal_mlp_proj_width_enabled(int C_);  // FOCAL_MLP_PROJ (mlp.hip)
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------------------------- element math of the fused kernels

@@ -55,6 +55,9 @@ struct WideFwdParams {
   bf16_t* hg;         // [M][H]   d gelu x mask
   MaskParams drop_h;  // over [M][H]
   GemmParams g2;      // the fc2 product as focal_linear_fwd / focal_linear_resid_ln_fwd would launch it: bias, resid, C, epi, ln_*, aux_out
+  // PROJ: the attention branch's tail in front of the MLP (x_mid = x + drop_p(o Wp^T + bp), a2 = norm2(x_mid)): `a` and g2.resid are then
+  // OUTPUTS (a2, x_mid), st2 the LayerNorm's {mean, rstd}
+  const bf16_t* o; const float* x; const bf16_t* wp; const float* bp; MaskParams drop_p; const float* ng2; const float* nbt2; float* st2; float ln2_eps;
 };
 
 constexpr int NLOAD = 2, R = 2;
@@ -79,7 +82,7 @@ template <int C> struct WideLayout {
   static constexpr int NP1 = NIMG1 * 8, NP2 = C / 8, L1 = NP1 / NLOAD, L2 = NP2 / NLOAD, LSTEP = L1 + L2;
   static constexpr int WPITCH = C + 4;
   static constexpr int STG_BYTES = C == 128 ? NW * 16 * WPITCH * 4 : 0;  // 128 channels: the shared epilogue's transposition region per wave
-  static constexpr int B1_BYTES = H * 4 + 3 * C * 4;  // + fc2's bias + (256 channels) the next LayerNorm's gamma / beta  // fc1's bias, staged once (a global load inside the step loop would wait, through the in-order vmcnt, for the
+  static constexpr int B1_BYTES = H * 4 + 6 * C * 4;  // + fc2's bias + (256 channels) the next LayerNorm's gamma / beta + (PROJ) proj bias, norm2's gamma / beta  // fc1's bias, staged once (a global load inside the step loop would wait, through the in-order vmcnt, for the
                                           // previous step's h / h' stores)
   static constexpr int LDS_BYTES = R * SLOT_BYTES + STG_BYTES + B1_BYTES;
 };
@@ -99,11 +102,17 @@ __device__ __forceinline__ f32x4 gload4(const float* p) {
 // EPI2: EPI_RESID or EPI_RESID_LN.  DROP: the hidden dropout is on (its mask hash then runs unconditionally: MaskEval's run-time `on` test is
 // a scalar branch per four elements); FULL: M is a multiple of the tile height (every shape of the step: no row guards).  Both keep the
 // step loop ONE basic block, so that hipcc can interleave the second half's element math with the first half's fc2 MFMAs.
-template <int C, int EPI2, bool DROP, bool FULL>
+// PROJ (round 6): per tile, NP = C / 64 ring steps in front of the MLP's carry the proj weight 64 output channels at a time (the same image
+// geometry and row permutation as a W1 slice); the wave multiplies its o rows against them, finishes x_mid = x + drop_p(. + bp) in
+// registers and stores it, then norm2 on the row -- with the summation tree and roundings of the launch it replaces (focal_linear_resid_ln_fwd's
+// epilogue at 128 channels, ln_fwd_kernel at 256) -- stores a2 / statistics and keeps a2 as fc1's operand.  12 proj launches and 8 norm2
+// launches fewer per step; x_mid and a2 are not re-read.
+template <int C, int EPI2, bool DROP, bool FULL, bool PROJ>
 __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_kernel(const WideFwdParams p) {
   using L = WideLayout<C>;
   constexpr int NW = L::NW, BM = L::BM;
   constexpr int H = L::H, KK = L::KK, CT = L::CT, NSTEP = L::NSTEP, SLOT_BYTES = L::SLOT_BYTES, W1_BYTES = L::W1_BYTES;
+  constexpr int NP = PROJ ? C / 64 : 0, TSTEP = NSTEP + NP;   // ring steps per tile
   static_assert(C == 128 || C == 256, "128 or 256 channels");
   static_assert(EPI2 == EPI_RESID || EPI2 == EPI_RESID_LN, "fc2 epilogue");
   extern __shared__ __attribute__((aligned(1024))) char wide_lds[];
@@ -111,9 +120,16 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = (p.M + BM - 1) / BM, G = gridDim.x;
   const int ntl = (ntiles - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup: blockIdx.x, + G, ...
-  const int total = ntl * NSTEP;
+  const int total = ntl * TSTEP;
   {
     float* b1s = reinterpret_cast<float*>(wide_lds + R * SLOT_BYTES + L::STG_BYTES);
+    if constexpr (PROJ) {
+      for (int i = tid; i < C; i += 64 * (NW + NLOAD)) {
+        b1s[H + 3 * C + i] = p.bp[i];
+        b1s[H + 4 * C + i] = p.ng2[i];
+        b1s[H + 5 * C + i] = p.nbt2[i];
+      }
+    }
     for (int i = tid; i < H; i += 64 * (NW + NLOAD)) b1s[i] = p.b1[i];
     for (int i = tid; i < C; i += 64 * (NW + NLOAD)) b1s[H + i] = p.g2.bias[i];
     if (EPI2 == EPI_RESID_LN && C == 256) {
@@ -144,23 +160,28 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
     }
     const char* w1b = reinterpret_cast<const char*>(p.w1);
     const char* w2b = reinterpret_cast<const char*>(p.w2);
+    const char* wpb = reinterpret_cast<const char*>(p.wp);
     int issued = 0, f_st = 0;
     auto issue_next = [&]() __attribute__((always_inline)) {
       const uint32_t slot = (uint32_t)(issued & (R - 1)) * SLOT_BYTES;
-      const char* s1 = w1b + (long)f_st * (64 * C * 2);
-      const char* s2 = w2b + (long)f_st * 128;
+      const bool proj_step = PROJ && f_st < NP;   // (wave-uniform) the first NP steps of a tile: 64 rows of the proj weight, no W2 part
+      const int mst = f_st - NP;
+      const char* s1 = proj_step ? wpb + (long)f_st * (64 * C * 2) : w1b + (long)mst * (64 * C * 2);
+      const char* s2 = w2b + (long)mst * 128;
 #pragma unroll
       for (int t = 0; t < L1; ++t) {
         const int i = lw + NLOAD * t;
         __builtin_amdgcn_global_load_lds((pipe_glb_ptr)(s1 + off1[t]), (pipe_lds_ptr)(wide_lds + slot + (i >> 3) * 8192 + (i & 7) * 1024), 16, 0, 0);
       }
+      if (!proj_step) {
 #pragma unroll
-      for (int t = 0; t < L2; ++t) {
-        const int q = lw + NLOAD * t;
-        __builtin_amdgcn_global_load_lds((pipe_glb_ptr)(s2 + off2[t]), (pipe_lds_ptr)(wide_lds + slot + W1_BYTES + q * 1024), 16, 0, 0);
+        for (int t = 0; t < L2; ++t) {
+          const int q = lw + NLOAD * t;
+          __builtin_amdgcn_global_load_lds((pipe_glb_ptr)(s2 + off2[t]), (pipe_lds_ptr)(wide_lds + slot + W1_BYTES + q * 1024), 16, 0, 0);
+        }
       }
       ++issued;
-      if (++f_st == NSTEP) f_st = 0;
+      if (++f_st == TSTEP) f_st = 0;
     };
     static_assert(R == 2, "the wait below assumes one step in flight behind the one awaited");
     WS_DECL(ws_wait); WS_DECL(ws_bar); WS_DECL(ws_issue); WS_DECL(ws_all);
@@ -185,9 +206,10 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
   const int g4 = lane >> 4, l15 = lane & 15, swz = (lane >> 1) & 7;
   const uint32_t lds0 = pipe_lds_addr(wide_lds);
   const uint32_t fo0 = lds0 + l15 * 128 + ((g4 ^ swz) << 4), fo1 = lds0 + l15 * 128 + (((4 + g4) ^ swz) << 4);
-  MaskEval meH, meO;
+  MaskEval meH, meO, meP;
   meH.init(p.drop_h);
   meO.init(p.g2.epi);
+  if constexpr (PROJ) meP.init(p.drop_p);
   float* est = reinterpret_cast<float*>(wide_lds + R * SLOT_BYTES) + wave * 16 * L::WPITCH;
   const float* b1s = reinterpret_cast<const float*>(wide_lds + R * SLOT_BYTES + L::STG_BYTES);
   const float* b2s = b1s + H;
@@ -205,8 +227,127 @@ __global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_
     const bool mok = FULL || m < p.M;
     const long mrow = mok ? m : p.M - 1;
     bf16x8 xa[KK];
+    if constexpr (!PROJ) {
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) xa[kk] = *reinterpret_cast<const bf16x8*>(p.a + mrow * C + kk * 32 + 8 * g4);
+      for (int kk = 0; kk < KK; ++kk) xa[kk] = *reinterpret_cast<const bf16x8*>(p.a + mrow * C + kk * 32 + 8 * g4);
+    } else {
+      // ---- x_mid = x + drop_p(o Wp^T + bp); a2 = norm2(x_mid).  Step pp: output channels 64 pp + 32 s + 8 g .. + 7 (s = 0, 1) of this lane's token
+      bf16x8 oa[KK];
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) oa[kk] = *reinterpret_cast<const bf16x8*>(p.o + mrow * C + kk * 32 + 8 * g4);
+      const float* bps = b2s + 3 * C;
+      const float* g2s = b2s + 4 * C;
+      const float* bt2s = b2s + 5 * C;
+      float* xmid = const_cast<float*>(p.g2.resid);
+      bf16_t* a2o = const_cast<bf16_t*>(p.a);
+      const float rowmp = meP.row_mult(m);
+      float xm[NP][2][8];
+      pipe_static_for<0, NP>([&](auto pp_) {
+        constexpr int pp = decltype(pp_)::value;
+        f32x4 xr[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          xr[s][0] = gload4(p.x + mrow * C + 64 * pp + 32 * s + 8 * g4);
+          xr[s][1] = gload4(p.x + mrow * C + 64 * pp + 32 * s + 8 * g4 + 4);
+        }
+        ring_barrier();
+        const uint32_t sb = (uint32_t)slot * SLOT_BYTES;
+        f32x4 pu[4];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) pu[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pipe_static_for<0, KK / 2>([&](auto kc_) {
+          constexpr int kc = decltype(kc_)::value;
+          bf16x8 w[8];
+          pipe_static_for<0, 4>([&](auto T_) {
+            constexpr int T = decltype(T_)::value;
+            w[T] = pipe_lds_read128<kc * 8192 + T * 2048>(fo0 + sb);
+            w[4 + T] = pipe_lds_read128<kc * 8192 + T * 2048>(fo1 + sb);
+          });
+          lds_wait8(w);
+#pragma unroll
+          for (int T = 0; T < 4; ++T) pu[T] = mma16(w[T], oa[2 * kc], pu[T]);
+#pragma unroll
+          for (int T = 0; T < 4; ++T) pu[T] = mma16(w[4 + T], oa[2 * kc + 1], pu[T]);
+        });
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int c0 = 64 * pp + 32 * s + 8 * g4;
+          const f32x4 bq0 = *reinterpret_cast<const f32x4*>(bps + c0), bq1 = *reinterpret_cast<const f32x4*>(bps + c0 + 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = (e < 4 ? pu[2 * s][e] : pu[2 * s + 1][e - 4]) * p.g2.alpha + (e < 4 ? bq0[e] : bq1[e - 4]);
+            float t;
+            {
+#pragma clang fp contract(off)
+              t = v * rowmp;
+            }
+            xm[pp][s][e] = __builtin_fmaf(t, meP.elem_mult(m, c0 + e), e < 4 ? xr[s][0][e] : xr[s][1][e - 4]);
+          }
+          if (mok) {
+            store4(xmid + (long)m * C + c0, f32x4{xm[pp][s][0], xm[pp][s][1], xm[pp][s][2], xm[pp][s][3]});
+            store4(xmid + (long)m * C + c0 + 4, f32x4{xm[pp][s][4], xm[pp][s][5], xm[pp][s][6], xm[pp][s][7]});
+          }
+        }
+        slot ^= 1;
+      });
+      // norm2 with the replaced launch's summation tree: there lane li of a row holds channels 4 li .. + 3 and the partial sums meet pairwise over
+      // li's bits 0, 1, 2 ... (row16_sum, then xadd 16 [, xadd 32]); here li = 16 pp + 8 s + 2 g + h: bit 0 = h (the halves of the lane's 8
+      // channels), bits 1 / 2 = lane bits 4 / 5, bit 3 = s, bits 4 [, 5] = pp
+      auto tree = [&](float (&q)[NP][2][2]) __attribute__((always_inline)) {
+        float t[NP][2];
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) t[pp][s] = xadd32(xadd16(q[pp][s][0] + q[pp][s][1]));
+        float u2[NP];
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) u2[pp] = t[pp][0] + t[pp][1];
+#pragma unroll
+        for (int w = 1; w < NP; w <<= 1)
+#pragma unroll
+          for (int pp = 0; pp < NP; pp += 2 * w) u2[pp] = u2[pp] + u2[pp + w];
+        return u2[0];
+      };
+      float q1[NP][2][2];
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) q1[pp][s][h] = ((xm[pp][s][4 * h] + xm[pp][s][4 * h + 1]) + xm[pp][s][4 * h + 2]) + xm[pp][s][4 * h + 3];
+      const float mean = C == 128 ? tree(q1) * (1.0f / 128.0f) : tree(q1) / C;
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#pragma clang fp contract(off)
+            const float d0 = xm[pp][s][4 * h] - mean, d1 = xm[pp][s][4 * h + 1] - mean, d2 = xm[pp][s][4 * h + 2] - mean, d3 = xm[pp][s][4 * h + 3] - mean;
+            q1[pp][s][h] = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+          }
+      const float rstd = rsqrtf(__builtin_fmaf(tree(q1), 1.0f / C, p.ln2_eps));
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int c0 = 64 * pp + 32 * s + 8 * g4;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t;
+            {
+#pragma clang fp contract(off)
+              t = (xm[pp][s][e] - mean) * rstd;
+            }
+            xa[2 * pp + s][e] = (bf16_t)__builtin_fmaf(g2s[c0 + e], t, bt2s[c0 + e]);
+          }
+          if (mok) *reinterpret_cast<bf16x8*>(a2o + (long)m * C + c0) = xa[2 * pp + s];
+        }
+      if (mok && g4 == 0) *reinterpret_cast<float2*>(p.st2 + 2 * (long)m) = make_float2(mean, rstd);
+      // (x_mid's rows are read back by other lanes of this wave in fc2's epilogue: see mlp.hip)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     f32x4 yacc[CT];
 #pragma unroll
     for (int j = 0; j < CT; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -682,10 +823,10 @@ extern "C" int focal_mlp_wide_supported(int dtype, int C_, int hidden) {
   return atoi(on) == C_;
 }
 
-template <int C, int EPI2, bool DROP, bool FULL>
+template <int C, int EPI2, bool DROP, bool FULL, bool PROJ>
 static int launch_wide_fwd_t(const WideFwdParams& p, hipStream_t st) {
   using L = WideLayout<C>;
-  auto kern = mlp_wide_fwd_kernel<C, EPI2, DROP, FULL>;
+  auto kern = mlp_wide_fwd_kernel<C, EPI2, DROP, FULL, PROJ>;
   static std::atomic<bool> attr_set{false};
   if (!attr_set.load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES) != hipSuccess) {
@@ -707,20 +848,26 @@ static int launch_wide_fwd_t(const WideFwdParams& p, hipStream_t st) {
 template <int C, int EPI2>
 static int launch_wide_fwd(const WideFwdParams& p, hipStream_t st) {
   const bool drop = p.drop_h.p_elem > 0.f, full = p.M % WideLayout<C>::BM == 0;
-  if (drop) return full ? launch_wide_fwd_t<C, EPI2, true, true>(p, st) : launch_wide_fwd_t<C, EPI2, true, false>(p, st);
-  return full ? launch_wide_fwd_t<C, EPI2, false, true>(p, st) : launch_wide_fwd_t<C, EPI2, false, false>(p, st);
+  if (p.o != nullptr) {
+    if (drop) return full ? launch_wide_fwd_t<C, EPI2, true, true, true>(p, st) : launch_wide_fwd_t<C, EPI2, true, false, true>(p, st);
+    return full ? launch_wide_fwd_t<C, EPI2, false, true, true>(p, st) : launch_wide_fwd_t<C, EPI2, false, false, true>(p, st);
+  }
+  if (drop) return full ? launch_wide_fwd_t<C, EPI2, true, true, false>(p, st) : launch_wide_fwd_t<C, EPI2, true, false, false>(p, st);
+  return full ? launch_wide_fwd_t<C, EPI2, false, true, false>(p, st) : launch_wide_fwd_t<C, EPI2, false, false, false>(p, st);
 }
 
-extern "C" int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
-                                  const float* b2, float* y, void* h, void* hg, const float* ln_gamma, const float* ln_beta, void* y_ln,
-                                  float* ln_stats, void* stream) {
-  FOCAL_CHECK_ARG(d != nullptr, "mlp_wide_fwd: null descriptor");
+struct WideProjArgs { const void* o; const float* x; const void* wp; const float* bp; const focal_drop_desc* drop; const float* g2; const float* bt2; float* st2; };
+
+static int mlp_wide_fwd_launch(const char* who, const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
+                               const float* b2, float* y, void* h, void* hg, const float* ln_gamma, const float* ln_beta, void* y_ln,
+                               float* ln_stats, const WideProjArgs* pj, void* stream) {
+  FOCAL_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
   FOCAL_CHECK_ARG(d->dtype == FOCAL_BF16 && (d->C == 128 || d->C == 256) && d->hidden == 4 * d->C,
-                  "mlp_wide_fwd: bf16, C = 128 or 256, hidden = 4 C (got dtype %d, C %d, hidden %d)", d->dtype, d->C, d->hidden);
-  FOCAL_CHECK_ARG(d->M > 0, "mlp_wide_fwd: M = %d", d->M);
-  FOCAL_CHECK_ARG(a && resid && w1 && b1 && w2 && b2 && y && h && hg, "mlp_wide_fwd: null tensor");
+                  "%s: bf16, C = 128 or 256, hidden = 4 C (got dtype %d, C %d, hidden %d)", who, d->dtype, d->C, d->hidden);
+  FOCAL_CHECK_ARG(d->M > 0, "%s: M = %d", who, d->M);
+  FOCAL_CHECK_ARG(a && resid && w1 && b1 && w2 && b2 && y && h && hg, "%s: null tensor", who);
   const bool ln = y_ln != nullptr;
-  if (ln) FOCAL_CHECK_ARG(ln_gamma && ln_beta && ln_stats, "mlp_wide_fwd: the fused LayerNorm needs gamma, beta and a statistics buffer");
+  if (ln) FOCAL_CHECK_ARG(ln_gamma && ln_beta && ln_stats, "%s: the fused LayerNorm needs gamma, beta and a statistics buffer", who);
   WideFwdParams p;
   memset(&p, 0, sizeof(p));
   p.M = d->M;
@@ -740,12 +887,43 @@ extern "C" int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const 
   g.aux_out = y_ln;
   g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.ln_stats = ln_stats; g.ln_eps = d->ln_eps;
   g.epi = wide_mask(d->drop_out, d->C);
+  if (pj) {
+    FOCAL_CHECK_ARG(pj->o && pj->x && pj->wp && pj->bp && pj->g2 && pj->bt2 && pj->st2, "%s: null proj / norm2 tensor", who);
+    FOCAL_CHECK_ARG(((uintptr_t)pj->wp | (uintptr_t)pj->o | (uintptr_t)pj->x | (uintptr_t)a | (uintptr_t)resid) % 16 == 0, "%s: 16-byte aligned operands", who);
+    p.o = reinterpret_cast<const bf16_t*>(pj->o);
+    p.x = pj->x;
+    p.wp = reinterpret_cast<const bf16_t*>(pj->wp);
+    p.bp = pj->bp;
+    focal_drop_desc dd;
+    memset(&dd, 0, sizeof(dd));
+    if (pj->drop) dd = *pj->drop;
+    p.drop_p = wide_mask(dd, d->C);
+    p.ng2 = pj->g2; p.nbt2 = pj->bt2; p.st2 = pj->st2; p.ln2_eps = d->ln_eps;
+  }
 #ifdef WIDE_STAMPS
   g.colsumA = reinterpret_cast<float*>(ln_stats && !ln ? ln_stats : nullptr);  // lab build: the stamp buffer rides in ln_stats when no LayerNorm is asked for
 #endif
   hipStream_t st = (hipStream_t)stream;
   if (d->C == 128) return ln ? launch_wide_fwd<128, EPI_RESID_LN>(p, st) : launch_wide_fwd<128, EPI_RESID>(p, st);
   return ln ? launch_wide_fwd<256, EPI_RESID_LN>(p, st) : launch_wide_fwd<256, EPI_RESID>(p, st);
+}
+
+extern "C" int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
+                                  const float* b2, float* y, void* h, void* hg, const float* ln_gamma, const float* ln_beta, void* y_ln,
+                                  float* ln_stats, void* stream) {
+  return mlp_wide_fwd_launch("mlp_wide_fwd", d, a, resid, w1, b1, w2, b2, y, h, hg, ln_gamma, ln_beta, y_ln, ln_stats, nullptr, stream);
+}
+
+extern "C" int focal_mlp_wide_proj_supported(int dtype, int C_, int hidden) {
+  return focal_mlp_wide_supported(dtype, C_, hidden) && focal_mlp_proj_width_enabled(C_);
+}
+
+extern "C" int focal_mlp_wide_proj_fwd(const focal_mlp_desc* d, const void* o, const float* x, const void* wp, const float* bp, const focal_drop_desc* drop_proj,
+                                       const float* g2, const float* bt2, float* x_mid, void* a2, float* st2, const void* w1, const float* b1, const void* w2,
+                                       const float* b2, float* y, void* h, void* hg, const float* ln_gamma, const float* ln_beta, void* y_ln,
+                                       float* ln_stats, void* stream) {
+  const WideProjArgs pj = {o, x, wp, bp, drop_proj, g2, bt2, st2};
+  return mlp_wide_fwd_launch("mlp_wide_proj_fwd", d, a2, x_mid, w1, b1, w2, b2, y, h, hg, ln_gamma, ln_beta, y_ln, ln_stats, &pj, stream);
 }
 
 // NOT the default: inside the replayed step the one-launch backward data path is neutral at 128 channels and costs 1.2 % at 256 (three

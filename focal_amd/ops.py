@@ -592,6 +592,28 @@ def mlp_wide_fwd(d, a, resid, w1, b1, w2, b2, y, h, hg, next_ln=None):
     return y_ln, stats
 
 
+def mlp_wide_proj_supported(dtype, Cc, hidden):
+    return bool(_lib.load().focal_mlp_wide_proj_supported(code(dtype), Cc, hidden))
+
+
+def mlp_wide_proj_fwd(d, o, x, wp, bp, drop_proj, g2, bt2, x_mid, w1, b1, w2, b2, y, h, hg, next_ln=None):
+    """mlp_proj_fwd's form at 128 / 256 channels (focal_mlp_wide_proj_fwd): x_mid = x + drop_proj(o wp^T + bp) (written to `x_mid`),
+    a2 = LayerNorm(x_mid; g2, bt2), then mlp_wide_fwd.  Returns (a2, st2), (y_ln, stats) | None."""
+    _need_cuda(o, x, wp, bp, g2, bt2, x_mid, w1, b1, w2, b2, y, h, hg)
+    a2 = torch.empty(d.M, d.C, dtype=o.dtype, device=o.device)
+    st2 = torch.empty(d.M, 2, dtype=torch.float32, device=o.device)
+    mask = drop_proj or NO_DROP
+    if next_ln is None:
+        check(_lib.load().focal_mlp_wide_proj_fwd(C.byref(d), _p(o), _p(x), _p(wp), _p(bp), C.byref(mask), _p(g2), _p(bt2), _p(x_mid), _p(a2), _p(st2), _p(w1), _p(b1),
+                                                  _p(w2), _p(b2), _p(y), _p(h), _p(hg), None, None, None, None, _stream()))
+        return (a2, st2), None
+    y_ln = torch.empty(d.M, d.C, dtype=o.dtype, device=o.device)
+    stats = torch.empty(d.M, 2, dtype=torch.float32, device=o.device)
+    check(_lib.load().focal_mlp_wide_proj_fwd(C.byref(d), _p(o), _p(x), _p(wp), _p(bp), C.byref(mask), _p(g2), _p(bt2), _p(x_mid), _p(a2), _p(st2), _p(w1), _p(b1),
+                                              _p(w2), _p(b2), _p(y), _p(h), _p(hg), _p(next_ln[0]), _p(next_ln[1]), _p(y_ln), _p(stats), _stream()))
+    return (a2, st2), (y_ln, stats)
+
+
 def mlp_wide_bwd_supported(dtype, Cc, hidden):
     return bool(_lib.load().focal_mlp_wide_bwd_supported(code(dtype), Cc, hidden))
 

@@ -136,7 +136,9 @@ class SwinModEncoder:
                 fuse_wide = Cc <= LN_FUSE_MAX_C
                 # 64-channel blocks (round 6): proj + residual + norm2 ride in FRONT of the fused MLP, in its launch (ops.mlp_proj_fwd below)
                 proj_in_mlp = fuse_ln and fuse_mlp and ops.mlp_supported(ct, Cc, 4 * Cc) and ops.mlp_proj_supported(ct, Cc, 4 * Cc)
-                if proj_in_mlp:
+                # ... and so do the 128 / 256-channel ones in front of the one-launch MLP of stages 1-2 (ops.mlp_wide_proj_fwd)
+                proj_in_wide = fuse_ln and fuse_mlp and ops.mlp_wide_supported(ct, Cc, 4 * Cc) and ops.mlp_wide_proj_supported(ct, Cc, 4 * Cc)
+                if proj_in_mlp or proj_in_wide:
                     a2 = st2 = None
                 elif fuse_ln and (Cc == 64 or fuse_wide) and ops.resid_ln_supported(cc, Cc, Cc):
                     a2, st2 = ops.linear_resid_ln_fwd(d_proj, o, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"),
@@ -184,8 +186,14 @@ class SwinModEncoder:
                         # the next block's norm1 comes out bit-identical to the stand-alone launch it replaces)
                         nb = f"{self.pre}.{si}.blocks.{bi + 1}"
                         nxt_ln = (ar.master(f"{nb}.norm1.weight"), ar.master(f"{nb}.norm1.bias"))
-                    pre_ln = ops.mlp_wide_fwd(d_wide, a2, x_mid, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
-                                              ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_out, h, hg, next_ln=nxt_ln)
+                    if proj_in_wide:
+                        (a2, st2), pre_ln = ops.mlp_wide_proj_fwd(d_wide, o, x, ar.operand(f"{pb}.attn.proj.weight"), ar.master(f"{pb}.attn.proj.bias"), d_proj.out_drop,
+                                                                  ar.master(f"{pb}.norm2.weight"), ar.master(f"{pb}.norm2.bias"), x_mid,
+                                                                  ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
+                                                                  ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_out, h, hg, next_ln=nxt_ln)
+                    else:
+                        pre_ln = ops.mlp_wide_fwd(d_wide, a2, x_mid, ar.operand(f"{pb}.mlp.fc1.weight"), ar.master(f"{pb}.mlp.fc1.bias"),
+                                                  ar.operand(f"{pb}.mlp.fc2.weight"), ar.master(f"{pb}.mlp.fc2.bias"), x_out, h, hg, next_ln=nxt_ln)
                     saved["blocks"].append(dict(pb=pb, x=x, st1=st1, a1=a1, qkv=qkv, o=o, x_mid=x_mid, st2=st2, a2=a2, h=h, hg=hg,
                                                 d_qkv=d_qkv, d_att=d_att, d_proj=d_proj, d_fc1=d_fc1, d_fc2=d_fc2, M=M, C=Cc))
                     x = x_out

@@ -343,6 +343,14 @@ int focal_mlp_wide_bwd_supported(int dtype, int C, int hidden);
 int focal_mlp_wide_fwd(const focal_mlp_desc* d, const void* a, const float* resid, const void* w1, const float* b1, const void* w2,
                        const float* b2, float* y, void* h, void* hg, const float* ln_gamma, const float* ln_beta, void* y_ln,
                        float* ln_stats, void* stream);
+/* focal_mlp_proj_fwd's form for these widths (round 6): proj + residual + DropPath + norm2 of the attention branch in front of the MLP, in its
+ * launch -- the proj weight rides the same ring, 64 output channels per step; x_mid, a2, st2 are outputs.  Bit-identical to
+ * focal_linear_resid_ln_fwd (128) / focal_linear_fwd + focal_layernorm_fwd (256) followed by focal_mlp_wide_fwd with the masks off. */
+int focal_mlp_wide_proj_supported(int dtype, int C, int hidden);
+int focal_mlp_wide_proj_fwd(const focal_mlp_desc* d, const void* o, const float* x, const void* wp, const float* bp, const focal_drop_desc* drop_proj,
+                            const float* g2, const float* bt2, float* x_mid, void* a2, float* st2, const void* w1, const float* b1, const void* w2,
+                            const float* b2, float* y, void* h, void* hg, const float* ln_gamma, const float* ln_beta, void* y_ln,
+                            float* ln_stats, void* stream);
 /* The data path of the same branch's backward pass as one launch: du = (gm w2) x hg ([M, hidden], written once: fc1's weight gradient reads
  * it), then dc = du w1 = dL/da2, either stored (dc, dtype [M, C]; ln_x == NULL) or -- C = 128 -- finished on the row as the backward of
  * the LayerNorm that produced a2 (norm2), exactly as focal_linear_bwd_data_ln does: g += dLN (in place), g_masked = dtype(g x mask),

@@ -220,3 +220,52 @@ def test_encoder_with_the_one_launch_backward_equals_the_default(cfg, monkeypatc
         assert (e0[m] - e1[m]).abs().max().item() <= 1e-5 * e0[m].abs().max().item()
     assert (g0 - g1).abs().max().item() <= 1e-2 * g0.abs().max().item()
     assert ((g0 - g1).norm() / g0.norm()).item() < 5e-3
+
+
+@pytest.mark.parametrize("C,M,drop,ln", [(128, 36864, False, True), (128, 1000, False, False), (128, 9216, True, True), (256, 9216, False, True), (256, 18432, False, False),
+                                         (256, 1000, True, True), (256, 50, False, True)])
+def test_proj_and_norm2_in_front_of_the_wide_mlp_equal_their_own_launches(ops, C, M, drop, ln, monkeypatch):
+    """focal_mlp_wide_proj_fwd: x_mid = x + drop(o Wp^T + bp), a2 = norm2(x_mid) and the MLP branch in ONE launch against
+    focal_linear_resid_ln_fwd (128 channels) / focal_linear_fwd + focal_layernorm_fwd (256) followed by focal_mlp_wide_fwd.  Masks off: every
+    output bit-identical (the in-kernel LayerNorm repeats the replaced launch's summation tree and roundings)."""
+    from focal_amd._lib import ACT_NONE, EPI_RESIDUAL
+    cc, f32 = ops.code(BF), ops.code(torch.float32)
+    monkeypatch.setenv("FOCAL_MLP_PROJ", "0")
+    assert not ops.mlp_wide_proj_supported(BF, C, 4 * C)
+    monkeypatch.delenv("FOCAL_MLP_PROJ")
+    assert ops.mlp_wide_proj_supported(BF, C, 4 * C)
+    _, w1, b1, w2, b2, _ = _operands(M, C, seed=70 + C)
+    o, x = rnd(M, C, seed=81, dtype=BF), rnd(M, C, seed=82)
+    wp, bp = rnd(C, C, scale=C ** -0.5, seed=83, dtype=BF), rnd(C, scale=0.3, seed=84)
+    g2, bt2 = rnd(C, seed=85) * 0.2 + 1.0, rnd(C, seed=86) * 0.1
+    lnp = (rnd(C, seed=87) * 0.2 + 1.0, rnd(C, seed=88) * 0.1) if ln else None
+    rng = ops.new_rng_state(815 + M, DEV)
+    dp = ops.drop_desc(rng, 5, 0.2, 9, 0.1, 64) if drop else None
+    dh = ops.drop_desc(rng, 6, 0.2, 10, 0.0, 1) if drop else None
+    do = ops.drop_desc(rng, 7, 0.2, 11, 0.1, 64) if drop else None
+    d_proj = ops.linear_desc(cc, M, C, C, cc, f32, ACT_NONE, EPI_RESIDUAL, out_drop=dp)
+    d = ops.mlp_desc(cc, M, C, 4 * C, dh, do)
+    xm0 = torch.empty(M, C, device=DEV)
+    if C == 128:
+        a20, st20 = ops.linear_resid_ln_fwd(d_proj, o, wp, bp, x, xm0, g2, bt2, BF)
+    else:
+        ops.linear_fwd(d_proj, o, wp, bp, x, xm0)
+        a20, st20 = ops.layernorm_fwd(xm0, g2, bt2, BF)
+    h0, hg0 = torch.empty(M, 4 * C, dtype=BF, device=DEV), torch.empty(M, 4 * C, dtype=BF, device=DEV)
+    y0 = torch.empty(M, C, device=DEV)
+    n0 = ops.mlp_wide_fwd(d, a20, xm0, w1, b1, w2, b2, y0, h0, hg0, next_ln=lnp)
+    xm1, y1 = torch.full((M, C), 5.0, device=DEV), torch.full((M, C), 5.0, device=DEV)
+    h1, hg1 = torch.full((M, 4 * C), 5.0, dtype=BF, device=DEV), torch.full((M, 4 * C), 5.0, dtype=BF, device=DEV)
+    (a21, st21), n1 = ops.mlp_wide_proj_fwd(d, o, x, wp, bp, dp, g2, bt2, xm1, w1, b1, w2, b2, y1, h1, hg1, next_ln=lnp)
+    torch.cuda.synchronize()
+    if not drop:
+        assert torch.equal(xm1, xm0)
+        assert torch.equal(st21, st20) and torch.equal(a21, a20)
+        assert torch.equal(h1, h0) and torch.equal(hg1, hg0) and torch.equal(y1, y0)
+        if ln:
+            assert torch.equal(n1[0], n0[0]) and torch.equal(n1[1], n0[1])
+        assert rel_err(xm1, x + o.float() @ wp.float().t() + bp) < 2e-3
+    else:
+        assert (xm1 - xm0).abs().max().item() <= 2.5e-7 * xm0.abs().max().item()
+        assert (a21 != a20).float().mean().item() < 2e-3 and torch.allclose(st21, st20, rtol=1e-5, atol=1e-6)
+        assert rel_err(y1, y0) < 2e-3 and rel_err(h1.float(), h0.float()) < 2e-3

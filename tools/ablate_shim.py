@@ -27,6 +27,12 @@ def install():
         names.remove("proj64")
         real = lib.focal_linear_resid_ln_fwd
         setattr(lib, "focal_linear_resid_ln_fwd", lambda d, *a, **k: 0 if d._obj.N == 64 else real(d, *a, **k))
+    if "proj_wide" in names:  # the proj launches of stages 1-2 (128 / 256 channels): the bound of folding them into the wide MLP kernel
+        names.remove("proj_wide")
+        real_ln = lib.focal_linear_resid_ln_fwd
+        real_fw = lib.focal_linear_fwd
+        setattr(lib, "focal_linear_resid_ln_fwd", lambda d, *a, **k: 0 if d._obj.N == 128 and d._obj.K == 128 else real_ln(d, *a, **k))
+        setattr(lib, "focal_linear_fwd", lambda d, *a, **k: 0 if (d._obj.N == 256 and d._obj.K == 256 and d._obj.epilogue == 1) else real_fw(d, *a, **k))
     for n in names:
         for sym in FAMILIES[n]:
             setattr(lib, sym, lambda *a, **k: 0)  # shadows the ctypes function object on this CDLL instance
