@@ -22,7 +22,7 @@
 #pragma once
 #include "gemm_pipe.hpp"
 
-constexpr int DWG_MAX_PROBLEMS = 8;
+constexpr int DWG_MAX_PROBLEMS = FOCAL_DW_GROUP_MAX_PROBLEMS;  // (include/focal_hip.h)
 
 struct DwGroupProblem {
   const bf16_t* A; const bf16_t* B; float* C; float* colsum;  // colsum may be null
@@ -167,6 +167,19 @@ __global__ __launch_bounds__(512) void focal_dw_group_kernel(const DwGroupParams
     fstage = (fstage + 1 == NST) ? 0 : fstage + 1;
   }
   if (nk == 0) return;  // an empty slice (the last slices of a short token range) adds nothing
+#if defined(DWG_LAB_NOEPI)  // lab: the launch without its epilogue (tools/mb_dw.py; every accumulator stays live through a never-taken store)
+  {
+    float lab = 0.f;
+#pragma unroll
+    for (int i = 0; i < NFA; ++i) {
+      lab += accb[i][0];
+#pragma unroll
+      for (int j = 0; j < NFB; ++j) lab += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    }
+    if (lab == 12345.678f) p.C[0] = 1.f;
+    return;
+  }
+#endif
 
   // ---- epilogue.  acc[i][j][e] = C[m0 + 64 wm + 16 i + l15][n0 + 32 wn + 16 j + 4 g + e]
   const int mrow = m0 + 64 * wm, ncol = n0 + 32 * wn;
@@ -193,7 +206,11 @@ __global__ __launch_bounds__(512) void focal_dw_group_kernel(const DwGroupParams
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: no barrier needed
       float* crow = p.C + (long)(mrow + 16 * i + erow) * p.ldc + ncol + ecol;
 #pragma unroll 4
+#if defined(DWG_LAB_STORE)  // lab: plain stores where the atomics are (same bytes, wrong sums)
+      for (int r = 0; r < 16; r += 2) crow[(long)r * p.ldc] = est[(r + erow) * WPITCH + ecol];
+#else
       for (int r = 0; r < 16; r += 2) atomicAdd(crow + (long)r * p.ldc, est[(r + erow) * WPITCH + ecol]);
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads above are done before the next fragment row overwrites the region
     }
   }

@@ -274,7 +274,7 @@ static int dw_group_build(int dtype, int n, const focal_dw_problem* probs, DwGro
     p.M = q.N; p.N = q.K; p.rows = q.M;
     p.exclusive = q.exclusive ? 1 : 0;
   }
-  const int target = 256, min_steps = 8;  // ~one workgroup per CU, at least 8 ring stages each (swept in round 3: profiles/r3_dw_group.txt)
+  const int target = getenv("FOCAL_LAB_DWG_TARGET") ? atoi(getenv("FOCAL_LAB_DWG_TARGET")) : 256, min_steps = 8;  // ~one workgroup per CU, at least 8 ring stages each (swept in round 3: profiles/r3_dw_group.txt)
   *wgs = focal_dw_group_plan<64>(*gp, target, min_steps);
   return FOCAL_OK;
 }

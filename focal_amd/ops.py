@@ -480,6 +480,9 @@ def _dw_problems(items, exclusive):
     return arr
 
 
+DW_GROUP_MAX_PROBLEMS = 20  # FOCAL_DW_GROUP_MAX_PROBLEMS (include/focal_hip.h)
+
+
 def linear_bwd_weight_group(dtype_code, items, exclusive=True):
     """items: [(dy [M, N], x [M, K], dw [N, K] fp32, dbias [N] fp32 | None)] -- the weight gradients of several linear layers as ONE
     launch (focal_linear_bwd_weight_group).  exclusive: nothing else adds to these dw while the launch runs."""

@@ -304,6 +304,32 @@ class SwinModEncoder:
         # (A block's weight gradients on a side stream -- nothing in the backward pass waits for them -- was measured in round 3 and lost
         # 9 % / 20 %: their operands must then outlive the block, and every later temporary lands on memory the Infinity Cache does not
         # hold; profiles/r3_dw_stream_ab.txt.  The code was removed in round 4.)
+        # FOCAL_DW_PAIR = n > 1: the group launches of n consecutive blocks (128 x 128 tiles: stages 1-2) go out as ONE launch.  A launch costs
+        # ~8 us of ramp and ~8 us of memory-side fp32 atomics (one 64 KB tile per workgroup whatever the problem count: tools/lab_dwg.sh), and
+        # twice the tiles need half the token slices -- but 96 tiles x 144 ring stages cut into <= 256 workgroups is 2 slices of 72 stages
+        # (192 workgroups) against 5 of 29 (240), and the operands of the waiting block stay alive a block longer: measured -0.4 ... -0.9 % (2) and
+        # -0.9 ... +0.7 % (4) inside the step (tools/ab_dw_pair.sh, profiles/r6_dw_group_fixed_cost.txt).  NOT the default.
+        dw_pair = int(os.environ.get("FOCAL_DW_PAIR", "1"))
+        pending = state.setdefault("dw_pending", [])
+
+        def flush_dw():
+            if pending:
+                ops.linear_bwd_weight_group(cc, list(pending), exclusive=exclusive_dw)
+                pending.clear()
+                state["dw_pending_blocks"] = 0
+
+        def submit_dw(items, mergeable):
+            """Launch a block's grouped weight gradients, or park them for the next block's launch; True when they are still waiting."""
+            if not mergeable or dw_pair <= 1:
+                ops.linear_bwd_weight_group(cc, items, exclusive=exclusive_dw)
+                return False
+            pending.extend(items)
+            state["dw_pending_blocks"] = state.get("dw_pending_blocks", 0) + 1
+            if state["dw_pending_blocks"] >= dw_pair or len(pending) + 5 > ops.DW_GROUP_MAX_PROBLEMS:
+                flush_dw()
+                return False
+            return True
+
         for k in range(state["next"], stop - 1, -1):
             if (k + 1) in merges:  # a PatchMerging sits between block k and block k+1
                 mg = merges[k + 1]
@@ -423,12 +449,13 @@ class SwinModEncoder:
             mg_dw = merges.get(k) if grouped128 else None
             if mg_dw is not None and ops.dw_group_kind(cc, mg_dw["d_red"].M, mg_dw["d_red"].N, mg_dw["d_red"].K) != 2:
                 mg_dw = None
+            waiting = False
             if mg_dw is None and dw_items:
-                ops.linear_bwd_weight_group(cc, dw_items, exclusive=exclusive_dw)
+                waiting = submit_dw(dw_items, grouped128)
             du = None
             want_gm = nxt is not None or mg_dw is not None
-            if want_gm and mg_dw is not None:
-                gm = torch.empty_like(gm)  # the old buffer is an operand of the group launch that has not run yet
+            if want_gm and (mg_dw is not None or waiting):
+                gm = torch.empty_like(gm)  # the old buffer is an operand of a group launch that has not run yet
             if ln1_fused:  # dX of qkv and norm1's backward in one kernel
                 # the encoder's first block behind the frozen patch embedding: its input is a leaf nobody differentiates, so the
                 # residual-stream gradient stops here -- only norm1's dgamma / dbeta are produced (no read / update / re-cast of g)
@@ -441,11 +468,12 @@ class SwinModEncoder:
                                   dx_masked=gm if want_gm else None, mask=nxt)
             if mg_dw is not None:
                 dw_items.append((gm.view(mg_dw["d_red"].M, mg_dw["d_red"].N), mg_dw["a4"], ar.g(f"{mg_dw['pm']}.reduction.weight"), None))
-                ops.linear_bwd_weight_group(cc, dw_items, exclusive=exclusive_dw)
+                submit_dw(dw_items, True)
                 mg_dw["dw_done"] = True
             del dqkv
             blocks[k] = None  # free this block's activations as we go
             dw_items = dw_calls = weight_grad = None
+        flush_dw()
         state.update(g=g, gm=gm, next=stop - 1)
 
     def _backward_tail(self, saved, state):

@@ -261,7 +261,9 @@ int focal_linear_bwd_weight_workgroups(const focal_linear_desc* d);
  * ring for bf16 shapes made of whole 64-tiles, given 16-byte aligned operands; 512-thread workgroups of two token slices each).  0 = invalid descriptor. */
 int focal_linear_bwd_weight_kernel(const focal_linear_desc* d);
 
-/* The weight gradients of up to 8 linear layers in ONE launch (the four linears of a Swin block: qkv, proj, fc1, fc2): per problem
+#define FOCAL_DW_GROUP_MAX_PROBLEMS 20
+/* The weight gradients of up to FOCAL_DW_GROUP_MAX_PROBLEMS linear layers in ONE launch (the four linears of a Swin block: qkv, proj, fc1, fc2 --
+ * of one block, or of several consecutive blocks whose operands the caller keeps alive: round 6): per problem
  * dw[N, K] += dy[M, N]^T . x[M, K], dbias[N] += column sums of dy (dbias may be NULL) -- n calls of focal_linear_bwd_weight with
  * plain `dtype` operands (bf16; dy already carries its dropout mask), as one kernel on 128 x 128 output tiles
  * (csrc/gemm_dw_group.hpp).  Needs M % 64 == 0 and N, K % 128 == 0 per problem (focal_linear_bwd_weight_group_supported), 16-byte
