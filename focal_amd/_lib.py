@@ -15,7 +15,7 @@ EPI_NONE, EPI_RESIDUAL, EPI_RELU, EPI_GELU = 0, 1, 2, 3
 BN_EVAL, BN_TRAIN, BN_PARTIAL, BN_FINALIZE = 0, 1, 2, 3
 BN_SCRATCH_ZEROED = 16  # OR into the mode: the scratch already holds zeros (no memset launch)
 BN_STAT_SLOTS = 16      # focal_conv_fwd_bn: column sums are spread over this many slots of the scratch
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class DropDesc(C.Structure):
@@ -210,6 +210,8 @@ PROTOTYPES = {
     "focal_bn_stats": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, C.c_int, P]),
     "focal_bn_running_combine": (C.c_int, [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.c_int, C.c_float, P]),
     "focal_bn_act_fwd": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P]),
+    "focal_bn_act_fwd_sums": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P, P, P, P]),
+    "focal_conv_fwd_bn_sums_supported": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(BNDesc), P, P]),
     "focal_bn_act_bwd": (C.c_int, [C.POINTER(BNDesc), P, P, P, P, P, P, P, P, P, C.c_int, P]),
     "focal_gru_gate_fwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, C.c_int, P, P, P, P, P, P, P]),
     "focal_gru_gate_bwd": (C.c_int, [C.POINTER(GRUDesc), C.c_int, C.c_int, P, C.c_long, C.c_long, C.c_float, P, P, P, P, P, P, P, P]),

@@ -120,12 +120,50 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ run_mean, const f
   mean_rstd[C + c] = rsqrtf(run_var[c] + eps);
 }
 
+// The statistics of a convolution that left only its per-channel sums behind (focal_conv_fwd_bn with mean_rstd = NULL: 16 slots of {sum[C],
+// sum of squares[C]} per group): every workgroup of the BatchNorm launch sums the slots itself (8 KB from L2) -- the arithmetic of the
+// convolution kernels' last-arriver finalisation, bit for bit -- and the first one of a group publishes mean / rstd for the backward pass and
+// updates the running buffers.  The convolution then ends on fire-and-forget atomics: no returning adds, no arrival ticket, no slot read-back
+// (three dependent memory-side round trips, ~9 us per launch: tools/prof_conv.sh).
+struct BnFromSums {
+  const float* sums;   // NULL: mean_rstd is an input
+  float* mean_rstd_out; float* run_mean; float* run_var;
+  float n, eps, momentum;
+};
+
 template <typename TY>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean_rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ resid, float* __restrict__ y, TY* __restrict__ ya,
                                                          long rows, int C, int rows_per_sample, const uint32_t* rng,
-                                                         uint32_t stream, float p) {
+                                                         uint32_t stream, float p, BnFromSums fs) {
+  __shared__ float mr_lds[2 * 64];
+  if (fs.sums != nullptr) {  // (C = 64: the launcher checks)
+    const float* sums = fs.sums + (size_t)blockIdx.y * (FOCAL_BN_STAT_SLOTS * 2 * C + 1);
+    if (threadIdx.x < C) {
+      const int c = threadIdx.x;
+      float sm = 0.f, sq = 0.f;
+      for (int sl = 0; sl < FOCAL_BN_STAT_SLOTS; ++sl) { sm += sums[sl * 2 * C + c]; sq += sums[sl * 2 * C + C + c]; }
+      const float mean = sm / fs.n;
+      float var = sq / fs.n - mean * mean;
+      var = fmaxf(var, 0.f);
+      const float rstd = rsqrtf(var + fs.eps);
+      mr_lds[c] = mean;
+      mr_lds[C + c] = rstd;
+      if (blockIdx.x == 0) {
+        float* const mr = fs.mean_rstd_out + (size_t)blockIdx.y * 2 * C;
+        mr[c] = mean;
+        mr[C + c] = rstd;
+        if (fs.run_mean) {
+          float* const rm = fs.run_mean + (size_t)blockIdx.y * C;
+          float* const rv = fs.run_var + (size_t)blockIdx.y * C;
+          rm[c] = (1.f - fs.momentum) * rm[c] + fs.momentum * mean;
+          rv[c] = (1.f - fs.momentum) * rv[c] + fs.momentum * var * (fs.n / fmaxf(fs.n - 1.f, 1.f));
+        }
+      }
+    }
+    __syncthreads();
+  }
   const DropCtx dc = make_drop(rng, stream, p);
   const bool drop_on = p > 0.f;
   const long n4 = rows * C / 4;
@@ -135,7 +173,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     z += off; y += off;
     if (resid) resid += off;
     if (ya) ya += off;
-    mean_rstd += (size_t)blockIdx.y * 2 * C;
+    mean_rstd = fs.sums != nullptr ? mr_lds : mean_rstd + (size_t)blockIdx.y * 2 * C;
   }
   const long row0 = (long)blockIdx.y * rows;  // (Dropout2d samples are numbered through the whole tensor)
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
@@ -364,12 +402,39 @@ extern "C" int focal_bn_act_fwd(const focal_bn_desc* d, const float* z, const fl
   const int G = bn_groups(d);
   const long rows_g = d->rows / G;
   const int blocks = ceil_div(stream_blocks(d->rows, d->C), G);
+  BnFromSums fs;
+  memset(&fs, 0, sizeof(fs));
   if (d->dtype == FOCAL_F32)
     FOCAL_LAUNCH((bn_act_fwd_kernel<float>), dim3(blocks, G), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (float*)y_cast,
-                       rows_g, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+                       rows_g, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop, fs);
   else
     FOCAL_LAUNCH((bn_act_fwd_kernel<bf16_t>), dim3(blocks, G), dim3(256), 0, st, z, mean_rstd, gamma, beta, resid, y, (bf16_t*)y_cast,
-                       rows_g, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop);
+                       rows_g, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop, fs);
+  FOCAL_LAUNCH_CHECK();
+  return FOCAL_OK;
+}
+
+extern "C" int focal_bn_act_fwd_sums(const focal_bn_desc* d, const float* z, const float* sums, float* mean_rstd, float* running_mean,
+                                     float* running_var, const float* gamma, const float* beta, const float* resid, float* y, void* y_cast,
+                                     void* stream) {
+  if (int rc = bn_check(d)) return rc;
+  FOCAL_CHECK_ARG(z && sums && mean_rstd && gamma && beta && y, "bn_act_fwd_sums: null tensor");
+  FOCAL_CHECK_ARG(d->C == 64 && (running_mean == nullptr) == (running_var == nullptr), "bn_act_fwd_sums: 64 channels (got %d), both running buffers or none", d->C);
+  hipStream_t st = (hipStream_t)stream;
+  const int G = bn_groups(d);
+  FOCAL_CHECK_ARG(G == 1 || d->stat_rows <= 0, "bn_act_fwd_sums: statistic groups and stat_rows do not combine");
+  const long rows_g = d->rows / G;
+  const int blocks = ceil_div(stream_blocks(d->rows, d->C), G);
+  BnFromSums fs;
+  fs.sums = sums; fs.mean_rstd_out = mean_rstd; fs.run_mean = running_mean; fs.run_var = running_var;
+  fs.n = (float)(G > 1 ? rows_g : (d->stat_rows > 0 ? d->stat_rows : d->rows));
+  fs.eps = d->eps; fs.momentum = d->momentum;
+  if (d->dtype == FOCAL_F32)
+    FOCAL_LAUNCH((bn_act_fwd_kernel<float>), dim3(blocks, G), dim3(256), 0, st, z, nullptr, gamma, beta, resid, y, (float*)y_cast,
+                       rows_g, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop, fs);
+  else
+    FOCAL_LAUNCH((bn_act_fwd_kernel<bf16_t>), dim3(blocks, G), dim3(256), 0, st, z, nullptr, gamma, beta, resid, y, (bf16_t*)y_cast,
+                       rows_g, d->C, d->rows_per_sample, d->rng, d->stream, d->p_drop, fs);
   FOCAL_LAUNCH_CHECK();
   return FOCAL_OK;
 }

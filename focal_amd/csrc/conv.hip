@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include "gemm.hpp"
 #include "patch_stage.hpp"
+#include "conv_ring.hpp"
 
 #define CIN_TOK 64
 
@@ -593,7 +594,7 @@ extern "C" int focal_conv_fwd_bn(const focal_conv_desc* d, const void* x, const 
                                  const focal_bn_desc* bn, float* scratch, float* mean_rstd, float* running_mean, float* running_var,
                                  void* stream) {
   if (int rc = conv_check(d)) return rc;
-  FOCAL_CHECK_ARG(x && w_fwd && z && bn && scratch && mean_rstd, "conv_fwd_bn: null tensor");
+  FOCAL_CHECK_ARG(x && w_fwd && z && bn && scratch, "conv_fwd_bn: null tensor");
   FOCAL_CHECK_ARG(bn->rows == d->rows && bn->C == d->C_out && (running_mean == nullptr) == (running_var == nullptr),
                   "conv_fwd_bn: the BatchNorm descriptor does not describe the convolution's output");
   if (d->dtype != FOCAL_BF16) {
@@ -601,6 +602,25 @@ extern "C" int focal_conv_fwd_bn(const focal_conv_desc* d, const void* x, const 
     return FOCAL_EUNSUPPORTED;
   }
   const int pad = d->k / 2, K = d->k * d->C_in;
+  {
+    const int G = bn->groups > 1 ? bn->groups : 1;
+    if (conv_ring_fits(d, d->C_in, d->C_out, x, w_fwd, G) && (G == 1 || bn->stat_rows <= 0)) {
+      ConvRingParams rp;
+      memset(&rp, 0, sizeof(rp));
+      rp.x = (const bf16_t*)x; rp.w = (const bf16_t*)w_fwd; rp.bias = bias; rp.out = z; rp.rows = d->rows; rp.S = d->S;
+      rp.bn_sums = scratch; rp.bn_mean_rstd = mean_rstd; rp.bn_run_mean = running_mean; rp.bn_run_var = running_var;
+      rp.bn_rows = G > 1 ? bn->rows / G : (bn->stat_rows > 0 ? bn->stat_rows : bn->rows);
+      rp.bn_eps = bn->eps; rp.bn_momentum = bn->momentum; rp.bn_groups = G;
+      focal_note_kernel(d->k == 5 ? "conv_ring_kernel<5, stats>" : "conv_ring_kernel<3, stats>");
+      hipError_t e = conv_ring_launch<CR_STORE_STATS>(rp, d->k, G, (hipStream_t)stream);
+      if (e != hipSuccess) { focal_set_error("conv_fwd_bn (row ring): launch failed: %s", hipGetErrorString(e)); return FOCAL_EHIP; }
+      return FOCAL_OK;
+    }
+  }
+  if (mean_rstd == nullptr) {
+    focal_set_error("conv_fwd_bn: the sums-only form (mean_rstd = NULL) needs the row-ring kernel (focal_conv_fwd_bn_sums_supported)");
+    return FOCAL_EUNSUPPORTED;
+  }
   GemmSpec s{d->dtype, d->dtype, d->dtype, FOCAL_F32, false, false, PRO_CONV, PRO_NONE, EPI_STORE_STATS};
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -620,10 +640,28 @@ extern "C" int focal_conv_fwd_bn(const focal_conv_desc* d, const void* x, const 
   return focal_launch_gemm(s, p, (hipStream_t)stream);
 }
 
+// 1: focal_conv_fwd_bn takes mean_rstd = NULL for this convolution (the row-ring kernel runs it) and focal_bn_act_fwd_sums finishes the statistics
+extern "C" int focal_conv_fwd_bn_sums_supported(const focal_conv_desc* d, const focal_bn_desc* bn, const void* x, const void* w_fwd) {
+  if (d == nullptr || bn == nullptr || d->k % 2 != 1 || d->S <= 0 || d->rows % d->S != 0) return 0;
+  const char* sel = getenv("FOCAL_CONV_BN_SUMS");
+  if (sel != nullptr && sel[0] == '0') return 0;
+  const int G = bn->groups > 1 ? bn->groups : 1;
+  return bn->rows == d->rows && bn->C == 64 && conv_ring_fits(d, d->C_in, d->C_out, x, w_fwd, G) && (G == 1 || bn->stat_rows <= 0);
+}
+
 extern "C" int focal_conv_fwd(const focal_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* z, void* stream) {
   if (int rc = conv_check(d)) return rc;
   FOCAL_CHECK_ARG(x && w_fwd && z, "conv_fwd: null tensor");
   const int pad = d->k / 2, K = d->k * d->C_in;
+  if (conv_ring_fits(d, d->C_in, d->C_out, x, w_fwd, 1)) {
+    ConvRingParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.x = (const bf16_t*)x; rp.w = (const bf16_t*)w_fwd; rp.bias = bias; rp.out = z; rp.rows = d->rows; rp.S = d->S;
+    focal_note_kernel(d->k == 5 ? "conv_ring_kernel<5, store>" : "conv_ring_kernel<3, store>");
+    hipError_t e = conv_ring_launch<CR_STORE>(rp, d->k, 1, (hipStream_t)stream);
+    if (e != hipSuccess) { focal_set_error("conv_fwd (row ring): launch failed: %s", hipGetErrorString(e)); return FOCAL_EHIP; }
+    return FOCAL_OK;
+  }
   GemmSpec s{d->dtype, d->dtype, d->dtype, FOCAL_F32, false, false, PRO_CONV, PRO_NONE, EPI_STORE};
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -641,6 +679,15 @@ extern "C" int focal_conv_bwd_data(const focal_conv_desc* d, const void* dz, con
   if (int rc = conv_check(d)) return rc;
   FOCAL_CHECK_ARG(dz && w_bwd && g_in && g_out, "conv_bwd_data: null tensor");
   const int pad = d->k / 2, K = d->k * d->C_out;
+  if (conv_ring_fits(d, d->C_out, d->C_in, dz, w_bwd, 1) && ((uintptr_t)g_in % 16 == 0) && ((uintptr_t)g_out % 16 == 0)) {
+    ConvRingParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.x = (const bf16_t*)dz; rp.w = (const bf16_t*)w_bwd; rp.resid = g_in; rp.out = g_out; rp.rows = d->rows; rp.S = d->S;
+    focal_note_kernel(d->k == 5 ? "conv_ring_kernel<5, resid>" : "conv_ring_kernel<3, resid>");
+    hipError_t e = conv_ring_launch<CR_RESID>(rp, d->k, 1, (hipStream_t)stream);
+    if (e != hipSuccess) { focal_set_error("conv_bwd_data (row ring): launch failed: %s", hipGetErrorString(e)); return FOCAL_EHIP; }
+    return FOCAL_OK;
+  }
   GemmSpec s{d->dtype, d->dtype, d->dtype, FOCAL_F32, false, false, PRO_CONV, PRO_NONE, EPI_RESID};
   GemmParams p;
   memset(&p, 0, sizeof(p));

@@ -167,6 +167,14 @@ class DeepSenseModEncoder:
             # (per-view statistics from the epilogue: a 64- or 128-row tile must lie inside one view)
             if training and ct == torch.bfloat16 and not (bb.sync_bn and ops._sync_world() > 1) and (G == 1 or (rows // G) % 128 == 0):
                 # the statistics come out of the convolution's epilogue: z is not read back for them, one launch less per layer
+                if ops.conv_fwd_bn_sums_supported(d_cv, d_bn, ya, w_fwd):
+                    # ... and are finished by the BatchNorm launch itself: the convolution ends on fire-and-forget adds (round 6)
+                    z, sums = ops.conv_fwd_bn_sums(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"), d_bn)
+                    y_next, ya_next, mr = ops.bn_act_fwd_sums(d_bn, z, sums, *running(pl, 1 + li), ar.master(f"{pl}.batch_norm.weight"),
+                                                              ar.master(f"{pl}.batch_norm.bias"), y, ct)
+                    sv["layers"].append(dict(p=pl, z=z, mr=mr, d_bn=d_bn, xa=ya))
+                    y, ya = y_next, ya_next
+                    continue
                 z, mr = ops.conv_fwd_bn(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"), d_bn, *running(pl, 1 + li))
             else:
                 z = ops.conv_fwd(d_cv, ya, w_fwd, ar.master(f"{pl}.conv.bias"))

@@ -831,6 +831,32 @@ def conv_fwd(d, x, w_fwd, bias):
     return z
 
 
+def conv_fwd_bn_sums_supported(d, d_bn, x, w_fwd):
+    return bool(_lib.load().focal_conv_fwd_bn_sums_supported(C.byref(d), C.byref(d_bn), _p(x), _p(w_fwd)))
+
+
+def conv_fwd_bn_sums(d, x, w_fwd, bias, d_bn):
+    """focal_conv_fwd_bn in its sums-only form (round 6): -> (z, sums); bn_act_fwd_sums finishes the statistics."""
+    dev = x.device
+    z = torch.empty(d.rows, d.C_out, dtype=torch.float32, device=dev)
+    n = _bn_groups(d_bn) * (_lib.BN_STAT_SLOTS * 2 * d_bn.C + 1)
+    scratch = pool_zeros(n, dev)
+    if scratch is None:
+        scratch = torch.zeros(n, dtype=torch.float32, device=dev)
+    check(_lib.load().focal_conv_fwd_bn(C.byref(d), _p(x), _p(w_fwd), _p(bias), _p(z), C.byref(d_bn), _p(scratch), None, None, None, _stream()))
+    return z, scratch
+
+
+def bn_act_fwd_sums(d, z, sums, running_mean, running_var, gamma, beta, resid, cast_dtype=None):
+    """bn_act_fwd on a convolution's per-channel sums (conv_fwd_bn_sums): -> (y, y_cast, mean_rstd)."""
+    y = torch.empty_like(z)
+    ya = torch.empty(z.shape, dtype=cast_dtype, device=z.device) if cast_dtype not in (None, torch.float32) else None
+    mean_rstd = torch.empty(_bn_groups(d) * 2 * d.C, dtype=torch.float32, device=z.device)
+    check(_lib.load().focal_bn_act_fwd_sums(C.byref(d), _p(z), _p(sums), _p(mean_rstd), _p(running_mean), _p(running_var), _p(gamma), _p(beta),
+                                            _p(resid), _p(y), _p(ya), _stream()))
+    return y, (ya if ya is not None else y), mean_rstd
+
+
 def conv_fwd_bn(d, x, w_fwd, bias, d_bn, running_mean, running_var):
     """conv_fwd + the training-mode statistics of the BatchNorm behind it in one launch (focal_conv_fwd_bn): -> (z, mean_rstd).  One rank /
     no sync_bn (the global-batch form all-reduces the sums between two kernels: conv_fwd + bn_stats)."""

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* 7: launch trace (focal_trace_*), focal_adamw_multi_advance takes the step-state length; 2: BatchNorm scratch of 2C + 1 floats; 3: fused MLP, warps, Mixup; 4: row-sharded loss head, weight-gradient launch queries */
-#define FOCAL_ABI_VERSION 12
+#define FOCAL_ABI_VERSION 13
 
 enum { FOCAL_OK = 0, FOCAL_EINVAL = -1, FOCAL_EUNSUPPORTED = -2, FOCAL_EWORKSPACE = -3, FOCAL_EHIP = -4 };
 enum { FOCAL_F32 = 0, FOCAL_BF16 = 1 };
@@ -463,6 +463,14 @@ int focal_bn_stats(const focal_bn_desc* d, const float* z, float* scratch, float
 #define FOCAL_BN_STAT_SLOTS 16
 int focal_conv_fwd_bn(const focal_conv_desc* d, const void* x, const void* w_fwd, const float* bias, float* z,
                       const focal_bn_desc* bn, float* scratch, float* mean_rstd, float* running_mean, float* running_var, void* stream);
+/* Round 6: the sums-only form.  Where focal_conv_fwd_bn_sums_supported(...) != 0 (64 -> 64 channels, k = 3 / 5, bf16, whole 64-row tiles per
+ * statistics group: csrc/conv_ring.hpp), focal_conv_fwd_bn may be called with mean_rstd = NULL (running buffers ignored): the launch then only
+ * adds its per-channel sums into `scratch` and ends, and focal_bn_act_fwd_sums -- focal_bn_act_fwd reading `scratch` instead of mean_rstd --
+ * finishes the statistics in its prologue (mean_rstd [groups x 2C] out for the backward pass, running buffers updated with d->momentum).  Same
+ * arithmetic as the one-launch form; the convolution loses three dependent memory-side round trips (~9 us per launch). */
+int focal_conv_fwd_bn_sums_supported(const focal_conv_desc* d, const focal_bn_desc* bn, const void* x, const void* w_fwd);
+int focal_bn_act_fwd_sums(const focal_bn_desc* d, const float* z, const float* sums, float* mean_rstd, float* running_mean, float* running_var,
+                          const float* gamma, const float* beta, const float* resid, float* y, void* y_cast, void* stream);
 /* The running-buffer updates of TWO passes (the two augmented views of a FOCAL step), applied after both have run: each pass records
  * its batch statistics instead of updating the buffers (focal_bn_stats with d->momentum = 1 and a per-pass sink in place of the running
  * buffers), this applies r <- (1 - m) ((1 - m) r + m s1) + m s2 to n buffers of C values in one launch -- what the reference's two

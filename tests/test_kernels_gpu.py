@@ -888,9 +888,80 @@ def test_conv_fwd_batchnorm_epilogue_with_statistic_groups(ops):
         z, mr = ops.conv_fwd_bn(d1, x[h * rows:(h + 1) * rows].contiguous(), w_fwd, b, bn1, rm, rv)
         assert torch.equal(z2[h * rows:(h + 1) * rows], z)
         assert rel_err(mr2[h * 2 * C:(h + 1) * 2 * C], mr) < 1e-5 and rel_err(sm[h], rm) < 1e-5 and rel_err(sv_[h], rv) < 1e-5
-    bad = ops.bn_desc(ops.code(ct), 2 * 1600, C, I * S, 0.0, None, 0, momentum=1.0, groups=2)   # 1600 rows per group: not whole tiles
+    bad = ops.bn_desc(ops.code(ct), 2 * 1620, C, I * S, 0.0, None, 0, momentum=1.0, groups=2)   # 1620 rows per group: not whole tiles
     with pytest.raises(Exception, match="multiple of"):
-        ops.conv_fwd_bn(ops.conv_desc(ops.code(ct), 3200, S, C, C, k), x[:3200].contiguous(), w_fwd, b, bad, sm, sv_)
+        ops.conv_fwd_bn(ops.conv_desc(ops.code(ct), 3240, S, C, C, k), x[:3240].contiguous(), w_fwd, b, bad, sm, sv_)
+
+
+@pytest.mark.parametrize("B,I,S,k,groups", [(16, 10, 20, 5, 1), (32, 10, 20, 3, 2), (64, 10, 9, 5, 1), (512, 10, 20, 5, 2), (512, 10, 20, 3, 1), (4, 4, 4, 3, 1)])
+def test_conv1xk_row_ring_kernel(ops, B, I, S, k, groups, monkeypatch):
+    """conv_ring_kernel (64 -> 64 channels, bf16, whole 64-row tiles: the DeepSense step's inter-layer convolutions and their data gradients)
+    against the definition in fp64 on the same bf16 operands, against the sliding-window GEMM it replaces (FOCAL_CONV_RING=0), and its BatchNorm
+    statistics against the tensor it wrote; one tile per workgroup, runs of 2 and 4 tiles, intervals shorter than a fragment, two statistic groups."""
+    C, ct = 64, torch.bfloat16
+    rows = B * I * S
+    assert rows % (64 * groups) == 0
+    x = rnd(rows, C, seed=374, dtype=ct)
+    w, b = rnd(C, C, 1, k, scale=(C * k) ** -0.5, seed=375), rnd(C, seed=376)
+    d = ops.conv_desc(ops.code(ct), rows, S, C, C, k)
+    w_fwd, w_bwd = ops.permute_pack(w, C, C, k, ct), ops.conv_pack_bwd(d, w, ct)
+    dz, g_in = rnd(rows, C, seed=377, dtype=ct), rnd(rows, C, seed=378)
+    d_bn = ops.bn_desc(ops.code(ct), rows, C, I * S, 0.0, None, 0, momentum=1.0, groups=groups)
+
+    from focal_amd import _lib
+    lib = _lib.load()
+
+    def run():
+        g = g_in.clone()
+        torch.cuda.synchronize()
+        _lib.check(lib.focal_trace_begin(64, _lib.TRACE_DISPATCH))
+        try:
+            z = ops.conv_fwd(d, x, w_fwd, b)
+            rm, rv = torch.zeros(groups, C, device=DEV), torch.zeros(groups, C, device=DEV)
+            z2, mr = ops.conv_fwd_bn(d, x, w_fwd, b, d_bn, rm, rv)
+            ops.conv_bwd_data(d, dz, w_bwd, g, g)
+            torch.cuda.synchronize()
+        finally:
+            lib.focal_trace_end()
+        n = lib.focal_trace_count()
+        recs = (_lib.TraceRecord * max(n, 1))()
+        _lib.check(lib.focal_trace_read(0, n, recs))
+        return z, z2, mr, rm, rv, g, [recs[i].kernel.decode() for i in range(n)]
+
+    monkeypatch.delenv("FOCAL_CONV_RING", raising=False)
+    z0, z20, mr0, rm0, rv0, g0, names0 = run()
+    assert not any("conv_ring_kernel" in n for n in names0), names0   # (not the default: csrc/conv_ring.hpp)
+    monkeypatch.setenv("FOCAL_CONV_RING", "1")
+    z, z2, mr, rm, rv, g, names = run()
+    assert sum("conv_ring_kernel" in n for n in names) == 3, names
+    # the definition, in fp64 on the bf16-rounded operands
+    wq = w.bfloat16().double()
+    xi = x.double().view(B * I, S, C).permute(0, 2, 1).unsqueeze(2).requires_grad_(True)
+    ref = F.conv2d(xi, wq, b.double(), padding=(0, k // 2)).squeeze(2).permute(0, 2, 1).reshape(rows, C)
+    assert rel_err(z, ref.float()) < 2e-6 and torch.equal(z2, z)
+    assert rel_err(z, z0) < 2e-6 and rel_err(g, g0) < 2e-6
+    ref.backward(dz.double())
+    dx_ref = xi.grad.squeeze(2).permute(0, 2, 1).reshape(rows, C)
+    assert rel_err(g - g_in, dx_ref.float()) < 2e-5
+    rg = rows // groups
+    for h in range(groups):
+        zh = z[h * rg:(h + 1) * rg].double()
+        mean, var = zh.mean(0), zh.var(0, unbiased=False)
+        assert rel_err(mr[h * 2 * C:h * 2 * C + C], mean.float()) < 1e-4 and rel_err(mr[h * 2 * C + C:(h + 1) * 2 * C], (var + d_bn.eps).rsqrt().float()) < 1e-4
+        assert rel_err(rm[h], mean.float()) < 1e-4 and rel_err(rv[h], (var * rg / (rg - 1)).float()) < 1e-4
+    assert rel_err(mr, mr0) < 1e-5 and rel_err(rm, rm0) < 1e-5 and rel_err(rv, rv0) < 1e-5
+    # the sums-only form + the BatchNorm launch that finishes the statistics == the one-launch form followed by focal_bn_act_fwd
+    assert ops.conv_fwd_bn_sums_supported(d, d_bn, x, w_fwd)
+    gam, bet, res = 1 + 0.1 * rnd(C, seed=379), 0.1 * rnd(C, seed=380), rnd(rows, C, seed=381)
+    y0, ya0 = ops.bn_act_fwd(d_bn, z2, mr, gam, bet, res, ct)
+    zs, sums = ops.conv_fwd_bn_sums(d, x, w_fwd, b, d_bn)
+    rm1, rv1 = torch.zeros(groups, C, device=DEV), torch.zeros(groups, C, device=DEV)
+    y1, ya1, mr1 = ops.bn_act_fwd_sums(d_bn, zs, sums, rm1, rv1, gam, bet, res, ct)
+    assert torch.equal(zs, z2) and rel_err(mr1, mr) < 1e-6 and rel_err(rm1, rm) < 1e-6 and rel_err(rv1, rv) < 1e-6
+    # (the slot sums of two launches differ in their last bits -- atomics in another order --, so a few bf16 copies round the other way)
+    assert rel_err(y1, y0) < 1e-5 and (ya1 != ya0).float().mean().item() < 1e-3 and rel_err(ya1.float(), ya0.float()) < 1e-2
+    monkeypatch.setenv("FOCAL_CONV_BN_SUMS", "0")
+    assert not ops.conv_fwd_bn_sums_supported(d, d_bn, x, w_fwd)
 
 
 @pytest.mark.parametrize("ct", [torch.float32, torch.bfloat16])

@@ -258,8 +258,9 @@ def test_host_side_launch_plans_of_the_abi():
     assert wg == sum(t * s for t, s in zip(tiles, (6, 11, 3, 6)))
     assert lib.focal_linear_bwd_weight_group_f32_workgroups(bf, 4, probs, 100000) == sum(t * 20 for t in tiles)   # 5 120 / 256 = 20 slices at most
     assert lib.focal_linear_bwd_weight_group_f32_workgroups(bf, 9, probs, 0) == 0 and b"1 .. 8 problems" in lib.focal_last_error()
-    # BatchNorm statistic groups: the descriptor grew by one field (ABI 10), the GRU descriptor by one (ABI 11); ABI 12 added focal_view_draw_shared
-    assert C.sizeof(_lib.BNDesc) == 56 and C.sizeof(_lib.GRUDesc) == 16 and lib.focal_abi_version() == 12
+    # BatchNorm statistic groups: the descriptor grew by one field (ABI 10), the GRU descriptor by one (ABI 11); ABI 12 added focal_view_draw_shared,
+    # ABI 13 the sums-only convolution statistics (focal_bn_act_fwd_sums) and 20 problems per grouped weight-gradient launch
+    assert C.sizeof(_lib.BNDesc) == 56 and C.sizeof(_lib.GRUDesc) == 16 and lib.focal_abi_version() == 13
     ld = _lib.LossDesc(2, 2048, 256, 4, 0.07, 1.0, 1.0, 1.0, 3.0, 5.0, 0)  # config 4's global batch: b = 512 subsequences
     need = lib.focal_loss_head_workspace(C.byref(ld))
     assert need > 0
