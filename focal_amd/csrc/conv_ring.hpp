@@ -143,10 +143,15 @@ __global__ __launch_bounds__(320, 3) void conv_ring_kernel(const ConvRingParams 
           }
         }
       };
+      // (k = 5 with a residual or statistics epilogue: the second register set spills at the 168 registers of two workgroups per CU -- 17 / 21
+      //  spilled registers made those launches 34.7 / 29.2 us against 20.5 / 27.1 un-pipelined; they keep one set)
+      constexpr bool PIPE = !(KT == 5 && EPI != CR_STORE);
       request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
       pipe_static_for<0, KT>([&](auto tc) {
-        constexpr int t = decltype(tc)::value, cur = t & 1;
-        if constexpr (t + 1 < KT) {
+        constexpr int t = decltype(tc)::value, cur = PIPE ? (t & 1) : 0;
+        if constexpr (!PIPE) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0][0]), "+v"(xa[0][0][1]), "+v"(xa[0][1][0]), "+v"(xa[0][1][1]));
+        } else if constexpr (t + 1 < KT) {
           request(std::integral_constant<int, t + 1>{}, std::integral_constant<int, (t + 1) & 1>{});
           asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xa[cur][0][0]), "+v"(xa[cur][0][1]), "+v"(xa[cur][1][0]), "+v"(xa[cur][1][1]));
         } else {
@@ -162,6 +167,11 @@ __global__ __launch_bounds__(320, 3) void conv_ring_kernel(const ConvRingParams 
 #else
             for (int j = 0; j < 2; ++j) acc[i][j] = mma16(wb[j][2 * t + h], xa[cur][h][i], acc[i][j]);
 #endif
+        if constexpr (!PIPE && t + 1 < KT) {
+          // the MFMAs above have read set 0 when the next tap's reads overwrite it: the fragment registers are operands of this statement
+          asm volatile("" : "+v"(xa[0][0][0]), "+v"(xa[0][0][1]), "+v"(xa[0][1][0]), "+v"(xa[0][1][1]));
+          request(std::integral_constant<int, t + 1>{}, std::integral_constant<int, 0>{});
+        }
       });
 #else
       acc[0][0][0] = (float)wb[0][0][0] + (float)wb[1][KS - 1][7] + (float)wb[0][KS / 2][3] + (float)s_in[0] + (float)s_in[1];
@@ -255,14 +265,14 @@ __global__ __launch_bounds__(320, 3) void conv_ring_kernel(const ConvRingParams 
 }
 
 // Does the row-ring kernel take this convolution?  64 -> 64 channels, k = 3 / 5, bf16 operands, whole 64-row tiles (per statistics group),
-// intervals of at least k tokens, 16-byte aligned operands -- and FOCAL_CONV_RING=1: NOT the default.  Alone on the chip the kernel is
-// 8 - 10 % faster than the sliding-window GEMM per launch (k = 5: 18.0 vs ~20 us forward, 20.5 vs ~24 us data gradient; tools/prof_conv.sh),
-// inside the replayed DeepSense step -- two modality encoders side by side -- the step is 2 - 4 % SLOWER with it (130.3 - 131.1 k vs 133.3 -
-// 136.0 k windows/s, three interleaved repetitions): 400 persistent workgroups that hold 2 x 31 KB of LDS and 168 registers per CU for the
-// whole launch leave the other encoder's kernels less room than 1 600 short-lived GEMM workgroups do.  profiles/r6_conv_ring.txt.
+// intervals of at least k tokens, 16-byte aligned operands.  FOCAL_CONV_RING=0 keeps the sliding-window GEMM (A/B runs, the tests' second path).
+// Alone on the chip the kernel is 5 - 25 % faster than that GEMM per launch (k = 5 / 3 forward 16.3 / 12.1 vs ~20 / ~14 us, data gradient
+// 21.2 / 18.9 vs ~24 / ~21; tools/prof_conv.sh); inside the replayed DeepSense step +1.4 ... +2.3 %, +2.0 ... +2.9 % with the sums-only
+// statistics (tools/ab_conv_ring.sh, three interleaved repetitions; profiles/r6_conv_ring.txt -- which also records the build whose second
+// fragment set spilled: that one LOST 2 - 4 % in the step).
 static inline bool conv_ring_fits(const focal_conv_desc* d, int c_in, int c_out, const void* x, const void* w, int groups) {
   const char* sel = getenv("FOCAL_CONV_RING");  // (read per call: the tests switch paths inside one process)
-  if (sel == nullptr || sel[0] != '1' || d->dtype != FOCAL_BF16 || c_in != 64 || c_out != 64 || (d->k != 3 && d->k != 5)) return false;
+  if ((sel != nullptr && sel[0] == '0') || d->dtype != FOCAL_BF16 || c_in != 64 || c_out != 64 || (d->k != 3 && d->k != 5)) return false;
   if (groups < 1 || d->rows % (64 * groups) != 0 || d->rows >= (1 << 20) || d->S < d->k || d->S >= (1 << 12)) return false;
   return ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0);
 }

@@ -928,12 +928,12 @@ def test_conv1xk_row_ring_kernel(ops, B, I, S, k, groups, monkeypatch):
         _lib.check(lib.focal_trace_read(0, n, recs))
         return z, z2, mr, rm, rv, g, [recs[i].kernel.decode() for i in range(n)]
 
-    monkeypatch.delenv("FOCAL_CONV_RING", raising=False)
+    monkeypatch.setenv("FOCAL_CONV_RING", "0")
     z0, z20, mr0, rm0, rv0, g0, names0 = run()
-    assert not any("conv_ring_kernel" in n for n in names0), names0   # (not the default: csrc/conv_ring.hpp)
-    monkeypatch.setenv("FOCAL_CONV_RING", "1")
+    assert not any("conv_ring_kernel" in n for n in names0), names0
+    monkeypatch.delenv("FOCAL_CONV_RING")
     z, z2, mr, rm, rv, g, names = run()
-    assert sum("conv_ring_kernel" in n for n in names) == 3, names
+    assert sum("conv_ring_kernel" in n for n in names) == 3, names   # (the default: csrc/conv_ring.hpp)
     # the definition, in fp64 on the bf16-rounded operands
     wq = w.bfloat16().double()
     xi = x.double().view(B * I, S, C).permute(0, 2, 1).unsqueeze(2).requires_grad_(True)

@@ -16,6 +16,6 @@ for r in list(csv.DictReader(open(f)))[:8]:
         print(f'{r["Name"][:100]:100s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"]) / 1e3:7.1f} us  min {float(r["MinNs"]) / 1e3:7.1f}')
 PY
 }
-run ring FOCAL_CONV_RING=1
-for lib in "$@"; do run $(basename $lib .so) FOCAL_CONV_RING=1 FOCAL_HIP_LIB=$root/$lib; done
+run ring X=1
+for lib in "$@"; do run $(basename $lib .so) FOCAL_HIP_LIB=$root/$lib; done
 run gemm_path FOCAL_CONV_RING=0
