@@ -284,6 +284,8 @@ static inline hipError_t conv_ring_launch(ConvRingParams& p, int k, int groups, 
   p.tiles_per_group = tiles / groups;
   const int slots = 2 * focal_cu_count();              // two workgroups per CU
   const int per_group = slots / groups > 0 ? slots / groups : 1;
+  // (an even cut over ALL slots -- 512 workgroups of 3 or 4 tiles instead of 400 of 4 -- was slower alone (statistics form 28.6 vs 26.3 us) and
+  //  lost the step's gain: more weight-fragment loads, more slot adds, less room for the other encoder; tools/ab_conv_ring.sh)
   p.run = (p.tiles_per_group + per_group - 1) / per_group;
   p.wgs_per_group = (p.tiles_per_group + p.run - 1) / p.run;
   p.s_magic = 0xFFFFFFFFu / (uint32_t)p.S + 1u;
