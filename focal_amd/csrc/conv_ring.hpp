@@ -282,9 +282,12 @@ static inline hipError_t conv_ring_launch(ConvRingParams& p, int k, int groups, 
   constexpr int LDS_BYTES = 3 * 80 * 128 + 128;  // the ring + the zero row
   const int tiles = p.rows / 64;
   p.tiles_per_group = tiles / groups;
-  const int slots = 2 * focal_cu_count();              // two workgroups per CU
+  static const int lab_slots = getenv("FOCAL_LAB_CONV_SLOTS") ? atoi(getenv("FOCAL_LAB_CONV_SLOTS")) : 0;
+  // one workgroup per CU (229 workgroups of 7 tiles at the step's shape), although two fit: inside the step -- the other modality's encoder runs
+  // beside this one -- 256 slots gave 136.9 / 138.7 / 139.3 k windows/s against 136.7 / 135.9 / 137.2 k for 512 (tools/ab_conv_slots.sh)
+  const int slots = lab_slots > 0 ? lab_slots : focal_cu_count();
   const int per_group = slots / groups > 0 ? slots / groups : 1;
-  // (an even cut over ALL slots -- 512 workgroups of 3 or 4 tiles instead of 400 of 4 -- was slower alone (statistics form 28.6 vs 26.3 us) and
+  // (an even cut over 512 slots -- 512 workgroups of 3 or 4 tiles instead of 400 of 4 -- was slower alone (statistics form 28.6 vs 26.3 us) and
   //  lost the step's gain: more weight-fragment loads, more slot adds, less room for the other encoder; tools/ab_conv_ring.sh)
   p.run = (p.tiles_per_group + per_group - 1) / per_group;
   p.wgs_per_group = (p.tiles_per_group + p.run - 1) / p.run;
