@@ -705,15 +705,19 @@ def _clock_files(device):
 
 def gpu_clocks(device):
     """sclk (MHz), mclk level, socket power (W) and power cap of this rank's GPU from sysfs (a few tens of microseconds: the paths are
-    resolved once).  Read right before the timed region, once in its middle (after the middle step's loss.item(): the only sample that
-    sees the GPU under load -- it clocks down within a millisecond of its last kernel) and right after it: tells a power- or clock-limited
-    box from a fast one in the driver's record.  None where sysfs is not readable."""
+    resolved once).  Read right before the timed region and right after it (FOCAL_BENCH_MID_CLOCKS=1: also once in its middle, after the
+    middle step's loss.item() -- the only sample that sees the GPU under load): tells a power- or clock-limited box from a fast one in the
+    driver's record.  None where sysfs is not readable (the failed lookup is remembered: it is not repeated)."""
+    key = device.index or 0
+    if _CLOCK_FILES.get(key) is False:
+        return None
     try:
         f = _clock_files(device)
         rd = lambda path, div: (int(open(path).read().strip()) // div) if path else None
         mclk = [ln.split(":")[1].strip().rstrip("*").strip() for ln in open(f["mclk"]) if "*" in ln] if f["mclk"] else []
         return {"sclk_mhz": rd(f["sclk"], 1000000), "mclk": mclk[0] if mclk else None, "power_w": rd(f["power"], 1000000), "power_cap_w": rd(f["cap"], 1000000)}
     except Exception:  # noqa: BLE001  (a diagnostic must not cost the line)
+        _CLOCK_FILES[key] = False
         return None
 
 
@@ -799,8 +803,11 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
             else:
                 step.loss.item()  # the reference syncs on loss.item() every step (pretrain.py:74)
             stamps.append(time.perf_counter())
-            if k_step == steps // 2 and os.environ.get("FOCAL_BENCH_NO_CLOCKS") != "1":
-                mid_clocks = gpu_clocks(device)  # one sysfs sample under load (~50 us of host time inside the timed region, once)
+            if k_step == steps // 2 and os.environ.get("FOCAL_BENCH_MID_CLOCKS") == "1":
+                # opt-in: one sysfs sample under load.  It was the default until the round-6 evidence run showed what it costs where sysfs does
+                # NOT answer: the failed lookup (device properties + glob, retried) stretched that one step by 0.5-0.6 ms -- 0.6 % of a 20-step
+                # timed region (step_series.timed_ms of profiles/r6_z_bench_driver_line.json: 5.53 ms at index 11, 4.9-5.1 elsewhere)
+                mid_clocks = gpu_clocks(device)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

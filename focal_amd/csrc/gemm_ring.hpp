@@ -366,6 +366,7 @@ static inline bool focal_ring_disabled() {
 static inline int focal_cu_count() {
   // (initialised once, thread-safe: C++11 magic static; `static const bool off` above is one too)
   static const int n = [] {
+    if (const char* lab = getenv("FOCAL_LAB_CUS")) { if (atoi(lab) > 0) return atoi(lab); }  // lab: size the persistent grids for fewer CUs
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
     return 256;
