@@ -754,11 +754,14 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
                 inner()
         # Every step ends with loss.item(), so host stamps after it are the steps' durations: the JSON line carries the whole series
         # (`step_series`), warm-up included.  After the `warmup` requested steps the UNTIMED phase goes on until three consecutive steps
-        # agree to 1 % (cap 0.5 s): the first replays of a cold process run 3-10 % slow while clocks / power ramp (profiles/
-        # r6_warmup_transient.txt), and a 0.1 s timed region must not start inside that ramp.  The timed region below is untouched:
-        # exactly `steps` full steps.  `warmup_effective` = the untimed steps actually run.
+        # agree to 1 % AND the untimed phase as a whole has lasted 0.2 s (cap: 0.5 s of settling): the first replays of a cold process run
+        # 3-10 % slow while clocks / power ramp (profiles/r6_warmup_transient.txt), the next ~30 another ~1 % (same box, --steps 20: warm-up 5
+        # -> 51 137 / 51 340, warm-up 30 -> 51 668 / 51 820, warm-up 60 -> 51 691; step-to-step noise is +-1 %, so three agreeing steps alone do
+        # not see that tail), and a 0.1 s timed region must not start inside either.  The timed region below is untouched: exactly `steps` full
+        # steps.  `warmup_effective` = the untimed steps actually run.  FOCAL_BENCH_MIN_UNTIMED_S overrides the 0.2 s.
         series = step.series = {"warmup_ms": [], "settle_ms": [], "timed_ms": []}
-        tp = time.perf_counter()
+        min_untimed = float(os.environ.get("FOCAL_BENCH_MIN_UNTIMED_S", "0.2"))
+        tp = t_untimed = time.perf_counter()
         for _ in range(warmup):
             run()
             step.loss.item()
@@ -768,7 +771,8 @@ def timed_steps(a, step, world, rank, device, steps, warmup):
         t_settle = tp
         recent = series["warmup_ms"][-3:]
         while os.environ.get("FOCAL_BENCH_NO_SETTLE") != "1" and warmup > 0:
-            more = not (len(recent) == 3 and max(recent) <= 1.01 * min(recent)) and (tp - t_settle) < 0.5
+            agree = len(recent) == 3 and max(recent) <= 1.01 * min(recent)
+            more = (not agree or (tp - t_untimed) < min_untimed) and (tp - t_settle) < 0.5
             if world > 1:  # the ranks must leave this loop together (the step holds collectives)
                 f = torch.tensor([1 if more else 0], device=device, dtype=torch.int32)
                 dist.all_reduce(f, op=dist.ReduceOp.MAX)
