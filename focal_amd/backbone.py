@@ -98,7 +98,7 @@ class HipBackbone(nn.Module):
     def _anchor(self, device):
         # torch.autograd only schedules a node whose inputs need grad; parameter gradients are written straight into
         # the arena by the HIP kernels, so a dummy differentiable input keeps each encoder node alive.
-        return torch.zeros(1, device=device, requires_grad=True)
+        return runtime.anchor(device)  # (one cached leaf per device: a fresh torch.zeros per stage call was a fill launch in the step)
 
 
 def _join_after_backward(device):

@@ -25,7 +25,7 @@ import os
 
 import torch
 
-from . import distributed
+from . import distributed, runtime
 
 
 class CaptureAborted(RuntimeError):
@@ -93,7 +93,13 @@ class StepSegments:
         if split:
             bb.split_backward = True
         try:
-            loss.backward()
+            # the root gradient is a cached scalar 1 (autograd's ones_like(loss) is a fill launch per step; the loss head recognises this
+            # tensor and skips its x1 multiply: runtime.unit_grad)
+            unit = runtime.unit_grad(loss.device) if (loss.dim() == 0 and loss.dtype == torch.float32 and loss.is_cuda) else None
+            if unit is not None:
+                loss.backward(gradient=unit)
+            else:
+                loss.backward()
         finally:
             if split:
                 bb.split_backward = False

@@ -106,3 +106,49 @@ def join_all(device):
     for (dev, _), st in _SIDE.items():
         if dev == torch.device(device) and st != cur:
             cur.wait_stream(st)
+
+
+# ---------------------------------------------------------------------------------------------- constants the step would otherwise re-create
+# Round 6: the replayed step carried nine one-workgroup torch fill / multiply launches (profiles' timeline: `FillFunctor<float>` x 8,
+# one BinaryFunctor), five of them on a serial stretch of the step -- each ~4 us of kernel + a launch gap.  Three kinds:
+#   * the dummy differentiable input that keeps an encoder's autograd node alive (backbone._anchor): one per run_stage call -> one cached leaf
+#     per device (its gradient is always None: nothing accumulates into it);
+#   * autograd's ones_like(loss) root gradient and the loss head's `flat *= grad_output`: the training step passes THIS cached scalar as the
+#     root gradient, and the loss head skips the multiply when it is handed exactly this tensor (x1);
+#   * the zero-initialised output of the split-K mod_in product: a slice of the step's zero pool (ops.zeros).
+_ANCHOR, _UNIT = {}, {}
+
+
+def _no_constants():
+    return os.environ.get("FOCAL_NO_STEP_CONSTANTS") == "1"  # same-box A/B (tools/ab_env.sh): a fresh anchor per stage call, autograd's own ones_like
+
+
+def anchor(device):
+    key = torch.device(device)
+    if _no_constants():
+        return torch.zeros(1, device=device, requires_grad=True)
+    t = _ANCHOR.get(key)
+    if t is None:
+        if key.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return torch.zeros(1, device=device, requires_grad=True)  # (never cache something created inside a capture)
+        t = _ANCHOR[key] = torch.zeros(1, device=device, requires_grad=True)
+    return t
+
+
+def unit_grad(device):
+    """The scalar 1.0 of this device, created once: the root gradient of a training step's loss.backward()."""
+    key = torch.device(device)
+    if _no_constants():
+        return None
+    t = _UNIT.get(key)
+    if t is None:
+        if key.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return None
+        t = _UNIT[key] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+def is_unit_grad(g):
+    t = _UNIT.get(g.device)
+    return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0
+
