@@ -104,6 +104,13 @@ class StepSegments:
             if split:
                 bb.split_backward = False
 
+    def _keep_loss(self, loss):
+        """self.loss = the step's loss.  A reference, not a copy: under replay the loss head writes the same graph-pool address every step
+        (holding the tensor keeps its block out of the pool's hands), and the copy was a one-workgroup launch on the serial stretch between
+        the end of backward and AdamW."""
+        t = loss.detach()
+        self.loss = t if (t.dim() == 0 and t.dtype == torch.float32) else t.float().reshape(())
+
     def seg_rest(self):
         """The parked part of a split backward pass (the encoder stages in front of the last one)."""
         self.model.backbone.backward_continue()
@@ -133,7 +140,7 @@ class StepSegments:
             self.feats = self.dist.unpack_gathered(self.gathered, self.keys, 2)
         loss = self.loss_fn(*self.feats)
         self._backward(loss)
-        self.loss.copy_(loss.detach())
+        self._keep_loss(loss)
         self.feats = None
 
     def seg_b1(self):
@@ -146,7 +153,7 @@ class StepSegments:
     def seg_b2(self):
         loss = self.loss_fn.finish()
         self._backward(loss)
-        self.loss.copy_(loss.detach())
+        self._keep_loss(loss)
         self.feats = None
 
     def reduce(self):
