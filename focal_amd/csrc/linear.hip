@@ -179,6 +179,10 @@ extern "C" int focal_linear_bwd_data_ln(const focal_linear_desc* d, const void* 
              focal_ring_fits<float, EPI_LN_BWD, true, 64, 128, 4, false, 4, 1, 2, false, false>(p)) {  // (stage 1; lab 0.88 at 73 728 rows, 0.94-0.97 at 36 864)
     focal_note_kernel("focal_gemm_ring_kernel<f32, epi=%d (LayerNorm backward), trB=1, 64x128, 4x1 waves, ring 4>", EPI_LN_BWD);
     e = focal_launch_gemm_ring<float, EPI_LN_BWD, true, 64, 128, 4, false, 4, 1, 2, false, false>(p, (hipStream_t)stream);
+  } else if (d->K == 256 && d->M >= 2048 && !focal_ring_disabled() && getenv("FOCAL_LAB_LN_BWD_RING256") != nullptr &&
+             focal_ring_fits<float, EPI_LN_BWD, true, 64, 256, 2, false, 4, 1, 2, false, false>(p)) {  // (stage 2: lab, round 6)
+    focal_note_kernel("focal_gemm_ring_kernel<f32, epi=%d (LayerNorm backward), trB=1, 64x256, 4x1 waves, ring 2>", EPI_LN_BWD);
+    e = focal_launch_gemm_ring<float, EPI_LN_BWD, true, 64, 256, 2, false, 4, 1, 2, false, false>(p, (hipStream_t)stream);
   } else {
     focal_note_kernel("focal_gemm_pipe_kernel<f32, epi=%d (LayerNorm backward), trB=1, %dx%d, 4x%d waves>", EPI_LN_BWD, d->K == 256 ? 64 : 128,
                       d->K, d->K == 256 ? 2 : 1);
