@@ -73,10 +73,13 @@ constexpr int NLOAD = 2, R = 2;
 #ifndef WIDE_NW256
 #define WIDE_NW256 6
 #endif
-template <int C> struct WideWaves { static constexpr int NW = C == 128 ? WIDE_NW128 : WIDE_NW256, BM = 16 * NW; };
+// NWX != 0: that many consumer waves instead (the forward kernel at 256 channels runs 4 -- 64-row tiles, one consumer per SIMD -- where the 64-row
+// tiles still fit one round of the chip: a workgroup is ONE tile's chain of 12 ring steps, its time is the slowest SIMD's element math, and
+// with 6 consumers two SIMDs carry two of them; focal_mlp_wide_fwd's launcher)
+template <int C, int NWX = 0> struct WideWaves { static constexpr int NW = NWX != 0 ? NWX : (C == 128 ? WIDE_NW128 : WIDE_NW256), BM = 16 * NW; };
 
-template <int C> struct WideLayout {
-  static constexpr int NW = WideWaves<C>::NW, BM = WideWaves<C>::BM;
+template <int C, int NWX = 0> struct WideLayout {
+  static constexpr int NW = WideWaves<C, NWX>::NW, BM = WideWaves<C, NWX>::BM;
   static constexpr int H = 4 * C, KK = C / 32, NIMG1 = C / 64, CT = C / 16, NSTEP = H / 64;
   static constexpr int W1_BYTES = NIMG1 * 8192, W2_BYTES = C * 128, SLOT_BYTES = W1_BYTES + W2_BYTES;
   static constexpr int NP1 = NIMG1 * 8, NP2 = C / 8, L1 = NP1 / NLOAD, L2 = NP2 / NLOAD, LSTEP = L1 + L2;
@@ -107,9 +110,9 @@ __device__ __forceinline__ f32x4 gload4(const float* p) {
 // registers and stores it, then norm2 on the row -- with the summation tree and roundings of the launch it replaces (focal_linear_resid_ln_fwd's
 // epilogue at 128 channels, ln_fwd_kernel at 256) -- stores a2 / statistics and keeps a2 as fc1's operand.  12 proj launches and 8 norm2
 // launches fewer per step; x_mid and a2 are not re-read.
-template <int C, int EPI2, bool DROP, bool FULL, bool PROJ>
-__global__ __launch_bounds__(64 * (WideWaves<C>::NW + NLOAD)) void mlp_wide_fwd_kernel(const WideFwdParams p) {
-  using L = WideLayout<C>;
+template <int C, int EPI2, bool DROP, bool FULL, bool PROJ, int NWX = 0>
+__global__ __launch_bounds__(64 * (WideWaves<C, NWX>::NW + NLOAD)) void mlp_wide_fwd_kernel(const WideFwdParams p) {
+  using L = WideLayout<C, NWX>;
   constexpr int NW = L::NW, BM = L::BM;
   constexpr int H = L::H, KK = L::KK, CT = L::CT, NSTEP = L::NSTEP, SLOT_BYTES = L::SLOT_BYTES, W1_BYTES = L::W1_BYTES;
   constexpr int NP = PROJ ? C / 64 : 0, TSTEP = NSTEP + NP;   // ring steps per tile
@@ -823,10 +826,10 @@ extern "C" int focal_mlp_wide_supported(int dtype, int C_, int hidden) {
   return atoi(on) == C_;
 }
 
-template <int C, int EPI2, bool DROP, bool FULL, bool PROJ>
+template <int C, int EPI2, bool DROP, bool FULL, bool PROJ, int NWX = 0>
 static int launch_wide_fwd_t(const WideFwdParams& p, hipStream_t st) {
-  using L = WideLayout<C>;
-  auto kern = mlp_wide_fwd_kernel<C, EPI2, DROP, FULL, PROJ>;
+  using L = WideLayout<C, NWX>;
+  auto kern = mlp_wide_fwd_kernel<C, EPI2, DROP, FULL, PROJ, NWX>;
   static std::atomic<bool> attr_set{false};
   if (!attr_set.load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES) != hipSuccess) {
@@ -847,6 +850,16 @@ static int launch_wide_fwd_t(const WideFwdParams& p, hipStream_t st) {
 
 template <int C, int EPI2>
 static int launch_wide_fwd(const WideFwdParams& p, hipStream_t st) {
+  if constexpr (C == 256) {
+    // 64-row tiles with four consumer waves while they fit ONE round of the chip (the step: the seismic encoder's 9 216 rows = 144 tiles; the
+    // audio encoder's 18 432 rows would be 288 = two rounds and keep the 96-row tiles); only the step's own instantiation (dropout on, whole
+    // tiles, proj folded).  Measured inside the step: 51 546 / 51 213 / 51 742 against 51 394 / 51 340 / 51 541 windows/s with six waves
+    // everywhere (tools/ab_wide_nw4.sh) -- noise: the CUs the 96-tile launch leaves idle are the other encoder's anyway.  Opt-in
+    // (FOCAL_LAB_WIDE_NW4=1).
+    static const bool nw4 = [] { const char* e = getenv("FOCAL_LAB_WIDE_NW4"); return e != nullptr && e[0] == '1'; }();
+    if (nw4 && p.o != nullptr && p.drop_h.p_elem > 0.f && p.M % 64 == 0 && p.M / 64 <= focal_cu_count() && p.M / 64 > focal_cu_count() / 3)
+      return launch_wide_fwd_t<C, EPI2, true, true, true, 4>(p, st);
+  }
   const bool drop = p.drop_h.p_elem > 0.f, full = p.M % WideLayout<C>::BM == 0;
   if (p.o != nullptr) {
     if (drop) return full ? launch_wide_fwd_t<C, EPI2, true, true, true>(p, st) : launch_wide_fwd_t<C, EPI2, true, false, true>(p, st);
