@@ -412,3 +412,40 @@ def test_bf16_path_equals_operand_rounded_oracle(cfg):
         # evaluation with bf16-rounded operands is -- its distance is operand rounding, not kernel arithmetic.
         assert to_ref < 1.25 * emu_to_ref + 1e-3, (m, to_ref, emu_to_ref)
         assert to_emu < 1.25 * emu_to_ref + 1e-3, (m, to_emu, emu_to_ref)
+
+
+def test_step_constants_leave_the_gradients_unchanged(cfg, monkeypatch):
+    """Round 6: the training step hands loss.backward() a cached scalar 1 (runtime.unit_grad) that the loss head recognises and does not
+    multiply by, and every encoder node hangs on one cached autograd anchor per device.  Same loss, bit-identical parameter gradients as
+    autograd's own ones_like root gradient with a fresh anchor per stage call (FOCAL_NO_STEP_CONSTANTS=1); a non-unit root gradient still scales."""
+    from focal_amd import runtime
+    args, net, focal, loss_fn = build(cfg, "fp32")
+    net.train()
+    x1, x2 = inputs(cfg)
+
+    def grads(root):
+        ar = net.arena()
+        ar.grad.zero_()
+        loss = loss_fn(*focal(x1, x2, proj_head=True))
+        if root is None:
+            loss.backward()
+        else:
+            loss.backward(gradient=root)
+        torch.cuda.synchronize()
+        return float(loss), ar.grad.clone()
+
+    unit = runtime.unit_grad(torch.device("cuda", torch.cuda.current_device()))
+    assert unit is not None and runtime.is_unit_grad(unit) and not runtime.is_unit_grad(torch.ones((), device="cuda"))
+    a0 = runtime.anchor(unit.device)
+    assert runtime.anchor(unit.device) is a0 and a0.grad is None
+    l_unit, g_unit = grads(unit)
+    assert a0.grad is None   # (the anchor never receives a gradient: nothing accumulates into the shared leaf)
+    monkeypatch.setenv("FOCAL_NO_STEP_CONSTANTS", "1")
+    assert runtime.unit_grad(unit.device) is None and runtime.anchor(unit.device) is not a0
+    l_ref, g_ref = grads(None)
+    monkeypatch.delenv("FOCAL_NO_STEP_CONSTANTS")
+    # (split-K atomics -- the mod_in product forward, a few weight gradients backward -- make repeated runs differ in the last bits: compare to that level)
+    assert abs(l_unit - l_ref) < 1e-5 * abs(l_ref) and g_ref.abs().max().item() > 0
+    assert ((g_unit - g_ref).abs().max() / g_ref.abs().max()).item() < 1e-5
+    l2, g2 = grads(torch.full((), 2.0, device="cuda"))
+    assert ((g2 - 2.0 * g_ref).abs().max() / g_ref.abs().max()).item() < 2e-5
