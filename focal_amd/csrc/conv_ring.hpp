@@ -8,9 +8,10 @@
 // step (102 400 rows: 13 MB in, 26 MB out) in 19.4 us forward, 27.5 us with the BatchNorm statistics, 24.7 us as the data gradient
 // (tools/mb_conv.py).  Here a token row is read from memory ONCE into LDS (128 bytes) and serves its k taps as k row-shifted fragment reads of
 // the same image; the weight lives in the consumer waves' registers for the whole launch (20 fragments per wave at k = 5); an interval
-// boundary is one select per fragment (a lane's 8 operand elements belong to one row and one tap).
+// boundary is one select per fragment address (a lane's 8 operand elements belong to one row and one tap: the lane reads a zero row instead).
 //
-// Workgroup = 4 consumer waves (2 x 2: 32 rows x 32 output channels each) + 1 loader wave, 64-row tiles, two workgroups per CU.  The loader
+// Workgroup = 4 consumer waves (2 x 2: 32 rows x 32 output channels each) + 1 loader wave, 64-row tiles; 168 registers and 31 KB of LDS let two
+// workgroups share a CU, the launcher starts one per CU (the step runs another encoder beside this one: conv_ring_launch).  The loader
 // keeps two tiles ahead of the consumers in a 3-buffer ring (a tile = 80 rows: 8 halo rows either side, 1 KB pieces of 8 rows, chunk c of row r
 // at position c ^ ((r >> 1) & 7)) and publishes a buffer with a counted vmcnt in front of the tile's one s_barrier; the consumers' own loads
 // (the residual of the data-gradient form) and stores are ordinary compiler-scheduled accesses -- no LDS-DMA is ever in flight in those waves.
